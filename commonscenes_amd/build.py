@@ -1,0 +1,72 @@
+"""Build libcommonscenes_hip.so for gfx950 with hipcc (in-tree, so the .so travels with the repo).
+
+The library is the product: there is no CPU fallback.  `build_native()` is what
+`__graft_entry__.build()` calls; it cross-compiles without a GPU.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+PKG_DIR = Path(__file__).resolve().parent
+CSRC = PKG_DIR / "csrc"
+LIB_NAME = "libcommonscenes_hip.so"
+LIB_PATH = PKG_DIR / LIB_NAME
+SOURCES = ["cs_gemm.hip", "cs_norm.hip", "cs_attention.hip", "cs_ops.hip"]
+HEADERS = [CSRC / "cs_common.h", PKG_DIR.parent / "include" / "commonscenes_hip.h"]
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f"--offload-arch={ARCH}", "-Wall",
+         "-Wno-unused-function"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found: cannot build libcommonscenes_hip.so")
+
+
+def needs_build() -> bool:
+    if not LIB_PATH.exists():
+        return True
+    t = LIB_PATH.stat().st_mtime
+    deps = [CSRC / s for s in SOURCES] + HEADERS + [Path(__file__)]
+    return any(d.stat().st_mtime > t for d in deps)
+
+
+def build_native(force: bool = False, verbose: bool = True) -> Path:
+    if not force and not needs_build():
+        return LIB_PATH
+    hipcc = _hipcc()
+    objdir = PKG_DIR / "build"
+    objdir.mkdir(exist_ok=True)
+    procs = []
+    objs = []
+    for s in SOURCES:
+        obj = objdir / (s.replace(".hip", ".o"))
+        cmd = [hipcc, *FLAGS, "-c", str(CSRC / s), "-o", str(obj)]
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        objs.append(str(obj))
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            sys.stderr.write(out.decode())
+            raise RuntimeError(f"hipcc failed on {s}")
+        if verbose and out.strip():
+            print(out.decode())
+    tmp = LIB_PATH.with_suffix(".so.tmp")
+    cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", str(tmp)]
+    if verbose:
+        print("[build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    os.replace(tmp, LIB_PATH)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_native(force="--force" in sys.argv))

@@ -1,0 +1,48 @@
+// Shared device helpers for libcommonscenes_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/commonscenes_hip.h"
+
+#define CS_CHECK_LAUNCH()                         \
+  do {                                            \
+    hipError_t e_ = hipGetLastError();            \
+    if (e_ != hipSuccess) return (int)e_;         \
+  } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float cs_silu(float x) { return x / (1.0f + __expf(-x)); }
+// exact SiLU: x * sigmoid(x) with an accurate exp (torch computes x * 1/(1+exp(-x)) in fp32)
+__device__ __forceinline__ float cs_silu_acc(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float cs_gelu(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float cs_act(float v, int act) {
+  switch (act) {
+    case CS_ACT_RELU: return v > 0.f ? v : 0.f;
+    case CS_ACT_SILU: return cs_silu_acc(v);
+    case CS_ACT_GELU: return cs_gelu(v);
+    default: return v;
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+static inline int cs_grid_for(int64_t n, int block, int cap = 256 * 16) {
+  int64_t g = (n + block - 1) / block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}

@@ -1,0 +1,336 @@
+// Implicit-GEMM conv3d / linear on fp32-input MFMA (v_mfma_f32_32x32x2_f32) for gfx950.
+//
+// One kernel family covers every dense contraction on the CommonScenes shape path:
+//   3x3x3 conv (stride 1 / (1,2,2), optional fused nearest upsample), 1x1x1 conv, nn.Linear.
+// GEMM view: M = nb*dout*hout*wout output voxels (or tokens), N = cout, K = taps*cin.
+// Activations are NDHWC so a K-chunk of one tap is a contiguous run of channels;
+// weights are pre-laid-out [tap][cin][cout] so a B tile row is a contiguous run of cout.
+//
+// Workgroup = 256 threads = 4 waves, one per SIMD.  Tile BM x BN x 16, register-prefetched and
+// double-buffered in LDS (one barrier per K-chunk).  A is stored transposed in LDS ([k][m]) so
+// that both MFMA operand reads are 32 consecutive words (conflict free for ds_read_b32).
+// MFMA operand maps (cdna_hip_programming.md section 3):
+//   A[i = lane&31][k = lane>>5], B[k = lane>>5][j = lane&31],
+//   D: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5), r in [0,16).
+#include "cs_common.h"
+
+namespace {
+
+constexpr int BK = 16;
+
+template <int WMB, int WNB, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void conv_gemm_f32_kernel(const CsConvGemm p, int M,
+                                                            int tiles_n, int taps_hw, int kw_) {
+  constexpr int BM = 32 * WMB * WAVES_M;
+  constexpr int BN = 32 * WNB * WAVES_N;
+  constexpr int LDAS = BM + 4;
+  constexpr int LDBS = BN + 4;
+  constexpr int RPT = (BM + 63) / 64;        // A rows per thread
+  constexpr int BUNITS = BK * BN / 4;        // float4 units in a B tile
+  constexpr int BPT = (BUNITS + 255) / 256;  // B float4 per thread
+  constexpr int A_SZ = BK * LDAS;
+  constexpr int B_SZ = BK * LDBS;
+  __shared__ __attribute__((aligned(16))) float smem[2 * A_SZ + 2 * B_SZ];
+  float* As = smem;
+  float* Bs = smem + 2 * A_SZ;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int l31 = lane & 31;
+  const int half = lane >> 5;
+  const int wm0 = (wave / WAVES_N) * (32 * WMB);
+  const int wn0 = (wave % WAVES_N) * (32 * WNB);
+
+  // XCD-aware tile mapping: block b runs on XCD b%8; give each XCD a contiguous run of tiles so
+  // neighbouring tiles (same A rows / same weight panel) share that XCD's L2.
+  int tile;
+  {
+    const int nblk = gridDim.x, b = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7, xcd = b & 7, within = b >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+  }
+  const int tn = tile % tiles_n;
+  const int tm = tile / tiles_n;
+  const int m0 = tm * BM;
+  const int n0 = tn * BN;
+
+  // ---- per-thread A row bookkeeping ----
+  const int kq = tid & 3;
+  int id0[RPT], ih0[RPT], iw0[RPT];
+  int64_t nbase[RPT];
+  bool rvalid[RPT];
+  const int vdin = p.din << p.ud, vhin = p.hin << p.uh, vwin = p.win << p.uw;
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int row = (tid >> 2) + 64 * i;
+    const int m = m0 + row;
+    rvalid[i] = (row < BM) && (m < M);
+    int mm = rvalid[i] ? m : 0;
+    const int ow = mm % p.wout;
+    mm /= p.wout;
+    const int oh = mm % p.hout;
+    mm /= p.hout;
+    const int od = mm % p.dout;
+    const int n = mm / p.dout;
+    id0[i] = od * p.sd - p.pd;
+    ih0[i] = oh * p.sh - p.ph;
+    iw0[i] = ow * p.sw - p.pw;
+    nbase[i] = (int64_t)n * p.din * p.hin * p.win;
+  }
+
+  const int kchunks_per_tap = (p.cin + BK - 1) / BK;
+  const int ntaps = p.kd * taps_hw;
+  const int nk = ntaps * kchunks_per_tap;
+
+  float4 ra[RPT];
+  float4 rb[BPT];
+
+  auto load_chunk = [&](int tap, int c0) {
+    const int kd_ = tap / taps_hw;
+    const int rem = tap - kd_ * taps_hw;
+    const int kh_ = rem / kw_;
+    const int kwi = rem - kh_ * kw_;
+    const int c = c0 + kq * 4;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int vd = id0[i] + kd_, vh = ih0[i] + kh_, vw = iw0[i] + kwi;
+      const bool ok = rvalid[i] && (unsigned)vd < (unsigned)vdin && (unsigned)vh < (unsigned)vhin &&
+                      (unsigned)vw < (unsigned)vwin && c < p.cin;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) {
+        const int64_t srow =
+            nbase[i] + ((int64_t)(vd >> p.ud) * p.hin + (vh >> p.uh)) * p.win + (vw >> p.uw);
+        v = *reinterpret_cast<const float4*>(p.x + srow * p.lda + c);
+      }
+      ra[i] = v;
+    }
+    const float* wt = p.w + ((int64_t)tap * p.cin) * p.ldw;
+#pragma unroll
+    for (int i = 0; i < BPT; ++i) {
+      const int u = tid + 256 * i;
+      const int krow = u / (BN / 4);
+      const int c4 = u - krow * (BN / 4);
+      const int kk = c0 + krow;
+      const int n = n0 + c4 * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (u < BUNITS && kk < p.cin && n < p.ldw)
+        v = *reinterpret_cast<const float4*>(wt + (int64_t)kk * p.ldw + n);
+      rb[i] = v;
+    }
+  };
+
+  auto store_chunk = [&](int buf) {
+    float* a = As + buf * A_SZ;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int row = (tid >> 2) + 64 * i;
+      if (row < BM) {
+        a[(kq * 4 + 0) * LDAS + row] = ra[i].x;
+        a[(kq * 4 + 1) * LDAS + row] = ra[i].y;
+        a[(kq * 4 + 2) * LDAS + row] = ra[i].z;
+        a[(kq * 4 + 3) * LDAS + row] = ra[i].w;
+      }
+    }
+    float* b = Bs + buf * B_SZ;
+#pragma unroll
+    for (int i = 0; i < BPT; ++i) {
+      const int u = tid + 256 * i;
+      if (u < BUNITS) {
+        const int krow = u / (BN / 4);
+        const int c4 = u - krow * (BN / 4);
+        *reinterpret_cast<float4*>(b + krow * LDBS + c4 * 4) = rb[i];
+      }
+    }
+  };
+
+  f32x16 acc[WMB][WNB];
+#pragma unroll
+  for (int i = 0; i < WMB; ++i)
+#pragma unroll
+    for (int j = 0; j < WNB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int tap = 0, c0 = 0;
+  load_chunk(tap, c0);
+  store_chunk(0);
+  __syncthreads();
+
+  for (int kc = 0; kc < nk; ++kc) {
+    const int buf = kc & 1;
+    const bool more = (kc + 1) < nk;
+    if (more) {
+      c0 += BK;
+      if (c0 >= p.cin) {
+        c0 = 0;
+        ++tap;
+      }
+      load_chunk(tap, c0);
+    }
+    const float* a = As + buf * A_SZ + wm0 + l31;
+    const float* b = Bs + buf * B_SZ + wn0 + l31;
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      float av[WMB], bv[WNB];
+#pragma unroll
+      for (int i = 0; i < WMB; ++i) av[i] = a[(2 * kk + half) * LDAS + 32 * i];
+#pragma unroll
+      for (int j = 0; j < WNB; ++j) bv[j] = b[(2 * kk + half) * LDBS + 32 * j];
+#pragma unroll
+      for (int i = 0; i < WMB; ++i)
+#pragma unroll
+        for (int j = 0; j < WNB; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_chunk(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue ----
+#pragma unroll
+  for (int j = 0; j < WNB; ++j) {
+    const int n = n0 + wn0 + 32 * j + l31;
+    const bool nok = n < p.cout;
+    const float bias = (nok && p.bias) ? p.bias[n] : 0.f;
+    const float sc = (nok && p.scale) ? p.scale[n] : 1.f;
+    const float sh = (nok && p.shift) ? p.shift[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < WMB; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int m = m0 + row;
+        if (nok && m < M) {
+          float v = acc[i][j][r] + bias;
+          if (p.scale) v = v * sc + sh;
+          if (p.rowvec) v += p.rowvec[(int64_t)(m / p.rv_rows) * p.ldrv + n];
+          v = cs_act(v, p.act);
+          if (p.res) v += p.res[(int64_t)m * p.ldr + n];
+          p.out[(int64_t)m * p.ldo + n] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int WMB, int WNB, int WAVES_M, int WAVES_N>
+int launch(const CsConvGemm& p, int M, hipStream_t stream) {
+  constexpr int BM = 32 * WMB * WAVES_M;
+  constexpr int BN = 32 * WNB * WAVES_N;
+  const int tiles_m = (M + BM - 1) / BM;
+  const int tiles_n = (p.cout + BN - 1) / BN;
+  const int64_t nblk = (int64_t)tiles_m * tiles_n;
+  if (nblk > 0x7fffffffLL) return CS_EINVAL;
+  hipLaunchKernelGGL((conv_gemm_f32_kernel<WMB, WNB, WAVES_M, WAVES_N>), dim3((unsigned)nblk),
+                     dim3(256), 0, stream, p, M, tiles_n, p.kh * p.kw, p.kw);
+  CS_CHECK_LAUNCH();
+  return CS_OK;
+}
+
+__global__ void relayout_weight_kernel(const float* __restrict__ w, float* __restrict__ o, int cout,
+                                       int cin, int taps, int cin_pad, int ldw) {
+  // w: (cout, cin, taps) torch order; o: [tap][cin_pad][ldw]
+  const int64_t total = (int64_t)taps * cin_pad * ldw;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i % ldw);
+    const int64_t t = i / ldw;
+    const int c = (int)(t % cin_pad);
+    const int tap = (int)(t / cin_pad);
+    float v = 0.f;
+    if (n < cout && c < cin) v = w[((int64_t)n * cin + c) * taps + tap];
+    o[i] = v;
+  }
+}
+
+}  // namespace
+
+extern "C" int cs_conv_gemm(const CsConvGemm* d, cs_stream_t stream) {
+  if (!d || !d->x || !d->w || !d->out) return CS_EINVAL;
+  const CsConvGemm& p = *d;
+  if (p.nb <= 0 || p.cin <= 0 || p.cout <= 0 || p.dout <= 0 || p.hout <= 0 || p.wout <= 0)
+    return CS_EINVAL;
+  if ((p.cin & 3) || (p.lda & 3) || (p.ldw & 3) || p.ldw < p.cout || p.lda < p.cin)
+    return CS_EINVAL;
+  if (((uintptr_t)p.x & 15) || ((uintptr_t)p.w & 15)) return CS_EINVAL;
+  if (p.kd <= 0 || p.kh <= 0 || p.kw <= 0 || p.sd <= 0 || p.sh <= 0 || p.sw <= 0) return CS_EINVAL;
+  if (p.ud < 0 || p.uh < 0 || p.uw < 0 || p.ud > 4 || p.uh > 4 || p.uw > 4) return CS_EINVAL;
+  if (p.scale && !p.shift) return CS_EINVAL;
+  if (p.rowvec && p.rv_rows <= 0) return CS_EINVAL;
+  if (p.ldo < p.cout || (p.res && p.ldr < p.cout)) return CS_EINVAL;
+  if (p.math != CS_MATH_FP32) return CS_EINVAL;
+  const int64_t M64 = (int64_t)p.nb * p.dout * p.hout * p.wout;
+  if (M64 > 0x7fffffffLL) return CS_EINVAL;
+  const int M = (int)M64;
+  int tile = p.tile;
+  if (tile == 0) {
+    if (p.cout % 224 == 0 && M >= 2048)
+      tile = 2;
+    else if (p.cout <= 64 || (int64_t)((M + 127) / 128) * ((p.cout + 127) / 128) < 128)
+      tile = 3;
+    else
+      tile = 1;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  switch (tile) {
+    case 1: return launch<2, 2, 2, 2>(p, M, s);
+    case 2: return launch<1, 7, 4, 1>(p, M, s);
+    case 3: return launch<1, 1, 2, 2>(p, M, s);
+    default: return CS_EINVAL;
+  }
+}
+
+static void fill_conv(CsConvGemm& p, const float* x, const float* w, const float* bias, float* out,
+                      int nb, int d, int h, int w_, int cin, int cout, int sh, int sw) {
+  p = CsConvGemm{};
+  p.x = x; p.w = w; p.bias = bias; p.out = out;
+  p.nb = nb; p.din = d; p.hin = h; p.win = w_;
+  p.dout = d; p.hout = (h + 2 - 3) / sh + 1; p.wout = (w_ + 2 - 3) / sw + 1;
+  p.cin = cin; p.cout = cout;
+  p.lda = cin; p.ldw = (cout + 3) & ~3; p.ldo = cout;
+  p.kd = p.kh = p.kw = 3;
+  p.sd = 1; p.sh = sh; p.sw = sw;
+  p.pd = p.ph = p.pw = 1;
+  p.rv_rows = 1;
+}
+
+extern "C" int cs_conv3d_3x3x3_s111(const float* x, const float* w, const float* bias, float* out,
+                                    int nb, int d, int h, int w_, int cin, int cout,
+                                    cs_stream_t stream) {
+  CsConvGemm p;
+  fill_conv(p, x, w, bias, out, nb, d, h, w_, cin, cout, 1, 1);
+  return cs_conv_gemm(&p, stream);
+}
+
+extern "C" int cs_conv3d_3x3x3_s122(const float* x, const float* w, const float* bias, float* out,
+                                    int nb, int d, int h, int w_, int cin, int cout,
+                                    cs_stream_t stream) {
+  CsConvGemm p;
+  fill_conv(p, x, w, bias, out, nb, d, h, w_, cin, cout, 2, 2);
+  return cs_conv_gemm(&p, stream);
+}
+
+extern "C" int cs_gemm_tokens(const float* x, const float* w, const float* bias, const float* res,
+                              float* out, int m, int k, int n, int act, cs_stream_t stream) {
+  CsConvGemm p = CsConvGemm{};
+  p.x = x; p.w = w; p.bias = bias; p.res = res; p.out = out;
+  p.nb = m; p.din = p.hin = p.win = 1; p.dout = p.hout = p.wout = 1;
+  p.cin = k; p.cout = n; p.lda = k; p.ldw = (n + 3) & ~3; p.ldo = n; p.ldr = n;
+  p.kd = p.kh = p.kw = 1; p.sd = p.sh = p.sw = 1;
+  p.act = act; p.rv_rows = 1;
+  return cs_conv_gemm(&p, stream);
+}
+
+extern "C" int cs_relayout_weight(const float* w_torch, float* w_out, int cout, int cin, int taps,
+                                  int cin_pad, int ldw, cs_stream_t stream) {
+  if (!w_torch || !w_out || cout <= 0 || cin <= 0 || taps <= 0 || cin_pad < cin || ldw < cout)
+    return CS_EINVAL;
+  const int64_t total = (int64_t)taps * cin_pad * ldw;
+  hipLaunchKernelGGL(relayout_weight_kernel, dim3(cs_grid_for(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, w_torch, w_out, cout, cin, taps, cin_pad, ldw);
+  CS_CHECK_LAUNCH();
+  return CS_OK;
+}
+
+extern "C" int cs_abi_version(void) { return 1; }

@@ -1,0 +1,239 @@
+// GroupNorm (NDHWC) and LayerNorm for gfx950.  Both are HBM-bound streaming kernels:
+// float4 coalesced loads, fp64 accumulation for GroupNorm statistics (a group spans up to
+// 4096*42 elements), wave64 shuffles for LayerNorm rows.
+#include "cs_common.h"
+
+namespace {
+
+constexpr int GN_MIN_SPLIT_ROWS = 64;  // minimum rows handled by one statistics block
+constexpr int GN_MAX_SPLITS = 256;
+
+// Pass 1: partial[n][split][g] = (sum, sumsq) in fp64.  Each thread owns fixed channel chunks so
+// its accumulation order is fixed; the cross-thread reduction runs in a fixed order too, so the
+// statistics are bit-reproducible run to run.
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, int rows, int c,
+                                                         int ldx, int groups, int nsplit, int rps,
+                                                         double* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];  // [rowlanes][c][2]
+  const int n = blockIdx.x / nsplit;
+  const int split = blockIdx.x % nsplit;
+  const int ch4 = c >> 2;
+  const int tpr = ch4 < 256 ? ch4 : 256;  // threads per row
+  const int rowlanes = 256 / tpr;
+  const int tid = threadIdx.x;
+  const int rl = tid / tpr;
+  const int cl = tid - rl * tpr;
+  const int r0 = split * rps;
+  const int r1 = min(rows, r0 + rps);
+  const float* xb = x + (int64_t)n * rows * ldx;
+  if (rl < rowlanes) {
+    for (int c4 = cl; c4 < ch4; c4 += tpr) {
+      double s0 = 0, s1 = 0, s2 = 0, s3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+      for (int r = r0 + rl; r < r1; r += rowlanes) {
+        const float4 v = *reinterpret_cast<const float4*>(xb + (int64_t)r * ldx + c4 * 4);
+        s0 += v.x; q0 += (double)v.x * v.x;
+        s1 += v.y; q1 += (double)v.y * v.y;
+        s2 += v.z; q2 += (double)v.z * v.z;
+        s3 += v.w; q3 += (double)v.w * v.w;
+      }
+      double* d = sm + ((int64_t)rl * c + c4 * 4) * 2;
+      d[0] = s0; d[1] = q0; d[2] = s1; d[3] = q1; d[4] = s2; d[5] = q2; d[6] = s3; d[7] = q3;
+    }
+  }
+  __syncthreads();
+  if (tid < groups) {
+    const int cpg = c / groups;
+    double s = 0, q = 0;
+    for (int l = 0; l < rowlanes; ++l)
+      for (int k = 0; k < cpg; ++k) {
+        const double* d = sm + ((int64_t)l * c + tid * cpg + k) * 2;
+        s += d[0];
+        q += d[1];
+      }
+    double* o = partial + (((int64_t)n * nsplit + split) * groups + tid) * 2;
+    o[0] = s;
+    o[1] = q;
+  }
+}
+
+__global__ void gn_finalize_kernel(const double* __restrict__ partial, int nsplit, int groups,
+                                   double count, float eps, float* __restrict__ stats, int total) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // n*groups + g
+  if (i >= total) return;
+  const int n = i / groups, g = i - n * groups;
+  double s = 0, q = 0;
+  for (int k = 0; k < nsplit; ++k) {
+    const double* d = partial + (((int64_t)n * nsplit + k) * groups + g) * 2;
+    s += d[0];
+    q += d[1];
+  }
+  const double mean = s / count;
+  double var = q / count - mean * mean;
+  if (var < 0) var = 0;
+  stats[2 * i] = (float)mean;
+  stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x,
+                                                       const float* __restrict__ stats,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta,
+                                                       float* __restrict__ y, int nb, int rows, int c,
+                                                       int ldx, int ldy, int groups, int act) {
+  const int ch4 = c >> 2;
+  const int cpg = c / groups;
+  const int64_t total = (int64_t)nb * rows * ch4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % ch4);
+    const int64_t row = i / ch4;  // n*rows + r
+    const int n = (int)(row / rows);
+    const float4 v = *reinterpret_cast<const float4*>(x + row * ldx + c4 * 4);
+    const float4 g = *reinterpret_cast<const float4*>(gamma + c4 * 4);
+    const float4 b = *reinterpret_cast<const float4*>(beta + c4 * 4);
+    float in[4] = {v.x, v.y, v.z, v.w};
+    const float gg[4] = {g.x, g.y, g.z, g.w};
+    const float bb[4] = {b.x, b.y, b.z, b.w};
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int grp = (c4 * 4 + k) / cpg;
+      const float mean = stats[((int64_t)n * groups + grp) * 2];
+      const float rstd = stats[((int64_t)n * groups + grp) * 2 + 1];
+      o[k] = cs_act((in[k] - mean) * rstd * gg[k] + bb[k], act);
+    }
+    *reinterpret_cast<float4*>(y + row * ldy + c4 * 4) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// LayerNorm: one wave per row; each lane owns up to MAXV float4 chunks (c <= 64*4*MAXV).
+template <int MAXV>
+__global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x,
+                                                 const float* __restrict__ gamma,
+                                                 const float* __restrict__ beta,
+                                                 float* __restrict__ y, int m, int c, int ldx,
+                                                 int ldy, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int ch4 = c >> 2;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < m; row += (int64_t)gridDim.x * 4) {
+    float4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const int c4 = lane + 64 * k;
+      v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c4 < ch4) v[k] = *reinterpret_cast<const float4*>(x + row * ldx + c4 * 4);
+      s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    }
+    const float mean = wave_sum(s) / (float)c;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const int c4 = lane + 64 * k;
+      if (c4 < ch4) {
+        const float a = v[k].x - mean, b = v[k].y - mean, cc = v[k].z - mean, d = v[k].w - mean;
+        q += (a * a + b * b) + (cc * cc + d * d);
+      }
+    }
+    const float var = wave_sum(q) / (float)c;
+    const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const int c4 = lane + 64 * k;
+      if (c4 < ch4) {
+        const float4 g = *reinterpret_cast<const float4*>(gamma + c4 * 4);
+        const float4 b = *reinterpret_cast<const float4*>(beta + c4 * 4);
+        float4 o;
+        o.x = (v[k].x - mean) * rstd * g.x + b.x;
+        o.y = (v[k].y - mean) * rstd * g.y + b.y;
+        o.z = (v[k].z - mean) * rstd * g.z + b.z;
+        o.w = (v[k].w - mean) * rstd * g.w + b.w;
+        *reinterpret_cast<float4*>(y + row * ldy + c4 * 4) = o;
+      }
+    }
+  }
+}
+
+int gn_nsplit(int rows) {
+  const int n = (rows + GN_MIN_SPLIT_ROWS - 1) / GN_MIN_SPLIT_ROWS;
+  return n < GN_MAX_SPLITS ? n : GN_MAX_SPLITS;
+}
+
+}  // namespace
+
+extern "C" int64_t cs_groupnorm_ws_bytes(int nb, int groups) {
+  return (int64_t)nb * GN_MAX_SPLITS * groups * 2 * (int64_t)sizeof(double);
+}
+
+extern "C" int cs_groupnorm_stats(const float* x, int nb, int rows, int c, int ldx, int groups,
+                                  float eps, void* ws, float* stats, cs_stream_t stream) {
+  if (!x || !ws || !stats || nb <= 0 || rows <= 0 || c <= 0 || groups <= 0) return CS_EINVAL;
+  if ((c & 3) || (ldx & 3) || ldx < c || c % groups || groups > 256) return CS_EINVAL;
+  if (((uintptr_t)x & 15) || ((uintptr_t)ws & 7)) return CS_EINVAL;
+  const int nsplit = gn_nsplit(rows);
+  const int rps = (rows + nsplit - 1) / nsplit;
+  const int ch4 = c >> 2;
+  const int tpr = ch4 < 256 ? ch4 : 256;
+  const int rowlanes = 256 / tpr;
+  const size_t smem = (size_t)rowlanes * c * 2 * sizeof(double);
+  if (smem > 64 * 1024) return CS_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(gn_partial_kernel, dim3((unsigned)(nb * nsplit)), dim3(256), smem, s, x, rows,
+                     c, ldx, groups, nsplit, rps, (double*)ws);
+  CS_CHECK_LAUNCH();
+  const int total = nb * groups;
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, s,
+                     (const double*)ws, nsplit, groups, (double)rows * (c / groups), eps, stats,
+                     total);
+  CS_CHECK_LAUNCH();
+  return CS_OK;
+}
+
+extern "C" int cs_groupnorm_apply(const float* x, const float* stats, const float* gamma,
+                                  const float* beta, float* y, int nb, int rows, int c, int ldx,
+                                  int ldy, int groups, int act, cs_stream_t stream) {
+  if (!x || !stats || !gamma || !beta || !y || nb <= 0 || rows <= 0 || c <= 0 || groups <= 0)
+    return CS_EINVAL;
+  if ((c & 3) || (ldx & 3) || (ldy & 3) || ldx < c || ldy < c || c % groups) return CS_EINVAL;
+  if (((uintptr_t)x & 15) || ((uintptr_t)y & 15) || ((uintptr_t)gamma & 15) ||
+      ((uintptr_t)beta & 15))
+    return CS_EINVAL;
+  const int64_t total = (int64_t)nb * rows * (c >> 2);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(cs_grid_for(total, 256, 256 * 32)), dim3(256), 0,
+                     (hipStream_t)stream, x, stats, gamma, beta, y, nb, rows, c, ldx, ldy, groups,
+                     act);
+  CS_CHECK_LAUNCH();
+  return CS_OK;
+}
+
+extern "C" int cs_groupnorm_silu_ndhwc(const float* x, const float* gamma, const float* beta,
+                                       float* y, int nb, int rows, int c, int groups, float eps,
+                                       void* ws, float* stats, cs_stream_t stream) {
+  int rc = cs_groupnorm_stats(x, nb, rows, c, c, groups, eps, ws, stats, stream);
+  if (rc) return rc;
+  return cs_groupnorm_apply(x, stats, gamma, beta, y, nb, rows, c, c, c, groups, CS_ACT_SILU,
+                            stream);
+}
+
+extern "C" int cs_layernorm(const float* x, const float* gamma, const float* beta, float* y, int m,
+                            int c, int ldx, int ldy, float eps, cs_stream_t stream) {
+  if (!x || !gamma || !beta || !y || m <= 0 || c <= 0) return CS_EINVAL;
+  if ((c & 3) || (ldx & 3) || (ldy & 3) || ldx < c || ldy < c) return CS_EINVAL;
+  if (((uintptr_t)x & 15) || ((uintptr_t)y & 15) || ((uintptr_t)gamma & 15) ||
+      ((uintptr_t)beta & 15))
+    return CS_EINVAL;
+  const int ch4 = c >> 2;
+  const int grid = cs_grid_for(((int64_t)m + 3) / 4, 1, 256 * 32);
+  hipStream_t s = (hipStream_t)stream;
+  if (ch4 <= 64 * 2)
+    hipLaunchKernelGGL(ln_kernel<2>, dim3(grid), dim3(256), 0, s, x, gamma, beta, y, m, c, ldx, ldy, eps);
+  else if (ch4 <= 64 * 4)
+    hipLaunchKernelGGL(ln_kernel<4>, dim3(grid), dim3(256), 0, s, x, gamma, beta, y, m, c, ldx, ldy, eps);
+  else if (ch4 <= 64 * 8)
+    hipLaunchKernelGGL(ln_kernel<8>, dim3(grid), dim3(256), 0, s, x, gamma, beta, y, m, c, ldx, ldy, eps);
+  else
+    return CS_EINVAL;
+  CS_CHECK_LAUNCH();
+  return CS_OK;
+}

@@ -1,0 +1,385 @@
+// HBM-bound elementwise / gather / scatter kernels of the CommonScenes shape path (gfx950):
+// GEGLU gate, strided row copy (channel concat), row-vector add, NCDHW<->NDHWC, timestep embedding,
+// fused CFG + DDIM update, VQ nearest-code lookup, scene-graph gather / segment-mean, embedding.
+#include "cs_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void geglu_kernel(const float* __restrict__ x, float* __restrict__ o,
+                                                    int64_t m, int h, int ldx, int ldo) {
+  const int h4 = h >> 2;
+  const int64_t total = m * h4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % h4);
+    const int64_t row = i / h4;
+    const float4 a = *reinterpret_cast<const float4*>(x + row * ldx + c4 * 4);
+    const float4 g = *reinterpret_cast<const float4*>(x + row * ldx + h + c4 * 4);
+    float4 r;
+    r.x = a.x * cs_gelu(g.x);
+    r.y = a.y * cs_gelu(g.y);
+    r.z = a.z * cs_gelu(g.z);
+    r.w = a.w * cs_gelu(g.w);
+    *reinterpret_cast<float4*>(o + row * ldo + c4 * 4) = r;
+  }
+}
+
+__global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict__ s, float* __restrict__ d,
+                                                        int64_t m, int c, int lds, int ldd) {
+  const int c4n = c >> 2;
+  const int64_t total = m * c4n;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % c4n);
+    const int64_t row = i / c4n;
+    *reinterpret_cast<float4*>(d + row * ldd + c4 * 4) =
+        *reinterpret_cast<const float4*>(s + row * lds + c4 * 4);
+  }
+}
+
+__global__ __launch_bounds__(256) void add_rowvec_kernel(float* __restrict__ x, const float* __restrict__ v,
+                                                         int64_t m, int c, int ldx, int ldv, int rows) {
+  const int c4n = c >> 2;
+  const int64_t total = m * c4n;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % c4n);
+    const int64_t row = i / c4n;
+    float4 a = *reinterpret_cast<float4*>(x + row * ldx + c4 * 4);
+    const float4 b = *reinterpret_cast<const float4*>(v + (row / rows) * ldv + c4 * 4);
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    *reinterpret_cast<float4*>(x + row * ldx + c4 * 4) = a;
+  }
+}
+
+// [nb][c][s] -> [nb][s][cpad]
+__global__ __launch_bounds__(256) void nchw_to_ndhwc_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                            int nb, int c, int s, int cpad) {
+  const int64_t total = (int64_t)nb * s * cpad;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % cpad);
+    const int64_t t = i / cpad;
+    const int sp = (int)(t % s);
+    const int n = (int)(t / s);
+    y[i] = ch < c ? x[((int64_t)n * c + ch) * s + sp] : 0.f;
+  }
+}
+
+// [nb][s][ldx] -> [nb][c][s]
+__global__ __launch_bounds__(256) void ndhwc_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                            int nb, int c, int s, int ldx) {
+  const int64_t total = (int64_t)nb * c * s;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int sp = (int)(i % s);
+    const int64_t t = i / s;
+    const int ch = (int)(t % c);
+    const int n = (int)(t / c);
+    y[i] = x[((int64_t)n * s + sp) * ldx + ch];
+  }
+}
+
+__global__ void timestep_embedding_kernel(const int64_t* __restrict__ t, float* __restrict__ out, int nb,
+                                          int dim, float max_period) {
+  const int half = dim / 2;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nb * dim) return;
+  const int b = i / dim, k = i - b * dim;
+  float v = 0.f;
+  if (k < 2 * half) {
+    const int kk = k < half ? k : k - half;
+    // freqs = exp(-log(max_period) * arange(half) / half), computed in fp32 like the reference
+    const float f = expf(-logf(max_period) * (float)kk / (float)half);
+    const float a = (float)t[b] * f;
+    v = k < half ? cosf(a) : sinf(a);
+  }
+  out[i] = v;
+}
+
+__global__ __launch_bounds__(256) void ddim_update_kernel(const float* __restrict__ x,
+                                                          const float* __restrict__ eps,
+                                                          const float* __restrict__ noise,
+                                                          float* __restrict__ x_prev,
+                                                          float* __restrict__ pred_x0, int64_t n,
+                                                          int64_t uc_off, float sqrt_at,
+                                                          float sqrt_aprev, float dir_coef,
+                                                          float sigma_t, float sqrt_one_minus_at,
+                                                          float cfg_scale, int cfg) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float e;
+    if (cfg) {
+      const float eu = eps[i];
+      const float ec = eps[uc_off + i];
+      e = eu + cfg_scale * (ec - eu);
+    } else {
+      e = eps[i];
+    }
+    const float xv = x[i];
+    const float p0 = (xv - sqrt_one_minus_at * e) / sqrt_at;
+    const float dir = dir_coef * e;
+    float xp = sqrt_aprev * p0 + dir;
+    xp += noise ? sigma_t * noise[i] : 0.f;  // reference adds sigma_t*noise (== +0 when eta == 0)
+    if (pred_x0) pred_x0[i] = p0;
+    x_prev[i] = xp;
+  }
+}
+
+// VQ: codebook (+ squared norms) staged in LDS; every lane scans all codes with broadcast reads.
+__global__ __launch_bounds__(256) void vq_kernel(const float* __restrict__ z, const float* __restrict__ cb,
+                                                 int64_t* __restrict__ idx, float* __restrict__ zq,
+                                                 int64_t m, int ncode, int edim, int ldz, int ldq) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // [ncode][4] : e0,e1,e2|0,ee
+  for (int i = threadIdx.x; i < ncode; i += blockDim.x) {
+    float e[3] = {0.f, 0.f, 0.f};
+    float ee = 0.f;
+    for (int d = 0; d < edim && d < 3; ++d) e[d] = cb[(int64_t)i * edim + d];
+    // torch.sum(w**2, dim=1): sequential fp32 sum over edim entries
+    for (int d = 0; d < edim; ++d) {
+      const float w = cb[(int64_t)i * edim + d];
+      ee += w * w;
+    }
+    sm[4 * i + 0] = e[0];
+    sm[4 * i + 1] = e[1];
+    sm[4 * i + 2] = e[2];
+    sm[4 * i + 3] = ee;
+  }
+  __syncthreads();
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < m;
+       r += (int64_t)gridDim.x * blockDim.x) {
+    float zz[3] = {0.f, 0.f, 0.f};
+    float z2 = 0.f;
+    for (int d = 0; d < edim; ++d) {
+      zz[d] = z[r * ldz + d];
+      z2 += zz[d] * zz[d];
+    }
+    float best = INFINITY;
+    int bi = 0;
+    for (int i = 0; i < ncode; ++i) {
+      const float4 c = *reinterpret_cast<const float4*>(sm + 4 * i);
+      // z.e as the K=3 dot product of the reference einsum: ((z0*e0) + z1*e1) + z2*e2 via fma chain
+      float dot = zz[0] * c.x;
+      dot = fmaf(zz[1], c.y, dot);
+      dot = fmaf(zz[2], c.z, dot);
+      const float d = (z2 + c.w) - 2.0f * dot;
+      if (d < best) {
+        best = d;
+        bi = i;
+      }
+    }
+    idx[r] = bi;
+    for (int d = 0; d < edim; ++d) zq[r * ldq + d] = cb[(int64_t)bi * edim + d];
+  }
+}
+
+__global__ __launch_bounds__(256) void gcn_gather_cat_kernel(const float* __restrict__ obj,
+                                                             const float* __restrict__ pred,
+                                                             const int64_t* __restrict__ edges,
+                                                             float* __restrict__ out, int n_obj, int n_tri,
+                                                             int d_obj, int d_pred, int32_t* err) {
+  const int width = 2 * d_obj + d_pred;
+  const int64_t total = (int64_t)n_tri * width;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % width);
+    const int t = (int)(i / width);
+    float v;
+    if (c < d_obj) {
+      const int64_t s = edges[2 * t];
+      if (s < 0 || s >= n_obj) { if (err) *err = 1; v = 0.f; }
+      else v = obj[s * d_obj + c];
+    } else if (c < d_obj + d_pred) {
+      v = pred[(int64_t)t * d_pred + (c - d_obj)];
+    } else {
+      const int64_t o = edges[2 * t + 1];
+      if (o < 0 || o >= n_obj) { if (err) *err = 1; v = 0.f; }
+      else v = obj[o * d_obj + (c - d_obj - d_pred)];
+    }
+    out[i] = v;
+  }
+}
+
+// One thread per (object, channel); walks the edge list in order: all subject contributions, then
+// all object contributions -- the summation order of two sequential scatter_add calls on the CPU.
+__global__ __launch_bounds__(256) void gcn_segment_mean_kernel(const float* __restrict__ nt,
+                                                               const int64_t* __restrict__ edges,
+                                                               float* __restrict__ pooled, int n_obj,
+                                                               int n_tri, int h, int off_o, int ld_t,
+                                                               int32_t* err) {
+  const int64_t total = (int64_t)n_obj * h;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % h);
+    const int o = (int)(i / h);
+    float acc = 0.f;
+    float cnt = 0.f;
+    for (int t = 0; t < n_tri; ++t) {
+      const int64_t s = edges[2 * t];
+      if (s < 0 || s >= n_obj) { if (err) *err = 1; continue; }
+      if (s == o) {
+        acc += nt[(int64_t)t * ld_t + c];
+        cnt += 1.f;
+      }
+    }
+    for (int t = 0; t < n_tri; ++t) {
+      const int64_t ob = edges[2 * t + 1];
+      if (ob < 0 || ob >= n_obj) { if (err) *err = 1; continue; }
+      if (ob == o) {
+        acc += nt[(int64_t)t * ld_t + off_o + c];
+        cnt += 1.f;
+      }
+    }
+    pooled[i] = acc / fmaxf(cnt, 1.f);
+  }
+}
+
+__global__ __launch_bounds__(256) void embedding_kernel(const float* __restrict__ table,
+                                                        const int64_t* __restrict__ idx,
+                                                        float* __restrict__ out, int n, int dim, int n_rows,
+                                                        int ldo, int32_t* err) {
+  const int64_t total = (int64_t)n * dim;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % dim);
+    const int r = (int)(i / dim);
+    const int64_t k = idx[r];
+    float v = 0.f;
+    if (k < 0 || k >= n_rows) { if (err) *err = 1; }
+    else v = table[k * dim + c];
+    out[(int64_t)r * ldo + c] = v;
+  }
+}
+
+inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+}  // namespace
+
+extern "C" int cs_geglu(const float* x, float* out, int m, int h, int ldx, int ldo, cs_stream_t stream) {
+  if (!x || !out || m <= 0 || h <= 0 || (h & 3) || (ldx & 3) || (ldo & 3) || ldx < 2 * h || ldo < h)
+    return CS_EINVAL;
+  if (!al16(x) || !al16(out)) return CS_EINVAL;
+  hipLaunchKernelGGL(geglu_kernel, dim3(cs_grid_for((int64_t)m * (h >> 2), 256, 256 * 32)), dim3(256), 0,
+                     (hipStream_t)stream, x, out, (int64_t)m, h, ldx, ldo);
+  CS_CHECK_LAUNCH();
+  return CS_OK;
+}
+
+extern "C" int cs_copy_rows(const float* src, float* dst, int64_t m, int c, int lds, int ldd,
+                            cs_stream_t stream) {
+  if (!src || !dst || m <= 0 || c <= 0 || (c & 3) || (lds & 3) || (ldd & 3) || lds < c || ldd < c)
+    return CS_EINVAL;
+  if (!al16(src) || !al16(dst)) return CS_EINVAL;
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(cs_grid_for(m * (c >> 2), 256, 256 * 32)), dim3(256), 0,
+                     (hipStream_t)stream, src, dst, m, c, lds, ldd);
+  CS_CHECK_LAUNCH();
+  return CS_OK;
+}
+
+extern "C" int cs_add_rowvec(float* x, const float* v, int64_t m, int c, int ldx, int ldv, int rows,
+                             cs_stream_t stream) {
+  if (!x || !v || m <= 0 || c <= 0 || rows <= 0 || (c & 3) || (ldx & 3) || (ldv & 3) || ldx < c ||
+      ldv < c)
+    return CS_EINVAL;
+  if (!al16(x) || !al16(v)) return CS_EINVAL;
+  hipLaunchKernelGGL(add_rowvec_kernel, dim3(cs_grid_for(m * (c >> 2), 256, 256 * 32)), dim3(256), 0,
+                     (hipStream_t)stream, x, v, m, c, ldx, ldv, rows);
+  CS_CHECK_LAUNCH();
+  return CS_OK;
+}
+
+extern "C" int cs_nchw_to_ndhwc(const float* x, float* y, int nb, int c, int s, int cpad,
+                                cs_stream_t stream) {
+  if (!x || !y || nb <= 0 || c <= 0 || s <= 0 || cpad < c) return CS_EINVAL;
+  hipLaunchKernelGGL(nchw_to_ndhwc_kernel, dim3(cs_grid_for((int64_t)nb * s * cpad, 256, 256 * 32)),
+                     dim3(256), 0, (hipStream_t)stream, x, y, nb, c, s, cpad);
+  CS_CHECK_LAUNCH();
+  return CS_OK;
+}
+
+extern "C" int cs_ndhwc_to_nchw(const float* x, float* y, int nb, int c, int s, int ldx,
+                                cs_stream_t stream) {
+  if (!x || !y || nb <= 0 || c <= 0 || s <= 0 || ldx < c) return CS_EINVAL;
+  hipLaunchKernelGGL(ndhwc_to_nchw_kernel, dim3(cs_grid_for((int64_t)nb * s * c, 256, 256 * 32)),
+                     dim3(256), 0, (hipStream_t)stream, x, y, nb, c, s, ldx);
+  CS_CHECK_LAUNCH();
+  return CS_OK;
+}
+
+extern "C" int cs_timestep_embedding(const int64_t* t, float* out, int nb, int dim, float max_period,
+                                     cs_stream_t stream) {
+  if (!t || !out || nb <= 0 || dim <= 1 || !(max_period > 1.f)) return CS_EINVAL;
+  const int total = nb * dim;
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3((total + 255) / 256), dim3(256), 0,
+                     (hipStream_t)stream, t, out, nb, dim, max_period);
+  CS_CHECK_LAUNCH();
+  return CS_OK;
+}
+
+extern "C" int cs_ddim_cfg_update(const float* x, const float* eps, const float* noise, float* x_prev,
+                                  float* pred_x0, int64_t nb, int64_t per, float a_t, float a_prev,
+                                  float sigma_t, float sqrt_one_minus_at, float cfg_scale, int cfg,
+                                  cs_stream_t stream) {
+  if (!x || !eps || !x_prev || nb <= 0 || per <= 0) return CS_EINVAL;
+  if (!(a_t > 0.f) || a_prev < 0.f) return CS_EINVAL;
+  const int64_t n = nb * per;
+  // coefficient arithmetic in fp32, as torch does on fp32 scalars-turned-tensors (ddim.py:228-243)
+  const float sqrt_at = sqrtf(a_t);
+  const float sqrt_aprev = sqrtf(a_prev);
+  const float dir_coef = sqrtf(1.0f - a_prev - sigma_t * sigma_t);
+  hipLaunchKernelGGL(ddim_update_kernel, dim3(cs_grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     eps, noise, x_prev, pred_x0, n, n, sqrt_at, sqrt_aprev, dir_coef, sigma_t,
+                     sqrt_one_minus_at, cfg_scale, cfg);
+  CS_CHECK_LAUNCH();
+  return CS_OK;
+}
+
+extern "C" int cs_vq_argmin_lookup(const float* z, const float* codebook, int64_t* idx, float* zq,
+                                   int64_t m, int ncode, int edim, int ldz, int ldq, cs_stream_t stream) {
+  if (!z || !codebook || !idx || !zq || m <= 0 || ncode <= 0 || edim <= 0 || edim > 3 || ldz < edim ||
+      ldq < edim)
+    return CS_EINVAL;
+  const size_t smem = (size_t)ncode * 4 * sizeof(float);
+  if (smem > 160 * 1024) return CS_EINVAL;
+  if (smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)vq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)smem);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(vq_kernel, dim3(cs_grid_for(m, 256, 1024)), dim3(256), smem, (hipStream_t)stream, z,
+                     codebook, idx, zq, m, ncode, edim, ldz, ldq);
+  CS_CHECK_LAUNCH();
+  return CS_OK;
+}
+
+extern "C" int cs_gcn_gather_cat(const float* obj, const float* pred, const int64_t* edges, float* out,
+                                 int n_obj, int n_tri, int d_obj, int d_pred, int32_t* err,
+                                 cs_stream_t stream) {
+  if (!obj || !pred || !edges || !out || n_obj <= 0 || n_tri <= 0 || d_obj <= 0 || d_pred <= 0)
+    return CS_EINVAL;
+  hipLaunchKernelGGL(gcn_gather_cat_kernel,
+                     dim3(cs_grid_for((int64_t)n_tri * (2 * d_obj + d_pred), 256)), dim3(256), 0,
+                     (hipStream_t)stream, obj, pred, edges, out, n_obj, n_tri, d_obj, d_pred, err);
+  CS_CHECK_LAUNCH();
+  return CS_OK;
+}
+
+extern "C" int cs_gcn_segment_mean(const float* new_t, const int64_t* edges, float* pooled, int n_obj,
+                                   int n_tri, int h, int off_o, int ld_t, int32_t* err,
+                                   cs_stream_t stream) {
+  if (!new_t || !edges || !pooled || n_obj <= 0 || n_tri <= 0 || h <= 0 || off_o < 0 || ld_t < off_o + h)
+    return CS_EINVAL;
+  hipLaunchKernelGGL(gcn_segment_mean_kernel, dim3(cs_grid_for((int64_t)n_obj * h, 256)), dim3(256), 0,
+                     (hipStream_t)stream, new_t, edges, pooled, n_obj, n_tri, h, off_o, ld_t, err);
+  CS_CHECK_LAUNCH();
+  return CS_OK;
+}
+
+extern "C" int cs_embedding(const float* table, const int64_t* idx, float* out, int n, int dim,
+                            int n_rows, int ldo, int32_t* err, cs_stream_t stream) {
+  if (!table || !idx || !out || n <= 0 || dim <= 0 || n_rows <= 0 || ldo < dim) return CS_EINVAL;
+  hipLaunchKernelGGL(embedding_kernel, dim3(cs_grid_for((int64_t)n * dim, 256)), dim3(256), 0,
+                     (hipStream_t)stream, table, idx, out, n, dim, n_rows, ldo, err);
+  CS_CHECK_LAUNCH();
+  return CS_OK;
+}

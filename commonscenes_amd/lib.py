@@ -1,0 +1,106 @@
+"""ctypes binding of libcommonscenes_hip.so (the C ABI declared in include/commonscenes_hip.h).
+
+The HIP library IS the compute path: loading fails loudly when the .so is missing, and no function
+in this package falls back to PyTorch/CPU arithmetic.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+from .build import LIB_PATH
+
+CS_OK = 0
+CS_EINVAL = -22
+ACT_NONE, ACT_RELU, ACT_SILU, ACT_GELU = 0, 1, 2, 3
+MATH_FP32, MATH_F16X3 = 0, 1
+
+_f = C.c_void_p   # device float*
+_i = C.c_int
+_l = C.c_int64
+_s = C.c_void_p   # hipStream_t
+_fl = C.c_float
+
+
+class CsConvGemm(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("w", C.c_void_p), ("out", C.c_void_p), ("bias", C.c_void_p),
+        ("scale", C.c_void_p), ("shift", C.c_void_p), ("rowvec", C.c_void_p), ("res", C.c_void_p),
+        ("nb", C.c_int32), ("din", C.c_int32), ("hin", C.c_int32), ("win", C.c_int32),
+        ("dout", C.c_int32), ("hout", C.c_int32), ("wout", C.c_int32),
+        ("cin", C.c_int32), ("cout", C.c_int32),
+        ("lda", C.c_int32), ("ldw", C.c_int32), ("ldo", C.c_int32), ("ldr", C.c_int32),
+        ("ldrv", C.c_int32),
+        ("kd", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32),
+        ("sd", C.c_int32), ("sh", C.c_int32), ("sw", C.c_int32),
+        ("pd", C.c_int32), ("ph", C.c_int32), ("pw", C.c_int32),
+        ("ud", C.c_int32), ("uh", C.c_int32), ("uw", C.c_int32),
+        ("act", C.c_int32), ("rv_rows", C.c_int32), ("math", C.c_int32), ("tile", C.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol declared in include/commonscenes_hip.h
+SIGNATURES = {
+    "cs_conv_gemm": (_i, [C.POINTER(CsConvGemm), _s]),
+    "cs_conv3d_3x3x3_s111": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _s]),
+    "cs_conv3d_3x3x3_s122": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _s]),
+    "cs_gemm_tokens": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _s]),
+    "cs_relayout_weight": (_i, [_f, _f, _i, _i, _i, _i, _i, _s]),
+    "cs_groupnorm_ws_bytes": (_l, [_i, _i]),
+    "cs_groupnorm_stats": (_i, [_f, _i, _i, _i, _i, _i, _fl, _f, _f, _s]),
+    "cs_groupnorm_apply": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),
+    "cs_groupnorm_silu_ndhwc": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _fl, _f, _f, _s]),
+    "cs_layernorm": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _fl, _s]),
+    "cs_attn_selfattn": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _s]),
+    "cs_geglu": (_i, [_f, _f, _i, _i, _i, _i, _s]),
+    "cs_copy_rows": (_i, [_f, _f, _l, _i, _i, _i, _s]),
+    "cs_add_rowvec": (_i, [_f, _f, _l, _i, _i, _i, _i, _s]),
+    "cs_nchw_to_ndhwc": (_i, [_f, _f, _i, _i, _i, _i, _s]),
+    "cs_ndhwc_to_nchw": (_i, [_f, _f, _i, _i, _i, _i, _s]),
+    "cs_timestep_embedding": (_i, [_f, _f, _i, _i, _fl, _s]),
+    "cs_ddim_cfg_update": (_i, [_f, _f, _f, _f, _f, _l, _l, _fl, _fl, _fl, _fl, _fl, _i, _s]),
+    "cs_vq_argmin_lookup": (_i, [_f, _f, _f, _f, _l, _i, _i, _i, _i, _s]),
+    "cs_gcn_gather_cat": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _f, _s]),
+    "cs_gcn_segment_mean": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _f, _s]),
+    "cs_embedding": (_i, [_f, _f, _f, _i, _i, _i, _i, _f, _s]),
+    "cs_abi_version": (_i, []),
+}
+
+_LIB = None
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+def load(path: Path | None = None) -> C.CDLL:
+    """Load the HIP library; raise (never fall back) if it is absent or lacks a symbol."""
+    global _LIB
+    if _LIB is not None and path is None:
+        return _LIB
+    p = Path(path) if path else LIB_PATH
+    if not p.exists():
+        raise NativeLibraryMissing(
+            f"{p} not found. Build it with `python -m commonscenes_amd.build` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback.")
+    lib = C.CDLL(str(p))
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:  # pragma: no cover
+            raise NativeLibraryMissing(f"{p} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _LIB = lib
+    return lib
+
+
+class CsError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str) -> None:
+    if rc != CS_OK:
+        kind = "invalid argument" if rc == CS_EINVAL else f"hipError_t {rc}"
+        raise CsError(f"{what} failed: {kind}")

@@ -1,0 +1,371 @@
+"""Thin torch-tensor front end over the C ABI (include/commonscenes_hip.h).
+
+torch is used for device memory, streams and shapes only; every arithmetic op below is one call
+into libcommonscenes_hip.so on the current HIP stream.  Tensors are fp32, channels-last
+(`[nb, d, h, w, c]` or token matrices `[nb, n, c]`), possibly views into a wider buffer (row stride
+`ld` > c) so channel concatenation needs no extra pass.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import lib as L
+
+Tensor = torch.Tensor
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t: Tensor, name: str, dtype=torch.float32) -> None:
+    if not t.is_cuda:
+        raise L.CsError(f"{name}: expected a HIP device tensor (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise L.CsError(f"{name}: expected {dtype}, got {t.dtype}")
+
+
+def rows_ld(t: Tensor, name: str = "tensor") -> Tuple[int, int, int]:
+    """View `t` as a row matrix [M, c] with row stride ld; raise unless its layout allows it."""
+    if t.dim() < 1 or (t.shape[-1] != 1 and t.stride(-1) != 1):
+        raise L.CsError(f"{name}: innermost dim must be contiguous")
+    c = t.shape[-1]
+    dims = [(s, st) for s, st in zip(t.shape[:-1], t.stride()[:-1]) if s != 1]
+    if not dims:
+        return 1, c, c
+    ld = dims[-1][1]
+    if ld < c:
+        raise L.CsError(f"{name}: overlapping rows {tuple(t.shape)} {t.stride()}")
+    m = 1
+    expect = ld
+    for s, st in reversed(dims):
+        if st != expect:
+            raise L.CsError(f"{name}: not a row-strided layout {tuple(t.shape)} {t.stride()}")
+        expect *= s
+        m *= s
+    return m, c, ld
+
+
+@dataclass
+class PackedWeight:
+    """Weights re-laid-out for the implicit GEMM: wt[tap][cin_pad][ldw], bias[cout]."""
+    wt: Tensor
+    bias: Optional[Tensor]
+    cout: int
+    cin: int
+    cin_pad: int
+    ldw: int
+    k: Tuple[int, int, int]
+
+
+def pack_weight(w: Tensor, bias: Optional[Tensor] = None, cin_pad: Optional[int] = None) -> PackedWeight:
+    """torch Conv3d (cout,cin,kd,kh,kw) or Linear (out,in) weight -> PackedWeight (device op)."""
+    _chk(w, "weight")
+    w = w.contiguous()
+    if w.dim() == 5:
+        cout, cin, kd, kh, kw = w.shape
+    elif w.dim() == 2:
+        cout, cin = w.shape
+        kd = kh = kw = 1
+    else:
+        raise L.CsError("weight must be 2-D (Linear) or 5-D (Conv3d)")
+    taps = kd * kh * kw
+    cp = cin_pad if cin_pad is not None else (cin + 3) // 4 * 4
+    ldw = (cout + 3) // 4 * 4
+    wt = torch.empty((taps, cp, ldw), dtype=torch.float32, device=w.device)
+    L.check(L.load().cs_relayout_weight(w.data_ptr(), wt.data_ptr(), cout, cin, taps, cp, ldw, _stream()),
+            "cs_relayout_weight")
+    b = None
+    if bias is not None:
+        _chk(bias, "bias")
+        b = bias.contiguous()
+    return PackedWeight(wt, b, cout, cin, cp, ldw, (kd, kh, kw))
+
+
+def conv_gemm(x: Tensor, w: PackedWeight, *, spatial: Optional[Tuple[int, int, int, int]] = None,
+              stride: Sequence[int] = (1, 1, 1), up: Sequence[int] = (0, 0, 0), act: int = L.ACT_NONE,
+              rowvec: Optional[Tensor] = None, rv_rows: int = 1, res: Optional[Tensor] = None,
+              scale: Optional[Tensor] = None, shift: Optional[Tensor] = None,
+              out: Optional[Tensor] = None, tile: int = 0, math: int = L.MATH_FP32) -> Tensor:
+    """Conv3d (k in {1,3}, pad k//2) / Linear.  x: [nb,d,h,w,c] (conv) or [..., c] rows (linear).
+
+    `spatial=(nb,d,h,w)` lets a row matrix be interpreted as a volume without reshaping.
+    """
+    _chk(x, "x")
+    m, c, lda = rows_ld(x, "x")
+    if c != w.cin_pad:
+        raise L.CsError(f"x has {c} channels, packed weight expects {w.cin_pad}")
+    kd, kh, kw = w.k
+    if spatial is None:
+        if kd * kh * kw == 1 and tuple(stride) == (1, 1, 1) and tuple(up) == (0, 0, 0):
+            nb, d, h, wd = m, 1, 1, 1
+        else:
+            if x.dim() != 5:
+                raise L.CsError("conv needs x as [nb,d,h,w,c] or an explicit spatial=")
+            nb, d, h, wd = x.shape[:4]
+    else:
+        nb, d, h, wd = spatial
+        if nb * d * h * wd != m:
+            raise L.CsError("spatial does not match x rows")
+    pd, ph, pw = kd // 2, kh // 2, kw // 2
+    vd, vh, vw = d << up[0], h << up[1], wd << up[2]
+    do = (vd + 2 * pd - kd) // stride[0] + 1
+    ho = (vh + 2 * ph - kh) // stride[1] + 1
+    wo = (vw + 2 * pw - kw) // stride[2] + 1
+    mo = nb * do * ho * wo
+    if out is None:
+        if spatial is None and x.dim() == 5:
+            out = torch.empty((nb, do, ho, wo, w.cout), dtype=torch.float32, device=x.device)
+        elif kd * kh * kw == 1 and spatial is None:
+            out = torch.empty((*x.shape[:-1], w.cout), dtype=torch.float32, device=x.device)
+        else:
+            out = torch.empty((nb, do, ho, wo, w.cout), dtype=torch.float32, device=x.device)
+    _chk(out, "out")
+    om, oc, ldo = rows_ld(out, "out")
+    if om != mo or oc != w.cout:
+        raise L.CsError(f"out has shape {tuple(out.shape)}, expected {mo} rows x {w.cout}")
+    p = L.CsConvGemm()
+    p.x, p.w, p.out = x.data_ptr(), w.wt.data_ptr(), out.data_ptr()
+    p.bias = _ptr(w.bias)
+    p.scale, p.shift = _ptr(scale), _ptr(shift)
+    p.rowvec = _ptr(rowvec)
+    p.res = _ptr(res)
+    p.nb, p.din, p.hin, p.win = nb, d, h, wd
+    p.dout, p.hout, p.wout = do, ho, wo
+    p.cin, p.cout = w.cin_pad, w.cout
+    p.lda, p.ldw, p.ldo = lda, w.ldw, ldo
+    p.ldr = 0
+    if res is not None:
+        _chk(res, "res")
+        rm, rc, ldr = rows_ld(res, "res")
+        if rm != mo or rc != w.cout:
+            raise L.CsError("res shape mismatch")
+        p.ldr = ldr
+    p.ldrv = 0
+    if rowvec is not None:
+        _chk(rowvec, "rowvec")
+        vm, vc, ldrv = rows_ld(rowvec, "rowvec")
+        if vc != w.cout or vm * rv_rows < mo:
+            raise L.CsError("rowvec shape mismatch")
+        p.ldrv = ldrv
+    p.kd, p.kh, p.kw = kd, kh, kw
+    p.sd, p.sh, p.sw = stride
+    p.pd, p.ph, p.pw = pd, ph, pw
+    p.ud, p.uh, p.uw = up
+    p.act, p.rv_rows, p.math, p.tile = act, rv_rows, math, tile
+    L.check(L.load().cs_conv_gemm(C.byref(p), _stream()), "cs_conv_gemm")
+    return out
+
+
+def linear(x: Tensor, w: PackedWeight, **kw) -> Tensor:
+    return conv_gemm(x, w, **kw)
+
+
+def groupnorm(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float, act: int = L.ACT_NONE,
+              out: Optional[Tensor] = None) -> Tensor:
+    """GroupNorm over [nb, ..., c] (stats per sample & group), fused activation."""
+    _chk(x, "x")
+    nb = x.shape[0]
+    m, c, ldx = rows_ld(x, "x")
+    rows = m // nb
+    lib = L.load()
+    ws = torch.empty(lib.cs_groupnorm_ws_bytes(nb, groups) // 8, dtype=torch.float64, device=x.device)
+    stats = torch.empty((nb, groups, 2), dtype=torch.float32, device=x.device)
+    L.check(lib.cs_groupnorm_stats(x.data_ptr(), nb, rows, c, ldx, groups, eps, ws.data_ptr(),
+                                   stats.data_ptr(), _stream()), "cs_groupnorm_stats")
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    om, oc, ldy = rows_ld(out, "out")
+    if om != m or oc != c:
+        raise L.CsError("groupnorm out shape mismatch")
+    L.check(lib.cs_groupnorm_apply(x.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                   out.data_ptr(), nb, rows, c, ldx, ldy, groups, act, _stream()),
+            "cs_groupnorm_apply")
+    return out
+
+
+def layernorm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5, out: Optional[Tensor] = None) -> Tensor:
+    _chk(x, "x")
+    m, c, ldx = rows_ld(x, "x")
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    _, _, ldy = rows_ld(out, "out")
+    L.check(L.load().cs_layernorm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), m, c,
+                                  ldx, ldy, eps, _stream()), "cs_layernorm")
+    return out
+
+
+def attention(q: Tensor, k: Tensor, v: Tensor, heads: int, scale: float, out: Optional[Tensor] = None) -> Tensor:
+    """q: [nb, nq, heads*dh] (views with wider row stride allowed), k/v: [nb, nk, heads*dh]."""
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        _chk(t, n)
+        if t.dim() != 3:
+            raise L.CsError(f"{n} must be [nb, n, c]")
+    nb, nq, cq = q.shape
+    nk = k.shape[1]
+    dh = cq // heads
+    _, _, ldq = rows_ld(q, "q")
+    _, _, ldk = rows_ld(k, "k")
+    _, _, ldv = rows_ld(v, "v")
+    if out is None:
+        out = torch.empty((nb, nq, cq), dtype=torch.float32, device=q.device)
+    _, _, ldo = rows_ld(out, "out")
+    L.check(L.load().cs_attn_selfattn(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), nb, nq, nk,
+                                      heads, dh, ldq, ldk, ldv, ldo, scale, _stream()), "cs_attn_selfattn")
+    return out
+
+
+def geglu(x: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    _chk(x, "x")
+    m, c2, ldx = rows_ld(x, "x")
+    h = c2 // 2
+    if out is None:
+        out = torch.empty((*x.shape[:-1], h), dtype=torch.float32, device=x.device)
+    _, _, ldo = rows_ld(out, "out")
+    L.check(L.load().cs_geglu(x.data_ptr(), out.data_ptr(), m, h, ldx, ldo, _stream()), "cs_geglu")
+    return out
+
+
+def copy_rows(src: Tensor, dst: Tensor) -> Tensor:
+    _chk(src, "src"); _chk(dst, "dst")
+    m, c, lds = rows_ld(src, "src")
+    dm, dc, ldd = rows_ld(dst, "dst")
+    if dm != m or dc != c:
+        raise L.CsError("copy_rows shape mismatch")
+    L.check(L.load().cs_copy_rows(src.data_ptr(), dst.data_ptr(), m, c, lds, ldd, _stream()), "cs_copy_rows")
+    return dst
+
+
+def concat_channels(a: Tensor, b: Tensor) -> Tensor:
+    """torch.cat([a, b], channel) for channels-last tensors (openai_model_3d.py:781)."""
+    ca, cb = a.shape[-1], b.shape[-1]
+    out = torch.empty((*a.shape[:-1], ca + cb), dtype=torch.float32, device=a.device)
+    copy_rows(a, out[..., :ca])
+    copy_rows(b, out[..., ca:])
+    return out
+
+
+def add_rowvec_(x: Tensor, v: Tensor, rows: int) -> Tensor:
+    _chk(x, "x"); _chk(v, "v")
+    m, c, ldx = rows_ld(x, "x")
+    _, vc, ldv = rows_ld(v, "v")
+    if vc != c:
+        raise L.CsError("add_rowvec shape mismatch")
+    L.check(L.load().cs_add_rowvec(x.data_ptr(), v.data_ptr(), m, c, ldx, ldv, rows, _stream()), "cs_add_rowvec")
+    return x
+
+
+def nchw_to_ndhwc(x: Tensor, cpad: Optional[int] = None) -> Tensor:
+    """[nb, c, d, h, w] -> [nb, d, h, w, cpad] (zero padded channels)."""
+    _chk(x, "x")
+    x = x.contiguous()
+    nb, c = x.shape[:2]
+    sp = tuple(x.shape[2:])
+    s = 1
+    for v in sp:
+        s *= v
+    cp = cpad if cpad is not None else c
+    y = torch.empty((nb, *sp, cp), dtype=torch.float32, device=x.device)
+    L.check(L.load().cs_nchw_to_ndhwc(x.data_ptr(), y.data_ptr(), nb, c, s, cp, _stream()), "cs_nchw_to_ndhwc")
+    return y
+
+
+def ndhwc_to_nchw(x: Tensor, c: Optional[int] = None) -> Tensor:
+    """[nb, d, h, w, ld] -> [nb, c, d, h, w] keeping the first c channels."""
+    _chk(x, "x")
+    m, cx, ldx = rows_ld(x, "x")
+    nb = x.shape[0]
+    sp = tuple(x.shape[1:-1])
+    cc = c if c is not None else cx
+    y = torch.empty((nb, cc, *sp), dtype=torch.float32, device=x.device)
+    L.check(L.load().cs_ndhwc_to_nchw(x.data_ptr(), y.data_ptr(), nb, cc, m // nb, ldx, _stream()),
+            "cs_ndhwc_to_nchw")
+    return y
+
+
+def timestep_embedding(t: Tensor, dim: int, max_period: float = 10000.0) -> Tensor:
+    _chk(t, "t", torch.int64)
+    t = t.contiguous()
+    out = torch.empty((t.shape[0], dim), dtype=torch.float32, device=t.device)
+    L.check(L.load().cs_timestep_embedding(t.data_ptr(), out.data_ptr(), t.shape[0], dim, max_period, _stream()),
+            "cs_timestep_embedding")
+    return out
+
+
+def ddim_cfg_update(x: Tensor, eps: Tensor, a_t: float, a_prev: float, sigma_t: float,
+                    sqrt_one_minus_at: float, cfg_scale: float, cfg: bool,
+                    noise: Optional[Tensor] = None, want_pred_x0: bool = True,
+                    out: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
+    _chk(x, "x"); _chk(eps, "eps")
+    x = x.contiguous(); eps = eps.contiguous()
+    nb = x.shape[0]
+    per = x.numel() // nb
+    if eps.numel() != (2 if cfg else 1) * x.numel():
+        raise L.CsError("eps must hold [uc; c] halves when cfg is on")
+    xp = out if out is not None else torch.empty_like(x)
+    p0 = torch.empty_like(x) if want_pred_x0 else None
+    if noise is not None:
+        noise = noise.contiguous()
+    L.check(L.load().cs_ddim_cfg_update(x.data_ptr(), eps.data_ptr(), _ptr(noise), xp.data_ptr(), _ptr(p0),
+                                        nb, per, a_t, a_prev, sigma_t, sqrt_one_minus_at, cfg_scale,
+                                        1 if cfg else 0, _stream()), "cs_ddim_cfg_update")
+    return xp, p0
+
+
+def vq_lookup(z: Tensor, codebook: Tensor) -> Tuple[Tensor, Tensor]:
+    """z: [..., ld>=edim] rows (first edim columns used); returns (idx int64 [M], zq [..., edim_pad])."""
+    _chk(z, "z"); _chk(codebook, "codebook")
+    m, c, ldz = rows_ld(z, "z")
+    ncode, edim = codebook.shape
+    idx = torch.empty((m,), dtype=torch.int64, device=z.device)
+    zq = torch.zeros(z.shape, dtype=torch.float32, device=z.device)
+    _, _, ldq = rows_ld(zq, "zq")
+    L.check(L.load().cs_vq_argmin_lookup(z.data_ptr(), codebook.contiguous().data_ptr(), idx.data_ptr(),
+                                         zq.data_ptr(), m, ncode, edim, ldz, ldq, _stream()),
+            "cs_vq_argmin_lookup")
+    return idx, zq
+
+
+def gcn_gather_cat(obj: Tensor, pred: Tensor, edges: Tensor) -> Tensor:
+    _chk(obj, "obj"); _chk(pred, "pred"); _chk(edges, "edges", torch.int64)
+    obj = obj.contiguous(); pred = pred.contiguous(); edges = edges.contiguous()
+    n_obj, d_obj = obj.shape
+    n_tri, d_pred = pred.shape
+    out = torch.empty((n_tri, 2 * d_obj + d_pred), dtype=torch.float32, device=obj.device)
+    err = torch.zeros((1,), dtype=torch.int32, device=obj.device)
+    L.check(L.load().cs_gcn_gather_cat(obj.data_ptr(), pred.data_ptr(), edges.data_ptr(), out.data_ptr(),
+                                       n_obj, n_tri, d_obj, d_pred, err.data_ptr(), _stream()),
+            "cs_gcn_gather_cat")
+    return out
+
+
+def gcn_segment_mean(new_t: Tensor, edges: Tensor, n_obj: int, h: int, off_o: int) -> Tensor:
+    _chk(new_t, "new_t"); _chk(edges, "edges", torch.int64)
+    n_tri, _, ld_t = rows_ld(new_t, "new_t")
+    pooled = torch.empty((n_obj, h), dtype=torch.float32, device=new_t.device)
+    err = torch.zeros((1,), dtype=torch.int32, device=new_t.device)
+    L.check(L.load().cs_gcn_segment_mean(new_t.data_ptr(), edges.contiguous().data_ptr(), pooled.data_ptr(),
+                                         n_obj, n_tri, h, off_o, ld_t, err.data_ptr(), _stream()),
+            "cs_gcn_segment_mean")
+    return pooled
+
+
+def embedding(table: Tensor, idx: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    _chk(table, "table"); _chk(idx, "idx", torch.int64)
+    n_rows, dim = table.shape
+    n = idx.numel()
+    if out is None:
+        out = torch.empty((n, dim), dtype=torch.float32, device=table.device)
+    _, oc, ldo = rows_ld(out, "out")
+    err = torch.zeros((1,), dtype=torch.int32, device=table.device)
+    L.check(L.load().cs_embedding(table.contiguous().data_ptr(), idx.contiguous().data_ptr(), out.data_ptr(),
+                                  n, dim, n_rows, ldo, err.data_ptr(), _stream()), "cs_embedding")
+    return out

@@ -1,0 +1,386 @@
+"""MI355X-native 3D UNet denoiser behind the reference's `DiffusionUNet` interface.
+
+Mirrors (API, parameter names, semantics) of
+  model/networks/diffusion_networks/network.py:11-42        DiffusionUNet(unet_params, vq_conf, conditioning_key)
+  model/networks/diffusion_networks/openai_model_3d.py:452-789  UNet3DModel
+  model/networks/diffusion_networks/attention.py:154-351   CrossAttention / BasicTransformerBlock / SpatialTransformer3D
+but is NOT a translation: activations live channels-last (NDHWC == token-major, so the
+`b c d h w -> b (d h w) c` rearranges of the reference vanish), every conv / linear is one
+implicit-GEMM MFMA kernel with bias / timestep-embedding / residual fused into its epilogue,
+q/k/v projections are one GEMM, self-attention is a flash kernel, and the one-token
+cross-attention collapses to a per-sample row vector folded into the attn1 output GEMM.
+
+`state_dict()` / `load_state_dict()` speak the reference's key layout.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import lib as L
+from . import ops
+
+Tensor = torch.Tensor
+
+
+# ------------------------------------------------------------------------------------------------
+# architecture description (openai_model_3d.py:558-728)
+# ------------------------------------------------------------------------------------------------
+def _cfg(unet_params) -> dict:
+    g = (lambda k, d=None: unet_params.get(k, d)) if isinstance(unet_params, dict) else (
+        lambda k, d=None: getattr(unet_params, k, d))
+    cfg = dict(
+        image_size=int(g("image_size", 16)), in_channels=int(g("in_channels", 3)),
+        out_channels=int(g("out_channels", 3)), model_channels=int(g("model_channels")),
+        num_res_blocks=int(g("num_res_blocks")), attention_resolutions=tuple(g("attention_resolutions")),
+        channel_mult=tuple(g("channel_mult")), num_heads=int(g("num_heads", -1)),
+        context_dim=g("context_dim"), dims=int(g("dims", 3)),
+        use_spatial_transformer=bool(g("use_spatial_transformer", True)),
+    )
+    if cfg["dims"] != 3 or not cfg["use_spatial_transformer"] or cfg["num_heads"] <= 0:
+        raise NotImplementedError("only the shipped crossattn config family is supported: dims=3, "
+                                  "use_spatial_transformer=True, num_heads>0 (config/sdfusion-txt2shape.yaml)")
+    if g("use_scale_shift_norm", False) or g("resblock_updown", False) or g("num_classes") is not None:
+        raise NotImplementedError("use_scale_shift_norm / resblock_updown / num_classes are not on the path")
+    cfg["context_dim"] = int(cfg["context_dim"])
+    return cfg
+
+
+def unet_blocks(cfg: dict):
+    """Block list with channel bookkeeping.  Each block: list of layer dicts
+    {kind: conv_in|res|attn|down|up, idx, cin, cout}."""
+    mc, mult, nres = cfg["model_channels"], cfg["channel_mult"], cfg["num_res_blocks"]
+    attn_res = set(cfg["attention_resolutions"])
+    inp = [[dict(kind="conv_in", idx=0, cin=cfg["in_channels"], cout=mc)]]
+    chans = [mc]
+    ch, ds = mc, 1
+    for level, m in enumerate(mult):
+        for _ in range(nres):
+            layers = [dict(kind="res", idx=0, cin=ch, cout=m * mc)]
+            ch = m * mc
+            if ds in attn_res:
+                layers.append(dict(kind="attn", idx=1, cin=ch, cout=ch))
+            inp.append(layers)
+            chans.append(ch)
+        if level != len(mult) - 1:
+            inp.append([dict(kind="down", idx=0, cin=ch, cout=ch)])
+            chans.append(ch)
+            ds *= 2
+    mid = [dict(kind="res", idx=0, cin=ch, cout=ch), dict(kind="attn", idx=1, cin=ch, cout=ch),
+           dict(kind="res", idx=2, cin=ch, cout=ch)]
+    out = []
+    for level, m in list(enumerate(mult))[::-1]:
+        for i in range(nres + 1):
+            ich = chans.pop()
+            layers = [dict(kind="res", idx=0, cin=ch + ich, cout=mc * m)]
+            ch = mc * m
+            if ds in attn_res:
+                layers.append(dict(kind="attn", idx=1, cin=ch, cout=ch))
+            if level and i == nres:
+                layers.append(dict(kind="up", idx=len(layers), cin=ch, cout=ch))
+                ds //= 2
+            out.append(layers)
+    return inp, mid, out, ch
+
+
+def unet_param_shapes(cfg: dict, prefix: str = "diffusion_net.") -> "OrderedDict[str, Tuple[int, ...]]":
+    """Every state_dict entry of the reference UNet3DModel for this config: name -> shape."""
+    cfg = _cfg(cfg)
+    mc = cfg["model_channels"]
+    ted = 4 * mc
+    ctx = cfg["context_dim"]
+    S: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+
+    def lin(p, o, i, bias=True):
+        S[p + ".weight"] = (o, i)
+        if bias:
+            S[p + ".bias"] = (o,)
+
+    def conv(p, o, i, k):
+        S[p + ".weight"] = (o, i, k, k, k)
+        S[p + ".bias"] = (o,)
+
+    def norm(p, c):
+        S[p + ".weight"] = (c,)
+        S[p + ".bias"] = (c,)
+
+    def res(p, cin, cout):
+        norm(p + ".in_layers.0", cin)
+        conv(p + ".in_layers.2", cout, cin, 3)
+        lin(p + ".emb_layers.1", cout, ted)
+        norm(p + ".out_layers.0", cout)
+        conv(p + ".out_layers.3", cout, cout, 3)
+        if cin != cout:
+            conv(p + ".skip_connection", cout, cin, 1)
+
+    def attn(p, c):
+        norm(p + ".norm", c)
+        conv(p + ".proj_in", c, c, 1)
+        t = p + ".transformer_blocks.0"
+        for a, cd in (("attn1", c), ("attn2", ctx)):
+            lin(f"{t}.{a}.to_q", c, c, bias=False)
+            lin(f"{t}.{a}.to_k", c, cd, bias=False)
+            lin(f"{t}.{a}.to_v", c, cd, bias=False)
+            lin(f"{t}.{a}.to_out.0", c, c)
+        lin(f"{t}.ff.net.0.proj", 8 * c, c)
+        lin(f"{t}.ff.net.2", c, 4 * c)
+        for n in ("norm1", "norm2", "norm3"):
+            norm(f"{t}.{n}", c)
+        conv(p + ".proj_out", c, c, 1)
+
+    def block(bp, layers):
+        for l in layers:
+            p = f"{bp}.{l['idx']}"
+            if l["kind"] == "conv_in":
+                conv(p, l["cout"], l["cin"], 3)
+            elif l["kind"] == "res":
+                res(p, l["cin"], l["cout"])
+            elif l["kind"] == "attn":
+                attn(p, l["cin"])
+            elif l["kind"] == "down":
+                conv(p + ".op", l["cout"], l["cin"], 3)
+            elif l["kind"] == "up":
+                conv(p + ".conv", l["cout"], l["cin"], 3)
+
+    lin(prefix + "time_embed.0", ted, mc)
+    lin(prefix + "time_embed.2", ted, ted)
+    inp, mid, out, ch = unet_blocks(cfg)
+    for i, layers in enumerate(inp):
+        block(f"{prefix}input_blocks.{i}", layers)
+    block(prefix + "middle_block", mid)
+    for i, layers in enumerate(out):
+        block(f"{prefix}output_blocks.{i}", layers)
+    norm(prefix + "out.0", ch)
+    conv(prefix + "out.2", cfg["out_channels"], mc, 3)
+    return S
+
+
+# ------------------------------------------------------------------------------------------------
+# the module
+# ------------------------------------------------------------------------------------------------
+class DiffusionUNet:
+    """Drop-in for reference `DiffusionUNet` (network.py:11-42): `df(x, t, c_crossattn=[ctx])`,
+    `.conditioning_key`, `.state_dict()`, `.load_state_dict()`, `.to()`, `.eval()`, `.parameters()`.
+    Inference only (the sampler runs under torch.no_grad() in the reference too)."""
+
+    def __init__(self, unet_params, vq_conf=None, conditioning_key: Optional[str] = None,
+                 device: str | torch.device = "cuda"):
+        self.cfg = _cfg(unet_params)
+        self.conditioning_key = conditioning_key
+        self.device = torch.device(device)
+        self.prefix = "diffusion_net."
+        self.shapes = unet_param_shapes(self.cfg, self.prefix)
+        self._sd: Dict[str, Tensor] = {}
+        self._packed = None
+        self.training = False
+        self.math = L.MATH_FP32
+
+    # ---- nn.Module-like surface -----------------------------------------------------------
+    def state_dict(self) -> "OrderedDict[str, Tensor]":
+        return OrderedDict((k, self._sd[k]) for k in self.shapes if k in self._sd)
+
+    def load_state_dict(self, sd, strict: bool = True):
+        missing = [k for k in self.shapes if k not in sd]
+        unexpected = [k for k in sd if k not in self.shapes]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"DiffusionUNet.load_state_dict: missing {missing[:5]} unexpected {unexpected[:5]}")
+        for k, shp in self.shapes.items():
+            if k in sd:
+                t = sd[k]
+                if tuple(t.shape) != tuple(shp):
+                    raise RuntimeError(f"size mismatch for {k}: {tuple(t.shape)} vs {shp}")
+                self._sd[k] = t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        self._packed = None
+        return self
+
+    def parameters(self):
+        return iter(self._sd.values())
+
+    def to(self, device):
+        self.device = torch.device(device)
+        self._sd = {k: v.to(self.device) for k, v in self._sd.items()}
+        self._packed = None
+        return self
+
+    def cuda(self):
+        return self.to("cuda")
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode: bool = True):
+        if mode:
+            raise NotImplementedError("the MI355X-native UNet is an inference (sampler) implementation")
+        return self
+
+    def num_parameters(self) -> int:
+        n = 0
+        for s in self.shapes.values():
+            k = 1
+            for v in s:
+                k *= v
+            n += k
+        return n
+
+    # ---- weight packing -------------------------------------------------------------------
+    def _pack(self):
+        if self.device.type != "cuda":
+            raise L.CsError("DiffusionUNet: weights must be on the HIP device (no CPU path)")
+        sd, P = self._sd, self.prefix
+        missing = [k for k in self.shapes if k not in sd]
+        if missing:
+            raise RuntimeError(f"DiffusionUNet: weights not loaded ({len(missing)} tensors missing)")
+        pk: Dict[str, object] = {}
+
+        def pw(p, cin_pad=None):
+            pk[p] = ops.pack_weight(sd[p + ".weight"], sd.get(p + ".bias"), cin_pad=cin_pad)
+
+        pw(P + "time_embed.0")
+        pw(P + "time_embed.2")
+        inp, mid, out, ch = unet_blocks(self.cfg)
+
+        def pack_block(bp, layers):
+            for l in layers:
+                p = f"{bp}.{l['idx']}"
+                k = l["kind"]
+                if k == "conv_in":
+                    pw(p, cin_pad=(l["cin"] + 3) // 4 * 4)
+                elif k == "res":
+                    pw(p + ".in_layers.2")
+                    pw(p + ".emb_layers.1")
+                    pw(p + ".out_layers.3")
+                    if l["cin"] != l["cout"]:
+                        pw(p + ".skip_connection")
+                elif k == "attn":
+                    pw(p + ".proj_in")
+                    pw(p + ".proj_out")
+                    t = p + ".transformer_blocks.0"
+                    wqkv = torch.cat([sd[f"{t}.attn1.to_q.weight"], sd[f"{t}.attn1.to_k.weight"],
+                                      sd[f"{t}.attn1.to_v.weight"]], dim=0)
+                    pk[t + ".attn1.qkv"] = ops.pack_weight(wqkv)
+                    pw(t + ".attn1.to_out.0")
+                    pw(t + ".attn2.to_q")
+                    pw(t + ".attn2.to_k")
+                    pw(t + ".attn2.to_v")
+                    pw(t + ".attn2.to_out.0")
+                    pw(t + ".ff.net.0.proj")
+                    pw(t + ".ff.net.2")
+                elif k == "down":
+                    pw(p + ".op")
+                elif k == "up":
+                    pw(p + ".conv")
+
+        for i, layers in enumerate(inp):
+            pack_block(f"{P}input_blocks.{i}", layers)
+        pack_block(P + "middle_block", mid)
+        for i, layers in enumerate(out):
+            pack_block(f"{P}output_blocks.{i}", layers)
+        pw(P + "out.2")
+        self._packed = pk
+        self._blocks = (inp, mid, out)
+
+    # ---- forward --------------------------------------------------------------------------
+    def _res(self, p: str, l: dict, x: Tensor, semb: Tensor) -> Tensor:
+        sd, pk = self._sd, self._packed
+        nb = x.shape[0]
+        rows = x.shape[1] * x.shape[2] * x.shape[3]
+        hn = ops.groupnorm(x, sd[p + ".in_layers.0.weight"], sd[p + ".in_layers.0.bias"], 32, 1e-5, L.ACT_SILU)
+        embo = ops.linear(semb, pk[p + ".emb_layers.1"], math=self.math)
+        h = ops.conv_gemm(hn, pk[p + ".in_layers.2"], rowvec=embo, rv_rows=rows, math=self.math)
+        hn2 = ops.groupnorm(h, sd[p + ".out_layers.0.weight"], sd[p + ".out_layers.0.bias"], 32, 1e-5, L.ACT_SILU)
+        skip = x if l["cin"] == l["cout"] else ops.conv_gemm(x, pk[p + ".skip_connection"], math=self.math)
+        return ops.conv_gemm(hn2, pk[p + ".out_layers.3"], res=skip, math=self.math)
+
+    def _attn(self, p: str, l: dict, x: Tensor, ctx: Tensor) -> Tensor:
+        sd, pk = self._sd, self._packed
+        heads = self.cfg["num_heads"]
+        nb, d, h, w, c = x.shape
+        n = d * h * w
+        dh = c // heads
+        t = p + ".transformer_blocks.0"
+        xn = ops.groupnorm(x, sd[p + ".norm.weight"], sd[p + ".norm.bias"], 32, 1e-6, L.ACT_NONE)
+        t0 = ops.linear(xn.view(nb, n, c), pk[p + ".proj_in"], math=self.math)
+        n1 = ops.layernorm(t0, sd[t + ".norm1.weight"], sd[t + ".norm1.bias"])
+        qkv = ops.linear(n1, pk[t + ".attn1.qkv"], math=self.math)
+        a = ops.attention(qkv[..., 0:c], qkv[..., c:2 * c], qkv[..., 2 * c:3 * c], heads, dh ** -0.5)
+        if ctx.shape[1] == 1:
+            # one context token: softmax over one key == 1, attn2(x) = to_out(to_v(ctx)) for every
+            # query row -> a per-sample row vector folded into the attn1 output GEMM.
+            v2 = ops.linear(ctx.reshape(nb, -1), pk[t + ".attn2.to_v"], math=self.math)
+            v2 = ops.linear(v2, pk[t + ".attn2.to_out.0"], math=self.math)
+            t1 = ops.linear(a, pk[t + ".attn1.to_out.0"], res=t0, rowvec=v2, rv_rows=n, math=self.math)
+        else:
+            t1a = ops.linear(a, pk[t + ".attn1.to_out.0"], res=t0, math=self.math)
+            n2 = ops.layernorm(t1a, sd[t + ".norm2.weight"], sd[t + ".norm2.bias"])
+            q2 = ops.linear(n2, pk[t + ".attn2.to_q"], math=self.math)
+            k2 = ops.linear(ctx, pk[t + ".attn2.to_k"], math=self.math)
+            vv2 = ops.linear(ctx, pk[t + ".attn2.to_v"], math=self.math)
+            a2 = ops.attention(q2, k2, vv2, heads, dh ** -0.5)
+            t1 = ops.linear(a2, pk[t + ".attn2.to_out.0"], res=t1a, math=self.math)
+        n3 = ops.layernorm(t1, sd[t + ".norm3.weight"], sd[t + ".norm3.bias"])
+        ff = ops.linear(n3, pk[t + ".ff.net.0.proj"], math=self.math)
+        gg = ops.geglu(ff)
+        t2 = ops.linear(gg, pk[t + ".ff.net.2"], res=t1, math=self.math)
+        out = ops.linear(t2, pk[p + ".proj_out"], res=x.view(nb, n, c), math=self.math)
+        return out.view(nb, d, h, w, c)
+
+    def _run(self, bp: str, layers, h: Tensor, semb: Tensor, ctx: Tensor) -> Tensor:
+        pk = self._packed
+        for l in layers:
+            p = f"{bp}.{l['idx']}"
+            k = l["kind"]
+            if k == "conv_in":
+                h = ops.conv_gemm(h, pk[p], math=self.math)
+            elif k == "res":
+                h = self._res(p, l, h, semb)
+            elif k == "attn":
+                h = self._attn(p, l, h, ctx)
+            elif k == "down":
+                h = ops.conv_gemm(h, pk[p + ".op"], stride=(1, 2, 2), math=self.math)
+            elif k == "up":
+                h = ops.conv_gemm(h, pk[p + ".conv"], up=(0, 1, 1), math=self.math)
+        return h
+
+    @torch.no_grad()
+    def forward_ndhwc(self, h: Tensor, t: Tensor, ctx: Tensor) -> Tensor:
+        """x as [nb, d, h, w, cpad(4)] channels-last -> eps [nb, d, h, w, out_channels]."""
+        if self._packed is None:
+            self._pack()
+        sd, pk, P = self._sd, self._packed, self.prefix
+        inp, mid, out = self._blocks
+        temb = ops.timestep_embedding(t, self.cfg["model_channels"])
+        e1 = ops.linear(temb, pk[P + "time_embed.0"], act=L.ACT_SILU, math=self.math)
+        # every consumer of `emb` is emb_layers = SiLU -> Linear (openai_model_3d.py:257-263): keep SiLU(emb)
+        semb = ops.linear(e1, pk[P + "time_embed.2"], act=L.ACT_SILU, math=self.math)
+        hs: List[Tensor] = []
+        for i, layers in enumerate(inp):
+            h = self._run(f"{P}input_blocks.{i}", layers, h, semb, ctx)
+            hs.append(h)
+        h = self._run(P + "middle_block", mid, h, semb, ctx)
+        for i, layers in enumerate(out):
+            h = ops.concat_channels(h, hs.pop())
+            h = self._run(f"{P}output_blocks.{i}", layers, h, semb, ctx)
+        hn = ops.groupnorm(h, sd[P + "out.0.weight"], sd[P + "out.0.bias"], 32, 1e-5, L.ACT_SILU)
+        return ops.conv_gemm(hn, pk[P + "out.2"], math=self.math)
+
+    @torch.no_grad()
+    def forward(self, x: Tensor, t: Tensor, c_concat: Optional[list] = None,
+                c_crossattn: Optional[list] = None) -> Tensor:
+        """network.py:20-42.  x: (B, C, D, H, W) fp32 on the HIP device; t: (B,) int64."""
+        if self.conditioning_key != "crossattn":
+            raise NotImplementedError(f"conditioning_key={self.conditioning_key!r}: only 'crossattn' "
+                                      "(config/sdfusion-txt2shape.yaml:5) is implemented")
+        if c_crossattn is None:
+            raise ValueError("c_crossattn is required for conditioning_key='crossattn'")
+        ctx = c_crossattn[0] if len(c_crossattn) == 1 else torch.cat(c_crossattn, 1)
+        ctx = ctx.to(dtype=torch.float32).contiguous()
+        if t.dtype != torch.int64:
+            t = t.to(torch.int64)
+        h = ops.nchw_to_ndhwc(x.to(torch.float32), cpad=(self.cfg["in_channels"] + 3) // 4 * 4)
+        eps = self.forward_ndhwc(h, t.contiguous(), ctx)
+        return ops.ndhwc_to_nchw(eps)
+
+    __call__ = forward

@@ -1,0 +1,202 @@
+/*
+ * commonscenes_hip.h -- C ABI of libcommonscenes_hip.so (gfx950 / MI355X).
+ *
+ * This is the drop-in boundary for the CommonScenes shape-branch sampler
+ * (SURVEY.md section 8b).  The reference has no native code on this path: every
+ * entry below replaces a PyTorch/ATen call made from a reference Python file, cited
+ * per entry as  <reference file>:<line>.  The only native precedent in the reference
+ * (extension/chamfer_cuda.cpp:9-26, extension/chamfer.cu:136-151) returns an int
+ * status and writes into caller-allocated outputs; this library keeps that contract.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer valid on the current HIP device;
+ *   - the caller owns every buffer, including workspaces; the library allocates
+ *     nothing and keeps no global state;
+ *   - every entry enqueues on `stream` and never synchronises;
+ *   - return value: 0 = success, CS_EINVAL = bad argument, otherwise hipError_t;
+ *   - activations are channels-last: NDHWC, i.e. [n][d][h][w][c] with c contiguous and an
+ *     explicit row stride `ld*` (in floats) so a tensor can live inside a wider
+ *     (concatenated) buffer.  Token matrices [n][tokens][c] are the same memory.
+ *   - all arithmetic is fp32 (fp32-input MFMA v_mfma_f32_32x32x2_f32, fp32 accumulate);
+ *     GroupNorm statistics accumulate in fp64.
+ */
+#ifndef COMMONSCENES_HIP_H
+#define COMMONSCENES_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* cs_stream_t; /* == hipStream_t */
+
+#define CS_OK 0
+#define CS_EINVAL (-22)
+
+/* epilogue activation codes */
+#define CS_ACT_NONE 0
+#define CS_ACT_RELU 1
+#define CS_ACT_SILU 2
+#define CS_ACT_GELU 3 /* exact (erf) GELU, torch.nn.GELU() default */
+
+/* GEMM numerics mode */
+#define CS_MATH_FP32 0     /* v_mfma_f32_32x32x2_f32, bit-equal to an fp32 fma chain  */
+#define CS_MATH_F16X3 1    /* 3x v_mfma_f32_32x32x16_f16 on hi/lo fp16 splits (~2^-21) */
+
+/*
+ * Implicit-GEMM convolution / linear descriptor.
+ *   out[m][n] = act( (sum_{tap,c} x[src(m,tap)][c] * w[tap][c][n] + bias[n]) * scale[n] + shift[n]
+ *                    + rowvec[m / rv_rows][n] ) + res[m][n]
+ * with m = ((b*dout + od)*hout + oh)*wout + ow and
+ *   src(m,tap): v = o*stride + k - pad in the "virtual" (nearest-upsampled) input of extent
+ *   (din<<ud, hin<<uh, win<<uw); out-of-range taps read zero; physical coord = v >> u.
+ * A plain Linear / 1x1x1 conv is kd=kh=kw=1, strides 1, pads 0, spatial extents 1.
+ * Replaces: torch.nn.Conv3d / F.interpolate(nearest)+Conv3d / nn.Linear calls in
+ *   model/networks/diffusion_networks/openai_model_3d.py:146-158,188-199,240-314,561,727
+ *   model/networks/diffusion_networks/attention.py:42-46,163-170,313-328
+ *   model/networks/vqvae_networks/vqvae_modules.py:24-39,64-123,128-152,337-399
+ *   model/layers.py:21-38 (Linear + BatchNorm1d(eval) + ReLU via scale/shift/act)
+ */
+typedef struct CsConvGemm {
+  const float* x;      /* [nb][din][hin][win][lda]                                  */
+  const float* w;      /* [kd*kh*kw][cin][ldw]   (re-laid-out weights, n contiguous) */
+  float* out;          /* [nb*dout*hout*wout][ldo]                                  */
+  const float* bias;   /* [cout] or NULL */
+  const float* scale;  /* [cout] or NULL (requires shift) */
+  const float* shift;  /* [cout] or NULL */
+  const float* rowvec; /* [ceil(M/rv_rows)][ldrv] or NULL */
+  const float* res;    /* [M][ldr] or NULL */
+  int32_t nb, din, hin, win;
+  int32_t dout, hout, wout;
+  int32_t cin, cout;
+  int32_t lda, ldw, ldo, ldr, ldrv;
+  int32_t kd, kh, kw;
+  int32_t sd, sh, sw;
+  int32_t pd, ph, pw;
+  int32_t ud, uh, uw; /* log2 nearest-upsample factor applied to x before the conv */
+  int32_t act;
+  int32_t rv_rows;    /* rows per rowvec entry (tokens / voxels per sample) */
+  int32_t math;       /* CS_MATH_* */
+  int32_t tile;       /* 0 = auto, 1 = 128x128, 2 = 128x224, 3 = 64x64 */
+} CsConvGemm;
+
+int cs_conv_gemm(const CsConvGemm* desc, cs_stream_t stream);
+
+/* Convenience entries named in SURVEY.md section 8b (thin wrappers over cs_conv_gemm). */
+int cs_conv3d_3x3x3_s111(const float* x, const float* w, const float* bias, float* out,
+                         int nb, int d, int h, int w_, int cin, int cout, cs_stream_t stream);
+int cs_conv3d_3x3x3_s122(const float* x, const float* w, const float* bias, float* out,
+                         int nb, int d, int h, int w_, int cin, int cout, cs_stream_t stream);
+int cs_gemm_tokens(const float* x, const float* w, const float* bias, const float* res, float* out,
+                   int m, int k, int n, int act, cs_stream_t stream);
+
+/*
+ * Weight re-layout: torch (cout, cin, kd, kh, kw) -> [tap][cin_pad][ldw] (zero padded).
+ * Also used for Linear (out,in) with taps = 1.
+ */
+int cs_relayout_weight(const float* w_torch, float* w_out, int cout, int cin, int taps,
+                       int cin_pad, int ldw, cs_stream_t stream);
+
+/*
+ * GroupNorm over NDHWC. Two entries: statistics (fp64 accumulation), then normalise+affine+act.
+ *   ws: workspace of cs_groupnorm_ws_bytes(nb, groups) bytes.
+ *   stats: [nb][groups][2] floats (mean, rstd).
+ * Replaces GroupNorm32 (ldm_diffusion_util.py:222-239), Normalize (attention.py:78-79,
+ * vqvae_modules.py:13-21) followed by SiLU / swish / GELU / identity.
+ */
+int64_t cs_groupnorm_ws_bytes(int nb, int groups);
+int cs_groupnorm_stats(const float* x, int nb, int rows, int c, int ldx, int groups, float eps,
+                       void* ws, float* stats, cs_stream_t stream);
+int cs_groupnorm_apply(const float* x, const float* stats, const float* gamma, const float* beta,
+                       float* y, int nb, int rows, int c, int ldx, int ldy, int groups, int act,
+                       cs_stream_t stream);
+/* SURVEY name: both steps, SiLU epilogue. */
+int cs_groupnorm_silu_ndhwc(const float* x, const float* gamma, const float* beta, float* y,
+                            int nb, int rows, int c, int groups, float eps, void* ws, float* stats,
+                            cs_stream_t stream);
+
+/* LayerNorm over the last dim of [m][c] (nn.LayerNorm, attention.py:229-231). */
+int cs_layernorm(const float* x, const float* gamma, const float* beta, float* y, int m, int c,
+                 int ldx, int ldy, float eps, cs_stream_t stream);
+
+/*
+ * Multi-head attention, flash style (no score matrix in HBM), fp32.
+ *   q: [nb][nq][ldq], head h at columns [h*dh, (h+1)*dh);  k, v likewise over nk keys.
+ *   out[b][i][h*dh + d] = sum_j softmax_j(scale * q_i . k_j) v_j[d]
+ * Replaces CrossAttention.forward einsum/softmax/einsum (attention.py:201-218) and
+ * AttnBlock.forward bmm/softmax/bmm (vqvae_modules.py:162-173).
+ */
+int cs_attn_selfattn(const float* q, const float* k, const float* v, float* out, int nb, int nq,
+                     int nk, int heads, int dh, int ldq, int ldk, int ldv, int ldo, float scale,
+                     cs_stream_t stream);
+
+/* GEGLU gate: out[m][j] = x[m][j] * gelu(x[m][h + j])  (attention.py:44-46). */
+int cs_geglu(const float* x, float* out, int m, int h, int ldx, int ldo, cs_stream_t stream);
+
+/* dst[m][0:c] = src[m][0:c] with independent row strides (channel concat, openai_model_3d.py:781). */
+int cs_copy_rows(const float* src, float* dst, int64_t m, int c, int lds, int ldd,
+                 cs_stream_t stream);
+
+/* x[m][c] += v[m / rows][c]   (cross-attention with one context token). */
+int cs_add_rowvec(float* x, const float* v, int64_t m, int c, int ldx, int ldv, int rows,
+                  cs_stream_t stream);
+
+/* Layout: NCDHW [nb][c][s] -> NDHWC [nb][s][cpad] (channels >= c zero filled) and back. */
+int cs_nchw_to_ndhwc(const float* x, float* y, int nb, int c, int s, int cpad, cs_stream_t stream);
+int cs_ndhwc_to_nchw(const float* x, float* y, int nb, int c, int s, int ldx, cs_stream_t stream);
+
+/*
+ * Sinusoidal timestep embedding (ldm_diffusion_util.py:174-194):
+ *   out[b][0:half] = cos(t[b]*f_k), out[b][half:2*half] = sin(t[b]*f_k), f_k = exp(-ln(max_period)*k/half).
+ */
+int cs_timestep_embedding(const int64_t* t, float* out, int nb, int dim, float max_period,
+                          cs_stream_t stream);
+
+/*
+ * Fused classifier-free guidance + DDIM update (samplers/ddim.py:206-243), eta == 0 path plus
+ * optional noise term.  eps: [2*nb][per] with the unconditional half first.
+ *   e      = e_uc + scale * (e_c - e_uc)
+ *   pred   = (x - sqrt_one_minus_at * e) / sqrt(a_t)
+ *   x_prev = sqrt(a_prev) * pred + sqrt(1 - a_prev - sigma^2) * e + sigma * noise
+ * x_prev may alias x.  pred_x0 and noise may be NULL.  If cfg == 0, eps is [nb][per].
+ */
+int cs_ddim_cfg_update(const float* x, const float* eps, const float* noise, float* x_prev,
+                       float* pred_x0, int64_t nb, int64_t per, float a_t, float a_prev,
+                       float sigma_t, float sqrt_one_minus_at, float cfg_scale, int cfg,
+                       cs_stream_t stream);
+
+/*
+ * VQ nearest-code lookup (quantizer.py:76-84): z [m][ldz] (first edim entries of each row),
+ * codebook [ncode][edim] -> idx[m] (int64, first minimum) and zq [m][ldq] = codebook[idx].
+ * d = sum(z^2) + sum(e^2) - 2 z.e evaluated in fp32 in that order.  edim <= 4.
+ */
+int cs_vq_argmin_lookup(const float* z, const float* codebook, int64_t* idx, float* zq, int64_t m,
+                        int ncode, int edim, int ldz, int ldq, cs_stream_t stream);
+
+/*
+ * Scene-graph convolution helpers (model/graph.py:146-151,176-199).
+ *   cs_gcn_gather_cat:   out[t] = [obj[s_t] | pred[t] | obj[o_t]],  edges [t][2] int64
+ *   cs_gcn_segment_mean: pooled[i] = (sum_{t: s_t = i} new_t[0:h] (edge order) then
+ *                                     + sum_{t: o_t = i} new_t[off_o : off_o + h]) / max(count_i, 1)
+ *     -- sequential edge order == torch CPU scatter_add order, so sums are deterministic.
+ * Returns CS_EINVAL semantics cannot be reported for bad indices from the device; indices are
+ * range-checked in-kernel and out-of-range edges are skipped with *err set to 1.
+ */
+int cs_gcn_gather_cat(const float* obj, const float* pred, const int64_t* edges, float* out,
+                      int n_obj, int n_tri, int d_obj, int d_pred, int32_t* err,
+                      cs_stream_t stream);
+int cs_gcn_segment_mean(const float* new_t, const int64_t* edges, float* pooled, int n_obj,
+                        int n_tri, int h, int off_o, int ld_t, int32_t* err, cs_stream_t stream);
+
+/* Embedding row gather: out[i] = table[idx[i]] (nn.Embedding, VAEGAN_V2FULL.py:225-226). */
+int cs_embedding(const float* table, const int64_t* idx, float* out, int n, int dim, int n_rows,
+                 int ldo, int32_t* err, cs_stream_t stream);
+
+/* Library / device self-description. */
+int cs_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COMMONSCENES_HIP_H */
