@@ -251,6 +251,38 @@ __global__ __launch_bounds__(256) void embedding_kernel(const float* __restrict_
   }
 }
 
+// one wave per row
+__global__ __launch_bounds__(256) void log_softmax_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          int m, int c, int ldx, int ldy) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= m) return;
+  const float* xr = x + (int64_t)row * ldx;
+  float mx = -INFINITY;
+  for (int i = lane; i < c; i += 64) mx = fmaxf(mx, xr[i]);
+  mx = wave_max(mx);
+  float s = 0.f;
+  for (int i = lane; i < c; i += 64) s += expf(xr[i] - mx);
+  s = wave_sum(s);
+  const float ls = logf(s);
+  for (int i = lane; i < c; i += 64) y[(int64_t)row * ldy + i] = (xr[i] - mx) - ls;
+}
+
+__global__ __launch_bounds__(256) void synth_fill_kernel(float* __restrict__ out, int64_t n, uint64_t base,
+                                                         double scale, double offset) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    uint64_t z = (uint64_t)i * 0x9E3779B97F4A7C15ull + base;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    const int64_t k = (int64_t)(z >> 40);
+    const double u = (double)(2 * k - (1ll << 24)) / 16777216.0;
+    const double v = u * scale;
+    out[i] = (float)(v + offset);
+  }
+}
+
 inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
@@ -380,6 +412,23 @@ extern "C" int cs_embedding(const float* table, const int64_t* idx, float* out, 
   if (!table || !idx || !out || n <= 0 || dim <= 0 || n_rows <= 0 || ldo < dim) return CS_EINVAL;
   hipLaunchKernelGGL(embedding_kernel, dim3(cs_grid_for((int64_t)n * dim, 256)), dim3(256), 0,
                      (hipStream_t)stream, table, idx, out, n, dim, n_rows, ldo, err);
+  CS_CHECK_LAUNCH();
+  return CS_OK;
+}
+
+extern "C" int cs_log_softmax(const float* x, float* y, int m, int c, int ldx, int ldy, cs_stream_t stream) {
+  if (!x || !y || m <= 0 || c <= 0 || ldx < c || ldy < c) return CS_EINVAL;
+  hipLaunchKernelGGL(log_softmax_kernel, dim3((m + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, y, m, c,
+                     ldx, ldy);
+  CS_CHECK_LAUNCH();
+  return CS_OK;
+}
+
+extern "C" int cs_synth_fill(float* out, int64_t n, uint64_t base, double scale, double offset,
+                             cs_stream_t stream) {
+  if (!out || n <= 0) return CS_EINVAL;
+  hipLaunchKernelGGL(synth_fill_kernel, dim3(cs_grid_for(n, 256, 256 * 32)), dim3(256), 0, (hipStream_t)stream,
+                     out, n, base, scale, offset);
   CS_CHECK_LAUNCH();
   return CS_OK;
 }

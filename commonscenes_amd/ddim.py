@@ -1,0 +1,156 @@
+"""DDIM sampler behind the reference's `DDIMSampler` interface, device work in HIP.
+
+Mirrors model/networks/diffusion_networks/samplers/ddim.py:15-244 (make_schedule, sample,
+ddim_sampling, p_sample_ddim) and ldm_diffusion_util.py:68-96 (timestep selection, sampling
+parameters).  The coefficient tables are built on the host exactly as the reference builds them
+(including its fp32 / float64 rounding points); the per-step work -- classifier-free
+guidance combine + x0 prediction + x_{t-1} update -- is ONE fused elementwise kernel
+(cs_ddim_cfg_update) instead of ~12 ATen launches, and the loop issues no host synchronisation
+(the reference's CrossAttention NaN traps cost 44 syncs per UNet forward).
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional
+
+import numpy as np
+import torch
+
+from . import ops
+
+Tensor = torch.Tensor
+
+
+def make_ddim_timesteps(ddim_discr_method: str, num_ddim_timesteps: int, num_ddpm_timesteps: int,
+                        verbose: bool = False) -> np.ndarray:
+    """ldm_diffusion_util.py:68-82."""
+    if ddim_discr_method == "uniform":
+        c = num_ddpm_timesteps // num_ddim_timesteps
+        ddim_timesteps = np.asarray(list(range(0, num_ddpm_timesteps, c)))
+    elif ddim_discr_method == "quad":
+        ddim_timesteps = ((np.linspace(0, np.sqrt(num_ddpm_timesteps * .8), num_ddim_timesteps)) ** 2).astype(int)
+    else:
+        raise NotImplementedError(f'There is no ddim discretization method called "{ddim_discr_method}"')
+    steps_out = ddim_timesteps + 1
+    if verbose:
+        print(f"Selected timesteps for ddim sampler: {steps_out}")
+    return steps_out
+
+
+def make_ddim_sampling_parameters(alphacums: Tensor, ddim_timesteps: np.ndarray, eta: float, verbose: bool = False):
+    """ldm_diffusion_util.py:85-96.  `alphacums` is the fp32 CPU tensor of cumulative alphas; the
+    result dtypes follow the reference: alphas fp32, alphas_prev float64 holding fp32 values."""
+    alphas = alphacums[ddim_timesteps]                                   # fp32 tensor
+    alphas_prev = np.asarray([alphacums[0]] + alphacums[ddim_timesteps[:-1]].tolist())
+    a64 = alphas.numpy().astype(np.float64)
+    sigmas = eta * np.sqrt((1 - alphas_prev) / (1 - a64) * (1 - a64 / alphas_prev))
+    if verbose:
+        print(f"Selected alphas for ddim sampler: a_t: {alphas}; a_(t-1): {alphas_prev}")
+    return sigmas, alphas, alphas_prev
+
+
+class DDIMSampler(object):
+    def __init__(self, model, schedule: str = "linear", **kwargs):
+        self.model = model
+        self.ddpm_num_timesteps = model.num_timesteps
+        self.schedule = schedule
+
+    def register_buffer(self, name, attr):
+        setattr(self, name, attr)
+
+    def make_schedule(self, ddim_num_steps, ddim_discretize="uniform", ddim_eta=0., verbose=True):
+        self.ddim_timesteps = make_ddim_timesteps(ddim_discretize, ddim_num_steps, self.ddpm_num_timesteps, verbose)
+        alphas_cumprod = self.model.alphas_cumprod
+        assert alphas_cumprod.shape[0] == self.ddpm_num_timesteps, "alphas have to be defined for each timestep"
+        ac = alphas_cumprod.detach().to(torch.float32).cpu()
+        self.register_buffer("alphas_cumprod", ac)
+        sig, a, ap = make_ddim_sampling_parameters(ac, self.ddim_timesteps, ddim_eta, verbose)
+        # host-side tables (python floats at use); the values match the reference's buffers bit for bit
+        self.register_buffer("ddim_sigmas", np.asarray(sig, dtype=np.float64))
+        self.register_buffer("ddim_alphas", a.numpy().astype(np.float32))
+        self.register_buffer("ddim_alphas_prev", np.asarray(ap, dtype=np.float64))
+        self.register_buffer("ddim_sqrt_one_minus_alphas", torch.sqrt(1.0 - a).numpy().astype(np.float32))
+
+    @torch.no_grad()
+    def sample(self, S, batch_size, shape, conditioning=None, callback=None, normals_sequence=None,
+               img_callback=None, quantize_x0=False, eta=0., mask=None, x0=None, temperature=1.,
+               noise_dropout=0., score_corrector=None, corrector_kwargs=None, verbose=True, x_T=None,
+               log_every_t=100, unconditional_guidance_scale=1., unconditional_conditioning=None,
+               mm_cls_free=False, **kwargs):
+        if conditioning is not None and not isinstance(conditioning, dict):
+            if conditioning.shape[0] != batch_size:
+                print(f"Warning: Got {conditioning.shape[0]} conditionings but batch-size is {batch_size}")
+        for name, val, ok in (("mask", mask, None), ("x0", x0, None), ("score_corrector", score_corrector, None)):
+            if val is not ok:
+                raise NotImplementedError(f"DDIMSampler.sample({name}=...) is not on the rel2shape path")
+        if quantize_x0 or mm_cls_free or noise_dropout > 0. or temperature != 1.:
+            raise NotImplementedError("quantize_x0 / mm_cls_free / noise_dropout / temperature are not on the "
+                                      "rel2shape path (sdfusion_txt2shape_model.py:498-507)")
+        self.make_schedule(ddim_num_steps=S, ddim_eta=eta, verbose=verbose)
+        if len(shape) == 4:
+            C_, D, H, W = shape
+            size = (batch_size, C_, D, H, W)
+        else:
+            C_, H, W = shape
+            size = (batch_size, C_, H, W)
+        if verbose:
+            print(f"Data shape for DDIM sampling is {size}, eta {eta}")
+        return self.ddim_sampling(conditioning, size, callback=callback, img_callback=img_callback, x_T=x_T,
+                                  log_every_t=log_every_t,
+                                  unconditional_guidance_scale=unconditional_guidance_scale,
+                                  unconditional_conditioning=unconditional_conditioning,
+                                  max_steps=kwargs.get("max_steps"))
+
+    @torch.no_grad()
+    def ddim_sampling(self, cond, shape, x_T=None, callback=None, img_callback=None, log_every_t=100,
+                      unconditional_guidance_scale=1., unconditional_conditioning=None, max_steps=None):
+        device = self.model.device
+        b = shape[0]
+        img = torch.randn(shape, device=device) if x_T is None else x_T.to(device=device, dtype=torch.float32)
+        timesteps = self.ddim_timesteps
+        intermediates = {"x_inter": [img], "pred_x0": [img]}
+        time_range = np.flip(timesteps)
+        total_steps = timesteps.shape[0]
+        cfg = not (unconditional_conditioning is None or unconditional_guidance_scale == 1.)
+        # hoisted out of the loop: the conditioning batch [uc; c] never changes (ddim.py:208)
+        c_in = torch.cat([unconditional_conditioning, cond]) if cfg else cond
+        for i, step in enumerate(time_range):
+            if max_steps is not None and i >= max_steps:
+                break
+            index = total_steps - i - 1
+            want_p0 = bool(img_callback) or index % log_every_t == 0 or index == total_steps - 1
+            img, pred_x0 = self._step(img, c_in, int(step), index, cfg, unconditional_guidance_scale,
+                                      want_pred_x0=want_p0)
+            if callback:
+                callback(i)
+            if img_callback:
+                img_callback(pred_x0, i)
+            if index % log_every_t == 0 or index == total_steps - 1:
+                intermediates["x_inter"].append(img)
+                intermediates["pred_x0"].append(pred_x0)
+        return img, intermediates
+
+    @torch.no_grad()
+    def p_sample_ddim(self, x, c, t, index, repeat_noise=False, use_original_steps=False, quantize_denoised=False,
+                      temperature=1., noise_dropout=0., score_corrector=None, corrector_kwargs=None,
+                      unconditional_guidance_scale=1., unconditional_conditioning=None, mm_cls_free=False):
+        """Reference-signature single step (ddim.py:182-244): returns (x_prev, pred_x0)."""
+        if (repeat_noise or use_original_steps or quantize_denoised or temperature != 1. or noise_dropout > 0.
+                or score_corrector is not None or mm_cls_free):
+            raise NotImplementedError("only the options used by rel2shape are implemented")
+        cfg = not (unconditional_conditioning is None or unconditional_guidance_scale == 1.)
+        c_in = torch.cat([unconditional_conditioning, c]) if cfg else c
+        return self._step(x, c_in, int(t.flatten()[0].item()), int(index), cfg, unconditional_guidance_scale)
+
+    @torch.no_grad()
+    def _step(self, x, c_in, step: int, index: int, cfg: bool, scale: float, want_pred_x0: bool = True):
+        """One fused DDIM step; c_in is [uc; c] when cfg is on."""
+        b = x.shape[0]
+        nb = 2 * b if cfg else b
+        t_in = torch.full((nb,), step, device=x.device, dtype=torch.long)
+        x_in = torch.cat([x, x]) if cfg else x
+        eps = self.model.apply_model(x_in, t_in, c_in)
+        sigma = float(self.ddim_sigmas[index])
+        noise = torch.randn_like(x) if sigma != 0.0 else None     # eta == 0: sigma_t * noise == 0 exactly
+        return ops.ddim_cfg_update(x, eps, float(self.ddim_alphas[index]), float(self.ddim_alphas_prev[index]),
+                                   sigma, float(self.ddim_sqrt_one_minus_alphas[index]), float(scale), cfg,
+                                   noise=noise, want_pred_x0=want_pred_x0)

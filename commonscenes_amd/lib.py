@@ -63,6 +63,8 @@ SIGNATURES = {
     "cs_gcn_gather_cat": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _f, _s]),
     "cs_gcn_segment_mean": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _f, _s]),
     "cs_embedding": (_i, [_f, _f, _f, _i, _i, _i, _i, _f, _s]),
+    "cs_log_softmax": (_i, [_f, _f, _i, _i, _i, _i, _s]),
+    "cs_synth_fill": (_i, [_f, _l, C.c_uint64, C.c_double, C.c_double, _s]),
     "cs_abi_version": (_i, []),
 }
 

@@ -104,13 +104,14 @@ def conv_gemm(x: Tensor, w: PackedWeight, *, spatial: Optional[Tuple[int, int, i
     if c != w.cin_pad:
         raise L.CsError(f"x has {c} channels, packed weight expects {w.cin_pad}")
     kd, kh, kw = w.k
+    pointwise = kd * kh * kw == 1 and tuple(stride) == (1, 1, 1) and tuple(up) == (0, 0, 0)
     if spatial is None:
-        if kd * kh * kw == 1 and tuple(stride) == (1, 1, 1) and tuple(up) == (0, 0, 0):
+        if x.dim() == 5:
+            nb, d, h, wd = x.shape[:4]
+        elif pointwise:
             nb, d, h, wd = m, 1, 1, 1
         else:
-            if x.dim() != 5:
-                raise L.CsError("conv needs x as [nb,d,h,w,c] or an explicit spatial=")
-            nb, d, h, wd = x.shape[:4]
+            raise L.CsError("conv needs x as [nb,d,h,w,c] or an explicit spatial=")
     else:
         nb, d, h, wd = spatial
         if nb * d * h * wd != m:
@@ -122,12 +123,11 @@ def conv_gemm(x: Tensor, w: PackedWeight, *, spatial: Optional[Tuple[int, int, i
     wo = (vw + 2 * pw - kw) // stride[2] + 1
     mo = nb * do * ho * wo
     if out is None:
-        if spatial is None and x.dim() == 5:
-            out = torch.empty((nb, do, ho, wo, w.cout), dtype=torch.float32, device=x.device)
-        elif kd * kh * kw == 1 and spatial is None:
-            out = torch.empty((*x.shape[:-1], w.cout), dtype=torch.float32, device=x.device)
+        if spatial is None and x.dim() != 5:
+            oshape = (*x.shape[:-1], w.cout)
         else:
-            out = torch.empty((nb, do, ho, wo, w.cout), dtype=torch.float32, device=x.device)
+            oshape = (nb, do, ho, wo, w.cout)
+        out = torch.empty(oshape, dtype=torch.float32, device=x.device)
     _chk(out, "out")
     om, oc, ldo = rows_ld(out, "out")
     if om != mo or oc != w.cout:
@@ -369,3 +369,12 @@ def embedding(table: Tensor, idx: Tensor, out: Optional[Tensor] = None) -> Tenso
     L.check(L.load().cs_embedding(table.contiguous().data_ptr(), idx.contiguous().data_ptr(), out.data_ptr(),
                                   n, dim, n_rows, ldo, err.data_ptr(), _stream()), "cs_embedding")
     return out
+
+
+def log_softmax(x: Tensor) -> Tensor:
+    _chk(x, "x")
+    m, c, ldx = rows_ld(x, "x")
+    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    _, _, ldy = rows_ld(y, "y")
+    L.check(L.load().cs_log_softmax(x.data_ptr(), y.data_ptr(), m, c, ldx, ldy, _stream()), "cs_log_softmax")
+    return y

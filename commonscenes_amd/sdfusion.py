@@ -1,0 +1,205 @@
+"""Shape-diffusion model behind the reference's `SDFusionText2ShapeModel` interface (inference side).
+
+Mirrors model/sdfusion_txt2shape_model.py:
+  __init__ (:51-132)  builds df (DiffusionUNet), the DDPM schedule, the DDIM sampler, loads the VQ-VAE
+  register_schedule (:184-236), apply_model (:275-291), set_input (:238-256), rel2shape (:459-516)
+Like the reference's BaseModel (model/base_model.py:31) this is a plain class, not an nn.Module
+(SURVEY F11): `.df` / `.vqvae` carry their own state and are saved under 'df' / 'vqvae' keys.
+
+Extensions over the reference (SURVEY 8b "Extension the build adds"):
+  * rel2shape(..., x_T=None, mini_B=None): inject the shared initial noise (the reference seeds it from
+    time.time(), F7) and choose the sampler mini-batch (the reference hard-codes 7; objects are
+    independent, so any mini-batch gives the same per-object result -- the default here is 32).
+"""
+from __future__ import annotations
+
+import time
+from functools import partial
+from pathlib import Path
+from typing import Optional
+
+import numpy as np
+import torch
+import yaml
+
+from .ddim import DDIMSampler
+from .unet import DiffusionUNet
+from .vqvae import VQVAE, load_vqvae
+
+Tensor = torch.Tensor
+
+
+class AttrDict(dict):
+    """OmegaConf-lite: attribute access over the YAML mapping (OmegaConf is not installed here)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def to_attr(o):
+    if isinstance(o, dict):
+        return AttrDict({k: to_attr(v) for k, v in o.items()})
+    if isinstance(o, list):
+        return [to_attr(v) for v in o]
+    return o
+
+
+def load_yaml(path) -> AttrDict:
+    with open(path) as f:
+        return to_attr(yaml.safe_load(f))
+
+
+def make_beta_schedule(schedule, n_timestep, linear_start=1e-4, linear_end=2e-2, cosine_s=8e-3) -> np.ndarray:
+    """ldm_diffusion_util.py:43-65 ('linear' is what the shipped config uses)."""
+    if schedule == "linear":
+        betas = torch.linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep, dtype=torch.float64) ** 2
+    elif schedule == "sqrt_linear":
+        betas = torch.linspace(linear_start, linear_end, n_timestep, dtype=torch.float64)
+    elif schedule == "sqrt":
+        betas = torch.linspace(linear_start, linear_end, n_timestep, dtype=torch.float64) ** 0.5
+    else:
+        raise ValueError(f"schedule '{schedule}' unknown.")
+    return betas.numpy()
+
+
+class SDFusionText2ShapeModel:
+    def __init__(self, opt, resolve_dir: Optional[Path] = None):
+        """`opt`: the v2_full.yaml mapping (hyper / network / misc sections).  Relative df_cfg / vq_cfg /
+        vq_ckpt paths are resolved against `resolve_dir` (default: cwd, like the reference)."""
+        self.opt = opt if isinstance(opt, AttrDict) else to_attr(opt)
+        self.isTrain = False
+        self.model_name = self.name()
+        self.device = torch.device(self.opt.hyper.device)
+        if self.device.type != "cuda":
+            raise RuntimeError("commonscenes_amd runs on the HIP device only (hyper.device must be 'cuda')")
+        base = Path(resolve_dir) if resolve_dir else Path.cwd()
+        rp = lambda p: str(p) if Path(p).is_absolute() else str(base / p)
+        assert self.opt.network.df_cfg is not None and self.opt.network.vq_cfg is not None
+        df_conf = load_yaml(rp(self.opt.network.df_cfg))
+        vq_conf = load_yaml(rp(self.opt.network.vq_cfg))
+
+        ddconfig = vq_conf.model.params.ddconfig                       # :68-72
+        shape_res = ddconfig.resolution
+        z_ch, n_down = ddconfig.z_channels, len(ddconfig.ch_mult) - 1
+        z_sp = shape_res // (2 ** n_down)
+        self.z_shape = (z_ch, z_sp, z_sp, z_sp)
+
+        self.df = DiffusionUNet(df_conf.unet.params, vq_conf=vq_conf,
+                                conditioning_key=df_conf.model.params.conditioning_key, device=self.device)
+        self.init_diffusion_params(uc_scale=3., df_model_params=df_conf.model.params)
+        self.ddim_sampler = DDIMSampler(self)
+        ck = self.opt.network.get("vq_ckpt")
+        if ck is not None and Path(rp(ck)).exists():
+            self.vqvae = load_vqvae(vq_conf, rp(ck), device=str(self.device))
+        else:   # weights to be supplied through load_state_dict (e.g. a full checkpoint's 'vqvae' entry)
+            mp = vq_conf.model.params
+            self.vqvae = VQVAE(mp.ddconfig, mp.n_embed, mp.embed_dim, device=self.device)
+        self.df_module = self.df
+        self.vqvae_module = self.vqvae
+        self.ddim_steps = 100                                           # :128 (hard-coded in the reference)
+        self.mini_B = 32
+
+    def name(self):
+        return "SDFusion-Text2Shape-Model"
+
+    # ---- schedule (:152-236) ----
+    def init_diffusion_params(self, uc_scale=3., df_model_params=None):
+        self.parameterization = "eps"
+        self.register_schedule(timesteps=df_model_params.timesteps, linear_start=df_model_params.linear_start,
+                               linear_end=df_model_params.linear_end)
+        self.uc_scale = uc_scale
+        self.scale = uc_scale     # the reference reads an undefined self.scale when uc_scale=None (:474)
+
+    def register_schedule(self, beta_schedule="linear", timesteps=1000, linear_start=1e-4, linear_end=2e-2):
+        betas = make_beta_schedule(beta_schedule, timesteps, linear_start=linear_start, linear_end=linear_end)
+        alphas = 1. - betas
+        alphas_cumprod = np.cumprod(alphas, axis=0)
+        alphas_cumprod_prev = np.append(1., alphas_cumprod[:-1])
+        self.num_timesteps = int(betas.shape[0])
+        self.linear_start, self.linear_end = linear_start, linear_end
+        to_torch = partial(torch.tensor, dtype=torch.float32)
+        # kept on the host: the sampler only ever indexes them from Python (ddim.py:31-57)
+        self.betas = to_torch(betas)
+        self.alphas_cumprod = to_torch(alphas_cumprod)
+        self.alphas_cumprod_prev = to_torch(alphas_cumprod_prev)
+        self.sqrt_alphas_cumprod = to_torch(np.sqrt(alphas_cumprod))
+        self.sqrt_one_minus_alphas_cumprod = to_torch(np.sqrt(1. - alphas_cumprod))
+
+    # ---- reference surface ----
+    def set_input(self, input=None, max_sample=None):
+        self.x = input["sdf"]
+        self.rel = input["rel"]
+        self.uc_rel = input["uc"]
+        if max_sample is not None:
+            self.x, self.rel, self.uc_rel = self.x[:max_sample], self.rel[:max_sample], self.uc_rel[:max_sample]
+
+    def switch_eval(self):
+        self.df.eval()
+        self.vqvae.eval()
+
+    def switch_train(self):
+        raise NotImplementedError("training is out of scope (SURVEY 3.4)")
+
+    def apply_model(self, x_noisy, t, cond, return_ids=False):
+        """:275-291"""
+        if isinstance(cond, dict):
+            return self.df(x_noisy, t, **cond)
+        if not isinstance(cond, list):
+            cond = [cond]
+        key = "c_concat" if self.df_module.conditioning_key == "concat" else "c_crossattn"
+        return self.df(x_noisy, t, **{key: cond})
+
+    @torch.no_grad()
+    def rel2shape(self, data, ddim_steps=100, ddim_eta=0.0, uc_scale=None, x_T: Optional[Tensor] = None,
+                  mini_B: Optional[int] = None, return_latents: bool = False, max_steps: Optional[int] = None):
+        """:459-516.  data = {'sdf': (B,...) only its batch size is used, 'rel': (B,1,1280), 'uc': (B,1,1280)}."""
+        self.switch_eval()
+        self.set_input(data)
+        ddim_sampler = DDIMSampler(self)
+        if ddim_steps is None:
+            ddim_steps = self.ddim_steps
+        if uc_scale is None:
+            uc_scale = self.scale
+        uc = self.uc_rel.to(device=self.device, dtype=torch.float32)
+        c_text = self.rel.to(device=self.device, dtype=torch.float32)
+        B = c_text.shape[0]
+        shape = self.z_shape
+        C_, D, H, W = shape
+        if x_T is None:
+            torch.manual_seed(int(time.time()))                          # :489 (time-seeded in the reference)
+            single_noise = torch.randn((1, C_, D, H, W), device=self.device)
+        else:
+            single_noise = x_T.to(device=self.device, dtype=torch.float32).reshape(1, C_, D, H, W)
+        noise = single_noise.repeat(B, 1, 1, 1, 1)                       # every object shares one x_T (:491)
+        mb = int(mini_B or self.mini_B)
+        gen, lats = [], []
+        for i in range(int(np.ceil(B / mb))):
+            sl = slice(i * mb, (i + 1) * mb)
+            num = c_text[sl].shape[0]
+            samples, _ = ddim_sampler.sample(S=ddim_steps, batch_size=num, shape=shape, conditioning=c_text[sl],
+                                             x_T=noise[sl], verbose=False,
+                                             unconditional_guidance_scale=uc_scale,
+                                             unconditional_conditioning=uc[sl], eta=ddim_eta, max_steps=max_steps)
+            lats.append(samples)
+            gen.append(self.vqvae_module.decode_no_quant(samples))
+        self.gen_df = torch.cat(gen, dim=0)
+        if return_latents:
+            return self.gen_df, torch.cat(lats, dim=0)
+        return self.gen_df
+
+    # ---- checkpoint surface (VAEGAN_V2FULL.py:687-699 stores these under 'df' / 'vqvae') ----
+    def state_dict(self):
+        return {"df": self.df.state_dict(), "vqvae": self.vqvae.state_dict()}
+
+    def load_state_dict(self, sd):
+        if "df" in sd:
+            self.df.load_state_dict(sd["df"])
+        if "vqvae" in sd:
+            self.vqvae.load_state_dict(sd["vqvae"])
+        return self

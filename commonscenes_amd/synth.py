@@ -55,36 +55,61 @@ def _fan_in(shape: Tuple[int, ...]) -> int:
     return max(f, 1)
 
 
-def synth_state_dict(shapes: "Dict[str, Tuple[int, ...]]", seed: int = 111, gain: float = 3.0 ** 0.5
-                     ) -> "OrderedDict[str, torch.Tensor]":
+def _entry_params(name: str, shape, shapes, gain: float):
+    """(scale, offset) of the uniform law for one state_dict entry; None for integer bookkeeping entries."""
+    leaf = name.rsplit(".", 1)[-1]
+    if leaf == "num_batches_tracked":
+        return None
+    if leaf == "running_mean":
+        return 0.2, 0.0
+    if leaf == "running_var":
+        return 0.5, 1.0
+    if "embedding" in name and leaf == "weight" and len(shape) == 2 and "quantize" in name:
+        return 1.5, 0.0                                   # VQ codebook spread over the latent range
+    if "embeddings" in name and leaf == "weight":
+        return 1.0, 0.0
+    if leaf == "weight" and len(shape) == 1:
+        return 0.2, 1.0                                   # norm scale
+    if leaf == "bias" and (".norm" in name or "in_layers.0" in name or "out_layers.0" in name
+                           or name.endswith("out.0.bias") or _is_bn(name, shapes)):
+        return 0.1, 0.0                                   # norm shift
+    if leaf == "weight":
+        return float(gain / np.sqrt(_fan_in(shape))), 0.0
+    if leaf == "bias":
+        wshape = shapes.get(name[:-4] + "weight", (shape[0], 1))
+        return float(1.0 / np.sqrt(_fan_in(wshape))), 0.0
+    return 1.0, 0.0
+
+
+def tensor_device(name: str, shape: Tuple[int, ...], scale: float = 1.0, offset: float = 0.0, seed: int = 111,
+                  device="cuda") -> torch.Tensor:
+    """Same values as `tensor`, generated on the HIP device by cs_synth_fill (bit-identical)."""
+    import ctypes as C
+    from . import lib as L
+    n = int(np.prod(shape)) if len(shape) else 1
+    out = torch.empty(shape, dtype=torch.float32, device=device)
+    base = (_fnv1a(name) ^ (seed * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L.check(L.load().cs_synth_fill(out.data_ptr(), n, base, float(scale), float(offset), stream), "cs_synth_fill")
+    return out
+
+
+def synth_state_dict(shapes: "Dict[str, Tuple[int, ...]]", seed: int = 111, gain: float = 3.0 ** 0.5,
+                     device: str = "cpu") -> "OrderedDict[str, torch.Tensor]":
     """Weights for a {name: shape} table.  Conv/Linear weights ~ U(-a, a) with a = gain/sqrt(fan_in)
     (variance preserving), biases ~ U(-1, 1)/sqrt(fan_in) of their layer, norm scales 1 + 0.2u,
-    norm biases 0.1u, BatchNorm running_mean 0.2u, running_var 1 + 0.5u, embeddings U(-1, 1)."""
+    norm biases 0.1u, BatchNorm running_mean 0.2u, running_var 1 + 0.5u, embeddings U(-1, 1).
+    device='cuda' generates the identical values with the cs_synth_fill kernel."""
     sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    on_dev = str(device).startswith("cuda")
     for name, shape in shapes.items():
-        leaf = name.rsplit(".", 1)[-1]
-        if leaf == "num_batches_tracked":
+        pr = _entry_params(name, shape, shapes, gain)
+        if pr is None:
             sd[name] = torch.tensor(1, dtype=torch.long)
-        elif leaf == "running_mean":
-            sd[name] = tensor(name, shape, 0.2, 0.0, seed)
-        elif leaf == "running_var":
-            sd[name] = tensor(name, shape, 0.5, 1.0, seed)
-        elif "embedding" in name and leaf == "weight" and len(shape) == 2 and "quantize" in name:
-            sd[name] = tensor(name, shape, 1.5, 0.0, seed)          # VQ codebook spread over the latent range
-        elif "embeddings" in name and leaf == "weight":
-            sd[name] = tensor(name, shape, 1.0, 0.0, seed)
-        elif leaf == "weight" and len(shape) == 1:
-            sd[name] = tensor(name, shape, 0.2, 1.0, seed)           # norm scale
-        elif leaf == "bias" and (".norm" in name or "in_layers.0" in name or "out_layers.0" in name
-                                 or name.endswith("out.0.bias") or _is_bn(name, shapes)):
-            sd[name] = tensor(name, shape, 0.1, 0.0, seed)           # norm shift
-        elif leaf == "weight":
-            sd[name] = tensor(name, shape, gain / np.sqrt(_fan_in(shape)), 0.0, seed)
-        elif leaf == "bias":
-            wshape = shapes.get(name[:-4] + "weight", (shape[0], 1))
-            sd[name] = tensor(name, shape, 1.0 / np.sqrt(_fan_in(wshape)), 0.0, seed)
+        elif on_dev:
+            sd[name] = tensor_device(name, tuple(shape), pr[0], pr[1], seed, device)
         else:
-            sd[name] = tensor(name, shape, 1.0, 0.0, seed)
+            sd[name] = tensor(name, tuple(shape), pr[0], pr[1], seed)
     return sd
 
 

@@ -176,6 +176,7 @@ class DiffusionUNet:
         self._packed = None
         self.training = False
         self.math = L.MATH_FP32
+        self.trace: Optional[Dict[str, Tensor]] = None   # set to {} to capture per-block outputs (tests)
 
     # ---- nn.Module-like surface -----------------------------------------------------------
     def state_dict(self) -> "OrderedDict[str, Tensor]":
@@ -356,13 +357,20 @@ class DiffusionUNet:
         # every consumer of `emb` is emb_layers = SiLU -> Linear (openai_model_3d.py:257-263): keep SiLU(emb)
         semb = ops.linear(e1, pk[P + "time_embed.2"], act=L.ACT_SILU, math=self.math)
         hs: List[Tensor] = []
+        tr = self.trace
         for i, layers in enumerate(inp):
             h = self._run(f"{P}input_blocks.{i}", layers, h, semb, ctx)
             hs.append(h)
+            if tr is not None:
+                tr[f"input_blocks.{i}"] = h
         h = self._run(P + "middle_block", mid, h, semb, ctx)
+        if tr is not None:
+            tr["middle_block"] = h
         for i, layers in enumerate(out):
             h = ops.concat_channels(h, hs.pop())
             h = self._run(f"{P}output_blocks.{i}", layers, h, semb, ctx)
+            if tr is not None:
+                tr[f"output_blocks.{i}"] = h
         hn = ops.groupnorm(h, sd[P + "out.0.weight"], sd[P + "out.0.bias"], 32, 1e-5, L.ACT_SILU)
         return ops.conv_gemm(hn, pk[P + "out.2"], math=self.math)
 

@@ -193,6 +193,18 @@ int cs_gcn_segment_mean(const float* new_t, const int64_t* edges, float* pooled,
 int cs_embedding(const float* table, const int64_t* idx, float* out, int n, int dim, int n_rows,
                  int ldo, int32_t* err, cs_stream_t stream);
 
+/* Row-wise log_softmax over [m][c] (F.log_softmax(angle_net(...), dim=1), VAEGAN_V2FULL.py:286). */
+int cs_log_softmax(const float* x, float* y, int m, int c, int ldx, int ldy, cs_stream_t stream);
+
+/*
+ * Deterministic synthetic tensor fill (benchmarks / parity tests; no checkpoints are reachable offline):
+ *   z = splitmix64(base + i * 0x9E3779B97F4A7C15);  k = z >> 40;
+ *   out[i] = (float)( (double)(2k - 2^24) / 2^24 * scale + offset )
+ * bit-identical to commonscenes_amd/synth.py::tensor (integer ops exact, two correctly-rounded fp64 ops,
+ * one fp64->fp32 rounding).
+ */
+int cs_synth_fill(float* out, int64_t n, uint64_t base, double scale, double offset, cs_stream_t stream);
+
 /* Library / device self-description. */
 int cs_abi_version(void);
 

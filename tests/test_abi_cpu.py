@@ -1,0 +1,101 @@
+"""CPU suite: the C-ABI library builds, loads and exports every symbol include/commonscenes_hip.h declares
+(no compute calls without a GPU), and the host-side plumbing behaves."""
+import ctypes
+import re
+from pathlib import Path
+
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _header_symbols():
+    txt = (ROOT / "include" / "commonscenes_hip.h").read_text()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(cs_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    from commonscenes_amd import build, lib
+    path = build.build_native(verbose=False)
+    assert path.exists()
+    dll = lib.load()
+    syms = _header_symbols()
+    assert len(syms) >= 24
+    for s in syms:
+        assert hasattr(dll, s), f"{s} declared in the header but not exported"
+        assert s in lib.SIGNATURES, f"{s} has no ctypes signature"
+    assert set(lib.SIGNATURES) == set(syms)
+    assert dll.cs_abi_version() == 1
+
+
+def test_struct_layout_matches_header():
+    """field order/count of the ctypes mirror vs the C struct text."""
+    from commonscenes_amd import lib
+    txt = (ROOT / "include" / "commonscenes_hip.h").read_text()
+    body = txt[txt.index("typedef struct CsConvGemm {"):txt.index("} CsConvGemm;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for line in body.splitlines()[1:]:
+        line = line.strip().rstrip(";")
+        if not line:
+            continue
+        decl = line.split(None, 2) if line.startswith("const") else line.split(None, 1)
+        for n in decl[-1].split(","):
+            names.append(n.strip().lstrip("*").strip())
+    assert names == [f[0] for f in lib.CsConvGemm._fields_]
+    assert ctypes.sizeof(lib.CsConvGemm) == 8 * 8 + 30 * 4
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from commonscenes_amd import lib
+    with pytest.raises(lib.NativeLibraryMissing):
+        lib.load(tmp_path / "nope.so")
+
+
+def test_ops_refuse_cpu_tensors():
+    from commonscenes_amd import lib, ops
+    with pytest.raises(lib.CsError):
+        ops.layernorm(torch.zeros(4, 8), torch.ones(8), torch.zeros(8))
+    with pytest.raises(lib.CsError):
+        ops.geglu(torch.zeros(4, 8))
+
+
+def test_rows_ld_views():
+    from commonscenes_amd import lib, ops
+    t = torch.zeros(2, 3, 4, 5, 24)
+    assert ops.rows_ld(t) == (120, 24, 24)
+    assert ops.rows_ld(t[..., 4:12]) == (120, 8, 24)
+    assert ops.rows_ld(torch.zeros(7, 1, 16)) == (7, 16, 16)
+    assert ops.rows_ld(torch.zeros(16)) == (1, 16, 16)
+    with pytest.raises(lib.CsError):
+        ops.rows_ld(t.permute(0, 4, 1, 2, 3))
+    with pytest.raises(lib.CsError):
+        ops.rows_ld(t[:, ::2])
+
+
+def test_unet_param_table_matches_reference_counts():
+    """413,540,739 parameters in 496 tensors."""
+    import numpy as np
+    from commonscenes_amd.unet import unet_param_shapes, unet_blocks, _cfg
+    from oracle.ref_torch import UNET_FULL
+    cfg = dict(UNET_FULL, dims=3, use_spatial_transformer=True)
+    s = unet_param_shapes(cfg)
+    assert len(s) == 496
+    assert sum(int(np.prod(v)) for v in s.values()) == 413_540_739
+    inp, mid, out, ch = unet_blocks(_cfg(cfg))
+    assert len(inp) == 9 and len(out) == 9 and ch == 224
+    assert [l["cin"] for b in out for l in b if l["kind"] == "res"] == [1344, 1344, 1120, 1120, 896, 672, 672, 448, 448]
+
+
+def test_unsupported_configs_raise():
+    from commonscenes_amd.unet import DiffusionUNet
+    from oracle.ref_torch import UNET_SMALL
+    with pytest.raises(NotImplementedError):
+        DiffusionUNet(dict(UNET_SMALL, dims=4, use_spatial_transformer=False), conditioning_key="concat",
+                      device="cpu")
+    df = DiffusionUNet(dict(UNET_SMALL, dims=3, use_spatial_transformer=True), conditioning_key="concat",
+                       device="cpu")
+    with pytest.raises(NotImplementedError):
+        df(torch.zeros(1, 3, 16, 16, 16), torch.zeros(1, dtype=torch.long), c_concat=[torch.zeros(1)])

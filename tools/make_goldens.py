@@ -1,0 +1,441 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by importing the REFERENCE (read-only, /root/reference) on CPU.
+
+Runs only in the build container (the reference never travels to the GPU box).  Follows the
+harness recipe of SURVEY.md Appendix B: stub absent third-party modules, apply three harness-side
+monkeypatches (reference files untouched), load deterministic synthetic weights
+(commonscenes_amd/synth.py) into the reference modules with their own load_state_dict, run, and
+dump small input/output fixtures.  The fixtures are DATA (inputs + expected outputs); nothing of
+the reference's source is copied.
+
+    python tools/make_goldens.py [--only NAME ...]
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import tempfile
+import time
+import types
+from pathlib import Path
+from unittest import mock
+
+import numpy as np
+import torch
+import yaml
+
+ROOT = Path(__file__).resolve().parent.parent
+REF = Path("/root/reference")
+OUT = ROOT / "tests" / "golden"
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(REF))
+
+from commonscenes_amd import synth                       # noqa: E402
+from commonscenes_amd.unet import unet_param_shapes      # noqa: E402
+
+torch.set_num_threads(8)
+torch.manual_seed(0)
+
+
+# ---------------------------------------------------------------------------------------------
+# harness: stubs + patches (App. B steps 2-3)
+# ---------------------------------------------------------------------------------------------
+class _AttrDict(dict):
+    def __getattr__(self, k):
+        try:
+            v = self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+        return v
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def _wrap(o):
+    if isinstance(o, dict):
+        return _AttrDict({k: _wrap(v) for k, v in o.items()})
+    if isinstance(o, list):
+        return _ListConfig(_wrap(v) for v in o)
+    return o
+
+
+class _ListConfig(list):
+    pass
+
+
+def install_stubs():
+    for name in ["cv2", "mcubes", "termcolor", "torchvision", "torchvision.utils", "torchvision.transforms",
+                 "fvcore", "fvcore.common", "fvcore.common.param_scheduler", "pytorch3d", "pytorch3d.io",
+                 "pytorch3d.structures", "pytorch3d.renderer", "pytorch3d.transforms", "pytorch3d.ops",
+                 "trimesh", "h5py", "imageio", "skimage", "skimage.measure", "open3d", "tensorboardX", "clip"]:
+        if name not in sys.modules:
+            m = mock.MagicMock(name=name)
+            m.__path__ = []
+            sys.modules[name] = m
+    sys.modules["termcolor"].colored = lambda s, *a, **k: s
+    sys.modules["termcolor"].cprint = lambda *a, **k: None
+    oc = types.ModuleType("omegaconf")
+
+    class OmegaConf:
+        @staticmethod
+        def load(path):
+            with open(path) as f:
+                return _wrap(yaml.safe_load(f))
+    oc.OmegaConf = OmegaConf
+    lc = types.ModuleType("omegaconf.listconfig")
+    lc.ListConfig = _ListConfig
+    oc.listconfig = lc
+    sys.modules["omegaconf"] = oc
+    sys.modules["omegaconf.listconfig"] = lc
+
+
+def install_patches():
+    from model.networks.diffusion_networks.samplers import ddim as ddim_mod
+    ddim_mod.DDIMSampler.register_buffer = lambda self, n, a: setattr(self, n, a)   # F10
+    ddim_mod.tqdm = lambda it, **k: it
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    _randn = torch.randn
+
+    def randn(*a, **k):
+        if "device" in k and str(k["device"]).startswith("cuda"):
+            k["device"] = "cpu"
+        shape = a[0] if len(a) == 1 and isinstance(a[0], (tuple, list, torch.Size)) else a
+        if INJECT.get("x_T") is not None and tuple(shape) == tuple(INJECT["x_T"].shape):
+            return INJECT["x_T"].clone()
+        return _randn(*a, **k)
+    torch.randn = randn
+    import model.sdfusion_txt2shape_model as m
+    m.init_mesh_renderer = lambda **k: None
+
+
+INJECT: dict = {}
+
+
+def save(name: str, **arrs):
+    OUT.mkdir(parents=True, exist_ok=True)
+    conv = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        conv[k] = v
+    np.savez_compressed(OUT / f"{name}.npz", **conv)
+    sz = (OUT / f"{name}.npz").stat().st_size / 1e6
+    print(f"[golden] {name}.npz  {sz:.2f} MB  keys={list(conv)}", flush=True)
+
+
+# ---------------------------------------------------------------------------------------------
+# configs
+# ---------------------------------------------------------------------------------------------
+def unet_params(small: bool):
+    with open(REF / "config" / "sdfusion-txt2shape.yaml") as f:
+        y = yaml.safe_load(f)
+    p = dict(y["unet"]["params"])
+    if small:
+        p["model_channels"] = 32
+    p["use_checkpoint"] = False
+    return p
+
+
+def build_ref_unet(small: bool):
+    from model.networks.diffusion_networks.network import DiffusionUNet
+    p = unet_params(small)
+    df = DiffusionUNet(_wrap(p), conditioning_key="crossattn").eval()
+    shapes = unet_param_shapes(p)
+    ref_shapes = {k: tuple(v.shape) for k, v in df.state_dict().items()}
+    assert ref_shapes == dict(shapes), "unet_param_shapes disagrees with the reference state_dict"
+    sd = synth.synth_state_dict(shapes)
+    df.load_state_dict(sd, strict=True)
+    return df, p, sd
+
+
+def vq_conf():
+    with open(REF / "config" / "vqvae_snet.yaml") as f:
+        return _wrap(yaml.safe_load(f))
+
+
+def build_ref_vqvae():
+    from model.networks.vqvae_networks.network import VQVAE
+    from commonscenes_amd.vqvae import vqvae_param_shapes
+    mp = vq_conf().model.params
+    vq = VQVAE(mp.ddconfig, mp.n_embed, mp.embed_dim).eval()
+    shapes = vqvae_param_shapes(dict(mp.ddconfig), mp.n_embed, mp.embed_dim)
+    ref_shapes = {k: tuple(v.shape) for k, v in vq.state_dict().items()}
+    sub = {k: ref_shapes[k] for k in shapes}
+    assert sub == dict(shapes), "vqvae_param_shapes disagrees with the reference state_dict"
+    sd = synth.synth_state_dict(shapes)
+    missing, unexpected = vq.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.startswith(("encoder.", "quant_conv.")) for k in missing), missing
+    return vq, sd
+
+
+# ---------------------------------------------------------------------------------------------
+# fixtures
+# ---------------------------------------------------------------------------------------------
+def g_schedule():
+    from model.networks.diffusion_networks.ldm_diffusion_util import (make_beta_schedule, make_ddim_timesteps,
+                                                                       make_ddim_sampling_parameters)
+    from model.networks.diffusion_networks.samplers.ddim import DDIMSampler
+    betas = make_beta_schedule("linear", 1000, linear_start=0.00085, linear_end=0.012)
+    alphas_cumprod = np.cumprod(1.0 - betas, axis=0)
+
+    class M:
+        num_timesteps = 1000
+        device = "cpu"
+    m = M()
+    m.betas = torch.tensor(betas, dtype=torch.float32)
+    m.alphas_cumprod = torch.tensor(alphas_cumprod, dtype=torch.float32)
+    m.alphas_cumprod_prev = torch.tensor(np.append(1.0, alphas_cumprod[:-1]), dtype=torch.float32)
+    out = dict(betas=m.betas, alphas_cumprod=m.alphas_cumprod)
+    for S in (50, 100):
+        s = DDIMSampler(m)
+        s.make_schedule(S, ddim_eta=0.0, verbose=False)
+        out[f"timesteps_{S}"] = np.asarray(s.ddim_timesteps)
+        out[f"alphas_{S}"] = np.asarray(s.ddim_alphas, dtype=np.float64)
+        out[f"alphas_prev_{S}"] = np.asarray(s.ddim_alphas_prev, dtype=np.float64)
+        out[f"sigmas_{S}"] = np.asarray(s.ddim_sigmas, dtype=np.float64)
+        out[f"sqrt_one_minus_alphas_{S}"] = np.asarray(s.ddim_sqrt_one_minus_alphas, dtype=np.float64)
+    save("schedule", **out)
+
+
+def _unet_inputs(B, tag):
+    x = synth.gaussian_like(f"{tag}:x", (B, 3, 16, 16, 16))
+    ctx = synth.gaussian_like(f"{tag}:ctx", (B, 1, 1280))
+    return x, ctx
+
+
+def g_unet(small: bool):
+    name = "unet_small" if small else "unet_full"
+    df, p, sd = build_ref_unet(small)
+    x, ctx = _unet_inputs(2, name)
+    t = torch.tensor([981, 11], dtype=torch.long)
+    hooks = {}
+    if small:
+        net = df.diffusion_net
+        watch = {"input_blocks.1": net.input_blocks[1], "input_blocks.3": net.input_blocks[3],
+                 "input_blocks.4": net.input_blocks[4], "middle_block": net.middle_block,
+                 "output_blocks.2": net.output_blocks[2], "output_blocks.8": net.output_blocks[8]}
+        hs = [m.register_forward_hook(lambda mod, i, o, k=k: hooks.__setitem__(k, o.detach().clone()))
+              for k, m in watch.items()]
+    t0 = time.time()
+    with torch.no_grad():
+        y = df(x, t, c_crossattn=[ctx])
+    print(f"[{name}] reference forward {time.time() - t0:.1f}s  out rms {y.pow(2).mean().sqrt():.4f}")
+    arrs = dict(x=x, t=t, ctx=ctx, eps=y)
+    for k, v in hooks.items():
+        arrs["hook:" + k] = v
+    save(name, **arrs)
+
+
+def _ref_model_for_sampler(df):
+    """A minimal stand-in for SDFusionText2ShapeModel exposing what DDIMSampler reads
+    (ddim.py:16-20,31-37,134,188), with the reference's own schedule code."""
+    from model.networks.diffusion_networks.ldm_diffusion_util import make_beta_schedule
+    betas = make_beta_schedule("linear", 1000, linear_start=0.00085, linear_end=0.012)
+    ac = np.cumprod(1.0 - betas, axis=0)
+
+    class M:
+        num_timesteps = 1000
+        device = "cpu"
+
+        def apply_model(self, x, t, c):
+            return df(x, t, c_crossattn=[c])
+    m = M()
+    m.betas = torch.tensor(betas, dtype=torch.float32)
+    m.alphas_cumprod = torch.tensor(ac, dtype=torch.float32)
+    m.alphas_cumprod_prev = torch.tensor(np.append(1.0, ac[:-1]), dtype=torch.float32)
+    return m
+
+
+def g_ddim(small: bool):
+    """k-step CFG DDIM trajectories through the reference DDIMSampler (ddim.py:60-244)."""
+    from model.networks.diffusion_networks.samplers.ddim import DDIMSampler
+    name = "ddim_small" if small else "ddim_full"
+    df, p, sd = build_ref_unet(small)
+    m = _ref_model_for_sampler(df)
+    B = 2 if small else 1
+    S, k = (50, 3) if small else (50, 2)
+    x_T = synth.gaussian_like(f"{name}:xT", (1, 3, 16, 16, 16)).repeat(B, 1, 1, 1, 1)
+    c = synth.gaussian_like(f"{name}:c", (B, 1, 1280))
+    uc = synth.gaussian_like(f"{name}:uc", (B, 1, 1280))
+    sampler = DDIMSampler(m)
+    sampler.make_schedule(S, ddim_eta=0.0, verbose=False)
+    # truncate the loop after k steps: run ddim_sampling manually over the first k flipped timesteps
+    img = x_T
+    xs, p0s = [], []
+    ts = np.flip(sampler.ddim_timesteps)
+    t0 = time.time()
+    for i in range(k):
+        index = S - i - 1
+        tt = torch.full((B,), int(ts[i]), dtype=torch.long)
+        img, pred = sampler.p_sample_ddim(img, c, tt, index=index, unconditional_guidance_scale=3.0,
+                                          unconditional_conditioning=uc)
+        xs.append(img.clone())
+        p0s.append(pred.clone())
+    print(f"[{name}] {k} reference DDIM steps {time.time() - t0:.1f}s")
+    save(name, x_T=x_T, c=c, uc=uc, S=np.int64(S), steps=np.int64(k), scale=np.float32(3.0),
+         x=torch.stack(xs), pred_x0=torch.stack(p0s))
+
+
+def g_vq():
+    vq, sd = build_ref_vqvae()
+    h = synth.gaussian_like("vq:latent", (1, 3, 16, 16, 16), scale=0.8)
+    with torch.no_grad():
+        quant, _, info = vq.quantize(h, is_voxel=True)
+        t0 = time.time()
+        dec = vq.decode_no_quant(h)
+        print(f"[vq] reference decode_no_quant {time.time() - t0:.1f}s")
+        dec_nq = vq.decode_no_quant(h[:, :, :8, :8, :8].contiguous(), force_not_quantize=True)
+        dec_q = vq.decode(quant)
+    assert torch.equal(dec, dec_q)
+    save("vq_decode", latent=h, indices=info[2], quant=quant, dec=dec,
+         latent_nq=h[:, :, :8, :8, :8].contiguous(), dec_nq=dec_nq)
+
+
+def _scene_yaml(tmp: Path, small: bool, vq_ckpt: Path) -> Path:
+    with open(REF / "config" / "v2_full.yaml") as f:
+        y = yaml.safe_load(f)
+    y["hyper"]["device"] = "cpu"
+    y["hyper"]["logs_dir"] = str(tmp / "logs")
+    y["hyper"]["results_dir"] = str(tmp / "logs")
+    df_yaml = REF / "config" / "sdfusion-txt2shape.yaml"
+    if small:
+        with open(df_yaml) as f:
+            d = yaml.safe_load(f)
+        d["unet"]["params"]["model_channels"] = 32
+        d["unet"]["params"]["use_checkpoint"] = False
+        df_yaml = tmp / "df_small.yaml"
+        with open(df_yaml, "w") as f:
+            yaml.safe_dump(d, f)
+    y["network"]["df_cfg"] = str(df_yaml)
+    y["network"]["vq_cfg"] = str(REF / "config" / "vqvae_snet.yaml")
+    y["network"]["vq_ckpt"] = str(vq_ckpt)
+    out = tmp / "v2_full_cpu.yaml"
+    with open(out, "w") as f:
+        yaml.safe_dump(y, f)
+    return out
+
+
+def build_ref_scene(tmp: Path, small: bool = True):
+    """Construct the reference Sg2ScVAEModel the way eval does (model/VAE.py:60-62), App. B step 5."""
+    from model.VAEGAN_V2FULL import Sg2ScVAEModel
+    from commonscenes_amd.scene import scene_param_shapes
+    vq, vq_sd = build_ref_vqvae()
+    ck = tmp / "vq_synth.pth"
+    torch.save(vq.state_dict(), ck)
+    n_obj_cls, n_pred = 35, 16
+    vocab = dict(object_idx_to_name=[f"obj{i}\n" for i in range(n_obj_cls)],
+                 pred_idx_to_name=[f"pred{i}\n" for i in range(n_pred)],
+                 object_idx_to_name_grained=[f"objg{i}\n" for i in range(n_obj_cls)])
+    cwd = os.getcwd()
+    os.chdir(tmp)
+    try:
+        model = Sg2ScVAEModel(vocab, str(_scene_yaml(tmp, small, ck)), diffusion_bs=16, embedding_dim=64,
+                              decoder_cat=True, mlp_normalization="batch", gconv_num_layers=5, use_angles=True,
+                              distribution_before=True, use_E2=True, replace_latent=True, num_box_params=6,
+                              residual=True, clip=True).eval()
+    finally:
+        os.chdir(cwd)
+    shapes = scene_param_shapes(n_obj_cls, n_pred)
+    ref_shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sub = {k: ref_shapes[k] for k in shapes}
+    assert sub == dict(shapes), "scene_param_shapes disagrees with the reference state_dict"
+    sd = synth.synth_state_dict(shapes)
+    model.load_state_dict(sd, strict=False)
+    p = unet_params(small)
+    df_sd = synth.synth_state_dict(unet_param_shapes(p))
+    model.Diff.df.load_state_dict(df_sd, strict=True)
+    model.Diff.df.eval()
+    return model, sd, df_sd, vq_sd
+
+
+def g_gcn(tmp: Path):
+    model, sd, _, _ = build_ref_scene(tmp, small=True)
+    g = synth.random_scene_graph(6, seed=7)
+    with torch.no_grad():
+        uc, c = model.encoder_2(g["z"], g["objs"], g["triples"], g["text_feats"], g["rel_feats"], None)
+    save("gcn_encoder2", objs=g["objs"], triples=g["triples"], text_feats=g["text_feats"],
+         rel_feats=g["rel_feats"], z=g["z"], uc=uc, c=c)
+
+
+def g_e2e(tmp: Path):
+    """Sg2ScVAEModel.sample(gen_shape=True) end to end (VAEGAN_V2FULL.py:600-618), reduced-width UNet,
+    8 shaped objects (mini-batch boundary at 7), 2 DDIM steps."""
+    import functools
+    model, sd, df_sd, vq_sd = build_ref_scene(tmp, small=True)
+    nobj = 8
+    g = synth.random_scene_graph(nobj, seed=11)
+    O = g["objs"].shape[0]
+    dec_sdfs = torch.zeros(O, 1, 4, 4, 4)
+    dec_sdfs[:nobj] = 1.0                       # floor and _scene_ carry all-zero SDFs (dropped by the mask)
+    x_T = synth.gaussian_like("e2e:xT", (1, 3, 16, 16, 16))
+    INJECT["x_T"] = x_T
+    rec = {}
+    enc2 = model.encoder_2
+
+    def enc2_rec(z, *a, **k):
+        rec["z"] = z.detach().clone()
+        r = enc2(z, *a, **k)
+        rec["uc"], rec["c"] = r[0].detach().clone(), r[1].detach().clone()
+        return r
+    model.encoder_2 = enc2_rec
+    model.Diff.rel2shape = functools.partial(model.Diff.rel2shape, ddim_steps=2)
+    lat = []
+    dnq = model.Diff.vqvae_module.decode_no_quant
+
+    def dnq_rec(h, *a, **k):
+        lat.append(h.detach().clone())
+        return dnq(h, *a, **k)
+    model.Diff.vqvae_module.decode_no_quant = dnq_rec
+    np.random.seed(111)
+    t0 = time.time()
+    with torch.no_grad():
+        boxes, gen_sdf = model.sample(None, np.zeros(64), np.eye(64), g["objs"], g["triples"], dec_sdfs,
+                                      g["text_feats"], g["rel_feats"], attributes=None, gen_shape=True)
+    print(f"[e2e] reference sample() {time.time() - t0:.1f}s  gen_sdf {tuple(gen_sdf.shape)}")
+    INJECT["x_T"] = None
+    arrs = dict(objs=g["objs"], triples=g["triples"], text_feats=g["text_feats"], rel_feats=g["rel_feats"],
+                dec_sdfs_nonzero=(dec_sdfs.flatten(1).abs().sum(1) > 0), z=rec["z"], uc=rec["uc"], c=rec["c"],
+                x_T=x_T, latents=torch.cat(lat, 0), gen_sdf_sub=gen_sdf[:, :, ::2, ::2, ::2].contiguous(),
+                gen_sdf_obj7=gen_sdf[7])
+    if isinstance(boxes, tuple):
+        arrs["boxes"], arrs["angles"] = boxes[0], boxes[1]
+    else:
+        arrs["boxes"] = boxes
+    save("e2e_small", **arrs)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", nargs="*", default=None)
+    a = ap.parse_args()
+    install_stubs()
+    install_patches()
+    todo = a.only or ["schedule", "unet_small", "unet_full", "ddim_small", "ddim_full", "vq", "gcn", "e2e"]
+    with tempfile.TemporaryDirectory() as td:
+        tmp = Path(td)
+        for name in todo:
+            print(f"=== {name}", flush=True)
+            if name == "schedule":
+                g_schedule()
+            elif name == "unet_small":
+                g_unet(True)
+            elif name == "unet_full":
+                g_unet(False)
+            elif name == "ddim_small":
+                g_ddim(True)
+            elif name == "ddim_full":
+                g_ddim(False)
+            elif name == "vq":
+                g_vq()
+            elif name == "gcn":
+                g_gcn(tmp)
+            elif name == "e2e":
+                g_e2e(tmp)
+            else:
+                raise SystemExit(f"unknown fixture {name}")
+
+
+if __name__ == "__main__":
+    main()
