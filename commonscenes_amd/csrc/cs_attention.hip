@@ -179,7 +179,7 @@ int launch_attn(const float* q, const float* k, const float* v, float* out, int 
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), smem, s, q, k, v, out, nq, nk, heads,
+  CS_LAUNCH(kern, dim3((unsigned)grid), dim3(256), smem, s, q, k, v, out, nq, nk, heads,
                      dh, ldq, ldk, ldv, ldo, scale, qtiles);
   CS_CHECK_LAUNCH();
   return CS_OK;

@@ -10,6 +10,14 @@
     if (e_ != hipSuccess) return (int)e_;         \
   } while (0)
 
+// hipGetLastError() is sticky per thread: clear whatever an earlier, unrelated runtime call left behind
+// (e.g. a device probe) so CS_CHECK_LAUNCH reports this launch only.
+#define CS_LAUNCH(...)              \
+  do {                              \
+    (void)hipGetLastError();        \
+    hipLaunchKernelGGL(__VA_ARGS__); \
+  } while (0)
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));

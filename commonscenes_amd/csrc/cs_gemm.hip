@@ -222,7 +222,7 @@ int launch(const CsConvGemm& p, int M, hipStream_t stream) {
   const int tiles_n = (p.cout + BN - 1) / BN;
   const int64_t nblk = (int64_t)tiles_m * tiles_n;
   if (nblk > 0x7fffffffLL) return CS_EINVAL;
-  hipLaunchKernelGGL((conv_gemm_f32_kernel<WMB, WNB, WAVES_M, WAVES_N>), dim3((unsigned)nblk),
+  CS_LAUNCH((conv_gemm_f32_kernel<WMB, WNB, WAVES_M, WAVES_N>), dim3((unsigned)nblk),
                      dim3(256), 0, stream, p, M, tiles_n, p.kh * p.kw, p.kw);
   CS_CHECK_LAUNCH();
   return CS_OK;
@@ -327,7 +327,7 @@ extern "C" int cs_relayout_weight(const float* w_torch, float* w_out, int cout, 
   if (!w_torch || !w_out || cout <= 0 || cin <= 0 || taps <= 0 || cin_pad < cin || ldw < cout)
     return CS_EINVAL;
   const int64_t total = (int64_t)taps * cin_pad * ldw;
-  hipLaunchKernelGGL(relayout_weight_kernel, dim3(cs_grid_for(total, 256)), dim3(256), 0,
+  CS_LAUNCH(relayout_weight_kernel, dim3(cs_grid_for(total, 256)), dim3(256), 0,
                      (hipStream_t)stream, w_torch, w_out, cout, cin, taps, cin_pad, ldw);
   CS_CHECK_LAUNCH();
   return CS_OK;

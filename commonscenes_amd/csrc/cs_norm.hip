@@ -179,11 +179,11 @@ extern "C" int cs_groupnorm_stats(const float* x, int nb, int rows, int c, int l
   const size_t smem = (size_t)rowlanes * c * 2 * sizeof(double);
   if (smem > 64 * 1024) return CS_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(gn_partial_kernel, dim3((unsigned)(nb * nsplit)), dim3(256), smem, s, x, rows,
+  CS_LAUNCH(gn_partial_kernel, dim3((unsigned)(nb * nsplit)), dim3(256), smem, s, x, rows,
                      c, ldx, groups, nsplit, rps, (double*)ws);
   CS_CHECK_LAUNCH();
   const int total = nb * groups;
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, s,
+  CS_LAUNCH(gn_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, s,
                      (const double*)ws, nsplit, groups, (double)rows * (c / groups), eps, stats,
                      total);
   CS_CHECK_LAUNCH();
@@ -200,7 +200,7 @@ extern "C" int cs_groupnorm_apply(const float* x, const float* stats, const floa
       ((uintptr_t)beta & 15))
     return CS_EINVAL;
   const int64_t total = (int64_t)nb * rows * (c >> 2);
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(cs_grid_for(total, 256, 256 * 32)), dim3(256), 0,
+  CS_LAUNCH(gn_apply_kernel, dim3(cs_grid_for(total, 256, 256 * 32)), dim3(256), 0,
                      (hipStream_t)stream, x, stats, gamma, beta, y, nb, rows, c, ldx, ldy, groups,
                      act);
   CS_CHECK_LAUNCH();
@@ -227,11 +227,11 @@ extern "C" int cs_layernorm(const float* x, const float* gamma, const float* bet
   const int grid = cs_grid_for(((int64_t)m + 3) / 4, 1, 256 * 32);
   hipStream_t s = (hipStream_t)stream;
   if (ch4 <= 64 * 2)
-    hipLaunchKernelGGL(ln_kernel<2>, dim3(grid), dim3(256), 0, s, x, gamma, beta, y, m, c, ldx, ldy, eps);
+    CS_LAUNCH(ln_kernel<2>, dim3(grid), dim3(256), 0, s, x, gamma, beta, y, m, c, ldx, ldy, eps);
   else if (ch4 <= 64 * 4)
-    hipLaunchKernelGGL(ln_kernel<4>, dim3(grid), dim3(256), 0, s, x, gamma, beta, y, m, c, ldx, ldy, eps);
+    CS_LAUNCH(ln_kernel<4>, dim3(grid), dim3(256), 0, s, x, gamma, beta, y, m, c, ldx, ldy, eps);
   else if (ch4 <= 64 * 8)
-    hipLaunchKernelGGL(ln_kernel<8>, dim3(grid), dim3(256), 0, s, x, gamma, beta, y, m, c, ldx, ldy, eps);
+    CS_LAUNCH(ln_kernel<8>, dim3(grid), dim3(256), 0, s, x, gamma, beta, y, m, c, ldx, ldy, eps);
   else
     return CS_EINVAL;
   CS_CHECK_LAUNCH();

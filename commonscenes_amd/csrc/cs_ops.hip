@@ -291,7 +291,7 @@ extern "C" int cs_geglu(const float* x, float* out, int m, int h, int ldx, int l
   if (!x || !out || m <= 0 || h <= 0 || (h & 3) || (ldx & 3) || (ldo & 3) || ldx < 2 * h || ldo < h)
     return CS_EINVAL;
   if (!al16(x) || !al16(out)) return CS_EINVAL;
-  hipLaunchKernelGGL(geglu_kernel, dim3(cs_grid_for((int64_t)m * (h >> 2), 256, 256 * 32)), dim3(256), 0,
+  CS_LAUNCH(geglu_kernel, dim3(cs_grid_for((int64_t)m * (h >> 2), 256, 256 * 32)), dim3(256), 0,
                      (hipStream_t)stream, x, out, (int64_t)m, h, ldx, ldo);
   CS_CHECK_LAUNCH();
   return CS_OK;
@@ -302,7 +302,7 @@ extern "C" int cs_copy_rows(const float* src, float* dst, int64_t m, int c, int 
   if (!src || !dst || m <= 0 || c <= 0 || (c & 3) || (lds & 3) || (ldd & 3) || lds < c || ldd < c)
     return CS_EINVAL;
   if (!al16(src) || !al16(dst)) return CS_EINVAL;
-  hipLaunchKernelGGL(copy_rows_kernel, dim3(cs_grid_for(m * (c >> 2), 256, 256 * 32)), dim3(256), 0,
+  CS_LAUNCH(copy_rows_kernel, dim3(cs_grid_for(m * (c >> 2), 256, 256 * 32)), dim3(256), 0,
                      (hipStream_t)stream, src, dst, m, c, lds, ldd);
   CS_CHECK_LAUNCH();
   return CS_OK;
@@ -314,7 +314,7 @@ extern "C" int cs_add_rowvec(float* x, const float* v, int64_t m, int c, int ldx
       ldv < c)
     return CS_EINVAL;
   if (!al16(x) || !al16(v)) return CS_EINVAL;
-  hipLaunchKernelGGL(add_rowvec_kernel, dim3(cs_grid_for(m * (c >> 2), 256, 256 * 32)), dim3(256), 0,
+  CS_LAUNCH(add_rowvec_kernel, dim3(cs_grid_for(m * (c >> 2), 256, 256 * 32)), dim3(256), 0,
                      (hipStream_t)stream, x, v, m, c, ldx, ldv, rows);
   CS_CHECK_LAUNCH();
   return CS_OK;
@@ -323,7 +323,7 @@ extern "C" int cs_add_rowvec(float* x, const float* v, int64_t m, int c, int ldx
 extern "C" int cs_nchw_to_ndhwc(const float* x, float* y, int nb, int c, int s, int cpad,
                                 cs_stream_t stream) {
   if (!x || !y || nb <= 0 || c <= 0 || s <= 0 || cpad < c) return CS_EINVAL;
-  hipLaunchKernelGGL(nchw_to_ndhwc_kernel, dim3(cs_grid_for((int64_t)nb * s * cpad, 256, 256 * 32)),
+  CS_LAUNCH(nchw_to_ndhwc_kernel, dim3(cs_grid_for((int64_t)nb * s * cpad, 256, 256 * 32)),
                      dim3(256), 0, (hipStream_t)stream, x, y, nb, c, s, cpad);
   CS_CHECK_LAUNCH();
   return CS_OK;
@@ -332,7 +332,7 @@ extern "C" int cs_nchw_to_ndhwc(const float* x, float* y, int nb, int c, int s, 
 extern "C" int cs_ndhwc_to_nchw(const float* x, float* y, int nb, int c, int s, int ldx,
                                 cs_stream_t stream) {
   if (!x || !y || nb <= 0 || c <= 0 || s <= 0 || ldx < c) return CS_EINVAL;
-  hipLaunchKernelGGL(ndhwc_to_nchw_kernel, dim3(cs_grid_for((int64_t)nb * s * c, 256, 256 * 32)),
+  CS_LAUNCH(ndhwc_to_nchw_kernel, dim3(cs_grid_for((int64_t)nb * s * c, 256, 256 * 32)),
                      dim3(256), 0, (hipStream_t)stream, x, y, nb, c, s, ldx);
   CS_CHECK_LAUNCH();
   return CS_OK;
@@ -342,7 +342,7 @@ extern "C" int cs_timestep_embedding(const int64_t* t, float* out, int nb, int d
                                      cs_stream_t stream) {
   if (!t || !out || nb <= 0 || dim <= 1 || !(max_period > 1.f)) return CS_EINVAL;
   const int total = nb * dim;
-  hipLaunchKernelGGL(timestep_embedding_kernel, dim3((total + 255) / 256), dim3(256), 0,
+  CS_LAUNCH(timestep_embedding_kernel, dim3((total + 255) / 256), dim3(256), 0,
                      (hipStream_t)stream, t, out, nb, dim, max_period);
   CS_CHECK_LAUNCH();
   return CS_OK;
@@ -359,7 +359,7 @@ extern "C" int cs_ddim_cfg_update(const float* x, const float* eps, const float*
   const float sqrt_at = sqrtf(a_t);
   const float sqrt_aprev = sqrtf(a_prev);
   const float dir_coef = sqrtf(1.0f - a_prev - sigma_t * sigma_t);
-  hipLaunchKernelGGL(ddim_update_kernel, dim3(cs_grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x,
+  CS_LAUNCH(ddim_update_kernel, dim3(cs_grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x,
                      eps, noise, x_prev, pred_x0, n, n, sqrt_at, sqrt_aprev, dir_coef, sigma_t,
                      sqrt_one_minus_at, cfg_scale, cfg);
   CS_CHECK_LAUNCH();
@@ -378,7 +378,7 @@ extern "C" int cs_vq_argmin_lookup(const float* z, const float* codebook, int64_
                                        (int)smem);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(vq_kernel, dim3(cs_grid_for(m, 256, 1024)), dim3(256), smem, (hipStream_t)stream, z,
+  CS_LAUNCH(vq_kernel, dim3(cs_grid_for(m, 256, 1024)), dim3(256), smem, (hipStream_t)stream, z,
                      codebook, idx, zq, m, ncode, edim, ldz, ldq);
   CS_CHECK_LAUNCH();
   return CS_OK;
@@ -389,7 +389,7 @@ extern "C" int cs_gcn_gather_cat(const float* obj, const float* pred, const int6
                                  cs_stream_t stream) {
   if (!obj || !pred || !edges || !out || n_obj <= 0 || n_tri <= 0 || d_obj <= 0 || d_pred <= 0)
     return CS_EINVAL;
-  hipLaunchKernelGGL(gcn_gather_cat_kernel,
+  CS_LAUNCH(gcn_gather_cat_kernel,
                      dim3(cs_grid_for((int64_t)n_tri * (2 * d_obj + d_pred), 256)), dim3(256), 0,
                      (hipStream_t)stream, obj, pred, edges, out, n_obj, n_tri, d_obj, d_pred, err);
   CS_CHECK_LAUNCH();
@@ -401,7 +401,7 @@ extern "C" int cs_gcn_segment_mean(const float* new_t, const int64_t* edges, flo
                                    cs_stream_t stream) {
   if (!new_t || !edges || !pooled || n_obj <= 0 || n_tri <= 0 || h <= 0 || off_o < 0 || ld_t < off_o + h)
     return CS_EINVAL;
-  hipLaunchKernelGGL(gcn_segment_mean_kernel, dim3(cs_grid_for((int64_t)n_obj * h, 256)), dim3(256), 0,
+  CS_LAUNCH(gcn_segment_mean_kernel, dim3(cs_grid_for((int64_t)n_obj * h, 256)), dim3(256), 0,
                      (hipStream_t)stream, new_t, edges, pooled, n_obj, n_tri, h, off_o, ld_t, err);
   CS_CHECK_LAUNCH();
   return CS_OK;
@@ -410,7 +410,7 @@ extern "C" int cs_gcn_segment_mean(const float* new_t, const int64_t* edges, flo
 extern "C" int cs_embedding(const float* table, const int64_t* idx, float* out, int n, int dim,
                             int n_rows, int ldo, int32_t* err, cs_stream_t stream) {
   if (!table || !idx || !out || n <= 0 || dim <= 0 || n_rows <= 0 || ldo < dim) return CS_EINVAL;
-  hipLaunchKernelGGL(embedding_kernel, dim3(cs_grid_for((int64_t)n * dim, 256)), dim3(256), 0,
+  CS_LAUNCH(embedding_kernel, dim3(cs_grid_for((int64_t)n * dim, 256)), dim3(256), 0,
                      (hipStream_t)stream, table, idx, out, n, dim, n_rows, ldo, err);
   CS_CHECK_LAUNCH();
   return CS_OK;
@@ -418,7 +418,7 @@ extern "C" int cs_embedding(const float* table, const int64_t* idx, float* out, 
 
 extern "C" int cs_log_softmax(const float* x, float* y, int m, int c, int ldx, int ldy, cs_stream_t stream) {
   if (!x || !y || m <= 0 || c <= 0 || ldx < c || ldy < c) return CS_EINVAL;
-  hipLaunchKernelGGL(log_softmax_kernel, dim3((m + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, y, m, c,
+  CS_LAUNCH(log_softmax_kernel, dim3((m + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, y, m, c,
                      ldx, ldy);
   CS_CHECK_LAUNCH();
   return CS_OK;
@@ -427,7 +427,7 @@ extern "C" int cs_log_softmax(const float* x, float* y, int m, int c, int ldx, i
 extern "C" int cs_synth_fill(float* out, int64_t n, uint64_t base, double scale, double offset,
                              cs_stream_t stream) {
   if (!out || n <= 0) return CS_EINVAL;
-  hipLaunchKernelGGL(synth_fill_kernel, dim3(cs_grid_for(n, 256, 256 * 32)), dim3(256), 0, (hipStream_t)stream,
+  CS_LAUNCH(synth_fill_kernel, dim3(cs_grid_for(n, 256, 256 * 32)), dim3(256), 0, (hipStream_t)stream,
                      out, n, base, scale, offset);
   CS_CHECK_LAUNCH();
   return CS_OK;

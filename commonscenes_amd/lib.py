@@ -8,6 +8,12 @@ from __future__ import annotations
 import ctypes as C
 from pathlib import Path
 
+# torch must be imported BEFORE the library is dlopen'ed: both need libamdhip64.so.7 and whichever is
+# mapped first serves the whole process.  torch ships its own HIP + HSA runtime pair; letting
+# /opt/rocm's HIP runtime in first leaves two HSA runtimes loaded and every launch fails with
+# hipErrorNoDevice.  Device buffers and streams are torch's, so its runtime is the one to share.
+import torch  # noqa: F401
+
 from .build import LIB_PATH
 
 CS_OK = 0

@@ -161,8 +161,33 @@ def conv_gemm(x: Tensor, w: PackedWeight, *, spatial: Optional[Tuple[int, int, i
     p.pd, p.ph, p.pw = pd, ph, pw
     p.ud, p.uh, p.uw = up
     p.act, p.rv_rows, p.math, p.tile = act, rv_rows, math, tile
+    prof = GEMM_PROFILE
+    if prof is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     L.check(L.load().cs_conv_gemm(C.byref(p), _stream()), "cs_conv_gemm")
+    if prof is not None:
+        e1.record()
+        prof.append(dict(e0=e0, e1=e1, flops=2.0 * mo * w.cout * w.cin * kd * kh * kw, taps=kd * kh * kw,
+                         m=mo, n=w.cout, k=w.cin * kd * kh * kw, tile=tile_for(mo, w.cout, tile)))
     return out
+
+
+# Set to a list to collect one record per GEMM launch (HIP events on the launch stream): bench.py uses this
+# to measure the dominant kernel's achieved TFLOP/s inside the timed region.
+GEMM_PROFILE = None
+
+
+def tile_for(m: int, cout: int, tile: int = 0) -> int:
+    """mirror of the tile auto-selection in cs_conv_gemm (csrc/cs_gemm.hip)."""
+    if tile:
+        return tile
+    if cout % 224 == 0 and m >= 2048:
+        return 2
+    if cout <= 64 or ((m + 127) // 128) * ((cout + 127) // 128) < 128:
+        return 3
+    return 1
 
 
 def linear(x: Tensor, w: PackedWeight, **kw) -> Tensor:

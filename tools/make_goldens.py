@@ -338,7 +338,7 @@ def build_ref_scene(tmp: Path, small: bool = True):
     finally:
         os.chdir(cwd)
     shapes = scene_param_shapes(n_obj_cls, n_pred)
-    ref_shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    ref_shapes = {k: tuple(v.shape) for k, v in torch.nn.Module.state_dict(model).items()}
     sub = {k: ref_shapes[k] for k in shapes}
     assert sub == dict(shapes), "scene_param_shapes disagrees with the reference state_dict"
     sd = synth.synth_state_dict(shapes)
