@@ -36,6 +36,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X dense fp32-input MFMA peak (MI355X_MICROARCH.md)
+F16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
 UNET_GFLOP_PER_SAMPLE = 557.9   # SURVEY App. A (conv3 471.3 + linear 62.0 + conv1 13.9 + attention 10.45 + norms)
 
 
@@ -48,6 +49,8 @@ def parse():
     ap.add_argument("--ddim-steps", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-objects", type=int, default=4, help="objects in the bounded CPU-baseline sample")
+    ap.add_argument("--math", choices=["fp32", "f16x3"], default=os.environ.get("CS_MATH", "fp32"),
+                    help="GEMM numerics: fp32-input MFMA, or fp32 carried as fp16 hi/lo pairs on the fp16 MFMA")
     ap.add_argument("--small", action="store_true", help="reduced-width UNet (debug only; result is not the metric)")
     return ap.parse_args()
 
@@ -100,7 +103,7 @@ def main():
     from oracle.ref_torch import DIFFUSION, UNET_FULL, UNET_SMALL, register_schedule
 
     cfg = dict(UNET_SMALL if a.small else UNET_FULL, dims=3, use_spatial_transformer=True)
-    df = DiffusionUNet(cfg, conditioning_key="crossattn", device=dev)
+    df = DiffusionUNet(cfg, conditioning_key="crossattn", device=dev).set_math(a.math)
     df.load_state_dict(synth.synth_state_dict(unet_param_shapes(cfg), device=str(dev)))
     sch = register_schedule(**DIFFUSION)
 
@@ -186,6 +189,15 @@ def main():
         all_ms = sum(r["e0"].elapsed_time(r["e1"]) for r in prof)
         all_fl = sum(r["flops"] for r in prof)
         achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        if a.math == "f16x3":
+            # three fp16 MFMA passes per fp32-grade product: the pipe ceiling for ALGORITHMIC flops is 2.5 PF / 3
+            peak, kname = F16_MFMA_PEAK_TFLOPS / 3.0, ("conv_gemm_f16x3_kernel<1,7,4,1> (128x224-tile implicit "
+                                                       "GEMM, 3x v_mfma_f32_32x32x16_f16 per K=16 on hi/lo splits)")
+            dtype = "f32 (operands as fp16 hi+lo pairs, fp32 accumulate)"
+        else:
+            peak, kname = FP32_MFMA_PEAK_TFLOPS, ("conv_gemm_f32_kernel<1,7,4,1> (128x224-tile implicit GEMM, "
+                                                  "v_mfma_f32_32x32x2_f32)")
+            dtype = "f32"
         res = {
             "metric": "DDIM denoise steps/sec (32 objects, 16^3 latent)",
             "value": world * a.steps / dt,
@@ -193,15 +205,14 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": dtype, "data": "synthetic",
             "config": {"workload": "v2_full shape branch (BASELINE configs[2]): 32 objects/GPU, CFG scale 3.0, "
                                    f"{S}-step DDIM schedule, 3x16^3 latents, UNet "
                                    f"{df.num_parameters() / 1e6:.1f}M params fp32, 1 context token",
                        "objects_per_gpu": B, "unet_batch": 2 * B, "ddim_steps": S,
                        "parallelism": f"object-sharded x{world} (replicated weights, no per-step collective)"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "conv_gemm_f32_kernel<1,7,4,1> (128x224-tile implicit GEMM, v_mfma_f32_32x32x2_f32)",
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": None, "kernel": kname, "math": a.math,
                          "launches": len(conv), "avg_launch_ms": conv_ms / max(len(conv), 1),
                          "algorithmic_gflop_per_launch": conv_fl / max(len(conv), 1) / 1e9,
                          "share_of_step_time": conv_ms / (dt * 1e3),

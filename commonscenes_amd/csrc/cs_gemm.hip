@@ -246,12 +246,16 @@ __global__ void relayout_weight_kernel(const float* __restrict__ w, float* __res
 
 }  // namespace
 
+int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p, int M, int tile, hipStream_t s);  // cs_gemm_f16x3.hip
+
 extern "C" int cs_conv_gemm(const CsConvGemm* d, cs_stream_t stream) {
   if (!d || !d->x || !d->w || !d->out) return CS_EINVAL;
   const CsConvGemm& p = *d;
   if (p.nb <= 0 || p.cin <= 0 || p.cout <= 0 || p.dout <= 0 || p.hout <= 0 || p.wout <= 0)
     return CS_EINVAL;
-  if ((p.cin & 3) || (p.lda & 3) || (p.ldw & 3) || p.ldw < p.cout || p.lda < p.cin)
+  const bool f16x3 = p.math == CS_MATH_F16X3;
+  if ((p.cin & 3) || (p.lda & 3) || p.lda < p.cin) return CS_EINVAL;
+  if (!f16x3 && ((p.ldw & 3) || p.ldw < p.cout))
     return CS_EINVAL;
   if (((uintptr_t)p.x & 15) || ((uintptr_t)p.w & 15)) return CS_EINVAL;
   if (p.kd <= 0 || p.kh <= 0 || p.kw <= 0 || p.sd <= 0 || p.sh <= 0 || p.sw <= 0) return CS_EINVAL;
@@ -259,7 +263,7 @@ extern "C" int cs_conv_gemm(const CsConvGemm* d, cs_stream_t stream) {
   if (p.scale && !p.shift) return CS_EINVAL;
   if (p.rowvec && p.rv_rows <= 0) return CS_EINVAL;
   if (p.ldo < p.cout || (p.res && p.ldr < p.cout)) return CS_EINVAL;
-  if (p.math != CS_MATH_FP32) return CS_EINVAL;
+  if (p.math != CS_MATH_FP32 && !f16x3) return CS_EINVAL;
   const int64_t M64 = (int64_t)p.nb * p.dout * p.hout * p.wout;
   if (M64 > 0x7fffffffLL) return CS_EINVAL;
   const int M = (int)M64;
@@ -273,6 +277,7 @@ extern "C" int cs_conv_gemm(const CsConvGemm* d, cs_stream_t stream) {
       tile = 1;
   }
   hipStream_t s = (hipStream_t)stream;
+  if (f16x3) return cs_conv_gemm_f16x3_dispatch(p, M, tile, s);
   switch (tile) {
     case 1: return launch<2, 2, 2, 2>(p, M, s);
     case 2: return launch<1, 7, 4, 1>(p, M, s);
@@ -333,4 +338,4 @@ extern "C" int cs_relayout_weight(const float* w_torch, float* w_out, int cout, 
   return CS_OK;
 }
 
-extern "C" int cs_abi_version(void) { return 1; }
+extern "C" int cs_abi_version(void) { return 2; }

@@ -42,6 +42,7 @@ class CsConvGemm(C.Structure):
         ("pd", C.c_int32), ("ph", C.c_int32), ("pw", C.c_int32),
         ("ud", C.c_int32), ("uh", C.c_int32), ("uw", C.c_int32),
         ("act", C.c_int32), ("rv_rows", C.c_int32), ("math", C.c_int32), ("tile", C.c_int32),
+        ("w_lo", C.c_void_p), ("acc_scale", C.c_float), ("reserved", C.c_int32),
     ]
 
 
@@ -52,6 +53,7 @@ SIGNATURES = {
     "cs_conv3d_3x3x3_s122": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _s]),
     "cs_gemm_tokens": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _s]),
     "cs_relayout_weight": (_i, [_f, _f, _i, _i, _i, _i, _i, _s]),
+    "cs_pack_weight_f16x3": (_i, [_f, _f, _f, _i, _i, _i, _fl, _s]),
     "cs_groupnorm_ws_bytes": (_l, [_i, _i]),
     "cs_groupnorm_stats": (_i, [_f, _i, _i, _i, _i, _i, _fl, _f, _f, _s]),
     "cs_groupnorm_apply": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),

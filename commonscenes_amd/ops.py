@@ -57,17 +57,24 @@ def rows_ld(t: Tensor, name: str = "tensor") -> Tuple[int, int, int]:
 @dataclass
 class PackedWeight:
     """Weights re-laid-out for the implicit GEMM: wt[tap][cin_pad][ldw], bias[cout]."""
-    wt: Tensor
+    wt: Optional[Tensor]
     bias: Optional[Tensor]
     cout: int
     cin: int
     cin_pad: int
     ldw: int
     k: Tuple[int, int, int]
+    math: int = L.MATH_FP32
+    wh: Optional[Tensor] = None      # CS_MATH_F16X3: hi / lo fp16 halves, [tap][cin16/8][cout][8]
+    wl: Optional[Tensor] = None
+    acc_scale: float = 1.0
 
 
-def pack_weight(w: Tensor, bias: Optional[Tensor] = None, cin_pad: Optional[int] = None) -> PackedWeight:
+def pack_weight(w: Tensor, bias: Optional[Tensor] = None, cin_pad: Optional[int] = None,
+                math: int = L.MATH_FP32) -> PackedWeight:
     """torch Conv3d (cout,cin,kd,kh,kw) or Linear (out,in) weight -> PackedWeight (device op)."""
+    if math == L.MATH_F16X3:
+        return _pack_weight_f16x3(w, bias, cin_pad)
     _chk(w, "weight")
     w = w.contiguous()
     if w.dim() == 5:
@@ -88,6 +95,35 @@ def pack_weight(w: Tensor, bias: Optional[Tensor] = None, cin_pad: Optional[int]
         _chk(bias, "bias")
         b = bias.contiguous()
     return PackedWeight(wt, b, cout, cin, cp, ldw, (kd, kh, kw))
+
+
+def _pack_weight_f16x3(w: Tensor, bias: Optional[Tensor], cin_pad: Optional[int]) -> PackedWeight:
+    """fp32 weight -> (hi, lo) fp16 halves of w * 2^s with max|w| * 2^s < 2^14 (cs_pack_weight_f16x3)."""
+    import math as _m
+    _chk(w, "weight")
+    w = w.contiguous()
+    if w.dim() == 5:
+        cout, cin, kd, kh, kw = w.shape
+    elif w.dim() == 2:
+        cout, cin = w.shape
+        kd = kh = kw = 1
+    else:
+        raise L.CsError("weight must be 2-D (Linear) or 5-D (Conv3d)")
+    taps = kd * kh * kw
+    cp = cin_pad if cin_pad is not None else (cin + 3) // 4 * 4
+    amax = float(w.abs().max().item())            # weight preparation (load time), not the sampling loop
+    e = _m.frexp(amax)[1] if amax > 0 and _m.isfinite(amax) else 0
+    scale = 2.0 ** (14 - e)
+    kg = (cin + 15) // 16 * 2
+    wh = torch.empty((taps, kg, cout, 8), dtype=torch.float16, device=w.device)
+    wl = torch.empty_like(wh)
+    L.check(L.load().cs_pack_weight_f16x3(w.data_ptr(), wh.data_ptr(), wl.data_ptr(), cout, cin, taps, scale,
+                                          _stream()), "cs_pack_weight_f16x3")
+    b = None
+    if bias is not None:
+        _chk(bias, "bias")
+        b = bias.contiguous()
+    return PackedWeight(None, b, cout, cin, cp, cout, (kd, kh, kw), L.MATH_F16X3, wh, wl, 1.0 / (scale * 64.0))
 
 
 def conv_gemm(x: Tensor, w: PackedWeight, *, spatial: Optional[Tuple[int, int, int, int]] = None,
@@ -133,7 +169,12 @@ def conv_gemm(x: Tensor, w: PackedWeight, *, spatial: Optional[Tuple[int, int, i
     if om != mo or oc != w.cout:
         raise L.CsError(f"out has shape {tuple(out.shape)}, expected {mo} rows x {w.cout}")
     p = L.CsConvGemm()
-    p.x, p.w, p.out = x.data_ptr(), w.wt.data_ptr(), out.data_ptr()
+    math = w.math                      # the numerics mode is a property of how the weight was packed
+    if math == L.MATH_F16X3:
+        p.x, p.w, p.w_lo, p.out = x.data_ptr(), w.wh.data_ptr(), w.wl.data_ptr(), out.data_ptr()
+        p.acc_scale = w.acc_scale
+    else:
+        p.x, p.w, p.out = x.data_ptr(), w.wt.data_ptr(), out.data_ptr()
     p.bias = _ptr(w.bias)
     p.scale, p.shift = _ptr(scale), _ptr(shift)
     p.rowvec = _ptr(rowvec)

@@ -217,6 +217,17 @@ class DiffusionUNet:
             raise NotImplementedError("the MI355X-native UNet is an inference (sampler) implementation")
         return self
 
+    def set_math(self, mode) -> "DiffusionUNet":
+        """GEMM numerics: 'fp32' (fp32-input MFMA, bit-equal to an fp32 fma chain) or 'f16x3' (fp32 operands
+        carried as fp16 hi/lo pairs on the fp16 MFMA, ~2^-22 per product; csrc/cs_gemm_f16x3.hip)."""
+        m = {"fp32": L.MATH_FP32, "f16x3": L.MATH_F16X3}.get(mode, mode)
+        if m not in (L.MATH_FP32, L.MATH_F16X3):
+            raise ValueError(f"unknown math mode {mode!r}")
+        if m != self.math:
+            self.math = m
+            self._packed = None
+        return self
+
     def num_parameters(self) -> int:
         n = 0
         for s in self.shapes.values():
@@ -237,7 +248,7 @@ class DiffusionUNet:
         pk: Dict[str, object] = {}
 
         def pw(p, cin_pad=None):
-            pk[p] = ops.pack_weight(sd[p + ".weight"], sd.get(p + ".bias"), cin_pad=cin_pad)
+            pk[p] = ops.pack_weight(sd[p + ".weight"], sd.get(p + ".bias"), cin_pad=cin_pad, math=self.math)
 
         pw(P + "time_embed.0")
         pw(P + "time_embed.2")
@@ -261,7 +272,7 @@ class DiffusionUNet:
                     t = p + ".transformer_blocks.0"
                     wqkv = torch.cat([sd[f"{t}.attn1.to_q.weight"], sd[f"{t}.attn1.to_k.weight"],
                                       sd[f"{t}.attn1.to_v.weight"]], dim=0)
-                    pk[t + ".attn1.qkv"] = ops.pack_weight(wqkv)
+                    pk[t + ".attn1.qkv"] = ops.pack_weight(wqkv, math=self.math)
                     pw(t + ".attn1.to_out.0")
                     pw(t + ".attn2.to_q")
                     pw(t + ".attn2.to_k")

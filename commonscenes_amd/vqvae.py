@@ -135,6 +135,16 @@ class VQVAE:
     def eval(self):
         return self
 
+    def set_math(self, mode) -> "VQVAE":
+        """'fp32' or 'f16x3' GEMM numerics (see DiffusionUNet.set_math)."""
+        m = {"fp32": L.MATH_FP32, "f16x3": L.MATH_F16X3}.get(mode, mode)
+        if m not in (L.MATH_FP32, L.MATH_F16X3):
+            raise ValueError(f"unknown math mode {mode!r}")
+        if m != self.math:
+            self.math = m
+            self._packed = None
+        return self
+
     # ---- packing ----
     def _pack(self):
         sd = self._sd
@@ -153,14 +163,14 @@ class VQVAE:
                     pad = (-wz.shape[0]) % 4
                     wz = torch.cat([wz, wz.new_zeros((pad, *wz.shape[1:]))], dim=0)
                     bz = torch.cat([bz, bz.new_zeros(pad)], dim=0)
-                    pk[p] = ops.pack_weight(wz, bz, cin_pad=(wz.shape[1] + 3) // 4 * 4)
+                    pk[p] = ops.pack_weight(wz, bz, cin_pad=(wz.shape[1] + 3) // 4 * 4, math=self.math)
                     continue
                 cin = sd[k].shape[1]
-                pk[p] = ops.pack_weight(sd[k], sd.get(p + ".bias"), cin_pad=(cin + 3) // 4 * 4)
+                pk[p] = ops.pack_weight(sd[k], sd.get(p + ".bias"), cin_pad=(cin + 3) // 4 * 4, math=self.math)
         a = "decoder.mid.attn_1."
         wqkv = torch.cat([sd[a + "q.weight"], sd[a + "k.weight"], sd[a + "v.weight"]], dim=0)
         bqkv = torch.cat([sd[a + "q.bias"], sd[a + "k.bias"], sd[a + "v.bias"]], dim=0)
-        pk[a + "qkv"] = ops.pack_weight(wqkv, bqkv)
+        pk[a + "qkv"] = ops.pack_weight(wqkv, bqkv, math=self.math)
         self._packed = pk
 
     # ---- building blocks ----

@@ -1,0 +1,154 @@
+"""CS_MATH_F16X3 (fp32 operands as fp16 hi/lo pairs on the fp16 MFMA) against fp64 evaluations, the fp32-MFMA
+path and the reference goldens.  The mode must sit at fp32 rounding level, not at fp16 level."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return torch.randn(*shape, generator=g) * scale
+
+
+CASES = [
+    # nb, d, h, w, cin, cout, k, stride, up, tile
+    (2, 4, 8, 8, 32, 224, 3, (1, 1, 1), (0, 0, 0), 2),
+    (1, 16, 16, 16, 4, 224, 3, (1, 1, 1), (0, 0, 0), 0),
+    (2, 4, 8, 8, 48, 48, 3, (1, 2, 2), (0, 0, 0), 0),
+    (2, 4, 4, 4, 32, 32, 3, (1, 1, 1), (0, 1, 1), 0),
+    (1, 4, 4, 4, 16, 24, 3, (1, 1, 1), (1, 1, 1), 1),
+    (2, 4, 4, 4, 96, 3, 3, (1, 1, 1), (0, 0, 0), 0),
+    (3, 4, 4, 4, 40, 72, 1, (1, 1, 1), (0, 0, 0), 1),
+    (1, 5, 7, 3, 20, 36, 3, (1, 1, 1), (0, 0, 0), 3),
+    (1, 8, 8, 8, 672, 224, 3, (1, 1, 1), (0, 0, 0), 2),      # K = 18144
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_f16x3_conv_is_fp32_grade(case):
+    from commonscenes_amd import lib as L, ops
+    from oracle import ref_ops as R
+    nb, d, h, w, cin, cout, k, stride, up, tile = case
+    cin_real = 3 if cin == 4 else cin
+    x = _rand(nb, d, h, w, cin, seed=1)
+    if cin_real != cin:
+        x[..., cin_real:] = 0
+    wt = _rand(cout, cin_real, k, k, k, seed=2, scale=(cin_real * k ** 3) ** -0.5)
+    b = _rand(cout, seed=3)
+    ref = R.conv_ndhwc(x[..., :cin_real].double(), wt.double(), b.double(), stride, up)
+    xd = x.cuda()
+    o16 = ops.conv_gemm(xd, ops.pack_weight(wt.cuda(), b.cuda(), cin_pad=cin, math=L.MATH_F16X3), stride=stride,
+                        up=up, tile=tile)
+    o32 = ops.conv_gemm(xd, ops.pack_weight(wt.cuda(), b.cuda(), cin_pad=cin), stride=stride, up=up, tile=tile)
+    torch.cuda.synchronize()
+    e16, e32 = rel_l2(o16, ref), rel_l2(o32, ref)
+    assert e16 < 2e-6, (e16, e32)
+    assert e16 < 4 * e32 + 3e-7, (e16, e32)          # no worse than a few x the fp32 fma chain's own rounding
+
+
+def test_f16x3_wide_dynamic_range():
+    """weights spanning 1e-5..1, activations with outliers and tiny values: the split keeps absolute accuracy."""
+    from commonscenes_amd import lib as L, ops
+    m, k, n = 256, 512, 224
+    x = _rand(m, k, seed=5)
+    x[:, ::7] *= 1e-3
+    x[3, 5] = 300.0
+    x[9, 100] = -700.0
+    wt = _rand(n, k, seed=6, scale=k ** -0.5)
+    wt[::3] *= 1e-4
+    ref = x.double() @ wt.double().t()
+    out = ops.linear(x.cuda(), ops.pack_weight(wt.cuda(), math=L.MATH_F16X3))
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    # row-wise: error relative to the row's operand magnitudes (what a dot product can promise)
+    err = (out.cpu().double() - ref).abs()
+    bound = (x.double().abs() @ wt.double().abs().t()) * 1e-6
+    assert bool((err <= bound + 1e-12).all())
+
+
+def test_f16x3_epilogue_matches_fp32_contract():
+    from commonscenes_amd import lib as L, ops
+    from oracle import ref_ops as R
+    nb, d, h, w, cin, cout = 2, 4, 4, 4, 32, 48
+    x = _rand(nb, d, h, w, cin, seed=4)
+    wt = _rand(cout, cin, 3, 3, 3, seed=5, scale=(cin * 27) ** -0.5)
+    b, rv, res = _rand(cout, seed=6), _rand(nb, cout, seed=7), _rand(nb, d, h, w, cout, seed=8)
+    ref = R.conv_ndhwc(x, wt, b, rowvec=rv, res=res, act="silu")
+    out = ops.conv_gemm(x.cuda(), ops.pack_weight(wt.cuda(), b.cuda(), math=L.MATH_F16X3), rowvec=rv.cuda(),
+                        rv_rows=d * h * w, res=res.cuda(), act=L.ACT_SILU)
+    torch.cuda.synchronize()
+    assert rel_l2(out, ref) < 2e-6
+
+
+def _g(name):
+    p = GOLDEN / f"{name}.npz"
+    if not p.exists():
+        pytest.skip(f"{p.name} not generated")
+    return {k: v for k, v in np.load(p).items()}
+
+
+def _unet(small):
+    from commonscenes_amd import synth
+    from commonscenes_amd.unet import DiffusionUNet, unet_param_shapes
+    from oracle.ref_torch import UNET_FULL, UNET_SMALL
+    cfg = dict(UNET_SMALL if small else UNET_FULL, dims=3, use_spatial_transformer=True)
+    df = DiffusionUNet(cfg, conditioning_key="crossattn", device="cuda").set_math("f16x3")
+    df.load_state_dict(synth.synth_state_dict(unet_param_shapes(cfg), device="cuda"))
+    return df
+
+
+@pytest.mark.parametrize("small", [True, False])
+def test_f16x3_unet_vs_reference_golden(small):
+    g = _g("unet_small" if small else "unet_full")
+    df = _unet(small)
+    cu = lambda a: torch.from_numpy(a).cuda()
+    eps = df(cu(g["x"]), cu(g["t"]), c_crossattn=[cu(g["ctx"])])
+    torch.cuda.synchronize()
+    e16 = rel_l2(eps, torch.from_numpy(g["eps"]))
+    df.set_math("fp32")
+    eps32 = df(cu(g["x"]), cu(g["t"]), c_crossattn=[cu(g["ctx"])])
+    torch.cuda.synchronize()
+    e32 = rel_l2(eps32, torch.from_numpy(g["eps"]))
+    print(f"UNet {'small' if small else 'full'}: rel-L2 vs reference  f16x3 {e16:.3e}   fp32 {e32:.3e}")
+    assert e16 < 1e-5 and e32 < 1e-5
+
+
+def test_f16x3_ddim_full_vs_reference_golden():
+    from commonscenes_amd.ddim import DDIMSampler
+    from oracle.ref_torch import DIFFUSION, register_schedule
+    g = _g("ddim_full")
+    df = _unet(False)
+    sch = register_schedule(**DIFFUSION)
+
+    class M:
+        num_timesteps = 1000
+        device = torch.device("cuda")
+        alphas_cumprod = sch["alphas_cumprod"]
+
+        def apply_model(self, x, t, c):
+            return df(x, t, c_crossattn=[c])
+
+    cu = lambda a: torch.from_numpy(a).cuda()
+    k, S = int(g["steps"]), int(g["S"])
+    x, _ = DDIMSampler(M()).sample(S=S, batch_size=g["x_T"].shape[0], shape=(3, 16, 16, 16), conditioning=cu(g["c"]),
+                                   x_T=cu(g["x_T"]), verbose=False, unconditional_guidance_scale=float(g["scale"]),
+                                   unconditional_conditioning=cu(g["uc"]), eta=0.0, max_steps=k)
+    torch.cuda.synchronize()
+    assert rel_l2(x, torch.from_numpy(g["x"][k - 1])) < 1e-4
+
+
+def test_f16x3_vq_decode_vs_reference_golden():
+    from commonscenes_amd import synth
+    from commonscenes_amd.vqvae import VQVAE, vqvae_param_shapes
+    from oracle.ref_torch import VQ_FULL
+    g = _g("vq_decode")
+    vq = VQVAE(VQ_FULL, 8192, 3, device="cuda").set_math("f16x3")
+    vq.load_state_dict(synth.synth_state_dict(vqvae_param_shapes(VQ_FULL, 8192, 3), device="cuda"))
+    dec = vq.decode_no_quant(torch.from_numpy(g["latent"]).cuda())
+    torch.cuda.synchronize()
+    assert int((vq.last_indices.cpu().numpy() != g["indices"]).sum()) == 0
+    assert rel_l2(dec, torch.from_numpy(g["dec"])) < 1e-4
