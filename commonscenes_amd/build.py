@@ -41,13 +41,14 @@ def build_native(force: bool = False, verbose: bool = True) -> Path:
     if not force and not needs_build():
         return LIB_PATH
     hipcc = _hipcc()
+    extra = os.environ.get("CS_EXTRA_HIPCC_FLAGS", "").split()      # debug builds only (e.g. -DCS_ABLATE=1)
     objdir = PKG_DIR / "build"
     objdir.mkdir(exist_ok=True)
     procs = []
     objs = []
     for s in SOURCES:
         obj = objdir / (s.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, "-c", str(CSRC / s), "-o", str(obj)]
+        cmd = [hipcc, *FLAGS, *extra, "-c", str(CSRC / s), "-o", str(obj)]
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -161,10 +161,11 @@ __global__ __launch_bounds__(256) void conv_gemm_f32_kernel(const CsConvGemm p, 
     const int buf = kc & 1;
     const bool more = (kc + 1) < nk;
     if (more) {
-      c0 += BK;
-      if (c0 >= p.cin) {
-        c0 = 0;
-        ++tap;
+      // K order: channel chunk OUTER, tap INNER -- the 27 taps of one 16-channel chunk re-touch only this
+      // tile's rows + halo, so they hit L1/L2 instead of re-streaming the tensor from MALL/HBM per tap.
+      if (++tap == ntaps) {
+        tap = 0;
+        c0 += BK;
       }
       load_chunk(tap, c0);
     }

@@ -22,6 +22,9 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 constexpr int BKH = 16;       // K elements per chunk
 constexpr int AROW = 24;      // halves per LDS A row (16 data + 8 pad)
 constexpr float A_SCALE = 64.0f;
+#ifndef CS_ABLATE
+#define CS_ABLATE 0   // debug: 1 = no global loads, 2 = no LDS stores, 4 = no LDS operand reads, 8 = no barrier
+#endif
 
 __device__ __forceinline__ void split8(const float4& x, const float4& y, h8& hi, h8& lo) {
   const float v[8] = {x.x * A_SCALE, x.y * A_SCALE, x.z * A_SCALE, x.w * A_SCALE,
@@ -34,9 +37,28 @@ __device__ __forceinline__ void split8(const float4& x, const float4& y, h8& hi,
   }
 }
 
+constexpr unsigned OOB = 0xFFF00000u;   // byte offset past every buffer (tensors are < 0xFFE00000 bytes): loads 0
+
+// NB: take the builtin's result with `auto` and bit_cast the WHOLE vector -- element-wise extraction through
+// an ext_vector_type copy makes hipcc (ROCm 7.2) narrow the load to one dword and replicate it.
+__device__ __forceinline__ float4 ldg4(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+  const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+  const f32x4 f = __builtin_bit_cast(f32x4, v);
+  return make_float4(f[0], f[1], f[2], f[3]);
+}
+__device__ __forceinline__ h8 ldh8(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+  const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+  return __builtin_bit_cast(h8, v);
+}
+
+// The K loop is ONE basic block: no data-dependent branches.  Out-of-image taps, rows past M, channels past
+// cin and columns past cout are all expressed as an out-of-range buffer offset (the buffer unit returns 0),
+// so the compiler is free to slot the next chunk's address math, fp32->fp16 hi/lo conversion and LDS stores
+// into the issue gaps behind the current chunk's MFMAs (an in-order wave hides ~5 issues per 32-cycle MFMA).
 template <int WMB, int WNB, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(256) void conv_gemm_f16x3_kernel(const CsConvGemm p, int M, int tiles_n,
-                                                              int taps_hw, int kw_, int kg_per_tap) {
+                                                              int taps_hw, int kw_, int kg_per_tap,
+                                                              unsigned x_bytes, unsigned w_bytes) {
   constexpr int BM = 32 * WMB * WAVES_M;
   constexpr int BN = 32 * WNB * WAVES_N;
   constexpr int A_SZ = BM * AROW;          // halves per A image
@@ -46,7 +68,11 @@ __global__ __launch_bounds__(256) void conv_gemm_f16x3_kernel(const CsConvGemm p
   constexpr int APT = (AUNITS + 255) / 256;
   constexpr int BUNITS = 2 * BN;           // 16-byte units per B image
   constexpr int BPT = (BUNITS + 255) / 256;
-  __shared__ __attribute__((aligned(16))) _Float16 smem[2 * STAGE];
+  constexpr int MAX_TAPS = 27;
+  constexpr int DUMP = 2 * STAGE;          // 256 x 16 B scratch: where surplus loader lanes park their stores
+  constexpr int ROWOFF = DUMP + 256 * 8;
+  __shared__ __attribute__((aligned(16))) _Float16 smem[ROWOFF + 2 * BM * MAX_TAPS];
+  unsigned* rowoff = reinterpret_cast<unsigned*>(smem + ROWOFF);   // [ntaps][BM] byte offsets into x, or OOB
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -67,76 +93,84 @@ __global__ __launch_bounds__(256) void conv_gemm_f16x3_kernel(const CsConvGemm p
   const int m0 = tm * BM;
   const int n0 = tn * BN;
 
-  // ---- per-thread A row bookkeeping: unit u = tid + 256*i -> row u>>1, channel octet u&1 ----
-  int id0[APT], ih0[APT], iw0[APT];
-  int64_t nbase[APT];
-  bool rvalid[APT];
-  const int vdin = p.din << p.ud, vhin = p.hin << p.uh, vwin = p.win << p.uw;
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_lo, 0, w_bytes, 0x00020000);
+
+  // ---- source-row table: rowoff[tap][row] = byte offset of the source row in x, or OOB when the tap falls
+  // outside the (virtual, possibly upsampled) input or the row is past M.  Built once per workgroup.
+  const int ntaps = p.kd * taps_hw;
+  {
+    const int vdin = p.din << p.ud, vhin = p.hin << p.uh, vwin = p.win << p.uw;
+    for (int idx = tid; idx < BM * ntaps; idx += 256) {
+      const int t = idx / BM;
+      const int row = idx - t * BM;
+      const int m = m0 + row;
+      unsigned r = OOB;
+      if (m < M) {
+        int mm = m;
+        const int ow = mm % p.wout;
+        mm /= p.wout;
+        const int oh = mm % p.hout;
+        mm /= p.hout;
+        const int od = mm % p.dout;
+        const int n = mm / p.dout;
+        const int kd_ = t / taps_hw;
+        const int rem = t - kd_ * taps_hw;
+        const int kh_ = rem / kw_;
+        const int kwi = rem - kh_ * kw_;
+        const int vd = od * p.sd - p.pd + kd_, vh = oh * p.sh - p.ph + kh_, vw = ow * p.sw - p.pw + kwi;
+        if ((unsigned)vd < (unsigned)vdin && (unsigned)vh < (unsigned)vhin && (unsigned)vw < (unsigned)vwin)
+          r = (unsigned)(((n * p.din + (vd >> p.ud)) * p.hin + (vh >> p.uh)) * p.win + (vw >> p.uw)) *
+              (unsigned)(p.lda * 4);
+      }
+      rowoff[idx] = r;
+    }
+  }
+
+  const int chunks_per_tap = kg_per_tap >> 1;   // cin16 / 16
+  const int nk = ntaps * chunks_per_tap;
+
+  // per-thread loader constants
+  unsigned a_lds[APT], a_coff[APT], a_row[APT];
 #pragma unroll
   for (int i = 0; i < APT; ++i) {
     const int u = tid + 256 * i;
-    const int row = u >> 1;
-    const int m = m0 + row;
-    rvalid[i] = (u < AUNITS) && (m < M);
-    int mm = rvalid[i] ? m : 0;
-    const int ow = mm % p.wout;
-    mm /= p.wout;
-    const int oh = mm % p.hout;
-    mm /= p.hout;
-    const int od = mm % p.dout;
-    const int n = mm / p.dout;
-    id0[i] = od * p.sd - p.pd;
-    ih0[i] = oh * p.sh - p.ph;
-    iw0[i] = ow * p.sw - p.pw;
-    nbase[i] = (int64_t)n * p.din * p.hin * p.win;
+    const bool ok = u < AUNITS;
+    a_row[i] = ok ? (u >> 1) : 0;
+    a_coff[i] = (u & 1) * 8;
+    a_lds[i] = ok ? (unsigned)((u >> 1) * AROW + (u & 1) * 8) : (unsigned)(DUMP + tid * 8);
   }
-
-  const int ntaps = p.kd * taps_hw;
-  const int chunks_per_tap = kg_per_tap >> 1;   // cin16 / 16
-  const int nk = ntaps * chunks_per_tap;
-  const h8* wh = reinterpret_cast<const h8*>(p.w);
-  const h8* wl = reinterpret_cast<const h8*>(p.w_lo);
+  unsigned b_lds[BPT], b_goff[BPT];
+#pragma unroll
+  for (int i = 0; i < BPT; ++i) {
+    const int u = tid + 256 * i;
+    const int kg = u / BN;
+    const int n = u - kg * BN;
+    const bool ok = (u < BUNITS) && (n0 + n < p.cout);
+    b_goff[i] = ok ? (unsigned)((kg * p.cout + n0 + n) * 16) : OOB;
+    b_lds[i] = (u < BUNITS) ? (unsigned)(u * 8) : (unsigned)(DUMP + tid * 8);
+  }
 
   float4 ra[APT][2];
   h8 rbh[BPT], rbl[BPT];
 
-  auto load_chunk = [&](int tap, int cc) {   // cc = chunk index within the tap (16 channels each)
-    const int kd_ = tap / taps_hw;
-    const int rem = tap - kd_ * taps_hw;
-    const int kh_ = rem / kw_;
-    const int kwi = rem - kh_ * kw_;
+  auto load_chunk = [&](int tap, int cc) {   // cc = 16-channel chunk index; (tap, cc) past the end loads zeros
 #pragma unroll
     for (int i = 0; i < APT; ++i) {
-      const int u = tid + 256 * i;
-      const int c = cc * BKH + (u & 1) * 8;
-      const int vd = id0[i] + kd_, vh = ih0[i] + kh_, vw = iw0[i] + kwi;
-      const bool ok = rvalid[i] && (unsigned)vd < (unsigned)vdin && (unsigned)vh < (unsigned)vhin &&
-                      (unsigned)vw < (unsigned)vwin;
-      float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
-      if (ok) {
-        const int64_t srow =
-            nbase[i] + ((int64_t)(vd >> p.ud) * p.hin + (vh >> p.uh)) * p.win + (vw >> p.uw);
-        const float* src = p.x + srow * p.lda + c;
-        if (c < p.cin) v0 = *reinterpret_cast<const float4*>(src);
-        if (c + 4 < p.cin) v1 = *reinterpret_cast<const float4*>(src + 4);
-      }
-      ra[i][0] = v0;
-      ra[i][1] = v1;
+      const int c = cc * BKH + a_coff[i];
+      const unsigned r = rowoff[tap * BM + a_row[i]];
+      const unsigned o0 = (c < p.cin) ? r + (unsigned)c * 4u : OOB;
+      const unsigned o1 = (c + 4 < p.cin) ? r + (unsigned)c * 4u + 16u : OOB;
+      ra[i][0] = ldg4(xrs, o0);
+      ra[i][1] = ldg4(xrs, o1);
     }
-    const int64_t kg0 = (int64_t)tap * kg_per_tap + cc * 2;
+    const unsigned kbase = (unsigned)((tap * kg_per_tap + cc * 2) * p.cout) * 16u;
 #pragma unroll
     for (int i = 0; i < BPT; ++i) {
-      const int u = tid + 256 * i;
-      const int kg = u / BN;
-      const int n = u - kg * BN;
-      h8 vh_ = {0, 0, 0, 0, 0, 0, 0, 0}, vl_ = vh_;
-      if (u < BUNITS && n0 + n < p.cout) {
-        const int64_t off = (kg0 + kg) * p.cout + n0 + n;
-        vh_ = wh[off];
-        vl_ = wl[off];
-      }
-      rbh[i] = vh_;
-      rbl[i] = vl_;
+      const unsigned o = (b_goff[i] == OOB) ? OOB : b_goff[i] + kbase;
+      rbh[i] = ldh8(hrs, o);
+      rbl[i] = ldh8(lrs, o);
     }
   };
 
@@ -144,22 +178,19 @@ __global__ __launch_bounds__(256) void conv_gemm_f16x3_kernel(const CsConvGemm p
     _Float16* s = smem + buf * STAGE;
 #pragma unroll
     for (int i = 0; i < APT; ++i) {
-      const int u = tid + 256 * i;
-      if (u < AUNITS) {
-        h8 hi, lo;
-        split8(ra[i][0], ra[i][1], hi, lo);
-        const int off = (u >> 1) * AROW + (u & 1) * 8;
-        *reinterpret_cast<h8*>(s + off) = hi;
-        *reinterpret_cast<h8*>(s + A_SZ + off) = lo;
-      }
+      h8 hi, lo;
+      split8(ra[i][0], ra[i][1], hi, lo);
+      const bool ok = (tid + 256 * i) < AUNITS;
+      _Float16* d = ok ? s : smem;      // surplus lanes write into the DUMP area (absolute offset)
+      *reinterpret_cast<h8*>(d + a_lds[i]) = hi;
+      *reinterpret_cast<h8*>(d + a_lds[i] + (ok ? A_SZ : 0)) = lo;
     }
 #pragma unroll
     for (int i = 0; i < BPT; ++i) {
-      const int u = tid + 256 * i;
-      if (u < BUNITS) {
-        *reinterpret_cast<h8*>(s + 2 * A_SZ + u * 8) = rbh[i];
-        *reinterpret_cast<h8*>(s + 2 * A_SZ + B_SZ + u * 8) = rbl[i];
-      }
+      const bool ok = (tid + 256 * i) < BUNITS;
+      _Float16* d = ok ? s + 2 * A_SZ : smem;
+      *reinterpret_cast<h8*>(d + b_lds[i]) = rbh[i];
+      *reinterpret_cast<h8*>(d + b_lds[i] + (ok ? B_SZ : 0)) = rbl[i];
     }
   };
 
@@ -171,6 +202,7 @@ __global__ __launch_bounds__(256) void conv_gemm_f16x3_kernel(const CsConvGemm p
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  __syncthreads();   // rowoff table complete
   int tap = 0, cc = 0;
   load_chunk(tap, cc);
   store_chunk(0);
@@ -178,15 +210,14 @@ __global__ __launch_bounds__(256) void conv_gemm_f16x3_kernel(const CsConvGemm p
 
   for (int kc = 0; kc < nk; ++kc) {
     const int buf = kc & 1;
-    const bool more = (kc + 1) < nk;
-    if (more) {
-      if (++cc == chunks_per_tap) {
-        cc = 0;
-        ++tap;
-      }
-      load_chunk(tap, cc);
+    // K order: channel chunk OUTER, tap INNER (the 27 taps of one 16-channel chunk re-touch only this
+    // tile's rows + halo, so they hit L1/L2).  The prefetch after the last chunk runs past cin16 and reads 0.
+    if (++tap == ntaps) {
+      tap = 0;
+      ++cc;
     }
-    const _Float16* s = smem + buf * STAGE;
+    if (!(CS_ABLATE & 1)) load_chunk(tap, cc);
+    const _Float16* s = smem + ((CS_ABLATE & 4) ? 0 : buf * STAGE);
     h8 ah[WMB], al[WMB];
 #pragma unroll
     for (int i = 0; i < WMB; ++i) {
@@ -206,8 +237,8 @@ __global__ __launch_bounds__(256) void conv_gemm_f16x3_kernel(const CsConvGemm p
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh, acc[i][j], 0, 0, 0);
       }
     }
-    if (more) store_chunk(buf ^ 1);
-    __syncthreads();
+    if (!(CS_ABLATE & 2)) store_chunk(buf ^ 1);
+    if (!(CS_ABLATE & 8)) __syncthreads();
   }
 
   // ---- epilogue (identical contract to the fp32 kernel, after undoing the operand scales) ----
@@ -246,8 +277,13 @@ int launch16(const CsConvGemm& p, int M, hipStream_t stream) {
   const int64_t nblk = (int64_t)tiles_m * tiles_n;
   if (nblk > 0x7fffffffLL) return CS_EINVAL;
   const int kg_per_tap = ((p.cin + 15) / 16) * 2;
+  // buffer-descriptor extents: everything the loader may touch, and < 0xFFE00000 so OOB stays out of range
+  const int64_t x_rows = (int64_t)p.nb * p.din * p.hin * p.win;
+  const int64_t x_bytes = ((x_rows - 1) * p.lda + p.cin) * 4;
+  const int64_t w_bytes = (int64_t)p.kd * p.kh * p.kw * kg_per_tap * p.cout * 16;
+  if (x_bytes > 0xFFE00000LL || w_bytes > 0xFFE00000LL) return CS_EINVAL;
   CS_LAUNCH((conv_gemm_f16x3_kernel<WMB, WNB, WAVES_M, WAVES_N>), dim3((unsigned)nblk), dim3(256), 0,
-            stream, p, M, tiles_n, p.kh * p.kw, p.kw, kg_per_tap);
+            stream, p, M, tiles_n, p.kh * p.kw, p.kw, kg_per_tap, (unsigned)x_bytes, (unsigned)w_bytes);
   CS_CHECK_LAUNCH();
   return CS_OK;
 }
@@ -278,6 +314,8 @@ __global__ __launch_bounds__(256) void pack_f16x3_kernel(const float* __restrict
 // called from cs_conv_gemm (cs_gemm.hip) when desc->math == CS_MATH_F16X3; arguments already validated
 int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p, int M, int tile, hipStream_t s) {
   if (!p.w_lo || !(p.acc_scale > 0.f)) return CS_EINVAL;
+  if (p.kd * p.kh * p.kw > 27) return CS_EINVAL;                                   // LDS row table extent
+  if ((int64_t)p.nb * p.din * p.hin * p.win > 0x7fffffffLL) return CS_EINVAL;      // int32 row indices
   if (((uintptr_t)p.w & 15) || ((uintptr_t)p.w_lo & 15)) return CS_EINVAL;
   switch (tile) {
     case 1: return launch16<2, 2, 2, 2>(p, M, s);
