@@ -7,11 +7,19 @@
 // Three fp16 MFMAs per K=16 step cost 96 SIMD cycles against 512 for the fp32-input MFMA: a 5.3x higher
 // matrix-pipe ceiling at ~fp32 accuracy (measured error vs fp64 is reported by tests/test_f16x3_gpu.py).
 //
-// Weights are split offline (cs_pack_weight_f16x3), activations on the fly in the loader (scale 2^6).
-// Tile BM x BN x 16, 4 waves; LDS holds [A_hi | A_lo | B_hi | B_lo] per stage, two stages (one barrier per
-// K-chunk).  LDS images are MFMA-fragment shaped so every operand read is one conflict-free ds_read_b128:
-//   A: [m][16 halves + 8 pad]  (48-byte rows: 16 consecutive rows hit 16 distinct 16-byte slots)
-//   B: [k/8][n][8 halves]      (32 consecutive n = 512 contiguous bytes)
+// Data movement is ALL LDS-DMA (buffer_load ... lds): no VGPR staging, no ds_write, no data-dependent
+// branch in the K loop.
+//   * weights are split offline (cs_pack_weight_f16x3) into hi / lo images laid out [tap][k/8][n][8 halves]
+//     = the MFMA B-fragment order, so a B tile is a straight 16-byte-per-lane DMA;
+//   * activations arrive as raw fp32 rows ([m][16 ch] = 64 B, 16-byte pieces XOR-swizzled by (m>>2)&3 on the
+//     SOURCE address so the fragment reads are conflict-free) and are split into hi / lo fp16 with scale 2^6
+//     by the consuming wave right before its MFMAs (VALU work that overlaps the other wave's MFMAs);
+//   * zero padding (out-of-image taps, rows past M, channels past cin, columns past cout) is an out-of-range
+//     buffer offset: the buffer unit writes zeros, the loop stays one basic block.
+// Pipeline: 3-stage LDS ring, prefetch distance 2, one raw s_barrier per K-chunk, counted vmcnt:
+//     wait vmcnt(D) [chunk k landed, chunk k+1 may fly] ; s_barrier ; issue DMA(k+2) ; MFMAs on chunk k
+// K order: channel chunk OUTER, tap INNER (the 27 taps of one 16-channel chunk re-touch only this tile's rows
+// + halo, so they hit L1/L2 instead of re-streaming the activation tensor per tap).
 // fp16 32x32x16 operand map: lane l holds row/col l&31 and k = 8*(l>>5) .. 8*(l>>5)+7; C/D as for fp32.
 #include "cs_common.h"
 
@@ -20,15 +28,16 @@ namespace {
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 constexpr int BKH = 16;       // K elements per chunk
-constexpr int AROW = 24;      // halves per LDS A row (16 data + 8 pad)
 constexpr float A_SCALE = 64.0f;
+constexpr unsigned OOB = 0xFFF00000u;   // byte offset past every buffer (extents are < 0xFFE00000): reads 0
+constexpr int MAX_TAPS = 27;
 #ifndef CS_ABLATE
-#define CS_ABLATE 0   // debug: 1 = no global loads, 2 = no LDS stores, 4 = no LDS operand reads, 8 = no barrier
+#define CS_ABLATE 0   // debug: 1 = no DMA issue, 8 = no barrier
 #endif
 
-__device__ __forceinline__ void split8(const float4& x, const float4& y, h8& hi, h8& lo) {
-  const float v[8] = {x.x * A_SCALE, x.y * A_SCALE, x.z * A_SCALE, x.w * A_SCALE,
-                      y.x * A_SCALE, y.y * A_SCALE, y.z * A_SCALE, y.w * A_SCALE};
+__device__ __forceinline__ void split8(const f32x4& x, const f32x4& y, h8& hi, h8& lo) {
+  const float v[8] = {x[0] * A_SCALE, x[1] * A_SCALE, x[2] * A_SCALE, x[3] * A_SCALE,
+                      y[0] * A_SCALE, y[1] * A_SCALE, y[2] * A_SCALE, y[3] * A_SCALE};
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const _Float16 h = (_Float16)v[i];
@@ -37,46 +46,47 @@ __device__ __forceinline__ void split8(const float4& x, const float4& y, h8& hi,
   }
 }
 
-constexpr unsigned OOB = 0xFFF00000u;   // byte offset past every buffer (tensors are < 0xFFE00000 bytes): loads 0
-
-// NB: take the builtin's result with `auto` and bit_cast the WHOLE vector -- element-wise extraction through
-// an ext_vector_type copy makes hipcc (ROCm 7.2) narrow the load to one dword and replicate it.
-__device__ __forceinline__ float4 ldg4(__amdgpu_buffer_rsrc_t rs, unsigned off) {
-  const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
-  const f32x4 f = __builtin_bit_cast(f32x4, v);
-  return make_float4(f[0], f[1], f[2], f[3]);
-}
-__device__ __forceinline__ h8 ldh8(__amdgpu_buffer_rsrc_t rs, unsigned off) {
-  const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
-  return __builtin_bit_cast(h8, v);
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
 }
 
-// The K loop is ONE basic block: no data-dependent branches.  Out-of-image taps, rows past M, channels past
-// cin and columns past cout are all expressed as an out-of-range buffer offset (the buffer unit returns 0),
-// so the compiler is free to slot the next chunk's address math, fp32->fp16 hi/lo conversion and LDS stores
-// into the issue gaps behind the current chunk's MFMAs (an in-order wave hides ~5 issues per 32-cycle MFMA).
 template <int WMB, int WNB, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(256) void conv_gemm_f16x3_kernel(const CsConvGemm p, int M, int tiles_n,
                                                               int taps_hw, int kw_, int kg_per_tap,
                                                               unsigned x_bytes, unsigned w_bytes) {
   constexpr int BM = 32 * WMB * WAVES_M;
   constexpr int BN = 32 * WNB * WAVES_N;
-  constexpr int A_SZ = BM * AROW;          // halves per A image
-  constexpr int B_SZ = 2 * BN * 8;         // halves per B image: [2 k-groups][BN][8]
-  constexpr int STAGE = 2 * A_SZ + 2 * B_SZ;
-  constexpr int AUNITS = BM * 2;           // (row, 8-channel half-row) units
-  constexpr int APT = (AUNITS + 255) / 256;
-  constexpr int BUNITS = 2 * BN;           // 16-byte units per B image
-  constexpr int BPT = (BUNITS + 255) / 256;
-  constexpr int MAX_TAPS = 27;
-  constexpr int DUMP = 2 * STAGE;          // 256 x 16 B scratch: where surplus loader lanes park their stores
-  constexpr int ROWOFF = DUMP + 256 * 8;
-  __shared__ __attribute__((aligned(16))) _Float16 smem[ROWOFF + 2 * BM * MAX_TAPS];
-  unsigned* rowoff = reinterpret_cast<unsigned*>(smem + ROWOFF);   // [ntaps][BM] byte offsets into x, or OOB
+  // ---- LDS map (bytes) ----
+  constexpr int A_BYTES = BM * 64;                 // raw fp32 [BM][16]
+  constexpr int B_BYTES = 2 * BN * 16;             // one fp16 image [2 k-groups][BN][8]
+  constexpr int STAGE = A_BYTES + 2 * B_BYTES;
+  constexpr int NSTAGE = 3;
+  constexpr int DUMP = NSTAGE * STAGE;             // 1 KB: where surplus DMA wave-instructions land
+  constexpr int ROWBASE = DUMP + 1024;             // int32 [BM]: source row of the window origin
+  constexpr int DELTA = ROWBASE + BM * 4;          // int16 [MAX_TAPS][BM]: source row - rowbase, or INVALID
+  constexpr int LDS_BYTES = DELTA + MAX_TAPS * BM * 2;
+  constexpr short INVALID = (short)0x8000;
+  // ---- DMA schedule: wave-instructions of 64 x 16 B ----
+  constexpr int A_WI = BM / 16;                    // A wave-instructions per chunk
+  constexpr int B_WI = BN / 32;                    // per B image
+  constexpr int A_PW = A_WI / 4;                   // per wave
+  constexpr int B_PW = (2 * B_WI + 3) / 4;         // per wave, hi + lo together (surplus ones go to DUMP)
+  constexpr int D = A_PW + B_PW;                   // DMA instructions per wave per chunk
+  static_assert(A_WI % 4 == 0, "A tile must split evenly over 4 waves");
+  static_assert(D <= 7, "vmcnt immediates");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31;
   const int half = lane >> 5;
   const int wm0 = (wave / WAVES_N) * (32 * WMB);
@@ -97,100 +107,97 @@ __global__ __launch_bounds__(256) void conv_gemm_f16x3_kernel(const CsConvGemm p
   const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, w_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_lo, 0, w_bytes, 0x00020000);
 
-  // ---- source-row table: rowoff[tap][row] = byte offset of the source row in x, or OOB when the tap falls
-  // outside the (virtual, possibly upsampled) input or the row is past M.  Built once per workgroup.
+  // ---- source-row tables, built once per workgroup ----
   const int ntaps = p.kd * taps_hw;
+  int* rowbase = reinterpret_cast<int*>(smem + ROWBASE);
+  short* delta = reinterpret_cast<short*>(smem + DELTA);
   {
     const int vdin = p.din << p.ud, vhin = p.hin << p.uh, vwin = p.win << p.uw;
     for (int idx = tid; idx < BM * ntaps; idx += 256) {
       const int t = idx / BM;
       const int row = idx - t * BM;
       const int m = m0 + row;
-      unsigned r = OOB;
+      short dl = INVALID;
+      int mm = m < M ? m : 0;
+      const int ow = mm % p.wout;
+      mm /= p.wout;
+      const int oh = mm % p.hout;
+      mm /= p.hout;
+      const int od = mm % p.dout;
+      const int n = mm / p.dout;
+      // reference position: the (clamped) source voxel of the window origin
+      const int cd = min(max(od * p.sd - p.pd, 0), vdin - 1) >> p.ud;
+      const int ch = min(max(oh * p.sh - p.ph, 0), vhin - 1) >> p.uh;
+      const int cw = min(max(ow * p.sw - p.pw, 0), vwin - 1) >> p.uw;
+      const int base = ((n * p.din + cd) * p.hin + ch) * p.win + cw;
+      if (t == 0) rowbase[row] = base;
       if (m < M) {
-        int mm = m;
-        const int ow = mm % p.wout;
-        mm /= p.wout;
-        const int oh = mm % p.hout;
-        mm /= p.hout;
-        const int od = mm % p.dout;
-        const int n = mm / p.dout;
         const int kd_ = t / taps_hw;
         const int rem = t - kd_ * taps_hw;
         const int kh_ = rem / kw_;
         const int kwi = rem - kh_ * kw_;
         const int vd = od * p.sd - p.pd + kd_, vh = oh * p.sh - p.ph + kh_, vw = ow * p.sw - p.pw + kwi;
-        if ((unsigned)vd < (unsigned)vdin && (unsigned)vh < (unsigned)vhin && (unsigned)vw < (unsigned)vwin)
-          r = (unsigned)(((n * p.din + (vd >> p.ud)) * p.hin + (vh >> p.uh)) * p.win + (vw >> p.uw)) *
-              (unsigned)(p.lda * 4);
+        if ((unsigned)vd < (unsigned)vdin && (unsigned)vh < (unsigned)vhin && (unsigned)vw < (unsigned)vwin) {
+          const int r = ((n * p.din + (vd >> p.ud)) * p.hin + (vh >> p.uh)) * p.win + (vw >> p.uw);
+          dl = (short)(r - base);
+        }
       }
-      rowoff[idx] = r;
+      delta[idx] = dl;
     }
   }
+  __syncthreads();
 
   const int chunks_per_tap = kg_per_tap >> 1;   // cin16 / 16
   const int nk = ntaps * chunks_per_tap;
 
-  // per-thread loader constants
-  unsigned a_lds[APT], a_coff[APT], a_row[APT];
+  // ---- per-lane DMA constants ----
+  // A wave-instruction w (0..A_WI-1) covers units 64w..64w+63: row = 16w + lane/4, LDS slot q = lane&3 holds
+  // global 16-byte piece q ^ ((row>>2)&3).
+  int a_rowbase[A_PW];
+  unsigned a_piece[A_PW];
+  int a_rowidx[A_PW];
 #pragma unroll
-  for (int i = 0; i < APT; ++i) {
-    const int u = tid + 256 * i;
-    const bool ok = u < AUNITS;
-    a_row[i] = ok ? (u >> 1) : 0;
-    a_coff[i] = (u & 1) * 8;
-    a_lds[i] = ok ? (unsigned)((u >> 1) * AROW + (u & 1) * 8) : (unsigned)(DUMP + tid * 8);
+  for (int i = 0; i < A_PW; ++i) {
+    const int w = wave * A_PW + i;
+    const int row = 16 * w + (lane >> 2);
+    a_rowidx[i] = row;
+    a_rowbase[i] = rowbase[row];
+    a_piece[i] = (unsigned)(((lane & 3) ^ ((row >> 2) & 3)) * 4);   // first channel of the piece
   }
-  unsigned b_lds[BPT], b_goff[BPT];
+  // B wave-instruction v (0..2*B_WI-1): image v / B_WI (0 = hi, 1 = lo), units 64*(v % B_WI) .. +63
+  unsigned b_off[B_PW];     // byte offset inside the chunk's [2][cout][8] slab, or OOB
 #pragma unroll
-  for (int i = 0; i < BPT; ++i) {
-    const int u = tid + 256 * i;
+  for (int i = 0; i < B_PW; ++i) {
+    const int v = wave * B_PW + i;
+    const int img = v / B_WI;
+    const int u = (v - img * B_WI) * 64 + lane;           // unit inside the image: kg = u / BN, n = u % BN
     const int kg = u / BN;
     const int n = u - kg * BN;
-    const bool ok = (u < BUNITS) && (n0 + n < p.cout);
-    b_goff[i] = ok ? (unsigned)((kg * p.cout + n0 + n) * 16) : OOB;
-    b_lds[i] = (u < BUNITS) ? (unsigned)(u * 8) : (unsigned)(DUMP + tid * 8);
+    b_off[i] = (v < 2 * B_WI && n0 + n < p.cout) ? (unsigned)((kg * p.cout + n0 + n) * 16) : OOB;
   }
 
-  float4 ra[APT][2];
-  h8 rbh[BPT], rbl[BPT];
-
-  auto load_chunk = [&](int tap, int cc) {   // cc = 16-channel chunk index; (tap, cc) past the end loads zeros
+  auto issue_dma = [&](int tap, int cc, int stage) {
+    unsigned char* st = smem + stage * STAGE;
 #pragma unroll
-    for (int i = 0; i < APT; ++i) {
-      const int c = cc * BKH + a_coff[i];
-      const unsigned r = rowoff[tap * BM + a_row[i]];
-      const unsigned o0 = (c < p.cin) ? r + (unsigned)c * 4u : OOB;
-      const unsigned o1 = (c + 4 < p.cin) ? r + (unsigned)c * 4u + 16u : OOB;
-      ra[i][0] = ldg4(xrs, o0);
-      ra[i][1] = ldg4(xrs, o1);
+    for (int i = 0; i < A_PW; ++i) {
+      const short dl = delta[tap * BM + a_rowidx[i]];
+      const int c = cc * BKH + (int)a_piece[i];
+      const unsigned off = (dl != INVALID && c < p.cin)
+                               ? (unsigned)(a_rowbase[i] + (int)dl) * (unsigned)(p.lda * 4) + (unsigned)c * 4u
+                               : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, st + (wave * A_PW + i) * 1024, 16, off, 0, 0, 0);
     }
     const unsigned kbase = (unsigned)((tap * kg_per_tap + cc * 2) * p.cout) * 16u;
 #pragma unroll
-    for (int i = 0; i < BPT; ++i) {
-      const unsigned o = (b_goff[i] == OOB) ? OOB : b_goff[i] + kbase;
-      rbh[i] = ldh8(hrs, o);
-      rbl[i] = ldh8(lrs, o);
-    }
-  };
-
-  auto store_chunk = [&](int buf) {
-    _Float16* s = smem + buf * STAGE;
-#pragma unroll
-    for (int i = 0; i < APT; ++i) {
-      h8 hi, lo;
-      split8(ra[i][0], ra[i][1], hi, lo);
-      const bool ok = (tid + 256 * i) < AUNITS;
-      _Float16* d = ok ? s : smem;      // surplus lanes write into the DUMP area (absolute offset)
-      *reinterpret_cast<h8*>(d + a_lds[i]) = hi;
-      *reinterpret_cast<h8*>(d + a_lds[i] + (ok ? A_SZ : 0)) = lo;
-    }
-#pragma unroll
-    for (int i = 0; i < BPT; ++i) {
-      const bool ok = (tid + 256 * i) < BUNITS;
-      _Float16* d = ok ? s + 2 * A_SZ : smem;
-      *reinterpret_cast<h8*>(d + b_lds[i]) = rbh[i];
-      *reinterpret_cast<h8*>(d + b_lds[i] + (ok ? B_SZ : 0)) = rbl[i];
+    for (int i = 0; i < B_PW; ++i) {
+      const int v = wave * B_PW + i;                       // wave-uniform
+      const int img = v / B_WI;
+      const unsigned off = (b_off[i] == OOB || cc >= chunks_per_tap) ? OOB : b_off[i] + kbase;
+      unsigned char* dst = (v < 2 * B_WI) ? st + A_BYTES + img * B_BYTES + (v - img * B_WI) * 1024 : smem + DUMP;
+      if (img == 1)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(lrs, dst, 16, off, 0, 0, 0);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(hrs, dst, 16, off, 0, 0, 0);
     }
   };
 
@@ -202,34 +209,51 @@ __global__ __launch_bounds__(256) void conv_gemm_f16x3_kernel(const CsConvGemm p
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  __syncthreads();   // rowoff table complete
-  int tap = 0, cc = 0;
-  load_chunk(tap, cc);
-  store_chunk(0);
-  __syncthreads();
-
-  for (int kc = 0; kc < nk; ++kc) {
-    const int buf = kc & 1;
-    // K order: channel chunk OUTER, tap INNER (the 27 taps of one 16-channel chunk re-touch only this
-    // tile's rows + halo, so they hit L1/L2).  The prefetch after the last chunk runs past cin16 and reads 0.
-    if (++tap == ntaps) {
-      tap = 0;
-      ++cc;
+  // DMA stream position (chunk index q -> tap = q % ntaps, cc = q / ntaps), two chunks ahead of compute
+  int dtap = 0, dcc = 0;
+  auto advance = [&]() {
+    if (++dtap == ntaps) {
+      dtap = 0;
+      ++dcc;
     }
-    if (!(CS_ABLATE & 1)) load_chunk(tap, cc);
-    const _Float16* s = smem + ((CS_ABLATE & 4) ? 0 : buf * STAGE);
+  };
+  issue_dma(dtap, dcc, 0);
+  advance();
+  issue_dma(dtap, dcc, 1);
+  advance();
+
+  // fragment addressing
+  int a_frag[WMB][2];
+#pragma unroll
+  for (int i = 0; i < WMB; ++i) {
+    const int row = wm0 + 32 * i + l31;
+    const int s = (row >> 2) & 3;
+    a_frag[i][0] = row * 64 + (((2 * half) ^ s) * 16);
+    a_frag[i][1] = row * 64 + (((2 * half + 1) ^ s) * 16);
+  }
+  const int b_frag = A_BYTES + (half * BN + wn0 + l31) * 16;
+
+  int stage = 0, dstage = 2;
+  for (int kc = 0; kc < nk; ++kc) {
+    wait_vmcnt<D>();                              // this wave's share of chunk kc has landed
+    if (!(CS_ABLATE & 8)) __builtin_amdgcn_s_barrier();   // everyone's share landed; everyone left chunk kc-1
+    if (!(CS_ABLATE & 1)) issue_dma(dtap, dcc, dstage);   // chunk kc+2 -> the stage chunk kc-1 just vacated
+    advance();
+    dstage = (dstage == NSTAGE - 1) ? 0 : dstage + 1;
+
+    const unsigned char* s = smem + stage * STAGE;
+    stage = (stage == NSTAGE - 1) ? 0 : stage + 1;
     h8 ah[WMB], al[WMB];
 #pragma unroll
     for (int i = 0; i < WMB; ++i) {
-      const int off = (wm0 + 32 * i + l31) * AROW + 8 * half;
-      ah[i] = *reinterpret_cast<const h8*>(s + off);
-      al[i] = *reinterpret_cast<const h8*>(s + A_SZ + off);
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(s + a_frag[i][0]);
+      const f32x4 x1 = *reinterpret_cast<const f32x4*>(s + a_frag[i][1]);
+      split8(x0, x1, ah[i], al[i]);
     }
 #pragma unroll
     for (int j = 0; j < WNB; ++j) {
-      const int off = (half * BN + wn0 + 32 * j + l31) * 8;
-      const h8 bh = *reinterpret_cast<const h8*>(s + 2 * A_SZ + off);
-      const h8 bl = *reinterpret_cast<const h8*>(s + 2 * A_SZ + B_SZ + off);
+      const h8 bh = *reinterpret_cast<const h8*>(s + b_frag + j * 512);
+      const h8 bl = *reinterpret_cast<const h8*>(s + b_frag + B_BYTES + j * 512);
 #pragma unroll
       for (int i = 0; i < WMB; ++i) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh, acc[i][j], 0, 0, 0);
@@ -237,9 +261,8 @@ __global__ __launch_bounds__(256) void conv_gemm_f16x3_kernel(const CsConvGemm p
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh, acc[i][j], 0, 0, 0);
       }
     }
-    if (!(CS_ABLATE & 2)) store_chunk(buf ^ 1);
-    if (!(CS_ABLATE & 8)) __syncthreads();
   }
+  wait_vmcnt<0>();   // drain the two zero-fill prefetches issued past the end before LDS is released
 
   // ---- epilogue (identical contract to the fp32 kernel, after undoing the operand scales) ----
 #pragma unroll
@@ -314,8 +337,10 @@ __global__ __launch_bounds__(256) void pack_f16x3_kernel(const float* __restrict
 // called from cs_conv_gemm (cs_gemm.hip) when desc->math == CS_MATH_F16X3; arguments already validated
 int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p, int M, int tile, hipStream_t s) {
   if (!p.w_lo || !(p.acc_scale > 0.f)) return CS_EINVAL;
-  if (p.kd * p.kh * p.kw > 27) return CS_EINVAL;                                   // LDS row table extent
+  if (p.kd * p.kh * p.kw > MAX_TAPS) return CS_EINVAL;                             // LDS row table extent
   if ((int64_t)p.nb * p.din * p.hin * p.win > 0x7fffffffLL) return CS_EINVAL;      // int32 row indices
+  // 16-bit row deltas: the farthest tap is (kd-1) planes + (kh-1) rows + (kw-1) voxels from the window origin
+  if ((int64_t)(p.kd - 1) * p.hin * p.win + (int64_t)(p.kh - 1) * p.win + p.kw > 32000) return CS_EINVAL;
   if (((uintptr_t)p.w & 15) || ((uintptr_t)p.w_lo & 15)) return CS_EINVAL;
   switch (tile) {
     case 1: return launch16<2, 2, 2, 2>(p, M, s);
