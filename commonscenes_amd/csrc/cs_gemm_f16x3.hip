@@ -16,8 +16,8 @@
 //     by the consuming wave right before its MFMAs (VALU work that overlaps the other wave's MFMAs);
 //   * zero padding (out-of-image taps, rows past M, channels past cin, columns past cout) is an out-of-range
 //     buffer offset: the buffer unit writes zeros, the loop stays one basic block.
-// Pipeline: 3-stage LDS ring, prefetch distance 2, one raw s_barrier per K-chunk, counted vmcnt:
-//     wait vmcnt(D) [chunk k landed, chunk k+1 may fly] ; s_barrier ; issue DMA(k+2) ; MFMAs on chunk k
+// Pipeline: 3-stage LDS ring, one raw s_barrier per K-chunk, counted vmcnt (DMAs stay in flight across it):
+//     wait vmcnt(B_PW) [A(k+1) and older landed] ; s_barrier ; MFMAs on chunk k || issue DMA(k+2), split A(k+1)
 // K order: channel chunk OUTER, tap INNER (the 27 taps of one 16-channel chunk re-touch only this tile's rows
 // + halo, so they hit L1/L2 instead of re-streaming the activation tensor per tap).
 // fp16 32x32x16 operand map: lane l holds row/col l&31 and k = 8*(l>>5) .. 8*(l>>5)+7; C/D as for fp32.
@@ -233,23 +233,33 @@ __global__ __launch_bounds__(256) void conv_gemm_f16x3_kernel(const CsConvGemm p
   }
   const int b_frag = A_BYTES + (half * BN + wn0 + l31) * 16;
 
-  int stage = 0, dstage = 2;
-  for (int kc = 0; kc < nk; ++kc) {
-    wait_vmcnt<D>();                              // this wave's share of chunk kc has landed
-    if (!(CS_ABLATE & 8)) __builtin_amdgcn_s_barrier();   // everyone's share landed; everyone left chunk kc-1
-    if (!(CS_ABLATE & 1)) issue_dma(dtap, dcc, dstage);   // chunk kc+2 -> the stage chunk kc-1 just vacated
-    advance();
-    dstage = (dstage == NSTAGE - 1) ? 0 : dstage + 1;
-
-    const unsigned char* s = smem + stage * STAGE;
-    stage = (stage == NSTAGE - 1) ? 0 : stage + 1;
-    h8 ah[WMB], al[WMB];
+  // Software pipeline: the hi/lo split of chunk k+1's A fragment runs inside chunk k's MFMA stream.
+  //   top of iteration k : outstanding DMAs (oldest first) = [B(k) leftovers] A(k+1) B(k+1)
+  //   wait vmcnt(B_PW)   : everything up to A(k+1) has landed, only B(k+1) may still fly
+  //   s_barrier          : ... for every wave; every wave has also left iteration k-1
+  //   issue A(k+2), B(k+2) into the stage iteration k-1 vacated (A first, so the next wait covers it)
+  //   MFMAs on B(k) with the already-split A(k)  ||  read + split A(k+1)
+  auto load_a = [&](int st, h8 (&hi)[WMB], h8 (&lo)[WMB]) {
+    const unsigned char* s = smem + st * STAGE;
 #pragma unroll
     for (int i = 0; i < WMB; ++i) {
       const f32x4 x0 = *reinterpret_cast<const f32x4*>(s + a_frag[i][0]);
       const f32x4 x1 = *reinterpret_cast<const f32x4*>(s + a_frag[i][1]);
-      split8(x0, x1, ah[i], al[i]);
+      split8(x0, x1, hi[i], lo[i]);
     }
+  };
+  h8 ah[WMB], al[WMB];
+  wait_vmcnt<D>();                     // chunk 0 (issued first) has landed for this wave
+  __builtin_amdgcn_s_barrier();
+  load_a(0, ah, al);
+
+  int stage = 0, dstage = 2;
+  for (int kc = 0; kc < nk; ++kc) {
+    wait_vmcnt<B_PW>();
+    if (!(CS_ABLATE & 8)) __builtin_amdgcn_s_barrier();
+    const unsigned char* s = smem + stage * STAGE;
+    const int nstage = (stage == NSTAGE - 1) ? 0 : stage + 1;
+    h8 ah2[WMB], al2[WMB];
 #pragma unroll
     for (int j = 0; j < WNB; ++j) {
       const h8 bh = *reinterpret_cast<const h8*>(s + b_frag + j * 512);
@@ -260,7 +270,19 @@ __global__ __launch_bounds__(256) void conv_gemm_f16x3_kernel(const CsConvGemm p
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl, acc[i][j], 0, 0, 0);
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh, acc[i][j], 0, 0, 0);
       }
+      if (j == 0) {                    // behind the first MFMAs: launch the prefetch, then split A(k+1)
+        if (!(CS_ABLATE & 1)) issue_dma(dtap, dcc, dstage);
+        advance();
+        dstage = (dstage == NSTAGE - 1) ? 0 : dstage + 1;
+        load_a(nstage, ah2, al2);
+      }
     }
+#pragma unroll
+    for (int i = 0; i < WMB; ++i) {
+      ah[i] = ah2[i];
+      al[i] = al2[i];
+    }
+    stage = nstage;
   }
   wait_vmcnt<0>();   // drain the two zero-fill prefetches issued past the end before LDS is released
 
