@@ -49,8 +49,9 @@ def parse():
     ap.add_argument("--ddim-steps", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-objects", type=int, default=4, help="objects in the bounded CPU-baseline sample")
-    ap.add_argument("--math", choices=["fp32", "f16x3"], default=os.environ.get("CS_MATH", "fp32"),
+    ap.add_argument("--math", choices=["fp32", "f16x3"], default=os.environ.get("CS_MATH", "f16x3"),
                     help="GEMM numerics: fp32-input MFMA, or fp32 carried as fp16 hi/lo pairs on the fp16 MFMA")
+    ap.add_argument("--gemm-table", action="store_true", help="print per-shape GEMM timings to stderr (debug)")
     ap.add_argument("--small", action="store_true", help="reduced-width UNet (debug only; result is not the metric)")
     return ap.parse_args()
 
@@ -189,6 +190,18 @@ def main():
         all_ms = sum(r["e0"].elapsed_time(r["e1"]) for r in prof)
         all_fl = sum(r["flops"] for r in prof)
         achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        if a.gemm_table:
+            agg = {}
+            for r in prof:
+                k = (r["taps"], r["m"], r["k"], r["n"], r["tile"])
+                t = agg.setdefault(k, [0, 0.0, 0.0])
+                t[0] += 1
+                t[1] += r["e0"].elapsed_time(r["e1"])
+                t[2] += r["flops"]
+            print(f"{'taps':>4} {'M':>7} {'K':>6} {'N':>6} tile {'calls':>5} {'ms/step':>8} {'TF/s':>7}", file=sys.stderr)
+            for k, t in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                print(f"{k[0]:4d} {k[1]:7d} {k[2]:6d} {k[3]:6d} {k[4]:4d} {t[0]:5d} {t[1] / a.steps:8.3f} "
+                      f"{t[2] / t[1] / 1e9:7.1f}", file=sys.stderr)
         if a.math == "f16x3":
             # three fp16 MFMA passes per fp32-grade product: the pipe ceiling for ALGORITHMIC flops is 2.5 PF / 3
             peak, kname = F16_MFMA_PEAK_TFLOPS / 3.0, ("conv_gemm_f16x3_kernel<1,7,4,1> (128x224-tile implicit "
