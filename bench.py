@@ -202,6 +202,10 @@ def main():
             for k, t in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                 print(f"{k[0]:4d} {k[1]:7d} {k[2]:6d} {k[3]:6d} {k[4]:4d} {t[0]:5d} {t[1] / a.steps:8.3f} "
                       f"{t[2] / t[1] / 1e9:7.1f}", file=sys.stderr)
+        traffic = None
+        tf = ROOT / "profiles" / ("r01_traffic_f16x3.json" if a.math == "f16x3" else "r01_traffic_fp32.json")
+        if tf.exists() and B == 32 and not a.small:       # PMC passes cannot run inside this process: the figure is
+            traffic = json.loads(tf.read_text())["hbm_bytes_per_launch"]   # the committed rocprofv3 --pmc result
         if a.math == "f16x3":
             # three fp16 MFMA passes per fp32-grade product: the pipe ceiling for ALGORITHMIC flops is 2.5 PF / 3
             peak, kname = F16_MFMA_PEAK_TFLOPS / 3.0, ("conv_gemm_f16x3_kernel<1,7,4,1> (128x224-tile implicit "
@@ -225,7 +229,10 @@ def main():
                        "objects_per_gpu": B, "unet_batch": 2 * B, "ddim_steps": S,
                        "parallelism": f"object-sharded x{world} (replicated weights, no per-step collective)"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": None, "kernel": kname, "math": a.math,
+                         "frac": achieved / peak, "traffic": traffic,
+                         "traffic_note": "HBM bytes per launch of the dominant kernel, FETCH_SIZE x2 (gfx950) + WRITE_SIZE, "
+                                         "from profiles/r01_traffic_*.json (separate rocprofv3 --pmc passes of this command)",
+                         "kernel": kname, "math": a.math,
                          "launches": len(conv), "avg_launch_ms": conv_ms / max(len(conv), 1),
                          "algorithmic_gflop_per_launch": conv_fl / max(len(conv), 1) / 1e9,
                          "share_of_step_time": conv_ms / (dt * 1e3),

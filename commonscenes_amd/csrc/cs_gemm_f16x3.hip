@@ -12,8 +12,9 @@
 //   * weights are split offline (cs_pack_weight_f16x3) into hi / lo images laid out [tap][k/8][n][8 halves]
 //     = the MFMA B-fragment order, so a B tile is a straight 16-byte-per-lane DMA;
 //   * activations arrive as raw fp32 rows ([m][16 ch] = 64 B, 16-byte pieces XOR-swizzled by (m>>2)&3 on the
-//     SOURCE address so the fragment reads are conflict-free) and are split into hi / lo fp16 with scale 2^6
-//     by the consuming wave right before its MFMAs (VALU work that overlaps the other wave's MFMAs);
+//     SOURCE address so the fragment reads are conflict-free) and are split into hi / lo fp16
+//     (scale a_scale, default 2^4)
+//     by the consuming wave inside the previous chunk's MFMA stream (VALU work that overlaps the other wave's MFMAs);
 //   * zero padding (out-of-image taps, rows past M, channels past cin, columns past cout) is an out-of-range
 //     buffer offset: the buffer unit writes zeros, the loop stays one basic block.
 // Pipeline: 3-stage LDS ring, one raw s_barrier per K-chunk, counted vmcnt (DMAs stay in flight across it):
@@ -28,16 +29,16 @@ namespace {
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 constexpr int BKH = 16;       // K elements per chunk
-constexpr float A_SCALE = 64.0f;
+constexpr float A_SCALE_DEFAULT = 16.0f;
 constexpr unsigned OOB = 0xFFF00000u;   // byte offset past every buffer (extents are < 0xFFE00000): reads 0
 constexpr int MAX_TAPS = 27;
 #ifndef CS_ABLATE
 #define CS_ABLATE 0   // debug: 1 = no DMA issue, 8 = no barrier
 #endif
 
-__device__ __forceinline__ void split8(const f32x4& x, const f32x4& y, h8& hi, h8& lo) {
-  const float v[8] = {x[0] * A_SCALE, x[1] * A_SCALE, x[2] * A_SCALE, x[3] * A_SCALE,
-                      y[0] * A_SCALE, y[1] * A_SCALE, y[2] * A_SCALE, y[3] * A_SCALE};
+__device__ __forceinline__ void split8(const f32x4& x, const f32x4& y, float a_scale, h8& hi, h8& lo) {
+  const float v[8] = {x[0] * a_scale, x[1] * a_scale, x[2] * a_scale, x[3] * a_scale,
+                      y[0] * a_scale, y[1] * a_scale, y[2] * a_scale, y[3] * a_scale};
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const _Float16 h = (_Float16)v[i];
@@ -147,6 +148,7 @@ __global__ __launch_bounds__(256) void conv_gemm_f16x3_kernel(const CsConvGemm p
   }
   __syncthreads();
 
+  const float a_scale = p.a_scale;
   const int chunks_per_tap = kg_per_tap >> 1;   // cin16 / 16
   const int nk = ntaps * chunks_per_tap;
 
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(256) void conv_gemm_f16x3_kernel(const CsConvGemm p
     for (int i = 0; i < WMB; ++i) {
       const f32x4 x0 = *reinterpret_cast<const f32x4*>(s + a_frag[i][0]);
       const f32x4 x1 = *reinterpret_cast<const f32x4*>(s + a_frag[i][1]);
-      split8(x0, x1, hi[i], lo[i]);
+      split8(x0, x1, a_scale, hi[i], lo[i]);
     }
   };
   h8 ah[WMB], al[WMB];
@@ -357,8 +359,10 @@ __global__ __launch_bounds__(256) void pack_f16x3_kernel(const float* __restrict
 }  // namespace
 
 // called from cs_conv_gemm (cs_gemm.hip) when desc->math == CS_MATH_F16X3; arguments already validated
-int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p, int M, int tile, hipStream_t s) {
-  if (!p.w_lo || !(p.acc_scale > 0.f)) return CS_EINVAL;
+int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p_in, int M, int tile, hipStream_t s) {
+  CsConvGemm p = p_in;
+  if (p.a_scale == 0.f) p.a_scale = A_SCALE_DEFAULT;
+  if (!p.w_lo || !(p.acc_scale > 0.f) || !(p.a_scale > 0.f)) return CS_EINVAL;
   if (p.kd * p.kh * p.kw > MAX_TAPS) return CS_EINVAL;                             // LDS row table extent
   if ((int64_t)p.nb * p.din * p.hin * p.win > 0x7fffffffLL) return CS_EINVAL;      // int32 row indices
   // 16-bit row deltas: the farthest tap is (kd-1) planes + (kh-1) rows + (kw-1) voxels from the window origin

@@ -42,7 +42,7 @@ class CsConvGemm(C.Structure):
         ("pd", C.c_int32), ("ph", C.c_int32), ("pw", C.c_int32),
         ("ud", C.c_int32), ("uh", C.c_int32), ("uw", C.c_int32),
         ("act", C.c_int32), ("rv_rows", C.c_int32), ("math", C.c_int32), ("tile", C.c_int32),
-        ("w_lo", C.c_void_p), ("acc_scale", C.c_float), ("reserved", C.c_int32),
+        ("w_lo", C.c_void_p), ("acc_scale", C.c_float), ("a_scale", C.c_float),
     ]
 
 

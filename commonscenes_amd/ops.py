@@ -97,6 +97,9 @@ def pack_weight(w: Tensor, bias: Optional[Tensor] = None, cin_pad: Optional[int]
     return PackedWeight(wt, b, cout, cin, cp, ldw, (kd, kh, kw))
 
 
+A_SCALE = 16.0      # activation pre-scale of the f16x3 mode (CsConvGemm.a_scale); power of two
+
+
 def _pack_weight_f16x3(w: Tensor, bias: Optional[Tensor], cin_pad: Optional[int]) -> PackedWeight:
     """fp32 weight -> (hi, lo) fp16 halves of w * 2^s with max|w| * 2^s < 2^14 (cs_pack_weight_f16x3)."""
     import math as _m
@@ -123,7 +126,7 @@ def _pack_weight_f16x3(w: Tensor, bias: Optional[Tensor], cin_pad: Optional[int]
     if bias is not None:
         _chk(bias, "bias")
         b = bias.contiguous()
-    return PackedWeight(None, b, cout, cin, cp, cout, (kd, kh, kw), L.MATH_F16X3, wh, wl, 1.0 / (scale * 64.0))
+    return PackedWeight(None, b, cout, cin, cp, cout, (kd, kh, kw), L.MATH_F16X3, wh, wl, 1.0 / (scale * A_SCALE))
 
 
 def conv_gemm(x: Tensor, w: PackedWeight, *, spatial: Optional[Tuple[int, int, int, int]] = None,
@@ -173,6 +176,7 @@ def conv_gemm(x: Tensor, w: PackedWeight, *, spatial: Optional[Tuple[int, int, i
     if math == L.MATH_F16X3:
         p.x, p.w, p.w_lo, p.out = x.data_ptr(), w.wh.data_ptr(), w.wl.data_ptr(), out.data_ptr()
         p.acc_scale = w.acc_scale
+        p.a_scale = A_SCALE
     else:
         p.x, p.w, p.out = x.data_ptr(), w.wt.data_ptr(), out.data_ptr()
     p.bias = _ptr(w.bias)

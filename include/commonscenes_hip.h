@@ -80,10 +80,12 @@ typedef struct CsConvGemm {
   int32_t math;       /* CS_MATH_* */
   int32_t tile;       /* 0 = auto, 1 = 128x128, 2 = 128x224, 3 = 64x64 */
   /* CS_MATH_F16X3 only: w = hi halves, w_lo = lo halves, both laid out [tap][cin16/8][cout][8] by
-   * cs_pack_weight_f16x3 (cin16 = cin rounded up to 16); acc_scale = 1 / (weight_scale * 64).  */
+   * cs_pack_weight_f16x3 (cin16 = cin rounded up to 16).  Activations are multiplied by a_scale (a power of
+   * two; 0 means the default 16) before the fp16 split: |a| * a_scale must stay below 65504, and values
+   * below 2^-14 / a_scale lose relative (not absolute) precision.  acc_scale = 1 / (weight_scale * a_scale). */
   const void* w_lo;
   float acc_scale;
-  int32_t reserved;
+  float a_scale;
 } CsConvGemm;
 
 int cs_conv_gemm(const CsConvGemm* desc, cs_stream_t stream);
@@ -108,7 +110,7 @@ int cs_relayout_weight(const float* w_torch, float* w_out, int cout, int cin, in
  *   hi = fp16(v'), lo = fp16(v' - hi)  (22 mantissa bits together), and the contraction evaluates
  *   a.w ~= (a_hi.w_hi + a_hi.w_lo + a_lo.w_hi) * 2^-(s_a + s_w) with three v_mfma_f32_32x32x16_f16 per
  * K=16 step, fp32 accumulation (each fp16 x fp16 product is exact in fp32).  Activations are split on the
- * fly inside the GEMM loader with s_a = 6; `scale` = 2^s_w is chosen by the caller so that
+ * fly inside the GEMM (scale CsConvGemm.a_scale, default 2^4); `scale` = 2^s_w is chosen by the caller so that
  * max|w| * scale <= 2^14.  Output layout: [tap][cin16/8][cout][8] halves, cin16 = round_up(cin, 16).
  */
 int cs_pack_weight_f16x3(const float* w_torch, void* w_hi, void* w_lo, int cout, int cin, int taps,
