@@ -116,6 +116,9 @@ def main():
         def apply_model(self, x, t, c):
             return df(x, t, c_crossattn=[c])
 
+        def apply_model_cfg(self, x, t, c_in):
+            return df.forward_cfg(x, t, c_in)
+
     # ---- conditioning: rank 0 runs the scene-graph GCN for all world*B objects, broadcast over RCCL ----
     B = a.objects
     total = B * world

@@ -146,9 +146,14 @@ class DDIMSampler(object):
         """One fused DDIM step; c_in is [uc; c] when cfg is on."""
         b = x.shape[0]
         nb = 2 * b if cfg else b
-        t_in = torch.full((nb,), step, device=x.device, dtype=torch.long)
-        x_in = torch.cat([x, x]) if cfg else x
-        eps = self.model.apply_model(x_in, t_in, c_in)
+        fast = getattr(self.model, "apply_model_cfg", None) if cfg else None
+        if fast is not None:
+            # the two guidance halves share (x, t): let the model evaluate the context-free prefix once
+            eps = fast(x, torch.full((b,), step, device=x.device, dtype=torch.long), c_in)
+        else:
+            t_in = torch.full((nb,), step, device=x.device, dtype=torch.long)
+            x_in = torch.cat([x, x]) if cfg else x
+            eps = self.model.apply_model(x_in, t_in, c_in)
         sigma = float(self.ddim_sigmas[index])
         noise = torch.randn_like(x) if sigma != 0.0 else None     # eta == 0: sigma_t * noise == 0 exactly
         return ops.ddim_cfg_update(x, eps, float(self.ddim_alphas[index]), float(self.ddim_alphas_prev[index]),

@@ -319,7 +319,14 @@ def concat_channels(a: Tensor, b: Tensor) -> Tensor:
     ca, cb = a.shape[-1], b.shape[-1]
     out = torch.empty((*a.shape[:-1], ca + cb), dtype=torch.float32, device=a.device)
     copy_rows(a, out[..., :ca])
-    copy_rows(b, out[..., ca:])
+    if b.shape[0] == a.shape[0]:
+        copy_rows(b, out[..., ca:])
+    elif a.shape[0] % b.shape[0] == 0:           # b shared by a.shape[0] / b.shape[0] groups of samples (CFG pairs)
+        nb = b.shape[0]
+        for g in range(a.shape[0] // nb):
+            copy_rows(b, out[g * nb:(g + 1) * nb, ..., ca:])
+    else:
+        raise L.CsError("concat_channels: batch mismatch")
     return out
 
 

@@ -155,6 +155,10 @@ class SDFusionText2ShapeModel:
         key = "c_concat" if self.df_module.conditioning_key == "concat" else "c_crossattn"
         return self.df(x_noisy, t, **{key: cond})
 
+    def apply_model_cfg(self, x, t, c_in):
+        """[eps_uc; eps_c] for the guidance pair batch (ddim.py:206-209) without duplicating (x, t)."""
+        return self.df.forward_cfg(x, t, c_in)
+
     @torch.no_grad()
     def rel2shape(self, data, ddim_steps=100, ddim_eta=0.0, uc_scale=None, x_T: Optional[Tensor] = None,
                   mini_B: Optional[int] = None, return_latents: bool = False, max_steps: Optional[int] = None):

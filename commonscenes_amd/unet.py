@@ -396,8 +396,14 @@ class DiffusionUNet:
         return h
 
     @torch.no_grad()
-    def forward_ndhwc(self, h: Tensor, t: Tensor, ctx: Tensor) -> Tensor:
-        """x as [nb, d, h, w, cpad(4)] channels-last -> eps [nb, d, h, w, out_channels]."""
+    def forward_ndhwc(self, h: Tensor, t: Tensor, ctx: Tensor, cfg_pairs: bool = False) -> Tensor:
+        """x as [nb, d, h, w, cpad(4)] channels-last -> eps [nb, d, h, w, out_channels].
+
+        cfg_pairs=True: classifier-free guidance evaluates the SAME (x, t) under two contexts
+        (samplers/ddim.py:206-209 builds x_in = cat([x] * 2)).  Everything upstream of the first
+        cross-attention depends on (x, t) only, so `h`, `t` are passed once (B samples), ctx holds the 2B
+        contexts [uc; c], the prefix blocks run at batch B and their outputs are shared by both halves.
+        Per-sample results are bit-identical to running the duplicated batch (rows never mix)."""
         if self._packed is None:
             self._pack()
         sd, pk, P = self._sd, self._packed, self.prefix
@@ -410,21 +416,42 @@ class DiffusionUNet:
         ctx = self._context_vectors(ctx)
         hs: List[Tensor] = []
         tr = self.trace
+        shared = cfg_pairs          # True while h still holds one copy per (x, t) pair
         for i, layers in enumerate(inp):
+            if shared and any(l["kind"] == "attn" for l in layers):
+                h = torch.cat([h, h], dim=0)          # first context-dependent block: split into [uc; c]
+                semb = torch.cat([semb, semb], dim=0)
+                shared = False
             h = self._run(f"{P}input_blocks.{i}", layers, h, semb, ctx)
             hs.append(h)
             if tr is not None:
                 tr[f"input_blocks.{i}"] = h
+        if shared:
+            h = torch.cat([h, h], dim=0)
+            semb = torch.cat([semb, semb], dim=0)
         h = self._run(P + "middle_block", mid, h, semb, ctx)
         if tr is not None:
             tr["middle_block"] = h
         for i, layers in enumerate(out):
-            h = ops.concat_channels(h, hs.pop())
+            h = ops.concat_channels(h, hs.pop())      # a shared (B-sized) skip tensor feeds both halves
             h = self._run(f"{P}output_blocks.{i}", layers, h, semb, ctx)
             if tr is not None:
                 tr[f"output_blocks.{i}"] = h
         hn = ops.groupnorm(h, sd[P + "out.0.weight"], sd[P + "out.0.bias"], 32, 1e-5, L.ACT_SILU)
         return ops.conv_gemm(hn, pk[P + "out.2"], math=self.math)
+
+    @torch.no_grad()
+    def forward_cfg(self, x: Tensor, t: Tensor, c_in: Tensor) -> Tensor:
+        """eps for the classifier-free-guidance pair batch without duplicating (x, t):
+        x (B,C,D,H,W), t (B,), c_in (2B,1,ctx) = [uc; c]  ->  (2B,C,D,H,W) = [eps_uc; eps_c]."""
+        if self.conditioning_key != "crossattn":
+            raise NotImplementedError("forward_cfg: crossattn conditioning only")
+        ctx = c_in.to(dtype=torch.float32).contiguous()
+        if ctx.shape[0] != 2 * x.shape[0]:
+            raise ValueError("c_in must hold [uc; c] for every sample of x")
+        h = ops.nchw_to_ndhwc(x.to(torch.float32), cpad=(self.cfg["in_channels"] + 3) // 4 * 4)
+        eps = self.forward_ndhwc(h, t.to(torch.int64).contiguous(), ctx, cfg_pairs=True)
+        return ops.ndhwc_to_nchw(eps)
 
     @torch.no_grad()
     def forward(self, x: Tensor, t: Tensor, c_concat: Optional[list] = None,

@@ -312,3 +312,21 @@ def test_rel2shape_minibatch_and_shared_noise_semantics(tmp_path):
     assert torch.equal(la, lb) and torch.equal(a, b)
     assert torch.equal(la[0], la[8]) and torch.equal(a[0], a[8])
     assert not torch.equal(la[0], la[1])
+
+
+def test_forward_cfg_shares_the_context_free_prefix_exactly():
+    """forward_cfg(x, t, [uc; c]) == forward(cat[x,x], cat[t,t], [uc; c]) bit for bit (fp32 and f16x3)."""
+    from commonscenes_amd import synth
+    df = _unet(True)
+    B = 3
+    x = synth.gaussian_like("cfg:x", (B, 3, 16, 16, 16)).cuda()
+    t = torch.tensor([771, 771, 771], dtype=torch.long).cuda()
+    c_in = synth.gaussian_like("cfg:c", (2 * B, 1, 1280)).cuda()
+    for mode in ("fp32", "f16x3"):
+        df.set_math(mode)
+        a = df.forward_cfg(x, t, c_in)
+        b = df(torch.cat([x, x]), torch.cat([t, t]), c_crossattn=[c_in])
+        torch.cuda.synchronize()
+        assert a.shape == b.shape == (2 * B, 3, 16, 16, 16)
+        assert torch.equal(a, b), mode
+    df.set_math("fp32")
