@@ -270,12 +270,15 @@ extern "C" int cs_conv_gemm(const CsConvGemm* d, cs_stream_t stream) {
   const int M = (int)M64;
   int tile = p.tile;
   if (tile == 0) {
-    if (p.cout % 224 == 0 && M >= 2048)
+    // largest tile that still gives every one of the 256 CUs a workgroup; small problems take the 64x64 tile
+    // (measured at CFG batch 2: 64x64 is ~2x the 128x224 tile, which leaves 3/4 of the chip idle)
+    const int64_t mt = (M + 127) / 128;
+    if (p.cout % 224 == 0 && mt * (p.cout / 224) >= 256)
       tile = 2;
-    else if (p.cout <= 64 || (int64_t)((M + 127) / 128) * ((p.cout + 127) / 128) < 128)
-      tile = 3;
-    else
+    else if (p.cout > 64 && mt * ((p.cout + 127) / 128) >= 256)
       tile = 1;
+    else
+      tile = 3;
   }
   hipStream_t s = (hipStream_t)stream;
   if (f16x3) return cs_conv_gemm_f16x3_dispatch(p, M, tile, s);

@@ -23,6 +23,7 @@
 // + halo, so they hit L1/L2 instead of re-streaming the activation tensor per tap).
 // fp16 32x32x16 operand map: lane l holds row/col l&31 and k = 8*(l>>5) .. 8*(l>>5)+7; C/D as for fp32.
 #include "cs_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -255,13 +256,19 @@ __global__ __launch_bounds__(256) void conv_gemm_f16x3_kernel(const CsConvGemm p
   __builtin_amdgcn_s_barrier();
   load_a(0, ah, al);
 
-  int stage = 0, dstage = 2;
-  for (int kc = 0; kc < nk; ++kc) {
+  // One ring position per call, with the stage a compile-time constant: every LDS address (fragment reads and
+  // the DMA destinations that go through M0) folds to an immediate instead of per-iteration scalar arithmetic.
+  auto step = [&](auto stage_c) {
+    constexpr int stage = decltype(stage_c)::value;
+    constexpr int nstage = (stage + 1) % NSTAGE;
+    constexpr int dstage = (stage + 2) % NSTAGE;
     wait_vmcnt<B_PW>();
     if (!(CS_ABLATE & 8)) __builtin_amdgcn_s_barrier();
     const unsigned char* s = smem + stage * STAGE;
-    const int nstage = (stage == NSTAGE - 1) ? 0 : stage + 1;
     h8 ah2[WMB], al2[WMB];
+#if CS_ABLATE & 16
+    __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int j = 0; j < WNB; ++j) {
       const h8 bh = *reinterpret_cast<const h8*>(s + b_frag + j * 512);
@@ -275,16 +282,22 @@ __global__ __launch_bounds__(256) void conv_gemm_f16x3_kernel(const CsConvGemm p
       if (j == 0) {                    // behind the first MFMAs: launch the prefetch, then split A(k+1)
         if (!(CS_ABLATE & 1)) issue_dma(dtap, dcc, dstage);
         advance();
-        dstage = (dstage == NSTAGE - 1) ? 0 : dstage + 1;
         load_a(nstage, ah2, al2);
       }
     }
+#if CS_ABLATE & 16
+    __builtin_amdgcn_s_setprio(0);
+#endif
 #pragma unroll
     for (int i = 0; i < WMB; ++i) {
       ah[i] = ah2[i];
       al[i] = al2[i];
     }
-    stage = nstage;
+  };
+  for (int kc = 0; kc < nk; kc += NSTAGE) {
+    step(std::integral_constant<int, 0>{});
+    if (kc + 1 < nk) step(std::integral_constant<int, 1>{});
+    if (kc + 2 < nk) step(std::integral_constant<int, 2>{});
   }
   wait_vmcnt<0>();   // drain the two zero-fill prefetches issued past the end before LDS is released
 

@@ -228,11 +228,12 @@ def tile_for(m: int, cout: int, tile: int = 0) -> int:
     """mirror of the tile auto-selection in cs_conv_gemm (csrc/cs_gemm.hip)."""
     if tile:
         return tile
-    if cout % 224 == 0 and m >= 2048:
+    mt = (m + 127) // 128
+    if cout % 224 == 0 and mt * (cout // 224) >= 256:
         return 2
-    if cout <= 64 or ((m + 127) // 128) * ((cout + 127) // 128) < 128:
-        return 3
-    return 1
+    if cout > 64 and mt * ((cout + 127) // 128) >= 256:
+        return 1
+    return 3
 
 
 def linear(x: Tensor, w: PackedWeight, **kw) -> Tensor:

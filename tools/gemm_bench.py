@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--only", type=int, default=-1)
+    ap.add_argument("--tile", type=int, default=0)
     a = ap.parse_args()
     modes = ["fp32", "f16x3"] if a.math == "both" else [a.math]
     for si, (name, sp, cin, cout, k) in enumerate(SHAPES):
@@ -44,12 +45,12 @@ def main():
         line = f"{name:26s} M={a.batch * sp[0] * sp[1] * sp[2]:7d} K={cin * k ** 3:6d} N={cout:5d} "
         for mode in modes:
             pw = ops.pack_weight(w, b, math=L.MATH_F16X3 if mode == "f16x3" else L.MATH_FP32)
-            ops.conv_gemm(x, pw)
+            ops.conv_gemm(x, pw, tile=a.tile)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(a.iters):
-                ops.conv_gemm(x, pw)
+                ops.conv_gemm(x, pw, tile=a.tile)
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / a.iters
