@@ -1,0 +1,267 @@
+// Flash attention with fp32 operands carried as fp16 hi/lo pairs on the fp16 MFMA (CS_MATH_F16X3 companion of
+// cs_attention.hip; same "swapped" formulation, same contract, ~fp32 accuracy at a 5x higher pipe ceiling).
+//
+//   S^T[j][i] = sum_d K[j][d] Q[i][d]   : A = K tile  (LDS, [key][d] fp16 hi/lo images), B = Q (registers, hi/lo)
+//   O^T[d][i] += sum_j V[j][d] P^T[j][i] : A = V^T tile (LDS, [d][key'] fp16 hi/lo images), B = P^T straight from the
+//                                          S^T accumulator registers (split into hi/lo in place)
+// each contraction = 3 v_mfma_f32_32x32x16_f16 (lo*hi + hi*lo + hi*hi), fp32 accumulate.
+//
+// Register -> key map of the 32x32 C/D layout: lane (i = lane&31, h = lane>>5) holds S^T[j][i] for
+// j = (r&3) + 8*(r>>2) + 4*h.  PV MFMA (jb, q) takes registers r = 8q..8q+7 as its 8 k-slots, so k-slot (h, e) is
+// key 32*jb + ((8q+e)&3) + 8*((8q+e)>>2) + 4*h; the V^T image stores key j at column pos(j) = j with bits 2 and 3
+// swapped, which makes those 8 keys one contiguous 16-byte read.
+#include "cs_common.h"
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+constexpr float QK_SCALE = 16.0f;     // operand pre-scale (power of two) for Q*scale, K and V
+constexpr float P_SCALE = 1024.0f;    // probabilities are <= 1
+
+__device__ __forceinline__ void split1(float v, _Float16& hi, _Float16& lo) {
+  hi = (_Float16)v;
+  lo = (_Float16)(v - (float)hi);
+}
+
+__device__ __forceinline__ int vpos(int j) {   // swap bits 2 and 3
+  return (j & ~12) | ((j & 4) << 1) | ((j & 8) >> 1);
+}
+
+template <int DB, int KT>
+__global__ __launch_bounds__(256) void attn_f16x3_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                         const float* __restrict__ v, float* __restrict__ out,
+                                                         int nq, int nk, int heads, int dh, int ldq, int ldk,
+                                                         int ldv, int ldo, float scale, int qtiles) {
+  constexpr int DP = 32 * DB;
+  constexpr int LDK = DP + 8;          // halves; 16 consecutive rows hit 16 distinct 16-byte slots
+  constexpr int LDV = KT + 8;
+  constexpr int JB = KT / 32;
+  constexpr int KS = DP / 16;          // k-steps of the QK^T contraction
+  extern __shared__ __attribute__((aligned(16))) _Float16 sm[];
+  _Float16* Kh = sm;                   // [KT][LDK]
+  _Float16* Kl = Kh + KT * LDK;
+  _Float16* Vh = Kl + KT * LDK;        // [DP][LDV]  (V^T, permuted key order)
+  _Float16* Vl = Vh + DP * LDV;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int l31 = lane & 31;
+  const int half = lane >> 5;
+
+  int bid = blockIdx.x;
+  const int qt = bid % qtiles;
+  bid /= qtiles;
+  const int h = bid % heads;
+  const int b = bid / heads;
+
+  const int q0 = qt * 128 + wave * 32;
+  const int qi = min(q0 + l31, nq - 1);
+  const float* qp = q + ((int64_t)b * nq + qi) * ldq + h * dh;
+  const float* kb = k + (int64_t)b * nk * ldk + h * dh;
+  const float* vb = v + (int64_t)b * nk * ldv + h * dh;
+
+  // Q fragments: qh[t][e] = Q[i][16t + 8*half + e] * scale * QK_SCALE
+  h8 qh[KS], ql[KS];
+#pragma unroll
+  for (int t = 0; t < KS; ++t)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int d = 16 * t + 8 * half + e;
+      const float x = d < dh ? qp[d] * (scale * QK_SCALE) : 0.f;
+      _Float16 a, c;
+      split1(x, a, c);
+      qh[t][e] = a;
+      ql[t][e] = c;
+    }
+
+  // zero the padding (d >= dh) of the K images and the V^T images once
+  for (int u = tid; u < KT * (LDK - dh); u += 256) {
+    const int j = u / (LDK - dh);
+    const int d = dh + (u - j * (LDK - dh));
+    Kh[j * LDK + d] = (_Float16)0.f;
+    Kl[j * LDK + d] = (_Float16)0.f;
+  }
+  for (int u = tid; u < (DP - dh) * LDV; u += 256) {
+    Vh[dh * LDV + u] = (_Float16)0.f;
+    Vl[dh * LDV + u] = (_Float16)0.f;
+  }
+
+  f32x16 oacc[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+  float mrun = -INFINITY;
+  float lrun = 0.f;
+  const float inv_s = 1.0f / (QK_SCALE * QK_SCALE);
+
+  const int dh4 = dh >> 2;
+  for (int kt0 = 0; kt0 < nk; kt0 += KT) {
+    __syncthreads();  // previous tile fully consumed
+    // K tile: unit = (key j, 4 channels); coalesced along d
+    for (int u = tid; u < KT * dh4; u += 256) {
+      const int j = u / dh4;
+      const int c4 = u - j * dh4;
+      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (kt0 + j < nk) kv = *reinterpret_cast<const float4*>(kb + (int64_t)(kt0 + j) * ldk + c4 * 4);
+      h4 hi, lo;
+      _Float16 a, c;
+      split1(kv.x * QK_SCALE, a, c); hi[0] = a; lo[0] = c;
+      split1(kv.y * QK_SCALE, a, c); hi[1] = a; lo[1] = c;
+      split1(kv.z * QK_SCALE, a, c); hi[2] = a; lo[2] = c;
+      split1(kv.w * QK_SCALE, a, c); hi[3] = a; lo[3] = c;
+      *reinterpret_cast<h4*>(Kh + j * LDK + c4 * 4) = hi;
+      *reinterpret_cast<h4*>(Kl + j * LDK + c4 * 4) = lo;
+    }
+    // V tile -> V^T images: unit = (4 channels, key j), key fastest so a wave writes one contiguous row run
+    for (int u = tid; u < KT * dh4; u += 256) {
+      const int c4 = u / KT;
+      const int j = u - c4 * KT;
+      float4 vv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (kt0 + j < nk) vv = *reinterpret_cast<const float4*>(vb + (int64_t)(kt0 + j) * ldv + c4 * 4);
+      const int pj = vpos(j);
+      const float x[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        _Float16 a, c;
+        split1(x[i] * QK_SCALE, a, c);
+        Vh[(c4 * 4 + i) * LDV + pj] = a;
+        Vl[(c4 * 4 + i) * LDV + pj] = c;
+      }
+    }
+    __syncthreads();
+
+    // ---- S^T = K Q^T ----
+    f32x16 sacc[JB];
+#pragma unroll
+    for (int jb = 0; jb < JB; ++jb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[jb][r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < KS; ++t)
+#pragma unroll
+      for (int jb = 0; jb < JB; ++jb) {
+        const int off = (jb * 32 + l31) * LDK + 16 * t + 8 * half;
+        const h8 kh = *reinterpret_cast<const h8*>(Kh + off);
+        const h8 kl = *reinterpret_cast<const h8*>(Kl + off);
+        sacc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[t], sacc[jb], 0, 0, 0);
+        sacc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[t], sacc[jb], 0, 0, 0);
+        sacc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[t], sacc[jb], 0, 0, 0);
+      }
+
+    // ---- online softmax (per query i = lane&31) ----
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int jb = 0; jb < JB; ++jb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = kt0 + jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const float sv = (j < nk) ? sacc[jb][r] * inv_s : -INFINITY;
+        sacc[jb][r] = sv;
+        mloc = fmaxf(mloc, sv);
+      }
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float mnew = fmaxf(mrun, mloc);
+    const float alpha = (mrun == -INFINITY) ? 0.f : expf(mrun - mnew);
+    float psum = 0.f;
+#pragma unroll
+    for (int jb = 0; jb < JB; ++jb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = expf(sacc[jb][r] - mnew);
+        sacc[jb][r] = pv;
+        psum += pv;
+      }
+    lrun = lrun * alpha + psum;
+    mrun = mnew;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+
+    // ---- O^T += V^T P^T ----
+#pragma unroll
+    for (int jb = 0; jb < JB; ++jb)
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) {
+        h8 ph, pl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          _Float16 a, c;
+          split1(sacc[jb][8 * qq + e] * P_SCALE, a, c);
+          ph[e] = a;
+          pl[e] = c;
+        }
+#pragma unroll
+        for (int d = 0; d < DB; ++d) {
+          const int off = (32 * d + l31) * LDV + 32 * jb + 16 * qq + 8 * half;
+          const h8 vh = *reinterpret_cast<const h8*>(Vh + off);
+          const h8 vl = *reinterpret_cast<const h8*>(Vl + off);
+          oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, oacc[d], 0, 0, 0);
+          oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, oacc[d], 0, 0, 0);
+          oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, oacc[d], 0, 0, 0);
+        }
+      }
+  }
+
+  const float ltot = lrun + __shfl_xor(lrun, 32, 64);
+  const float inv = 1.0f / (ltot * QK_SCALE * P_SCALE);
+  if (q0 + l31 < nq) {
+    float* op = out + ((int64_t)b * nq + q0 + l31) * ldo + h * dh;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int dd = 32 * d + 8 * g + 4 * half;
+        if (dd < dh) {
+          float4 o;
+          o.x = oacc[d][4 * g + 0] * inv;
+          o.y = oacc[d][4 * g + 1] * inv;
+          o.z = oacc[d][4 * g + 2] * inv;
+          o.w = oacc[d][4 * g + 3] * inv;
+          *reinterpret_cast<float4*>(op + dd) = o;
+        }
+      }
+  }
+}
+
+template <int DB, int KT>
+int launch_attn16(const float* q, const float* k, const float* v, float* out, int nb, int nq, int nk, int heads,
+                  int dh, int ldq, int ldk, int ldv, int ldo, float scale, hipStream_t s) {
+  constexpr int DP = 32 * DB;
+  const size_t smem = (size_t)(2 * KT * (DP + 8) + 2 * DP * (KT + 8)) * sizeof(_Float16);
+  const int qtiles = (nq + 127) / 128;
+  const int64_t grid = (int64_t)qtiles * heads * nb;
+  if (grid > 0x7fffffffLL) return CS_EINVAL;
+  auto kern = attn_f16x3_kernel<DB, KT>;
+  if (smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+  }
+  CS_LAUNCH(kern, dim3((unsigned)grid), dim3(256), smem, s, q, k, v, out, nq, nk, heads, dh, ldq, ldk, ldv, ldo,
+            scale, qtiles);
+  CS_CHECK_LAUNCH();
+  return CS_OK;
+}
+
+}  // namespace
+
+extern "C" int cs_attn_selfattn_f16x3(const float* q, const float* k, const float* v, float* out, int nb, int nq,
+                                      int nk, int heads, int dh, int ldq, int ldk, int ldv, int ldo, float scale,
+                                      cs_stream_t stream) {
+  if (!q || !k || !v || !out || nb <= 0 || nq <= 0 || nk <= 0 || heads <= 0 || dh <= 0) return CS_EINVAL;
+  if ((dh & 3) || (ldq & 3) || (ldk & 3) || (ldv & 3) || (ldo & 3)) return CS_EINVAL;
+  if (ldq < heads * dh || ldk < heads * dh || ldv < heads * dh || ldo < heads * dh) return CS_EINVAL;
+  if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || ((uintptr_t)out & 15))
+    return CS_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (dh <= 32) return launch_attn16<1, 64>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, s);
+  if (dh <= 64) return launch_attn16<2, 64>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, s);
+  if (dh <= 96) return launch_attn16<3, 64>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, s);
+  if (dh <= 128) return launch_attn16<4, 64>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, s);
+  if (dh <= 256) return launch_attn16<8, 32>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, s);
+  return CS_EINVAL;
+}

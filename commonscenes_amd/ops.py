@@ -274,7 +274,8 @@ def layernorm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5, out: Op
     return out
 
 
-def attention(q: Tensor, k: Tensor, v: Tensor, heads: int, scale: float, out: Optional[Tensor] = None) -> Tensor:
+def attention(q: Tensor, k: Tensor, v: Tensor, heads: int, scale: float, out: Optional[Tensor] = None,
+              math: int = L.MATH_FP32) -> Tensor:
     """q: [nb, nq, heads*dh] (views with wider row stride allowed), k/v: [nb, nk, heads*dh]."""
     for t, n in ((q, "q"), (k, "k"), (v, "v")):
         _chk(t, n)
@@ -289,8 +290,9 @@ def attention(q: Tensor, k: Tensor, v: Tensor, heads: int, scale: float, out: Op
     if out is None:
         out = torch.empty((nb, nq, cq), dtype=torch.float32, device=q.device)
     _, _, ldo = rows_ld(out, "out")
-    L.check(L.load().cs_attn_selfattn(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), nb, nq, nk,
-                                      heads, dh, ldq, ldk, ldv, ldo, scale, _stream()), "cs_attn_selfattn")
+    fn = L.load().cs_attn_selfattn_f16x3 if math == L.MATH_F16X3 else L.load().cs_attn_selfattn
+    L.check(fn(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo,
+               scale, _stream()), "cs_attn_selfattn")
     return out
 
 

@@ -358,7 +358,7 @@ class DiffusionUNet:
         t0 = ops.linear(xn.view(nb, n, c), pk[p + ".proj_in"], math=self.math)
         n1 = ops.layernorm(t0, sd[t + ".norm1.weight"], sd[t + ".norm1.bias"])
         qkv = ops.linear(n1, pk[t + ".attn1.qkv"], math=self.math)
-        a = ops.attention(qkv[..., 0:c], qkv[..., c:2 * c], qkv[..., 2 * c:3 * c], heads, dh ** -0.5)
+        a = ops.attention(qkv[..., 0:c], qkv[..., c:2 * c], qkv[..., 2 * c:3 * c], heads, dh ** -0.5, math=self.math)
         if isinstance(ctx, tuple):
             # one context token: softmax over one key == 1, attn2(x) = to_out(to_v(ctx)) for every
             # query row -> a per-sample row vector folded into the attn1 output GEMM.
@@ -369,7 +369,7 @@ class DiffusionUNet:
             q2 = ops.linear(n2, pk[t + ".attn2.to_q"], math=self.math)
             k2 = ops.linear(ctx, pk[t + ".attn2.to_k"], math=self.math)
             vv2 = ops.linear(ctx, pk[t + ".attn2.to_v"], math=self.math)
-            a2 = ops.attention(q2, k2, vv2, heads, dh ** -0.5)
+            a2 = ops.attention(q2, k2, vv2, heads, dh ** -0.5, math=self.math)
             t1 = ops.linear(a2, pk[t + ".attn2.to_out.0"], res=t1a, math=self.math)
         n3 = ops.layernorm(t1, sd[t + ".norm3.weight"], sd[t + ".norm3.bias"])
         ff = ops.linear(n3, pk[t + ".ff.net.0.proj"], math=self.math)

@@ -190,7 +190,7 @@ class VQVAE:
         n = d * h * w
         hn = ops.groupnorm(x, sd[p + ".norm.weight"], sd[p + ".norm.bias"], _vq_groups(c), 1e-6, L.ACT_NONE)
         qkv = ops.linear(hn.view(nb, n, c), pk[p + ".qkv"], math=self.math)
-        a = ops.attention(qkv[..., 0:c], qkv[..., c:2 * c], qkv[..., 2 * c:], 1, int(c) ** (-0.5))
+        a = ops.attention(qkv[..., 0:c], qkv[..., c:2 * c], qkv[..., 2 * c:], 1, int(c) ** (-0.5), math=self.math)
         out = ops.linear(a, pk[p + ".proj_out"], res=x.view(nb, n, c), math=self.math)
         return out.view(nb, d, h, w, c)
 

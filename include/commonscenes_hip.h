@@ -149,6 +149,12 @@ int cs_attn_selfattn(const float* q, const float* k, const float* v, float* out,
                      int nk, int heads, int dh, int ldq, int ldk, int ldv, int ldo, float scale,
                      cs_stream_t stream);
 
+/* Same contract, CS_MATH_F16X3 numerics: Q, K, V and the probabilities are carried as fp16 hi/lo pairs on the
+ * fp16 MFMA (3 products per contraction, fp32 accumulate and fp32 softmax). */
+int cs_attn_selfattn_f16x3(const float* q, const float* k, const float* v, float* out, int nb, int nq,
+                           int nk, int heads, int dh, int ldq, int ldk, int ldv, int ldo, float scale,
+                           cs_stream_t stream);
+
 /* GEGLU gate: out[m][j] = x[m][j] * gelu(x[m][h + j])  (attention.py:44-46). */
 int cs_geglu(const float* x, float* out, int m, int h, int ldx, int ldo, cs_stream_t stream);
 

@@ -152,3 +152,34 @@ def test_f16x3_vq_decode_vs_reference_golden():
     torch.cuda.synchronize()
     assert int((vq.last_indices.cpu().numpy() != g["indices"]).sum()) == 0
     assert rel_l2(dec, torch.from_numpy(g["dec"])) < 1e-4
+
+
+@pytest.mark.parametrize("nb,nq,nk,heads,dh", [(2, 256, 256, 8, 84), (1, 1024, 1024, 8, 56), (1, 512, 512, 1, 256),
+                                               (2, 200, 72, 4, 32), (1, 130, 3, 2, 12)])
+def test_f16x3_attention_is_fp32_grade(nb, nq, nk, heads, dh):
+    from commonscenes_amd import lib as L, ops
+    from oracle import ref_ops as R
+    c = heads * dh
+    qkv = _rand(nb, max(nq, nk), 3 * c, seed=27)
+    q, k, v = qkv[:, :nq, 0:c].contiguous(), qkv[:, :nk, c:2 * c].contiguous(), qkv[:, :nk, 2 * c:].contiguous()
+    ref = R.attention(q.double(), k.double(), v.double(), heads, dh ** -0.5)
+    o16 = ops.attention(q.cuda(), k.cuda(), v.cuda(), heads, dh ** -0.5, math=L.MATH_F16X3)
+    o32 = ops.attention(q.cuda(), k.cuda(), v.cuda(), heads, dh ** -0.5)
+    torch.cuda.synchronize()
+    e16, e32 = rel_l2(o16, ref), rel_l2(o32, ref)
+    assert e16 < 2e-6, (e16, e32)
+
+
+def test_f16x3_attention_spiked_logits():
+    from commonscenes_amd import lib as L, ops
+    from oracle import ref_ops as R
+    nb, n, heads, dh = 1, 256, 2, 56
+    c = heads * dh
+    q, k, v = _rand(nb, n, c, seed=28), _rand(nb, n, c, seed=29), _rand(nb, n, c, seed=30)
+    k[:, 200] = q[:, 17] * 40.0
+    k[:, 3] = -q[:, 17] * 40.0
+    ref = R.attention(q.double(), k.double(), v.double(), heads, dh ** -0.5)
+    out = ops.attention(q.cuda(), k.cuda(), v.cuda(), heads, dh ** -0.5, math=L.MATH_F16X3)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    assert rel_l2(out, ref) < 2e-6
