@@ -61,9 +61,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 template <int WMB, int WNB, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256) void conv_gemm_f16x3_kernel(const CsConvGemm p, int M, int tiles_n,
+__global__ __launch_bounds__(256, 2) void conv_gemm_f16x3_kernel(const CsConvGemm p, int M, int tiles_n,
                                                               int taps_hw, int kw_, int kg_per_tap,
-                                                              unsigned x_bytes, unsigned w_bytes) {
+                                                              unsigned x_bytes, unsigned w_bytes, int vec_epilogue) {
   constexpr int BM = 32 * WMB * WAVES_M;
   constexpr int BN = 32 * WNB * WAVES_N;
   // ---- LDS map (bytes) ----
@@ -302,6 +302,56 @@ __global__ __launch_bounds__(256) void conv_gemm_f16x3_kernel(const CsConvGemm p
   wait_vmcnt<0>();   // drain the two zero-fill prefetches issued past the end before LDS is released
 
   // ---- epilogue (identical contract to the fp32 kernel, after undoing the operand scales) ----
+  // Fast path: the C/D layout gives a lane one column and 16 scattered rows, i.e. 112 dword stores (+112 dword
+  // residual loads) per lane -- issue-bound, and for the short-K token GEMMs as long as the main loop.  Stage
+  // 16 rows x (32*WNB) columns per wave through the (now idle) LDS ring and write whole rows as float4.
+  constexpr int WCOLS = 32 * WNB;
+  constexpr int EPI_BYTES = 16 * WCOLS * 4;                 // per wave, per pass
+  static_assert(4 * EPI_BYTES <= NSTAGE * STAGE, "epilogue staging must fit in the ring");
+  const bool vec_ok = !(CS_ABLATE & 32) && vec_epilogue && (n0 + wn0 + WCOLS <= p.cout);
+  if (vec_ok) {
+    __syncthreads();                                        // every wave has left the ring
+    float* ep = reinterpret_cast<float*>(smem + wave * EPI_BYTES);
+#pragma unroll
+    for (int i = 0; i < WMB; ++i)
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph) {
+#pragma unroll
+        for (int j = 0; j < WNB; ++j)
+#pragma unroll
+          for (int rr = 0; rr < 8; ++rr) {
+            const int r = 8 * ph + rr;
+            const int lrow = (r & 3) + 8 * ((r >> 2) & 1) + 4 * half;
+            ep[lrow * WCOLS + 32 * j + l31] = acc[i][j][r] * p.acc_scale;
+          }
+        // same-wave LDS ops are ordered; the compiler waits on lgkmcnt before the reads below
+        constexpr int UNITS = 16 * (WCOLS / 4);
+#pragma unroll
+        for (int u0 = 0; u0 < UNITS; u0 += 64) {
+          const int u = u0 + lane;
+          if (u < UNITS) {
+            const int lrow = u / (WCOLS / 4);
+            const int c4 = u - lrow * (WCOLS / 4);
+            const int m = m0 + wm0 + 32 * i + 16 * ph + lrow;
+            const int n = n0 + wn0 + 4 * c4;
+            if (m < M) {
+              f32x4 v = *reinterpret_cast<const f32x4*>(ep + lrow * WCOLS + 4 * c4);
+              if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+              if (p.scale)
+                v = v * *reinterpret_cast<const f32x4*>(p.scale + n) + *reinterpret_cast<const f32x4*>(p.shift + n);
+              if (p.rowvec) v += *reinterpret_cast<const f32x4*>(p.rowvec + (int64_t)(m / p.rv_rows) * p.ldrv + n);
+              if (p.act != CS_ACT_NONE) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = cs_act(v[e], p.act);
+              }
+              if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (int64_t)m * p.ldr + n);
+              *reinterpret_cast<f32x4*>(p.out + (int64_t)m * p.ldo + n) = v;
+            }
+          }
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < WNB; ++j) {
     const int n = n0 + wn0 + 32 * j + l31;
@@ -342,8 +392,13 @@ int launch16(const CsConvGemm& p, int M, hipStream_t stream) {
   const int64_t x_bytes = ((x_rows - 1) * p.lda + p.cin) * 4;
   const int64_t w_bytes = (int64_t)p.kd * p.kh * p.kw * kg_per_tap * p.cout * 16;
   if (x_bytes > 0xFFE00000LL || w_bytes > 0xFFE00000LL) return CS_EINVAL;
+  // float4 epilogue needs 16-byte aligned rows in every operand it touches
+  auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+  const int vec = (p.cout % 4 == 0) && (p.ldo % 4 == 0) && al16(p.out) && (!p.bias || al16(p.bias)) &&
+                  (!p.scale || (al16(p.scale) && al16(p.shift))) &&
+                  (!p.rowvec || (p.ldrv % 4 == 0 && al16(p.rowvec))) && (!p.res || (p.ldr % 4 == 0 && al16(p.res)));
   CS_LAUNCH((conv_gemm_f16x3_kernel<WMB, WNB, WAVES_M, WAVES_N>), dim3((unsigned)nblk), dim3(256), 0,
-            stream, p, M, tiles_n, p.kh * p.kw, p.kw, kg_per_tap, (unsigned)x_bytes, (unsigned)w_bytes);
+            stream, p, M, tiles_n, p.kh * p.kw, p.kw, kg_per_tap, (unsigned)x_bytes, (unsigned)w_bytes, vec);
   CS_CHECK_LAUNCH();
   return CS_OK;
 }
