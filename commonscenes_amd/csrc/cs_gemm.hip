@@ -263,7 +263,9 @@ extern "C" int cs_conv_gemm(const CsConvGemm* d, cs_stream_t stream) {
   if (p.ud < 0 || p.uh < 0 || p.uw < 0 || p.ud > 4 || p.uh > 4 || p.uw > 4) return CS_EINVAL;
   if (p.scale && !p.shift) return CS_EINVAL;
   if (p.rowvec && p.rv_rows <= 0) return CS_EINVAL;
-  if (p.ldo < p.cout || (p.res && p.ldr < p.cout)) return CS_EINVAL;
+  const int out_cols = (p.act == CS_ACT_GEGLU) ? p.cout / 2 : p.cout;
+  if (p.act == CS_ACT_GEGLU && (!f16x3 || (p.cout & 1))) return CS_EINVAL;
+  if (p.ldo < out_cols || (p.res && p.ldr < p.cout)) return CS_EINVAL;
   if (p.math != CS_MATH_FP32 && !f16x3) return CS_EINVAL;
   const int64_t M64 = (int64_t)p.nb * p.dout * p.hout * p.wout;
   if (M64 > 0x7fffffffLL) return CS_EINVAL;

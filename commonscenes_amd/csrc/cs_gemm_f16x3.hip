@@ -325,6 +325,34 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f16x3_kernel(const CsConvGem
             ep[lrow * WCOLS + 32 * j + l31] = acc[i][j][r] * p.acc_scale;
           }
         // same-wave LDS ops are ordered; the compiler waits on lgkmcnt before the reads below
+        if (p.act == CS_ACT_GEGLU) {
+          // columns of this wave = [x (WCOLS/2) | gate (WCOLS/2)] (weights packed that way by the host):
+          // out[m][n/2 ..] = (x + bias_x) * gelu(gate + bias_g)   -- attention.py:44-46 fused into ff.net.0.proj
+          constexpr int HC = WCOLS / 2;
+          constexpr int UNITS = 16 * (HC / 4);
+#pragma unroll
+          for (int u0 = 0; u0 < UNITS; u0 += 64) {
+            const int u = u0 + lane;
+            if (u < UNITS) {
+              const int lrow = u / (HC / 4);
+              const int c4 = u - lrow * (HC / 4);
+              const int m = m0 + wm0 + 32 * i + 16 * ph + lrow;
+              const int n = n0 + wn0 + 4 * c4;
+              if (m < M) {
+                f32x4 xv = *reinterpret_cast<const f32x4*>(ep + lrow * WCOLS + 4 * c4);
+                f32x4 gv = *reinterpret_cast<const f32x4*>(ep + lrow * WCOLS + HC + 4 * c4);
+                if (p.bias) {
+                  xv += *reinterpret_cast<const f32x4*>(p.bias + n);
+                  gv += *reinterpret_cast<const f32x4*>(p.bias + n + HC);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xv[e] = xv[e] * cs_gelu(gv[e]);
+                *reinterpret_cast<f32x4*>(p.out + (int64_t)m * p.ldo + (n0 + wn0) / 2 + 4 * c4) = xv;
+              }
+            }
+          }
+          continue;
+        }
         constexpr int UNITS = 16 * (WCOLS / 4);
 #pragma unroll
         for (int u0 = 0; u0 < UNITS; u0 += 64) {
@@ -397,6 +425,11 @@ int launch16(const CsConvGemm& p, int M, hipStream_t stream) {
   const int vec = (p.cout % 4 == 0) && (p.ldo % 4 == 0) && al16(p.out) && (!p.bias || al16(p.bias)) &&
                   (!p.scale || (al16(p.scale) && al16(p.shift))) &&
                   (!p.rowvec || (p.ldrv % 4 == 0 && al16(p.rowvec))) && (!p.res || (p.ldr % 4 == 0 && al16(p.res)));
+  if (p.act == CS_ACT_GEGLU) {
+    // fused gate: needs the float4 epilogue, whole [x | gate] column groups per wave and no other epilogue terms
+    constexpr int WCOLS = 32 * WNB;
+    if (!vec || (WCOLS / 2) % 4 || p.cout % WCOLS || p.scale || p.rowvec || p.res) return CS_EINVAL;
+  }
   CS_LAUNCH((conv_gemm_f16x3_kernel<WMB, WNB, WAVES_M, WAVES_N>), dim3((unsigned)nblk), dim3(256), 0,
             stream, p, M, tiles_n, p.kh * p.kw, p.kw, kg_per_tap, (unsigned)x_bytes, (unsigned)w_bytes, vec);
   CS_CHECK_LAUNCH();

@@ -18,7 +18,7 @@ from .build import LIB_PATH
 
 CS_OK = 0
 CS_EINVAL = -22
-ACT_NONE, ACT_RELU, ACT_SILU, ACT_GELU = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_SILU, ACT_GELU, ACT_GEGLU = 0, 1, 2, 3, 4
 MATH_FP32, MATH_F16X3 = 0, 1
 
 _f = C.c_void_p   # device float*

@@ -129,6 +129,19 @@ def _pack_weight_f16x3(w: Tensor, bias: Optional[Tensor], cin_pad: Optional[int]
     return PackedWeight(None, b, cout, cin, cp, cout, (kd, kh, kw), L.MATH_F16X3, wh, wl, 1.0 / (scale * A_SCALE))
 
 
+def pack_geglu_weight(w: Tensor, bias: Tensor, group: int = 112) -> PackedWeight:
+    """GEGLU.proj (attention.py:42) weight (2H, C) -> f16x3 pack whose output columns are interleaved per
+    `2*group`-column GEMM tile as [x (group) | gate (group)], so the gate is applied in the GEMM epilogue
+    (act=ACT_GEGLU) and the (.., 2H) intermediate never reaches HBM."""
+    h2 = w.shape[0]
+    h = h2 // 2
+    if h % group:
+        raise L.CsError(f"GEGLU width {h} is not a multiple of {group}")
+    idx = torch.arange(h, device=w.device).view(h // group, group)
+    perm = torch.cat([idx, idx + h], dim=1).reshape(-1)          # [x tile0 | gate tile0 | x tile1 | ...]
+    return pack_weight(w[perm].contiguous(), bias[perm].contiguous(), math=L.MATH_F16X3)
+
+
 def conv_gemm(x: Tensor, w: PackedWeight, *, spatial: Optional[Tuple[int, int, int, int]] = None,
               stride: Sequence[int] = (1, 1, 1), up: Sequence[int] = (0, 0, 0), act: int = L.ACT_NONE,
               rowvec: Optional[Tensor] = None, rv_rows: int = 1, res: Optional[Tensor] = None,
@@ -161,15 +174,16 @@ def conv_gemm(x: Tensor, w: PackedWeight, *, spatial: Optional[Tuple[int, int, i
     ho = (vh + 2 * ph - kh) // stride[1] + 1
     wo = (vw + 2 * pw - kw) // stride[2] + 1
     mo = nb * do * ho * wo
+    ocols = w.cout // 2 if act == L.ACT_GEGLU else w.cout
     if out is None:
         if spatial is None and x.dim() != 5:
-            oshape = (*x.shape[:-1], w.cout)
+            oshape = (*x.shape[:-1], ocols)
         else:
-            oshape = (nb, do, ho, wo, w.cout)
+            oshape = (nb, do, ho, wo, ocols)
         out = torch.empty(oshape, dtype=torch.float32, device=x.device)
     _chk(out, "out")
     om, oc, ldo = rows_ld(out, "out")
-    if om != mo or oc != w.cout:
+    if om != mo or oc != ocols:
         raise L.CsError(f"out has shape {tuple(out.shape)}, expected {mo} rows x {w.cout}")
     p = L.CsConvGemm()
     math = w.math                      # the numerics mode is a property of how the weight was packed

@@ -14,6 +14,7 @@ cross-attention collapses to a per-sample row vector folded into the attn1 outpu
 """
 from __future__ import annotations
 
+import os
 from collections import OrderedDict
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -277,7 +278,12 @@ class DiffusionUNet:
                     pw(t + ".attn2.to_k")
                     pw(t + ".attn2.to_v")
                     pw(t + ".attn2.to_out.0")
-                    pw(t + ".ff.net.0.proj")
+                    if (self.math == L.MATH_F16X3 and (4 * l["cin"]) % 112 == 0
+                            and not os.environ.get("CS_NO_FUSED_GEGLU")):
+                        pk[t + ".ff.geglu"] = ops.pack_geglu_weight(sd[t + ".ff.net.0.proj.weight"],
+                                                                    sd[t + ".ff.net.0.proj.bias"])
+                    else:
+                        pw(t + ".ff.net.0.proj")
                     pw(t + ".ff.net.2")
                 elif k == "down":
                     pw(p + ".op")
@@ -372,8 +378,11 @@ class DiffusionUNet:
             a2 = ops.attention(q2, k2, vv2, heads, dh ** -0.5, math=self.math)
             t1 = ops.linear(a2, pk[t + ".attn2.to_out.0"], res=t1a, math=self.math)
         n3 = ops.layernorm(t1, sd[t + ".norm3.weight"], sd[t + ".norm3.bias"])
-        ff = ops.linear(n3, pk[t + ".ff.net.0.proj"], math=self.math)
-        gg = ops.geglu(ff)
+        if (t + ".ff.geglu") in pk:      # GEGLU gate fused into the projection GEMM's epilogue
+            gg = ops.linear(n3, pk[t + ".ff.geglu"], act=L.ACT_GEGLU, tile=2)
+        else:
+            ff = ops.linear(n3, pk[t + ".ff.net.0.proj"], math=self.math)
+            gg = ops.geglu(ff)
         t2 = ops.linear(gg, pk[t + ".ff.net.2"], res=t1, math=self.math)
         out = ops.linear(t2, pk[p + ".proj_out"], res=x.view(nb, n, c), math=self.math)
         return out.view(nb, d, h, w, c)

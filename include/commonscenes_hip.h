@@ -39,6 +39,8 @@ typedef struct ihipStream_t* cs_stream_t; /* == hipStream_t */
 #define CS_ACT_RELU 1
 #define CS_ACT_SILU 2
 #define CS_ACT_GELU 3 /* exact (erf) GELU, torch.nn.GELU() default */
+#define CS_ACT_GEGLU 4 /* CS_MATH_F16X3 only: weight columns packed per 224-column tile as [x(112) | gate(112)];
+                          out[m][n/2] = (x + bias) * gelu(gate + bias), out has cout/2 columns (attention.py:39-46) */
 
 /* GEMM numerics mode */
 #define CS_MATH_FP32 0     /* v_mfma_f32_32x32x2_f32, bit-equal to an fp32 fma chain  */

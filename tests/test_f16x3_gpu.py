@@ -183,3 +183,19 @@ def test_f16x3_attention_spiked_logits():
     torch.cuda.synchronize()
     assert torch.isfinite(out).all()
     assert rel_l2(out, ref) < 2e-6
+
+
+def test_f16x3_fused_geglu_projection():
+    """ff.net.0.proj + GEGLU gate in one GEMM (act=ACT_GEGLU) == Linear -> chunk -> x * gelu(gate)."""
+    from commonscenes_amd import lib as L, ops
+    m, c, h = 300, 448, 1792
+    x = _rand(m, c, seed=51)
+    w = _rand(2 * h, c, seed=52, scale=c ** -0.5)
+    b = _rand(2 * h, seed=53) * 0.1
+    y = x.double() @ w.double().t() + b.double()
+    a, g = y.chunk(2, dim=-1)
+    ref = a * torch.nn.functional.gelu(g)
+    out = ops.linear(x.cuda(), ops.pack_geglu_weight(w.cuda(), b.cuda()), act=L.ACT_GEGLU, tile=2)
+    torch.cuda.synchronize()
+    assert out.shape == (m, h)
+    assert rel_l2(out, ref) < 2e-6
