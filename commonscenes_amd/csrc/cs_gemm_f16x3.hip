@@ -60,14 +60,17 @@ __device__ __forceinline__ void wait_vmcnt() {
   else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
 }
 
-template <int WMB, int WNB, int WAVES_M, int WAVES_N>
+// PRE = the activations arrive already split: p.x / p.x_lo are fp16 hi / lo images [rows][lda halves] written by
+// the producer (cs_groupnorm_apply_split16) with the a_scale factor applied -- the split is then done once per
+// element instead of once per tap per N-tile, and the K loop carries no conversion VALU at all.
+template <int WMB, int WNB, int WAVES_M, int WAVES_N, bool PRE>
 __global__ __launch_bounds__(256, 2) void conv_gemm_f16x3_kernel(const CsConvGemm p, int M, int tiles_n,
                                                               int taps_hw, int kw_, int kg_per_tap,
                                                               unsigned x_bytes, unsigned w_bytes, int vec_epilogue) {
   constexpr int BM = 32 * WMB * WAVES_M;
   constexpr int BN = 32 * WNB * WAVES_N;
   // ---- LDS map (bytes) ----
-  constexpr int A_BYTES = BM * 64;                 // raw fp32 [BM][16]
+  constexpr int A_BYTES = BM * 64;                 // raw fp32 [BM][16], or (PRE) fp16 hi [BM][16] + lo [BM][16]
   constexpr int B_BYTES = 2 * BN * 16;             // one fp16 image [2 k-groups][BN][8]
   constexpr int STAGE = A_BYTES + 2 * B_BYTES;
   constexpr int NSTAGE = 3;
@@ -106,6 +109,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f16x3_kernel(const CsConvGem
   const int n0 = tn * BN;
 
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xlrs =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(PRE ? p.x_lo : (const void*)p.x), 0, x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, w_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_lo, 0, w_bytes, 0x00020000);
 
@@ -162,10 +167,19 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f16x3_kernel(const CsConvGem
 #pragma unroll
   for (int i = 0; i < A_PW; ++i) {
     const int w = wave * A_PW + i;
-    const int row = 16 * w + (lane >> 2);
-    a_rowidx[i] = row;
-    a_rowbase[i] = rowbase[row];
-    a_piece[i] = (unsigned)(((lane & 3) ^ ((row >> 2) & 3)) * 4);   // first channel of the piece
+    if constexpr (PRE) {
+      // image w / (A_WI/2) (0 = hi, 1 = lo); rows of 16 halves = two 16-byte pieces, slot q holds piece q ^ ((row>>3)&1)
+      const int within = w % (A_WI / 2);
+      const int row = 32 * within + (lane >> 1);
+      a_rowidx[i] = row;
+      a_rowbase[i] = rowbase[row];
+      a_piece[i] = (unsigned)(((lane & 1) ^ ((row >> 3) & 1)) * 8);
+    } else {
+      const int row = 16 * w + (lane >> 2);
+      a_rowidx[i] = row;
+      a_rowbase[i] = rowbase[row];
+      a_piece[i] = (unsigned)(((lane & 3) ^ ((row >> 2) & 3)) * 4);   // first channel of the piece
+    }
   }
   // B wave-instruction v (0..2*B_WI-1): image v / B_WI (0 = hi, 1 = lo), units 64*(v % B_WI) .. +63
   unsigned b_off[B_PW];     // byte offset inside the chunk's [2][cout][8] slab, or OOB
@@ -185,10 +199,19 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f16x3_kernel(const CsConvGem
     for (int i = 0; i < A_PW; ++i) {
       const short dl = delta[tap * BM + a_rowidx[i]];
       const int c = cc * BKH + (int)a_piece[i];
+      constexpr unsigned ESZ = PRE ? 2u : 4u;
       const unsigned off = (dl != INVALID && c < p.cin)
-                               ? (unsigned)(a_rowbase[i] + (int)dl) * (unsigned)(p.lda * 4) + (unsigned)c * 4u
+                               ? (unsigned)(a_rowbase[i] + (int)dl) * ((unsigned)p.lda * ESZ) + (unsigned)c * ESZ
                                : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, st + (wave * A_PW + i) * 1024, 16, off, 0, 0, 0);
+      const int w = wave * A_PW + i;                      // wave-uniform
+      if constexpr (PRE) {
+        if (w >= A_WI / 2)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xlrs, st + w * 1024, 16, off, 0, 0, 0);
+        else
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, st + w * 1024, 16, off, 0, 0, 0);
+      } else {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, st + w * 1024, 16, off, 0, 0, 0);
+      }
     }
     const unsigned kbase = (unsigned)((tap * kg_per_tap + cc * 2) * p.cout) * 16u;
 #pragma unroll
@@ -230,9 +253,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f16x3_kernel(const CsConvGem
 #pragma unroll
   for (int i = 0; i < WMB; ++i) {
     const int row = wm0 + 32 * i + l31;
-    const int s = (row >> 2) & 3;
-    a_frag[i][0] = row * 64 + (((2 * half) ^ s) * 16);
-    a_frag[i][1] = row * 64 + (((2 * half + 1) ^ s) * 16);
+    if constexpr (PRE) {
+      a_frag[i][0] = row * 32 + ((half ^ ((row >> 3) & 1)) * 16);          // hi image
+      a_frag[i][1] = a_frag[i][0] + BM * 32;                                // lo image
+    } else {
+      const int s = (row >> 2) & 3;
+      a_frag[i][0] = row * 64 + (((2 * half) ^ s) * 16);
+      a_frag[i][1] = row * 64 + (((2 * half + 1) ^ s) * 16);
+    }
   }
   const int b_frag = A_BYTES + (half * BN + wn0 + l31) * 16;
 
@@ -246,9 +274,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f16x3_kernel(const CsConvGem
     const unsigned char* s = smem + st * STAGE;
 #pragma unroll
     for (int i = 0; i < WMB; ++i) {
-      const f32x4 x0 = *reinterpret_cast<const f32x4*>(s + a_frag[i][0]);
-      const f32x4 x1 = *reinterpret_cast<const f32x4*>(s + a_frag[i][1]);
-      split8(x0, x1, a_scale, hi[i], lo[i]);
+      if constexpr (PRE) {
+        hi[i] = *reinterpret_cast<const h8*>(s + a_frag[i][0]);
+        lo[i] = *reinterpret_cast<const h8*>(s + a_frag[i][1]);
+      } else {
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(s + a_frag[i][0]);
+        const f32x4 x1 = *reinterpret_cast<const f32x4*>(s + a_frag[i][1]);
+        split8(x0, x1, a_scale, hi[i], lo[i]);
+      }
     }
   };
   h8 ah[WMB], al[WMB];
@@ -406,7 +439,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f16x3_kernel(const CsConvGem
   }
 }
 
-template <int WMB, int WNB, int WAVES_M, int WAVES_N>
+template <int WMB, int WNB, int WAVES_M, int WAVES_N, bool PRE>
 int launch16(const CsConvGemm& p, int M, hipStream_t stream) {
   constexpr int BM = 32 * WMB * WAVES_M;
   constexpr int BN = 32 * WNB * WAVES_N;
@@ -417,7 +450,7 @@ int launch16(const CsConvGemm& p, int M, hipStream_t stream) {
   const int kg_per_tap = ((p.cin + 15) / 16) * 2;
   // buffer-descriptor extents: everything the loader may touch, and < 0xFFE00000 so OOB stays out of range
   const int64_t x_rows = (int64_t)p.nb * p.din * p.hin * p.win;
-  const int64_t x_bytes = ((x_rows - 1) * p.lda + p.cin) * 4;
+  const int64_t x_bytes = ((x_rows - 1) * p.lda + p.cin) * (PRE ? 2 : 4);
   const int64_t w_bytes = (int64_t)p.kd * p.kh * p.kw * kg_per_tap * p.cout * 16;
   if (x_bytes > 0xFFE00000LL || w_bytes > 0xFFE00000LL) return CS_EINVAL;
   // float4 epilogue needs 16-byte aligned rows in every operand it touches
@@ -430,7 +463,7 @@ int launch16(const CsConvGemm& p, int M, hipStream_t stream) {
     constexpr int WCOLS = 32 * WNB;
     if (!vec || (WCOLS / 2) % 4 || p.cout % WCOLS || p.scale || p.rowvec || p.res) return CS_EINVAL;
   }
-  CS_LAUNCH((conv_gemm_f16x3_kernel<WMB, WNB, WAVES_M, WAVES_N>), dim3((unsigned)nblk), dim3(256), 0,
+  CS_LAUNCH((conv_gemm_f16x3_kernel<WMB, WNB, WAVES_M, WAVES_N, PRE>), dim3((unsigned)nblk), dim3(256), 0,
             stream, p, M, tiles_n, p.kh * p.kw, p.kw, kg_per_tap, (unsigned)x_bytes, (unsigned)w_bytes, vec);
   CS_CHECK_LAUNCH();
   return CS_OK;
@@ -469,10 +502,20 @@ int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p_in, int M, int tile, hipStre
   // 16-bit row deltas: the farthest tap is (kd-1) planes + (kh-1) rows + (kw-1) voxels from the window origin
   if ((int64_t)(p.kd - 1) * p.hin * p.win + (int64_t)(p.kh - 1) * p.win + p.kw > 32000) return CS_EINVAL;
   if (((uintptr_t)p.w & 15) || ((uintptr_t)p.w_lo & 15)) return CS_EINVAL;
+  if (p.a_format == 1) {
+    if (!p.x_lo || ((uintptr_t)p.x_lo & 15) || (p.cin & 7) || (p.lda & 7)) return CS_EINVAL;
+    switch (tile) {
+      case 1: return launch16<2, 2, 2, 2, true>(p, M, s);
+      case 2: return launch16<1, 7, 4, 1, true>(p, M, s);
+      case 3: return launch16<1, 1, 2, 2, true>(p, M, s);
+      default: return CS_EINVAL;
+    }
+  }
+  if (p.a_format != 0) return CS_EINVAL;
   switch (tile) {
-    case 1: return launch16<2, 2, 2, 2>(p, M, s);
-    case 2: return launch16<1, 7, 4, 1>(p, M, s);
-    case 3: return launch16<1, 1, 2, 2>(p, M, s);
+    case 1: return launch16<2, 2, 2, 2, false>(p, M, s);
+    case 2: return launch16<1, 7, 4, 1, false>(p, M, s);
+    case 3: return launch16<1, 1, 2, 2, false>(p, M, s);
     default: return CS_EINVAL;
   }
 }

@@ -106,6 +106,47 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
   }
 }
 
+// GroupNorm apply emitting the fp16 hi / lo pair of y * a_scale (A operand of the F16X3 GEMMs): the fp32 -> pair
+// split costs nothing here (this kernel is HBM-bound) and is then done once per element instead of once per
+// conv tap inside the GEMM.  Output bytes equal the fp32 version (2 + 2 per element).
+typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void gn_apply_split16_kernel(const float* __restrict__ x,
+                                                               const float* __restrict__ stats,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta,
+                                                               _Float16* __restrict__ yh, _Float16* __restrict__ yl,
+                                                               int nb, int rows, int c, int ldx, int ldy, int groups,
+                                                               int act, float a_scale) {
+  const int ch4 = c >> 2;
+  const int cpg = c / groups;
+  const int64_t total = (int64_t)nb * rows * ch4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % ch4);
+    const int64_t row = i / ch4;
+    const int n = (int)(row / rows);
+    const float4 v = *reinterpret_cast<const float4*>(x + row * ldx + c4 * 4);
+    const float4 g = *reinterpret_cast<const float4*>(gamma + c4 * 4);
+    const float4 b = *reinterpret_cast<const float4*>(beta + c4 * 4);
+    const float in[4] = {v.x, v.y, v.z, v.w};
+    const float gg[4] = {g.x, g.y, g.z, g.w};
+    const float bb[4] = {b.x, b.y, b.z, b.w};
+    h4v hi, lo;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int grp = (c4 * 4 + k) / cpg;
+      const float mean = stats[((int64_t)n * groups + grp) * 2];
+      const float rstd = stats[((int64_t)n * groups + grp) * 2 + 1];
+      const float o = cs_act((in[k] - mean) * rstd * gg[k] + bb[k], act) * a_scale;
+      const _Float16 h = (_Float16)o;
+      hi[k] = h;
+      lo[k] = (_Float16)(o - (float)h);
+    }
+    *reinterpret_cast<h4v*>(yh + row * ldy + c4 * 4) = hi;
+    *reinterpret_cast<h4v*>(yl + row * ldy + c4 * 4) = lo;
+  }
+}
+
 // LayerNorm: one wave per row; each lane owns up to MAXV float4 chunks (c <= 64*4*MAXV).
 template <int MAXV>
 __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x,
@@ -203,6 +244,23 @@ extern "C" int cs_groupnorm_apply(const float* x, const float* stats, const floa
   CS_LAUNCH(gn_apply_kernel, dim3(cs_grid_for(total, 256, 256 * 32)), dim3(256), 0,
                      (hipStream_t)stream, x, stats, gamma, beta, y, nb, rows, c, ldx, ldy, groups,
                      act);
+  CS_CHECK_LAUNCH();
+  return CS_OK;
+}
+
+extern "C" int cs_groupnorm_apply_split16(const float* x, const float* stats, const float* gamma,
+                                          const float* beta, void* y_hi, void* y_lo, int nb, int rows, int c,
+                                          int ldx, int ldy, int groups, int act, float a_scale,
+                                          cs_stream_t stream) {
+  if (!x || !stats || !gamma || !beta || !y_hi || !y_lo || nb <= 0 || rows <= 0 || c <= 0 || groups <= 0)
+    return CS_EINVAL;
+  if ((c & 7) || (ldx & 3) || (ldy & 7) || ldx < c || ldy < c || c % groups || !(a_scale > 0.f)) return CS_EINVAL;
+  if (((uintptr_t)x & 15) || ((uintptr_t)y_hi & 15) || ((uintptr_t)y_lo & 15) || ((uintptr_t)gamma & 15) ||
+      ((uintptr_t)beta & 15))
+    return CS_EINVAL;
+  const int64_t total = (int64_t)nb * rows * (c >> 2);
+  CS_LAUNCH(gn_apply_split16_kernel, dim3(cs_grid_for(total, 256, 256 * 32)), dim3(256), 0, (hipStream_t)stream, x,
+            stats, gamma, beta, (_Float16*)y_hi, (_Float16*)y_lo, nb, rows, c, ldx, ldy, groups, act, a_scale);
   CS_CHECK_LAUNCH();
   return CS_OK;
 }

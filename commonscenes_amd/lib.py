@@ -43,6 +43,7 @@ class CsConvGemm(C.Structure):
         ("ud", C.c_int32), ("uh", C.c_int32), ("uw", C.c_int32),
         ("act", C.c_int32), ("rv_rows", C.c_int32), ("math", C.c_int32), ("tile", C.c_int32),
         ("w_lo", C.c_void_p), ("acc_scale", C.c_float), ("a_scale", C.c_float),
+        ("x_lo", C.c_void_p), ("a_format", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -57,6 +58,7 @@ SIGNATURES = {
     "cs_groupnorm_ws_bytes": (_l, [_i, _i]),
     "cs_groupnorm_stats": (_i, [_f, _i, _i, _i, _i, _i, _fl, _f, _f, _s]),
     "cs_groupnorm_apply": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),
+    "cs_groupnorm_apply_split16": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _fl, _s]),
     "cs_groupnorm_silu_ndhwc": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _fl, _f, _f, _s]),
     "cs_layernorm": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _fl, _s]),
     "cs_attn_selfattn": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _s]),

@@ -177,10 +177,13 @@ class VQVAE:
     def _res(self, p: str, x: Tensor) -> Tensor:
         sd, pk = self._sd, self._packed
         c = x.shape[-1]
-        h = ops.groupnorm(x, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], _vq_groups(c), 1e-6, L.ACT_SILU)
+        s16 = self.math == L.MATH_F16X3
+        h = ops.groupnorm(x, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], _vq_groups(c), 1e-6, L.ACT_SILU,
+                          split16=s16)
         h = ops.conv_gemm(h, pk[p + ".conv1"], math=self.math)
         co = h.shape[-1]
-        h = ops.groupnorm(h, sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], _vq_groups(co), 1e-6, L.ACT_SILU)
+        h = ops.groupnorm(h, sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], _vq_groups(co), 1e-6, L.ACT_SILU,
+                          split16=s16)
         skip = x if (p + ".nin_shortcut") not in pk else ops.conv_gemm(x, pk[p + ".nin_shortcut"], math=self.math)
         return ops.conv_gemm(h, pk[p + ".conv2"], res=skip, math=self.math)
 
@@ -188,7 +191,8 @@ class VQVAE:
         sd, pk = self._sd, self._packed
         nb, d, h, w, c = x.shape
         n = d * h * w
-        hn = ops.groupnorm(x, sd[p + ".norm.weight"], sd[p + ".norm.bias"], _vq_groups(c), 1e-6, L.ACT_NONE)
+        hn = ops.groupnorm(x, sd[p + ".norm.weight"], sd[p + ".norm.bias"], _vq_groups(c), 1e-6, L.ACT_NONE,
+                           split16=self.math == L.MATH_F16X3)
         qkv = ops.linear(hn.view(nb, n, c), pk[p + ".qkv"], math=self.math)
         a = ops.attention(qkv[..., 0:c], qkv[..., c:2 * c], qkv[..., 2 * c:], 1, int(c) ** (-0.5), math=self.math)
         out = ops.linear(a, pk[p + ".proj_out"], res=x.view(nb, n, c), math=self.math)
@@ -210,7 +214,8 @@ class VQVAE:
             if i_level != 0:
                 h = ops.conv_gemm(h, pk[f"{D}up.{i_level}.upsample.conv"], up=(1, 1, 1), math=self.math)
         c = h.shape[-1]
-        h = ops.groupnorm(h, sd[D + "norm_out.weight"], sd[D + "norm_out.bias"], _vq_groups(c), 1e-6, L.ACT_GELU)
+        h = ops.groupnorm(h, sd[D + "norm_out.weight"], sd[D + "norm_out.bias"], _vq_groups(c), 1e-6, L.ACT_GELU,
+                          split16=self.math == L.MATH_F16X3)
         return ops.conv_gemm(h, pk[D + "conv_out"], math=self.math)
 
     # ---- reference API ----

@@ -88,6 +88,11 @@ typedef struct CsConvGemm {
   const void* w_lo;
   float acc_scale;
   float a_scale;
+  /* CS_MATH_F16X3, a_format = 1: the activations are already split -- x = fp16 hi image, x_lo = fp16 lo image,
+   * both [rows][lda] halves holding value * a_scale (written by cs_groupnorm_apply_split16); cin, lda % 8 == 0. */
+  const void* x_lo;
+  int32_t a_format;
+  int32_t reserved;
 } CsConvGemm;
 
 int cs_conv_gemm(const CsConvGemm* desc, cs_stream_t stream);
@@ -131,6 +136,11 @@ int cs_groupnorm_stats(const float* x, int nb, int rows, int c, int ldx, int gro
 int cs_groupnorm_apply(const float* x, const float* stats, const float* gamma, const float* beta,
                        float* y, int nb, int rows, int c, int ldx, int ldy, int groups, int act,
                        cs_stream_t stream);
+/* Same as cs_groupnorm_apply but the result is emitted as the fp16 hi / lo pair of y * a_scale (two [rows][ldy]
+ * half images), the A-operand format of CS_MATH_F16X3 GEMMs with a_format = 1. */
+int cs_groupnorm_apply_split16(const float* x, const float* stats, const float* gamma, const float* beta,
+                               void* y_hi, void* y_lo, int nb, int rows, int c, int ldx, int ldy, int groups,
+                               int act, float a_scale, cs_stream_t stream);
 /* SURVEY name: both steps, SiLU epilogue. */
 int cs_groupnorm_silu_ndhwc(const float* x, const float* gamma, const float* beta, float* y,
                             int nb, int rows, int c, int groups, float eps, void* ws, float* stats,

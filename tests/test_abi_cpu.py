@@ -45,7 +45,7 @@ def test_struct_layout_matches_header():
         for n in decl[-1].split(","):
             names.append(n.strip().lstrip("*").strip())
     assert names == [f[0] for f in lib.CsConvGemm._fields_]
-    assert ctypes.sizeof(lib.CsConvGemm) == 9 * 8 + 31 * 4 + 4
+    assert ctypes.sizeof(lib.CsConvGemm) == 10 * 8 + 32 * 4 + 2 * 4
 
 
 def test_missing_library_fails_loudly(tmp_path):

@@ -199,3 +199,27 @@ def test_f16x3_fused_geglu_projection():
     torch.cuda.synchronize()
     assert out.shape == (m, h)
     assert rel_l2(out, ref) < 2e-6
+
+
+@pytest.mark.parametrize("shape,cin,cout,tile", [((2, 4, 8, 8), 32, 224, 2), ((1, 5, 7, 3), 24, 36, 3),
+                                                 ((2, 4, 4, 4), 64, 128, 1), ((1, 8, 8, 8), 672, 224, 2)])
+def test_f16x3_presplit_activation_path(shape, cin, cout, tile, monkeypatch):
+    """GroupNorm+SiLU emitting the fp16 hi/lo pair (cs_groupnorm_apply_split16) -> conv reading it (a_format=1)
+    == fp64 GroupNorm -> SiLU -> conv."""
+    from commonscenes_amd import lib as L, ops
+    from oracle import ref_ops as R
+    monkeypatch.setattr(ops, "SPLIT16_PRODUCERS", True)
+    nb, d, h, w = shape
+    x = _rand(nb, d, h, w, cin, seed=61) * 1.5 + 0.3
+    g = _rand(cin, seed=62) * 0.2 + 1.0
+    b = _rand(cin, seed=63) * 0.1
+    wt = _rand(cout, cin, 3, 3, 3, seed=64, scale=(cin * 27) ** -0.5)
+    bias = _rand(cout, seed=65)
+    groups = 8 if cin % 32 else 32
+    ref = R.conv_ndhwc(R.groupnorm_ndhwc(x.double(), g.double(), b.double(), groups, 1e-5, "silu"), wt.double(),
+                       bias.double())
+    hn = ops.groupnorm(x.cuda(), g.cuda(), b.cuda(), groups, 1e-5, L.ACT_SILU, split16=True)
+    assert isinstance(hn, ops.Split16) and hn.hi.dtype == torch.float16
+    out = ops.conv_gemm(hn, ops.pack_weight(wt.cuda(), bias.cuda(), math=L.MATH_F16X3), tile=tile)
+    torch.cuda.synchronize()
+    assert rel_l2(out, ref) < 2e-6
