@@ -183,11 +183,13 @@ def main():
     finite = bool(torch.isfinite(x).all().item())
 
     if rank == 0:
-        # dominant kernel = the 128x224-tile instantiation (3x3x3 convs + the token GEMMs that share it):
+        # dominant kernel = the tile instantiation with the most time (3x3x3 convs + the token GEMMs that share it):
         # every one of its launches counts, so the average matches rocprofv3's per-kernel average
-        conv = [r for r in prof if r["tile"] == 2]
-        if not conv:
-            conv = prof
+        by_tile = {}
+        for r in prof:
+            by_tile[r["tile"]] = by_tile.get(r["tile"], 0.0) + r["e0"].elapsed_time(r["e1"])
+        dom_tile = max(by_tile, key=by_tile.get) if by_tile else 0
+        conv = [r for r in prof if r["tile"] == dom_tile] or prof
         conv_ms = sum(r["e0"].elapsed_time(r["e1"]) for r in conv)
         conv_fl = sum(r["flops"] for r in conv)
         all_ms = sum(r["e0"].elapsed_time(r["e1"]) for r in prof)
@@ -211,7 +213,9 @@ def main():
             traffic = json.loads(tf.read_text())["hbm_bytes_per_launch"]   # the committed rocprofv3 --pmc result
         if a.math == "f16x3":
             # three fp16 MFMA passes per fp32-grade product: the pipe ceiling for ALGORITHMIC flops is 2.5 PF / 3
-            peak, kname = F16_MFMA_PEAK_TFLOPS / 3.0, ("conv_gemm_f16x3_kernel<1,7,4,1> (128x224-tile implicit "
+            shape = {1: "<2,2,2,2,false> (128x128", 2: "<1,7,4,1,false> (128x224", 3: "<1,1,2,2,false> (64x64",
+                     4: "<1,7,8,1,false> (256x224"}.get(dom_tile, "(?")
+            peak, kname = F16_MFMA_PEAK_TFLOPS / 3.0, (f"conv_gemm_f16x3_kernel{shape}-tile implicit "
                                                        "GEMM, 3x v_mfma_f32_32x32x16_f16 per K=16 on hi/lo splits)")
             dtype = "f32 (operands as fp16 hi+lo pairs, fp32 accumulate)"
         else:

@@ -64,11 +64,13 @@ __device__ __forceinline__ void wait_vmcnt() {
 // the producer (cs_groupnorm_apply_split16) with the a_scale factor applied -- the split is then done once per
 // element instead of once per tap per N-tile, and the K loop carries no conversion VALU at all.
 template <int WMB, int WNB, int WAVES_M, int WAVES_N, bool PRE>
-__global__ __launch_bounds__(256, 2) void conv_gemm_f16x3_kernel(const CsConvGemm p, int M, int tiles_n,
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_kernel(const CsConvGemm p, int M, int tiles_n,
                                                               int taps_hw, int kw_, int kg_per_tap,
                                                               unsigned x_bytes, unsigned w_bytes, int vec_epilogue) {
   constexpr int BM = 32 * WMB * WAVES_M;
   constexpr int BN = 32 * WNB * WAVES_N;
+  constexpr int NW = WAVES_M * WAVES_N;            // waves per workgroup (4, or 8 for the 256-row tile)
+  constexpr int NT = 64 * NW;
   // ---- LDS map (bytes) ----
   constexpr int A_BYTES = BM * 64;                 // raw fp32 [BM][16], or (PRE) fp16 hi [BM][16] + lo [BM][16]
   constexpr int B_BYTES = 2 * BN * 16;             // one fp16 image [2 k-groups][BN][8]
@@ -82,10 +84,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f16x3_kernel(const CsConvGem
   // ---- DMA schedule: wave-instructions of 64 x 16 B ----
   constexpr int A_WI = BM / 16;                    // A wave-instructions per chunk
   constexpr int B_WI = BN / 32;                    // per B image
-  constexpr int A_PW = A_WI / 4;                   // per wave
-  constexpr int B_PW = (2 * B_WI + 3) / 4;         // per wave, hi + lo together (surplus ones go to DUMP)
+  constexpr int A_PW = A_WI / NW;                  // per wave
+  constexpr int B_PW = (2 * B_WI + NW - 1) / NW;   // per wave, hi + lo together (surplus ones go to DUMP)
   constexpr int D = A_PW + B_PW;                   // DMA instructions per wave per chunk
-  static_assert(A_WI % 4 == 0, "A tile must split evenly over 4 waves");
+  static_assert(A_WI % NW == 0, "A tile must split evenly over the waves");
   static_assert(D <= 7, "vmcnt immediates");
   __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
 
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f16x3_kernel(const CsConvGem
   short* delta = reinterpret_cast<short*>(smem + DELTA);
   {
     const int vdin = p.din << p.ud, vhin = p.hin << p.uh, vwin = p.win << p.uw;
-    for (int idx = tid; idx < BM * ntaps; idx += 256) {
+    for (int idx = tid; idx < BM * ntaps; idx += NT) {
       const int t = idx / BM;
       const int row = idx - t * BM;
       const int m = m0 + row;
@@ -339,8 +341,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f16x3_kernel(const CsConvGem
   // residual loads) per lane -- issue-bound, and for the short-K token GEMMs as long as the main loop.  Stage
   // 16 rows x (32*WNB) columns per wave through the (now idle) LDS ring and write whole rows as float4.
   constexpr int WCOLS = 32 * WNB;
-  constexpr int EPI_BYTES = 16 * WCOLS * 4;                 // per wave, per pass
-  static_assert(4 * EPI_BYTES <= NSTAGE * STAGE, "epilogue staging must fit in the ring");
+  constexpr int PASS_R = (NW * 16 * WCOLS * 4 <= NSTAGE * STAGE) ? 8 : 4;   // accumulator registers per pass
+  constexpr int EPI_ROWS = 2 * PASS_R;                                       // rows staged per wave per pass
+  constexpr int EPI_BYTES = EPI_ROWS * WCOLS * 4;                            // per wave, per pass
+  static_assert(NW * EPI_BYTES <= NSTAGE * STAGE, "epilogue staging must fit in the ring");
   const bool vec_ok = !(CS_ABLATE & 32) && vec_epilogue && (n0 + wn0 + WCOLS <= p.cout);
   if (vec_ok) {
     __syncthreads();                                        // every wave has left the ring
@@ -348,13 +352,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f16x3_kernel(const CsConvGem
 #pragma unroll
     for (int i = 0; i < WMB; ++i)
 #pragma unroll
-      for (int ph = 0; ph < 2; ++ph) {
+      for (int ph = 0; ph < 16 / PASS_R; ++ph) {
 #pragma unroll
         for (int j = 0; j < WNB; ++j)
 #pragma unroll
-          for (int rr = 0; rr < 8; ++rr) {
-            const int r = 8 * ph + rr;
-            const int lrow = (r & 3) + 8 * ((r >> 2) & 1) + 4 * half;
+          for (int rr = 0; rr < PASS_R; ++rr) {
+            const int r = PASS_R * ph + rr;
+            const int lrow = (r & 3) + 8 * ((r >> 2) % (PASS_R / 4)) + 4 * half;
             ep[lrow * WCOLS + 32 * j + l31] = acc[i][j][r] * p.acc_scale;
           }
         // same-wave LDS ops are ordered; the compiler waits on lgkmcnt before the reads below
@@ -362,14 +366,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f16x3_kernel(const CsConvGem
           // columns of this wave = [x (WCOLS/2) | gate (WCOLS/2)] (weights packed that way by the host):
           // out[m][n/2 ..] = (x + bias_x) * gelu(gate + bias_g)   -- attention.py:44-46 fused into ff.net.0.proj
           constexpr int HC = WCOLS / 2;
-          constexpr int UNITS = 16 * (HC / 4);
+          constexpr int UNITS = EPI_ROWS * (HC / 4);
 #pragma unroll
           for (int u0 = 0; u0 < UNITS; u0 += 64) {
             const int u = u0 + lane;
             if (u < UNITS) {
               const int lrow = u / (HC / 4);
               const int c4 = u - lrow * (HC / 4);
-              const int m = m0 + wm0 + 32 * i + 16 * ph + lrow;
+              const int m = m0 + wm0 + 32 * i + EPI_ROWS * ph + lrow;
               const int n = n0 + wn0 + 4 * c4;
               if (m < M) {
                 f32x4 xv = *reinterpret_cast<const f32x4*>(ep + lrow * WCOLS + 4 * c4);
@@ -386,14 +390,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f16x3_kernel(const CsConvGem
           }
           continue;
         }
-        constexpr int UNITS = 16 * (WCOLS / 4);
+        constexpr int UNITS = EPI_ROWS * (WCOLS / 4);
 #pragma unroll
         for (int u0 = 0; u0 < UNITS; u0 += 64) {
           const int u = u0 + lane;
           if (u < UNITS) {
             const int lrow = u / (WCOLS / 4);
             const int c4 = u - lrow * (WCOLS / 4);
-            const int m = m0 + wm0 + 32 * i + 16 * ph + lrow;
+            const int m = m0 + wm0 + 32 * i + EPI_ROWS * ph + lrow;
             const int n = n0 + wn0 + 4 * c4;
             if (m < M) {
               f32x4 v = *reinterpret_cast<const f32x4*>(ep + lrow * WCOLS + 4 * c4);
@@ -463,7 +467,7 @@ int launch16(const CsConvGemm& p, int M, hipStream_t stream) {
     constexpr int WCOLS = 32 * WNB;
     if (!vec || (WCOLS / 2) % 4 || p.cout % WCOLS || p.scale || p.rowvec || p.res) return CS_EINVAL;
   }
-  CS_LAUNCH((conv_gemm_f16x3_kernel<WMB, WNB, WAVES_M, WAVES_N, PRE>), dim3((unsigned)nblk), dim3(256), 0,
+  CS_LAUNCH((conv_gemm_f16x3_kernel<WMB, WNB, WAVES_M, WAVES_N, PRE>), dim3((unsigned)nblk), dim3(64 * WAVES_M * WAVES_N), 0,
             stream, p, M, tiles_n, p.kh * p.kw, p.kw, kg_per_tap, (unsigned)x_bytes, (unsigned)w_bytes, vec);
   CS_CHECK_LAUNCH();
   return CS_OK;
@@ -508,6 +512,7 @@ int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p_in, int M, int tile, hipStre
       case 1: return launch16<2, 2, 2, 2, true>(p, M, s);
       case 2: return launch16<1, 7, 4, 1, true>(p, M, s);
       case 3: return launch16<1, 1, 2, 2, true>(p, M, s);
+      case 4: return launch16<1, 7, 8, 1, true>(p, M, s);
       default: return CS_EINVAL;
     }
   }
@@ -516,6 +521,7 @@ int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p_in, int M, int tile, hipStre
     case 1: return launch16<2, 2, 2, 2, false>(p, M, s);
     case 2: return launch16<1, 7, 4, 1, false>(p, M, s);
     case 3: return launch16<1, 1, 2, 2, false>(p, M, s);
+    case 4: return launch16<1, 7, 8, 1, false>(p, M, s);
     default: return CS_EINVAL;
   }
 }

@@ -241,7 +241,7 @@ def conv_gemm(x: Tensor, w: PackedWeight, *, spatial: Optional[Tuple[int, int, i
     if prof is not None:
         e1.record()
         prof.append(dict(e0=e0, e1=e1, flops=2.0 * mo * w.cout * w.cin * kd * kh * kw, taps=kd * kh * kw,
-                         m=mo, n=w.cout, k=w.cin * kd * kh * kw, tile=tile_for(mo, w.cout, tile)))
+                         m=mo, n=w.cout, k=w.cin * kd * kh * kw, tile=tile_for(mo, w.cout, tile, w.math)))
     return out
 
 
@@ -250,11 +250,13 @@ def conv_gemm(x: Tensor, w: PackedWeight, *, spatial: Optional[Tuple[int, int, i
 GEMM_PROFILE = None
 
 
-def tile_for(m: int, cout: int, tile: int = 0) -> int:
+def tile_for(m: int, cout: int, tile: int = 0, math: int = L.MATH_FP32) -> int:
     """mirror of the tile auto-selection in cs_conv_gemm (csrc/cs_gemm.hip)."""
     if tile:
         return tile
     mt = (m + 127) // 128
+    if math == L.MATH_F16X3 and cout % 224 == 0 and ((m + 255) // 256) * (cout // 224) >= 192:
+        return 4
     if cout % 224 == 0 and mt * (cout // 224) >= 256:
         return 2
     if cout > 64 and mt * ((cout + 127) // 128) >= 256:

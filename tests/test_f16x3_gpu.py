@@ -25,6 +25,10 @@ CASES = [
     (3, 4, 4, 4, 40, 72, 1, (1, 1, 1), (0, 0, 0), 1),
     (1, 5, 7, 3, 20, 36, 3, (1, 1, 1), (0, 0, 0), 3),
     (1, 8, 8, 8, 672, 224, 3, (1, 1, 1), (0, 0, 0), 2),      # K = 18144
+    (2, 4, 8, 8, 32, 224, 3, (1, 1, 1), (0, 0, 0), 4),       # 256-row, 8-wave tile
+    (1, 5, 7, 3, 20, 236, 3, (1, 1, 1), (0, 0, 0), 4),       # ragged M and N on it (scalar epilogue on the edge tile)
+    (3, 4, 8, 8, 48, 448, 3, (1, 2, 2), (0, 0, 0), 4),
+    (1, 4, 8, 8, 64, 224, 3, (1, 1, 1), (0, 1, 1), 4),
 ]
 
 
@@ -185,7 +189,8 @@ def test_f16x3_attention_spiked_logits():
     assert rel_l2(out, ref) < 2e-6
 
 
-def test_f16x3_fused_geglu_projection():
+@pytest.mark.parametrize("tile", [2, 4])
+def test_f16x3_fused_geglu_projection(tile):
     """ff.net.0.proj + GEGLU gate in one GEMM (act=ACT_GEGLU) == Linear -> chunk -> x * gelu(gate)."""
     from commonscenes_amd import lib as L, ops
     m, c, h = 300, 448, 1792
@@ -195,7 +200,7 @@ def test_f16x3_fused_geglu_projection():
     y = x.double() @ w.double().t() + b.double()
     a, g = y.chunk(2, dim=-1)
     ref = a * torch.nn.functional.gelu(g)
-    out = ops.linear(x.cuda(), ops.pack_geglu_weight(w.cuda(), b.cuda()), act=L.ACT_GEGLU, tile=2)
+    out = ops.linear(x.cuda(), ops.pack_geglu_weight(w.cuda(), b.cuda()), act=L.ACT_GEGLU, tile=tile)
     torch.cuda.synchronize()
     assert out.shape == (m, h)
     assert rel_l2(out, ref) < 2e-6
