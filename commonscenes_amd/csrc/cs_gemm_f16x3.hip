@@ -34,7 +34,9 @@ constexpr float A_SCALE_DEFAULT = 16.0f;
 constexpr unsigned OOB = 0xFFF00000u;   // byte offset past every buffer (extents are < 0xFFE00000): reads 0
 constexpr int MAX_TAPS = 27;
 #ifndef CS_ABLATE
-#define CS_ABLATE 0   // debug: 1 = no DMA issue, 8 = no barrier
+#define CS_ABLATE 0   // debug builds, timing only (results are wrong): 1 = no DMA issue, 2 = DMAs fetch nothing (all
+                      // offsets out of range -> zero fill), 4 = no vmcnt wait in the loop, 8 = no barrier,
+                      // 16 = s_setprio around the MFMAs, 32 = scalar epilogue, 64 = all fetches from one 16 KB window
 #endif
 
 __device__ __forceinline__ void split8(const f32x4& x, const f32x4& y, float a_scale, h8& hi, h8& lo) {
@@ -202,9 +204,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
       const short dl = delta[tap * BM + a_rowidx[i]];
       const int c = cc * BKH + (int)a_piece[i];
       constexpr unsigned ESZ = PRE ? 2u : 4u;
-      const unsigned off = (dl != INVALID && c < p.cin)
-                               ? (unsigned)(a_rowbase[i] + (int)dl) * ((unsigned)p.lda * ESZ) + (unsigned)c * ESZ
-                               : OOB;
+      unsigned off = (dl != INVALID && c < p.cin)
+                         ? (unsigned)(a_rowbase[i] + (int)dl) * ((unsigned)p.lda * ESZ) + (unsigned)c * ESZ
+                         : OOB;
+      if (CS_ABLATE & 2) off = OOB;
+      if ((CS_ABLATE & 64) && off != OOB) off &= 0x3FF0u;      // every fetch from one 16 KB window (cache hits)
       const int w = wave * A_PW + i;                      // wave-uniform
       if constexpr (PRE) {
         if (w >= A_WI / 2)
@@ -220,7 +224,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
     for (int i = 0; i < B_PW; ++i) {
       const int v = wave * B_PW + i;                       // wave-uniform
       const int img = v / B_WI;
-      const unsigned off = (b_off[i] == OOB || cc >= chunks_per_tap) ? OOB : b_off[i] + kbase;
+      unsigned off = (b_off[i] == OOB || cc >= chunks_per_tap) ? OOB : b_off[i] + kbase;
+      if (CS_ABLATE & 2) off = OOB;
+      if ((CS_ABLATE & 64) && off != OOB) off &= 0x3FF0u;
       unsigned char* dst = (v < 2 * B_WI) ? st + A_BYTES + img * B_BYTES + (v - img * B_WI) * 1024 : smem + DUMP;
       if (img == 1)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(lrs, dst, 16, off, 0, 0, 0);
@@ -297,7 +303,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
     constexpr int stage = decltype(stage_c)::value;
     constexpr int nstage = (stage + 1) % NSTAGE;
     constexpr int dstage = (stage + 2) % NSTAGE;
-    wait_vmcnt<B_PW>();
+    if (!(CS_ABLATE & 4)) wait_vmcnt<B_PW>();
     if (!(CS_ABLATE & 8)) __builtin_amdgcn_s_barrier();
     const unsigned char* s = smem + stage * STAGE;
     h8 ah2[WMB], al2[WMB];
