@@ -126,6 +126,37 @@ __global__ __launch_bounds__(256) void ddim_update_kernel(const float* __restric
   }
 }
 
+// Same update with the five step coefficients read from device memory: a captured HIP graph of one sampling
+// step is replayed for every timestep, only the 20-byte coefficient block (and the timestep vector) change.
+__global__ __launch_bounds__(256) void ddim_update_dev_kernel(const float* __restrict__ x,
+                                                              const float* __restrict__ eps,
+                                                              const float* __restrict__ noise,
+                                                              float* __restrict__ x_prev,
+                                                              float* __restrict__ pred_x0, int64_t n,
+                                                              int64_t uc_off, const float* __restrict__ coef,
+                                                              float cfg_scale, int cfg) {
+  const float sqrt_at = coef[0], sqrt_aprev = coef[1], dir_coef = coef[2], sigma_t = coef[3],
+              sqrt_one_minus_at = coef[4];
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float e;
+    if (cfg) {
+      const float eu = eps[i];
+      const float ec = eps[uc_off + i];
+      e = eu + cfg_scale * (ec - eu);
+    } else {
+      e = eps[i];
+    }
+    const float xv = x[i];
+    const float p0 = (xv - sqrt_one_minus_at * e) / sqrt_at;
+    const float dir = dir_coef * e;
+    float xp = sqrt_aprev * p0 + dir;
+    xp += noise ? sigma_t * noise[i] : 0.f;
+    if (pred_x0) pred_x0[i] = p0;
+    x_prev[i] = xp;
+  }
+}
+
 // VQ: codebook (+ squared norms) staged in LDS; every lane scans all codes with broadcast reads.
 __global__ __launch_bounds__(256) void vq_kernel(const float* __restrict__ z, const float* __restrict__ cb,
                                                  int64_t* __restrict__ idx, float* __restrict__ zq,
@@ -362,6 +393,28 @@ extern "C" int cs_ddim_cfg_update(const float* x, const float* eps, const float*
   CS_LAUNCH(ddim_update_kernel, dim3(cs_grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x,
                      eps, noise, x_prev, pred_x0, n, n, sqrt_at, sqrt_aprev, dir_coef, sigma_t,
                      sqrt_one_minus_at, cfg_scale, cfg);
+  CS_CHECK_LAUNCH();
+  return CS_OK;
+}
+
+extern "C" int cs_ddim_coefficients(float a_t, float a_prev, float sigma_t, float sqrt_one_minus_at,
+                                    float* coef5_host) {
+  if (!coef5_host || !(a_t > 0.f) || a_prev < 0.f) return CS_EINVAL;
+  coef5_host[0] = sqrtf(a_t);
+  coef5_host[1] = sqrtf(a_prev);
+  coef5_host[2] = sqrtf(1.0f - a_prev - sigma_t * sigma_t);
+  coef5_host[3] = sigma_t;
+  coef5_host[4] = sqrt_one_minus_at;
+  return CS_OK;
+}
+
+extern "C" int cs_ddim_cfg_update_dev(const float* x, const float* eps, const float* noise, float* x_prev,
+                                      float* pred_x0, int64_t nb, int64_t per, const float* coef5_dev,
+                                      float cfg_scale, int cfg, cs_stream_t stream) {
+  if (!x || !eps || !x_prev || !coef5_dev || nb <= 0 || per <= 0) return CS_EINVAL;
+  const int64_t n = nb * per;
+  CS_LAUNCH(ddim_update_dev_kernel, dim3(cs_grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, eps, noise,
+            x_prev, pred_x0, n, n, coef5_dev, cfg_scale, cfg);
   CS_CHECK_LAUNCH();
   return CS_OK;
 }

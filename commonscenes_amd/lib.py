@@ -70,6 +70,8 @@ SIGNATURES = {
     "cs_ndhwc_to_nchw": (_i, [_f, _f, _i, _i, _i, _i, _s]),
     "cs_timestep_embedding": (_i, [_f, _f, _i, _i, _fl, _s]),
     "cs_ddim_cfg_update": (_i, [_f, _f, _f, _f, _f, _l, _l, _fl, _fl, _fl, _fl, _fl, _i, _s]),
+    "cs_ddim_coefficients": (_i, [_fl, _fl, _fl, _fl, _f]),
+    "cs_ddim_cfg_update_dev": (_i, [_f, _f, _f, _f, _f, _l, _l, _f, _fl, _i, _s]),
     "cs_vq_argmin_lookup": (_i, [_f, _f, _f, _f, _l, _i, _i, _i, _i, _s]),
     "cs_gcn_gather_cat": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _f, _s]),
     "cs_gcn_segment_mean": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _f, _s]),

@@ -459,6 +459,32 @@ def ddim_cfg_update(x: Tensor, eps: Tensor, a_t: float, a_prev: float, sigma_t: 
     return xp, p0
 
 
+def ddim_coefficients(a_t: float, a_prev: float, sigma_t: float, sqrt_one_minus_at: float) -> Tuple[float, ...]:
+    """Host helper: the five fp32 coefficients cs_ddim_cfg_update derives from its scalar arguments."""
+    buf = (C.c_float * 5)()
+    L.check(L.load().cs_ddim_coefficients(a_t, a_prev, sigma_t, sqrt_one_minus_at,
+                                          C.cast(buf, C.c_void_p).value), "cs_ddim_coefficients")
+    return tuple(float(v) for v in buf)
+
+
+def ddim_cfg_update_dev(x: Tensor, eps: Tensor, coef: Tensor, cfg_scale: float, cfg: bool,
+                        noise: Optional[Tensor] = None, pred_x0: Optional[Tensor] = None,
+                        out: Optional[Tensor] = None) -> Tensor:
+    """ddim_cfg_update with the step coefficients (ddim_coefficients(...)) in a 5-float device tensor."""
+    _chk(x, "x"); _chk(eps, "eps"); _chk(coef, "coef")
+    if not (x.is_contiguous() and eps.is_contiguous()) or coef.numel() < 5:
+        raise L.CsError("ddim_cfg_update_dev needs contiguous x / eps and a 5-float coefficient block")
+    nb = x.shape[0]
+    per = x.numel() // nb
+    if eps.numel() != (2 if cfg else 1) * x.numel():
+        raise L.CsError("eps must hold [uc; c] halves when cfg is on")
+    xp = out if out is not None else torch.empty_like(x)
+    L.check(L.load().cs_ddim_cfg_update_dev(x.data_ptr(), eps.data_ptr(), _ptr(noise), xp.data_ptr(),
+                                            _ptr(pred_x0), nb, per, coef.data_ptr(), cfg_scale,
+                                            1 if cfg else 0, _stream()), "cs_ddim_cfg_update_dev")
+    return xp
+
+
 def vq_lookup(z: Tensor, codebook: Tensor) -> Tuple[Tensor, Tensor]:
     """z: [..., ld>=edim] rows (first edim columns used); returns (idx int64 [M], zq [..., edim_pad])."""
     _chk(z, "z"); _chk(codebook, "codebook")

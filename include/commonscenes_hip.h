@@ -203,6 +203,20 @@ int cs_ddim_cfg_update(const float* x, const float* eps, const float* noise, flo
                        cs_stream_t stream);
 
 /*
+ * The same update for a CAPTURED sampling step (one HIP graph replayed for every timestep of
+ * DDIMSampler.ddim_sampling, samplers/ddim.py:146-179): the step's coefficients live in device memory.
+ *   cs_ddim_coefficients : HOST helper, no device work.  Fills coef5_host = {sqrt(a_t), sqrt(a_prev),
+ *                          sqrt(1 - a_prev - sigma_t^2), sigma_t, sqrt_one_minus_at} with exactly the fp32
+ *                          arithmetic cs_ddim_cfg_update performs, so both entry points give identical bits.
+ *   cs_ddim_cfg_update_dev : coef5_dev = that block, resident on the device (the caller copies the step's
+ *                          row there before each replay).  Everything else as cs_ddim_cfg_update.
+ */
+int cs_ddim_coefficients(float a_t, float a_prev, float sigma_t, float sqrt_one_minus_at, float* coef5_host);
+int cs_ddim_cfg_update_dev(const float* x, const float* eps, const float* noise, float* x_prev,
+                           float* pred_x0, int64_t nb, int64_t per, const float* coef5_dev,
+                           float cfg_scale, int cfg, cs_stream_t stream);
+
+/*
  * VQ nearest-code lookup (quantizer.py:76-84): z [m][ldz] (first edim entries of each row),
  * codebook [ncode][edim] -> idx[m] (int64, first minimum) and zq [m][ldq] = codebook[idx].
  * d = sum(z^2) + sum(e^2) - 2 z.e evaluated in fp32 in that order.  edim <= 4.

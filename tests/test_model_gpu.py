@@ -193,6 +193,48 @@ def test_ddim_guidance_scale_one_is_unconditional_path():
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("cfg", [True, False])
+def test_ddim_graph_replay_equals_eager_loop(cfg):
+    """The captured-step replay loop (one hipGraph, device-resident timestep + coefficients) must reproduce the
+    eager loop bit for bit, including the reference's `intermediates` bookkeeping (ddim.py:175-177)."""
+    from commonscenes_amd import synth
+    from commonscenes_amd.ddim import DDIMSampler
+    m = _SamplerModel(_unet(True))
+    x_T = synth.gaussian_like("gr:x", (3, 3, 16, 16, 16)).cuda()
+    c = synth.gaussian_like("gr:c", (3, 1, 1280)).cuda()
+    uc = synth.gaussian_like("gr:uc", (3, 1, 1280)).cuda()
+    kw = dict(conditioning=c, x_T=x_T, verbose=False, log_every_t=2)
+    if cfg:
+        kw.update(unconditional_guidance_scale=3.0, unconditional_conditioning=uc)
+    outs = []
+    for use_graph in (False, True):
+        s = DDIMSampler(m)
+        s.use_graph = use_graph
+        x, inter = s.sample(5, 3, (3, 16, 16, 16), **kw)
+        torch.cuda.synchronize()
+        outs.append((x, inter))
+    (xe, ie), (xg, ig) = outs
+    assert torch.isfinite(xg).all()
+    assert torch.equal(xe, xg)
+    assert len(ie["x_inter"]) == len(ig["x_inter"]) == 1 + 3       # x_T + indices 4, 2, 0
+    for a, b in zip(ie["x_inter"] + ie["pred_x0"], ig["x_inter"] + ig["pred_x0"]):
+        assert torch.equal(a, b)
+
+
+def test_ddim_coefficient_helper_matches_scalar_entry():
+    """cs_ddim_cfg_update_dev + cs_ddim_coefficients == cs_ddim_cfg_update on the same step."""
+    from commonscenes_amd import ops, synth
+    x = synth.gaussian_like("dc:x", (2, 3, 16, 16, 16)).cuda()
+    eps = synth.gaussian_like("dc:e", (4, 3, 16, 16, 16)).cuda()
+    a_t, a_prev, s1m = 0.4321, 0.5678, float(np.sqrt(np.float32(1 - 0.4321)))
+    ref, p0 = ops.ddim_cfg_update(x, eps, a_t, a_prev, 0.0, s1m, 3.0, True)
+    coef = torch.tensor(ops.ddim_coefficients(a_t, a_prev, 0.0, s1m), dtype=torch.float32).cuda()
+    p1 = torch.empty_like(x)
+    out = ops.ddim_cfg_update_dev(x, eps, coef, 3.0, True, pred_x0=p1)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref) and torch.equal(p1, p0)
+
+
 # ---------------------------------------------------------------------------------------------------
 # VQ decode
 # ---------------------------------------------------------------------------------------------------
