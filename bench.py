@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--cpu-objects", type=int, default=4, help="objects in the bounded CPU-baseline sample")
     ap.add_argument("--math", choices=["fp32", "f16x3"], default=os.environ.get("CS_MATH", "f16x3"),
                     help="GEMM numerics: fp32-input MFMA, or fp32 carried as fp16 hi/lo pairs on the fp16 MFMA")
+    ap.add_argument("--driver", choices=["python", "native"], default="python",
+                    help="who sequences the UNet's kernels: commonscenes_amd/unet.py (default; carries the per-GEMM "
+                         "HIP-event hooks the roofline block needs) or the native cs_unet_step driver")
     ap.add_argument("--gemm-table", action="store_true", help="print per-shape GEMM timings to stderr (debug)")
     ap.add_argument("--small", action="store_true", help="reduced-width UNet (debug only; result is not the metric)")
     return ap.parse_args()
@@ -104,7 +107,11 @@ def main():
     from oracle.ref_torch import DIFFUSION, UNET_FULL, UNET_SMALL, register_schedule
 
     cfg = dict(UNET_SMALL if a.small else UNET_FULL, dims=3, use_spatial_transformer=True)
-    df = DiffusionUNet(cfg, conditioning_key="crossattn", device=dev).set_math(a.math)
+    if a.driver == "native":
+        from commonscenes_amd.unet_native import NativeDiffusionUNet
+        df = NativeDiffusionUNet(cfg, conditioning_key="crossattn", device=dev, math=a.math)
+    else:
+        df = DiffusionUNet(cfg, conditioning_key="crossattn", device=dev).set_math(a.math)
     df.load_state_dict(synth.synth_state_dict(unet_param_shapes(cfg), device=str(dev)))
     sch = register_schedule(**DIFFUSION)
 
@@ -194,7 +201,7 @@ def main():
         conv_fl = sum(r["flops"] for r in conv)
         all_ms = sum(r["e0"].elapsed_time(r["e1"]) for r in prof)
         all_fl = sum(r["flops"] for r in prof)
-        achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else None   # None: --driver native (no hooks)
         if a.gemm_table:
             agg = {}
             for r in prof:
@@ -236,7 +243,7 @@ def main():
                        "objects_per_gpu": B, "unet_batch": 2 * B, "ddim_steps": S,
                        "parallelism": f"object-sharded x{world} (replicated weights, no per-step collective)"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic,
+                         "frac": achieved / peak if achieved is not None else None, "traffic": traffic,
                          "traffic_note": "HBM bytes per launch of the dominant kernel, FETCH_SIZE x2 (gfx950) + WRITE_SIZE, "
                                          "from profiles/r01_traffic_*.json (separate rocprofv3 --pmc passes of this command)",
                          "kernel": kname, "math": a.math,
@@ -247,7 +254,7 @@ def main():
                          "all_gemm_share_of_step_time": all_ms / (dt * 1e3),
                          "whole_step_tflops": (2 * B * UNET_GFLOP_PER_SAMPLE * 1e9 * a.steps / dt / 1e12)
                          if not a.small else None},
-            "conditioning_ms": cond_ms, "finite": finite,
+            "conditioning_ms": cond_ms, "finite": finite, "unet_driver": a.driver,
         }
         if not a.no_cpu_baseline and not a.small:
             res["cpu_baseline"] = cpu_baseline(df, cfg, a.cpu_objects, B)

@@ -1,0 +1,909 @@
+// cs_unet_*: the whole UNet forward of the shape-branch denoiser as ONE native call over a packed weight arena
+// (SURVEY 8b "cs_unet_step").  Host-side C++ only sequences the library's own kernels (cs_conv_gemm,
+// cs_groupnorm_*, cs_layernorm, cs_attn_selfattn*, cs_copy_rows, ...) -- the same launches, in the same order,
+// with the same arguments as commonscenes_amd/unet.py::DiffusionUNet.forward_ndhwc, so both drivers produce
+// identical bits -- and owns nothing on the device: the caller passes the raw parameters, the arena, the
+// workspace and the stream.
+//
+// Reference being replaced:
+//   model/networks/diffusion_networks/openai_model_3d.py:452-789   UNet3DModel.__init__ / forward
+//   model/networks/diffusion_networks/attention.py:154-351         CrossAttention / BasicTransformerBlock /
+//                                                                  SpatialTransformer3D
+//   model/networks/diffusion_networks/network.py:20-42             DiffusionUNet.forward (crossattn branch)
+// Scope: the shipped config family (dims=3 i.e. H,W-only resampling, use_spatial_transformer, one transformer
+// block per SpatialTransformer3D, ONE context token -- SURVEY F4: cross-attention over a single key is the
+// per-sample row vector to_out(to_v(ctx)), computed once per sampling run by cs_unet_context).
+#include "cs_common.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+constexpr int64_t ALIGN = 256;
+inline int64_t align_up(int64_t v) { return (v + ALIGN - 1) / ALIGN * ALIGN; }
+
+struct Param {
+  std::string name;
+  int64_t shape[5];
+  int ndim;
+  int64_t numel;
+  int64_t raw_off;   // bytes into the caller's raw parameter buffer
+};
+
+struct Piece {       // rows [row0, row0 + rows) of parameter `param` seen as a [rows_total][cols] matrix
+  int param;
+  int row0;
+  int rows;
+};
+
+struct Gemm {        // one packed GEMM weight (possibly several reference tensors concatenated along cout)
+  std::vector<Piece> w, b;
+  int cout = 0, cin = 0, cin_pad = 0, k = 1, taps = 1, ldw = 0;
+  int64_t w_off = 0, wlo_off = 0, b_off = -1;
+  float acc_scale = 1.f;
+};
+
+struct Norm {
+  int gp, bp, c;
+  int64_t g_off, b_off;
+};
+
+enum Kind { CONV_IN, RES, ATTN, DOWN, UP };
+
+struct Layer {
+  Kind kind;
+  int cin, cout;
+  int g[8];
+  int n[4];
+  int emb_lo = 0;      // RES: column offset into the batched emb_layers projection
+  int ctx_off = 0;     // ATTN: column offset into the context-vector block
+  bool fused_geglu = false;
+};
+
+struct FreeBlock {
+  int64_t off, size;
+};
+
+}  // namespace
+
+struct cs_unet {
+  CsUnetConfig cfg;
+  std::vector<Param> params;
+  std::vector<Gemm> gemms;
+  std::vector<Norm> norms;
+  std::vector<std::vector<Layer>> inp, out;
+  std::vector<Layer> mid;
+  int g_te0 = -1, g_te2 = -1, g_emb_all = -1, g_out = -1, n_out = -1;
+  int emb_total = 0, ctx_total = 0, cpad_in = 4, ch_final = 0;
+  int64_t raw_bytes = 0, arena_bytes = 0, amax_off = 0;
+  bool packed = false;
+};
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------
+// plan construction (mirrors unet.py::unet_blocks / unet_param_shapes / DiffusionUNet._pack)
+// ---------------------------------------------------------------------------------------------------------
+int add_param(cs_unet& u, const std::string& name, std::initializer_list<int64_t> shape) {
+  Param p;
+  p.name = name;
+  p.ndim = (int)shape.size();
+  p.numel = 1;
+  int i = 0;
+  for (int64_t s : shape) {
+    p.shape[i++] = s;
+    p.numel *= s;
+  }
+  for (; i < 5; ++i) p.shape[i] = 1;
+  p.raw_off = u.raw_bytes;
+  u.raw_bytes += align_up(p.numel * 4);
+  u.params.push_back(p);
+  return (int)u.params.size() - 1;
+}
+
+int add_norm(cs_unet& u, const std::string& p, int c) {
+  Norm n;
+  n.gp = add_param(u, p + ".weight", {c});
+  n.bp = add_param(u, p + ".bias", {c});
+  n.c = c;
+  n.g_off = n.b_off = 0;
+  u.norms.push_back(n);
+  return (int)u.norms.size() - 1;
+}
+
+// registers <p>.weight (+ .bias); returns the parameter indices
+void add_wb(cs_unet& u, const std::string& p, int o, int i, int k, bool bias, int& wp, int& bp) {
+  if (k > 1)
+    wp = add_param(u, p + ".weight", {o, i, k, k, k});
+  else if (k == 1)
+    wp = add_param(u, p + ".weight", {o, i, 1, 1, 1});
+  else
+    wp = add_param(u, p + ".weight", {o, i});   // Linear
+  bp = bias ? add_param(u, p + ".bias", {o}) : -1;
+}
+
+int add_gemm(cs_unet& u, std::vector<Piece> w, std::vector<Piece> b, int cout, int cin, int k, int cin_pad = 0) {
+  Gemm g;
+  g.w = std::move(w);
+  g.b = std::move(b);
+  g.cout = cout;
+  g.cin = cin;
+  g.k = k < 1 ? 1 : k;
+  g.taps = g.k * g.k * g.k;
+  g.cin_pad = cin_pad ? cin_pad : (cin + 3) / 4 * 4;
+  u.gemms.push_back(g);
+  return (int)u.gemms.size() - 1;
+}
+
+// conv (k = 3 or 1) or Linear (k = 0) as a single-tensor GEMM
+int add_layer_gemm(cs_unet& u, const std::string& p, int o, int i, int k, bool bias = true, int cin_pad = 0) {
+  int wp, bp;
+  add_wb(u, p, o, i, k, bias, wp, bp);
+  std::vector<Piece> b;
+  if (bp >= 0) b.push_back({bp, 0, o});
+  return add_gemm(u, {{wp, 0, o}}, b, o, i, k, cin_pad);
+}
+
+struct EmbAcc {
+  std::vector<Piece> w, b;
+  int total = 0;
+};
+
+Layer make_res(cs_unet& u, const std::string& p, int cin, int cout, int ted, EmbAcc& emb) {
+  Layer l{};
+  l.kind = RES;
+  l.cin = cin;
+  l.cout = cout;
+  l.n[0] = add_norm(u, p + ".in_layers.0", cin);
+  l.g[0] = add_layer_gemm(u, p + ".in_layers.2", cout, cin, 3);
+  int wp, bp;
+  add_wb(u, p + ".emb_layers.1", cout, ted, 0, true, wp, bp);
+  emb.w.push_back({wp, 0, cout});
+  emb.b.push_back({bp, 0, cout});
+  l.emb_lo = emb.total;
+  emb.total += cout;
+  l.n[1] = add_norm(u, p + ".out_layers.0", cout);
+  l.g[1] = add_layer_gemm(u, p + ".out_layers.3", cout, cout, 3);
+  l.g[2] = (cin != cout) ? add_layer_gemm(u, p + ".skip_connection", cout, cin, 1) : -1;
+  return l;
+}
+
+Layer make_attn(cs_unet& u, const std::string& p, int c, int ctx_dim, bool f16x3) {
+  Layer l{};
+  l.kind = ATTN;
+  l.cin = l.cout = c;
+  l.n[0] = add_norm(u, p + ".norm", c);
+  l.g[0] = add_layer_gemm(u, p + ".proj_in", c, c, 1);
+  const std::string t = p + ".transformer_blocks.0";
+  int q, k, v, dummy;
+  add_wb(u, t + ".attn1.to_q", c, c, 0, false, q, dummy);
+  add_wb(u, t + ".attn1.to_k", c, c, 0, false, k, dummy);
+  add_wb(u, t + ".attn1.to_v", c, c, 0, false, v, dummy);
+  l.g[1] = add_gemm(u, {{q, 0, c}, {k, 0, c}, {v, 0, c}}, {}, 3 * c, c, 0);      // fused q|k|v projection
+  l.g[2] = add_layer_gemm(u, t + ".attn1.to_out.0", c, c, 0);
+  // attn2.to_q / to_k are parameters of the reference module but unused with one context token (softmax == 1)
+  add_wb(u, t + ".attn2.to_q", c, c, 0, false, q, dummy);
+  add_wb(u, t + ".attn2.to_k", c, ctx_dim, 0, false, k, dummy);
+  l.g[3] = add_layer_gemm(u, t + ".attn2.to_v", c, ctx_dim, 0, false);
+  l.g[4] = add_layer_gemm(u, t + ".attn2.to_out.0", c, c, 0);
+  int wp, bp;
+  add_wb(u, t + ".ff.net.0.proj", 8 * c, c, 0, true, wp, bp);
+  const int hdim = 4 * c;
+  l.fused_geglu = f16x3 && (hdim % 112 == 0);
+  if (l.fused_geglu) {
+    // output columns interleaved per 224-column tile as [x (112) | gate (112)]  (ops.pack_geglu_weight)
+    std::vector<Piece> w, b;
+    for (int blk = 0; blk < hdim / 112; ++blk) {
+      w.push_back({wp, blk * 112, 112});
+      w.push_back({wp, hdim + blk * 112, 112});
+      b.push_back({bp, blk * 112, 112});
+      b.push_back({bp, hdim + blk * 112, 112});
+    }
+    l.g[5] = add_gemm(u, w, b, 8 * c, c, 0);
+  } else {
+    l.g[5] = add_gemm(u, {{wp, 0, 8 * c}}, {{bp, 0, 8 * c}}, 8 * c, c, 0);
+  }
+  l.g[6] = add_layer_gemm(u, t + ".ff.net.2", c, 4 * c, 0);
+  l.n[1] = add_norm(u, t + ".norm1", c);
+  l.n[2] = add_norm(u, t + ".norm2", c);
+  l.n[3] = add_norm(u, t + ".norm3", c);
+  l.g[7] = add_layer_gemm(u, p + ".proj_out", c, c, 1);
+  l.ctx_off = u.ctx_total;
+  u.ctx_total += c;
+  return l;
+}
+
+bool in_list(const int32_t* v, int n, int x) {
+  for (int i = 0; i < n; ++i)
+    if (v[i] == x) return true;
+  return false;
+}
+
+int build(cs_unet& u) {
+  const CsUnetConfig& c = u.cfg;
+  if (c.model_channels <= 0 || c.model_channels % 32 || c.num_res_blocks <= 0 || c.n_mult <= 0 || c.n_mult > 8 ||
+      c.n_attn_res < 0 || c.n_attn_res > 8 || c.num_heads <= 0 || c.context_dim <= 0 || c.in_channels <= 0 ||
+      c.out_channels <= 0 || c.d <= 0 || c.h <= 0 || c.w <= 0)
+    return CS_EINVAL;
+  if (c.math != CS_MATH_FP32 && c.math != CS_MATH_F16X3) return CS_EINVAL;
+  if ((c.h >> (c.n_mult - 1)) << (c.n_mult - 1) != c.h || (c.w >> (c.n_mult - 1)) << (c.n_mult - 1) != c.w)
+    return CS_EINVAL;
+  const bool f16 = c.math == CS_MATH_F16X3;
+  const int mc = c.model_channels, ted = 4 * mc, nres = c.num_res_blocks;
+  const std::string P = "diffusion_net.";
+  u.cpad_in = (c.in_channels + 3) / 4 * 4;
+  u.g_te0 = add_layer_gemm(u, P + "time_embed.0", ted, mc, 0);
+  u.g_te2 = add_layer_gemm(u, P + "time_embed.2", ted, ted, 0);
+  EmbAcc emb;
+  std::vector<int> chans;
+  int ch = mc, ds = 1, bi = 0;
+  {
+    Layer l{};
+    l.kind = CONV_IN;
+    l.cin = c.in_channels;
+    l.cout = mc;
+    l.g[0] = add_layer_gemm(u, P + "input_blocks.0.0", mc, c.in_channels, 3, true, u.cpad_in);
+    u.inp.push_back({l});
+    chans.push_back(mc);
+    bi = 1;
+  }
+  for (int level = 0; level < c.n_mult; ++level) {
+    const int m = c.channel_mult[level];
+    if (m <= 0) return CS_EINVAL;
+    for (int r = 0; r < nres; ++r) {
+      const std::string bp = P + "input_blocks." + std::to_string(bi++);
+      std::vector<Layer> layers;
+      layers.push_back(make_res(u, bp + ".0", ch, m * mc, ted, emb));
+      ch = m * mc;
+      if (ch % c.num_heads) return CS_EINVAL;
+      if (in_list(c.attention_resolutions, c.n_attn_res, ds))
+        layers.push_back(make_attn(u, bp + ".1", ch, c.context_dim, f16));
+      u.inp.push_back(layers);
+      chans.push_back(ch);
+    }
+    if (level != c.n_mult - 1) {
+      const std::string bp = P + "input_blocks." + std::to_string(bi++);
+      Layer l{};
+      l.kind = DOWN;
+      l.cin = l.cout = ch;
+      l.g[0] = add_layer_gemm(u, bp + ".0.op", ch, ch, 3);
+      u.inp.push_back({l});
+      chans.push_back(ch);
+      ds *= 2;
+    }
+  }
+  u.mid.push_back(make_res(u, P + "middle_block.0", ch, ch, ted, emb));
+  u.mid.push_back(make_attn(u, P + "middle_block.1", ch, c.context_dim, f16));
+  u.mid.push_back(make_res(u, P + "middle_block.2", ch, ch, ted, emb));
+  int oi = 0;
+  for (int level = c.n_mult - 1; level >= 0; --level) {
+    const int m = c.channel_mult[level];
+    for (int i = 0; i <= nres; ++i) {
+      const int ich = chans.back();
+      chans.pop_back();
+      const std::string bp = P + "output_blocks." + std::to_string(oi++);
+      std::vector<Layer> layers;
+      layers.push_back(make_res(u, bp + ".0", ch + ich, mc * m, ted, emb));
+      ch = mc * m;
+      if (in_list(c.attention_resolutions, c.n_attn_res, ds))
+        layers.push_back(make_attn(u, bp + ".1", ch, c.context_dim, f16));
+      if (level && i == nres) {
+        Layer l{};
+        l.kind = UP;
+        l.cin = l.cout = ch;
+        l.g[0] = add_layer_gemm(u, bp + "." + std::to_string(layers.size()) + ".conv", ch, ch, 3);
+        layers.push_back(l);
+        ds /= 2;
+      }
+      u.out.push_back(layers);
+    }
+  }
+  u.ch_final = ch;
+  u.n_out = add_norm(u, P + "out.0", ch);
+  u.g_out = add_layer_gemm(u, P + "out.2", c.out_channels, mc, 3);
+  // all ResBlock emb_layers Linears read the same SiLU(emb): one GEMM [nb, 4mc] x [4mc, sum(cout)]
+  u.g_emb_all = add_gemm(u, emb.w, emb.b, emb.total, ted, 0);
+  u.emb_total = emb.total;
+
+  // arena layout
+  int64_t off = 0;
+  for (Gemm& g : u.gemms) {
+    if (f16) {
+      const int64_t kg = (int64_t)(g.cin + 15) / 16 * 2;
+      const int64_t img = (int64_t)g.taps * kg * g.cout * 16;
+      g.ldw = g.cout;
+      g.w_off = off;
+      off += align_up(img);
+      g.wlo_off = off;
+      off += align_up(img);
+    } else {
+      g.ldw = (g.cout + 3) / 4 * 4;
+      g.w_off = off;
+      off += align_up((int64_t)g.taps * g.cin_pad * g.ldw * 4);
+    }
+    if (!g.b.empty()) {
+      g.b_off = off;
+      off += align_up((int64_t)g.cout * 4);
+    }
+  }
+  for (Norm& n : u.norms) {
+    n.g_off = off;
+    off += align_up((int64_t)n.c * 4);
+    n.b_off = off;
+    off += align_up((int64_t)n.c * 4);
+  }
+  u.amax_off = off;
+  off += align_up((int64_t)u.params.size() * 4);
+  u.arena_bytes = off;
+  return CS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// weight packing kernels (piece-wise versions of cs_pack_weight_f16x3 / cs_relayout_weight: a piece is a row
+// range of a reference tensor landing at a column offset of a possibly fused GEMM weight)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ w, int64_t n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float m = 0.f;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    m = fmaxf(m, fabsf(w[i]));
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    // non-negative floats order like their bit patterns
+    atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));
+  }
+}
+
+__global__ __launch_bounds__(256) void pack_part_f16x3_kernel(const float* __restrict__ w, _Float16* __restrict__ wh,
+                                                              _Float16* __restrict__ wl, int rows, int n_off,
+                                                              int cout_total, int cin, int taps, int kg_per_tap,
+                                                              float scale) {
+  const int64_t total = (int64_t)taps * kg_per_tap * rows * 8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 7);
+    int64_t t = i >> 3;
+    const int n = (int)(t % rows);
+    t /= rows;
+    const int kg = (int)(t % kg_per_tap);
+    const int tap = (int)(t / kg_per_tap);
+    const int c = kg * 8 + j;
+    float v = 0.f;
+    if (c < cin) v = w[((int64_t)n * cin + c) * taps + tap] * scale;
+    const _Float16 h = (_Float16)v;
+    const int64_t o = (((int64_t)tap * kg_per_tap + kg) * cout_total + n_off + n) * 8 + j;
+    wh[o] = h;
+    wl[o] = (_Float16)(v - (float)h);
+  }
+}
+
+__global__ __launch_bounds__(256) void pack_part_f32_kernel(const float* __restrict__ w, float* __restrict__ o,
+                                                            int rows, int n_off, int cin, int taps, int cin_pad,
+                                                            int ldw) {
+  // w: rows of a (cout, cin, taps) torch tensor; o: [tap][cin_pad][ldw], columns n_off .. n_off + rows
+  const int64_t total = (int64_t)taps * cin_pad * rows;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i % rows);
+    const int64_t t = i / rows;
+    const int c = (int)(t % cin_pad);
+    const int tap = (int)(t / cin_pad);
+    float v = 0.f;
+    if (c < cin) v = w[((int64_t)n * cin + c) * taps + tap];
+    o[((int64_t)tap * cin_pad + c) * ldw + n_off + n] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// execution
+// ---------------------------------------------------------------------------------------------------------
+struct Buf {
+  int64_t off = -1, bytes = 0;
+  int64_t rows = 0;
+  int c = 0;
+};
+
+struct Act {   // an activation volume, channels-last
+  Buf b;
+  int nb = 0, d = 0, h = 0, w = 0;
+};
+
+struct Exec {
+  const cs_unet& u;
+  const char* arena;
+  char* ws;
+  int64_t ws_bytes;
+  bool dry;
+  hipStream_t st;
+  int rc = CS_OK;
+  int64_t peak = 0;
+  std::vector<FreeBlock> fl;
+
+  Exec(const cs_unet& u_, const void* arena_, void* ws_, int64_t ws_bytes_, bool dry_, hipStream_t st_)
+      : u(u_), arena((const char*)arena_), ws((char*)ws_), ws_bytes(ws_bytes_), dry(dry_), st(st_) {
+    fl.push_back({0, dry ? (int64_t)1 << 60 : ws_bytes});
+  }
+  bool ok() const { return rc == CS_OK; }
+  void chk(int r) {
+    if (rc == CS_OK && r != CS_OK) rc = r;
+  }
+  float* p(const Buf& b) const { return reinterpret_cast<float*>(ws + b.off); }
+  const float* wf(int64_t off) const { return reinterpret_cast<const float*>(arena + off); }
+
+  Buf alloc(int64_t rows, int c) {
+    Buf b;
+    b.rows = rows;
+    b.c = c;
+    b.bytes = align_up(rows * c * 4);
+    for (size_t i = 0; i < fl.size(); ++i) {
+      if (fl[i].size >= b.bytes) {
+        b.off = fl[i].off;
+        fl[i].off += b.bytes;
+        fl[i].size -= b.bytes;
+        if (fl[i].size == 0) fl.erase(fl.begin() + i);
+        if (b.off + b.bytes > peak) peak = b.off + b.bytes;
+        return b;
+      }
+    }
+    chk(CS_ENOMEM);
+    b.off = 0;
+    return b;
+  }
+  void release(Buf& b) {
+    if (b.off < 0 || b.bytes == 0) return;
+    size_t i = 0;
+    while (i < fl.size() && fl[i].off < b.off) ++i;
+    fl.insert(fl.begin() + i, {b.off, b.bytes});
+    if (i + 1 < fl.size() && fl[i].off + fl[i].size == fl[i + 1].off) {
+      fl[i].size += fl[i + 1].size;
+      fl.erase(fl.begin() + i + 1);
+    }
+    if (i > 0 && fl[i - 1].off + fl[i - 1].size == fl[i].off) {
+      fl[i - 1].size += fl[i].size;
+      fl.erase(fl.begin() + i);
+    }
+    b.off = -1;
+    b.bytes = 0;
+  }
+
+  // conv (k^3 taps, stride (1,s,s), nearest upsample (0,up,up)) or pointwise/linear GEMM with the fused epilogue
+  Buf gemm(const Buf& x, int gi, int nb, int d, int h, int w, int s_hw = 1, int up_hw = 0, int act = CS_ACT_NONE,
+           const float* rowvec = nullptr, int ldrv = 0, int rv_rows = 1, const float* res = nullptr, int ldr = 0,
+           int tile = 0) {
+    const Gemm& g = u.gemms[gi];
+    const int k = g.k, pad = k / 2;
+    const int vh = h << up_hw, vw = w << up_hw;
+    const int dout = (d + 2 * pad - k) + 1;
+    const int hout = (vh + 2 * pad - k) / s_hw + 1;
+    const int wout = (vw + 2 * pad - k) / s_hw + 1;
+    const int64_t mo = (int64_t)nb * dout * hout * wout;
+    const int ocols = act == CS_ACT_GEGLU ? g.cout / 2 : g.cout;
+    Buf out = alloc(mo, ocols);
+    if (!ok() || dry) return out;
+    if (x.c != g.cin_pad || x.rows != (int64_t)nb * d * h * w) {
+      chk(CS_EINVAL);
+      return out;
+    }
+    CsConvGemm q;
+    memset(&q, 0, sizeof(q));
+    q.x = p(x);
+    q.out = p(out);
+    q.w = reinterpret_cast<const float*>(arena + g.w_off);
+    if (u.cfg.math == CS_MATH_F16X3) {
+      q.w_lo = arena + g.wlo_off;
+      q.acc_scale = g.acc_scale;
+      q.a_scale = 16.0f;
+    }
+    q.bias = g.b_off >= 0 ? wf(g.b_off) : nullptr;
+    q.rowvec = rowvec;
+    q.res = res;
+    q.nb = nb; q.din = d; q.hin = h; q.win = w;
+    q.dout = dout; q.hout = hout; q.wout = wout;
+    q.cin = g.cin_pad; q.cout = g.cout;
+    q.lda = x.c; q.ldw = g.ldw; q.ldo = ocols; q.ldr = res ? ldr : 0; q.ldrv = rowvec ? ldrv : 0;
+    q.kd = q.kh = q.kw = k;
+    q.sd = 1; q.sh = q.sw = s_hw;
+    q.pd = q.ph = q.pw = pad;
+    q.ud = 0; q.uh = q.uw = up_hw;
+    q.act = act; q.rv_rows = rv_rows; q.math = u.cfg.math; q.tile = tile;
+    chk(cs_conv_gemm(&q, st));
+    return out;
+  }
+  Buf linear(const Buf& x, int gi, int act = CS_ACT_NONE, const float* rowvec = nullptr, int ldrv = 0,
+             int rv_rows = 1, const float* res = nullptr, int ldr = 0, int tile = 0) {
+    return gemm(x, gi, (int)x.rows, 1, 1, 1, 1, 0, act, rowvec, ldrv, rv_rows, res, ldr, tile);
+  }
+
+  Buf groupnorm(const Buf& x, int ni, int nb, float eps, int act) {
+    const Norm& n = u.norms[ni];
+    Buf y = alloc(x.rows, x.c);
+    Buf wsb = alloc((cs_groupnorm_ws_bytes(nb, 32) + 3) / 4, 1);
+    Buf stats = alloc((int64_t)nb * 32 * 2, 1);
+    if (ok() && !dry) {
+      const int rows = (int)(x.rows / nb);
+      chk(cs_groupnorm_stats(p(x), nb, rows, x.c, x.c, 32, eps, p(wsb), p(stats), st));
+      chk(cs_groupnorm_apply(p(x), p(stats), wf(n.g_off), wf(n.b_off), p(y), nb, rows, x.c, x.c, x.c, 32, act, st));
+    }
+    release(wsb);
+    release(stats);
+    return y;
+  }
+  Buf layernorm(const Buf& x, int ni) {
+    const Norm& n = u.norms[ni];
+    Buf y = alloc(x.rows, x.c);
+    if (ok() && !dry) chk(cs_layernorm(p(x), wf(n.g_off), wf(n.b_off), p(y), (int)x.rows, x.c, x.c, x.c, 1e-5f, st));
+    return y;
+  }
+
+  Act res_block(const Layer& l, const Act& x, const Buf& semb) {
+    const int rows = x.d * x.h * x.w;
+    Buf hn = groupnorm(x.b, l.n[0], x.nb, 1e-5f, CS_ACT_SILU);
+    Buf h1 = gemm(hn, l.g[0], x.nb, x.d, x.h, x.w, 1, 0, CS_ACT_NONE, dry ? nullptr : p(semb) + l.emb_lo, semb.c, rows);
+    release(hn);
+    Buf hn2 = groupnorm(h1, l.n[1], x.nb, 1e-5f, CS_ACT_SILU);
+    release(h1);
+    Buf skip = x.b;
+    if (l.g[2] >= 0) skip = gemm(x.b, l.g[2], x.nb, x.d, x.h, x.w);
+    Act o = x;
+    o.b = gemm(hn2, l.g[1], x.nb, x.d, x.h, x.w, 1, 0, CS_ACT_NONE, nullptr, 0, 1, dry ? nullptr : p(skip), skip.c);
+    release(hn2);
+    if (l.g[2] >= 0) release(skip);
+    return o;
+  }
+
+  Act attn_block(const Layer& l, const Act& x, const float* ctxvec) {
+    const int c = l.cin, heads = u.cfg.num_heads, dh = c / heads;
+    const int n = x.d * x.h * x.w;
+    const int64_t rows = (int64_t)x.nb * n;
+    Buf xn = groupnorm(x.b, l.n[0], x.nb, 1e-6f, CS_ACT_NONE);
+    Buf t0 = linear(xn, l.g[0]);
+    release(xn);
+    Buf n1 = layernorm(t0, l.n[1]);
+    Buf qkv = linear(n1, l.g[1]);
+    release(n1);
+    Buf a = alloc(rows, c);
+    if (ok() && !dry) {
+      const float scale = (float)std::pow((double)dh, -0.5);
+      const float* q = p(qkv);
+      auto fn = u.cfg.math == CS_MATH_F16X3 ? cs_attn_selfattn_f16x3 : cs_attn_selfattn;
+      chk(fn(q, q + c, q + 2 * c, p(a), x.nb, n, n, heads, dh, 3 * c, 3 * c, 3 * c, c, scale, st));
+    }
+    release(qkv);
+    // one context token: attn2(x) == to_out(to_v(ctx)) for every query row -> a row vector in this epilogue
+    Buf t1 = linear(a, l.g[2], CS_ACT_NONE, ctxvec ? ctxvec + l.ctx_off : nullptr, u.ctx_total, n,
+                    dry ? nullptr : p(t0), c);
+    release(a);
+    release(t0);
+    Buf n3 = layernorm(t1, l.n[3]);
+    Buf gg;
+    if (l.fused_geglu) {
+      const Gemm& g = u.gemms[l.g[5]];
+      const bool big = ((rows + 255) / 256) * (int64_t)(g.cout / 224) >= 192;     // cs_conv_gemm's rule
+      gg = linear(n3, l.g[5], CS_ACT_GEGLU, nullptr, 0, 1, nullptr, 0, big ? 4 : 2);
+    } else {
+      Buf ff = linear(n3, l.g[5]);
+      gg = alloc(rows, 4 * c);
+      if (ok() && !dry) chk(cs_geglu(p(ff), p(gg), (int)rows, 4 * c, 8 * c, 4 * c, st));
+      release(ff);
+    }
+    release(n3);
+    Buf t2 = linear(gg, l.g[6], CS_ACT_NONE, nullptr, 0, 1, dry ? nullptr : p(t1), c);
+    release(gg);
+    release(t1);
+    Act o = x;
+    o.b = linear(t2, l.g[7], CS_ACT_NONE, nullptr, 0, 1, dry ? nullptr : p(x.b), c);
+    release(t2);
+    return o;
+  }
+
+  // runs the layers of one block; `keep_in` says whether the caller still needs the input buffer
+  Act run(const std::vector<Layer>& layers, Act h, const Buf& semb, const float* ctxvec, bool keep_in) {
+    bool owned = !keep_in;
+    for (const Layer& l : layers) {
+      Act o;
+      switch (l.kind) {
+        case CONV_IN:
+          o = h;
+          o.b = gemm(h.b, l.g[0], h.nb, h.d, h.h, h.w);
+          break;
+        case RES:
+          o = res_block(l, h, semb);
+          break;
+        case ATTN:
+          o = attn_block(l, h, ctxvec);
+          break;
+        case DOWN:
+          o = h;
+          o.b = gemm(h.b, l.g[0], h.nb, h.d, h.h, h.w, 2, 0);
+          o.h = h.h / 2;
+          o.w = h.w / 2;
+          break;
+        case UP:
+          o = h;
+          o.b = gemm(h.b, l.g[0], h.nb, h.d, h.h, h.w, 1, 1);
+          o.h = h.h * 2;
+          o.w = h.w * 2;
+          break;
+      }
+      if (owned) release(h.b);
+      h = o;
+      owned = true;
+    }
+    return h;
+  }
+
+  Buf duplicate(const Buf& a) {   // torch.cat([a, a], dim=0)
+    Buf o = alloc(2 * a.rows, a.c);
+    if (ok() && !dry) {
+      const size_t bytes = (size_t)a.rows * a.c * 4;
+      if (hipMemcpyAsync(p(o), p(a), bytes, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+          hipMemcpyAsync((char*)p(o) + bytes, p(a), bytes, hipMemcpyDeviceToDevice, st) != hipSuccess)
+        chk(CS_EINVAL);
+    }
+    return o;
+  }
+};
+
+bool has_attn(const std::vector<Layer>& layers) {
+  for (const Layer& l : layers)
+    if (l.kind == ATTN) return true;
+  return false;
+}
+
+int forward(Exec& e, const float* x_ncdhw, const int64_t* t, const float* ctxvec, float* eps_ncdhw, int nbx,
+            int cfg_pairs) {
+  const cs_unet& u = e.u;
+  const CsUnetConfig& c = u.cfg;
+  const int S = c.d * c.h * c.w;
+  Buf temb = e.alloc(nbx, c.model_channels);
+  if (e.ok() && !e.dry) e.chk(cs_timestep_embedding(t, e.p(temb), nbx, c.model_channels, 10000.0f, e.st));
+  Buf e1 = e.linear(temb, u.g_te0, CS_ACT_SILU);
+  e.release(temb);
+  // every consumer of `emb` is emb_layers = SiLU -> Linear (openai_model_3d.py:257-263): keep SiLU(emb)
+  Buf e2 = e.linear(e1, u.g_te2, CS_ACT_SILU);
+  e.release(e1);
+  Buf semb = e.linear(e2, u.g_emb_all);
+  e.release(e2);
+  Act h;
+  h.nb = nbx; h.d = c.d; h.h = c.h; h.w = c.w;
+  h.b = e.alloc((int64_t)nbx * S, u.cpad_in);
+  if (e.ok() && !e.dry) e.chk(cs_nchw_to_ndhwc(x_ncdhw, e.p(h.b), nbx, c.in_channels, S, u.cpad_in, e.st));
+  bool shared = cfg_pairs != 0;
+  auto split = [&](bool h_retained) {   // first context-dependent block: one copy per guidance half, [uc; c]
+    Buf h2 = e.duplicate(h.b);
+    if (!h_retained) e.release(h.b);     // otherwise it lives on in `hs` as a (shared) skip tensor
+    h.b = h2;
+    h.nb *= 2;
+    Buf s2 = e.duplicate(semb);
+    e.release(semb);
+    semb = s2;
+    shared = false;
+  };
+  std::vector<Act> hs;
+  bool first = true;
+  for (const auto& layers : u.inp) {
+    bool keep = !first;           // the block input is the previous block's output, retained in `hs`
+    if (shared && has_attn(layers)) {
+      split(!first);              // the duplicate is a fresh buffer this block may consume
+      keep = false;
+    }
+    h = e.run(layers, h, semb, ctxvec, keep);
+    hs.push_back(h);
+    first = false;
+    if (!e.ok()) return e.rc;
+  }
+  bool keep_mid = true;           // h is hs.back()
+  if (shared) {
+    split(true);
+    keep_mid = false;
+  }
+  h = e.run(u.mid, h, semb, ctxvec, keep_mid);
+  for (const auto& layers : u.out) {
+    Act sk = hs.back();
+    hs.pop_back();
+    // torch.cat([h, skip], channel); a shared (nbx-sized) skip tensor feeds both guidance halves
+    Act cat = h;
+    cat.b = e.alloc(h.b.rows, h.b.c + sk.b.c);
+    if (e.ok() && !e.dry) {
+      e.chk(cs_copy_rows(e.p(h.b), e.p(cat.b), h.b.rows, h.b.c, h.b.c, cat.b.c, e.st));
+      const int groups = h.nb / sk.nb;
+      if (groups * sk.nb != h.nb) e.chk(CS_EINVAL);
+      for (int g = 0; g < groups && e.ok(); ++g)
+        e.chk(cs_copy_rows(e.p(sk.b), e.p(cat.b) + (int64_t)g * sk.b.rows * cat.b.c + h.b.c, sk.b.rows, sk.b.c,
+                           sk.b.c, cat.b.c, e.st));
+    }
+    e.release(h.b);
+    e.release(sk.b);
+    h = e.run(layers, cat, semb, ctxvec, false);
+    if (!e.ok()) return e.rc;
+  }
+  Buf hn = e.groupnorm(h.b, u.n_out, h.nb, 1e-5f, CS_ACT_SILU);
+  e.release(h.b);
+  Buf eps = e.gemm(hn, u.g_out, h.nb, h.d, h.h, h.w);
+  e.release(hn);
+  if (e.ok() && !e.dry) e.chk(cs_ndhwc_to_nchw(e.p(eps), eps_ncdhw, h.nb, c.out_channels, S, eps.c, e.st));
+  e.release(eps);
+  e.release(semb);
+  return e.rc;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int cs_unet_create(const CsUnetConfig* cfg, cs_unet** out) {
+  if (!cfg || !out) return CS_EINVAL;
+  cs_unet* u = new (std::nothrow) cs_unet();
+  if (!u) return CS_ENOMEM;
+  u->cfg = *cfg;
+  const int rc = build(*u);
+  if (rc != CS_OK) {
+    delete u;
+    return rc;
+  }
+  *out = u;
+  return CS_OK;
+}
+
+extern "C" void cs_unet_destroy(cs_unet* u) { delete u; }
+
+extern "C" int cs_unet_param_count(const cs_unet* u) { return u ? (int)u->params.size() : 0; }
+
+extern "C" int cs_unet_param_info(const cs_unet* u, int i, const char** name, int64_t shape5[5], int* ndim,
+                                  int64_t* raw_offset_bytes) {
+  if (!u || i < 0 || i >= (int)u->params.size()) return CS_EINVAL;
+  const Param& p = u->params[i];
+  if (name) *name = p.name.c_str();
+  if (shape5) memcpy(shape5, p.shape, sizeof(p.shape));
+  if (ndim) *ndim = p.ndim;
+  if (raw_offset_bytes) *raw_offset_bytes = p.raw_off;
+  return CS_OK;
+}
+
+extern "C" int64_t cs_unet_raw_bytes(const cs_unet* u) { return u ? u->raw_bytes : 0; }
+extern "C" int64_t cs_unet_arena_bytes(const cs_unet* u) { return u ? u->arena_bytes : 0; }
+extern "C" int64_t cs_unet_context_floats(const cs_unet* u) { return u ? u->ctx_total : 0; }
+
+extern "C" int cs_unet_pack(cs_unet* u, const void* raw_dev, void* arena_dev, cs_stream_t stream) {
+  if (!u || !raw_dev || !arena_dev) return CS_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const char* raw = (const char*)raw_dev;
+  char* arena = (char*)arena_dev;
+  const bool f16 = u->cfg.math == CS_MATH_F16X3;
+  auto src = [&](int param) { return reinterpret_cast<const float*>(raw + u->params[param].raw_off); };
+  std::vector<float> amax(u->params.size(), 0.f);
+  if (f16) {
+    // per-tensor |w| maxima for the power-of-two operand scales: one device pass, ONE host sync (load time)
+    float* d_amax = reinterpret_cast<float*>(arena + u->amax_off);
+    if (hipMemsetAsync(d_amax, 0, u->params.size() * 4, st) != hipSuccess) return CS_EINVAL;
+    for (const Gemm& g : u->gemms)
+      for (const Piece& pc : g.w) {
+        const Param& p = u->params[pc.param];
+        CS_LAUNCH(absmax_kernel, dim3(cs_grid_for(p.numel, 256, 256)), dim3(256), 0, st, src(pc.param), p.numel,
+                  d_amax + pc.param);
+        CS_CHECK_LAUNCH();
+      }
+    if (hipMemcpyAsync(amax.data(), d_amax, amax.size() * 4, hipMemcpyDeviceToHost, st) != hipSuccess)
+      return CS_EINVAL;
+    if (hipStreamSynchronize(st) != hipSuccess) return CS_EINVAL;
+  }
+  for (Gemm& g : u->gemms) {
+    const int cols = g.cin * g.taps;    // row length of the reference tensor seen as [cout][cin * taps]
+    float scale = 1.f;
+    if (f16) {
+      // scale by the whole tensor's maximum even when only a row range is used (GEGLU pieces): what
+      // ops._pack_weight_f16x3 sees is the permuted full tensor, whose maximum is the same
+      float m = 0.f;
+      for (const Piece& pc : g.w) m = fmaxf(m, amax[pc.param]);
+      int ex = 0;
+      if (m > 0.f && std::isfinite(m)) (void)std::frexp((double)m, &ex);
+      scale = (float)std::ldexp(1.0, 14 - ex);
+      g.acc_scale = 1.0f / (scale * 16.0f);
+    } else {
+      if (hipMemsetAsync(arena + g.w_off, 0, (size_t)g.taps * g.cin_pad * g.ldw * 4, st) != hipSuccess)
+        return CS_EINVAL;
+    }
+    int n_off = 0;
+    for (const Piece& pc : g.w) {
+      const float* w = src(pc.param) + (int64_t)pc.row0 * cols;
+      if (f16) {
+        const int kg = (g.cin + 15) / 16 * 2;
+        const int64_t total = (int64_t)g.taps * kg * pc.rows * 8;
+        CS_LAUNCH(pack_part_f16x3_kernel, dim3(cs_grid_for(total, 256, 256 * 32)), dim3(256), 0, st, w,
+                  (_Float16*)(arena + g.w_off), (_Float16*)(arena + g.wlo_off), pc.rows, n_off, g.cout, g.cin,
+                  g.taps, kg, scale);
+      } else {
+        const int64_t total = (int64_t)g.taps * g.cin_pad * pc.rows;
+        CS_LAUNCH(pack_part_f32_kernel, dim3(cs_grid_for(total, 256)), dim3(256), 0, st, w,
+                  (float*)(arena + g.w_off), pc.rows, n_off, g.cin, g.taps, g.cin_pad, g.ldw);
+      }
+      CS_CHECK_LAUNCH();
+      n_off += pc.rows;
+    }
+    if (n_off != g.cout) return CS_EINVAL;
+    n_off = 0;
+    for (const Piece& pc : g.b) {
+      if (hipMemcpyAsync(arena + g.b_off + (int64_t)n_off * 4, src(pc.param) + pc.row0, (size_t)pc.rows * 4,
+                         hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return CS_EINVAL;
+      n_off += pc.rows;
+    }
+  }
+  for (const Norm& n : u->norms) {
+    if (hipMemcpyAsync(arena + n.g_off, src(n.gp), (size_t)n.c * 4, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(arena + n.b_off, src(n.bp), (size_t)n.c * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+      return CS_EINVAL;
+  }
+  u->packed = true;
+  return CS_OK;
+}
+
+extern "C" int64_t cs_unet_workspace_bytes(const cs_unet* u, int nb_x, int cfg_pairs) {
+  if (!u || nb_x <= 0) return CS_EINVAL;
+  Exec e(*u, nullptr, nullptr, 0, true, nullptr);
+  const int rc = forward(e, nullptr, nullptr, nullptr, nullptr, nb_x, cfg_pairs);
+  if (rc != CS_OK) return rc;
+  // the context pass needs one [nb_ctx][max c] temporary
+  int maxc = 0;
+  for (const Gemm& g : u->gemms) maxc = g.cout > maxc && g.cin == u->cfg.context_dim ? g.cout : maxc;
+  const int64_t ctx_ws = align_up((int64_t)(cfg_pairs ? 2 : 1) * nb_x * maxc * 4) + ALIGN;
+  return e.peak > ctx_ws ? e.peak : ctx_ws;
+}
+
+extern "C" int cs_unet_context(const cs_unet* u, const void* arena, const float* ctx, int nb_ctx, float* ctxvec,
+                               void* workspace, int64_t workspace_bytes, cs_stream_t stream) {
+  if (!u || !u->packed || !arena || !ctx || !ctxvec || !workspace || nb_ctx <= 0) return CS_EINVAL;
+  Exec e(*u, arena, workspace, workspace_bytes, false, (hipStream_t)stream);
+  // ctx rows are read in place: describe them as a buffer view at offset (ctx - workspace)
+  auto visit = [&](const Layer& l) {
+    if (l.kind != ATTN || !e.ok()) return;
+    const Gemm& gv = u->gemms[l.g[3]];
+    const Gemm& go = u->gemms[l.g[4]];
+    Buf v2 = e.alloc(nb_ctx, gv.cout);
+    if (!e.ok()) return;
+    CsConvGemm q;
+    for (int pass = 0; pass < 2 && e.ok(); ++pass) {
+      const Gemm& g = pass == 0 ? gv : go;
+      memset(&q, 0, sizeof(q));
+      q.x = pass == 0 ? ctx : e.p(v2);
+      q.out = pass == 0 ? e.p(v2) : ctxvec + l.ctx_off;
+      q.w = reinterpret_cast<const float*>(e.arena + g.w_off);
+      if (u->cfg.math == CS_MATH_F16X3) {
+        q.w_lo = e.arena + g.wlo_off;
+        q.acc_scale = g.acc_scale;
+        q.a_scale = 16.0f;
+      }
+      q.bias = g.b_off >= 0 ? e.wf(g.b_off) : nullptr;
+      q.nb = nb_ctx; q.din = q.hin = q.win = q.dout = q.hout = q.wout = 1;
+      q.cin = g.cin_pad; q.cout = g.cout;
+      q.lda = g.cin_pad; q.ldw = g.ldw; q.ldo = pass == 0 ? g.cout : u->ctx_total;
+      q.kd = q.kh = q.kw = 1; q.sd = q.sh = q.sw = 1;
+      q.rv_rows = 1; q.math = u->cfg.math;
+      e.chk(cs_conv_gemm(&q, e.st));
+    }
+    e.release(v2);
+  };
+  for (const auto& layers : u->inp)
+    for (const Layer& l : layers) visit(l);
+  for (const Layer& l : u->mid) visit(l);
+  for (const auto& layers : u->out)
+    for (const Layer& l : layers) visit(l);
+  return e.rc;
+}
+
+extern "C" int cs_unet_step(const cs_unet* u, const void* arena, const float* x_ncdhw, const int64_t* t,
+                            const float* ctxvec, float* eps_ncdhw, int nb_x, int cfg_pairs, void* workspace,
+                            int64_t workspace_bytes, cs_stream_t stream) {
+  if (!u || !u->packed || !arena || !x_ncdhw || !t || !ctxvec || !eps_ncdhw || !workspace || nb_x <= 0)
+    return CS_EINVAL;
+  if (((uintptr_t)workspace & 15) || ((uintptr_t)arena & 15) || ((uintptr_t)ctxvec & 15)) return CS_EINVAL;
+  Exec e(*u, arena, workspace, workspace_bytes, false, (hipStream_t)stream);
+  return forward(e, x_ncdhw, t, ctxvec, eps_ncdhw, nb_x, cfg_pairs);
+}

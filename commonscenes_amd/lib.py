@@ -18,6 +18,7 @@ from .build import LIB_PATH
 
 CS_OK = 0
 CS_EINVAL = -22
+CS_ENOMEM = -12
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_GELU, ACT_GEGLU = 0, 1, 2, 3, 4
 MATH_FP32, MATH_F16X3 = 0, 1
 
@@ -47,6 +48,18 @@ class CsConvGemm(C.Structure):
     ]
 
 
+class CsUnetConfig(C.Structure):
+    _fields_ = [
+        ("in_channels", C.c_int32), ("out_channels", C.c_int32), ("model_channels", C.c_int32),
+        ("num_res_blocks", C.c_int32), ("n_mult", C.c_int32), ("channel_mult", C.c_int32 * 8),
+        ("n_attn_res", C.c_int32), ("attention_resolutions", C.c_int32 * 8),
+        ("num_heads", C.c_int32), ("context_dim", C.c_int32),
+        ("d", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("math", C.c_int32),
+    ]
+
+
+_pp = C.POINTER(C.c_void_p)
+
 # name -> (restype, argtypes); must list every symbol declared in include/commonscenes_hip.h
 SIGNATURES = {
     "cs_conv_gemm": (_i, [C.POINTER(CsConvGemm), _s]),
@@ -72,6 +85,18 @@ SIGNATURES = {
     "cs_ddim_cfg_update": (_i, [_f, _f, _f, _f, _f, _l, _l, _fl, _fl, _fl, _fl, _fl, _i, _s]),
     "cs_ddim_coefficients": (_i, [_fl, _fl, _fl, _fl, _f]),
     "cs_ddim_cfg_update_dev": (_i, [_f, _f, _f, _f, _f, _l, _l, _f, _fl, _i, _s]),
+    "cs_unet_create": (_i, [C.POINTER(CsUnetConfig), _pp]),
+    "cs_unet_destroy": (None, [C.c_void_p]),
+    "cs_unet_param_count": (_i, [C.c_void_p]),
+    "cs_unet_param_info": (_i, [C.c_void_p, _i, C.POINTER(C.c_char_p), C.POINTER(C.c_int64 * 5), C.POINTER(C.c_int),
+                                C.POINTER(C.c_int64)]),
+    "cs_unet_raw_bytes": (_l, [C.c_void_p]),
+    "cs_unet_arena_bytes": (_l, [C.c_void_p]),
+    "cs_unet_context_floats": (_l, [C.c_void_p]),
+    "cs_unet_pack": (_i, [C.c_void_p, _f, _f, _s]),
+    "cs_unet_workspace_bytes": (_l, [C.c_void_p, _i, _i]),
+    "cs_unet_context": (_i, [C.c_void_p, _f, _f, _i, _f, _f, _l, _s]),
+    "cs_unet_step": (_i, [C.c_void_p, _f, _f, _f, _f, _f, _i, _i, _f, _l, _s]),
     "cs_vq_argmin_lookup": (_i, [_f, _f, _f, _f, _l, _i, _i, _i, _i, _s]),
     "cs_gcn_gather_cat": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _f, _s]),
     "cs_gcn_segment_mean": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _f, _s]),
@@ -117,5 +142,5 @@ class CsError(RuntimeError):
 
 def check(rc: int, what: str) -> None:
     if rc != CS_OK:
-        kind = "invalid argument" if rc == CS_EINVAL else f"hipError_t {rc}"
+        kind = {CS_EINVAL: "invalid argument", CS_ENOMEM: "workspace too small"}.get(rc, f"hipError_t {rc}")
         raise CsError(f"{what} failed: {kind}")

@@ -13,6 +13,8 @@ Extensions over the reference (SURVEY 8b "Extension the build adds"):
 """
 from __future__ import annotations
 
+import os
+
 import time
 from functools import partial
 from pathlib import Path
@@ -24,6 +26,7 @@ import yaml
 
 from .ddim import DDIMSampler
 from .unet import DiffusionUNet
+from .unet_native import NativeDiffusionUNet
 from .vqvae import VQVAE, load_vqvae
 
 Tensor = torch.Tensor
@@ -90,8 +93,14 @@ class SDFusionText2ShapeModel:
         z_sp = shape_res // (2 ** n_down)
         self.z_shape = (z_ch, z_sp, z_sp, z_sp)
 
-        self.df = DiffusionUNet(df_conf.unet.params, vq_conf=vq_conf,
-                                conditioning_key=df_conf.model.params.conditioning_key, device=self.device)
+        # two interchangeable sequencers of the same HIP kernels: the Python one (unet.py) and the native
+        # whole-forward driver (csrc/cs_unet.hip, cs_unet_step); bit-identical outputs
+        driver = str(self.opt.network.get("unet_driver") or os.environ.get("CS_UNET_DRIVER", "python"))
+        if driver not in ("python", "native"):
+            raise ValueError(f"unet_driver must be 'python' or 'native', got {driver!r}")
+        unet_cls = NativeDiffusionUNet if driver == "native" else DiffusionUNet
+        self.df = unet_cls(df_conf.unet.params, vq_conf=vq_conf,
+                           conditioning_key=df_conf.model.params.conditioning_key, device=self.device)
         self.init_diffusion_params(uc_scale=3., df_model_params=df_conf.model.params)
         self.ddim_sampler = DDIMSampler(self)
         ck = self.opt.network.get("vq_ckpt")

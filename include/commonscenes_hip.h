@@ -32,6 +32,7 @@ extern "C" {
 typedef struct ihipStream_t* cs_stream_t; /* == hipStream_t */
 
 #define CS_OK 0
+#define CS_ENOMEM (-12)
 #define CS_EINVAL (-22)
 
 /* epilogue activation codes */
@@ -254,6 +255,56 @@ int cs_log_softmax(const float* x, float* y, int m, int c, int ldx, int ldy, cs_
  * one fp64->fp32 rounding).
  */
 int cs_synth_fill(float* out, int64_t n, uint64_t base, double scale, double offset, cs_stream_t stream);
+
+/*
+ * Whole-forward driver (SURVEY 8b "cs_unet_step"): UNet3DModel.forward (openai_model_3d.py:752-789) with the
+ * crossattn conditioning of DiffusionUNet.forward (network.py:28-30) as ONE call over a packed weight arena.
+ * The plan object is host memory only (architecture walk, arena layout, packing recipe); every device buffer --
+ * raw parameters, arena, context vectors, workspace -- is caller-owned, and nothing synchronises except
+ * cs_unet_pack (one stream sync at load time to read the per-tensor |w| maxima in CS_MATH_F16X3).
+ *
+ *   cs_unet_create        config -> plan.  Scope: dims=3 (H,W-only resampling), use_spatial_transformer, one
+ *                         transformer block per SpatialTransformer3D, ONE context token (attention.py:170-199
+ *                         over a single key is the row vector to_out(to_v(ctx))).
+ *   cs_unet_param_*       the reference state_dict entries (names as in SURVEY App. C, reference shapes) and
+ *                         where each one goes in the caller's raw fp32 parameter buffer (cs_unet_raw_bytes).
+ *   cs_unet_pack          raw parameters -> arena (cs_unet_arena_bytes): GEMM weights in the layout of the
+ *                         plan's math mode (q|k|v fused, all ResBlock emb_layers fused, GEGLU columns
+ *                         interleaved per 224-column tile), biases, norm affine parameters.
+ *   cs_unet_context       once per sampling run: ctx [nb_ctx][context_dim] -> ctxvec [nb_ctx][cs_unet_context_floats]
+ *   cs_unet_step          eps = UNet(x, t, ctx).  x: NCDHW [nb_x][in_channels][d][h][w]; t: int64 [nb_x];
+ *                         cfg_pairs = 0: nb_ctx == nb_x.  cfg_pairs = 1 (classifier-free guidance, ddim.py:206-209):
+ *                         the SAME (x, t) under two contexts, ctxvec holds 2*nb_x rows [uc; c], the context-free
+ *                         prefix runs once, eps is [2*nb_x] = [eps_uc; eps_c].  workspace >= cs_unet_workspace_bytes.
+ * All return CS_OK / CS_EINVAL / CS_ENOMEM (workspace too small) / a hipError_t.
+ */
+typedef struct CsUnetConfig {
+  int32_t in_channels, out_channels, model_channels, num_res_blocks;
+  int32_t n_mult;
+  int32_t channel_mult[8];
+  int32_t n_attn_res;
+  int32_t attention_resolutions[8];
+  int32_t num_heads, context_dim;
+  int32_t d, h, w;   /* latent grid, 16 x 16 x 16 */
+  int32_t math;      /* CS_MATH_FP32 / CS_MATH_F16X3 */
+} CsUnetConfig;
+typedef struct cs_unet cs_unet;
+
+int cs_unet_create(const CsUnetConfig* cfg, cs_unet** out);
+void cs_unet_destroy(cs_unet* u);
+int cs_unet_param_count(const cs_unet* u);
+int cs_unet_param_info(const cs_unet* u, int i, const char** name, int64_t shape5[5], int* ndim,
+                       int64_t* raw_offset_bytes);
+int64_t cs_unet_raw_bytes(const cs_unet* u);
+int64_t cs_unet_arena_bytes(const cs_unet* u);
+int64_t cs_unet_context_floats(const cs_unet* u);
+int cs_unet_pack(cs_unet* u, const void* raw_dev, void* arena_dev, cs_stream_t stream);
+int64_t cs_unet_workspace_bytes(const cs_unet* u, int nb_x, int cfg_pairs);
+int cs_unet_context(const cs_unet* u, const void* arena, const float* ctx, int nb_ctx, float* ctxvec,
+                    void* workspace, int64_t workspace_bytes, cs_stream_t stream);
+int cs_unet_step(const cs_unet* u, const void* arena, const float* x_ncdhw, const int64_t* t,
+                 const float* ctxvec, float* eps_ncdhw, int nb_x, int cfg_pairs, void* workspace,
+                 int64_t workspace_bytes, cs_stream_t stream);
 
 /* Library / device self-description. */
 int cs_abi_version(void);

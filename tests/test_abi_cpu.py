@@ -27,7 +27,7 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(dll, s), f"{s} declared in the header but not exported"
         assert s in lib.SIGNATURES, f"{s} has no ctypes signature"
     assert set(lib.SIGNATURES) == set(syms)
-    assert dll.cs_abi_version() == 2
+    assert dll.cs_abi_version() == 3
 
 
 def test_struct_layout_matches_header():
@@ -99,3 +99,26 @@ def test_unsupported_configs_raise():
                        device="cpu")
     with pytest.raises(NotImplementedError):
         df(torch.zeros(1, 3, 16, 16, 16), torch.zeros(1, dtype=torch.long), c_concat=[torch.zeros(1)])
+
+
+def test_unet_plan_is_host_only_and_lists_the_reference_state_dict():
+    """cs_unet_create / param_info / *_bytes need no GPU: the plan's parameter table must be the reference
+    UNet3DModel state_dict (names, shapes, order -- SURVEY App. C) and the sizes must be sane."""
+    from commonscenes_amd import lib as L
+    from commonscenes_amd.unet import unet_param_shapes
+    from commonscenes_amd.unet_native import NativeDiffusionUNet
+    from oracle.ref_torch import UNET_FULL
+    cfg = dict(UNET_FULL, dims=3, use_spatial_transformer=True)
+    n = NativeDiffusionUNet(cfg, device="cpu")
+    ref = unet_param_shapes(cfg)
+    assert list(n.shapes.items()) == list(ref.items())
+    assert n.num_parameters() == 413_540_739
+    lib = L.load()
+    assert lib.cs_unet_raw_bytes(n._h) >= 4 * 413_540_739
+    assert lib.cs_unet_arena_bytes(n._h) > 0
+    w1, w32 = lib.cs_unet_workspace_bytes(n._h, 1, 1), lib.cs_unet_workspace_bytes(n._h, 32, 1)
+    assert 0 < w1 < w32 < 8 * 2 ** 30
+    assert n.ctx_floats == 5 * 448 + 6 * 672
+    bad = L.CsUnetConfig()
+    h = __import__("ctypes").c_void_p()
+    assert lib.cs_unet_create(__import__("ctypes").byref(bad), __import__("ctypes").byref(h)) == L.CS_EINVAL
