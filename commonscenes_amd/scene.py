@@ -180,10 +180,13 @@ class Sg2ScVAEModel:
         self.diff_cfg = diff_opt if isinstance(diff_opt, dict) else load_yaml(diff_opt)
         self.diffusion_bs = diffusion_bs
         self.Diff = SDFusionText2ShapeModel(self.diff_cfg, resolve_dir=resolve_dir)
-        if self.Diff.df.conditioning_key != "crossattn":
-            raise NotImplementedError("concat conditioning (config/v2_full_concat.yaml) is row N1 of SURVEY 8f")
+        if self.Diff.df.conditioning_key not in ("crossattn", "concat"):
+            raise NotImplementedError(f"conditioning_key={self.Diff.df.conditioning_key!r}")
+        # VAEGAN_V2FULL.py:152-155: the concat family's rel_mlp ends in a 16^3 = 4096-voxel condition volume
+        rel_dims = (1280, 4096) if self.Diff.df.conditioning_key == "concat" else (960, 1280)
         self.shapes = scene_param_shapes(self.num_objs, self.num_preds, embedding_dim,
-                                         gconv_num_layers=gconv_num_layers, num_box_params=num_box_params)
+                                         gconv_num_layers=gconv_num_layers, num_box_params=num_box_params,
+                                         rel_dims=rel_dims)
         self._sd: Dict[str, Tensor] = {}
         self._nets = None
 
@@ -245,7 +248,7 @@ class Sg2ScVAEModel:
 
     @torch.no_grad()
     def encoder_2(self, z, objs, triples, dec_text_feat, dec_rel_feat, attributes=None, manipulate=False):
-        """VAEGAN_V2FULL.py:220-242 -> (uc, c), each (O, 1, 1280)."""
+        """VAEGAN_V2FULL.py:220-242 -> (uc, c), each (O, 1, 1280) -- (O, 1, 4096) in the concat family."""
         if self._nets is None:
             self._build()
         rel_vecs_, pred_vecs_, edges = self._node_edge_feats(objs, triples, dec_text_feat, dec_rel_feat, z)

@@ -96,6 +96,8 @@ class SDFusionText2ShapeModel:
         # two interchangeable sequencers of the same HIP kernels: the Python one (unet.py) and the native
         # whole-forward driver (csrc/cs_unet.hip, cs_unet_step); bit-identical outputs
         driver = str(self.opt.network.get("unet_driver") or os.environ.get("CS_UNET_DRIVER", "python"))
+        if df_conf.model.params.conditioning_key != "crossattn":
+            driver = "python"                       # cs_unet_step implements the crossattn family only
         if driver not in ("python", "native"):
             raise ValueError(f"unet_driver must be 'python' or 'native', got {driver!r}")
         unet_cls = NativeDiffusionUNet if driver == "native" else DiffusionUNet
@@ -145,6 +147,11 @@ class SDFusionText2ShapeModel:
         self.x = input["sdf"]
         self.rel = input["rel"]
         self.uc_rel = input["uc"]
+        if self.df.conditioning_key == "concat":                        # :246-248: the condition is a volume
+            B = self.rel.shape[0]
+            C_, D, H, W = self.z_shape
+            self.rel = self.rel.reshape(B, -1, D, H, W)
+            self.uc_rel = self.uc_rel.reshape(B, -1, D, H, W)
         if max_sample is not None:
             self.x, self.rel, self.uc_rel = self.x[:max_sample], self.rel[:max_sample], self.uc_rel[:max_sample]
 

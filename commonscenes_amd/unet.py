@@ -40,12 +40,21 @@ def _cfg(unet_params) -> dict:
         context_dim=g("context_dim"), dims=int(g("dims", 3)),
         use_spatial_transformer=bool(g("use_spatial_transformer", True)),
     )
-    if cfg["dims"] != 3 or not cfg["use_spatial_transformer"] or cfg["num_heads"] <= 0:
-        raise NotImplementedError("only the shipped crossattn config family is supported: dims=3, "
-                                  "use_spatial_transformer=True, num_heads>0 (config/sdfusion-txt2shape.yaml)")
+    # the two shipped families: crossattn (config/sdfusion-txt2shape.yaml: dims=3 -> H,W-only resampling,
+    # SpatialTransformer3D blocks) and concat (config/sdfusion-txt2shape_concat.yaml: dims=4 -> Conv3d with true
+    # 3-D stride-2 resampling, conv_nd / Downsample / Upsample at openai_model_3d.py:146-199, AttentionBlock blocks)
+    if cfg["dims"] not in (3, 4) or cfg["num_heads"] <= 0:
+        raise NotImplementedError("supported: dims in (3, 4) and num_heads > 0 (config/sdfusion-txt2shape*.yaml)")
     if g("use_scale_shift_norm", False) or g("resblock_updown", False) or g("num_classes") is not None:
         raise NotImplementedError("use_scale_shift_norm / resblock_updown / num_classes are not on the path")
-    cfg["context_dim"] = int(cfg["context_dim"])
+    if g("num_head_channels", -1) not in (-1, None) or g("use_new_attention_order", False):
+        raise NotImplementedError("num_head_channels / use_new_attention_order are not used by the shipped configs")
+    if cfg["use_spatial_transformer"]:
+        if cfg["context_dim"] is None:
+            raise ValueError("use_spatial_transformer=True needs context_dim (openai_model_3d.py:512-513)")
+        cfg["context_dim"] = int(cfg["context_dim"])
+    else:
+        cfg["context_dim"] = None
     return cfg
 
 
@@ -117,6 +126,13 @@ def unet_param_shapes(cfg: dict, prefix: str = "diffusion_net.") -> "OrderedDict
             conv(p + ".skip_connection", cout, cin, 1)
 
     def attn(p, c):
+        if not cfg["use_spatial_transformer"]:          # AttentionBlock (openai_model_3d.py:316-366): Conv1d k=1
+            norm(p + ".norm", c)
+            S[p + ".qkv.weight"] = (3 * c, c, 1)
+            S[p + ".qkv.bias"] = (3 * c,)
+            S[p + ".proj_out.weight"] = (c, c, 1)
+            S[p + ".proj_out.bias"] = (c,)
+            return
         norm(p + ".norm", c)
         conv(p + ".proj_in", c, c, 1)
         t = p + ".transformer_blocks.0"
@@ -266,6 +282,15 @@ class DiffusionUNet:
                     pw(p + ".out_layers.3")
                     if l["cin"] != l["cout"]:
                         pw(p + ".skip_connection")
+                elif k == "attn" and not self.cfg["use_spatial_transformer"]:
+                    # QKVAttentionLegacy (openai_model_3d.py:388-416) reads qkv channels as [head][q|k|v][ch];
+                    # permuting the Conv1d's output rows to [q|k|v][head][ch] makes q, k, v plain column slices
+                    c, heads = l["cin"], self.cfg["num_heads"]
+                    perm = torch.arange(3 * c, device=self.device).view(heads, 3, c // heads).permute(1, 0, 2).reshape(-1)
+                    pk[p + ".qkv"] = ops.pack_weight(sd[p + ".qkv.weight"].view(3 * c, c)[perm].contiguous(),
+                                                     sd[p + ".qkv.bias"][perm].contiguous(), math=self.math)
+                    pk[p + ".proj_out"] = ops.pack_weight(sd[p + ".proj_out.weight"].view(c, c),
+                                                          sd[p + ".proj_out.bias"], math=self.math)
                 elif k == "attn":
                     pw(p + ".proj_in")
                     pw(p + ".proj_out")
@@ -356,6 +381,20 @@ class DiffusionUNet:
         self._ctx_cache = (key, cached)
         return cached
 
+    def _attnblock(self, p: str, l: dict, x: Tensor) -> Tensor:
+        """AttentionBlock._forward (openai_model_3d.py:360-366): GN -> qkv (Conv1d k=1) -> QKVAttentionLegacy ->
+        proj_out + x.  The reference scales q and k by ch^-1/4 each; the flash kernel scales the logits by ch^-1/2."""
+        sd, pk = self._sd, self._packed
+        heads = self.cfg["num_heads"]
+        nb, d, h, w, c = x.shape
+        n = d * h * w
+        xn = ops.groupnorm(x, sd[p + ".norm.weight"], sd[p + ".norm.bias"], 32, 1e-5, L.ACT_NONE)
+        qkv = ops.linear(xn.view(nb, n, c), pk[p + ".qkv"], math=self.math)
+        a = ops.attention(qkv[..., 0:c], qkv[..., c:2 * c], qkv[..., 2 * c:3 * c], heads, (c // heads) ** -0.5,
+                          math=self.math)
+        out = ops.linear(a, pk[p + ".proj_out"], res=x.view(nb, n, c), math=self.math)
+        return out.view(nb, d, h, w, c)
+
     def _attn(self, p: str, l: dict, x: Tensor, ctx) -> Tensor:
         sd, pk = self._sd, self._packed
         heads = self.cfg["num_heads"]
@@ -403,11 +442,13 @@ class DiffusionUNet:
             elif k == "res":
                 h = self._res(p, l, h, semb)
             elif k == "attn":
-                h = self._attn(p, l, h, ctx)
-            elif k == "down":
-                h = ops.conv_gemm(h, pk[p + ".op"], stride=(1, 2, 2), math=self.math)
-            elif k == "up":
-                h = ops.conv_gemm(h, pk[p + ".conv"], up=(0, 1, 1), math=self.math)
+                h = self._attn(p, l, h, ctx) if self.cfg["use_spatial_transformer"] else self._attnblock(p, l, h)
+            elif k == "down":      # dims == 3: inner two dims only (openai_model_3d.py:188); dims == 4: all three
+                h = ops.conv_gemm(h, pk[p + ".op"], stride=(1, 2, 2) if self.cfg["dims"] == 3 else (2, 2, 2),
+                                  math=self.math)
+            elif k == "up":        # nearest x2 folded into the conv's addressing (openai_model_3d.py:148-157)
+                h = ops.conv_gemm(h, pk[p + ".conv"], up=(0, 1, 1) if self.cfg["dims"] == 3 else (1, 1, 1),
+                                  math=self.math)
         return h
 
     @torch.no_grad()
@@ -428,7 +469,7 @@ class DiffusionUNet:
         # every consumer of `emb` is emb_layers = SiLU -> Linear (openai_model_3d.py:257-263): keep SiLU(emb)
         semb = ops.linear(e1, pk[P + "time_embed.2"], act=L.ACT_SILU, math=self.math)
         semb = ops.linear(semb, pk["emb_all"], math=self.math)          # [nb, sum(cout)] for all ResBlocks
-        ctx = self._context_vectors(ctx)
+        ctx = self._context_vectors(ctx) if ctx is not None else None
         hs: List[Tensor] = []
         tr = self.trace
         shared = cfg_pairs          # True while h still holds one copy per (x, t) pair
@@ -460,8 +501,11 @@ class DiffusionUNet:
     def forward_cfg(self, x: Tensor, t: Tensor, c_in: Tensor) -> Tensor:
         """eps for the classifier-free-guidance pair batch without duplicating (x, t):
         x (B,C,D,H,W), t (B,), c_in (2B,1,ctx) = [uc; c]  ->  (2B,C,D,H,W) = [eps_uc; eps_c]."""
+        if self.conditioning_key == "concat":
+            # the condition is an input channel: nothing upstream of it to share, run the duplicated batch
+            return self.forward(torch.cat([x, x]), torch.cat([t, t]), c_concat=[c_in])
         if self.conditioning_key != "crossattn":
-            raise NotImplementedError("forward_cfg: crossattn conditioning only")
+            raise NotImplementedError("forward_cfg: crossattn / concat conditioning only")
         ctx = c_in.to(dtype=torch.float32).contiguous()
         if ctx.shape[0] != 2 * x.shape[0]:
             raise ValueError("c_in must hold [uc; c] for every sample of x")
@@ -473,9 +517,24 @@ class DiffusionUNet:
     def forward(self, x: Tensor, t: Tensor, c_concat: Optional[list] = None,
                 c_crossattn: Optional[list] = None) -> Tensor:
         """network.py:20-42.  x: (B, C, D, H, W) fp32 on the HIP device; t: (B,) int64."""
+        if t.dtype != torch.int64:
+            t = t.to(torch.int64)
+        cpad = (self.cfg["in_channels"] + 3) // 4 * 4
+        if self.conditioning_key == "concat":          # network.py:25-27
+            if not c_concat:
+                raise ValueError("c_concat is required for conditioning_key='concat'")
+            if self.cfg["use_spatial_transformer"]:
+                raise NotImplementedError("concat conditioning with SpatialTransformer3D blocks (needs a context)")
+            xc = torch.cat([x.to(torch.float32)] + [c.to(device=x.device, dtype=torch.float32) for c in c_concat], dim=1)
+            if xc.shape[1] != self.cfg["in_channels"]:
+                raise ValueError(f"x + c_concat have {xc.shape[1]} channels, in_channels={self.cfg['in_channels']}")
+            return ops.ndhwc_to_nchw(self.forward_ndhwc(ops.nchw_to_ndhwc(xc, cpad=cpad), t.contiguous(), None))
         if self.conditioning_key != "crossattn":
-            raise NotImplementedError(f"conditioning_key={self.conditioning_key!r}: only 'crossattn' "
-                                      "(config/sdfusion-txt2shape.yaml:5) is implemented")
+            raise NotImplementedError(f"conditioning_key={self.conditioning_key!r}: 'crossattn' "
+                                      "(config/sdfusion-txt2shape.yaml:5) and 'concat' "
+                                      "(config/sdfusion-txt2shape_concat.yaml:5) are implemented")
+        if not self.cfg["use_spatial_transformer"]:
+            raise NotImplementedError("crossattn conditioning needs use_spatial_transformer=True")
         if c_crossattn is None:
             raise ValueError("c_crossattn is required for conditioning_key='crossattn'")
         ctx = c_crossattn[0] if len(c_crossattn) == 1 else torch.cat(c_crossattn, 1)

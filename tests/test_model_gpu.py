@@ -150,6 +150,71 @@ def test_unet_multi_token_context_path():
 
 
 # ---------------------------------------------------------------------------------------------------
+# UNet, concat-conditioning family (config/sdfusion-txt2shape_concat.yaml)
+# ---------------------------------------------------------------------------------------------------
+def _unet_concat(small, math="fp32"):
+    key = ("unet_concat", small, math)
+    if key not in _CACHE:
+        from commonscenes_amd import synth
+        from commonscenes_amd.unet import DiffusionUNet, unet_param_shapes
+        from oracle.ref_torch import UNET_CONCAT_FULL, UNET_CONCAT_SMALL
+        cfg = dict(UNET_CONCAT_SMALL if small else UNET_CONCAT_FULL)
+        df = DiffusionUNet(cfg, conditioning_key="concat", device="cuda").set_math(math)
+        df.load_state_dict(synth.synth_state_dict(unet_param_shapes(cfg), device="cuda"))
+        _CACHE[key] = df
+    return _CACHE[key]
+
+
+@pytest.mark.parametrize("math", ["fp32", "f16x3"])
+def test_unet_concat_small_vs_reference_golden(math):
+    g = _g("unet_concat_small")
+    df = _unet_concat(True, math)
+    df.trace = {}
+    eps = df(_cu(g["x"]), _cu(g["t"]), c_concat=[_cu(g["c"])])
+    torch.cuda.synchronize()
+    tr, df.trace = df.trace, None
+    for k in [k for k in g if k.startswith("hook:")]:
+        mine = tr[k[5:]].permute(0, 4, 1, 2, 3)
+        assert rel_l2(mine, torch.from_numpy(g[k])) < 1e-5, k
+    assert rel_l2(eps, torch.from_numpy(g["eps"])) < 1e-5
+
+
+def test_unet_concat_full_vs_reference_golden():
+    g = _g("unet_concat_full")
+    for math in ("fp32", "f16x3"):
+        df = _unet_concat(False, math)
+        eps = df(_cu(g["x"]), _cu(g["t"]), c_concat=[_cu(g["c"])])
+        torch.cuda.synchronize()
+        assert eps.shape == (2, 3, 16, 16, 16)
+        assert rel_l2(eps, torch.from_numpy(g["eps"])) < 1e-5, math
+        _CACHE.pop(("unet_concat", False, math))
+        del df
+        torch.cuda.empty_cache()
+
+
+def test_ddim_concat_steps_vs_reference_golden():
+    from commonscenes_amd.ddim import DDIMSampler
+    g = _g("ddim_concat_small")
+    df = _unet_concat(True, "f16x3")
+
+    class M(_SamplerModel):
+        def apply_model(self, x, t, c):
+            return self.df(x, t, c_concat=[c])
+
+        def apply_model_cfg(self, x, t, c_in):
+            return self.df.forward_cfg(x, t, c_in)
+    m = M(df)
+    k, S = int(g["steps"]), int(g["S"])
+    B = g["x_T"].shape[0]
+    for n in range(1, k + 1):
+        x, _ = DDIMSampler(m).sample(S=S, batch_size=B, shape=(3, 16, 16, 16), conditioning=_cu(g["c"]),
+                                     x_T=_cu(g["x_T"]), verbose=False, unconditional_guidance_scale=float(g["scale"]),
+                                     unconditional_conditioning=_cu(g["uc"]), eta=0.0, max_steps=n)
+        torch.cuda.synchronize()
+        assert rel_l2(x, torch.from_numpy(g["x"][n - 1])) < 1e-4, n
+
+
+# ---------------------------------------------------------------------------------------------------
 # DDIM
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("small", [True, False])
@@ -269,7 +334,7 @@ def test_vq_decode_batch_invariance():
 # ---------------------------------------------------------------------------------------------------
 # GCN conditioning + end to end
 # ---------------------------------------------------------------------------------------------------
-def _scene(tmp_path, small=True):
+def _scene(tmp_path, small=True, concat=False):
     """Sg2ScVAEModel on synthetic weights, constructed like model/VAE.py:60-62 does."""
     import yaml
     from commonscenes_amd import synth
@@ -277,9 +342,10 @@ def _scene(tmp_path, small=True):
     from commonscenes_amd.unet import unet_param_shapes
     from commonscenes_amd.vqvae import vqvae_param_shapes
     from oracle.ref_torch import VQ_FULL
-    ucfg = _unet_cfg(small)
-    df_yaml = dict(model=dict(params=dict(linear_start=0.00085, linear_end=0.012, conditioning_key="crossattn",
-                                          timesteps=1000)),
+    from oracle.ref_torch import UNET_CONCAT_FULL, UNET_CONCAT_SMALL
+    ucfg = dict(UNET_CONCAT_SMALL if small else UNET_CONCAT_FULL) if concat else _unet_cfg(small)
+    df_yaml = dict(model=dict(params=dict(linear_start=0.00085, linear_end=0.012,
+                                          conditioning_key="concat" if concat else "crossattn", timesteps=1000)),
                    unet=dict(params={k: (list(v) if isinstance(v, tuple) else v) for k, v in ucfg.items()}))
     vq_yaml = dict(model=dict(params=dict(embed_dim=3, n_embed=8192, ddconfig=dict(
         double_z=False, z_channels=3, resolution=64, in_channels=1, out_ch=1, ch=64, ch_mult=[1, 2, 4],
@@ -295,26 +361,31 @@ def _scene(tmp_path, small=True):
     m = Sg2ScVAEModel(vocab, opt, diffusion_bs=16, embedding_dim=64, decoder_cat=True, mlp_normalization="batch",
                       gconv_num_layers=5, use_angles=True, distribution_before=True, use_E2=True,
                       replace_latent=True, num_box_params=6, residual=True, clip=True)
-    m.load_state_dict(synth.synth_state_dict(scene_param_shapes(35, 16), device="cuda"))
+    m.load_state_dict(synth.synth_state_dict(
+        scene_param_shapes(35, 16, rel_dims=(1280, 4096) if concat else (960, 1280)), device="cuda"))
     m.Diff.df.load_state_dict(synth.synth_state_dict(unet_param_shapes(ucfg), device="cuda"))
     m.Diff.vqvae.load_state_dict(synth.synth_state_dict(vqvae_param_shapes(VQ_FULL, 8192, 3), device="cuda"))
     return m
 
 
-def test_gcn_encoder2_vs_reference_golden(tmp_path):
-    g = _g("gcn_encoder2")
-    m = _scene(tmp_path)
+@pytest.mark.parametrize("concat", [False, True])
+def test_gcn_encoder2_vs_reference_golden(tmp_path, concat):
+    g = _g("gcn_encoder2_concat" if concat else "gcn_encoder2")
+    m = _scene(tmp_path, concat=concat)
     uc, c = m.encoder_2(_cu(g["z"]), _cu(g["objs"]), _cu(g["triples"]), _cu(g["text_feats"]), _cu(g["rel_feats"]))
     torch.cuda.synchronize()
-    assert uc.shape == (8, 1, 1280) and c.shape == (8, 1, 1280)
+    width = 4096 if concat else 1280
+    assert uc.shape == (8, 1, width) and c.shape == (8, 1, width)
     assert rel_l2(uc, torch.from_numpy(g["uc"])) < 2e-6
     assert rel_l2(c, torch.from_numpy(g["c"])) < 2e-6
 
 
-def test_sample_end_to_end_vs_reference_golden(tmp_path):
-    """Sg2ScVAEModel.sample(gen_shape=True): 8 shaped objects + floor + scene node, 2 DDIM steps, decode."""
-    g = _g("e2e_small")
-    m = _scene(tmp_path)
+@pytest.mark.parametrize("concat", [False, True])
+def test_sample_end_to_end_vs_reference_golden(tmp_path, concat):
+    """Sg2ScVAEModel.sample(gen_shape=True): 8 shaped objects + floor + scene node, 2 DDIM steps, decode --
+    both shipped families (config/v2_full.yaml crossattn, config/v2_full_concat.yaml concat)."""
+    g = _g("e2e_concat_small" if concat else "e2e_small")
+    m = _scene(tmp_path, concat=concat)
     O = g["objs"].shape[0]
     dec_sdfs = torch.zeros(O, 1, 4, 4, 4)
     dec_sdfs[torch.from_numpy(g["dec_sdfs_nonzero"])] = 1.0
@@ -325,6 +396,8 @@ def test_sample_end_to_end_vs_reference_golden(tmp_path):
                           gen_shape=True, z=torch.from_numpy(g["z"]), x_T=torch.from_numpy(g["x_T"]), ddim_steps=2)
     torch.cuda.synchronize()
     assert gen.shape == (8, 1, 64, 64, 64)
+    if "latents" in g:
+        pass          # latent-level parity is covered by the DDIM goldens; here the decoded SDFs are compared
     d3, ang = boxes
     assert rel_l2(d3, torch.from_numpy(g["boxes"])) < 2e-6
     assert rel_l2(ang, torch.from_numpy(g["angles"])) < 2e-6

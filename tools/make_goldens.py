@@ -128,8 +128,8 @@ def save(name: str, **arrs):
 # ---------------------------------------------------------------------------------------------
 # configs
 # ---------------------------------------------------------------------------------------------
-def unet_params(small: bool):
-    with open(REF / "config" / "sdfusion-txt2shape.yaml") as f:
+def unet_params(small: bool, concat: bool = False):
+    with open(REF / "config" / ("sdfusion-txt2shape_concat.yaml" if concat else "sdfusion-txt2shape.yaml")) as f:
         y = yaml.safe_load(f)
     p = dict(y["unet"]["params"])
     if small:
@@ -138,10 +138,10 @@ def unet_params(small: bool):
     return p
 
 
-def build_ref_unet(small: bool):
+def build_ref_unet(small: bool, concat: bool = False):
     from model.networks.diffusion_networks.network import DiffusionUNet
-    p = unet_params(small)
-    df = DiffusionUNet(_wrap(p), conditioning_key="crossattn").eval()
+    p = unet_params(small, concat)
+    df = DiffusionUNet(_wrap(p), conditioning_key="concat" if concat else "crossattn").eval()
     shapes = unet_param_shapes(p)
     ref_shapes = {k: tuple(v.shape) for k, v in df.state_dict().items()}
     assert ref_shapes == dict(shapes), "unet_param_shapes disagrees with the reference state_dict"
@@ -228,7 +228,57 @@ def g_unet(small: bool):
     save(name, **arrs)
 
 
-def _ref_model_for_sampler(df):
+def g_unet_concat(small: bool):
+    """UNet3DModel at config/sdfusion-txt2shape_concat.yaml (dims=4, AttentionBlock) behind DiffusionUNet's concat
+    branch (network.py:25-27): x (B,3,16^3) + one condition volume (B,1,16^3)."""
+    name = "unet_concat_small" if small else "unet_concat_full"
+    df, p, sd = build_ref_unet(small, concat=True)
+    x = synth.gaussian_like(f"{name}:x", (2, 3, 16, 16, 16))
+    cvol = synth.gaussian_like(f"{name}:c", (2, 1, 16, 16, 16))
+    t = torch.tensor([981, 11], dtype=torch.long)
+    hooks = {}
+    if small:
+        net = df.diffusion_net
+        watch = {"input_blocks.1": net.input_blocks[1], "input_blocks.3": net.input_blocks[3],
+                 "input_blocks.4": net.input_blocks[4], "middle_block": net.middle_block,
+                 "output_blocks.2": net.output_blocks[2], "output_blocks.8": net.output_blocks[8]}
+        hs = [m.register_forward_hook(lambda mod, i, o, k=k: hooks.__setitem__(k, o.detach().clone()))
+              for k, m in watch.items()]
+    t0 = time.time()
+    with torch.no_grad():
+        y = df(x, t, c_concat=[cvol])
+    print(f"[{name}] reference forward {time.time() - t0:.1f}s  out rms {y.pow(2).mean().sqrt():.4f}")
+    arrs = dict(x=x, t=t, c=cvol, eps=y)
+    for k, v in hooks.items():
+        arrs["hook:" + k] = v
+    save(name, **arrs)
+
+
+def g_ddim_concat():
+    """3 CFG DDIM steps through the reference DDIMSampler with the concat-conditioned reduced-width UNet."""
+    from model.networks.diffusion_networks.samplers.ddim import DDIMSampler
+    name = "ddim_concat_small"
+    df, p, sd = build_ref_unet(True, concat=True)
+    m = _ref_model_for_sampler(df, key="c_concat")
+    B, S, k = 2, 50, 3
+    x_T = synth.gaussian_like(f"{name}:xT", (1, 3, 16, 16, 16)).repeat(B, 1, 1, 1, 1)
+    c = synth.gaussian_like(f"{name}:c", (B, 1, 16, 16, 16))
+    uc = synth.gaussian_like(f"{name}:uc", (B, 1, 16, 16, 16))
+    sampler = DDIMSampler(m)
+    sampler.make_schedule(S, ddim_eta=0.0, verbose=False)
+    img, xs, p0s = x_T, [], []
+    ts = np.flip(sampler.ddim_timesteps)
+    for i in range(k):
+        tt = torch.full((B,), int(ts[i]), dtype=torch.long)
+        img, pred = sampler.p_sample_ddim(img, c, tt, index=S - i - 1, unconditional_guidance_scale=3.0,
+                                          unconditional_conditioning=uc)
+        xs.append(img.clone())
+        p0s.append(pred.clone())
+    save(name, x_T=x_T, c=c, uc=uc, S=np.int64(S), steps=np.int64(k), scale=np.float32(3.0),
+         x=torch.stack(xs), pred_x0=torch.stack(p0s))
+
+
+def _ref_model_for_sampler(df, key="c_crossattn"):
     """A minimal stand-in for SDFusionText2ShapeModel exposing what DDIMSampler reads
     (ddim.py:16-20,31-37,134,188), with the reference's own schedule code."""
     from model.networks.diffusion_networks.ldm_diffusion_util import make_beta_schedule
@@ -240,7 +290,7 @@ def _ref_model_for_sampler(df):
         device = "cpu"
 
         def apply_model(self, x, t, c):
-            return df(x, t, c_crossattn=[c])
+            return df(x, t, **{key: [c]})
     m = M()
     m.betas = torch.tensor(betas, dtype=torch.float32)
     m.alphas_cumprod = torch.tensor(ac, dtype=torch.float32)
@@ -293,13 +343,13 @@ def g_vq():
          latent_nq=h[:, :, :8, :8, :8].contiguous(), dec_nq=dec_nq)
 
 
-def _scene_yaml(tmp: Path, small: bool, vq_ckpt: Path) -> Path:
-    with open(REF / "config" / "v2_full.yaml") as f:
+def _scene_yaml(tmp: Path, small: bool, vq_ckpt: Path, concat: bool = False) -> Path:
+    with open(REF / "config" / ("v2_full_concat.yaml" if concat else "v2_full.yaml")) as f:
         y = yaml.safe_load(f)
     y["hyper"]["device"] = "cpu"
     y["hyper"]["logs_dir"] = str(tmp / "logs")
     y["hyper"]["results_dir"] = str(tmp / "logs")
-    df_yaml = REF / "config" / "sdfusion-txt2shape.yaml"
+    df_yaml = REF / "config" / ("sdfusion-txt2shape_concat.yaml" if concat else "sdfusion-txt2shape.yaml")
     if small:
         with open(df_yaml) as f:
             d = yaml.safe_load(f)
@@ -317,7 +367,7 @@ def _scene_yaml(tmp: Path, small: bool, vq_ckpt: Path) -> Path:
     return out
 
 
-def build_ref_scene(tmp: Path, small: bool = True):
+def build_ref_scene(tmp: Path, small: bool = True, concat: bool = False):
     """Construct the reference Sg2ScVAEModel the way eval does (model/VAE.py:60-62), App. B step 5."""
     from model.VAEGAN_V2FULL import Sg2ScVAEModel
     from commonscenes_amd.scene import scene_param_shapes
@@ -331,39 +381,39 @@ def build_ref_scene(tmp: Path, small: bool = True):
     cwd = os.getcwd()
     os.chdir(tmp)
     try:
-        model = Sg2ScVAEModel(vocab, str(_scene_yaml(tmp, small, ck)), diffusion_bs=16, embedding_dim=64,
+        model = Sg2ScVAEModel(vocab, str(_scene_yaml(tmp, small, ck, concat)), diffusion_bs=16, embedding_dim=64,
                               decoder_cat=True, mlp_normalization="batch", gconv_num_layers=5, use_angles=True,
                               distribution_before=True, use_E2=True, replace_latent=True, num_box_params=6,
                               residual=True, clip=True).eval()
     finally:
         os.chdir(cwd)
-    shapes = scene_param_shapes(n_obj_cls, n_pred)
+    shapes = scene_param_shapes(n_obj_cls, n_pred, rel_dims=(1280, 4096) if concat else (960, 1280))
     ref_shapes = {k: tuple(v.shape) for k, v in torch.nn.Module.state_dict(model).items()}
     sub = {k: ref_shapes[k] for k in shapes}
     assert sub == dict(shapes), "scene_param_shapes disagrees with the reference state_dict"
     sd = synth.synth_state_dict(shapes)
     model.load_state_dict(sd, strict=False)
-    p = unet_params(small)
+    p = unet_params(small, concat)
     df_sd = synth.synth_state_dict(unet_param_shapes(p))
     model.Diff.df.load_state_dict(df_sd, strict=True)
     model.Diff.df.eval()
     return model, sd, df_sd, vq_sd
 
 
-def g_gcn(tmp: Path):
-    model, sd, _, _ = build_ref_scene(tmp, small=True)
+def g_gcn(tmp: Path, concat: bool = False):
+    model, sd, _, _ = build_ref_scene(tmp, small=True, concat=concat)
     g = synth.random_scene_graph(6, seed=7)
     with torch.no_grad():
         uc, c = model.encoder_2(g["z"], g["objs"], g["triples"], g["text_feats"], g["rel_feats"], None)
-    save("gcn_encoder2", objs=g["objs"], triples=g["triples"], text_feats=g["text_feats"],
+    save("gcn_encoder2_concat" if concat else "gcn_encoder2", objs=g["objs"], triples=g["triples"], text_feats=g["text_feats"],
          rel_feats=g["rel_feats"], z=g["z"], uc=uc, c=c)
 
 
-def g_e2e(tmp: Path):
+def g_e2e(tmp: Path, concat: bool = False):
     """Sg2ScVAEModel.sample(gen_shape=True) end to end (VAEGAN_V2FULL.py:600-618), reduced-width UNet,
     8 shaped objects (mini-batch boundary at 7), 2 DDIM steps."""
     import functools
-    model, sd, df_sd, vq_sd = build_ref_scene(tmp, small=True)
+    model, sd, df_sd, vq_sd = build_ref_scene(tmp, small=True, concat=concat)
     nobj = 8
     g = synth.random_scene_graph(nobj, seed=11)
     O = g["objs"].shape[0]
@@ -403,7 +453,7 @@ def g_e2e(tmp: Path):
         arrs["boxes"], arrs["angles"] = boxes[0], boxes[1]
     else:
         arrs["boxes"] = boxes
-    save("e2e_small", **arrs)
+    save("e2e_concat_small" if concat else "e2e_small", **arrs)
 
 
 def main():
@@ -412,7 +462,8 @@ def main():
     a = ap.parse_args()
     install_stubs()
     install_patches()
-    todo = a.only or ["schedule", "unet_small", "unet_full", "ddim_small", "ddim_full", "vq", "gcn", "e2e"]
+    todo = a.only or ["schedule", "unet_small", "unet_full", "ddim_small", "ddim_full", "vq", "gcn", "e2e",
+                      "unet_concat_small", "unet_concat_full", "ddim_concat_small", "gcn_concat", "e2e_concat"]
     with tempfile.TemporaryDirectory() as td:
         tmp = Path(td)
         for name in todo:
@@ -433,6 +484,16 @@ def main():
                 g_gcn(tmp)
             elif name == "e2e":
                 g_e2e(tmp)
+            elif name == "unet_concat_small":
+                g_unet_concat(True)
+            elif name == "unet_concat_full":
+                g_unet_concat(False)
+            elif name == "ddim_concat_small":
+                g_ddim_concat()
+            elif name == "gcn_concat":
+                g_gcn(tmp, concat=True)
+            elif name == "e2e_concat":
+                g_e2e(tmp, concat=True)
             else:
                 raise SystemExit(f"unknown fixture {name}")
 
