@@ -90,15 +90,30 @@ def test_unet_param_table_matches_reference_counts():
 
 
 def test_unsupported_configs_raise():
-    from commonscenes_amd.unet import DiffusionUNet
-    from oracle.ref_torch import UNET_SMALL
-    with pytest.raises(NotImplementedError):
-        DiffusionUNet(dict(UNET_SMALL, dims=4, use_spatial_transformer=False), conditioning_key="concat",
-                      device="cpu")
+    from commonscenes_amd.unet import DiffusionUNet, unet_param_shapes
+    from oracle.ref_torch import UNET_CONCAT_FULL, UNET_SMALL
+    for bad in (dict(dims=2), dict(use_scale_shift_norm=True), dict(num_head_channels=32), dict(num_classes=10)):
+        with pytest.raises(NotImplementedError):
+            DiffusionUNet(dict(UNET_SMALL, dims=3, use_spatial_transformer=True, **bad), conditioning_key="crossattn",
+                          device="cpu")
+    with pytest.raises(ValueError):          # a transformer UNet needs a context width (openai_model_3d.py:512-513)
+        DiffusionUNet(dict(UNET_SMALL, dims=3, use_spatial_transformer=True, context_dim=None), device="cpu")
+    # concat conditioning cannot feed SpatialTransformer3D blocks (no context), and vice versa
     df = DiffusionUNet(dict(UNET_SMALL, dims=3, use_spatial_transformer=True), conditioning_key="concat",
                        device="cpu")
     with pytest.raises(NotImplementedError):
-        df(torch.zeros(1, 3, 16, 16, 16), torch.zeros(1, dtype=torch.long), c_concat=[torch.zeros(1)])
+        df(torch.zeros(1, 3, 16, 16, 16), torch.zeros(1, dtype=torch.long), c_concat=[torch.zeros(1, 1, 16, 16, 16)])
+    df = DiffusionUNet(dict(UNET_CONCAT_FULL), conditioning_key="crossattn", device="cpu")
+    with pytest.raises(NotImplementedError):
+        df(torch.zeros(1, 3, 16, 16, 16), torch.zeros(1, dtype=torch.long), c_crossattn=[torch.zeros(1, 1, 1280)])
+    # the concat family's parameter count (config/sdfusion-txt2shape_concat.yaml)
+    n = 0
+    for shp in unet_param_shapes(dict(UNET_CONCAT_FULL)).values():
+        k = 1
+        for v in shp:
+            k *= v
+        n += k
+    assert n == 337_988_003
 
 
 def test_unet_plan_is_host_only_and_lists_the_reference_state_dict():
