@@ -94,8 +94,8 @@ def test_unsupported_configs_raise():
     from oracle.ref_torch import UNET_CONCAT_FULL, UNET_SMALL
     for bad in (dict(dims=2), dict(use_scale_shift_norm=True), dict(num_head_channels=32), dict(num_classes=10)):
         with pytest.raises(NotImplementedError):
-            DiffusionUNet(dict(UNET_SMALL, dims=3, use_spatial_transformer=True, **bad), conditioning_key="crossattn",
-                          device="cpu")
+            DiffusionUNet({**dict(UNET_SMALL, dims=3, use_spatial_transformer=True), **bad},
+                          conditioning_key="crossattn", device="cpu")
     with pytest.raises(ValueError):          # a transformer UNet needs a context width (openai_model_3d.py:512-513)
         DiffusionUNet(dict(UNET_SMALL, dims=3, use_spatial_transformer=True, context_dim=None), device="cpu")
     # concat conditioning cannot feed SpatialTransformer3D blocks (no context), and vice versa
