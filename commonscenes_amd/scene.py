@@ -44,10 +44,12 @@ def _mlp_shapes(S, p: str, dims: List[int], final_nonlinearity: bool):
             idx += 1
 
 
-def _gcn_shapes(S, p: str, layers: int, d_obj: int, d_pred: int, hidden: int, residual: bool = True):
+def _gcn_shapes(S, p: str, layers: int, d_obj: int, d_pred: int, hidden: int, residual: bool = True,
+                output_dim: Optional[int] = None):
+    """graph.py:214-244: `output_dim` applies to the last layer only."""
     for i in range(layers):
         q = f"{p}.gconvs.{i}"
-        dout = d_obj
+        dout = output_dim if (output_dim is not None and i >= layers - 1) else d_obj
         _mlp_shapes(S, q + ".net1", [2 * d_obj + d_pred, hidden, 2 * hidden + dout], True)
         _mlp_shapes(S, q + ".net2", [hidden, hidden, dout], True)
         if residual:

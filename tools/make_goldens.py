@@ -456,6 +456,47 @@ def g_e2e(tmp: Path, concat: bool = False):
     save("e2e_concat_small" if concat else "e2e_small", **arrs)
 
 
+def g_box():
+    """BASELINE configs[0]: the layout-only v2_box model (model/VAEGAN_V2BOX.py as model/VAE.py:52-56 builds it) on one
+    synthetic 8-node scene graph: encoder, decoder, manipulate, decoder_with_changes, decoder_with_additions."""
+    from model.VAEGAN_V2BOX import Sg2ScVAEModel as v2_box
+    from commonscenes_amd.scene_box import box_param_shapes
+    n_obj_cls, n_pred = 35, 16
+    vocab = dict(object_idx_to_name=[f"obj{i}\n" for i in range(n_obj_cls)],
+                 pred_idx_to_name=[f"pred{i}\n" for i in range(n_pred)])
+    model = v2_box(vocab, embedding_dim=64, decoder_cat=True, mlp_normalization="batch", input_dim=6,
+                   replace_latent=True, use_angles=True, residual=True, gconv_pooling="avg", gconv_num_layers=5).eval()
+    shapes = box_param_shapes(n_obj_cls, n_pred)
+    ref_shapes = {k: tuple(v.shape) for k, v in model.state_dict().items() if not k.endswith("num_batches_tracked")}
+    assert ref_shapes == dict(shapes), "box_param_shapes disagrees with the reference state_dict"
+    sd = synth.synth_state_dict(shapes)
+    model.load_state_dict(sd, strict=False)
+    g = synth.random_scene_graph(6, seed=13)
+    O = g["objs"].shape[0]
+    boxes_gt = synth.gaussian_like("box:gt", (O, 6))
+    angles_gt = torch.from_numpy(np.floor((synth.hash_uniform("box:ang", O) + 1.0) * 12.0)).long().clamp(0, 23)
+    a = (g["objs"], g["triples"])
+    tf, rf = g["text_feats"], g["rel_feats"]
+    with torch.no_grad():
+        mu, logvar = model.encoder(*a, boxes_gt, None, tf, rf, angles_gt)
+        z = synth.gaussian_like("box:z", (O, 64))
+        d3, ang = model.decoder(z, *a, tf, rf, None)
+        man = model.manipulate(torch.cat([z, synth.gaussian_like("box:chg", (O, 64))], dim=1), *a, tf, rf, None)
+        # manipulation: node 2 was added (its latent is missing from z), node 4 was relabelled
+        z_in = torch.cat([z[:2], z[3:]], dim=0)
+        np.random.seed(1234)
+        (d3c, angc), keepc = model.decoder_with_changes(z_in, *a, tf, rf, None, [2], [4])
+        np.random.seed(99)
+        (d3a, anga), keepa = model.decoder_with_additions(z_in, *a, tf, rf, None, [2], [4],
+                                                          distribution=(np.zeros(64), np.eye(64)))
+        np.random.seed(5)
+        d3s, angs = model.sampleBoxes(np.zeros(64), np.eye(64), *a, tf, rf, None)
+    save("box_small", objs=g["objs"], triples=g["triples"], text_feats=tf, rel_feats=rf, boxes_gt=boxes_gt,
+         angles_gt=angles_gt, mu=mu, logvar=logvar, z=z, d3=d3, angles=ang, man=man, z_in=z_in,
+         d3_changes=d3c, angles_changes=angc, keep_changes=keepc, d3_add=d3a, angles_add=anga, keep_add=keepa,
+         d3_sample=d3s, angles_sample=angs)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*", default=None)
@@ -463,7 +504,7 @@ def main():
     install_stubs()
     install_patches()
     todo = a.only or ["schedule", "unet_small", "unet_full", "ddim_small", "ddim_full", "vq", "gcn", "e2e",
-                      "unet_concat_small", "unet_concat_full", "ddim_concat_small", "gcn_concat", "e2e_concat"]
+                      "unet_concat_small", "unet_concat_full", "ddim_concat_small", "gcn_concat", "e2e_concat", "box"]
     with tempfile.TemporaryDirectory() as td:
         tmp = Path(td)
         for name in todo:
@@ -494,6 +535,8 @@ def main():
                 g_gcn(tmp, concat=True)
             elif name == "e2e_concat":
                 g_e2e(tmp, concat=True)
+            elif name == "box":
+                g_box()
             else:
                 raise SystemExit(f"unknown fixture {name}")
 
