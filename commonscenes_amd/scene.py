@@ -69,8 +69,24 @@ def scene_param_shapes(num_objs: int, num_preds: int, embedding_dim: int = 64, c
     e = embedding_dim
     d = 2 * e + clip_dim                      # 640
     hid = 4 * e                               # 256
+    box_e, ang_e = e * 3 // 4, e // 4         # use_angles=True (VAEGAN_V2FULL.py:45-49)
+    S["obj_embeddings_ec.weight"] = (num_objs + 1, e)
+    S["pred_embeddings_ec.weight"] = (num_preds, 2 * e)
     S["obj_embeddings_dc.weight"] = (num_objs + 1, e)
     S["pred_embeddings_dc.weight"] = (num_preds, 2 * e)
+    S["pred_embeddings_man_dc.weight"] = (num_preds, 3 * e)
+    S["d3_embeddings.weight"] = (box_e, num_box_params)
+    S["d3_embeddings.bias"] = (box_e,)
+    S["angle_embeddings.weight"] = (n_angle, ang_e)
+    _mlp_shapes(S, "mean_var", [d, hid, 2 * e], True)
+    _mlp_shapes(S, "mean", [2 * e, box_e], False)
+    _mlp_shapes(S, "var", [2 * e, box_e], False)
+    _mlp_shapes(S, "angle_mean_var", [d, hid, 2 * e], True)
+    _mlp_shapes(S, "angle_mean", [2 * e, ang_e], False)
+    _mlp_shapes(S, "angle_var", [2 * e, ang_e], False)
+    _gcn_shapes(S, "gconv_net_ec_box", gconv_num_layers, d, d, hid)
+    _gcn_shapes(S, "gconv_net_manipulation", min(gconv_num_layers, 5), 3 * e + clip_dim, 3 * e + clip_dim, hid,
+                output_dim=e)
     _gcn_shapes(S, "gconv_net_ec_rel", gconv_num_layers, d, d, hid)
     _mlp_shapes(S, "rel_mlp", [d, rel_dims[0], rel_dims[1]], False)
     _gcn_shapes(S, "gconv_net_dc", gconv_num_layers, d, d, hid)
@@ -153,11 +169,165 @@ GraphTripleConvNet2 = GraphTripleConvNet
 
 
 # ------------------------------------------------------------------------------------------------
+# box-VAE encoder / manipulation pieces shared by v2_box (VAEGAN_V2BOX.py) and v2_full (VAEGAN_V2FULL.py)
+# ------------------------------------------------------------------------------------------------
+class BoxVAEMixin:
+    """Needs: self._sd, self.device, self.embedding_dim, self.use_angles, self.input_dim, self.gconv_num_layers,
+    self.replace_all_latent, self._EC_NET (state_dict prefix of the encoder GCN)."""
+
+    def _box_nets(self) -> dict:
+        sd, n = self._sd, self.gconv_num_layers
+        # Linear(input_dim -> box_e): the GEMM wants K as a multiple of 4, pad the box parameters with zeros
+        self._box_pad = (self.input_dim + 3) // 4 * 4
+        nets = dict(
+            d3_emb=ops.pack_weight(sd["d3_embeddings.weight"], sd["d3_embeddings.bias"], cin_pad=self._box_pad),
+            mean_var=_MLP(sd, "mean_var", 2, True), mean=_MLP(sd, "mean", 1, False), var=_MLP(sd, "var", 1, False),
+            ec=GraphTripleConvNet(sd, self._EC_NET, n),
+            man=GraphTripleConvNet(sd, "gconv_net_manipulation", min(n, 5)),
+        )
+        if self.use_angles:
+            nets.update(angle_mean_var=_MLP(sd, "angle_mean_var", 2, True), angle_mean=_MLP(sd, "angle_mean", 1, False),
+                        angle_var=_MLP(sd, "angle_var", 1, False))
+        return nets
+
+    def _feats(self, objs, triples, text_feat, rel_feat, obj_table: str, pred_table: str, extra: List[Tensor],
+               lead: Optional[Tensor] = None):
+        """[lead | clip | class embedding | extra...] node features and [clip | predicate embedding] edge features,
+        each assembled in one buffer (embedding gathers write their column slice in place)."""
+        dev = self.device
+        triples = triples.to(dev)
+        objs = objs.to(dev)
+        s, p, o = triples[:, 0].contiguous(), triples[:, 1].contiguous(), triples[:, 2].contiguous()
+        edges = torch.stack([s, o], dim=1).contiguous()
+        O, T = objs.shape[0], triples.shape[0]
+        e = self.embedding_dim
+        text_feat = text_feat.to(device=dev, dtype=torch.float32)
+        rel_feat = rel_feat.to(device=dev, dtype=torch.float32)
+        cd = text_feat.shape[1]
+        l0 = lead.shape[1] if lead is not None else 0
+        width = l0 + cd + e + sum(x.shape[1] for x in extra)
+        obj_vecs = torch.empty((O, width), dtype=torch.float32, device=dev)
+        if lead is not None:
+            obj_vecs[:, :l0].copy_(lead)
+        obj_vecs[:, l0:l0 + cd].copy_(text_feat)
+        ops.embedding(self._sd[obj_table], objs, out=obj_vecs[:, l0 + cd:l0 + cd + e])
+        at = l0 + cd + e
+        for x in extra:
+            obj_vecs[:, at:at + x.shape[1]].copy_(x)
+            at += x.shape[1]
+        pe = self._sd[pred_table].shape[1]
+        pred_vecs = torch.empty((T, cd + pe), dtype=torch.float32, device=dev)
+        pred_vecs[:, :cd].copy_(rel_feat)
+        ops.embedding(self._sd[pred_table], p, out=pred_vecs[:, cd:])
+        return obj_vecs, pred_vecs, edges
+
+    @torch.no_grad()
+    def encoder(self, objs, triples, boxes_gt, attributes, enc_text_feat, enc_rel_feat, angles_gt=None):
+        """VAEGAN_V2BOX.py:127-158 / VAEGAN_V2FULL.py:185-218 -> (mu, logvar), each (O, embedding_dim)."""
+        if self._nets is None:
+            self._build()
+        dev, nets = self.device, self._nets
+        boxes = torch.zeros((boxes_gt.shape[0], self._box_pad), dtype=torch.float32, device=dev)
+        boxes[:, :self.input_dim].copy_(boxes_gt.to(device=dev, dtype=torch.float32))
+        extra = [ops.linear(boxes, nets["d3_emb"])]
+        if self.use_angles:
+            extra.append(ops.embedding(self._sd["angle_embeddings.weight"], angles_gt.to(dev)))
+        obj_vecs_, pred_vecs_, edges = self._feats(objs, triples, enc_text_feat, enc_rel_feat, "obj_embeddings_ec.weight",
+                                                   "pred_embeddings_ec.weight", extra)
+        obj_vecs_, _ = nets["ec"](obj_vecs_, pred_vecs_, edges)
+        h = nets["mean_var"](obj_vecs_)
+        mu, logvar = nets["mean"](h), nets["var"](h)
+        if self.use_angles:
+            ha = nets["angle_mean_var"](obj_vecs_)
+            mu = torch.cat([mu, nets["angle_mean"](ha)], dim=1)
+            logvar = torch.cat([logvar, nets["angle_var"](ha)], dim=1)
+        return mu, logvar
+
+    @torch.no_grad()
+    def manipulate(self, z, objs, triples, dec_text_feat, dec_rel_feat, attributes=None):
+        """VAEGAN_V2BOX.py:160-173 / VAEGAN_V2FULL.py:244-259: GCN over [z | clip | class embedding]."""
+        if self._nets is None:
+            self._build()
+        man_z, pred_vecs_, edges = self._feats(objs, triples, dec_text_feat, dec_rel_feat, "obj_embeddings_dc.weight",
+                                               "pred_embeddings_man_dc.weight", [],
+                                               lead=z.to(device=self.device, dtype=torch.float32))
+        man_z, _ = self._nets["man"](man_z, pred_vecs_, edges)
+        return man_z
+
+    # host-side bookkeeping identical to the reference (numpy's global RNG, call for call)
+    def _insert_nodes(self, z, missing_nodes, distribution, width):
+        nodes_added = []
+        z = z.to(device=self.device, dtype=torch.float32)
+        for i in range(len(missing_nodes)):
+            ad_id = missing_nodes[i] + i
+            nodes_added.append(ad_id)
+            if distribution is not None:
+                mu, cov = distribution
+                new = torch.from_numpy(np.random.multivariate_normal(mu, cov, 1)).float()
+            else:
+                new = torch.zeros(1, width)
+            z = torch.cat([z[:ad_id], new.to(self.device), z[ad_id:]], dim=0)
+        return z, nodes_added
+
+    def _keep(self, n, nodes_added, manipulated_nodes):
+        keep = [1 if (i not in nodes_added and i not in manipulated_nodes) else 0 for i in range(n)]
+        return torch.from_numpy(np.asarray(keep).reshape(-1, 1)).float().to(self.device)
+
+    def _changed_latent(self, z, dec_objs, dec_triples, text_feat, rel_feat, attributes, missing_nodes,
+                        manipulated_nodes, distribution):
+        """first half of decoder_with_changes (VAEGAN_V2BOX.py:292-327 / VAEGAN_V2FULL.py:332-365)."""
+        z, nodes_added = self._insert_nodes(z, missing_nodes, distribution, z.shape[1])
+        change = []
+        for i in range(len(z)):
+            if i not in nodes_added and i not in manipulated_nodes:
+                change.append(np.zeros(self.embedding_dim))
+            else:
+                change.append(np.random.normal(0, 1, self.embedding_dim))
+        change_repr = torch.from_numpy(np.stack(change, axis=0)).float().to(self.device)
+        z_prime = self.manipulate(torch.cat([z, change_repr], dim=1), dec_objs, dec_triples, text_feat, rel_feat,
+                                  attributes)
+        if not self.replace_all_latent:
+            z = z.clone()
+            for t in sorted(nodes_added + list(manipulated_nodes)):     # untouched nodes keep their latent
+                z[t] = z_prime[t]
+        else:
+            z = z_prime
+        return z, nodes_added
+
+    @torch.no_grad()
+    def collect_train_statistics(self, train_loader, with_points=False):
+        """VAEGAN_V2FULL.py:700-760 / VAEGAN_V2BOX.py:463-520: mean and covariance of the encoder means over a loader
+        yielding the reference's batch dicts (data['decoder'][objs|tripltes|boxes|text_feats|rel_feats])."""
+        mean_cat = []
+        for data in train_loader:
+            if data == -1:
+                continue
+            try:
+                dec = data["decoder"]
+                objs, triples, tight_boxes = dec["objs"], dec["tripltes"], dec["boxes"]
+                text, rel = dec["text_feats"], dec["rel_feats"]
+            except Exception as e:      # the reference skips malformed batches the same way
+                print("Exception", str(e))
+                continue
+            boxes = tight_boxes[:, :6]
+            angles = tight_boxes[:, 6].long() - 1
+            angles = torch.where(angles > 0, angles, torch.zeros_like(angles))
+            mean, _ = self.encoder(objs, triples, boxes, None, text, rel, angles)
+            mean_cat.append(mean.cpu().clone())
+        mean_cat = torch.cat(mean_cat, dim=0)
+        mean_est = torch.mean(mean_cat, dim=0, keepdim=True)
+        cov_est = np.cov((mean_cat - mean_est).numpy().T)
+        return mean_est[0], cov_est
+
+
+# ------------------------------------------------------------------------------------------------
 # the scene model
 # ------------------------------------------------------------------------------------------------
-class Sg2ScVAEModel:
-    """Inference drop-in for the v2_full `Sg2ScVAEModel` (VAEGAN_V2FULL.py:17-760): `encoder_2`,
-    `decoder`, `sample`, plus the checkpoint surface (`load_state_dict` / `state_dict`)."""
+class Sg2ScVAEModel(BoxVAEMixin):
+    """Inference drop-in for the v2_full `Sg2ScVAEModel` (VAEGAN_V2FULL.py:17-760): `encoder`, `encoder_2`,
+    `manipulate`, `decoder`, `decoder_with_changes`, `decoder_with_additions`, `sample`, `sampleBoxes`,
+    `collect_train_statistics`, plus the checkpoint surface (`load_state_dict` / `state_dict`)."""
+    _EC_NET = "gconv_net_ec_box"
 
     def __init__(self, vocab, diff_opt, diffusion_bs=8, embedding_dim=128, batch_size=32, train_3d=True,
                  decoder_cat=False, num_box_params=6, distribution_before=True, gconv_pooling="avg",
@@ -172,9 +342,12 @@ class Sg2ScVAEModel:
         self.vocab = vocab
         self.embedding_dim = embedding_dim
         self.use_angles = use_angles
-        self.num_box_params = num_box_params
+        self.num_box_params = self.input_dim = num_box_params
+        self.replace_all_latent = replace_latent
         self.gconv_num_layers = gconv_num_layers
         self.clip = clip
+        if not use_angles:
+            raise NotImplementedError("v2_full is evaluated with use_angles=True (scripts/eval_3dfront.py --with_angles)")
         self.device = torch.device(device)
         self.obj_classes_list = list(set(vocab["object_idx_to_name"]))
         self.edge_list = list(set(vocab["pred_idx_to_name"]))
@@ -221,6 +394,7 @@ class Sg2ScVAEModel:
             raise RuntimeError("Sg2ScVAEModel: weights not loaded")
         n = self.gconv_num_layers
         self._nets = dict(
+            **self._box_nets(),
             ec_rel=GraphTripleConvNet(sd, "gconv_net_ec_rel", n),
             rel_mlp=_MLP(sd, "rel_mlp", 2, False),
             dc=GraphTripleConvNet(sd, "gconv_net_dc", n),
@@ -271,6 +445,55 @@ class Sg2ScVAEModel:
             return d3, ops.log_softmax(self._nets["angle"](obj_vecs_))
         return d3
 
+    def _shapes_for(self, z, objs, triples, text, rel, dec_sdfs, attributes, x_T, ddim_steps):
+        """the gen_shape branch shared by sample / decoder_with_changes / decoder_with_additions
+        (VAEGAN_V2FULL.py:309-318, 367-376, 606-616)."""
+        dev = self.device
+        un_rel_feat, rel_feat = self.encoder_2(z, objs, triples, text, rel, attributes)
+        # nodes whose ground-truth SDF is non-zero (drops floor and _scene_); dec_sdfs stays on the host
+        mask = torch.ne(dec_sdfs, torch.zeros_like(dec_sdfs[0]))
+        ids = torch.unique(torch.where(mask)[0])
+        ids_d = ids.to(dev)
+        diff_dict = {"sdf": dec_sdfs[ids], "rel": rel_feat[ids_d], "uc": un_rel_feat[ids_d]}
+        return self.Diff.rel2shape(diff_dict, ddim_steps=ddim_steps, uc_scale=3., x_T=x_T)
+
+    @torch.no_grad()
+    def decoder_with_additions(self, z, objs, triples, encoded_dec_text_feat, encoded_dec_rel_feat, dec_sdfs,
+                               attributes, missing_nodes, manipulated_nodes, distribution=None, gen_shape=False,
+                               x_T: Optional[Tensor] = None, ddim_steps: int = 100):
+        """VAEGAN_V2FULL.py:291-330 -> (boxes[, angles]), gen_sdf | None, keep."""
+        z, nodes_added = self._insert_nodes(z, missing_nodes, distribution, z.shape[1])
+        text = encoded_dec_text_feat.to(device=self.device, dtype=torch.float32)
+        rel = encoded_dec_rel_feat.to(device=self.device, dtype=torch.float32)
+        gen_sdf = self._shapes_for(z, objs, triples, text, rel, dec_sdfs, attributes, x_T, ddim_steps) if gen_shape else None
+        pred = self.decoder(z, objs, triples, text, rel, attributes)
+        return pred, gen_sdf, self._keep(len(z), nodes_added, manipulated_nodes)
+
+    @torch.no_grad()
+    def decoder_with_changes(self, z, dec_objs, dec_triples, encoded_dec_text_feat, encoded_dec_rel_feat, dec_sdfs,
+                             attributes, missing_nodes, manipulated_nodes, distribution=None, gen_shape=False,
+                             x_T: Optional[Tensor] = None, ddim_steps: int = 100):
+        """VAEGAN_V2FULL.py:332-396 -> (boxes[, angles]), gen_sdf | None, keep."""
+        text = encoded_dec_text_feat.to(device=self.device, dtype=torch.float32)
+        rel = encoded_dec_rel_feat.to(device=self.device, dtype=torch.float32)
+        z, nodes_added = self._changed_latent(z, dec_objs, dec_triples, text, rel, attributes, missing_nodes,
+                                              manipulated_nodes, distribution)
+        gen_sdf = (self._shapes_for(z, dec_objs, dec_triples, text, rel, dec_sdfs, attributes, x_T, ddim_steps)
+                   if gen_shape else None)
+        pred = self.decoder(z, dec_objs, dec_triples, text, rel, attributes)
+        n = len(pred[0]) if self.use_angles else len(pred)
+        return pred, gen_sdf, self._keep(n, nodes_added, manipulated_nodes)
+
+    @torch.no_grad()
+    def sampleBoxes(self, mean_est, cov_est, dec_objs, dec_triplets, encoded_dec_text_feat=None,
+                    encoded_dec_rel_feat=None, attributes=None, z: Optional[Tensor] = None):
+        """VAEGAN_V2FULL.py:593-598 (whose own decoder call lacks the CLIP features; they are required here)."""
+        if encoded_dec_text_feat is None or encoded_dec_rel_feat is None:
+            raise ValueError("sampleBoxes needs the CLIP text / relation features (clip=True)")
+        if z is None:
+            z = torch.from_numpy(np.random.multivariate_normal(mean_est, cov_est, dec_objs.size(0))).float()
+        return self.decoder(z, dec_objs, dec_triplets, encoded_dec_text_feat, encoded_dec_rel_feat, attributes)
+
     @torch.no_grad()
     def sample(self, point_classes_idx, mean_est, cov_est, dec_objs, dec_triplets, dec_sdfs,
                encoded_dec_text_feat, encoded_dec_rel_feat, attributes=None, gen_shape=False,
@@ -283,14 +506,6 @@ class Sg2ScVAEModel:
         z = z.to(dev)
         text = encoded_dec_text_feat.to(device=dev, dtype=torch.float32)
         rel = encoded_dec_rel_feat.to(device=dev, dtype=torch.float32)
-        gen_sdf = None
-        if gen_shape:
-            un_rel_feat, rel_feat = self.encoder_2(z, dec_objs, dec_triplets, text, rel, attributes)
-            # nodes whose ground-truth SDF is non-zero (drops floor and _scene_); dec_sdfs stays on the host
-            sdf_candidates = dec_sdfs
-            mask = torch.ne(sdf_candidates, torch.zeros_like(sdf_candidates[0]))
-            ids = torch.unique(torch.where(mask)[0])
-            ids_d = ids.to(dev)
-            diff_dict = {"sdf": dec_sdfs[ids], "rel": rel_feat[ids_d], "uc": un_rel_feat[ids_d]}
-            gen_sdf = self.Diff.rel2shape(diff_dict, ddim_steps=ddim_steps, uc_scale=3., x_T=x_T)
+        gen_sdf = (self._shapes_for(z, dec_objs, dec_triplets, text, rel, dec_sdfs, attributes, x_T, ddim_steps)
+                   if gen_shape else None)
         return self.decoder(z, dec_objs, dec_triplets, text, rel, attributes), gen_sdf

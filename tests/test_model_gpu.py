@@ -409,6 +409,35 @@ def test_sample_end_to_end_vs_reference_golden(tmp_path, concat):
     assert rel_l2(gen[7], torch.from_numpy(g["gen_sdf_obj7"])) < 1e-2
 
 
+def test_v2full_manipulation_surface_vs_reference_golden(tmp_path):
+    """encoder / decoder_with_changes (gen_shape=True, 2 DDIM steps) / decoder_with_additions of the v2_full model
+    (VAEGAN_V2FULL.py:185-218, 291-396) with numpy's RNG seeded like the generator."""
+    g = _g("full_manip_small")
+    m = _scene(tmp_path)
+    t = lambda k: torch.from_numpy(np.ascontiguousarray(g[k]))
+    a = (t("objs"), t("triples"))
+    tf, rf = t("text_feats"), t("rel_feats")
+    O = a[0].shape[0]
+    dec_sdfs = torch.zeros(O, 1, 4, 4, 4)
+    dec_sdfs[t("dec_sdfs_nonzero")] = 1.0
+    mu, logvar = m.encoder(*a, t("boxes_gt"), None, tf, rf, t("angles_gt"))
+    np.random.seed(1234)
+    (d3c, angc), gen, keepc = m.decoder_with_changes(t("z_in"), *a, tf, rf, dec_sdfs, None, [2], [4], gen_shape=True,
+                                                     x_T=t("x_T"), ddim_steps=2)
+    np.random.seed(99)
+    (d3a, anga), none_sdf, keepa = m.decoder_with_additions(t("z_in"), *a, tf, rf, dec_sdfs, None, [2], [4],
+                                                            distribution=(np.zeros(64), np.eye(64)))
+    torch.cuda.synchronize()
+    assert none_sdf is None and gen.shape == (6, 1, 64, 64, 64)
+    for mine, key in ((mu, "mu"), (logvar, "logvar"), (d3c, "d3_changes"), (angc, "angles_changes"), (d3a, "d3_add"),
+                      (anga, "angles_add")):
+        assert rel_l2(mine, t(key)) < 3e-6, key
+    assert torch.equal(keepc.cpu(), t("keep_changes")) and torch.equal(keepa.cpu(), t("keep_add"))
+    sub, ref = gen[:, :, ::2, ::2, ::2], t("gen_sdf_sub")
+    per_obj = sorted(rel_l2(sub[i], ref[i]) for i in range(6))
+    assert per_obj[3] < 1e-4, per_obj          # code flips on near-ties aside (SURVEY F8)
+
+
 def test_rel2shape_minibatch_and_shared_noise_semantics(tmp_path):
     """per-object output is independent of the sampler mini-batch (7 vs 32) and all objects share x_T:
     identical conditioning => identical shapes (sdfusion_txt2shape_model.py:486-511)."""

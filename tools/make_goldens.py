@@ -497,6 +497,41 @@ def g_box():
          d3_sample=d3s, angles_sample=angs)
 
 
+def g_full_manip(tmp: Path):
+    """v2_full manipulation surface (VAEGAN_V2FULL.py:185-218 encoder, :244-259 manipulate, :291-396
+    decoder_with_additions / decoder_with_changes incl. the gen_shape branch with 2 DDIM steps)."""
+    import functools
+    model, sd, df_sd, vq_sd = build_ref_scene(tmp, small=True)
+    nobj = 6
+    g = synth.random_scene_graph(nobj, seed=17)
+    O = g["objs"].shape[0]
+    a = (g["objs"], g["triples"])
+    tf, rf = g["text_feats"], g["rel_feats"]
+    boxes_gt = synth.gaussian_like("fm:gt", (O, 6))
+    angles_gt = torch.from_numpy(np.floor((synth.hash_uniform("fm:ang", O) + 1.0) * 12.0)).long().clamp(0, 23)
+    dec_sdfs = torch.zeros(O, 1, 4, 4, 4)
+    dec_sdfs[:nobj] = 1.0
+    z = synth.gaussian_like("fm:z", (O, 64))
+    z_in = torch.cat([z[:2], z[3:]], dim=0)
+    x_T = synth.gaussian_like("fm:xT", (1, 3, 16, 16, 16))
+    model.Diff.rel2shape = functools.partial(model.Diff.rel2shape, ddim_steps=2)
+    with torch.no_grad():
+        mu, logvar = model.encoder(*a, boxes_gt, None, tf, rf, angles_gt)
+        INJECT["x_T"] = x_T
+        np.random.seed(1234)
+        (d3c, angc), gen_sdf, keepc = model.decoder_with_changes(z_in, *a, tf, rf, dec_sdfs, None, [2], [4],
+                                                                 gen_shape=True)
+        INJECT["x_T"] = None
+        np.random.seed(99)
+        (d3a, anga), none_sdf, keepa = model.decoder_with_additions(z_in, *a, tf, rf, dec_sdfs, None, [2], [4],
+                                                                    distribution=(np.zeros(64), np.eye(64)))
+    assert none_sdf is None and gen_sdf.shape == (nobj, 1, 64, 64, 64)
+    save("full_manip_small", objs=g["objs"], triples=g["triples"], text_feats=tf, rel_feats=rf, boxes_gt=boxes_gt,
+         angles_gt=angles_gt, dec_sdfs_nonzero=(dec_sdfs.flatten(1).abs().sum(1) > 0), mu=mu, logvar=logvar, z_in=z_in,
+         x_T=x_T, d3_changes=d3c, angles_changes=angc, keep_changes=keepc,
+         gen_sdf_sub=gen_sdf[:, :, ::2, ::2, ::2].contiguous(), d3_add=d3a, angles_add=anga, keep_add=keepa)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*", default=None)
@@ -504,7 +539,8 @@ def main():
     install_stubs()
     install_patches()
     todo = a.only or ["schedule", "unet_small", "unet_full", "ddim_small", "ddim_full", "vq", "gcn", "e2e",
-                      "unet_concat_small", "unet_concat_full", "ddim_concat_small", "gcn_concat", "e2e_concat", "box"]
+                      "unet_concat_small", "unet_concat_full", "ddim_concat_small", "gcn_concat", "e2e_concat", "box",
+                      "full_manip"]
     with tempfile.TemporaryDirectory() as td:
         tmp = Path(td)
         for name in todo:
@@ -537,6 +573,8 @@ def main():
                 g_e2e(tmp, concat=True)
             elif name == "box":
                 g_box()
+            elif name == "full_manip":
+                g_full_manip(tmp)
             else:
                 raise SystemExit(f"unknown fixture {name}")
 
