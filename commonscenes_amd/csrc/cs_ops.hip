@@ -419,6 +419,52 @@ extern "C" int cs_ddim_cfg_update_dev(const float* x, const float* eps, const fl
   return CS_OK;
 }
 
+// Nearest-neighbour squared distance of every point of xyz1 in xyz2 (one direction of the Chamfer distance,
+// extension/chamfer.cu:11-75 NmDistanceKernel): queries one per lane, the target cloud streamed through LDS in
+// 1024-point tiles (every lane reads the same LDS word per step: a broadcast, no bank conflicts).  The distance is
+// ((dx*dx + dy*dy) + dz*dz) in fp32 without contraction and the scan keeps the FIRST minimum, as the reference's
+// strict `d < best` / `result > best` comparisons do.
+__global__ __launch_bounds__(256) void chamfer_nm_kernel(const float* __restrict__ xyz1,
+                                                         const float* __restrict__ xyz2, float* __restrict__ dist,
+                                                         int32_t* __restrict__ idx, int n, int m) {
+  constexpr int TILE = 1024;
+  __shared__ float buf[TILE * 3];
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const float* q = xyz1 + ((int64_t)b * n + (j < n ? j : 0)) * 3;
+  const float x1 = q[0], y1 = q[1], z1 = q[2];
+  float best = 0.f;
+  int best_i = 0;
+  const float* t = xyz2 + (int64_t)b * m * 3;
+  for (int k0 = 0; k0 < m; k0 += TILE) {
+    const int cnt = min(TILE, m - k0);
+    __syncthreads();
+    for (int e = threadIdx.x; e < cnt * 3; e += blockDim.x) buf[e] = t[(int64_t)k0 * 3 + e];
+    __syncthreads();
+    for (int k = 0; k < cnt; ++k) {
+      const float dx = buf[3 * k] - x1, dy = buf[3 * k + 1] - y1, dz = buf[3 * k + 2] - z1;
+      const float d = (dx * dx + dy * dy) + dz * dz;
+      if ((k0 + k) == 0 || d < best) {
+        best = d;
+        best_i = k0 + k;
+      }
+    }
+  }
+  if (j < n) {
+    dist[(int64_t)b * n + j] = best;
+    idx[(int64_t)b * n + j] = best_i;
+  }
+}
+
+extern "C" int cs_chamfer_nm_distance(const float* xyz1, const float* xyz2, float* dist, int32_t* idx, int b, int n,
+                                      int m, cs_stream_t stream) {
+  if (!xyz1 || !xyz2 || !dist || !idx || b <= 0 || n <= 0 || m <= 0 || b > 65535) return CS_EINVAL;
+  CS_LAUNCH(chamfer_nm_kernel, dim3((n + 255) / 256, b), dim3(256), 0, (hipStream_t)stream, xyz1, xyz2, dist, idx, n,
+            m);
+  CS_CHECK_LAUNCH();
+  return CS_OK;
+}
+
 extern "C" int cs_vq_argmin_lookup(const float* z, const float* codebook, int64_t* idx, float* zq,
                                    int64_t m, int ncode, int edim, int ldz, int ldq, cs_stream_t stream) {
   if (!z || !codebook || !idx || !zq || m <= 0 || ncode <= 0 || edim <= 0 || edim > 3 || ldz < edim ||

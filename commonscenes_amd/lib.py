@@ -85,6 +85,7 @@ SIGNATURES = {
     "cs_ddim_cfg_update": (_i, [_f, _f, _f, _f, _f, _l, _l, _fl, _fl, _fl, _fl, _fl, _i, _s]),
     "cs_ddim_coefficients": (_i, [_fl, _fl, _fl, _fl, _f]),
     "cs_ddim_cfg_update_dev": (_i, [_f, _f, _f, _f, _f, _l, _l, _f, _fl, _i, _s]),
+    "cs_chamfer_nm_distance": (_i, [_f, _f, _f, _f, _i, _i, _i, _s]),
     "cs_unet_create": (_i, [C.POINTER(CsUnetConfig), _pp]),
     "cs_unet_destroy": (None, [C.c_void_p]),
     "cs_unet_param_count": (_i, [C.c_void_p]),

@@ -257,6 +257,16 @@ int cs_log_softmax(const float* x, float* y, int m, int c, int ldx, int ldy, cs_
 int cs_synth_fill(float* out, int64_t n, uint64_t base, double scale, double offset, cs_stream_t stream);
 
 /*
+ * One direction of the Chamfer distance (extension/chamfer.cu:11-75 NmDistanceKernel, bound by
+ * extension/chamfer_cuda.cpp:9-26 and wrapped by extension/dist_chamfer.py:12-29; used by the diversity metric of
+ * scripts/eval_3dfront.py:394-397): for each of the n points of xyz1 [b][n][3] the squared distance to, and the
+ * index of, its nearest neighbour among the m points of xyz2 [b][m][3].  Ties keep the lowest index.
+ * The reference's forward is this call twice (xyz1 -> xyz2, xyz2 -> xyz1).
+ */
+int cs_chamfer_nm_distance(const float* xyz1, const float* xyz2, float* dist, int32_t* idx, int b, int n, int m,
+                           cs_stream_t stream);
+
+/*
  * Whole-forward driver (SURVEY 8b "cs_unet_step"): UNet3DModel.forward (openai_model_3d.py:752-789) with the
  * crossattn conditioning of DiffusionUNet.forward (network.py:28-30) as ONE call over a packed weight arena.
  * The plan object is host memory only (architecture walk, arena layout, packing recipe); every device buffer --

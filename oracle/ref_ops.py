@@ -99,3 +99,25 @@ def gcn_pool(new_t, edges, n_obj, H, off_o):
     ones = torch.ones(edges.shape[0])
     cnt = cnt.scatter_add(0, s_idx, ones).scatter_add(0, o_idx, ones).clamp(min=1)
     return pooled / cnt.view(-1, 1)
+
+
+def chamfer_nm(xyz1, xyz2):
+    """extension/chamfer.cu:11-75 (NmDistanceKernel), one direction: for each xyz1[b, j] the squared distance to its
+    nearest xyz2[b, k] and the first minimising k.  fp32 arithmetic in the reference's operation order
+    ((dx*dx + dy*dy) + dz*dz, no fused multiply-add on this side).  PARITY UNPINNED against the CUDA build of the
+    reference (it cannot run in this image); the definition is the textbook one and the reference's own
+    extension/test.py checks it the same way (against a python loop)."""
+    import numpy as np
+    a = np.asarray(xyz1, dtype=np.float32)
+    b = np.asarray(xyz2, dtype=np.float32)
+    B, n, _ = a.shape
+    dist = np.empty((B, n), dtype=np.float32)
+    idx = np.empty((B, n), dtype=np.int32)
+    for i in range(B):
+        dx = b[i, None, :, 0] - a[i, :, None, 0]
+        dy = b[i, None, :, 1] - a[i, :, None, 1]
+        dz = b[i, None, :, 2] - a[i, :, None, 2]
+        d = (dx * dx + dy * dy) + dz * dz
+        idx[i] = np.argmin(d, axis=1).astype(np.int32)
+        dist[i] = d[np.arange(n), idx[i]]
+    return dist, idx

@@ -350,3 +350,37 @@ def test_embedding(ops):
     out = ops.embedding(_dev(tab), _dev(idx))
     torch.cuda.synchronize()
     assert torch.equal(out.cpu(), tab[idx])
+
+
+@pytest.mark.parametrize("b,n,m", [(3, 1000, 777), (1, 5, 3000), (2, 2048, 2048), (1, 1, 1)])
+def test_chamfer_nm_distance_bit_exact(b, n, m):
+    """cs_chamfer_nm_distance == the oracle's fp32 brute force, distances and first-minimum indices bit for bit
+    (ragged sizes, duplicated target points -> ties keep the lowest index)."""
+    from commonscenes_amd.chamfer import chamferDist, nm_distance
+    from oracle import ref_ops as R
+    g = torch.Generator().manual_seed(b * 1000 + n + m)
+    x1 = torch.randn(b, n, 3, generator=g)
+    x2 = torch.randn(b, m, 3, generator=g)
+    if m > 10:
+        x2[:, m // 2] = x2[:, 3]              # an exact duplicate: the tie must resolve to index 3
+        x1[:, 0] = x2[:, 3]
+    d, i = nm_distance(x1.cuda(), x2.cuda())
+    torch.cuda.synchronize()
+    rd, ri = R.chamfer_nm(x1.numpy(), x2.numpy())
+    assert np.array_equal(i.cpu().numpy(), ri)
+    assert np.array_equal(d.cpu().numpy(), rd)
+    if m > 10:
+        assert int(i[0, 0]) == 3 and float(d[0, 0]) == 0.0
+    d1, d2 = chamferDist()(x1.cuda(), x2.cuda())
+    rd2, _ = R.chamfer_nm(x2.numpy(), x1.numpy())
+    assert np.array_equal(d1.cpu().numpy(), rd) and np.array_equal(d2.cpu().numpy(), rd2)
+
+
+def test_chamfer_self_distance_is_zero_at_full_size():
+    from commonscenes_amd.chamfer import chamferDist
+    x = torch.randn(4, 20000, 3, generator=torch.Generator().manual_seed(5)).cuda()
+    cd = chamferDist()
+    d1, d2 = cd(x, x)
+    torch.cuda.synchronize()
+    assert float(d1.abs().max()) == 0.0 and float(d2.abs().max()) == 0.0
+    assert torch.equal(cd.idx1.long(), torch.arange(20000, device="cuda").expand(4, -1))
