@@ -94,45 +94,116 @@ __global__ __launch_bounds__(256) void attn_f16x3_kernel(const float* __restrict
   for (int d = 0; d < DB; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+  // Online softmax in the accumulator's own units: sacc = logit * QK_SCALE^2, so with c = log2(e) / QK_SCALE^2
+  //   p * P_SCALE = exp2((sacc - m) * c + log2(P_SCALE))
+  // is one subtract, one fma and one v_exp_f32 per element (the row maximum m stays in raw units, the P_SCALE the
+  // PV operands need is folded into the exponent, and the running sum carries it until the final normalisation).
   float mrun = -INFINITY;
   float lrun = 0.f;
-  const float inv_s = 1.0f / (QK_SCALE * QK_SCALE);
+  const float cexp = 1.44269504088896340736f / (QK_SCALE * QK_SCALE);
+  const float lp = 10.0f;             // log2(P_SCALE)
+  static_assert(P_SCALE == 1024.0f, "lp = log2(P_SCALE)");
 
+  // K / V tile staging, software-pipelined: the global loads of tile t+1 are issued (into registers) before tile t's
+  // MFMA / softmax work and only converted + written to LDS after it, so their latency never sits between barriers.
+  // Unit i of a thread: K -> (key j, 4 channels), coalesced along d; V -> (4 channels, key j) with the key fastest,
+  // so a wave writes one contiguous run of a V^T row.
   const int dh4 = dh >> 2;
+  constexpr bool PIPE = DB <= 2;
+  constexpr int NU = PIPE ? KT * DP / 1024 : 1;      // units per thread per tensor (KT * DP/4 units over 256 threads)
+  int k_g[NU], k_l[NU], v_g[NU], v_l[NU];
+#pragma unroll
+  for (int i = 0; i < NU; ++i) {
+    const int u = tid + 256 * i;
+    const bool ok = u < KT * dh4;
+    const int j = ok ? u / dh4 : 0;
+    const int c4 = ok ? u - j * dh4 : 0;
+    k_g[i] = j * ldk + c4 * 4;
+    k_l[i] = ok ? j * LDK + c4 * 4 : -1;
+    const int vc4 = ok ? u / KT : 0;
+    const int vj = ok ? u - vc4 * KT : 0;
+    v_g[i] = vj * ldv + vc4 * 4;
+    v_l[i] = ok ? (vc4 * 4) * LDV + vpos(vj) : -1;
+  }
+  float4 kr[NU], vr[NU];
+  auto load_tile = [&](int kt0) {
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      kr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      vr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      // key index of the unit, recovered from its LDS offset (only matters on the ragged last tile)
+      if (k_l[i] >= 0 && kt0 + k_l[i] / LDK < nk)
+        kr[i] = *reinterpret_cast<const float4*>(kb + (int64_t)kt0 * ldk + k_g[i]);
+      if (v_l[i] >= 0 && kt0 + vpos(v_l[i] % LDV) < nk)
+        vr[i] = *reinterpret_cast<const float4*>(vb + (int64_t)kt0 * ldv + v_g[i]);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      if (k_l[i] >= 0) {
+        h4 hi, lo;
+        _Float16 a, c;
+        split1(kr[i].x * QK_SCALE, a, c); hi[0] = a; lo[0] = c;
+        split1(kr[i].y * QK_SCALE, a, c); hi[1] = a; lo[1] = c;
+        split1(kr[i].z * QK_SCALE, a, c); hi[2] = a; lo[2] = c;
+        split1(kr[i].w * QK_SCALE, a, c); hi[3] = a; lo[3] = c;
+        *reinterpret_cast<h4*>(Kh + k_l[i]) = hi;
+        *reinterpret_cast<h4*>(Kl + k_l[i]) = lo;
+      }
+      if (v_l[i] >= 0) {
+        const float x[4] = {vr[i].x, vr[i].y, vr[i].z, vr[i].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          _Float16 a, c;
+          split1(x[e] * QK_SCALE, a, c);
+          Vh[v_l[i] + e * LDV] = a;
+          Vl[v_l[i] + e * LDV] = c;
+        }
+      }
+    }
+  };
+  // The prefetch costs 12 * NU registers: worth it while the kernel keeps >= 2 waves per SIMD (DB <= 2: 852 -> 661 us
+  // at 1024 tokens x dh 56), a loss once it drops the wider variants to one (dh 84: 105 -> 119 us), so those load
+  // and convert in place.
+  if (PIPE) load_tile(0);
   for (int kt0 = 0; kt0 < nk; kt0 += KT) {
     __syncthreads();  // previous tile fully consumed
-    // K tile: unit = (key j, 4 channels); coalesced along d
-    for (int u = tid; u < KT * dh4; u += 256) {
-      const int j = u / dh4;
-      const int c4 = u - j * dh4;
-      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (kt0 + j < nk) kv = *reinterpret_cast<const float4*>(kb + (int64_t)(kt0 + j) * ldk + c4 * 4);
-      h4 hi, lo;
-      _Float16 a, c;
-      split1(kv.x * QK_SCALE, a, c); hi[0] = a; lo[0] = c;
-      split1(kv.y * QK_SCALE, a, c); hi[1] = a; lo[1] = c;
-      split1(kv.z * QK_SCALE, a, c); hi[2] = a; lo[2] = c;
-      split1(kv.w * QK_SCALE, a, c); hi[3] = a; lo[3] = c;
-      *reinterpret_cast<h4*>(Kh + j * LDK + c4 * 4) = hi;
-      *reinterpret_cast<h4*>(Kl + j * LDK + c4 * 4) = lo;
-    }
-    // V tile -> V^T images: unit = (4 channels, key j), key fastest so a wave writes one contiguous row run
-    for (int u = tid; u < KT * dh4; u += 256) {
-      const int c4 = u / KT;
-      const int j = u - c4 * KT;
-      float4 vv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (kt0 + j < nk) vv = *reinterpret_cast<const float4*>(vb + (int64_t)(kt0 + j) * ldv + c4 * 4);
-      const int pj = vpos(j);
-      const float x[4] = {vv.x, vv.y, vv.z, vv.w};
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
+    if constexpr (PIPE) {
+      store_tile();
+    } else {
+      for (int u = tid; u < KT * dh4; u += 256) {          // K: unit = (key j, 4 channels)
+        const int j = u / dh4;
+        const int c4 = u - j * dh4;
+        float4 kv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kt0 + j < nk) kv = *reinterpret_cast<const float4*>(kb + (int64_t)(kt0 + j) * ldk + c4 * 4);
+        h4 hi, lo;
         _Float16 a, c;
-        split1(x[i] * QK_SCALE, a, c);
-        Vh[(c4 * 4 + i) * LDV + pj] = a;
-        Vl[(c4 * 4 + i) * LDV + pj] = c;
+        split1(kv.x * QK_SCALE, a, c); hi[0] = a; lo[0] = c;
+        split1(kv.y * QK_SCALE, a, c); hi[1] = a; lo[1] = c;
+        split1(kv.z * QK_SCALE, a, c); hi[2] = a; lo[2] = c;
+        split1(kv.w * QK_SCALE, a, c); hi[3] = a; lo[3] = c;
+        *reinterpret_cast<h4*>(Kh + j * LDK + c4 * 4) = hi;
+        *reinterpret_cast<h4*>(Kl + j * LDK + c4 * 4) = lo;
+      }
+      for (int u = tid; u < KT * dh4; u += 256) {          // V: unit = (4 channels, key j), key fastest
+        const int c4 = u / KT;
+        const int j = u - c4 * KT;
+        float4 vv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kt0 + j < nk) vv = *reinterpret_cast<const float4*>(vb + (int64_t)(kt0 + j) * ldv + c4 * 4);
+        const int pj = vpos(j);
+        const float x[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          _Float16 a, c;
+          split1(x[i] * QK_SCALE, a, c);
+          Vh[(c4 * 4 + i) * LDV + pj] = a;
+          Vl[(c4 * 4 + i) * LDV + pj] = c;
+        }
       }
     }
     __syncthreads();
+    if (PIPE && kt0 + KT < nk) load_tile(kt0 + KT);
 
     // ---- S^T = K Q^T ----
     f32x16 sacc[JB];
@@ -153,25 +224,29 @@ __global__ __launch_bounds__(256) void attn_f16x3_kernel(const float* __restrict
       }
 
     // ---- online softmax (per query i = lane&31) ----
+    if (kt0 + KT > nk) {               // ragged last tile only (wave-uniform): keys past nk take no weight
+#pragma unroll
+      for (int jb = 0; jb < JB; ++jb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = kt0 + jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (j >= nk) sacc[jb][r] = -INFINITY;
+        }
+    }
     float mloc = -INFINITY;
 #pragma unroll
     for (int jb = 0; jb < JB; ++jb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int j = kt0 + jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const float sv = (j < nk) ? sacc[jb][r] * inv_s : -INFINITY;
-        sacc[jb][r] = sv;
-        mloc = fmaxf(mloc, sv);
-      }
+      for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, sacc[jb][r]);
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
     const float mnew = fmaxf(mrun, mloc);
-    const float alpha = (mrun == -INFINITY) ? 0.f : expf(mrun - mnew);
+    const float alpha = (mrun == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((mrun - mnew) * cexp);
     float psum = 0.f;
 #pragma unroll
     for (int jb = 0; jb < JB; ++jb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = expf(sacc[jb][r] - mnew);
+        const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[jb][r] - mnew, cexp, lp));   // = p * P_SCALE
         sacc[jb][r] = pv;
         psum += pv;
       }
@@ -191,7 +266,7 @@ __global__ __launch_bounds__(256) void attn_f16x3_kernel(const float* __restrict
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           _Float16 a, c;
-          split1(sacc[jb][8 * qq + e] * P_SCALE, a, c);
+          split1(sacc[jb][8 * qq + e], a, c);
           ph[e] = a;
           pl[e] = c;
         }
@@ -208,7 +283,7 @@ __global__ __launch_bounds__(256) void attn_f16x3_kernel(const float* __restrict
   }
 
   const float ltot = lrun + __shfl_xor(lrun, 32, 64);
-  const float inv = 1.0f / (ltot * QK_SCALE * P_SCALE);
+  const float inv = 1.0f / (ltot * QK_SCALE);       // ltot already carries P_SCALE
   if (q0 + l31 < nq) {
     float* op = out + ((int64_t)b * nq + q0 + l31) * ldo + h * dh;
 #pragma unroll

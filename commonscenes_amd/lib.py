@@ -16,6 +16,7 @@ import torch  # noqa: F401
 
 from .build import LIB_PATH
 
+ABI_VERSION = 3      # cs_abi_version() of the library this module's SIGNATURES table describes
 CS_OK = 0
 CS_EINVAL = -22
 CS_ENOMEM = -12
@@ -132,6 +133,10 @@ def load(path: Path | None = None) -> C.CDLL:
             raise NativeLibraryMissing(f"{p} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
+    got = lib.cs_abi_version()
+    if got != ABI_VERSION:
+        raise NativeLibraryMissing(f"{p} has ABI version {got}, this package expects {ABI_VERSION}: rebuild it "
+                                   "(`python -m commonscenes_amd.build --force`)")
     if path is None:
         _LIB = lib
     return lib
