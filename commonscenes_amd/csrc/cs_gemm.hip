@@ -247,7 +247,58 @@ __global__ void relayout_weight_kernel(const float* __restrict__ w, float* __res
 
 }  // namespace
 
-int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p, int M, int tile, hipStream_t s);  // cs_gemm_f16x3.hip
+int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p, int M, int tile, int splits, hipStream_t s);  // cs_gemm_f16x3.hip
+
+namespace {
+
+// Split-K heuristic: F16X3 GEMMs on the 224-column tile whose output tiles would leave most of the 256 CUs idle
+// (small batches) and whose K loop is long enough to share: enough slices to reach ~256 workgroups, at least 16
+// K chunks per slice, at most 32 slices.
+int plan_splitk(const CsConvGemm& p, int64_t M) {
+  if (p.math != CS_MATH_F16X3 || p.act == CS_ACT_GEGLU || p.tile != 0 || p.cout % 224) return 1;
+  const int64_t wgs = ((M + 127) / 128) * (p.cout / 224);
+  if (wgs >= 160) return 1;
+  const int64_t nk = (int64_t)p.kd * p.kh * p.kw * ((p.cin + 15) / 16);
+  int64_t s = (256 + wgs - 1) / wgs;
+  if (s > nk / 16) s = nk / 16;
+  if (s > 32) s = 32;
+  return s < 2 ? 1 : (int)s;
+}
+
+// sums the split-K partial tiles in slice order and applies the epilogue of conv_gemm_* (bias, BN scale/shift,
+// row vector, activation, residual); one float4 of one output row per thread
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const CsConvGemm p, const float* __restrict__ ws, int M,
+                                                            int splits) {
+  const int n4 = p.cout >> 2;
+  const int64_t total = (int64_t)M * n4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i / n4);
+    const int n = (int)(i - (int64_t)m * n4) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(ws + (int64_t)m * p.cout + n);
+    for (int s = 1; s < splits; ++s) v += *reinterpret_cast<const f32x4*>(ws + ((int64_t)s * M + m) * p.cout + n);
+    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+    if (p.scale) v = v * *reinterpret_cast<const f32x4*>(p.scale + n) + *reinterpret_cast<const f32x4*>(p.shift + n);
+    if (p.rowvec) v += *reinterpret_cast<const f32x4*>(p.rowvec + (int64_t)(m / p.rv_rows) * p.ldrv + n);
+    if (p.act != CS_ACT_NONE) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = cs_act(v[e], p.act);
+    }
+    if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (int64_t)m * p.ldr + n);
+    *reinterpret_cast<f32x4*>(p.out + (int64_t)m * p.ldo + n) = v;
+  }
+}
+
+}  // namespace
+
+extern "C" int cs_conv_gemm_plan(const CsConvGemm* d, int32_t* splitk, int64_t* ws_bytes) {
+  if (!d || !splitk) return CS_EINVAL;
+  const int64_t M = (int64_t)d->nb * d->dout * d->hout * d->wout;
+  if (M <= 0 || d->cout <= 0) return CS_EINVAL;
+  const int s = plan_splitk(*d, M);
+  *splitk = s;
+  if (ws_bytes) *ws_bytes = s > 1 ? (int64_t)s * M * d->cout * 4 : 0;
+  return CS_OK;
+}
 
 extern "C" int cs_conv_gemm(const CsConvGemm* d, cs_stream_t stream) {
   if (!d || !d->x || !d->w || !d->out) return CS_EINVAL;
@@ -287,7 +338,29 @@ extern "C" int cs_conv_gemm(const CsConvGemm* d, cs_stream_t stream) {
       tile = 3;
   }
   hipStream_t s = (hipStream_t)stream;
-  if (f16x3) return cs_conv_gemm_f16x3_dispatch(p, M, tile, s);
+  if (p.splitk > 1) {
+    // caller-requested split-K (cs_conv_gemm_plan): partial tiles to the workspace, then reduce + epilogue
+    auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    if (!f16x3 || p.act == CS_ACT_GEGLU || p.cout % 224 || !p.splitk_ws || !al16(p.splitk_ws) || p.splitk > 64)
+      return CS_EINVAL;
+    if ((p.ldo & 3) || !al16(p.out) || (p.bias && !al16(p.bias)) || (p.scale && (!al16(p.scale) || !al16(p.shift))) ||
+        (p.rowvec && ((p.ldrv & 3) || !al16(p.rowvec))) || (p.res && ((p.ldr & 3) || !al16(p.res))))
+      return CS_EINVAL;
+    const int64_t nk = (int64_t)p.kd * p.kh * p.kw * ((p.cin + 15) / 16);
+    if (p.splitk > nk) return CS_EINVAL;
+    CsConvGemm part = p;
+    part.out = reinterpret_cast<float*>(p.splitk_ws);
+    part.ldo = p.cout;
+    part.bias = part.scale = part.shift = part.rowvec = part.res = nullptr;
+    part.act = CS_ACT_NONE;
+    const int rc = cs_conv_gemm_f16x3_dispatch(part, M, 2, p.splitk, s);
+    if (rc != CS_OK) return rc;
+    CS_LAUNCH(splitk_reduce_kernel, dim3(cs_grid_for((int64_t)M * (p.cout >> 2), 256)), dim3(256), 0, s, p,
+              reinterpret_cast<const float*>(p.splitk_ws), M, p.splitk);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+  }
+  if (f16x3) return cs_conv_gemm_f16x3_dispatch(p, M, tile, 1, s);
   switch (tile) {
     case 1: return launch<2, 2, 2, 2>(p, M, s);
     case 2: return launch<1, 7, 4, 1>(p, M, s);
@@ -349,4 +422,4 @@ extern "C" int cs_relayout_weight(const float* w_torch, float* w_out, int cout, 
   return CS_OK;
 }
 
-extern "C" int cs_abi_version(void) { return 3; }
+extern "C" int cs_abi_version(void) { return 4; }

@@ -68,7 +68,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 template <int WMB, int WNB, int WAVES_M, int WAVES_N, bool PRE>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_kernel(const CsConvGemm p, int M, int tiles_n,
                                                               int taps_hw, int kw_, int kg_per_tap,
-                                                              unsigned x_bytes, unsigned w_bytes, int vec_epilogue) {
+                                                              unsigned x_bytes, unsigned w_bytes, int vec_epilogue,
+                                                              int splits) {
   constexpr int BM = 32 * WMB * WAVES_M;
   constexpr int BN = 32 * WNB * WAVES_N;
   constexpr int NW = WAVES_M * WAVES_N;            // waves per workgroup (4, or 8 for the 256-row tile)
@@ -107,6 +108,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
     const int q = nblk >> 3, r = nblk & 7, xcd = b & 7, within = b >> 3;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
   }
+  // split-K: consecutive virtual tiles are the K slices of one output tile (same XCD: they share the A rows)
+  const int split = tile % splits;
+  tile /= splits;
   const int tn = tile % tiles_n;
   const int tm = tile / tiles_n;
   const int m0 = tm * BM;
@@ -160,7 +164,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
 
   const float a_scale = p.a_scale;
   const int chunks_per_tap = kg_per_tap >> 1;   // cin16 / 16
-  const int nk = ntaps * chunks_per_tap;
+  const int nk_all = ntaps * chunks_per_tap;
+  const int per_split = (nk_all + splits - 1) / splits;
+  const int k_first = split * per_split;                        // this workgroup's slice of the chunk sequence
+  const int nk = max(0, min(nk_all, k_first + per_split) - k_first);
 
   // ---- per-lane DMA constants ----
   // A wave-instruction w (0..A_WI-1) covers units 64w..64w+63: row = 16w + lane/4, LDS slot q = lane&3 holds
@@ -244,7 +251,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // DMA stream position (chunk index q -> tap = q % ntaps, cc = q / ntaps), two chunks ahead of compute
-  int dtap = 0, dcc = 0;
+  int dtap = k_first % ntaps, dcc = k_first / ntaps;
   auto advance = [&]() {
     if (++dtap == ntaps) {
       dtap = 0;
@@ -346,6 +353,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   // Fast path: the C/D layout gives a lane one column and 16 scattered rows, i.e. 112 dword stores (+112 dword
   // residual loads) per lane -- issue-bound, and for the short-K token GEMMs as long as the main loop.  Stage
   // 16 rows x (32*WNB) columns per wave through the (now idle) LDS ring and write whole rows as float4.
+  float* const outp = p.out + (int64_t)split * M * p.ldo;      // split-K: slice s owns rows [s*M, (s+1)*M) of the ws
   constexpr int WCOLS = 32 * WNB;
   constexpr int PASS_R = (NW * 16 * WCOLS * 4 <= NSTAGE * STAGE) ? 8 : 4;   // accumulator registers per pass
   constexpr int EPI_ROWS = 2 * PASS_R;                                       // rows staged per wave per pass
@@ -390,7 +398,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) xv[e] = xv[e] * cs_gelu(gv[e]);
-                *reinterpret_cast<f32x4*>(p.out + (int64_t)m * p.ldo + (n0 + wn0) / 2 + 4 * c4) = xv;
+                *reinterpret_cast<f32x4*>(outp + (int64_t)m * p.ldo + (n0 + wn0) / 2 + 4 * c4) = xv;
               }
             }
           }
@@ -416,7 +424,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
                 for (int e = 0; e < 4; ++e) v[e] = cs_act(v[e], p.act);
               }
               if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (int64_t)m * p.ldr + n);
-              *reinterpret_cast<f32x4*>(p.out + (int64_t)m * p.ldo + n) = v;
+              *reinterpret_cast<f32x4*>(outp + (int64_t)m * p.ldo + n) = v;
             }
           }
         }
@@ -442,7 +450,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
           if (p.rowvec) v += p.rowvec[(int64_t)(m / p.rv_rows) * p.ldrv + n];
           v = cs_act(v, p.act);
           if (p.res) v += p.res[(int64_t)m * p.ldr + n];
-          p.out[(int64_t)m * p.ldo + n] = v;
+          outp[(int64_t)m * p.ldo + n] = v;
         }
       }
     }
@@ -450,12 +458,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
 }
 
 template <int WMB, int WNB, int WAVES_M, int WAVES_N, bool PRE>
-int launch16(const CsConvGemm& p, int M, hipStream_t stream) {
+int launch16(const CsConvGemm& p, int M, int splits, hipStream_t stream) {
   constexpr int BM = 32 * WMB * WAVES_M;
   constexpr int BN = 32 * WNB * WAVES_N;
   const int tiles_m = (M + BM - 1) / BM;
   const int tiles_n = (p.cout + BN - 1) / BN;
-  const int64_t nblk = (int64_t)tiles_m * tiles_n;
+  const int64_t nblk = (int64_t)tiles_m * tiles_n * splits;
   if (nblk > 0x7fffffffLL) return CS_EINVAL;
   const int kg_per_tap = ((p.cin + 15) / 16) * 2;
   // buffer-descriptor extents: everything the loader may touch, and < 0xFFE00000 so OOB stays out of range
@@ -474,7 +482,7 @@ int launch16(const CsConvGemm& p, int M, hipStream_t stream) {
     if (!vec || (WCOLS / 2) % 4 || p.cout % WCOLS || p.scale || p.rowvec || p.res) return CS_EINVAL;
   }
   CS_LAUNCH((conv_gemm_f16x3_kernel<WMB, WNB, WAVES_M, WAVES_N, PRE>), dim3((unsigned)nblk), dim3(64 * WAVES_M * WAVES_N), 0,
-            stream, p, M, tiles_n, p.kh * p.kw, p.kw, kg_per_tap, (unsigned)x_bytes, (unsigned)w_bytes, vec);
+            stream, p, M, tiles_n, p.kh * p.kw, p.kw, kg_per_tap, (unsigned)x_bytes, (unsigned)w_bytes, vec, splits);
   CS_CHECK_LAUNCH();
   return CS_OK;
 }
@@ -503,8 +511,9 @@ __global__ __launch_bounds__(256) void pack_f16x3_kernel(const float* __restrict
 }  // namespace
 
 // called from cs_conv_gemm (cs_gemm.hip) when desc->math == CS_MATH_F16X3; arguments already validated
-int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p_in, int M, int tile, hipStream_t s) {
+int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p_in, int M, int tile, int splits, hipStream_t s) {
   CsConvGemm p = p_in;
+  if (splits < 1) splits = 1;
   if (p.a_scale == 0.f) p.a_scale = A_SCALE_DEFAULT;
   if (!p.w_lo || !(p.acc_scale > 0.f) || !(p.a_scale > 0.f)) return CS_EINVAL;
   if (p.kd * p.kh * p.kw > MAX_TAPS) return CS_EINVAL;                             // LDS row table extent
@@ -515,19 +524,19 @@ int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p_in, int M, int tile, hipStre
   if (p.a_format == 1) {
     if (!p.x_lo || ((uintptr_t)p.x_lo & 15) || (p.cin & 7) || (p.lda & 7)) return CS_EINVAL;
     switch (tile) {
-      case 1: return launch16<2, 2, 2, 2, true>(p, M, s);
-      case 2: return launch16<1, 7, 4, 1, true>(p, M, s);
-      case 3: return launch16<1, 1, 2, 2, true>(p, M, s);
-      case 4: return launch16<1, 7, 8, 1, true>(p, M, s);
+      case 1: return launch16<2, 2, 2, 2, true>(p, M, splits, s);
+      case 2: return launch16<1, 7, 4, 1, true>(p, M, splits, s);
+      case 3: return launch16<1, 1, 2, 2, true>(p, M, splits, s);
+      case 4: return launch16<1, 7, 8, 1, true>(p, M, splits, s);
       default: return CS_EINVAL;
     }
   }
   if (p.a_format != 0) return CS_EINVAL;
   switch (tile) {
-    case 1: return launch16<2, 2, 2, 2, false>(p, M, s);
-    case 2: return launch16<1, 7, 4, 1, false>(p, M, s);
-    case 3: return launch16<1, 1, 2, 2, false>(p, M, s);
-    case 4: return launch16<1, 7, 8, 1, false>(p, M, s);
+    case 1: return launch16<2, 2, 2, 2, false>(p, M, splits, s);
+    case 2: return launch16<1, 7, 4, 1, false>(p, M, splits, s);
+    case 3: return launch16<1, 1, 2, 2, false>(p, M, splits, s);
+    case 4: return launch16<1, 7, 8, 1, false>(p, M, splits, s);
     default: return CS_EINVAL;
   }
 }

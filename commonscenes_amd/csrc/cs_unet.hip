@@ -485,24 +485,26 @@ struct Exec {
     const int64_t mo = (int64_t)nb * dout * hout * wout;
     const int ocols = act == CS_ACT_GEGLU ? g.cout / 2 : g.cout;
     Buf out = alloc(mo, ocols);
-    if (!ok() || dry) return out;
+    if (!ok()) return out;
     if (x.c != g.cin_pad || x.rows != (int64_t)nb * d * h * w) {
       chk(CS_EINVAL);
       return out;
     }
     CsConvGemm q;
     memset(&q, 0, sizeof(q));
-    q.x = p(x);
-    q.out = p(out);
-    q.w = reinterpret_cast<const float*>(arena + g.w_off);
-    if (u.cfg.math == CS_MATH_F16X3) {
-      q.w_lo = arena + g.wlo_off;
-      q.acc_scale = g.acc_scale;
-      q.a_scale = 16.0f;
+    if (!dry) {
+      q.x = p(x);
+      q.out = p(out);
+      q.w = reinterpret_cast<const float*>(arena + g.w_off);
+      if (u.cfg.math == CS_MATH_F16X3) {
+        q.w_lo = arena + g.wlo_off;
+        q.acc_scale = g.acc_scale;
+        q.a_scale = 16.0f;
+      }
+      q.bias = g.b_off >= 0 ? wf(g.b_off) : nullptr;
+      q.rowvec = rowvec;
+      q.res = res;
     }
-    q.bias = g.b_off >= 0 ? wf(g.b_off) : nullptr;
-    q.rowvec = rowvec;
-    q.res = res;
     q.nb = nb; q.din = d; q.hin = h; q.win = w;
     q.dout = dout; q.hout = hout; q.wout = wout;
     q.cin = g.cin_pad; q.cout = g.cout;
@@ -512,7 +514,18 @@ struct Exec {
     q.pd = q.ph = q.pw = pad;
     q.ud = 0; q.uh = q.uw = up_hw;
     q.act = act; q.rv_rows = rv_rows; q.math = u.cfg.math; q.tile = tile;
-    chk(cs_conv_gemm(&q, st));
+    // small batches: few output tiles -> cut the K loop into slices (same plan function the Python host calls)
+    int32_t sk = 1;
+    int64_t wsb = 0;
+    Buf skws;
+    if (tile == 0 && cs_conv_gemm_plan(&q, &sk, &wsb) == CS_OK && sk > 1) {
+      skws = alloc(wsb / 4, 1);          // the dry run sizes the workspace with it too
+      if (!ok()) return out;
+      q.splitk = sk;
+      q.splitk_ws = dry ? nullptr : p(skws);
+    }
+    if (!dry) chk(cs_conv_gemm(&q, st));
+    release(skws);      // stream-ordered: later kernels that reuse the region run after the reduce
     return out;
   }
   Buf linear(const Buf& x, int gi, int act = CS_ACT_NONE, const float* rowvec = nullptr, int ldrv = 0,

@@ -16,7 +16,7 @@ import torch  # noqa: F401
 
 from .build import LIB_PATH
 
-ABI_VERSION = 3      # cs_abi_version() of the library this module's SIGNATURES table describes
+ABI_VERSION = 4      # cs_abi_version() of the library this module's SIGNATURES table describes
 CS_OK = 0
 CS_EINVAL = -22
 CS_ENOMEM = -12
@@ -45,7 +45,8 @@ class CsConvGemm(C.Structure):
         ("ud", C.c_int32), ("uh", C.c_int32), ("uw", C.c_int32),
         ("act", C.c_int32), ("rv_rows", C.c_int32), ("math", C.c_int32), ("tile", C.c_int32),
         ("w_lo", C.c_void_p), ("acc_scale", C.c_float), ("a_scale", C.c_float),
-        ("x_lo", C.c_void_p), ("a_format", C.c_int32), ("reserved", C.c_int32),
+        ("x_lo", C.c_void_p), ("a_format", C.c_int32), ("splitk", C.c_int32),
+        ("splitk_ws", C.c_void_p),
     ]
 
 
@@ -64,6 +65,7 @@ _pp = C.POINTER(C.c_void_p)
 # name -> (restype, argtypes); must list every symbol declared in include/commonscenes_hip.h
 SIGNATURES = {
     "cs_conv_gemm": (_i, [C.POINTER(CsConvGemm), _s]),
+    "cs_conv_gemm_plan": (_i, [C.POINTER(CsConvGemm), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "cs_conv3d_3x3x3_s111": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _s]),
     "cs_conv3d_3x3x3_s122": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _s]),
     "cs_gemm_tokens": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _s]),

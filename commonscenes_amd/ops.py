@@ -232,18 +232,30 @@ def conv_gemm(x: Tensor, w: PackedWeight, *, spatial: Optional[Tuple[int, int, i
     p.pd, p.ph, p.pw = pd, ph, pw
     p.ud, p.uh, p.uw = up
     p.act, p.rv_rows, p.math, p.tile = act, rv_rows, math, tile
+    lib = L.load()
+    if math == L.MATH_F16X3 and tile == 0 and SPLITK:
+        # few output tiles (small batches): let the library cut the K loop into slices; the partial tiles live in a
+        # scratch tensor that the stream-ordered allocator may reuse as soon as this call's kernels are queued
+        sk, wsb = C.c_int32(1), C.c_int64(0)
+        L.check(lib.cs_conv_gemm_plan(C.byref(p), C.byref(sk), C.byref(wsb)), "cs_conv_gemm_plan")
+        if sk.value > 1:
+            ws = torch.empty((wsb.value // 4,), dtype=torch.float32, device=x.device)
+            p.splitk, p.splitk_ws = sk.value, ws.data_ptr()
     prof = GEMM_PROFILE
     if prof is not None:
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
-    L.check(L.load().cs_conv_gemm(C.byref(p), _stream()), "cs_conv_gemm")
+    L.check(lib.cs_conv_gemm(C.byref(p), _stream()), "cs_conv_gemm")
     if prof is not None:
         e1.record()
         prof.append(dict(e0=e0, e1=e1, flops=2.0 * mo * w.cout * w.cin * kd * kh * kw, taps=kd * kh * kw,
                          m=mo, n=w.cout, k=w.cin * kd * kh * kw, tile=tile_for(mo, w.cout, tile, w.math)))
     return out
 
+
+# Split-K for GEMMs with few output tiles (cs_conv_gemm_plan decides); CS_NO_SPLITK=1 turns it off (A/B runs).
+SPLITK = not os.environ.get("CS_NO_SPLITK")
 
 # Set to a list to collect one record per GEMM launch (HIP events on the launch stream): bench.py uses this
 # to measure the dominant kernel's achieved TFLOP/s inside the timed region.

@@ -93,10 +93,20 @@ typedef struct CsConvGemm {
    * both [rows][lda] halves holding value * a_scale (written by cs_groupnorm_apply_split16); cin, lda % 8 == 0. */
   const void* x_lo;
   int32_t a_format;
-  int32_t reserved;
+  /* Split-K (CS_MATH_F16X3, 224-column tiles): splitk > 1 cuts the K loop (taps x channel chunks) into that many
+   * slices, one workgroup each, so a GEMM with few output tiles (small batches: 12 tiles at one object's 256-voxel
+   * level) still fills the 256 CUs.  Slices write fp32 partial tiles to splitk_ws ([splitk][M][cout] floats,
+   * caller-owned, 16-byte aligned); a second kernel adds them in slice order -- deterministic -- and applies the
+   * epilogue.  0 or 1 = off.  cs_conv_gemm_plan proposes the value. */
+  int32_t splitk;
+  void* splitk_ws;
 } CsConvGemm;
 
 int cs_conv_gemm(const CsConvGemm* desc, cs_stream_t stream);
+
+/* The split-K factor cs_conv_gemm's heuristic would pick for this descriptor (1 = none) and the workspace it then
+ * needs; host-only, no device work.  A caller that wants it sets desc->splitk / desc->splitk_ws accordingly. */
+int cs_conv_gemm_plan(const CsConvGemm* desc, int32_t* splitk, int64_t* splitk_ws_bytes);
 
 /* Convenience entries named in SURVEY.md section 8b (thin wrappers over cs_conv_gemm). */
 int cs_conv3d_3x3x3_s111(const float* x, const float* w, const float* bias, float* out,

@@ -228,3 +228,51 @@ def test_f16x3_presplit_activation_path(shape, cin, cout, tile, monkeypatch):
     out = ops.conv_gemm(hn, ops.pack_weight(wt.cuda(), bias.cuda(), math=L.MATH_F16X3), tile=tile)
     torch.cuda.synchronize()
     assert rel_l2(out, ref) < 2e-6
+
+
+@pytest.mark.parametrize("nb,shape,cin,cout,k,extras", [
+    (2, (16, 4, 4), 672, 672, 3, True),      # one object's 256-voxel level: 12 output tiles -> 22 K slices
+    (2, (16, 8, 8), 448, 448, 3, False),
+    (1, (4, 8, 8), 224, 224, 3, True),
+    (3, (1, 1, 170), 672, 224, 1, True),     # linear, ragged M
+])
+def test_f16x3_splitk_matches_fp64_and_unsplit(nb, shape, cin, cout, k, extras):
+    """cs_conv_gemm_plan proposes K slices for GEMMs with few output tiles; the sliced result (partials summed in
+    slice order + epilogue in the reduce kernel) stays fp32-grade and within rounding of the unsplit kernel."""
+    import ctypes as C
+    from commonscenes_amd import lib as L, ops
+    from oracle import ref_ops as R
+    d, h, w = shape
+    x = _rand(nb, d, h, w, cin, seed=71)
+    wt = _rand(cout, cin, k, k, k, seed=72, scale=(cin * k ** 3) ** -0.5)
+    b = _rand(cout, seed=73)
+    m = nb * d * h * w
+    res = _rand(nb, d, h, w, cout, seed=74) if extras else None
+    rv = _rand(nb, cout, seed=75) if extras else None
+    ref = R.conv_ndhwc(x.double(), wt.double(), b.double())
+    if extras:
+        ref = torch.nn.functional.silu(ref + rv.double().view(nb, 1, 1, 1, cout)) + res.double()
+    pw = ops.pack_weight(wt.cuda(), b.cuda(), math=L.MATH_F16X3)
+    kw = dict(act=L.ACT_SILU, rowvec=rv.cuda(), rv_rows=d * h * w, res=res.cuda()) if extras else {}
+    xd = x.cuda()
+    assert ops.SPLITK
+    split = ops.conv_gemm(xd, pw, **kw)
+    ops.SPLITK = False
+    try:
+        whole = ops.conv_gemm(xd, pw, **kw)
+    finally:
+        ops.SPLITK = True
+    torch.cuda.synchronize()
+    # the plan really split this shape
+    p = L.CsConvGemm()
+    p.nb, p.dout, p.hout, p.wout, p.cin, p.cout, p.kd, p.kh, p.kw, p.math = nb, d, h, w, cin, cout, k, k, k, L.MATH_F16X3
+    sk, wsb = C.c_int32(), C.c_int64()
+    assert L.load().cs_conv_gemm_plan(C.byref(p), C.byref(sk), C.byref(wsb)) == 0
+    assert sk.value > 1 and wsb.value == sk.value * m * cout * 4
+    assert torch.isfinite(split).all()
+    assert rel_l2(split, ref) < 2e-6
+    assert rel_l2(split, whole) < 1.5e-6        # two fp32 summation orders over K up to 18144
+    # deterministic: same bits on a second run
+    again = ops.conv_gemm(xd, pw, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(split, again)
