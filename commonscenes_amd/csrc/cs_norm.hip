@@ -29,12 +29,25 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
   if (rl < rowlanes) {
     for (int c4 = cl; c4 < ch4; c4 += tpr) {
       double s0 = 0, s1 = 0, s2 = 0, s3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
-      for (int r = r0 + rl; r < r1; r += rowlanes) {
-        const float4 v = *reinterpret_cast<const float4*>(xb + (int64_t)r * ldx + c4 * 4);
-        s0 += v.x; q0 += (double)v.x * v.x;
-        s1 += v.y; q1 += (double)v.y * v.y;
-        s2 += v.z; q2 += (double)v.z * v.z;
-        s3 += v.w; q3 += (double)v.w * v.w;
+      // four rows' loads in flight per thread (one 16-byte load per iteration left the kernel at ~45 % of the HBM
+      // rate: too few bytes in flight per CU); the accumulation order is unchanged
+      for (int r = r0 + rl; r < r1; r += 4 * rowlanes) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int rr = r + u * rowlanes;
+          v[u] = rr < r1 ? *reinterpret_cast<const float4*>(xb + (int64_t)rr * ldx + c4 * 4)
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (r + u * rowlanes < r1) {
+            s0 += v[u].x; q0 += (double)v[u].x * v[u].x;
+            s1 += v[u].y; q1 += (double)v[u].y * v[u].y;
+            s2 += v[u].z; q2 += (double)v[u].z * v[u].z;
+            s3 += v[u].w; q3 += (double)v[u].w * v[u].w;
+          }
+        }
       }
       double* d = sm + ((int64_t)rl * c + c4 * 4) * 2;
       d[0] = s0; d[1] = q0; d[2] = s1; d[3] = q1; d[4] = s2; d[5] = q2; d[6] = s3; d[7] = q3;
@@ -56,53 +69,91 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
   }
 }
 
-__global__ void gn_finalize_kernel(const double* __restrict__ partial, int nsplit, int groups,
-                                   double count, float eps, float* __restrict__ stats, int total) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // n*groups + g
+// One wave per (sample, group): lanes take the row-slice partials in a strided fashion and a fixed butterfly
+// combines them, so the result does not depend on scheduling (the serial version walked up to 256 dependent
+// loads per thread: 17-27 us for what is a few KB of data).
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ partial, int nsplit, int groups,
+                                                          double count, float eps, float* __restrict__ stats,
+                                                          int total) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);  // n*groups + g
   if (i >= total) return;
   const int n = i / groups, g = i - n * groups;
   double s = 0, q = 0;
-  for (int k = 0; k < nsplit; ++k) {
+  for (int k = lane; k < nsplit; k += 64) {
     const double* d = partial + (((int64_t)n * nsplit + k) * groups + g) * 2;
     s += d[0];
     q += d[1];
   }
-  const double mean = s / count;
-  double var = q / count - mean * mean;
-  if (var < 0) var = 0;
-  stats[2 * i] = (float)mean;
-  stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o, 64);
+    q += __shfl_xor(q, o, 64);
+  }
+  if (lane == 0) {
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0) var = 0;
+    stats[2 * i] = (float)mean;
+    stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
 }
 
+// One workgroup = a run of rows of ONE sample; a thread keeps its float4 column for the whole run, so the group
+// statistics and the affine parameters of its four channels are loaded once and the row loop has no index
+// arithmetic beyond a pointer bump (the previous flat element loop spent its time in 64-bit divisions: 45 % of the
+// HBM rate).  Four rows' loads are in flight per thread.
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x,
                                                        const float* __restrict__ stats,
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta,
-                                                       float* __restrict__ y, int nb, int rows, int c,
-                                                       int ldx, int ldy, int groups, int act) {
+                                                       float* __restrict__ y, int rows, int c, int ldx, int ldy,
+                                                       int groups, int act, int rows_per_block) {
   const int ch4 = c >> 2;
   const int cpg = c / groups;
-  const int64_t total = (int64_t)nb * rows * ch4;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int c4 = (int)(i % ch4);
-    const int64_t row = i / ch4;  // n*rows + r
-    const int n = (int)(row / rows);
-    const float4 v = *reinterpret_cast<const float4*>(x + row * ldx + c4 * 4);
+  const int tpr = ch4 < 256 ? ch4 : 256;   // threads per row
+  const int rowlanes = 256 / tpr;
+  const int tid = threadIdx.x;
+  const int rl = tid / tpr;
+  const int cl = tid - rl * tpr;
+  if (rl >= rowlanes) return;
+  const int n = blockIdx.y;
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(rows, r0 + rows_per_block);
+  const float* xb = x + (int64_t)n * rows * ldx;
+  float* yb = y + (int64_t)n * rows * ldy;
+  const float* st = stats + (int64_t)n * groups * 2;
+  for (int c4 = cl; c4 < ch4; c4 += tpr) {
     const float4 g = *reinterpret_cast<const float4*>(gamma + c4 * 4);
     const float4 b = *reinterpret_cast<const float4*>(beta + c4 * 4);
-    float in[4] = {v.x, v.y, v.z, v.w};
     const float gg[4] = {g.x, g.y, g.z, g.w};
     const float bb[4] = {b.x, b.y, b.z, b.w};
-    float o[4];
+    float mean[4], rstd[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int grp = (c4 * 4 + k) / cpg;
-      const float mean = stats[((int64_t)n * groups + grp) * 2];
-      const float rstd = stats[((int64_t)n * groups + grp) * 2 + 1];
-      o[k] = cs_act((in[k] - mean) * rstd * gg[k] + bb[k], act);
+      mean[k] = st[grp * 2];
+      rstd[k] = st[grp * 2 + 1];
     }
-    *reinterpret_cast<float4*>(y + row * ldy + c4 * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    for (int r = r0 + rl; r < r1; r += 4 * rowlanes) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int rr = r + u * rowlanes;
+        if (rr < r1) v[u] = *reinterpret_cast<const float4*>(xb + (int64_t)rr * ldx + c4 * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int rr = r + u * rowlanes;
+        if (rr < r1) {
+          const float in[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+          float o[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) o[k] = cs_act((in[k] - mean[k]) * rstd[k] * gg[k] + bb[k], act);
+          *reinterpret_cast<float4*>(yb + (int64_t)rr * ldy + c4 * 4) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+      }
+    }
   }
 }
 
@@ -196,8 +247,13 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x,
   }
 }
 
-int gn_nsplit(int rows) {
-  const int n = (rows + GN_MIN_SPLIT_ROWS - 1) / GN_MIN_SPLIT_ROWS;
+// row slices per sample: enough workgroups to fill the chip (~2048 in total) but no slice shorter than
+// GN_MIN_SPLIT_ROWS rows (each workgroup ends in a serial LDS reduction that longer slices amortise)
+int gn_nsplit(int rows, int nb) {
+  int n = (2048 + nb - 1) / nb;
+  const int cap = (rows + GN_MIN_SPLIT_ROWS - 1) / GN_MIN_SPLIT_ROWS;
+  if (n > cap) n = cap;
+  if (n < 1) n = 1;
   return n < GN_MAX_SPLITS ? n : GN_MAX_SPLITS;
 }
 
@@ -212,7 +268,7 @@ extern "C" int cs_groupnorm_stats(const float* x, int nb, int rows, int c, int l
   if (!x || !ws || !stats || nb <= 0 || rows <= 0 || c <= 0 || groups <= 0) return CS_EINVAL;
   if ((c & 3) || (ldx & 3) || ldx < c || c % groups || groups > 256) return CS_EINVAL;
   if (((uintptr_t)x & 15) || ((uintptr_t)ws & 7)) return CS_EINVAL;
-  const int nsplit = gn_nsplit(rows);
+  const int nsplit = gn_nsplit(rows, nb);
   const int rps = (rows + nsplit - 1) / nsplit;
   const int ch4 = c >> 2;
   const int tpr = ch4 < 256 ? ch4 : 256;
@@ -224,7 +280,7 @@ extern "C" int cs_groupnorm_stats(const float* x, int nb, int rows, int c, int l
                      c, ldx, groups, nsplit, rps, (double*)ws);
   CS_CHECK_LAUNCH();
   const int total = nb * groups;
-  CS_LAUNCH(gn_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, s,
+  CS_LAUNCH(gn_finalize_kernel, dim3((total + 3) / 4), dim3(256), 0, s,
                      (const double*)ws, nsplit, groups, (double)rows * (c / groups), eps, stats,
                      total);
   CS_CHECK_LAUNCH();
@@ -240,10 +296,17 @@ extern "C" int cs_groupnorm_apply(const float* x, const float* stats, const floa
   if (((uintptr_t)x & 15) || ((uintptr_t)y & 15) || ((uintptr_t)gamma & 15) ||
       ((uintptr_t)beta & 15))
     return CS_EINVAL;
-  const int64_t total = (int64_t)nb * rows * (c >> 2);
-  CS_LAUNCH(gn_apply_kernel, dim3(cs_grid_for(total, 256, 256 * 32)), dim3(256), 0,
-                     (hipStream_t)stream, x, stats, gamma, beta, y, nb, rows, c, ldx, ldy, groups,
-                     act);
+  if (nb > 65535) return CS_EINVAL;
+  // enough workgroups to fill the chip (>= ~2048 in total), each with at least 16 rows per row-lane
+  const int ch4 = c >> 2;
+  const int rowlanes = 256 / (ch4 < 256 ? ch4 : 256);
+  int blocks_per_sample = (2048 + nb - 1) / nb;
+  const int max_blocks = (rows + 16 * rowlanes - 1) / (16 * rowlanes);
+  if (blocks_per_sample > max_blocks) blocks_per_sample = max_blocks;
+  if (blocks_per_sample < 1) blocks_per_sample = 1;
+  const int rpb = (rows + blocks_per_sample - 1) / blocks_per_sample;
+  CS_LAUNCH(gn_apply_kernel, dim3((unsigned)((rows + rpb - 1) / rpb), (unsigned)nb), dim3(256), 0,
+            (hipStream_t)stream, x, stats, gamma, beta, y, rows, c, ldx, ldy, groups, act, rpb);
   CS_CHECK_LAUNCH();
   return CS_OK;
 }
