@@ -127,12 +127,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   int* rowbase = reinterpret_cast<int*>(smem + ROWBASE);
   short* delta = reinterpret_cast<short*>(smem + DELTA);
   {
+    // NT / BM threads per output row: the row's (n, od, oh, ow) decomposition -- three integer divisions -- is done
+    // once, the taps are then walked with adds and compares only
     const int vdin = p.din << p.ud, vhin = p.hin << p.uh, vwin = p.win << p.uw;
-    for (int idx = tid; idx < BM * ntaps; idx += NT) {
-      const int t = idx / BM;
-      const int row = idx - t * BM;
+    constexpr int TPR = NT / BM >= 1 ? NT / BM : 1;       // threads sharing a row (taps are dealt round-robin)
+    for (int row = tid / TPR; row < BM; row += NT / TPR) {
+      const int sub = tid % TPR;
       const int m = m0 + row;
-      short dl = INVALID;
       int mm = m < M ? m : 0;
       const int ow = mm % p.wout;
       mm /= p.wout;
@@ -145,19 +146,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
       const int ch = min(max(oh * p.sh - p.ph, 0), vhin - 1) >> p.uh;
       const int cw = min(max(ow * p.sw - p.pw, 0), vwin - 1) >> p.uw;
       const int base = ((n * p.din + cd) * p.hin + ch) * p.win + cw;
-      if (t == 0) rowbase[row] = base;
-      if (m < M) {
-        const int kd_ = t / taps_hw;
-        const int rem = t - kd_ * taps_hw;
-        const int kh_ = rem / kw_;
-        const int kwi = rem - kh_ * kw_;
-        const int vd = od * p.sd - p.pd + kd_, vh = oh * p.sh - p.ph + kh_, vw = ow * p.sw - p.pw + kwi;
-        if ((unsigned)vd < (unsigned)vdin && (unsigned)vh < (unsigned)vhin && (unsigned)vw < (unsigned)vwin) {
-          const int r = ((n * p.din + (vd >> p.ud)) * p.hin + (vh >> p.uh)) * p.win + (vw >> p.uw);
-          dl = (short)(r - base);
-        }
-      }
-      delta[idx] = dl;
+      if (sub == 0) rowbase[row] = base;
+      const int vd0 = od * p.sd - p.pd, vh0 = oh * p.sh - p.ph, vw0 = ow * p.sw - p.pw;
+      int t = 0;
+      for (int kd_ = 0; kd_ < p.kd; ++kd_)
+        for (int kh_ = 0; kh_ < p.kh; ++kh_)
+          for (int kwi = 0; kwi < kw_; ++kwi, ++t) {
+            if (t % TPR != sub) continue;
+            short dl = INVALID;
+            const int vd = vd0 + kd_, vh = vh0 + kh_, vw = vw0 + kwi;
+            if (m < M && (unsigned)vd < (unsigned)vdin && (unsigned)vh < (unsigned)vhin &&
+                (unsigned)vw < (unsigned)vwin) {
+              const int r = ((n * p.din + (vd >> p.ud)) * p.hin + (vh >> p.uh)) * p.win + (vw >> p.uw);
+              dl = (short)(r - base);
+            }
+            delta[t * BM + row] = dl;
+          }
     }
   }
   __syncthreads();
