@@ -137,3 +137,9 @@ def test_unet_plan_is_host_only_and_lists_the_reference_state_dict():
     bad = L.CsUnetConfig()
     h = __import__("ctypes").c_void_p()
     assert lib.cs_unet_create(__import__("ctypes").byref(bad), __import__("ctypes").byref(h)) == L.CS_EINVAL
+
+
+def test_graft_entry_build_passes():
+    """the driver's "does it build" check: compiles (if stale), loads, resolves every symbol, checks the ABI."""
+    import __graft_entry__ as g
+    g.build()
