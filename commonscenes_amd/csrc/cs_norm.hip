@@ -5,7 +5,7 @@
 
 namespace {
 
-constexpr int GN_MIN_SPLIT_ROWS = 64;  // minimum rows handled by one statistics block
+constexpr int GN_MIN_SPLIT_ROWS = 16;  // minimum rows handled by one statistics block
 constexpr int GN_MAX_SPLITS = 256;
 
 // Pass 1: partial[n][split][g] = (sum, sumsq) in fp64.  Each thread owns fixed channel chunks so
