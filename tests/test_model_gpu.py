@@ -149,6 +149,35 @@ def test_unet_multi_token_context_path():
     assert rel_l2(out, ref) < 1e-5
 
 
+def test_unet_full_size_batch_invariance_at_benchmark_shape():
+    """Size-independent property at BASELINE's full size (32 objects, CFG batch 64, 413.5 M-parameter UNet, F16X3):
+    samples never mix (GroupNorm / LayerNorm / attention are per sample), so object i's eps inside the 32-object
+    step equals its eps in a 2-object step.  The two runs take different GEMM plans (256-row tiles vs split-K), so
+    equality is to fp32 summation-order noise, not bitwise; the 32-object run itself is deterministic."""
+    from commonscenes_amd import synth
+    df = _unet(False)
+    df.set_math("f16x3")
+    try:
+        B = 32
+        x = synth.gaussian_like("fs:x", (B, 3, 16, 16, 16)).cuda()
+        t = torch.full((B,), 501, dtype=torch.long).cuda()
+        uc = synth.gaussian_like("fs:uc", (B, 1, 1280)).cuda()
+        c = synth.gaussian_like("fs:c", (B, 1, 1280)).cuda()
+        big = df.forward_cfg(x, t, torch.cat([uc, c]))
+        again = df.forward_cfg(x, t, torch.cat([uc, c]))
+        sel = [3, 29]
+        small = df.forward_cfg(x[sel], t[sel], torch.cat([uc[sel], c[sel]]))
+        torch.cuda.synchronize()
+        assert big.shape == (2 * B, 3, 16, 16, 16) and torch.isfinite(big).all()
+        assert torch.equal(big, again)
+        for k, i in enumerate(sel):
+            assert rel_l2(small[k], big[i]) < 1e-5              # uc half
+            assert rel_l2(small[2 + k], big[B + i]) < 1e-5      # c half
+        assert rel_l2(big[3], big[29]) > 1e-2                   # different objects really differ
+    finally:
+        df.set_math("fp32")
+
+
 # ---------------------------------------------------------------------------------------------------
 # UNet, concat-conditioning family (config/sdfusion-txt2shape_concat.yaml; SURVEY 8f N1)
 # ---------------------------------------------------------------------------------------------------
