@@ -27,6 +27,11 @@ from .sdfusion import SDFusionText2ShapeModel, load_yaml
 Tensor = torch.Tensor
 
 
+def _np(a):
+    """torch tensors (collect_train_statistics returns the mean as one) -> numpy, same values, for numpy's RNG calls."""
+    return a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a
+
+
 # ------------------------------------------------------------------------------------------------
 # parameter tables
 # ------------------------------------------------------------------------------------------------
@@ -263,7 +268,7 @@ class BoxVAEMixin:
             nodes_added.append(ad_id)
             if distribution is not None:
                 mu, cov = distribution
-                new = torch.from_numpy(np.random.multivariate_normal(mu, cov, 1)).float()
+                new = torch.from_numpy(np.random.multivariate_normal(_np(mu), _np(cov), 1)).float()
             else:
                 new = torch.zeros(1, width)
             z = torch.cat([z[:ad_id], new.to(self.device), z[ad_id:]], dim=0)
@@ -491,7 +496,7 @@ class Sg2ScVAEModel(BoxVAEMixin):
         if encoded_dec_text_feat is None or encoded_dec_rel_feat is None:
             raise ValueError("sampleBoxes needs the CLIP text / relation features (clip=True)")
         if z is None:
-            z = torch.from_numpy(np.random.multivariate_normal(mean_est, cov_est, dec_objs.size(0))).float()
+            z = torch.from_numpy(np.random.multivariate_normal(_np(mean_est), _np(cov_est), dec_objs.size(0))).float()
         return self.decoder(z, dec_objs, dec_triplets, encoded_dec_text_feat, encoded_dec_rel_feat, attributes)
 
     @torch.no_grad()
@@ -502,7 +507,7 @@ class Sg2ScVAEModel(BoxVAEMixin):
         draws z from numpy's global RNG and x_T from a time-seeded torch RNG)."""
         dev = self.device
         if z is None:
-            z = torch.from_numpy(np.random.multivariate_normal(mean_est, cov_est, dec_objs.size(0))).float()
+            z = torch.from_numpy(np.random.multivariate_normal(_np(mean_est), _np(cov_est), dec_objs.size(0))).float()
         z = z.to(dev)
         text = encoded_dec_text_feat.to(device=dev, dtype=torch.float32)
         rel = encoded_dec_rel_feat.to(device=dev, dtype=torch.float32)

@@ -25,7 +25,7 @@ import torch
 
 from . import lib as L
 from . import ops
-from .scene import BoxVAEMixin, GraphTripleConvNet, _MLP, _gcn_shapes, _mlp_shapes
+from .scene import BoxVAEMixin, _np, GraphTripleConvNet, _MLP, _gcn_shapes, _mlp_shapes
 
 Tensor = torch.Tensor
 
@@ -161,5 +161,5 @@ class Sg2ScVAEModel(BoxVAEMixin):
                     attributes=None, z: Optional[Tensor] = None):
         """VAEGAN_V2BOX.py:456-461.  Extension: `z` can be injected (the reference draws it from numpy's RNG)."""
         if z is None:
-            z = torch.from_numpy(np.random.multivariate_normal(mean_est, cov_est, dec_objs.size(0))).float()
+            z = torch.from_numpy(np.random.multivariate_normal(_np(mean_est), _np(cov_est), dec_objs.size(0))).float()
         return self.decoder(z, dec_objs, dec_triplets, encoded_dec_text_feat, encoded_dec_rel_feat, attributes)

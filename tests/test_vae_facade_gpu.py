@@ -1,0 +1,109 @@
+"""`commonscenes_amd.vae.VAE` (the object scripts/eval_3dfront.py builds, model/VAE.py) over the HIP models:
+checkpoint layout round trip, statistics cache, and that its calls are the underlying models' calls."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+VOCAB = dict(object_idx_to_name=[f"obj{i}\n" for i in range(35)], pred_idx_to_name=[f"pred{i}\n" for i in range(16)],
+             object_idx_to_name_grained=[f"objg{i}\n" for i in range(35)])
+
+
+def _loader(n_batches=3, seed=3):
+    from commonscenes_amd import synth
+    out = []
+    for b in range(n_batches):
+        g = synth.random_scene_graph(5 + b, seed=seed + b)
+        O = g["objs"].shape[0]
+        boxes = torch.cat([synth.gaussian_like(f"st:{b}", (O, 6)), torch.randint(0, 24, (O, 1)).float()], dim=1)
+        out.append({"decoder": {"objs": g["objs"], "tripltes": g["triples"], "boxes": boxes,
+                                "text_feats": g["text_feats"], "rel_feats": g["rel_feats"]}})
+    return out
+
+
+def test_v2_box_facade(tmp_path):
+    from commonscenes_amd import synth
+    from commonscenes_amd.scene_box import box_param_shapes
+    from commonscenes_amd.vae import VAE
+    (tmp_path / "checkpoint").mkdir()
+    sd = synth.synth_state_dict(box_param_shapes(35, 16))
+    torch.save(sd, tmp_path / "checkpoint" / "model_box_7.pth")
+    m = VAE(type="v2_box", vocab=VOCAB, replace_latent=True, with_angles=True, residual=True)
+    m.load_networks(str(tmp_path), 7)
+    m.compute_statistics(str(tmp_path), 7, _loader())
+    assert (tmp_path / "checkpoint" / "model_stats_box_7.pkl").exists()
+    mean, cov = m.mean_est_box, m.cov_est_box
+    assert tuple(mean.shape) == (64,) and cov.shape == (64, 64) and np.isfinite(cov).all()
+    m2 = VAE(type="v2_box", vocab=VOCAB, replace_latent=True, with_angles=True, residual=True)
+    m2.load_networks(str(tmp_path), 7)
+    m2.compute_statistics(str(tmp_path), 7, None)            # served from the pickle
+    assert torch.equal(torch.as_tensor(m2.mean_est_box), torch.as_tensor(mean))
+    g = synth.random_scene_graph(6, seed=21)
+    np.random.seed(4)
+    boxes, shapes = m.sample_box_and_shape(None, g["objs"], g["triples"], None, g["text_feats"], g["rel_feats"])
+    np.random.seed(4)
+    ref = m.vae_box.sampleBoxes(mean, cov, g["objs"], g["triples"], g["text_feats"], g["rel_feats"])
+    torch.cuda.synchronize()
+    assert shapes is None and torch.equal(boxes[0], ref[0]) and torch.equal(boxes[1], ref[1])
+    mu, logvar = m.encode_box(g["objs"], g["triples"], g["text_feats"], g["rel_feats"],
+                              synth.gaussian_like("vb:b", (8, 6)), torch.zeros(8, dtype=torch.long))
+    assert mu.shape == (8, 64) and torch.isfinite(mu).all() and torch.isfinite(logvar).all()
+    with pytest.raises(NotImplementedError):
+        VAE(type="v1_box", vocab=VOCAB)
+
+
+def test_v2_full_facade_checkpoint_and_sample(tmp_path):
+    import yaml
+    from commonscenes_amd import synth
+    from commonscenes_amd.scene import scene_param_shapes
+    from commonscenes_amd.unet import unet_param_shapes
+    from commonscenes_amd.vae import VAE
+    from commonscenes_amd.vqvae import vqvae_param_shapes
+    from oracle.ref_torch import UNET_SMALL, VQ_FULL
+    ucfg = dict(UNET_SMALL, dims=3, use_spatial_transformer=True)
+    df_yaml = dict(model=dict(params=dict(linear_start=0.00085, linear_end=0.012, conditioning_key="crossattn",
+                                          timesteps=1000)),
+                   unet=dict(params={k: (list(v) if isinstance(v, tuple) else v) for k, v in ucfg.items()}))
+    vq_yaml = dict(model=dict(params=dict(embed_dim=3, n_embed=8192, ddconfig=dict(
+        double_z=False, z_channels=3, resolution=64, in_channels=1, out_ch=1, ch=64, ch_mult=[1, 2, 4],
+        num_res_blocks=1, attn_resolutions=[], dropout=0.0))))
+    (tmp_path / "df.yaml").write_text(yaml.safe_dump(df_yaml))
+    (tmp_path / "vq.yaml").write_text(yaml.safe_dump(vq_yaml))
+    opt = dict(hyper=dict(device="cuda", batch_size=4), network=dict(df_cfg=str(tmp_path / "df.yaml"),
+                                                                      vq_cfg=str(tmp_path / "vq.yaml"), vq_ckpt=None),
+               misc=dict(seed=111))
+    # a checkpoint in the reference's layout (VAEGAN_V2FULL.py:687-699): scene tensors + 'vqvae' + 'df' + 'opt' + counters
+    ck = dict(synth.synth_state_dict(scene_param_shapes(35, 16)))
+    ck["vqvae"] = synth.synth_state_dict(vqvae_param_shapes(VQ_FULL, 8192, 3))
+    ck["df"] = synth.synth_state_dict(unet_param_shapes(ucfg))
+    ck.update(opt={}, epoch=12, counter=3456)
+    (tmp_path / "checkpoint").mkdir()
+    torch.save(ck, tmp_path / "checkpoint" / "model12.pth")
+    m = VAE(type="v2_full", diff_opt=opt, vocab=VOCAB, replace_latent=True, with_changes=True, residual=True,
+            with_angles=True, clip=True, with_E2=True)
+    m.load_networks(str(tmp_path), 12)
+    assert m.epoch == 12 and m.counter == 3456
+    m.compute_statistics(str(tmp_path), 12, _loader())
+    g = synth.random_scene_graph(4, seed=23)
+    O = g["objs"].shape[0]
+    dec_sdfs = torch.zeros(O, 1, 4, 4, 4)
+    dec_sdfs[:4] = 1.0
+    x_T = synth.gaussian_like("vf:x", (1, 3, 16, 16, 16))
+    np.random.seed(8)
+    boxes, sdf = m.sample_box_and_shape(None, g["objs"], g["triples"], dec_sdfs, g["text_feats"], g["rel_feats"],
+                                        gen_shape=True, x_T=x_T, ddim_steps=2)
+    np.random.seed(8)
+    ref_boxes, ref_sdf = m.vae_v2.sample(None, m.mean_est, m.cov_est, g["objs"], g["triples"], dec_sdfs,
+                                         g["text_feats"], g["rel_feats"], gen_shape=True, x_T=x_T, ddim_steps=2)
+    torch.cuda.synchronize()
+    assert sdf.shape == (4, 1, 64, 64, 64) and torch.isfinite(sdf).all()
+    assert torch.equal(sdf, ref_sdf) and torch.equal(boxes[0], ref_boxes[0])
+    # save() writes the same layout back
+    m.save(str(tmp_path), "checkpoint", 13, counter=1)
+    back = torch.load(tmp_path / "checkpoint" / "model13.pth", map_location="cpu")
+    assert "df" in back and "vqvae" in back and back["epoch"] == 13
+    k = "gconv_net_ec_rel.gconvs.0.net1.0.weight"
+    assert rel_l2(back[k], ck[k]) == 0.0
