@@ -4,7 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from commonscenes_amd import lib as L, ops, synth
-B = 64
+B = int(os.environ.get("KS_BATCH", "64"))
 pts = []
 for taps in (3, 1):
     for cin in (16, 32, 64, 128, 224, 448, 672):
