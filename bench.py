@@ -48,7 +48,9 @@ def parse():
     ap.add_argument("--objects", type=int, default=32, help="objects per GPU (BASELINE metric: 32)")
     ap.add_argument("--ddim-steps", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-objects", type=int, default=4, help="objects in the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-objects", type=int, default=7,
+                    help="objects in the bounded CPU-baseline sample (7 = the reference's sampler mini-batch, "
+                         "sdfusion_txt2shape_model.py:493)")
     ap.add_argument("--math", choices=["fp32", "f16x3"], default=os.environ.get("CS_MATH", "f16x3"),
                     help="GEMM numerics: fp32-input MFMA, or fp32 carried as fp16 hi/lo pairs on the fp16 MFMA")
     ap.add_argument("--driver", choices=["python", "native"], default="python",
