@@ -438,6 +438,32 @@ def test_sample_end_to_end_vs_reference_golden(tmp_path, concat):
     assert rel_l2(gen[7], torch.from_numpy(g["gen_sdf_obj7"])) < 1e-2
 
 
+def test_sample_end_to_end_full_width_vs_reference_golden(tmp_path):
+    """The whole path at the SHIPPED width (413.5 M-parameter UNet, full VQ-VAE decoder) against the reference:
+    Sg2ScVAEModel.sample(gen_shape=True), 8 shaped objects (mini-batches 7 + 1), 2 DDIM steps, F16X3 GEMMs."""
+    g = _g("e2e_full")
+    m = _scene(tmp_path, small=False)
+    m.Diff.df.set_math("f16x3")
+    m.Diff.vqvae.set_math("f16x3")
+    O = g["objs"].shape[0]
+    dec_sdfs = torch.zeros(O, 1, 4, 4, 4)
+    dec_sdfs[torch.from_numpy(g["dec_sdfs_nonzero"])] = 1.0
+    m.Diff.mini_B = 7
+    lat = []
+    dnq = m.Diff.vqvae.decode_no_quant
+    m.Diff.vqvae.decode_no_quant = m.Diff.vqvae_module.decode_no_quant = lambda h, *a, **k: (lat.append(h.clone()), dnq(h, *a, **k))[1]
+    boxes, gen = m.sample(None, np.zeros(64), np.eye(64), torch.from_numpy(g["objs"]), torch.from_numpy(g["triples"]),
+                          dec_sdfs, torch.from_numpy(g["text_feats"]), torch.from_numpy(g["rel_feats"]),
+                          gen_shape=True, z=torch.from_numpy(g["z"]), x_T=torch.from_numpy(g["x_T"]), ddim_steps=2)
+    torch.cuda.synchronize()
+    assert gen.shape == (8, 1, 64, 64, 64) and torch.isfinite(gen).all()
+    assert rel_l2(torch.cat(lat, 0), torch.from_numpy(g["latents"])) < 1e-4          # k-step DDIM latent gate
+    assert rel_l2(boxes[0], torch.from_numpy(g["boxes"])) < 3e-6
+    sub, ref = gen[:, :, ::2, ::2, ::2], torch.from_numpy(g["gen_sdf_sub"])
+    per_obj = sorted(rel_l2(sub[i], ref[i]) for i in range(8))
+    assert per_obj[5] < 1e-4, per_obj                     # SDF gate given equal code indices (flips: SURVEY F8)
+
+
 def test_v2full_manipulation_surface_vs_reference_golden(tmp_path):
     """encoder / decoder_with_changes (gen_shape=True, 2 DDIM steps) / decoder_with_additions of the v2_full model
     (VAEGAN_V2FULL.py:185-218, 291-396) with numpy's RNG seeded like the generator."""

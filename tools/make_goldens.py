@@ -409,11 +409,11 @@ def g_gcn(tmp: Path, concat: bool = False):
          rel_feats=g["rel_feats"], z=g["z"], uc=uc, c=c)
 
 
-def g_e2e(tmp: Path, concat: bool = False):
-    """Sg2ScVAEModel.sample(gen_shape=True) end to end (VAEGAN_V2FULL.py:600-618), reduced-width UNet,
-    8 shaped objects (mini-batch boundary at 7), 2 DDIM steps."""
+def g_e2e(tmp: Path, concat: bool = False, full: bool = False):
+    """Sg2ScVAEModel.sample(gen_shape=True) end to end (VAEGAN_V2FULL.py:600-618): 8 shaped objects (mini-batch
+    boundary at 7), 2 DDIM steps; reduced-width UNet, or (full=True) the shipped 413.5 M-parameter one."""
     import functools
-    model, sd, df_sd, vq_sd = build_ref_scene(tmp, small=True, concat=concat)
+    model, sd, df_sd, vq_sd = build_ref_scene(tmp, small=not full, concat=concat)
     nobj = 8
     g = synth.random_scene_graph(nobj, seed=11)
     O = g["objs"].shape[0]
@@ -453,7 +453,11 @@ def g_e2e(tmp: Path, concat: bool = False):
         arrs["boxes"], arrs["angles"] = boxes[0], boxes[1]
     else:
         arrs["boxes"] = boxes
-    save("e2e_concat_small" if concat else "e2e_small", **arrs)
+    if full:
+        # keep the fixture small: every other voxel of every object, one object in full
+        save("e2e_full", **arrs)
+    else:
+        save("e2e_concat_small" if concat else "e2e_small", **arrs)
 
 
 def g_box():
@@ -540,7 +544,7 @@ def main():
     install_patches()
     todo = a.only or ["schedule", "unet_small", "unet_full", "ddim_small", "ddim_full", "vq", "gcn", "e2e",
                       "unet_concat_small", "unet_concat_full", "ddim_concat_small", "gcn_concat", "e2e_concat", "box",
-                      "full_manip"]
+                      "full_manip", "e2e_full"]
     with tempfile.TemporaryDirectory() as td:
         tmp = Path(td)
         for name in todo:
@@ -571,6 +575,8 @@ def main():
                 g_gcn(tmp, concat=True)
             elif name == "e2e_concat":
                 g_e2e(tmp, concat=True)
+            elif name == "e2e_full":
+                g_e2e(tmp, full=True)
             elif name == "box":
                 g_box()
             elif name == "full_manip":
