@@ -53,7 +53,7 @@ struct Norm {
   int64_t g_off, b_off;
 };
 
-enum Kind { CONV_IN, RES, ATTN, DOWN, UP };
+enum Kind { CONV_IN, RES, ATTN, ATTNBLOCK, DOWN, UP };
 
 struct Layer {
   Kind kind;
@@ -218,6 +218,31 @@ Layer make_attn(cs_unet& u, const std::string& p, int c, int ctx_dim, bool f16x3
   return l;
 }
 
+// AttentionBlock (openai_model_3d.py:316-366; the concat family, use_spatial_transformer=False): GroupNorm ->
+// Conv1d(k=1) qkv -> QKVAttentionLegacy -> Conv1d(k=1) proj_out + x.  The legacy module reads the 3C qkv channels
+// as [head][q|k|v][ch]; the packed weight's rows are gathered as [q|k|v][head][ch] instead, so q, k, v are plain
+// column slices for the flash kernel (same permutation as unet.py::_pack).
+Layer make_attnblock(cs_unet& u, const std::string& p, int c, int heads) {
+  Layer l{};
+  l.kind = ATTNBLOCK;
+  l.cin = l.cout = c;
+  l.n[0] = add_norm(u, p + ".norm", c);
+  const int wq = add_param(u, p + ".qkv.weight", {3 * c, c, 1});
+  const int bq = add_param(u, p + ".qkv.bias", {3 * c});
+  const int ch = c / heads;
+  std::vector<Piece> w, b;
+  for (int j = 0; j < 3; ++j)
+    for (int h = 0; h < heads; ++h) {
+      w.push_back({wq, h * 3 * ch + j * ch, ch});
+      b.push_back({bq, h * 3 * ch + j * ch, ch});
+    }
+  l.g[0] = add_gemm(u, w, b, 3 * c, c, 0);
+  const int wo = add_param(u, p + ".proj_out.weight", {c, c, 1});
+  const int bo = add_param(u, p + ".proj_out.bias", {c});
+  l.g[1] = add_gemm(u, {{wo, 0, c}}, {{bo, 0, c}}, c, c, 0);
+  return l;
+}
+
 bool in_list(const int32_t* v, int n, int x) {
   for (int i = 0; i < n; ++i)
     if (v[i] == x) return true;
@@ -227,12 +252,18 @@ bool in_list(const int32_t* v, int n, int x) {
 int build(cs_unet& u) {
   const CsUnetConfig& c = u.cfg;
   if (c.model_channels <= 0 || c.model_channels % 32 || c.num_res_blocks <= 0 || c.n_mult <= 0 || c.n_mult > 8 ||
-      c.n_attn_res < 0 || c.n_attn_res > 8 || c.num_heads <= 0 || c.context_dim <= 0 || c.in_channels <= 0 ||
+      c.n_attn_res < 0 || c.n_attn_res > 8 || c.num_heads <= 0 || c.in_channels <= 0 ||
+      (c.use_spatial_transformer && c.context_dim <= 0) || (c.dims != 3 && c.dims != 4) ||
       c.out_channels <= 0 || c.d <= 0 || c.h <= 0 || c.w <= 0)
     return CS_EINVAL;
   if (c.math != CS_MATH_FP32 && c.math != CS_MATH_F16X3) return CS_EINVAL;
   if ((c.h >> (c.n_mult - 1)) << (c.n_mult - 1) != c.h || (c.w >> (c.n_mult - 1)) << (c.n_mult - 1) != c.w)
     return CS_EINVAL;
+  if (c.dims == 4 && (c.d >> (c.n_mult - 1)) << (c.n_mult - 1) != c.d) return CS_EINVAL;
+  auto attn_layer = [&](const std::string& q, int chn) {
+    return c.use_spatial_transformer ? make_attn(u, q, chn, c.context_dim, c.math == CS_MATH_F16X3)
+                                     : make_attnblock(u, q, chn, c.num_heads);
+  };
   const bool f16 = c.math == CS_MATH_F16X3;
   const int mc = c.model_channels, ted = 4 * mc, nres = c.num_res_blocks;
   const std::string P = "diffusion_net.";
@@ -262,7 +293,7 @@ int build(cs_unet& u) {
       ch = m * mc;
       if (ch % c.num_heads) return CS_EINVAL;
       if (in_list(c.attention_resolutions, c.n_attn_res, ds))
-        layers.push_back(make_attn(u, bp + ".1", ch, c.context_dim, f16));
+        layers.push_back(attn_layer(bp + ".1", ch));
       u.inp.push_back(layers);
       chans.push_back(ch);
     }
@@ -278,7 +309,7 @@ int build(cs_unet& u) {
     }
   }
   u.mid.push_back(make_res(u, P + "middle_block.0", ch, ch, ted, emb));
-  u.mid.push_back(make_attn(u, P + "middle_block.1", ch, c.context_dim, f16));
+  u.mid.push_back(attn_layer(P + "middle_block.1", ch));
   u.mid.push_back(make_res(u, P + "middle_block.2", ch, ch, ted, emb));
   int oi = 0;
   for (int level = c.n_mult - 1; level >= 0; --level) {
@@ -291,7 +322,7 @@ int build(cs_unet& u) {
       layers.push_back(make_res(u, bp + ".0", ch + ich, mc * m, ted, emb));
       ch = mc * m;
       if (in_list(c.attention_resolutions, c.n_attn_res, ds))
-        layers.push_back(make_attn(u, bp + ".1", ch, c.context_dim, f16));
+        layers.push_back(attn_layer(bp + ".1", ch));
       if (level && i == nres) {
         Layer l{};
         l.kind = UP;
@@ -475,11 +506,11 @@ struct Exec {
   // conv (k^3 taps, stride (1,s,s), nearest upsample (0,up,up)) or pointwise/linear GEMM with the fused epilogue
   Buf gemm(const Buf& x, int gi, int nb, int d, int h, int w, int s_hw = 1, int up_hw = 0, int act = CS_ACT_NONE,
            const float* rowvec = nullptr, int ldrv = 0, int rv_rows = 1, const float* res = nullptr, int ldr = 0,
-           int tile = 0) {
+           int tile = 0, int s_d = 1, int up_d = 0) {
     const Gemm& g = u.gemms[gi];
     const int k = g.k, pad = k / 2;
     const int vh = h << up_hw, vw = w << up_hw;
-    const int dout = (d + 2 * pad - k) + 1;
+    const int dout = ((d << up_d) + 2 * pad - k) / s_d + 1;
     const int hout = (vh + 2 * pad - k) / s_hw + 1;
     const int wout = (vw + 2 * pad - k) / s_hw + 1;
     const int64_t mo = (int64_t)nb * dout * hout * wout;
@@ -510,9 +541,9 @@ struct Exec {
     q.cin = g.cin_pad; q.cout = g.cout;
     q.lda = x.c; q.ldw = g.ldw; q.ldo = ocols; q.ldr = res ? ldr : 0; q.ldrv = rowvec ? ldrv : 0;
     q.kd = q.kh = q.kw = k;
-    q.sd = 1; q.sh = q.sw = s_hw;
+    q.sd = s_d; q.sh = q.sw = s_hw;
     q.pd = q.ph = q.pw = pad;
-    q.ud = 0; q.uh = q.uw = up_hw;
+    q.ud = up_d; q.uh = q.uw = up_hw;
     q.act = act; q.rv_rows = rv_rows; q.math = u.cfg.math; q.tile = tile;
     // small batches: few output tiles -> cut the K loop into slices (same plan function the Python host calls)
     int32_t sk = 1;
@@ -615,6 +646,27 @@ struct Exec {
     return o;
   }
 
+  Act attnblock(const Layer& l, const Act& x) {
+    const int c = l.cin, heads = u.cfg.num_heads, dh = c / heads;
+    const int n = x.d * x.h * x.w;
+    const int64_t rows = (int64_t)x.nb * n;
+    Buf xn = groupnorm(x.b, l.n[0], x.nb, 1e-5f, CS_ACT_NONE);
+    Buf qkv = linear(xn, l.g[0]);
+    release(xn);
+    Buf a = alloc(rows, c);
+    if (ok() && !dry) {
+      const float scale = (float)std::pow((double)dh, -0.5);
+      const float* q = p(qkv);
+      auto fn = u.cfg.math == CS_MATH_F16X3 ? cs_attn_selfattn_f16x3 : cs_attn_selfattn;
+      chk(fn(q, q + c, q + 2 * c, p(a), x.nb, n, n, heads, dh, 3 * c, 3 * c, 3 * c, c, scale, st));
+    }
+    release(qkv);
+    Act o = x;
+    o.b = linear(a, l.g[1], CS_ACT_NONE, nullptr, 0, 1, dry ? nullptr : p(x.b), c);
+    release(a);
+    return o;
+  }
+
   // runs the layers of one block; `keep_in` says whether the caller still needs the input buffer
   Act run(const std::vector<Layer>& layers, Act h, const Buf& semb, const float* ctxvec, bool keep_in) {
     bool owned = !keep_in;
@@ -631,18 +683,27 @@ struct Exec {
         case ATTN:
           o = attn_block(l, h, ctxvec);
           break;
-        case DOWN:
+        case ATTNBLOCK:
+          o = attnblock(l, h);
+          break;
+        case DOWN: {   // dims == 3: inner two dims only (openai_model_3d.py:188); dims == 4: all three
+          const int sd = u.cfg.dims == 3 ? 1 : 2;
           o = h;
-          o.b = gemm(h.b, l.g[0], h.nb, h.d, h.h, h.w, 2, 0);
+          o.b = gemm(h.b, l.g[0], h.nb, h.d, h.h, h.w, 2, 0, CS_ACT_NONE, nullptr, 0, 1, nullptr, 0, 0, sd, 0);
+          o.d = h.d / sd;
           o.h = h.h / 2;
           o.w = h.w / 2;
           break;
-        case UP:
+        }
+        case UP: {     // nearest x2 folded into the conv's addressing (openai_model_3d.py:148-157)
+          const int ud = u.cfg.dims == 3 ? 0 : 1;
           o = h;
-          o.b = gemm(h.b, l.g[0], h.nb, h.d, h.h, h.w, 1, 1);
+          o.b = gemm(h.b, l.g[0], h.nb, h.d, h.h, h.w, 1, 1, CS_ACT_NONE, nullptr, 0, 1, nullptr, 0, 0, 1, ud);
+          o.d = h.d << ud;
           o.h = h.h * 2;
           o.w = h.w * 2;
           break;
+        }
       }
       if (owned) release(h.b);
       h = o;
@@ -665,7 +726,7 @@ struct Exec {
 
 bool has_attn(const std::vector<Layer>& layers) {
   for (const Layer& l : layers)
-    if (l.kind == ATTN) return true;
+    if (l.kind == ATTN || l.kind == ATTNBLOCK) return true;
   return false;
 }
 
@@ -873,6 +934,7 @@ extern "C" int64_t cs_unet_workspace_bytes(const cs_unet* u, int nb_x, int cfg_p
 extern "C" int cs_unet_context(const cs_unet* u, const void* arena, const float* ctx, int nb_ctx, float* ctxvec,
                                void* workspace, int64_t workspace_bytes, cs_stream_t stream) {
   if (!u || !u->packed || !arena || !ctx || !ctxvec || !workspace || nb_ctx <= 0) return CS_EINVAL;
+  if (!u->cfg.use_spatial_transformer) return CS_EINVAL;      // the concat family has no context
   Exec e(*u, arena, workspace, workspace_bytes, false, (hipStream_t)stream);
   // ctx rows are read in place: describe them as a buffer view at offset (ctx - workspace)
   auto visit = [&](const Layer& l) {
@@ -914,8 +976,11 @@ extern "C" int cs_unet_context(const cs_unet* u, const void* arena, const float*
 extern "C" int cs_unet_step(const cs_unet* u, const void* arena, const float* x_ncdhw, const int64_t* t,
                             const float* ctxvec, float* eps_ncdhw, int nb_x, int cfg_pairs, void* workspace,
                             int64_t workspace_bytes, cs_stream_t stream) {
-  if (!u || !u->packed || !arena || !x_ncdhw || !t || !ctxvec || !eps_ncdhw || !workspace || nb_x <= 0)
-    return CS_EINVAL;
+  if (!u || !u->packed || !arena || !x_ncdhw || !t || !eps_ncdhw || !workspace || nb_x <= 0) return CS_EINVAL;
+  // crossattn family: ctxvec (cs_unet_context) is required.  concat family (no transformer blocks): there is no
+  // context, x carries the condition volume as its last channel(s) (network.py:25-27) and the guidance halves
+  // share nothing, so cfg_pairs must be 0 and the caller passes the duplicated batch.
+  if (u->cfg.use_spatial_transformer ? !ctxvec : (ctxvec != nullptr || cfg_pairs != 0)) return CS_EINVAL;
   if (((uintptr_t)workspace & 15) || ((uintptr_t)arena & 15) || ((uintptr_t)ctxvec & 15)) return CS_EINVAL;
   Exec e(*u, arena, workspace, workspace_bytes, false, (hipStream_t)stream);
   return forward(e, x_ncdhw, t, ctxvec, eps_ncdhw, nb_x, cfg_pairs);

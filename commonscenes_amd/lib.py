@@ -16,7 +16,7 @@ import torch  # noqa: F401
 
 from .build import LIB_PATH
 
-ABI_VERSION = 4      # cs_abi_version() of the library this module's SIGNATURES table describes
+ABI_VERSION = 5      # cs_abi_version() of the library this module's SIGNATURES table describes
 CS_OK = 0
 CS_EINVAL = -22
 CS_ENOMEM = -12
@@ -57,6 +57,7 @@ class CsUnetConfig(C.Structure):
         ("n_attn_res", C.c_int32), ("attention_resolutions", C.c_int32 * 8),
         ("num_heads", C.c_int32), ("context_dim", C.c_int32),
         ("d", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("math", C.c_int32),
+        ("use_spatial_transformer", C.c_int32), ("dims", C.c_int32),
     ]
 
 

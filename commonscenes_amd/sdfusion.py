@@ -96,8 +96,6 @@ class SDFusionText2ShapeModel:
         # two interchangeable sequencers of the same HIP kernels: the Python one (unet.py) and the native
         # whole-forward driver (csrc/cs_unet.hip, cs_unet_step); bit-identical outputs
         driver = str(self.opt.network.get("unet_driver") or os.environ.get("CS_UNET_DRIVER", "python"))
-        if df_conf.model.params.conditioning_key != "crossattn":
-            driver = "python"                       # cs_unet_step implements the crossattn family only
         if driver not in ("python", "native"):
             raise ValueError(f"unet_driver must be 'python' or 'native', got {driver!r}")
         unet_cls = NativeDiffusionUNet if driver == "native" else DiffusionUNet

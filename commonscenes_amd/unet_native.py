@@ -54,9 +54,10 @@ class NativeDiffusionUNet:
             c.channel_mult[i] = int(v)
         for i, v in enumerate(ar):
             c.attention_resolutions[i] = int(v)
-        c.num_heads, c.context_dim = cfg["num_heads"], cfg["context_dim"]
+        c.num_heads, c.context_dim = cfg["num_heads"], int(cfg["context_dim"] or 0)
         c.d, c.h, c.w = self.grid
         c.math = self.math
+        c.use_spatial_transformer, c.dims = int(cfg["use_spatial_transformer"]), cfg["dims"]
         lib = L.load()
         h = C.c_void_p()
         L.check(lib.cs_unet_create(C.byref(c), C.byref(h)), "cs_unet_create")
@@ -175,12 +176,16 @@ class NativeDiffusionUNet:
         if tuple(x.shape[1:]) != (self.cfg["in_channels"], *self.grid):
             raise ValueError(f"x must be (B, {self.cfg['in_channels']}, {self.grid}), got {tuple(x.shape)}")
         ws = self._workspace(nb, cfg_pairs)
-        vec = self.context_vectors(ctx, ws)
         nbo = 2 * nb if cfg_pairs else nb
-        if vec.shape[0] != nbo:
-            raise ValueError("context batch does not match x")
+        if ctx is None:                     # concat family: the condition volume is part of x, there is no context
+            vec_ptr = None
+        else:
+            vec = self.context_vectors(ctx, ws)
+            if vec.shape[0] != nbo:
+                raise ValueError("context batch does not match x")
+            vec_ptr = vec.data_ptr()
         out = torch.empty((nbo, self.cfg["out_channels"], *self.grid), dtype=torch.float32, device=self.device)
-        L.check(L.load().cs_unet_step(self._h, self._arena.data_ptr(), x.data_ptr(), t.data_ptr(), vec.data_ptr(),
+        L.check(L.load().cs_unet_step(self._h, self._arena.data_ptr(), x.data_ptr(), t.data_ptr(), vec_ptr,
                                       out.data_ptr(), nb, 1 if cfg_pairs else 0, ws.data_ptr(), ws.numel(), _stream()),
                 "cs_unet_step")
         return out
@@ -188,14 +193,21 @@ class NativeDiffusionUNet:
     @torch.no_grad()
     def forward_cfg(self, x: Tensor, t: Tensor, c_in: Tensor) -> Tensor:
         """[eps_uc; eps_c] for the guidance pair batch without duplicating (x, t) (samplers/ddim.py:206-209)."""
+        if self.conditioning_key == "concat":      # nothing upstream of the condition to share: duplicated batch
+            return self.forward(torch.cat([x, x]), torch.cat([t, t]), c_concat=[c_in])
         return self._step(x, t, c_in, True)
 
     @torch.no_grad()
     def forward(self, x: Tensor, t: Tensor, c_concat: Optional[list] = None,
                 c_crossattn: Optional[list] = None) -> Tensor:
         """network.py:20-42, crossattn branch."""
-        if self.conditioning_key != "crossattn":
-            raise NotImplementedError(f"conditioning_key={self.conditioning_key!r}: only 'crossattn' is implemented")
+        if self.conditioning_key == "concat":          # network.py:25-27
+            if not c_concat or self.cfg["use_spatial_transformer"]:
+                raise NotImplementedError("concat conditioning needs c_concat and AttentionBlock blocks")
+            xc = torch.cat([x.to(torch.float32)] + [c.to(device=x.device, dtype=torch.float32) for c in c_concat], dim=1)
+            return self._step(xc, t, None, False)
+        if self.conditioning_key != "crossattn" or not self.cfg["use_spatial_transformer"]:
+            raise NotImplementedError(f"conditioning_key={self.conditioning_key!r} with this block type")
         if c_crossattn is None:
             raise ValueError("c_crossattn is required for conditioning_key='crossattn'")
         ctx = c_crossattn[0] if len(c_crossattn) == 1 else torch.cat(c_crossattn, 1)

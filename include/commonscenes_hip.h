@@ -283,9 +283,9 @@ int cs_chamfer_nm_distance(const float* xyz1, const float* xyz2, float* dist, in
  * raw parameters, arena, context vectors, workspace -- is caller-owned, and nothing synchronises except
  * cs_unet_pack (one stream sync at load time to read the per-tensor |w| maxima in CS_MATH_F16X3).
  *
- *   cs_unet_create        config -> plan.  Scope: dims=3 (H,W-only resampling), use_spatial_transformer, one
- *                         transformer block per SpatialTransformer3D, ONE context token (attention.py:170-199
- *                         over a single key is the row vector to_out(to_v(ctx))).
+ *   cs_unet_create        config -> plan.  Scope: the two shipped families -- dims=3 with one transformer block per
+ *                         SpatialTransformer3D and ONE context token (attention.py:170-199 over a single key is
+ *                         the row vector to_out(to_v(ctx))), and dims=4 with AttentionBlock blocks.
  *   cs_unet_param_*       the reference state_dict entries (names as in SURVEY App. C, reference shapes) and
  *                         where each one goes in the caller's raw fp32 parameter buffer (cs_unet_raw_bytes).
  *   cs_unet_pack          raw parameters -> arena (cs_unet_arena_bytes): GEMM weights in the layout of the
@@ -307,6 +307,11 @@ typedef struct CsUnetConfig {
   int32_t num_heads, context_dim;
   int32_t d, h, w;   /* latent grid, 16 x 16 x 16 */
   int32_t math;      /* CS_MATH_FP32 / CS_MATH_F16X3 */
+  /* 1: SpatialTransformer3D blocks + one-token context (config/sdfusion-txt2shape.yaml, crossattn conditioning);
+   * 0: AttentionBlock / QKVAttentionLegacy blocks, no context (config/sdfusion-txt2shape_concat.yaml: the condition
+   *    volume is x's last input channel, cs_unet_step then takes ctxvec = NULL and cfg_pairs = 0). */
+  int32_t use_spatial_transformer;
+  int32_t dims;      /* 3: Down/Upsample act on H, W only; 4: on D, H, W (openai_model_3d.py:150-155,188) */
 } CsUnetConfig;
 typedef struct cs_unet cs_unet;
 

@@ -137,3 +137,28 @@ def test_sampler_over_native_driver_equals_python_driver():
         torch.cuda.synchronize()
         outs.append(x)
     assert torch.isfinite(outs[1]).all() and torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("math", ["fp32", "f16x3"])
+def test_native_driver_concat_family(math):
+    """cs_unet_step on the concat family (dims=4, AttentionBlock, condition volume as the 4th input channel):
+    reference golden at 1e-5 and bit-equality with the Python sequencer."""
+    from commonscenes_amd import synth
+    from commonscenes_amd.unet import DiffusionUNet, unet_param_shapes
+    from commonscenes_amd.unet_native import NativeDiffusionUNet
+    from oracle.ref_torch import UNET_CONCAT_SMALL
+    g = _g("unet_concat_small")
+    cfg = dict(UNET_CONCAT_SMALL)
+    sd = synth.synth_state_dict(unet_param_shapes(cfg), device="cuda")
+    py = DiffusionUNet(cfg, conditioning_key="concat", device="cuda").set_math(math)
+    py.load_state_dict(sd)
+    nat = NativeDiffusionUNet(cfg, conditioning_key="concat", device="cuda", math=math)
+    nat.load_state_dict(sd)
+    x, t, c = _cu(g["x"]), _cu(g["t"]), _cu(g["c"])
+    a = py(x, t, c_concat=[c])
+    b = nat(x, t, c_concat=[c])
+    torch.cuda.synchronize()
+    assert rel_l2(b, torch.from_numpy(g["eps"])) < 1e-5
+    assert torch.equal(a, b)
+    c2 = torch.cat([c.flip(0), c])
+    assert torch.equal(py.forward_cfg(x, t, c2), nat.forward_cfg(x, t, c2))
