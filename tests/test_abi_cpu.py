@@ -143,3 +143,63 @@ def test_graft_entry_build_passes():
     """the driver's "does it build" check: compiles (if stale), loads, resolves every symbol, checks the ABI."""
     import __graft_entry__ as g
     g.build()
+
+
+def test_every_entry_rejects_null_arguments_without_touching_the_device():
+    """Argument checks come first in every C entry: all-zero arguments (NULL pointers, zero sizes) must return
+    CS_EINVAL -- no launch, no HIP call, so this runs without a GPU."""
+    import ctypes as C
+    from commonscenes_amd import lib
+    dll = lib.load()
+    skip = {"cs_abi_version", "cs_groupnorm_ws_bytes", "cs_unet_destroy", "cs_unet_param_count", "cs_unet_raw_bytes",
+            "cs_unet_arena_bytes", "cs_unet_context_floats"}
+    checked = 0
+    for name, (res, args) in lib.SIGNATURES.items():
+        if name in skip:
+            continue
+        vals = []
+        for a in args:
+            if a in (C.c_float, C.c_double):
+                vals.append(0.0)
+            elif a in (C.c_int, C.c_int32, C.c_int64, C.c_uint64):
+                vals.append(0)
+            else:
+                vals.append(None)
+        rc = getattr(dll, name)(*vals)
+        assert rc == lib.CS_EINVAL, f"{name}(all zero) -> {rc}"
+        checked += 1
+    assert checked >= 35
+    # the queries that return sizes answer 0 for a NULL plan, and destroy(NULL) is a no-op
+    assert dll.cs_unet_param_count(None) == 0 and dll.cs_unet_raw_bytes(None) == 0
+    dll.cs_unet_destroy(None)
+
+
+def test_conv_gemm_descriptor_validation():
+    """cs_conv_gemm / cs_conv_gemm_plan reject malformed descriptors before any launch."""
+    import ctypes as C
+    from commonscenes_amd import lib
+    dll = lib.load()
+    buf = (C.c_float * 64)()
+    base = C.addressof(buf)
+    base += (-base) % 16
+
+    def desc(**kw):
+        p = lib.CsConvGemm()
+        p.x = p.w = p.out = base
+        p.nb, p.din, p.hin, p.win, p.dout, p.hout, p.wout = 1, 1, 1, 1, 1, 1, 1
+        p.cin, p.cout, p.lda, p.ldw, p.ldo = 4, 4, 4, 4, 4
+        p.kd = p.kh = p.kw = p.sd = p.sh = p.sw = 1
+        p.rv_rows = 1
+        for k, v in kw.items():
+            setattr(p, k, v)
+        return p
+
+    for bad in (dict(cin=3), dict(lda=2), dict(ldo=2), dict(kd=0), dict(sd=0), dict(ud=5), dict(math=7),
+                dict(x=base + 4), dict(scale=base), dict(rowvec=base, rv_rows=0), dict(act=lib.ACT_GEGLU),
+                dict(math=lib.MATH_F16X3), dict(splitk=2), dict(tile=9, math=lib.MATH_F16X3, w_lo=base, acc_scale=1.0)):
+        assert dll.cs_conv_gemm(C.byref(desc(**bad)), None) == lib.CS_EINVAL, bad
+    sk, ws = C.c_int32(-1), C.c_int64(-1)
+    assert dll.cs_conv_gemm_plan(C.byref(desc()), C.byref(sk), C.byref(ws)) == 0 and sk.value == 1 and ws.value == 0
+    big = desc(nb=2, dout=16, hout=4, wout=4, cin=672, cout=672, kd=3, kh=3, kw=3, math=lib.MATH_F16X3)
+    assert dll.cs_conv_gemm_plan(C.byref(big), C.byref(sk), C.byref(ws)) == 0
+    assert sk.value == 22 and ws.value == 22 * 512 * 672 * 4
