@@ -192,7 +192,7 @@ class DiffusionUNet:
         self._sd: Dict[str, Tensor] = {}
         self._packed = None
         self.training = False
-        self.math = L.MATH_FP32
+        self.math = L.DEFAULT_MATH      # F16X3 unless CS_MATH=fp32
         self.trace: Optional[Dict[str, Tensor]] = None   # set to {} to capture per-block outputs (tests)
 
     # ---- nn.Module-like surface -----------------------------------------------------------

@@ -26,11 +26,11 @@ def _stream() -> int:
 
 class NativeDiffusionUNet:
     def __init__(self, unet_params, vq_conf=None, conditioning_key: Optional[str] = "crossattn",
-                 device: str | torch.device = "cuda", math: str | int = "f16x3", grid: Tuple[int, int, int] = (16, 16, 16)):
+                 device: str | torch.device = "cuda", math: str | int | None = None, grid: Tuple[int, int, int] = (16, 16, 16)):
         self.cfg = _cfg(unet_params)
         self.conditioning_key = conditioning_key
         self.device = torch.device(device)
-        self.math = {"fp32": L.MATH_FP32, "f16x3": L.MATH_F16X3}.get(math, math)
+        self.math = L.DEFAULT_MATH if math is None else {"fp32": L.MATH_FP32, "f16x3": L.MATH_F16X3}.get(math, math)
         self.grid = tuple(grid)
         self._h = None
         self._arena: Optional[Tensor] = None

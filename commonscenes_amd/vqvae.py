@@ -99,7 +99,7 @@ class VQVAE:
         self.shapes = vqvae_param_shapes(ddconfig, n_embed, embed_dim)
         self._sd: Dict[str, Tensor] = {}
         self._packed = None
-        self.math = L.MATH_FP32
+        self.math = L.DEFAULT_MATH      # F16X3 unless CS_MATH=fp32
         self.last_indices: Optional[Tensor] = None
 
     # ---- nn.Module-like surface ----

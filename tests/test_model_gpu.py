@@ -33,14 +33,22 @@ def _unet_cfg(small):
 _CACHE = {}
 
 
-def _unet(small):
+def _unet(small, math=None):
+    """cached model; `math` None = whatever the class starts in (F16X3, the product default)."""
     key = ("unet", small)
+    if key in _CACHE and math is not None:
+        _CACHE[key].set_math(math)
+    elif key in _CACHE:
+        from commonscenes_amd import lib as L
+        _CACHE[key].set_math({L.MATH_FP32: "fp32", L.MATH_F16X3: "f16x3"}[L.DEFAULT_MATH])
     if key not in _CACHE:
         from commonscenes_amd import synth
         from commonscenes_amd.unet import DiffusionUNet, unet_param_shapes
         cfg = _unet_cfg(small)
         df = DiffusionUNet(cfg, conditioning_key="crossattn", device="cuda")
         df.load_state_dict(synth.synth_state_dict(unet_param_shapes(cfg), device="cuda"))
+        if math is not None:
+            df.set_math(math)
         _CACHE[key] = df
     return _CACHE[key]
 
@@ -87,9 +95,10 @@ def test_device_synth_fill_is_bit_identical_to_host():
 # ---------------------------------------------------------------------------------------------------
 # UNet
 # ---------------------------------------------------------------------------------------------------
-def test_unet_small_vs_reference_golden():
+@pytest.mark.parametrize("math", ["fp32", "f16x3"])
+def test_unet_small_vs_reference_golden(math):
     g = _g("unet_small")
-    df = _unet(True)
+    df = _unet(True, math)
     df.trace = {}
     eps = df(_cu(g["x"]), _cu(g["t"]), c_crossattn=[_cu(g["ctx"])])
     torch.cuda.synchronize()
@@ -100,9 +109,10 @@ def test_unet_small_vs_reference_golden():
     assert rel_l2(eps, torch.from_numpy(g["eps"])) < 1e-5
 
 
-def test_unet_full_vs_reference_golden():
+@pytest.mark.parametrize("math", ["fp32", "f16x3"])
+def test_unet_full_vs_reference_golden(math):
     g = _g("unet_full")
-    df = _unet(False)
+    df = _unet(False, math)
     eps = df(_cu(g["x"]), _cu(g["t"]), c_crossattn=[_cu(g["ctx"])])
     torch.cuda.synchronize()
     assert eps.shape == (2, 3, 16, 16, 16)
@@ -155,8 +165,7 @@ def test_unet_full_size_batch_invariance_at_benchmark_shape():
     step equals its eps in a 2-object step.  The two runs take different GEMM plans (256-row tiles vs split-K), so
     equality is to fp32 summation-order noise, not bitwise; the 32-object run itself is deterministic."""
     from commonscenes_amd import synth
-    df = _unet(False)
-    df.set_math("f16x3")
+    df = _unet(False, "f16x3")
     try:
         B = 32
         x = synth.gaussian_like("fs:x", (B, 3, 16, 16, 16)).cuda()
@@ -175,7 +184,7 @@ def test_unet_full_size_batch_invariance_at_benchmark_shape():
             assert rel_l2(small[2 + k], big[B + i]) < 1e-5      # c half
         assert rel_l2(big[3], big[29]) > 1e-2                   # different objects really differ
     finally:
-        df.set_math("fp32")
+        pass
 
 
 # ---------------------------------------------------------------------------------------------------
