@@ -6,6 +6,7 @@ in this package falls back to PyTorch/CPU arithmetic.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 # torch must be imported BEFORE the library is dlopen'ed: both need libamdhip64.so.7 and whichever is
@@ -24,7 +25,7 @@ ACT_NONE, ACT_RELU, ACT_SILU, ACT_GELU, ACT_GEGLU = 0, 1, 2, 3, 4
 MATH_FP32, MATH_F16X3 = 0, 1
 # The numerics mode model classes start in: F16X3 (fp32-grade, the benchmarked mode) unless CS_MATH=fp32 asks for the
 # fp32-input MFMA kernels.  `set_math()` switches per model.
-DEFAULT_MATH = MATH_FP32 if __import__("os").environ.get("CS_MATH", "f16x3").lower() == "fp32" else MATH_F16X3
+DEFAULT_MATH = MATH_FP32 if os.environ.get("CS_MATH", "f16x3").lower() == "fp32" else MATH_F16X3
 
 _f = C.c_void_p   # device float*
 _i = C.c_int

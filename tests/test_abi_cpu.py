@@ -134,9 +134,10 @@ def test_unet_plan_is_host_only_and_lists_the_reference_state_dict():
     w1, w32 = lib.cs_unet_workspace_bytes(n._h, 1, 1), lib.cs_unet_workspace_bytes(n._h, 32, 1)
     assert 0 < w1 < w32 < 8 * 2 ** 30
     assert n.ctx_floats == 5 * 448 + 6 * 672
+    import ctypes
     bad = L.CsUnetConfig()
-    h = __import__("ctypes").c_void_p()
-    assert lib.cs_unet_create(__import__("ctypes").byref(bad), __import__("ctypes").byref(h)) == L.CS_EINVAL
+    h = ctypes.c_void_p()
+    assert lib.cs_unet_create(ctypes.byref(bad), ctypes.byref(h)) == L.CS_EINVAL
 
 
 def test_graft_entry_build_passes():
