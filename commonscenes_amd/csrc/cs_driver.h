@@ -1,0 +1,477 @@
+// Shared machinery of the native whole-forward drivers (cs_unet.hip, cs_vqvae.hip): the host-side plan (reference
+// parameter table, packed-GEMM recipes, arena layout), the raw -> arena packing pass, and an executor that
+// sequences the library's own C entries over a caller-owned workspace (first-fit allocator, dry-run sizing).
+// Internal header: everything lives in an anonymous namespace of the including translation unit.
+#pragma once
+#include "cs_common.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+constexpr int64_t ALIGN = 256;
+inline int64_t align_up(int64_t v) { return (v + ALIGN - 1) / ALIGN * ALIGN; }
+
+struct Param {
+  std::string name;
+  int64_t shape[5];
+  int ndim;
+  int64_t numel;
+  int64_t raw_off;   // bytes into the caller's raw parameter buffer
+};
+
+struct Piece {       // rows [row0, row0 + rows) of parameter `param` seen as a [rows_total][cols] matrix
+  int param;
+  int row0;
+  int rows;
+};
+
+struct Gemm {        // one packed GEMM weight (possibly several reference tensors concatenated along cout)
+  std::vector<Piece> w, b;
+  int cout = 0, cin = 0, cin_pad = 0, k = 1, taps = 1, ldw = 0;
+  int64_t w_off = 0, wlo_off = 0, b_off = -1;
+  float acc_scale = 1.f;
+};
+
+struct Norm {
+  int gp, bp, c;
+  int64_t g_off, b_off;
+};
+
+struct RawCopy {     // a parameter copied verbatim into the arena (e.g. the VQ codebook)
+  int param;
+  int64_t arena_off;
+};
+
+struct FreeBlock {
+  int64_t off, size;
+};
+
+struct Plan {
+  int math = CS_MATH_FP32;
+  std::vector<Param> params;
+  std::vector<Gemm> gemms;
+  std::vector<Norm> norms;
+  std::vector<RawCopy> copies;
+  int64_t raw_bytes = 0, arena_bytes = 0, amax_off = 0;
+  bool packed = false;
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// plan construction
+// ---------------------------------------------------------------------------------------------------------
+int add_param(Plan& u, const std::string& name, std::initializer_list<int64_t> shape) {
+  Param p;
+  p.name = name;
+  p.ndim = (int)shape.size();
+  p.numel = 1;
+  int i = 0;
+  for (int64_t s : shape) {
+    p.shape[i++] = s;
+    p.numel *= s;
+  }
+  for (; i < 5; ++i) p.shape[i] = 1;
+  p.raw_off = u.raw_bytes;
+  u.raw_bytes += align_up(p.numel * 4);
+  u.params.push_back(p);
+  return (int)u.params.size() - 1;
+}
+
+int add_norm(Plan& u, const std::string& p, int c) {
+  Norm n;
+  n.gp = add_param(u, p + ".weight", {c});
+  n.bp = add_param(u, p + ".bias", {c});
+  n.c = c;
+  n.g_off = n.b_off = 0;
+  u.norms.push_back(n);
+  return (int)u.norms.size() - 1;
+}
+
+// registers <p>.weight (+ .bias); returns the parameter indices
+void add_wb(Plan& u, const std::string& p, int o, int i, int k, bool bias, int& wp, int& bp) {
+  if (k > 1)
+    wp = add_param(u, p + ".weight", {o, i, k, k, k});
+  else if (k == 1)
+    wp = add_param(u, p + ".weight", {o, i, 1, 1, 1});
+  else
+    wp = add_param(u, p + ".weight", {o, i});   // Linear
+  bp = bias ? add_param(u, p + ".bias", {o}) : -1;
+}
+
+int add_gemm(Plan& u, std::vector<Piece> w, std::vector<Piece> b, int cout, int cin, int k, int cin_pad = 0) {
+  Gemm g;
+  g.w = std::move(w);
+  g.b = std::move(b);
+  g.cout = cout;
+  g.cin = cin;
+  g.k = k < 1 ? 1 : k;
+  g.taps = g.k * g.k * g.k;
+  g.cin_pad = cin_pad ? cin_pad : (cin + 3) / 4 * 4;
+  u.gemms.push_back(g);
+  return (int)u.gemms.size() - 1;
+}
+
+// conv (k = 3 or 1) or Linear (k = 0) as a single-tensor GEMM
+int add_layer_gemm(Plan& u, const std::string& p, int o, int i, int k, bool bias = true, int cin_pad = 0) {
+  int wp, bp;
+  add_wb(u, p, o, i, k, bias, wp, bp);
+  std::vector<Piece> b;
+  if (bp >= 0) b.push_back({bp, 0, o});
+  return add_gemm(u, {{wp, 0, o}}, b, o, i, k, cin_pad);
+}
+
+int add_copy(Plan& u, int param) {
+  u.copies.push_back({param, 0});
+  return (int)u.copies.size() - 1;
+}
+
+void layout_arena(Plan& u) {
+  const bool f16 = u.math == CS_MATH_F16X3;
+  int64_t off = 0;
+  for (Gemm& g : u.gemms) {
+    if (f16) {
+      const int64_t kg = (int64_t)(g.cin + 15) / 16 * 2;
+      const int64_t img = (int64_t)g.taps * kg * g.cout * 16;
+      g.ldw = g.cout;
+      g.w_off = off;
+      off += align_up(img);
+      g.wlo_off = off;
+      off += align_up(img);
+    } else {
+      g.ldw = (g.cout + 3) / 4 * 4;
+      g.w_off = off;
+      off += align_up((int64_t)g.taps * g.cin_pad * g.ldw * 4);
+    }
+    if (!g.b.empty()) {
+      g.b_off = off;
+      off += align_up((int64_t)g.cout * 4);
+    }
+  }
+  for (Norm& n : u.norms) {
+    n.g_off = off;
+    off += align_up((int64_t)n.c * 4);
+    n.b_off = off;
+    off += align_up((int64_t)n.c * 4);
+  }
+  for (RawCopy& rc : u.copies) {
+    rc.arena_off = off;
+    off += align_up(u.params[rc.param].numel * 4);
+  }
+  u.amax_off = off;
+  off += align_up((int64_t)u.params.size() * 4);
+  u.arena_bytes = off;
+}
+
+int plan_param_info(const Plan* u, int i, const char** name, int64_t shape5[5], int* ndim, int64_t* raw_offset_bytes) {
+  if (!u || i < 0 || i >= (int)u->params.size()) return CS_EINVAL;
+  const Param& p = u->params[i];
+  if (name) *name = p.name.c_str();
+  if (shape5) memcpy(shape5, p.shape, sizeof(p.shape));
+  if (ndim) *ndim = p.ndim;
+  if (raw_offset_bytes) *raw_offset_bytes = p.raw_off;
+  return CS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// weight packing kernels (piece-wise versions of cs_pack_weight_f16x3 / cs_relayout_weight: a piece is a row
+// range of a reference tensor landing at a column offset of a possibly fused GEMM weight)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ w, int64_t n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float m = 0.f;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    m = fmaxf(m, fabsf(w[i]));
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    // non-negative floats order like their bit patterns
+    atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));
+  }
+}
+
+__global__ __launch_bounds__(256) void pack_part_f16x3_kernel(const float* __restrict__ w, _Float16* __restrict__ wh,
+                                                              _Float16* __restrict__ wl, int rows, int n_off,
+                                                              int cout_total, int cin, int taps, int kg_per_tap,
+                                                              float scale) {
+  const int64_t total = (int64_t)taps * kg_per_tap * rows * 8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 7);
+    int64_t t = i >> 3;
+    const int n = (int)(t % rows);
+    t /= rows;
+    const int kg = (int)(t % kg_per_tap);
+    const int tap = (int)(t / kg_per_tap);
+    const int c = kg * 8 + j;
+    float v = 0.f;
+    if (c < cin) v = w[((int64_t)n * cin + c) * taps + tap] * scale;
+    const _Float16 h = (_Float16)v;
+    const int64_t o = (((int64_t)tap * kg_per_tap + kg) * cout_total + n_off + n) * 8 + j;
+    wh[o] = h;
+    wl[o] = (_Float16)(v - (float)h);
+  }
+}
+
+__global__ __launch_bounds__(256) void pack_part_f32_kernel(const float* __restrict__ w, float* __restrict__ o,
+                                                            int rows, int n_off, int cin, int taps, int cin_pad,
+                                                            int ldw) {
+  // w: rows of a (cout, cin, taps) torch tensor; o: [tap][cin_pad][ldw], columns n_off .. n_off + rows
+  const int64_t total = (int64_t)taps * cin_pad * rows;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i % rows);
+    const int64_t t = i / rows;
+    const int c = (int)(t % cin_pad);
+    const int tap = (int)(t / cin_pad);
+    float v = 0.f;
+    if (c < cin) v = w[((int64_t)n * cin + c) * taps + tap];
+    o[((int64_t)tap * cin_pad + c) * ldw + n_off + n] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// execution
+// ---------------------------------------------------------------------------------------------------------
+
+// raw parameters -> arena: GEMM weights in the layout of the plan's math mode (pieces gathered into fused weights),
+// biases, norm affine parameters, verbatim copies.  One stream sync in F16X3 mode (per-tensor |w| maxima).
+int pack_plan(Plan* u, const void* raw_dev, void* arena_dev, cs_stream_t stream) {
+  if (!u || !raw_dev || !arena_dev) return CS_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const char* raw = (const char*)raw_dev;
+  char* arena = (char*)arena_dev;
+  const bool f16 = u->math == CS_MATH_F16X3;
+  auto src = [&](int param) { return reinterpret_cast<const float*>(raw + u->params[param].raw_off); };
+  std::vector<float> amax(u->params.size(), 0.f);
+  if (f16) {
+    // per-tensor |w| maxima for the power-of-two operand scales: one device pass, ONE host sync (load time)
+    float* d_amax = reinterpret_cast<float*>(arena + u->amax_off);
+    if (hipMemsetAsync(d_amax, 0, u->params.size() * 4, st) != hipSuccess) return CS_EINVAL;
+    for (const Gemm& g : u->gemms)
+      for (const Piece& pc : g.w) {
+        const Param& p = u->params[pc.param];
+        CS_LAUNCH(absmax_kernel, dim3(cs_grid_for(p.numel, 256, 256)), dim3(256), 0, st, src(pc.param), p.numel,
+                  d_amax + pc.param);
+        CS_CHECK_LAUNCH();
+      }
+    if (hipMemcpyAsync(amax.data(), d_amax, amax.size() * 4, hipMemcpyDeviceToHost, st) != hipSuccess)
+      return CS_EINVAL;
+    if (hipStreamSynchronize(st) != hipSuccess) return CS_EINVAL;
+  }
+  for (Gemm& g : u->gemms) {
+    const int cols = g.cin * g.taps;    // row length of the reference tensor seen as [cout][cin * taps]
+    float scale = 1.f;
+    if (f16) {
+      // scale by the whole tensor's maximum even when only a row range is used (GEGLU pieces): what
+      // ops._pack_weight_f16x3 sees is the permuted full tensor, whose maximum is the same
+      float m = 0.f;
+      for (const Piece& pc : g.w) m = fmaxf(m, amax[pc.param]);
+      int ex = 0;
+      if (m > 0.f && std::isfinite(m)) (void)std::frexp((double)m, &ex);
+      scale = (float)std::ldexp(1.0, 14 - ex);
+      g.acc_scale = 1.0f / (scale * 16.0f);
+    } else {
+      if (hipMemsetAsync(arena + g.w_off, 0, (size_t)g.taps * g.cin_pad * g.ldw * 4, st) != hipSuccess)
+        return CS_EINVAL;
+    }
+    int n_off = 0;
+    for (const Piece& pc : g.w) {
+      const float* w = src(pc.param) + (int64_t)pc.row0 * cols;
+      if (f16) {
+        const int kg = (g.cin + 15) / 16 * 2;
+        const int64_t total = (int64_t)g.taps * kg * pc.rows * 8;
+        CS_LAUNCH(pack_part_f16x3_kernel, dim3(cs_grid_for(total, 256, 256 * 32)), dim3(256), 0, st, w,
+                  (_Float16*)(arena + g.w_off), (_Float16*)(arena + g.wlo_off), pc.rows, n_off, g.cout, g.cin,
+                  g.taps, kg, scale);
+      } else {
+        const int64_t total = (int64_t)g.taps * g.cin_pad * pc.rows;
+        CS_LAUNCH(pack_part_f32_kernel, dim3(cs_grid_for(total, 256)), dim3(256), 0, st, w,
+                  (float*)(arena + g.w_off), pc.rows, n_off, g.cin, g.taps, g.cin_pad, g.ldw);
+      }
+      CS_CHECK_LAUNCH();
+      n_off += pc.rows;
+    }
+    if (n_off != g.cout) return CS_EINVAL;
+    n_off = 0;
+    for (const Piece& pc : g.b) {
+      if (hipMemcpyAsync(arena + g.b_off + (int64_t)n_off * 4, src(pc.param) + pc.row0, (size_t)pc.rows * 4,
+                         hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return CS_EINVAL;
+      n_off += pc.rows;
+    }
+  }
+  for (const Norm& n : u->norms) {
+    if (hipMemcpyAsync(arena + n.g_off, src(n.gp), (size_t)n.c * 4, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(arena + n.b_off, src(n.bp), (size_t)n.c * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+      return CS_EINVAL;
+  }
+  for (const RawCopy& rc : u->copies) {
+    if (hipMemcpyAsync(arena + rc.arena_off, src(rc.param), (size_t)u->params[rc.param].numel * 4,
+                       hipMemcpyDeviceToDevice, st) != hipSuccess)
+      return CS_EINVAL;
+  }
+  u->packed = true;
+  return CS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// execution
+// ---------------------------------------------------------------------------------------------------------
+struct Buf {
+  int64_t off = -1, bytes = 0;
+  int64_t rows = 0;
+  int c = 0;
+};
+
+struct Act {   // an activation volume, channels-last
+  Buf b;
+  int nb = 0, d = 0, h = 0, w = 0;
+};
+
+struct ExecBase {
+  const Plan& pl;
+  const char* arena;
+  char* ws;
+  int64_t ws_bytes;
+  bool dry;
+  hipStream_t st;
+  int rc = CS_OK;
+  int64_t peak = 0;
+  std::vector<FreeBlock> fl;
+
+  ExecBase(const Plan& pl_, const void* arena_, void* ws_, int64_t ws_bytes_, bool dry_, hipStream_t st_)
+      : pl(pl_), arena((const char*)arena_), ws((char*)ws_), ws_bytes(ws_bytes_), dry(dry_), st(st_) {
+    fl.push_back({0, dry ? (int64_t)1 << 60 : ws_bytes});
+  }
+  bool ok() const { return rc == CS_OK; }
+  void chk(int r) {
+    if (rc == CS_OK && r != CS_OK) rc = r;
+  }
+  float* p(const Buf& b) const { return reinterpret_cast<float*>(ws + b.off); }
+  const float* wf(int64_t off) const { return reinterpret_cast<const float*>(arena + off); }
+
+  Buf alloc(int64_t rows, int c) {
+    Buf b;
+    b.rows = rows;
+    b.c = c;
+    b.bytes = align_up(rows * c * 4);
+    for (size_t i = 0; i < fl.size(); ++i) {
+      if (fl[i].size >= b.bytes) {
+        b.off = fl[i].off;
+        fl[i].off += b.bytes;
+        fl[i].size -= b.bytes;
+        if (fl[i].size == 0) fl.erase(fl.begin() + i);
+        if (b.off + b.bytes > peak) peak = b.off + b.bytes;
+        return b;
+      }
+    }
+    chk(CS_ENOMEM);
+    b.off = 0;
+    return b;
+  }
+  void release(Buf& b) {
+    if (b.off < 0 || b.bytes == 0) return;
+    size_t i = 0;
+    while (i < fl.size() && fl[i].off < b.off) ++i;
+    fl.insert(fl.begin() + i, {b.off, b.bytes});
+    if (i + 1 < fl.size() && fl[i].off + fl[i].size == fl[i + 1].off) {
+      fl[i].size += fl[i + 1].size;
+      fl.erase(fl.begin() + i + 1);
+    }
+    if (i > 0 && fl[i - 1].off + fl[i - 1].size == fl[i].off) {
+      fl[i - 1].size += fl[i].size;
+      fl.erase(fl.begin() + i);
+    }
+    b.off = -1;
+    b.bytes = 0;
+  }
+
+  // conv (k^3 taps, stride (1,s,s), nearest upsample (0,up,up)) or pointwise/linear GEMM with the fused epilogue
+  Buf gemm(const Buf& x, int gi, int nb, int d, int h, int w, int s_hw = 1, int up_hw = 0, int act = CS_ACT_NONE,
+           const float* rowvec = nullptr, int ldrv = 0, int rv_rows = 1, const float* res = nullptr, int ldr = 0,
+           int tile = 0, int s_d = 1, int up_d = 0) {
+    const Gemm& g = pl.gemms[gi];
+    const int k = g.k, pad = k / 2;
+    const int vh = h << up_hw, vw = w << up_hw;
+    const int dout = ((d << up_d) + 2 * pad - k) / s_d + 1;
+    const int hout = (vh + 2 * pad - k) / s_hw + 1;
+    const int wout = (vw + 2 * pad - k) / s_hw + 1;
+    const int64_t mo = (int64_t)nb * dout * hout * wout;
+    const int ocols = act == CS_ACT_GEGLU ? g.cout / 2 : g.cout;
+    Buf out = alloc(mo, ocols);
+    if (!ok()) return out;
+    if (x.c != g.cin_pad || x.rows != (int64_t)nb * d * h * w) {
+      chk(CS_EINVAL);
+      return out;
+    }
+    CsConvGemm q;
+    memset(&q, 0, sizeof(q));
+    if (!dry) {
+      q.x = p(x);
+      q.out = p(out);
+      q.w = reinterpret_cast<const float*>(arena + g.w_off);
+      if (pl.math == CS_MATH_F16X3) {
+        q.w_lo = arena + g.wlo_off;
+        q.acc_scale = g.acc_scale;
+        q.a_scale = 16.0f;
+      }
+      q.bias = g.b_off >= 0 ? wf(g.b_off) : nullptr;
+      q.rowvec = rowvec;
+      q.res = res;
+    }
+    q.nb = nb; q.din = d; q.hin = h; q.win = w;
+    q.dout = dout; q.hout = hout; q.wout = wout;
+    q.cin = g.cin_pad; q.cout = g.cout;
+    q.lda = x.c; q.ldw = g.ldw; q.ldo = ocols; q.ldr = res ? ldr : 0; q.ldrv = rowvec ? ldrv : 0;
+    q.kd = q.kh = q.kw = k;
+    q.sd = s_d; q.sh = q.sw = s_hw;
+    q.pd = q.ph = q.pw = pad;
+    q.ud = up_d; q.uh = q.uw = up_hw;
+    q.act = act; q.rv_rows = rv_rows; q.math = pl.math; q.tile = tile;
+    // small batches: few output tiles -> cut the K loop into slices (same plan function the Python host calls)
+    int32_t sk = 1;
+    int64_t wsb = 0;
+    Buf skws;
+    if (tile == 0 && cs_conv_gemm_plan(&q, &sk, &wsb) == CS_OK && sk > 1) {
+      skws = alloc(wsb / 4, 1);          // the dry run sizes the workspace with it too
+      if (!ok()) return out;
+      q.splitk = sk;
+      q.splitk_ws = dry ? nullptr : p(skws);
+    }
+    if (!dry) chk(cs_conv_gemm(&q, st));
+    release(skws);      // stream-ordered: later kernels that reuse the region run after the reduce
+    return out;
+  }
+  Buf linear(const Buf& x, int gi, int act = CS_ACT_NONE, const float* rowvec = nullptr, int ldrv = 0,
+             int rv_rows = 1, const float* res = nullptr, int ldr = 0, int tile = 0) {
+    return gemm(x, gi, (int)x.rows, 1, 1, 1, 1, 0, act, rowvec, ldrv, rv_rows, res, ldr, tile);
+  }
+
+  Buf groupnorm(const Buf& x, int ni, int nb, float eps, int act, int groups = 32) {
+    const Norm& n = pl.norms[ni];
+    Buf y = alloc(x.rows, x.c);
+    Buf wsb = alloc((cs_groupnorm_ws_bytes(nb, groups) + 3) / 4, 1);
+    Buf stats = alloc((int64_t)nb * groups * 2, 1);
+    if (ok() && !dry) {
+      const int rows = (int)(x.rows / nb);
+      chk(cs_groupnorm_stats(p(x), nb, rows, x.c, x.c, groups, eps, p(wsb), p(stats), st));
+      chk(cs_groupnorm_apply(p(x), p(stats), wf(n.g_off), wf(n.b_off), p(y), nb, rows, x.c, x.c, x.c, groups, act, st));
+    }
+    release(wsb);
+    release(stats);
+    return y;
+  }
+  Buf layernorm(const Buf& x, int ni) {
+    const Norm& n = pl.norms[ni];
+    Buf y = alloc(x.rows, x.c);
+    if (ok() && !dry) chk(cs_layernorm(p(x), wf(n.g_off), wf(n.b_off), p(y), (int)x.rows, x.c, x.c, x.c, 1e-5f, st));
+    return y;
+  }
+};
+
+}  // namespace
