@@ -25,7 +25,8 @@ struct Param {
   int64_t raw_off;   // bytes into the caller's raw parameter buffer
 };
 
-struct Piece {       // rows [row0, row0 + rows) of parameter `param` seen as a [rows_total][cols] matrix
+struct Piece {       // rows [row0, row0 + rows) of parameter `param` seen as a [rows_total][cols] matrix;
+                     // param < 0: `rows` all-zero rows (channel padding)
   int param;
   int row0;
   int rows;
@@ -254,6 +255,7 @@ int pack_plan(Plan* u, const void* raw_dev, void* arena_dev, cs_stream_t stream)
     if (hipMemsetAsync(d_amax, 0, u->params.size() * 4, st) != hipSuccess) return CS_EINVAL;
     for (const Gemm& g : u->gemms)
       for (const Piece& pc : g.w) {
+        if (pc.param < 0) continue;
         const Param& p = u->params[pc.param];
         CS_LAUNCH(absmax_kernel, dim3(cs_grid_for(p.numel, 256, 256)), dim3(256), 0, st, src(pc.param), p.numel,
                   d_amax + pc.param);
@@ -270,17 +272,28 @@ int pack_plan(Plan* u, const void* raw_dev, void* arena_dev, cs_stream_t stream)
       // scale by the whole tensor's maximum even when only a row range is used (GEGLU pieces): what
       // ops._pack_weight_f16x3 sees is the permuted full tensor, whose maximum is the same
       float m = 0.f;
-      for (const Piece& pc : g.w) m = fmaxf(m, amax[pc.param]);
+      for (const Piece& pc : g.w)
+        if (pc.param >= 0) m = fmaxf(m, amax[pc.param]);
       int ex = 0;
       if (m > 0.f && std::isfinite(m)) (void)std::frexp((double)m, &ex);
       scale = (float)std::ldexp(1.0, 14 - ex);
       g.acc_scale = 1.0f / (scale * 16.0f);
+      const int64_t img = (int64_t)g.taps * ((g.cin + 15) / 16 * 2) * g.cout * 16;
+      bool zero_rows = false;
+      for (const Piece& pc : g.w) zero_rows |= pc.param < 0;
+      if (zero_rows && (hipMemsetAsync(arena + g.w_off, 0, (size_t)img, st) != hipSuccess ||
+                        hipMemsetAsync(arena + g.wlo_off, 0, (size_t)img, st) != hipSuccess))
+        return CS_EINVAL;
     } else {
       if (hipMemsetAsync(arena + g.w_off, 0, (size_t)g.taps * g.cin_pad * g.ldw * 4, st) != hipSuccess)
         return CS_EINVAL;
     }
     int n_off = 0;
     for (const Piece& pc : g.w) {
+      if (pc.param < 0) {     // zero rows: the images were cleared above
+        n_off += pc.rows;
+        continue;
+      }
       const float* w = src(pc.param) + (int64_t)pc.row0 * cols;
       if (f16) {
         const int kg = (g.cin + 15) / 16 * 2;
@@ -299,8 +312,11 @@ int pack_plan(Plan* u, const void* raw_dev, void* arena_dev, cs_stream_t stream)
     if (n_off != g.cout) return CS_EINVAL;
     n_off = 0;
     for (const Piece& pc : g.b) {
-      if (hipMemcpyAsync(arena + g.b_off + (int64_t)n_off * 4, src(pc.param) + pc.row0, (size_t)pc.rows * 4,
-                         hipMemcpyDeviceToDevice, st) != hipSuccess)
+      if (pc.param < 0) {
+        if (hipMemsetAsync(arena + g.b_off + (int64_t)n_off * 4, 0, (size_t)pc.rows * 4, st) != hipSuccess)
+          return CS_EINVAL;
+      } else if (hipMemcpyAsync(arena + g.b_off + (int64_t)n_off * 4, src(pc.param) + pc.row0, (size_t)pc.rows * 4,
+                                hipMemcpyDeviceToDevice, st) != hipSuccess)
         return CS_EINVAL;
       n_off += pc.rows;
     }

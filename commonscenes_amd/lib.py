@@ -17,7 +17,7 @@ import torch  # noqa: F401
 
 from .build import LIB_PATH
 
-ABI_VERSION = 5      # cs_abi_version() of the library this module's SIGNATURES table describes
+ABI_VERSION = 6      # cs_abi_version() of the library this module's SIGNATURES table describes
 CS_OK = 0
 CS_EINVAL = -22
 CS_ENOMEM = -12
@@ -62,6 +62,14 @@ class CsUnetConfig(C.Structure):
         ("num_heads", C.c_int32), ("context_dim", C.c_int32),
         ("d", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("math", C.c_int32),
         ("use_spatial_transformer", C.c_int32), ("dims", C.c_int32),
+    ]
+
+
+class CsVqvaeConfig(C.Structure):
+    _fields_ = [
+        ("ch", C.c_int32), ("out_ch", C.c_int32), ("n_mult", C.c_int32), ("ch_mult", C.c_int32 * 8),
+        ("num_res_blocks", C.c_int32), ("z_channels", C.c_int32), ("resolution", C.c_int32),
+        ("n_embed", C.c_int32), ("embed_dim", C.c_int32), ("math", C.c_int32),
     ]
 
 
@@ -112,6 +120,16 @@ SIGNATURES = {
     "cs_embedding": (_i, [_f, _f, _f, _i, _i, _i, _i, _f, _s]),
     "cs_log_softmax": (_i, [_f, _f, _i, _i, _i, _i, _s]),
     "cs_synth_fill": (_i, [_f, _l, C.c_uint64, C.c_double, C.c_double, _s]),
+    "cs_vqvae_create": (_i, [C.POINTER(CsVqvaeConfig), _pp]),
+    "cs_vqvae_destroy": (None, [C.c_void_p]),
+    "cs_vqvae_param_count": (_i, [C.c_void_p]),
+    "cs_vqvae_param_info": (_i, [C.c_void_p, _i, C.POINTER(C.c_char_p), C.POINTER(C.c_int64 * 5), C.POINTER(C.c_int),
+                                 C.POINTER(C.c_int64)]),
+    "cs_vqvae_raw_bytes": (_l, [C.c_void_p]),
+    "cs_vqvae_arena_bytes": (_l, [C.c_void_p]),
+    "cs_vqvae_pack": (_i, [C.c_void_p, _f, _f, _s]),
+    "cs_vqvae_workspace_bytes": (_l, [C.c_void_p, _i]),
+    "cs_vqvae_decode": (_i, [C.c_void_p, _f, _f, _f, _f, _i, _i, _f, _l, _s]),
     "cs_abi_version": (_i, []),
 }
 

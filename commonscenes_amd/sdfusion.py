@@ -27,6 +27,7 @@ import yaml
 from .ddim import DDIMSampler
 from .unet import DiffusionUNet
 from .unet_native import NativeDiffusionUNet
+from .vqvae_native import NativeVQVAE
 from .vqvae import VQVAE, load_vqvae
 
 Tensor = torch.Tensor
@@ -93,8 +94,8 @@ class SDFusionText2ShapeModel:
         z_sp = shape_res // (2 ** n_down)
         self.z_shape = (z_ch, z_sp, z_sp, z_sp)
 
-        # two interchangeable sequencers of the same HIP kernels: the Python one (unet.py) and the native
-        # whole-forward driver (csrc/cs_unet.hip, cs_unet_step); bit-identical outputs
+        # two interchangeable sequencers of the same HIP kernels: the Python ones (unet.py, vqvae.py) and the native
+        # whole-forward drivers (csrc/cs_unet.hip cs_unet_step, csrc/cs_vqvae.hip cs_vqvae_decode); bit-identical
         driver = str(self.opt.network.get("unet_driver") or os.environ.get("CS_UNET_DRIVER", "python"))
         if driver not in ("python", "native"):
             raise ValueError(f"unet_driver must be 'python' or 'native', got {driver!r}")
@@ -104,10 +105,15 @@ class SDFusionText2ShapeModel:
         self.init_diffusion_params(uc_scale=3., df_model_params=df_conf.model.params)
         self.ddim_sampler = DDIMSampler(self)
         ck = self.opt.network.get("vq_ckpt")
-        if ck is not None and Path(rp(ck)).exists():
+        mp = vq_conf.model.params
+        if driver == "native":
+            self.vqvae = NativeVQVAE(mp.ddconfig, mp.n_embed, mp.embed_dim, device=self.device)
+            if ck is not None and Path(rp(ck)).exists():
+                vsd = torch.load(rp(ck), map_location="cpu")
+                self.vqvae.load_state_dict(vsd["vqvae"] if "vqvae" in vsd else vsd)
+        elif ck is not None and Path(rp(ck)).exists():
             self.vqvae = load_vqvae(vq_conf, rp(ck), device=str(self.device))
         else:   # weights to be supplied through load_state_dict (e.g. a full checkpoint's 'vqvae' entry)
-            mp = vq_conf.model.params
             self.vqvae = VQVAE(mp.ddconfig, mp.n_embed, mp.embed_dim, device=self.device)
         self.df_module = self.df
         self.vqvae_module = self.vqvae

@@ -331,6 +331,40 @@ int cs_unet_step(const cs_unet* u, const void* arena, const float* x_ncdhw, cons
                  const float* ctxvec, float* eps_ncdhw, int nb_x, int cfg_pairs, void* workspace,
                  int64_t workspace_bytes, cs_stream_t stream);
 
+/*
+ * Whole-decode driver: VQVAE.decode_no_quant / decode (vqvae_networks/network.py:90-103) -- nearest-code
+ * quantisation (quantizer.py:76-84), post_quant_conv, Decoder3D (vqvae_modules.py:292-409) -- as ONE call over a
+ * packed weight arena; same ownership rules as cs_unet_* (host-only plan, caller-owned raw / arena / workspace).
+ *   latent_ncdhw : [nb][embed_dim][g][g][g], g = resolution >> (n_mult - 1)   (3 x 16^3 for config/vqvae_snet.yaml)
+ *   sdf_ncdhw    : [nb][out_ch][resolution]^3
+ *   quantize     : 1 = decode_no_quant(h) (despite its name the reference quantises first, network.py:97-101);
+ *                  0 = decode(quant) / force_not_quantize.  code_indices: int64 [nb * g^3] or NULL.
+ * The parameter table lists the decode-side state_dict entries of the reference VQVAE (decoder.*,
+ * quantize.embedding.weight, post_quant_conv.*).
+ */
+typedef struct CsVqvaeConfig {
+  int32_t ch, out_ch;
+  int32_t n_mult;
+  int32_t ch_mult[8];
+  int32_t num_res_blocks, z_channels, resolution;
+  int32_t n_embed, embed_dim;
+  int32_t math;
+} CsVqvaeConfig;
+typedef struct cs_vqvae cs_vqvae;
+
+int cs_vqvae_create(const CsVqvaeConfig* cfg, cs_vqvae** out);
+void cs_vqvae_destroy(cs_vqvae* u);
+int cs_vqvae_param_count(const cs_vqvae* u);
+int cs_vqvae_param_info(const cs_vqvae* u, int i, const char** name, int64_t shape5[5], int* ndim,
+                        int64_t* raw_offset_bytes);
+int64_t cs_vqvae_raw_bytes(const cs_vqvae* u);
+int64_t cs_vqvae_arena_bytes(const cs_vqvae* u);
+int cs_vqvae_pack(cs_vqvae* u, const void* raw_dev, void* arena_dev, cs_stream_t stream);
+int64_t cs_vqvae_workspace_bytes(const cs_vqvae* u, int nb);
+int cs_vqvae_decode(const cs_vqvae* u, const void* arena, const float* latent_ncdhw, float* sdf_ncdhw,
+                    int64_t* code_indices, int nb, int quantize, void* workspace, int64_t workspace_bytes,
+                    cs_stream_t stream);
+
 /* Library / device self-description. */
 int cs_abi_version(void);
 

@@ -27,7 +27,7 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(dll, s), f"{s} declared in the header but not exported"
         assert s in lib.SIGNATURES, f"{s} has no ctypes signature"
     assert set(lib.SIGNATURES) == set(syms)
-    assert dll.cs_abi_version() == lib.ABI_VERSION == 5
+    assert dll.cs_abi_version() == lib.ABI_VERSION == 6
 
 
 def test_struct_layout_matches_header():
@@ -153,7 +153,8 @@ def test_every_entry_rejects_null_arguments_without_touching_the_device():
     from commonscenes_amd import lib
     dll = lib.load()
     skip = {"cs_abi_version", "cs_groupnorm_ws_bytes", "cs_unet_destroy", "cs_unet_param_count", "cs_unet_raw_bytes",
-            "cs_unet_arena_bytes", "cs_unet_context_floats"}
+            "cs_unet_arena_bytes", "cs_unet_context_floats", "cs_vqvae_destroy", "cs_vqvae_param_count",
+            "cs_vqvae_raw_bytes", "cs_vqvae_arena_bytes"}
     checked = 0
     for name, (res, args) in lib.SIGNATURES.items():
         if name in skip:
@@ -204,3 +205,16 @@ def test_conv_gemm_descriptor_validation():
     big = desc(nb=2, dout=16, hout=4, wout=4, cin=672, cout=672, kd=3, kh=3, kw=3, math=lib.MATH_F16X3)
     assert dll.cs_conv_gemm_plan(C.byref(big), C.byref(sk), C.byref(ws)) == 0
     assert sk.value == 22 and ws.value == 22 * 512 * 672 * 4
+
+
+def test_vqvae_plan_is_host_only_and_lists_the_decode_side_state_dict():
+    from commonscenes_amd import lib as L
+    from commonscenes_amd.vqvae import vqvae_param_shapes
+    from commonscenes_amd.vqvae_native import NativeVQVAE
+    from oracle.ref_torch import VQ_FULL
+    n = NativeVQVAE(VQ_FULL, 8192, 3, device="cpu")
+    assert list(n.shapes.items()) == list(vqvae_param_shapes(VQ_FULL, 8192, 3).items())
+    lib = L.load()
+    assert lib.cs_vqvae_arena_bytes(n._h) > 0
+    w1, w8 = lib.cs_vqvae_workspace_bytes(n._h, 1), lib.cs_vqvae_workspace_bytes(n._h, 8)
+    assert 0 < w1 < w8 < 64 * 2 ** 30

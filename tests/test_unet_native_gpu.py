@@ -162,3 +162,28 @@ def test_native_driver_concat_family(math):
     assert torch.equal(a, b)
     c2 = torch.cat([c.flip(0), c])
     assert torch.equal(py.forward_cfg(x, t, c2), nat.forward_cfg(x, t, c2))
+
+
+def test_product_model_with_native_drivers_equals_python_drivers(tmp_path, monkeypatch):
+    """CS_UNET_DRIVER=native: Sg2ScVAEModel.sample(gen_shape=True) through cs_unet_step + cs_vqvae_decode equals the
+    Python-sequenced run bit for bit (8 objects, mini-batches 7 + 1, 2 DDIM steps)."""
+    import test_model_gpu as T
+    g = T._g("e2e_small")
+    outs = []
+    for drv in ("python", "native"):
+        monkeypatch.setenv("CS_UNET_DRIVER", drv)
+        m = T._scene(tmp_path)
+        assert type(m.Diff.df).__name__ == ("NativeDiffusionUNet" if drv == "native" else "DiffusionUNet")
+        assert type(m.Diff.vqvae).__name__ == ("NativeVQVAE" if drv == "native" else "VQVAE")
+        O = g["objs"].shape[0]
+        dec_sdfs = torch.zeros(O, 1, 4, 4, 4)
+        dec_sdfs[torch.from_numpy(g["dec_sdfs_nonzero"])] = 1.0
+        m.Diff.mini_B = 7
+        boxes, gen = m.sample(None, np.zeros(64), np.eye(64), torch.from_numpy(g["objs"]), torch.from_numpy(g["triples"]),
+                              dec_sdfs, torch.from_numpy(g["text_feats"]), torch.from_numpy(g["rel_feats"]),
+                              gen_shape=True, z=torch.from_numpy(g["z"]), x_T=torch.from_numpy(g["x_T"]), ddim_steps=2)
+        torch.cuda.synchronize()
+        outs.append(gen)
+    assert torch.isfinite(outs[1]).all() and torch.equal(outs[0], outs[1])
+    sub, ref = outs[1][:, :, ::2, ::2, ::2], torch.from_numpy(g["gen_sdf_sub"])
+    assert sorted(rel_l2(sub[i], ref[i]) for i in range(8))[5] < 1e-4

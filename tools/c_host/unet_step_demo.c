@@ -53,7 +53,7 @@ int main(int argc, char** argv) {
   cfg.num_heads = 8; cfg.context_dim = 1280; cfg.d = cfg.h = cfg.w = 16;
   cfg.math = CS_MATH_F16X3; cfg.use_spatial_transformer = 1; cfg.dims = 3;
 
-  if (cs_abi_version() < 5) { fprintf(stderr, "library ABI %d too old\n", cs_abi_version()); return 1; }
+  if (cs_abi_version() < 6) { fprintf(stderr, "library ABI %d too old\n", cs_abi_version()); return 1; }
   cs_unet* u = NULL;
   CHECK(cs_unet_create(&cfg, &u));
   hipStream_t st;
