@@ -29,3 +29,4 @@ def test_c_host_drives_cs_unet_step(tmp_path, width, objects):
     r = subprocess.run([str(exe), str(width), str(objects)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "ok: width" in r.stdout and "guidance-pair entry vs duplicated batch" in r.stdout
+    assert f"decode: {objects} x 64^3 SDF" in r.stdout

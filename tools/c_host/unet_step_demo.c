@@ -1,7 +1,7 @@
 /*
  * A host with no Python and no torch driving the whole-forward entry point of libcommonscenes_hip.so:
  * the sequence INTEGRATION.md section B.1 describes (plan -> raw parameters -> pack -> context -> step -> fused
- * guidance + DDIM update), on synthetic weights (cs_synth_fill).  It checks what a C caller can check on its own:
+ * guidance + DDIM update -> cs_vqvae_decode), on synthetic weights (cs_synth_fill).  It checks what a C caller can check on its own:
  *   - every call returns CS_OK and the outputs are finite;
  *   - two runs produce the same bits (no hidden state, deterministic kernels);
  *   - the guidance-pair entry (cfg_pairs = 1: shared (x, t), contexts [uc; c]) equals the duplicated batch
@@ -142,6 +142,43 @@ int main(int argc, char** argv) {
   CHECK(hipMemcpyAsync(h1, xprev, sizeof(float) * B * per, hipMemcpyDeviceToHost, st));
   CHECK(hipStreamSynchronize(st));
   if (!all_finite(h1, (size_t)B * per)) { fprintf(stderr, "non-finite x_prev\n"); return 1; }
+  /* ... and the downstream end: VQVAE.decode_no_quant of the updated latents (config/vqvae_snet.yaml) */
+  CsVqvaeConfig vc;
+  memset(&vc, 0, sizeof(vc));
+  vc.ch = 64; vc.out_ch = 1; vc.n_mult = 3; vc.ch_mult[0] = 1; vc.ch_mult[1] = 2; vc.ch_mult[2] = 4;
+  vc.num_res_blocks = 1; vc.z_channels = 3; vc.resolution = 64; vc.n_embed = 8192; vc.embed_dim = 3;
+  vc.math = CS_MATH_F16X3;
+  cs_vqvae* vq = NULL;
+  CHECK(cs_vqvae_create(&vc, &vq));
+  void *vraw = NULL, *varena = NULL, *vws = NULL;
+  CHECK(hipMalloc(&vraw, (size_t)cs_vqvae_raw_bytes(vq)));
+  CHECK(hipMalloc(&varena, (size_t)cs_vqvae_arena_bytes(vq)));
+  for (int i = 0; i < cs_vqvae_param_count(vq); ++i) {
+    const char* name; int64_t shape[5], off; int nd;
+    CHECK(cs_vqvae_param_info(vq, i, &name, shape, &nd, &off));
+    int64_t n = 1, fan_in = 1;
+    for (int k = 0; k < nd; ++k) n *= shape[k];
+    for (int k = 1; k < nd; ++k) fan_in *= shape[k];
+    const int gamma = nd == 1 && strstr(name, "norm") && strstr(name, ".weight");
+    const int book = strstr(name, "embedding") != NULL;
+    CHECK(cs_synth_fill((float*)((char*)vraw + off), n, fnv1a(name), book ? 1.5 : (nd == 1 ? (gamma ? 0.2 : 0.1) : sqrt(3.0 / (double)fan_in)),
+                        gamma ? 1.0 : 0.0, st));
+  }
+  CHECK(cs_vqvae_pack(vq, vraw, varena, st));
+  const int64_t vwsb = cs_vqvae_workspace_bytes(vq, B);
+  if (vwsb <= 0) { fprintf(stderr, "cs_vqvae_workspace_bytes -> %lld\n", (long long)vwsb); return 1; }
+  CHECK(hipMalloc(&vws, (size_t)vwsb));
+  float* sdf;
+  const size_t nsdf = (size_t)B * 64 * 64 * 64;
+  CHECK(hipMalloc((void**)&sdf, sizeof(float) * nsdf));
+  CHECK(cs_vqvae_decode(vq, varena, xprev, sdf, NULL, B, 1, vws, vwsb, st));
+  float* hs = (float*)malloc(sizeof(float) * nsdf);
+  CHECK(hipMemcpyAsync(hs, sdf, sizeof(float) * nsdf, hipMemcpyDeviceToHost, st));
+  CHECK(hipStreamSynchronize(st));
+  if (!all_finite(hs, nsdf)) { fprintf(stderr, "non-finite SDF\n"); return 1; }
+  printf("decode: %d x 64^3 SDF, workspace %.1f MB\n", B, vwsb / 1e6);
+  cs_vqvae_destroy(vq);
+
   double rms = 0;
   for (size_t i = 0; i < ne; ++i) rms += (double)h2[i] * h2[i];
   printf("ok: width %d, %d objects, eps rms %.4f, workspace %.1f MB\n", width, B, sqrt(rms / ne), wsb / 1e6);
