@@ -29,7 +29,9 @@ __device__ __forceinline__ int vpos(int j) {   // swap bits 2 and 3
   return (j & ~12) | ((j & 4) << 1) | ((j & 8) >> 1);
 }
 
-template <int DB, int KT>
+// X1 = plain fp16 operands (hi halves only: one MFMA per product instead of three) -- the reduced-precision
+// "fp16 MFMA attention" option of BASELINE configs[4]; not the default, outside the fp32 parity gates.
+template <int DB, int KT, bool X1>
 __global__ __launch_bounds__(256) void attn_f16x3_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                          const float* __restrict__ v, float* __restrict__ out,
                                                          int nq, int nk, int heads, int dh, int ldq, int ldk,
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(256) void attn_f16x3_kernel(const float* __restrict
         split1(kr[i].z * QK_SCALE, a, c); hi[2] = a; lo[2] = c;
         split1(kr[i].w * QK_SCALE, a, c); hi[3] = a; lo[3] = c;
         *reinterpret_cast<h4*>(Kh + k_l[i]) = hi;
-        *reinterpret_cast<h4*>(Kl + k_l[i]) = lo;
+        if constexpr (!X1) *reinterpret_cast<h4*>(Kl + k_l[i]) = lo;
       }
       if (v_l[i] >= 0) {
         const float x[4] = {vr[i].x, vr[i].y, vr[i].z, vr[i].w};
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(256) void attn_f16x3_kernel(const float* __restrict
           _Float16 a, c;
           split1(x[e] * QK_SCALE, a, c);
           Vh[v_l[i] + e * LDV] = a;
-          Vl[v_l[i] + e * LDV] = c;
+          if constexpr (!X1) Vl[v_l[i] + e * LDV] = c;
         }
       }
     }
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(256) void attn_f16x3_kernel(const float* __restrict
         split1(kv.z * QK_SCALE, a, c); hi[2] = a; lo[2] = c;
         split1(kv.w * QK_SCALE, a, c); hi[3] = a; lo[3] = c;
         *reinterpret_cast<h4*>(Kh + j * LDK + c4 * 4) = hi;
-        *reinterpret_cast<h4*>(Kl + j * LDK + c4 * 4) = lo;
+        if constexpr (!X1) *reinterpret_cast<h4*>(Kl + j * LDK + c4 * 4) = lo;
       }
       for (int u = tid; u < KT * dh4; u += 256) {          // V: unit = (4 channels, key j), key fastest
         const int c4 = u / KT;
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(256) void attn_f16x3_kernel(const float* __restrict
           _Float16 a, c;
           split1(x[i] * QK_SCALE, a, c);
           Vh[(c4 * 4 + i) * LDV + pj] = a;
-          Vl[(c4 * 4 + i) * LDV + pj] = c;
+          if constexpr (!X1) Vl[(c4 * 4 + i) * LDV + pj] = c;
         }
       }
     }
@@ -217,9 +219,11 @@ __global__ __launch_bounds__(256) void attn_f16x3_kernel(const float* __restrict
       for (int jb = 0; jb < JB; ++jb) {
         const int off = (jb * 32 + l31) * LDK + 16 * t + 8 * half;
         const h8 kh = *reinterpret_cast<const h8*>(Kh + off);
-        const h8 kl = *reinterpret_cast<const h8*>(Kl + off);
-        sacc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[t], sacc[jb], 0, 0, 0);
-        sacc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[t], sacc[jb], 0, 0, 0);
+        if constexpr (!X1) {
+          const h8 kl = *reinterpret_cast<const h8*>(Kl + off);
+          sacc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[t], sacc[jb], 0, 0, 0);
+          sacc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[t], sacc[jb], 0, 0, 0);
+        }
         sacc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[t], sacc[jb], 0, 0, 0);
       }
 
@@ -274,9 +278,11 @@ __global__ __launch_bounds__(256) void attn_f16x3_kernel(const float* __restrict
         for (int d = 0; d < DB; ++d) {
           const int off = (32 * d + l31) * LDV + 32 * jb + 16 * qq + 8 * half;
           const h8 vh = *reinterpret_cast<const h8*>(Vh + off);
-          const h8 vl = *reinterpret_cast<const h8*>(Vl + off);
-          oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, oacc[d], 0, 0, 0);
-          oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, oacc[d], 0, 0, 0);
+          if constexpr (!X1) {
+            const h8 vl = *reinterpret_cast<const h8*>(Vl + off);
+            oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, oacc[d], 0, 0, 0);
+            oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, oacc[d], 0, 0, 0);
+          }
           oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, oacc[d], 0, 0, 0);
         }
       }
@@ -303,7 +309,7 @@ __global__ __launch_bounds__(256) void attn_f16x3_kernel(const float* __restrict
   }
 }
 
-template <int DB, int KT>
+template <int DB, int KT, bool X1>
 int launch_attn16(const float* q, const float* k, const float* v, float* out, int nb, int nq, int nk, int heads,
                   int dh, int ldq, int ldk, int ldv, int ldo, float scale, hipStream_t s) {
   constexpr int DP = 32 * DB;
@@ -311,7 +317,7 @@ int launch_attn16(const float* q, const float* k, const float* v, float* out, in
   const int qtiles = (nq + 127) / 128;
   const int64_t grid = (int64_t)qtiles * heads * nb;
   if (grid > 0x7fffffffLL) return CS_EINVAL;
-  auto kern = attn_f16x3_kernel<DB, KT>;
+  auto kern = attn_f16x3_kernel<DB, KT, X1>;
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
@@ -324,19 +330,31 @@ int launch_attn16(const float* q, const float* k, const float* v, float* out, in
 
 }  // namespace
 
-extern "C" int cs_attn_selfattn_f16x3(const float* q, const float* k, const float* v, float* out, int nb, int nq,
-                                      int nk, int heads, int dh, int ldq, int ldk, int ldv, int ldo, float scale,
-                                      cs_stream_t stream) {
+template <bool X1>
+static int attn16_dispatch(const float* q, const float* k, const float* v, float* out, int nb, int nq, int nk, int heads,
+                           int dh, int ldq, int ldk, int ldv, int ldo, float scale, cs_stream_t stream) {
   if (!q || !k || !v || !out || nb <= 0 || nq <= 0 || nk <= 0 || heads <= 0 || dh <= 0) return CS_EINVAL;
   if ((dh & 3) || (ldq & 3) || (ldk & 3) || (ldv & 3) || (ldo & 3)) return CS_EINVAL;
   if (ldq < heads * dh || ldk < heads * dh || ldv < heads * dh || ldo < heads * dh) return CS_EINVAL;
   if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || ((uintptr_t)out & 15))
     return CS_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  if (dh <= 32) return launch_attn16<1, 64>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, s);
-  if (dh <= 64) return launch_attn16<2, 64>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, s);
-  if (dh <= 96) return launch_attn16<3, 64>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, s);
-  if (dh <= 128) return launch_attn16<4, 64>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, s);
-  if (dh <= 256) return launch_attn16<8, 32>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, s);
+  if (dh <= 32) return launch_attn16<1, 64, X1>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, s);
+  if (dh <= 64) return launch_attn16<2, 64, X1>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, s);
+  if (dh <= 96) return launch_attn16<3, 64, X1>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, s);
+  if (dh <= 128) return launch_attn16<4, 64, X1>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, s);
+  if (dh <= 256) return launch_attn16<8, 32, X1>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, s);
   return CS_EINVAL;
+}
+
+extern "C" int cs_attn_selfattn_f16x3(const float* q, const float* k, const float* v, float* out, int nb, int nq,
+                                      int nk, int heads, int dh, int ldq, int ldk, int ldv, int ldo, float scale,
+                                      cs_stream_t stream) {
+  return attn16_dispatch<false>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, stream);
+}
+
+extern "C" int cs_attn_selfattn_f16(const float* q, const float* k, const float* v, float* out, int nb, int nq,
+                                    int nk, int heads, int dh, int ldq, int ldk, int ldv, int ldo, float scale,
+                                    cs_stream_t stream) {
+  return attn16_dispatch<true>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, stream);
 }

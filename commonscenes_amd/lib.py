@@ -17,12 +17,13 @@ import torch  # noqa: F401
 
 from .build import LIB_PATH
 
-ABI_VERSION = 6      # cs_abi_version() of the library this module's SIGNATURES table describes
+ABI_VERSION = 7      # cs_abi_version() of the library this module's SIGNATURES table describes
 CS_OK = 0
 CS_EINVAL = -22
 CS_ENOMEM = -12
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_GELU, ACT_GEGLU = 0, 1, 2, 3, 4
 MATH_FP32, MATH_F16X3 = 0, 1
+MATH_F16 = 2        # attention only: plain fp16 operands (reduced precision, opt-in)
 # The numerics mode model classes start in: F16X3 (fp32-grade, the benchmarked mode) unless CS_MATH=fp32 asks for the
 # fp32-input MFMA kernels.  `set_math()` switches per model.
 DEFAULT_MATH = MATH_FP32 if os.environ.get("CS_MATH", "f16x3").lower() == "fp32" else MATH_F16X3
@@ -92,6 +93,7 @@ SIGNATURES = {
     "cs_layernorm": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _fl, _s]),
     "cs_attn_selfattn": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _s]),
     "cs_attn_selfattn_f16x3": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _s]),
+    "cs_attn_selfattn_f16": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _s]),
     "cs_geglu": (_i, [_f, _f, _i, _i, _i, _i, _s]),
     "cs_copy_rows": (_i, [_f, _f, _l, _i, _i, _i, _s]),
     "cs_add_rowvec": (_i, [_f, _f, _l, _i, _i, _i, _i, _s]),

@@ -361,7 +361,8 @@ def attention(q: Tensor, k: Tensor, v: Tensor, heads: int, scale: float, out: Op
     if out is None:
         out = torch.empty((nb, nq, cq), dtype=torch.float32, device=q.device)
     _, _, ldo = rows_ld(out, "out")
-    fn = L.load().cs_attn_selfattn_f16x3 if math == L.MATH_F16X3 else L.load().cs_attn_selfattn
+    lib = L.load()
+    fn = {L.MATH_F16X3: lib.cs_attn_selfattn_f16x3, L.MATH_F16: lib.cs_attn_selfattn_f16}.get(math, lib.cs_attn_selfattn)
     L.check(fn(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo,
                scale, _stream()), "cs_attn_selfattn")
     return out

@@ -193,6 +193,7 @@ class DiffusionUNet:
         self._packed = None
         self.training = False
         self.math = L.DEFAULT_MATH      # F16X3 unless CS_MATH=fp32
+        self.attn_math: Optional[int] = None        # None: follow self.math; L.MATH_F16: plain-fp16 attention (opt-in)
         self.trace: Optional[Dict[str, Tensor]] = None   # set to {} to capture per-block outputs (tests)
 
     # ---- nn.Module-like surface -----------------------------------------------------------
@@ -243,6 +244,13 @@ class DiffusionUNet:
         if m != self.math:
             self.math = m
             self._packed = None
+        return self
+
+    def set_attention_math(self, mode) -> "DiffusionUNet":
+        """None / 'same': attention follows set_math().  'f16': self-attention on plain fp16 operands (one MFMA pass,
+        fp32 softmax / accumulate) -- the "fp16 MFMA attention" option of BASELINE configs[4]; reduced precision,
+        outside the fp32 parity gates."""
+        self.attn_math = {None: None, "same": None, "f16": L.MATH_F16}[mode]
         return self
 
     def num_parameters(self) -> int:
@@ -391,7 +399,7 @@ class DiffusionUNet:
         xn = ops.groupnorm(x, sd[p + ".norm.weight"], sd[p + ".norm.bias"], 32, 1e-5, L.ACT_NONE)
         qkv = ops.linear(xn.view(nb, n, c), pk[p + ".qkv"], math=self.math)
         a = ops.attention(qkv[..., 0:c], qkv[..., c:2 * c], qkv[..., 2 * c:3 * c], heads, (c // heads) ** -0.5,
-                          math=self.math)
+                          math=self.attn_math if self.attn_math is not None else self.math)
         out = ops.linear(a, pk[p + ".proj_out"], res=x.view(nb, n, c), math=self.math)
         return out.view(nb, d, h, w, c)
 
@@ -407,7 +415,7 @@ class DiffusionUNet:
         t0 = ops.linear(xn.view(nb, n, c), pk[p + ".proj_in"], math=self.math)
         n1 = ops.layernorm(t0, sd[t + ".norm1.weight"], sd[t + ".norm1.bias"])
         qkv = ops.linear(n1, pk[t + ".attn1.qkv"], math=self.math)
-        a = ops.attention(qkv[..., 0:c], qkv[..., c:2 * c], qkv[..., 2 * c:3 * c], heads, dh ** -0.5, math=self.math)
+        a = ops.attention(qkv[..., 0:c], qkv[..., c:2 * c], qkv[..., 2 * c:3 * c], heads, dh ** -0.5, math=self.attn_math if self.attn_math is not None else self.math)
         if isinstance(ctx, tuple):
             # one context token: softmax over one key == 1, attn2(x) = to_out(to_v(ctx)) for every
             # query row -> a per-sample row vector folded into the attn1 output GEMM.
@@ -418,7 +426,7 @@ class DiffusionUNet:
             q2 = ops.linear(n2, pk[t + ".attn2.to_q"], math=self.math)
             k2 = ops.linear(ctx, pk[t + ".attn2.to_k"], math=self.math)
             vv2 = ops.linear(ctx, pk[t + ".attn2.to_v"], math=self.math)
-            a2 = ops.attention(q2, k2, vv2, heads, dh ** -0.5, math=self.math)
+            a2 = ops.attention(q2, k2, vv2, heads, dh ** -0.5, math=self.attn_math if self.attn_math is not None else self.math)
             t1 = ops.linear(a2, pk[t + ".attn2.to_out.0"], res=t1a, math=self.math)
         n3 = ops.layernorm(t1, sd[t + ".norm3.weight"], sd[t + ".norm3.bias"])
         if (t + ".ff.geglu") in pk:      # GEGLU gate fused into the projection GEMM's epilogue

@@ -178,6 +178,13 @@ int cs_attn_selfattn_f16x3(const float* q, const float* k, const float* v, float
                            int nk, int heads, int dh, int ldq, int ldk, int ldv, int ldo, float scale,
                            cs_stream_t stream);
 
+/* Same contract, PLAIN fp16 operands on the fp16 MFMA (one pass instead of three; fp32 softmax and accumulation):
+ * the "fp16 MFMA attention" option BASELINE configs[4] names.  Reduced precision (~3e-4 relative on the attention
+ * output) -- opt-in, outside the fp32 parity gates, never the default. */
+int cs_attn_selfattn_f16(const float* q, const float* k, const float* v, float* out, int nb, int nq,
+                         int nk, int heads, int dh, int ldq, int ldk, int ldv, int ldo, float scale,
+                         cs_stream_t stream);
+
 /* GEGLU gate: out[m][j] = x[m][j] * gelu(x[m][h + j])  (attention.py:44-46). */
 int cs_geglu(const float* x, float* out, int m, int h, int ldx, int ldo, cs_stream_t stream);
 

@@ -18,7 +18,7 @@ for n, c, heads in ((1024, 448, 8), (256, 672, 8), (512, 448, 8), (64, 672, 8)):
     q, k, v = qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:]
     dh = c // heads
     line = f"N={n:5d} dh={dh:3d} nb={a.batch}: "
-    for name, math in (("fp32", L.MATH_FP32), ("f16x3", L.MATH_F16X3)):
+    for name, math in (("fp32", L.MATH_FP32), ("f16x3", L.MATH_F16X3), ("f16(opt-in)", L.MATH_F16)):
         ops.attention(q, k, v, heads, dh ** -0.5, math=math)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
