@@ -227,10 +227,15 @@ extern "C" int cs_vqvae_pack(cs_vqvae* u, const void* raw_dev, void* arena_dev, 
   return pack_plan(u, raw_dev, arena_dev, stream);
 }
 
+// Objects decode independently; a 64^3 x 128-channel activation is 134 MB per object and the GEMM kernels address a
+// tensor through a 32-bit buffer descriptor (< 4 GiB), so a large batch is decoded in slices of this many objects
+// (which also bounds the workspace).
+constexpr int MAX_DECODE_BATCH = 16;
+
 extern "C" int64_t cs_vqvae_workspace_bytes(const cs_vqvae* u, int nb) {
   if (!u || nb <= 0) return CS_EINVAL;
   VExec e(*u, nullptr, nullptr, 0, true, nullptr);
-  const int rc = decode(e, nullptr, nullptr, nullptr, nb, 1);
+  const int rc = decode(e, nullptr, nullptr, nullptr, nb < MAX_DECODE_BATCH ? nb : MAX_DECODE_BATCH, 1);
   return rc != CS_OK ? rc : e.peak;
 }
 
@@ -239,6 +244,15 @@ extern "C" int cs_vqvae_decode(const cs_vqvae* u, const void* arena, const float
                                cs_stream_t stream) {
   if (!u || !u->packed || !arena || !latent_ncdhw || !sdf_ncdhw || !workspace || nb <= 0) return CS_EINVAL;
   if (((uintptr_t)workspace & 15) || ((uintptr_t)arena & 15)) return CS_EINVAL;
-  VExec e(*u, arena, workspace, workspace_bytes, false, (hipStream_t)stream);
-  return decode(e, latent_ncdhw, sdf_ncdhw, code_indices, nb, quantize);
+  const CsVqvaeConfig& c = u->cfg;
+  const int64_t g3 = (int64_t)u->grid * u->grid * u->grid;
+  const int64_t r3 = (int64_t)c.resolution * c.resolution * c.resolution;
+  for (int b0 = 0; b0 < nb; b0 += MAX_DECODE_BATCH) {
+    const int n = nb - b0 < MAX_DECODE_BATCH ? nb - b0 : MAX_DECODE_BATCH;
+    VExec e(*u, arena, workspace, workspace_bytes, false, (hipStream_t)stream);   // slices reuse the workspace in
+    const int rc = decode(e, latent_ncdhw + b0 * c.embed_dim * g3,              // stream order
+                          sdf_ncdhw + b0 * c.out_ch * r3, code_indices ? code_indices + b0 * g3 : nullptr, n, quantize);
+    if (rc != CS_OK) return rc;
+  }
+  return CS_OK;
 }

@@ -226,11 +226,18 @@ class VQVAE:
         idx, zq = ops.vq_lookup(zl, self._sd["quantize.embedding.weight"])
         return ops.ndhwc_to_nchw(zq, c=self.embed_dim), idx
 
+    # Objects decode independently; a 64^3 x 128-channel activation is 134 MB per object and the GEMM kernels address
+    # a tensor through a 32-bit buffer descriptor (< 4 GiB), so large batches are decoded in slices of this many.
+    MAX_DECODE_BATCH = 16
+
     @torch.no_grad()
     def decode(self, quant: Tensor) -> Tensor:
         """network.py:90-93: post_quant_conv + decoder on an already-quantised latent (NCDHW)."""
         if self._packed is None:
             self._pack()
+        if quant.shape[0] > self.MAX_DECODE_BATCH:
+            return torch.cat([self.decode(quant[i:i + self.MAX_DECODE_BATCH])
+                              for i in range(0, quant.shape[0], self.MAX_DECODE_BATCH)], dim=0)
         zl = ops.nchw_to_ndhwc(quant.to(torch.float32), cpad=4)
         return self._decode_cl(zl)
 
@@ -243,6 +250,15 @@ class VQVAE:
         """network.py:95-103: (despite the name) quantise to the nearest code, then decode."""
         if self._packed is None:
             self._pack()
+        if h.shape[0] > self.MAX_DECODE_BATCH:
+            outs, idxs = [], []
+            for i in range(0, h.shape[0], self.MAX_DECODE_BATCH):
+                outs.append(self.decode_no_quant(h[i:i + self.MAX_DECODE_BATCH], force_not_quantize))
+                if not force_not_quantize:
+                    idxs.append(self.last_indices)
+            if idxs:
+                self.last_indices = torch.cat(idxs)
+            return torch.cat(outs, dim=0)
         zl = ops.nchw_to_ndhwc(h.to(torch.float32), cpad=4)
         if not force_not_quantize:
             idx, zl = ops.vq_lookup(zl, self._sd["quantize.embedding.weight"])

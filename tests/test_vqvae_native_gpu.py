@@ -63,3 +63,18 @@ def test_native_vq_workspace_checked():
     assert lib.cs_vqvae_decode(*args, need, s) == 0
     torch.cuda.synchronize()
     assert torch.isfinite(out).all()
+
+
+def test_decode_of_a_32_object_batch_is_sliced():
+    """BASELINE configs[2] decodes 32 objects: a 64^3 x 128-channel activation of 32 objects is 4.3 GB, past the 4 GiB
+    buffer-descriptor window, so both sequencers decode in slices of 16 -- per object identical to a small batch."""
+    from commonscenes_amd import synth
+    py, nat = _pair("f16x3")
+    lat = synth.gaussian_like("big:l", (32, 3, 16, 16, 16), scale=0.8).cuda()
+    a = py.decode_no_quant(lat)
+    b = nat.decode_no_quant(lat)
+    torch.cuda.synchronize()
+    assert a.shape == (32, 1, 64, 64, 64) and torch.isfinite(a).all()
+    assert torch.equal(a, b) and torch.equal(py.last_indices, nat.last_indices)
+    one = py.decode_no_quant(lat[21:22])
+    assert torch.equal(one[0], a[21])
