@@ -18,18 +18,21 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--objects", type=int, default=32)
 ap.add_argument("--steps", type=int, default=100)
 ap.add_argument("--driver", default=os.environ.get("CS_UNET_DRIVER", "python"))
+ap.add_argument("--family", choices=["crossattn", "concat"], default="crossattn",
+                help="config/v2_full.yaml or config/v2_full_concat.yaml")
 a = ap.parse_args()
 os.environ["CS_UNET_DRIVER"] = a.driver
 from commonscenes_amd import synth
 from commonscenes_amd.scene import Sg2ScVAEModel, scene_param_shapes
 from commonscenes_amd.unet import unet_param_shapes
 from commonscenes_amd.vqvae import vqvae_param_shapes
-from oracle.ref_torch import UNET_FULL, VQ_FULL
+from oracle.ref_torch import UNET_CONCAT_FULL, UNET_FULL, VQ_FULL
 
 tmp = Path(tempfile.mkdtemp())
-ucfg = dict(UNET_FULL, dims=3, use_spatial_transformer=True)
+concat = a.family == "concat"
+ucfg = dict(UNET_CONCAT_FULL) if concat else dict(UNET_FULL, dims=3, use_spatial_transformer=True)
 (tmp / "df.yaml").write_text(yaml.safe_dump(dict(
-    model=dict(params=dict(linear_start=0.00085, linear_end=0.012, conditioning_key="crossattn", timesteps=1000)),
+    model=dict(params=dict(linear_start=0.00085, linear_end=0.012, conditioning_key=a.family, timesteps=1000)),
     unet=dict(params={k: (list(v) if isinstance(v, tuple) else v) for k, v in ucfg.items()}))))
 (tmp / "vq.yaml").write_text(yaml.safe_dump(dict(model=dict(params=dict(embed_dim=3, n_embed=8192, ddconfig=dict(
     double_z=False, z_channels=3, resolution=64, in_channels=1, out_ch=1, ch=64, ch_mult=[1, 2, 4], num_res_blocks=1,
@@ -42,7 +45,8 @@ t0 = time.perf_counter()
 m = Sg2ScVAEModel(vocab, opt, diffusion_bs=16, embedding_dim=64, decoder_cat=True, mlp_normalization="batch",
                   gconv_num_layers=5, use_angles=True, distribution_before=True, use_E2=True, replace_latent=True,
                   num_box_params=6, residual=True, clip=True)
-m.load_state_dict(synth.synth_state_dict(scene_param_shapes(35, 16), device="cuda"))
+m.load_state_dict(synth.synth_state_dict(scene_param_shapes(35, 16, rel_dims=(1280, 4096) if concat else (960, 1280)),
+                                         device="cuda"))
 m.Diff.df.load_state_dict(synth.synth_state_dict(unet_param_shapes(ucfg), device="cuda"))
 m.Diff.vqvae.load_state_dict(synth.synth_state_dict(vqvae_param_shapes(VQ_FULL, 8192, 3), device="cuda"))
 torch.cuda.synchronize()
