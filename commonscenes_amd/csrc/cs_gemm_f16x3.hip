@@ -68,7 +68,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 template <int WMB, int WNB, int WAVES_M, int WAVES_N, bool PRE>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_kernel(const CsConvGemm p, int M, int tiles_n,
                                                               int taps_hw, int kw_, int kg_per_tap,
-                                                              unsigned x_bytes, unsigned w_bytes, int vec_epilogue,
+                                                              long long x_bytes, unsigned w_bytes, int vec_epilogue,
                                                               int splits) {
   constexpr int BM = 32 * WMB * WAVES_M;
   constexpr int BN = 32 * WNB * WAVES_N;
@@ -82,7 +82,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   constexpr int DUMP = NSTAGE * STAGE;             // 1 KB: where surplus DMA wave-instructions land
   constexpr int ROWBASE = DUMP + 1024;             // int32 [BM]: source row of the window origin
   constexpr int DELTA = ROWBASE + BM * 4;          // int16 [MAX_TAPS][BM]: source row - rowbase, or INVALID
-  constexpr int LDS_BYTES = DELTA + MAX_TAPS * BM * 2;
+  constexpr int ROWMIN = DELTA + MAX_TAPS * BM * 2;   // int32: smallest source row of the tile (descriptor window base)
+  constexpr int LDS_BYTES = ROWMIN + 16;
   constexpr short INVALID = (short)0x8000;
   // ---- DMA schedule: wave-instructions of 64 x 16 B ----
   constexpr int A_WI = BM / 16;                    // A wave-instructions per chunk
@@ -116,15 +117,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   const int m0 = tm * BM;
   const int n0 = tn * BN;
 
-  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t xlrs =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(PRE ? p.x_lo : (const void*)p.x), 0, x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, w_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_lo, 0, w_bytes, 0x00020000);
 
   // ---- source-row tables, built once per workgroup ----
   const int ntaps = p.kd * taps_hw;
   int* rowbase = reinterpret_cast<int*>(smem + ROWBASE);
+  int* rowmin = reinterpret_cast<int*>(smem + ROWMIN);
+  if (tid == 0) *rowmin = 0x7fffffff;
+  __syncthreads();
   short* delta = reinterpret_cast<short*>(smem + DELTA);
   {
     // NT / BM threads per output row: the row's (n, od, oh, ow) decomposition -- three integer divisions -- is done
@@ -146,7 +147,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
       const int ch = min(max(oh * p.sh - p.ph, 0), vhin - 1) >> p.uh;
       const int cw = min(max(ow * p.sw - p.pw, 0), vwin - 1) >> p.uw;
       const int base = ((n * p.din + cd) * p.hin + ch) * p.win + cw;
-      if (sub == 0) rowbase[row] = base;
+      if (sub == 0) {
+        rowbase[row] = base;
+        if (m < M) atomicMin(rowmin, base);      // not simply row 0: with upsampling / clamped borders a later row of
+      }                                          // a tile that starts mid-line can sit at a smaller source row
       const int vd0 = od * p.sd - p.pd, vh0 = oh * p.sh - p.ph, vw0 = ow * p.sw - p.pw;
       int t = 0;
       for (int kd_ = 0; kd_ < p.kd; ++kd_)
@@ -165,6 +169,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
     }
   }
   __syncthreads();
+
+  // The activation buffer descriptors are per workgroup: based at the smallest source row this tile can touch (every
+  // valid tap sits at or after its row's clamped window origin, so that is the minimum of rowbase over the tile's
+  // rows), with 32-bit offsets inside a window of a few MB.  The tensor itself may therefore be larger than
+  // the 4 GiB a single descriptor spans (288 GB of HBM: 200+ objects per batch at the 16^3 x 672-channel level).
+  const int row_lo = __builtin_amdgcn_readfirstlane(*rowmin);
+  const long long x_skip = (long long)row_lo * p.lda * (PRE ? 2 : 4);
+  const long long x_left = x_bytes - x_skip;
+  const unsigned x_win = x_left > 0xFFE00000LL ? 0xFFE00000u : (unsigned)x_left;
+  const __amdgpu_buffer_rsrc_t xrs =
+      __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.x + x_skip), 0, x_win, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xlrs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((const char*)(PRE ? p.x_lo : (const void*)p.x) + x_skip), 0, x_win, 0x00020000);
 
   const float a_scale = p.a_scale;
   const int chunks_per_tap = kg_per_tap >> 1;   // cin16 / 16
@@ -187,12 +204,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
       const int within = w % (A_WI / 2);
       const int row = 32 * within + (lane >> 1);
       a_rowidx[i] = row;
-      a_rowbase[i] = rowbase[row];
+      a_rowbase[i] = rowbase[row] - row_lo;
       a_piece[i] = (unsigned)(((lane & 1) ^ ((row >> 3) & 1)) * 8);
     } else {
       const int row = 16 * w + (lane >> 2);
       a_rowidx[i] = row;
-      a_rowbase[i] = rowbase[row];
+      a_rowbase[i] = rowbase[row] - row_lo;
       a_piece[i] = (unsigned)(((lane & 3) ^ ((row >> 2) & 3)) * 4);   // first channel of the piece
     }
   }
@@ -474,7 +491,7 @@ int launch16(const CsConvGemm& p, int M, int splits, hipStream_t stream) {
   const int64_t x_rows = (int64_t)p.nb * p.din * p.hin * p.win;
   const int64_t x_bytes = ((x_rows - 1) * p.lda + p.cin) * (PRE ? 2 : 4);
   const int64_t w_bytes = (int64_t)p.kd * p.kh * p.kw * kg_per_tap * p.cout * 16;
-  if (x_bytes > 0xFFE00000LL || w_bytes > 0xFFE00000LL) return CS_EINVAL;
+  if (w_bytes > 0xFFE00000LL) return CS_EINVAL;      // activations: per-workgroup windows, no 4 GiB limit
   // float4 epilogue needs 16-byte aligned rows in every operand it touches
   auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
   const int vec = (p.cout % 4 == 0) && (p.ldo % 4 == 0) && al16(p.out) && (!p.bias || al16(p.bias)) &&
@@ -486,7 +503,7 @@ int launch16(const CsConvGemm& p, int M, int splits, hipStream_t stream) {
     if (!vec || (WCOLS / 2) % 4 || p.cout % WCOLS || p.scale || p.rowvec || p.res) return CS_EINVAL;
   }
   CS_LAUNCH((conv_gemm_f16x3_kernel<WMB, WNB, WAVES_M, WAVES_N, PRE>), dim3((unsigned)nblk), dim3(64 * WAVES_M * WAVES_N), 0,
-            stream, p, M, tiles_n, p.kh * p.kw, p.kw, kg_per_tap, (unsigned)x_bytes, (unsigned)w_bytes, vec, splits);
+            stream, p, M, tiles_n, p.kh * p.kw, p.kw, kg_per_tap, (long long)x_bytes, (unsigned)w_bytes, vec, splits);
   CS_CHECK_LAUNCH();
   return CS_OK;
 }

@@ -227,9 +227,8 @@ extern "C" int cs_vqvae_pack(cs_vqvae* u, const void* raw_dev, void* arena_dev, 
   return pack_plan(u, raw_dev, arena_dev, stream);
 }
 
-// Objects decode independently; a 64^3 x 128-channel activation is 134 MB per object and the GEMM kernels address a
-// tensor through a 32-bit buffer descriptor (< 4 GiB), so a large batch is decoded in slices of this many objects
-// (which also bounds the workspace).
+// Objects decode independently; a 64^3 x 128-channel activation is 134 MB per object (4.3 GB at 32), so a large
+// batch is decoded in slices of this many objects, which bounds the workspace.
 constexpr int MAX_DECODE_BATCH = 16;
 
 extern "C" int64_t cs_vqvae_workspace_bytes(const cs_vqvae* u, int nb) {

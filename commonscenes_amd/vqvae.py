@@ -226,8 +226,8 @@ class VQVAE:
         idx, zq = ops.vq_lookup(zl, self._sd["quantize.embedding.weight"])
         return ops.ndhwc_to_nchw(zq, c=self.embed_dim), idx
 
-    # Objects decode independently; a 64^3 x 128-channel activation is 134 MB per object and the GEMM kernels address
-    # a tensor through a 32-bit buffer descriptor (< 4 GiB), so large batches are decoded in slices of this many.
+    # Objects decode independently; a 64^3 x 128-channel activation is 134 MB per object (4.3 GB at 32), so large
+    # batches are decoded in slices of this many, which bounds the workspace.
     MAX_DECODE_BATCH = 16
 
     @torch.no_grad()

@@ -304,3 +304,24 @@ def test_plain_fp16_attention_option_is_reported_not_gated():
     ea, eb = rel_l2(eps, torch.from_numpy(g["eps"])), rel_l2(base, torch.from_numpy(g["eps"]))
     print(f"UNet(small) rel-L2 vs reference: fp16 attention {ea:.2e}, default {eb:.2e}")
     assert eb < 1e-5 and ea < 5e-3
+
+
+def test_f16x3_conv_on_a_tensor_larger_than_4_gib():
+    """The activation descriptors are per-workgroup windows, so the tensor itself may exceed the 4 GiB a single
+    buffer descriptor spans (e.g. 200+ objects per batch at the 16^3 x 672-channel level).  Checked on the tail of
+    a 4.6 GiB tensor against the same conv run on that tail alone (bit-identical: samples never mix)."""
+    from commonscenes_amd import lib as L, ops, synth
+    nb, d, h, w, cin, cout = 420, 16, 16, 16, 672, 224
+    x = torch.empty((nb, d, h, w, cin), dtype=torch.float32, device="cuda")
+    assert x.numel() * 4 > 2 ** 32
+    for i in range(0, nb, 60):               # fill in slices (the generator materialises fp64 temporaries)
+        x[i:i + 60] = synth.tensor_device(f"big:{i}", (min(60, nb - i), d, h, w, cin), 1.0)
+    wt = _rand(cout, cin, 3, 3, 3, seed=91, scale=(cin * 27) ** -0.5).cuda()
+    b = _rand(cout, seed=92).cuda()
+    pw = ops.pack_weight(wt, b, math=L.MATH_F16X3)
+    big = ops.conv_gemm(x, pw)
+    tail = ops.conv_gemm(x[-3:].contiguous(), pw)
+    head = ops.conv_gemm(x[:2].contiguous(), pw)
+    torch.cuda.synchronize()
+    assert torch.isfinite(big[-3:]).all() and float(big[-1].abs().max()) > 0
+    assert rel_l2(big[-3:], tail) < 1e-6 and rel_l2(big[:2], head) < 1e-6
