@@ -187,6 +187,19 @@ def test_unet_full_size_batch_invariance_at_benchmark_shape():
         pass
 
 
+def test_unet_single_sample_forward_matches_batched():
+    """smallest possible call (one sample, no guidance pair): equals the same sample inside the golden's batch of 2
+    to summation-order noise, and the golden itself."""
+    g = _g("unet_full")
+    df = _unet(False, "f16x3")
+    x, t, ctx = _cu(g["x"]), _cu(g["t"]), _cu(g["ctx"])
+    one = df(x[1:2], t[1:2], c_crossattn=[ctx[1:2]])
+    two = df(x, t, c_crossattn=[ctx])
+    torch.cuda.synchronize()
+    assert one.shape == (1, 3, 16, 16, 16)
+    assert rel_l2(one[0], two[1]) < 1e-5 and rel_l2(one[0], torch.from_numpy(g["eps"][1])) < 1e-5
+
+
 # ---------------------------------------------------------------------------------------------------
 # UNet, concat-conditioning family (config/sdfusion-txt2shape_concat.yaml; SURVEY 8f N1)
 # ---------------------------------------------------------------------------------------------------
