@@ -384,3 +384,41 @@ def test_chamfer_self_distance_is_zero_at_full_size():
     torch.cuda.synchronize()
     assert float(d1.abs().max()) == 0.0 and float(d2.abs().max()) == 0.0
     assert torch.equal(cd.idx1.long(), torch.arange(20000, device="cuda").expand(4, -1))
+
+
+def test_ddim_update_with_noise_term():
+    """eta > 0: x_prev = sqrt(a_prev) * pred_x0 + sqrt(1 - a_prev - sigma^2) * e + sigma * noise (ddim.py:234-243)."""
+    from commonscenes_amd import ops
+    x = _rand(3, 3, 16, 16, 16, seed=93)
+    eps = _rand(6, 3, 16, 16, 16, seed=94)
+    noise = _rand(3, 3, 16, 16, 16, seed=95)
+    a_t, a_prev, sigma = 0.4321, 0.4567, 0.125
+    s1m = float(np.sqrt(np.float32(1.0) - np.float32(a_t)))
+    e = eps[:3].double() + 3.0 * (eps[3:].double() - eps[:3].double())
+    p0 = (x.double() - s1m * e) / np.sqrt(a_t)
+    ref = np.sqrt(a_prev) * p0 + np.sqrt(1.0 - a_prev - sigma ** 2) * e + sigma * noise.double()
+    xp, pp = ops.ddim_cfg_update(x.cuda(), eps.cuda(), a_t, a_prev, sigma, s1m, 3.0, True, noise=noise.cuda())
+    torch.cuda.synchronize()
+    assert rel_l2(xp, ref) < 1e-6 and rel_l2(pp, p0) < 1e-6
+
+
+def test_sampler_eta_positive_runs_and_is_seed_deterministic():
+    """DDIMSampler.sample(eta=0.5): the stochastic branch (sigma_t > 0, torch RNG on the device) -- finite, different
+    from the deterministic trajectory, reproducible under torch.manual_seed."""
+    import test_model_gpu as T
+    from commonscenes_amd import synth
+    from commonscenes_amd.ddim import DDIMSampler
+    m = T._SamplerModel(T._unet(True))
+    x_T = synth.gaussian_like("eta:x", (2, 3, 16, 16, 16)).cuda()
+    c = synth.gaussian_like("eta:c", (2, 1, 1280)).cuda()
+    uc = synth.gaussian_like("eta:uc", (2, 1, 1280)).cuda()
+    kw = dict(S=50, batch_size=2, shape=(3, 16, 16, 16), conditioning=c, x_T=x_T, verbose=False,
+              unconditional_guidance_scale=3.0, unconditional_conditioning=uc, max_steps=3)
+    outs = []
+    for eta, seed in ((0.5, 7), (0.5, 7), (0.0, 7)):
+        torch.manual_seed(seed)
+        x, _ = DDIMSampler(m).sample(eta=eta, **kw)
+        torch.cuda.synchronize()
+        outs.append(x)
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1]) and not torch.equal(outs[0], outs[2])
