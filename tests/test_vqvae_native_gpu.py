@@ -78,3 +78,28 @@ def test_decode_of_a_32_object_batch_is_sliced():
     assert torch.equal(a, b) and torch.equal(py.last_indices, nat.last_indices)
     one = py.decode_no_quant(lat[21:22])
     assert torch.equal(one[0], a[21])
+
+
+def test_load_vqvae_from_checkpoint_file_and_quantize(tmp_path):
+    """model_utils.load_vqvae's job (model/model_utils.py:7-31): build from the YAML-shaped config, read a checkpoint
+    file (raw state_dict or {'vqvae': ...}, encoder entries ignored); VQVAE.quantize returns the golden's indices."""
+    from commonscenes_amd import synth
+    from commonscenes_amd.vqvae import load_vqvae, vqvae_param_shapes
+    from oracle.ref_torch import VQ_FULL
+    g = {k: v for k, v in np.load(GOLDEN / "vq_decode.npz").items()}
+    sd = dict(synth.synth_state_dict(vqvae_param_shapes(VQ_FULL, 8192, 3)))
+    sd["encoder.conv_in.weight"] = torch.zeros(64, 1, 3, 3, 3)          # decode side must ignore the encoder
+    conf = dict(model=dict(params=dict(embed_dim=3, n_embed=8192, ddconfig=dict(
+        double_z=False, z_channels=3, resolution=64, in_channels=1, out_ch=1, ch=64, ch_mult=[1, 2, 4],
+        num_res_blocks=1, attn_resolutions=[], dropout=0.0))))
+    py, _ = _pair("f16x3")
+    lat = torch.from_numpy(g["latent"]).cuda()
+    want = py.decode_no_quant(lat)
+    for payload, name in ((sd, "raw.pth"), ({"vqvae": sd}, "wrapped.pth")):
+        torch.save(payload, tmp_path / name)
+        vq = load_vqvae(conf, str(tmp_path / name), device="cuda")
+        assert torch.equal(vq.decode_no_quant(lat), want)
+    quant, idx = vq.quantize(lat)
+    torch.cuda.synchronize()
+    assert np.array_equal(idx.cpu().numpy().reshape(-1), g["indices"].reshape(-1))
+    assert quant.shape == lat.shape and torch.equal(vq.decode(quant), want)
