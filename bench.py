@@ -96,10 +96,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs the MI355X (the HIP path has no CPU fallback)"
+    # test hooks (a 1-GPU box cannot host two RCCL ranks): CS_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and
+    # CS_DIST_BACKEND=gloo swaps the process-group backend, so the multi-rank control flow can be exercised there
+    if os.environ.get("CS_BENCH_ONE_DEVICE"):
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
+        backend = os.environ.get("CS_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
     assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     from commonscenes_amd import ops, synth

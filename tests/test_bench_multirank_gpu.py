@@ -1,0 +1,30 @@
+"""bench.py's multi-rank control flow (rank arithmetic, packed-conditioning broadcast, barrier + max-over-ranks timing,
+rank-0-only JSON) run for real: two ranks launched by torch.distributed.run.  A 1-GPU box cannot host two RCCL ranks,
+so the test hooks put both ranks on cuda:0 and use the gloo backend; the collectives and everything around them are the
+code the driver's `--gpus N` run executes over RCCL."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_device():
+    env = dict(os.environ, CS_BENCH_ONE_DEVICE="1", CS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29541", str(ROOT / "bench.py"), "--gpus", "2",
+                        "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--objects", "4"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["finite"] is True and d["value"] > 0
+    assert abs(d["value"] - 2 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
+    assert d["config"]["objects_per_gpu"] == 4 and "x2" in d["config"]["parallelism"]
