@@ -31,8 +31,8 @@ __device__ __forceinline__ int vpos(int j) {   // swap bits 2 and 3
 
 // X1 = plain fp16 operands (hi halves only: one MFMA per product instead of three) -- the reduced-precision
 // "fp16 MFMA attention" option of BASELINE configs[4]; not the default, outside the fp32 parity gates.
-template <int DB, int KT, bool X1>
-__global__ __launch_bounds__(256) void attn_f16x3_kernel(const float* __restrict__ q, const float* __restrict__ k,
+template <int DB, int KT, bool X1, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_f16x3_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                          const float* __restrict__ v, float* __restrict__ out,
                                                          int nq, int nk, int heads, int dh, int ldq, int ldk,
                                                          int ldv, int ldo, float scale, int qtiles) {
@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256) void attn_f16x3_kernel(const float* __restrict
   const int h = bid % heads;
   const int b = bid / heads;
 
-  const int q0 = qt * 128 + wave * 32;
+  constexpr int NT = 64 * NW;          // NW waves of 32 queries share each staged K / V tile
+  const int q0 = qt * (32 * NW) + wave * 32;
   const int qi = min(q0 + l31, nq - 1);
   const float* qp = q + ((int64_t)b * nq + qi) * ldq + h * dh;
   const float* kb = k + (int64_t)b * nk * ldk + h * dh;
@@ -80,13 +81,13 @@ __global__ __launch_bounds__(256) void attn_f16x3_kernel(const float* __restrict
     }
 
   // zero the padding (d >= dh) of the K images and the V^T images once
-  for (int u = tid; u < KT * (LDK - dh); u += 256) {
+  for (int u = tid; u < KT * (LDK - dh); u += NT) {
     const int j = u / (LDK - dh);
     const int d = dh + (u - j * (LDK - dh));
     Kh[j * LDK + d] = (_Float16)0.f;
     Kl[j * LDK + d] = (_Float16)0.f;
   }
-  for (int u = tid; u < (DP - dh) * LDV; u += 256) {
+  for (int u = tid; u < (DP - dh) * LDV; u += NT) {
     Vh[dh * LDV + u] = (_Float16)0.f;
     Vl[dh * LDV + u] = (_Float16)0.f;
   }
@@ -112,11 +113,11 @@ __global__ __launch_bounds__(256) void attn_f16x3_kernel(const float* __restrict
   // so a wave writes one contiguous run of a V^T row.
   const int dh4 = dh >> 2;
   constexpr bool PIPE = DB <= 2;
-  constexpr int NU = PIPE ? KT * DP / 1024 : 1;      // units per thread per tensor (KT * DP/4 units over 256 threads)
+  constexpr int NU = PIPE ? (KT * DP / 4 + NT - 1) / NT : 1;   // units per thread per tensor (KT * DP/4 units over NT threads)
   int k_g[NU], k_l[NU], v_g[NU], v_l[NU];
 #pragma unroll
   for (int i = 0; i < NU; ++i) {
-    const int u = tid + 256 * i;
+    const int u = tid + NT * i;
     const bool ok = u < KT * dh4;
     const int j = ok ? u / dh4 : 0;
     const int c4 = ok ? u - j * dh4 : 0;
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(256) void attn_f16x3_kernel(const float* __restrict
     if constexpr (PIPE) {
       store_tile();
     } else {
-      for (int u = tid; u < KT * dh4; u += 256) {          // K: unit = (key j, 4 channels)
+      for (int u = tid; u < KT * dh4; u += NT) {          // K: unit = (key j, 4 channels)
         const int j = u / dh4;
         const int c4 = u - j * dh4;
         float4 kv = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(256) void attn_f16x3_kernel(const float* __restrict
         *reinterpret_cast<h4*>(Kh + j * LDK + c4 * 4) = hi;
         if constexpr (!X1) *reinterpret_cast<h4*>(Kl + j * LDK + c4 * 4) = lo;
       }
-      for (int u = tid; u < KT * dh4; u += 256) {          // V: unit = (4 channels, key j), key fastest
+      for (int u = tid; u < KT * dh4; u += NT) {          // V: unit = (4 channels, key j), key fastest
         const int c4 = u / KT;
         const int j = u - c4 * KT;
         float4 vv = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -309,20 +310,20 @@ __global__ __launch_bounds__(256) void attn_f16x3_kernel(const float* __restrict
   }
 }
 
-template <int DB, int KT, bool X1>
+template <int DB, int KT, bool X1, int NW = 4>
 int launch_attn16(const float* q, const float* k, const float* v, float* out, int nb, int nq, int nk, int heads,
                   int dh, int ldq, int ldk, int ldv, int ldo, float scale, hipStream_t s) {
   constexpr int DP = 32 * DB;
   const size_t smem = (size_t)(2 * KT * (DP + 8) + 2 * DP * (KT + 8)) * sizeof(_Float16);
-  const int qtiles = (nq + 127) / 128;
+  const int qtiles = (nq + 32 * NW - 1) / (32 * NW);
   const int64_t grid = (int64_t)qtiles * heads * nb;
   if (grid > 0x7fffffffLL) return CS_EINVAL;
-  auto kern = attn_f16x3_kernel<DB, KT, X1>;
+  auto kern = attn_f16x3_kernel<DB, KT, X1, NW>;
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
   }
-  CS_LAUNCH(kern, dim3((unsigned)grid), dim3(256), smem, s, q, k, v, out, nq, nk, heads, dh, ldq, ldk, ldv, ldo,
+  CS_LAUNCH(kern, dim3((unsigned)grid), dim3(64 * NW), smem, s, q, k, v, out, nq, nk, heads, dh, ldq, ldk, ldv, ldo,
             scale, qtiles);
   CS_CHECK_LAUNCH();
   return CS_OK;
@@ -340,8 +341,15 @@ static int attn16_dispatch(const float* q, const float* k, const float* v, float
     return CS_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   if (dh <= 32) return launch_attn16<1, 64, X1>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, s);
-  if (dh <= 64) return launch_attn16<2, 64, X1>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, s);
-  if (dh <= 96) return launch_attn16<3, 64, X1>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, s);
+  if (dh <= 64) {
+    if (nq >= 512)      // eight waves per staged tile: the K / V conversion is amortised over 256 queries
+      return launch_attn16<2, 64, X1, 8>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, s);
+    return launch_attn16<2, 64, X1>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, s);
+  }
+  if (dh <= 96) {
+    if (nq >= 256) return launch_attn16<3, 64, X1, 8>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, s);
+    return launch_attn16<3, 64, X1>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, s);
+  }
   if (dh <= 128) return launch_attn16<4, 64, X1>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, s);
   if (dh <= 256) return launch_attn16<8, 32, X1>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, s);
   return CS_EINVAL;
