@@ -49,7 +49,8 @@ def _worker(rank, ws, port, total, q):
         assert torch.equal(bx, x_T) and torch.equal(buc, uc) and torch.equal(bc, c)
         out = D.sharded_rel2shape(_fake_sampler, bx, buc, bc)
         lo, hi = D.shard_range(total, ws, rank)
-        q.put((rank, out, (lo, hi)))
+        # by value (numpy): a torch tensor would travel as a shared-memory handle that dies with this process
+        q.put((rank, out.numpy().copy(), (lo, hi)))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -73,6 +74,7 @@ def test_sharded_equals_unsharded(ws, total):
     assert ranges[0][0] == 0 and ranges[-1][1] == total
     assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
     for rank, out, _ in got:
+        out = torch.from_numpy(out)
         assert out.shape == ref.shape
         assert torch.equal(out, ref), f"rank {rank}: gathered result differs from the single-rank result"
 
