@@ -25,6 +25,12 @@ __device__ __forceinline__ void split1(float v, _Float16& hi, _Float16& lo) {
   lo = (_Float16)(v - (float)hi);
 }
 
+// operand split that also tracks the lane's largest |operand| (overflow report, see CS_STATUS_F16X3_OVERFLOW)
+__device__ __forceinline__ void split1m(float v, _Float16& hi, _Float16& lo, float& amax) {
+  amax = fmaxf(amax, fabsf(v));
+  split1(v, hi, lo);
+}
+
 __device__ __forceinline__ int vpos(int j) {   // swap bits 2 and 3
   return (j & ~12) | ((j & 4) << 1) | ((j & 8) >> 1);
 }
@@ -35,8 +41,10 @@ template <int DB, int KT, bool X1, int NW>
 __global__ __launch_bounds__(64 * NW) void attn_f16x3_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                          const float* __restrict__ v, float* __restrict__ out,
                                                          int nq, int nk, int heads, int dh, int ldq, int ldk,
-                                                         int ldv, int ldo, float scale, int qtiles) {
+                                                         int ldv, int ldo, float scale, int qtiles,
+                                                         int32_t* __restrict__ status) {
   constexpr int DP = 32 * DB;
+  float amax = 0.f;                    // largest |scaled Q / K / V operand| this lane converted to fp16
   constexpr int LDK = DP + 8;          // halves; 16 consecutive rows hit 16 distinct 16-byte slots
   constexpr int LDV = KT + 8;
   constexpr int JB = KT / 32;
@@ -75,7 +83,7 @@ __global__ __launch_bounds__(64 * NW) void attn_f16x3_kernel(const float* __rest
       const int d = 16 * t + 8 * half + e;
       const float x = d < dh ? qp[d] * (scale * QK_SCALE) : 0.f;
       _Float16 a, c;
-      split1(x, a, c);
+      split1m(x, a, c, amax);
       qh[t][e] = a;
       ql[t][e] = c;
     }
@@ -147,10 +155,10 @@ __global__ __launch_bounds__(64 * NW) void attn_f16x3_kernel(const float* __rest
       if (k_l[i] >= 0) {
         h4 hi, lo;
         _Float16 a, c;
-        split1(kr[i].x * QK_SCALE, a, c); hi[0] = a; lo[0] = c;
-        split1(kr[i].y * QK_SCALE, a, c); hi[1] = a; lo[1] = c;
-        split1(kr[i].z * QK_SCALE, a, c); hi[2] = a; lo[2] = c;
-        split1(kr[i].w * QK_SCALE, a, c); hi[3] = a; lo[3] = c;
+        split1m(kr[i].x * QK_SCALE, a, c, amax); hi[0] = a; lo[0] = c;
+        split1m(kr[i].y * QK_SCALE, a, c, amax); hi[1] = a; lo[1] = c;
+        split1m(kr[i].z * QK_SCALE, a, c, amax); hi[2] = a; lo[2] = c;
+        split1m(kr[i].w * QK_SCALE, a, c, amax); hi[3] = a; lo[3] = c;
         *reinterpret_cast<h4*>(Kh + k_l[i]) = hi;
         if constexpr (!X1) *reinterpret_cast<h4*>(Kl + k_l[i]) = lo;
       }
@@ -159,7 +167,7 @@ __global__ __launch_bounds__(64 * NW) void attn_f16x3_kernel(const float* __rest
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           _Float16 a, c;
-          split1(x[e] * QK_SCALE, a, c);
+          split1m(x[e] * QK_SCALE, a, c, amax);
           Vh[v_l[i] + e * LDV] = a;
           if constexpr (!X1) Vl[v_l[i] + e * LDV] = c;
         }
@@ -182,10 +190,10 @@ __global__ __launch_bounds__(64 * NW) void attn_f16x3_kernel(const float* __rest
         if (kt0 + j < nk) kv = *reinterpret_cast<const float4*>(kb + (int64_t)(kt0 + j) * ldk + c4 * 4);
         h4 hi, lo;
         _Float16 a, c;
-        split1(kv.x * QK_SCALE, a, c); hi[0] = a; lo[0] = c;
-        split1(kv.y * QK_SCALE, a, c); hi[1] = a; lo[1] = c;
-        split1(kv.z * QK_SCALE, a, c); hi[2] = a; lo[2] = c;
-        split1(kv.w * QK_SCALE, a, c); hi[3] = a; lo[3] = c;
+        split1m(kv.x * QK_SCALE, a, c, amax); hi[0] = a; lo[0] = c;
+        split1m(kv.y * QK_SCALE, a, c, amax); hi[1] = a; lo[1] = c;
+        split1m(kv.z * QK_SCALE, a, c, amax); hi[2] = a; lo[2] = c;
+        split1m(kv.w * QK_SCALE, a, c, amax); hi[3] = a; lo[3] = c;
         *reinterpret_cast<h4*>(Kh + j * LDK + c4 * 4) = hi;
         if constexpr (!X1) *reinterpret_cast<h4*>(Kl + j * LDK + c4 * 4) = lo;
       }
@@ -199,7 +207,7 @@ __global__ __launch_bounds__(64 * NW) void attn_f16x3_kernel(const float* __rest
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           _Float16 a, c;
-          split1(x[i] * QK_SCALE, a, c);
+          split1m(x[i] * QK_SCALE, a, c, amax);
           Vh[(c4 * 4 + i) * LDV + pj] = a;
           if constexpr (!X1) Vl[(c4 * 4 + i) * LDV + pj] = c;
         }
@@ -289,6 +297,7 @@ __global__ __launch_bounds__(64 * NW) void attn_f16x3_kernel(const float* __rest
       }
   }
 
+  if (status && amax >= 65504.f) atomicOr(status, CS_STATUS_F16X3_OVERFLOW);
   const float ltot = lrun + __shfl_xor(lrun, 32, 64);
   const float inv = 1.0f / (ltot * QK_SCALE);       // ltot already carries P_SCALE
   if (q0 + l31 < nq) {
@@ -312,7 +321,7 @@ __global__ __launch_bounds__(64 * NW) void attn_f16x3_kernel(const float* __rest
 
 template <int DB, int KT, bool X1, int NW = 4>
 int launch_attn16(const float* q, const float* k, const float* v, float* out, int nb, int nq, int nk, int heads,
-                  int dh, int ldq, int ldk, int ldv, int ldo, float scale, hipStream_t s) {
+                  int dh, int ldq, int ldk, int ldv, int ldo, float scale, int32_t* status, hipStream_t s) {
   constexpr int DP = 32 * DB;
   const size_t smem = (size_t)(2 * KT * (DP + 8) + 2 * DP * (KT + 8)) * sizeof(_Float16);
   const int qtiles = (nq + 32 * NW - 1) / (32 * NW);
@@ -324,7 +333,7 @@ int launch_attn16(const float* q, const float* k, const float* v, float* out, in
     if (e != hipSuccess) return (int)e;
   }
   CS_LAUNCH(kern, dim3((unsigned)grid), dim3(64 * NW), smem, s, q, k, v, out, nq, nk, heads, dh, ldq, ldk, ldv, ldo,
-            scale, qtiles);
+            scale, qtiles, status);
   CS_CHECK_LAUNCH();
   return CS_OK;
 }
@@ -333,36 +342,36 @@ int launch_attn16(const float* q, const float* k, const float* v, float* out, in
 
 template <bool X1>
 static int attn16_dispatch(const float* q, const float* k, const float* v, float* out, int nb, int nq, int nk, int heads,
-                           int dh, int ldq, int ldk, int ldv, int ldo, float scale, cs_stream_t stream) {
+                           int dh, int ldq, int ldk, int ldv, int ldo, float scale, int32_t* status, cs_stream_t stream) {
   if (!q || !k || !v || !out || nb <= 0 || nq <= 0 || nk <= 0 || heads <= 0 || dh <= 0) return CS_EINVAL;
   if ((dh & 3) || (ldq & 3) || (ldk & 3) || (ldv & 3) || (ldo & 3)) return CS_EINVAL;
   if (ldq < heads * dh || ldk < heads * dh || ldv < heads * dh || ldo < heads * dh) return CS_EINVAL;
   if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || ((uintptr_t)out & 15))
     return CS_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  if (dh <= 32) return launch_attn16<1, 64, X1>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, s);
+  if (dh <= 32) return launch_attn16<1, 64, X1>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, s);
   if (dh <= 64) {
     if (nq >= 512)      // eight waves per staged tile: the K / V conversion is amortised over 256 queries
-      return launch_attn16<2, 64, X1, 8>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, s);
-    return launch_attn16<2, 64, X1>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, s);
+      return launch_attn16<2, 64, X1, 8>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, s);
+    return launch_attn16<2, 64, X1>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, s);
   }
   if (dh <= 96) {
-    if (nq >= 256) return launch_attn16<3, 64, X1, 8>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, s);
-    return launch_attn16<3, 64, X1>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, s);
+    if (nq >= 256) return launch_attn16<3, 64, X1, 8>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, s);
+    return launch_attn16<3, 64, X1>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, s);
   }
-  if (dh <= 128) return launch_attn16<4, 64, X1>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, s);
-  if (dh <= 256) return launch_attn16<8, 32, X1>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, s);
+  if (dh <= 128) return launch_attn16<4, 64, X1>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, s);
+  if (dh <= 256) return launch_attn16<8, 32, X1>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, s);
   return CS_EINVAL;
 }
 
 extern "C" int cs_attn_selfattn_f16x3(const float* q, const float* k, const float* v, float* out, int nb, int nq,
                                       int nk, int heads, int dh, int ldq, int ldk, int ldv, int ldo, float scale,
-                                      cs_stream_t stream) {
-  return attn16_dispatch<false>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, stream);
+                                      int32_t* status, cs_stream_t stream) {
+  return attn16_dispatch<false>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, stream);
 }
 
 extern "C" int cs_attn_selfattn_f16(const float* q, const float* k, const float* v, float* out, int nb, int nq,
                                     int nk, int heads, int dh, int ldq, int ldk, int ldv, int ldo, float scale,
-                                    cs_stream_t stream) {
-  return attn16_dispatch<true>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, stream);
+                                    int32_t* status, cs_stream_t stream) {
+  return attn16_dispatch<true>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, stream);
 }

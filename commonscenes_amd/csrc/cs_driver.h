@@ -358,6 +358,7 @@ struct ExecBase {
   hipStream_t st;
   int rc = CS_OK;
   int64_t peak = 0;
+  int32_t* status = nullptr;     // caller's sticky CS_STATUS_* word (device) handed to every F16X3 kernel
   std::vector<FreeBlock> fl;
 
   ExecBase(const Plan& pl_, const void* arena_, void* ws_, int64_t ws_bytes_, bool dry_, hipStream_t st_)
@@ -439,6 +440,7 @@ struct ExecBase {
       q.bias = g.b_off >= 0 ? wf(g.b_off) : nullptr;
       q.rowvec = rowvec;
       q.res = res;
+      q.status = status;
     }
     q.nb = nb; q.din = d; q.hin = h; q.win = w;
     q.dout = dout; q.hout = hout; q.wout = wout;

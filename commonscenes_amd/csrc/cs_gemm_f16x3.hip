@@ -39,9 +39,15 @@ constexpr int MAX_TAPS = 27;
                       // 16 = s_setprio around the MFMAs, 32 = scalar epilogue, 64 = all fetches from one 16 KB window
 #endif
 
-__device__ __forceinline__ void split8(const f32x4& x, const f32x4& y, float a_scale, h8& hi, h8& lo) {
+// `amax` is the lane's running max |a * a_scale|: the kernel raises CS_STATUS_F16X3_OVERFLOW when it reaches the fp16
+// range (the hi half would be +-inf).  Four v_max3_f32 per eight elements, hidden under the MFMA stream.
+__device__ __forceinline__ void split8(const f32x4& x, const f32x4& y, float a_scale, h8& hi, h8& lo, float& amax) {
   const float v[8] = {x[0] * a_scale, x[1] * a_scale, x[2] * a_scale, x[3] * a_scale,
                       y[0] * a_scale, y[1] * a_scale, y[2] * a_scale, y[3] * a_scale};
+  amax = fmaxf(fmaxf(amax, fabsf(v[0])), fabsf(v[1]));
+  amax = fmaxf(fmaxf(amax, fabsf(v[2])), fabsf(v[3]));
+  amax = fmaxf(fmaxf(amax, fabsf(v[4])), fabsf(v[5]));
+  amax = fmaxf(fmaxf(amax, fabsf(v[6])), fabsf(v[7]));
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const _Float16 h = (_Float16)v[i];
@@ -306,6 +312,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   //   s_barrier          : ... for every wave; every wave has also left iteration k-1
   //   issue A(k+2), B(k+2) into the stage iteration k-1 vacated (A first, so the next wait covers it)
   //   MFMAs on B(k) with the already-split A(k)  ||  read + split A(k+1)
+  float amax = 0.f;
   auto load_a = [&](int st, h8 (&hi)[WMB], h8 (&lo)[WMB]) {
     const unsigned char* s = smem + st * STAGE;
 #pragma unroll
@@ -316,7 +323,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
       } else {
         const f32x4 x0 = *reinterpret_cast<const f32x4*>(s + a_frag[i][0]);
         const f32x4 x1 = *reinterpret_cast<const f32x4*>(s + a_frag[i][1]);
-        split8(x0, x1, a_scale, hi[i], lo[i]);
+        split8(x0, x1, a_scale, hi[i], lo[i], amax);
       }
     }
   };
@@ -369,6 +376,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
     if (kc + 2 < nk) step(std::integral_constant<int, 2>{});
   }
   wait_vmcnt<0>();   // drain the two zero-fill prefetches issued past the end before LDS is released
+  if constexpr (!PRE) {
+    // an activation at or beyond the fp16 range became +-inf in its hi half: tell the host (sticky flag)
+    if (p.status && amax >= 65504.f) atomicOr(p.status, CS_STATUS_F16X3_OVERFLOW);
+  }
 
   // ---- epilogue (identical contract to the fp32 kernel, after undoing the operand scales) ----
   // Fast path: the C/D layout gives a lane one column and 16 scattered rows, i.e. 112 dword stores (+112 dword

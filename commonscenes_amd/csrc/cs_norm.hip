@@ -167,7 +167,8 @@ __global__ __launch_bounds__(256) void gn_apply_split16_kernel(const float* __re
                                                                const float* __restrict__ beta,
                                                                _Float16* __restrict__ yh, _Float16* __restrict__ yl,
                                                                int nb, int rows, int c, int ldx, int ldy, int groups,
-                                                               int act, float a_scale) {
+                                                               int act, float a_scale, int32_t* __restrict__ status) {
+  float amax = 0.f;
   const int ch4 = c >> 2;
   const int cpg = c / groups;
   const int64_t total = (int64_t)nb * rows * ch4;
@@ -189,6 +190,7 @@ __global__ __launch_bounds__(256) void gn_apply_split16_kernel(const float* __re
       const float mean = stats[((int64_t)n * groups + grp) * 2];
       const float rstd = stats[((int64_t)n * groups + grp) * 2 + 1];
       const float o = cs_act((in[k] - mean) * rstd * gg[k] + bb[k], act) * a_scale;
+      amax = fmaxf(amax, fabsf(o));
       const _Float16 h = (_Float16)o;
       hi[k] = h;
       lo[k] = (_Float16)(o - (float)h);
@@ -196,6 +198,7 @@ __global__ __launch_bounds__(256) void gn_apply_split16_kernel(const float* __re
     *reinterpret_cast<h4v*>(yh + row * ldy + c4 * 4) = hi;
     *reinterpret_cast<h4v*>(yl + row * ldy + c4 * 4) = lo;
   }
+  if (status && amax >= 65504.f) atomicOr(status, CS_STATUS_F16X3_OVERFLOW);
 }
 
 // LayerNorm: one wave per row; each lane owns up to MAXV float4 chunks (c <= 64*4*MAXV).
@@ -314,7 +317,7 @@ extern "C" int cs_groupnorm_apply(const float* x, const float* stats, const floa
 extern "C" int cs_groupnorm_apply_split16(const float* x, const float* stats, const float* gamma,
                                           const float* beta, void* y_hi, void* y_lo, int nb, int rows, int c,
                                           int ldx, int ldy, int groups, int act, float a_scale,
-                                          cs_stream_t stream) {
+                                          int32_t* status, cs_stream_t stream) {
   if (!x || !stats || !gamma || !beta || !y_hi || !y_lo || nb <= 0 || rows <= 0 || c <= 0 || groups <= 0)
     return CS_EINVAL;
   if ((c & 7) || (ldx & 3) || (ldy & 7) || ldx < c || ldy < c || c % groups || !(a_scale > 0.f)) return CS_EINVAL;
@@ -323,7 +326,7 @@ extern "C" int cs_groupnorm_apply_split16(const float* x, const float* stats, co
     return CS_EINVAL;
   const int64_t total = (int64_t)nb * rows * (c >> 2);
   CS_LAUNCH(gn_apply_split16_kernel, dim3(cs_grid_for(total, 256, 256 * 32)), dim3(256), 0, (hipStream_t)stream, x,
-            stats, gamma, beta, (_Float16*)y_hi, (_Float16*)y_lo, nb, rows, c, ldx, ldy, groups, act, a_scale);
+            stats, gamma, beta, (_Float16*)y_hi, (_Float16*)y_lo, nb, rows, c, ldx, ldy, groups, act, a_scale, status);
   CS_CHECK_LAUNCH();
   return CS_OK;
 }

@@ -97,10 +97,12 @@ __global__ void timestep_embedding_kernel(const int64_t* __restrict__ t, float* 
   out[i] = v;
 }
 
-__global__ __launch_bounds__(256) void ddim_update_kernel(const float* __restrict__ x,
+// x_prev may alias x (in-place update, used by the graph-replay sampler): neither is __restrict__, and every element
+// is read before it is written by the same thread.
+__global__ __launch_bounds__(256) void ddim_update_kernel(const float* x,
                                                           const float* __restrict__ eps,
                                                           const float* __restrict__ noise,
-                                                          float* __restrict__ x_prev,
+                                                          float* x_prev,
                                                           float* __restrict__ pred_x0, int64_t n,
                                                           int64_t uc_off, float sqrt_at,
                                                           float sqrt_aprev, float dir_coef,
@@ -128,10 +130,10 @@ __global__ __launch_bounds__(256) void ddim_update_kernel(const float* __restric
 
 // Same update with the five step coefficients read from device memory: a captured HIP graph of one sampling
 // step is replayed for every timestep, only the 20-byte coefficient block (and the timestep vector) change.
-__global__ __launch_bounds__(256) void ddim_update_dev_kernel(const float* __restrict__ x,
+__global__ __launch_bounds__(256) void ddim_update_dev_kernel(const float* x,
                                                               const float* __restrict__ eps,
                                                               const float* __restrict__ noise,
-                                                              float* __restrict__ x_prev,
+                                                              float* x_prev,
                                                               float* __restrict__ pred_x0, int64_t n,
                                                               int64_t uc_off, const float* __restrict__ coef,
                                                               float cfg_scale, int cfg) {
@@ -415,6 +417,59 @@ extern "C" int cs_ddim_cfg_update_dev(const float* x, const float* eps, const fl
   const int64_t n = nb * per;
   CS_LAUNCH(ddim_update_dev_kernel, dim3(cs_grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, eps, noise,
             x_prev, pred_x0, n, n, coef5_dev, cfg_scale, cfg);
+  CS_CHECK_LAUNCH();
+  return CS_OK;
+}
+
+// PLMS step (samplers/plms.py:175-236): guidance combine, the pseudo linear multistep combination of the current
+// and up to three earlier noise predictions, then the same x0 / x_{t-1} update as DDIM at eta = 0 -- one pass.
+// The multistep forms are evaluated exactly as the reference writes them (fp32, no contraction).
+__global__ __launch_bounds__(256) void plms_update_kernel(const float* x, const float* __restrict__ eps,
+                                                          const float* __restrict__ h1, const float* __restrict__ h2,
+                                                          const float* __restrict__ h3, float* __restrict__ e_out,
+                                                          float* x_prev, float* __restrict__ pred_x0, int64_t n,
+                                                          int64_t uc_off, int mode, float sqrt_at, float sqrt_aprev,
+                                                          float dir_coef, float sqrt_one_minus_at, float cfg_scale,
+                                                          int cfg) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float e;
+    if (cfg) {
+      const float eu = eps[i];
+      const float ec = eps[uc_off + i];
+      e = eu + cfg_scale * (ec - eu);
+    } else {
+      e = eps[i];
+    }
+    if (e_out) e_out[i] = e;
+    float ep;
+    switch (mode) {
+      case CS_PLMS_AB2: ep = (3.f * e - h1[i]) / 2.f; break;                                       // plms.py:224
+      case CS_PLMS_AB3: ep = (23.f * e - 16.f * h1[i] + 5.f * h2[i]) / 12.f; break;                // :227
+      case CS_PLMS_AB4: ep = (55.f * e - 59.f * h1[i] + 37.f * h2[i] - 9.f * h3[i]) / 24.f; break;  // :230
+      case CS_PLMS_EULER_AVG: ep = (h1[i] + e) / 2.f; break;                                       // :221, h1 = e_t
+      default: ep = e; break;
+    }
+    const float xv = x[i];
+    const float p0 = (xv - sqrt_one_minus_at * ep) / sqrt_at;
+    const float xp = sqrt_aprev * p0 + dir_coef * ep;        // + sigma_t * noise with sigma_t == 0 (eta must be 0)
+    if (pred_x0) pred_x0[i] = p0;
+    x_prev[i] = xp;
+  }
+}
+
+extern "C" int cs_plms_update(const float* x, const float* eps, const float* h1, const float* h2, const float* h3,
+                              float* e_out, float* x_prev, float* pred_x0, int64_t nb, int64_t per, int mode,
+                              float a_t, float a_prev, float sqrt_one_minus_at, float cfg_scale, int cfg,
+                              cs_stream_t stream) {
+  if (!x || !eps || !x_prev || nb <= 0 || per <= 0) return CS_EINVAL;
+  if (!(a_t > 0.f) || a_prev < 0.f || mode < CS_PLMS_PLAIN || mode > CS_PLMS_EULER_AVG) return CS_EINVAL;
+  const int need = mode == CS_PLMS_AB4 ? 3 : mode == CS_PLMS_AB3 ? 2 : mode == CS_PLMS_PLAIN ? 0 : 1;
+  if ((need >= 1 && !h1) || (need >= 2 && !h2) || (need >= 3 && !h3)) return CS_EINVAL;
+  const int64_t n = nb * per;
+  CS_LAUNCH(plms_update_kernel, dim3(cs_grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, eps, h1, h2, h3, e_out,
+            x_prev, pred_x0, n, n, mode, sqrtf(a_t), sqrtf(a_prev), sqrtf(1.0f - a_prev), sqrt_one_minus_at, cfg_scale,
+            cfg);
   CS_CHECK_LAUNCH();
   return CS_OK;
 }

@@ -274,8 +274,10 @@ struct Exec : ExecBase {
     if (ok() && !dry) {
       const float scale = (float)std::pow((double)dh, -0.5);
       const float* q = p(qkv);
-      auto fn = u.cfg.math == CS_MATH_F16X3 ? cs_attn_selfattn_f16x3 : cs_attn_selfattn;
-      chk(fn(q, q + c, q + 2 * c, p(a), x.nb, n, n, heads, dh, 3 * c, 3 * c, 3 * c, c, scale, st));
+      chk(u.cfg.math == CS_MATH_F16X3
+              ? cs_attn_selfattn_f16x3(q, q + c, q + 2 * c, p(a), x.nb, n, n, heads, dh, 3 * c, 3 * c, 3 * c, c, scale,
+                                       status, st)
+              : cs_attn_selfattn(q, q + c, q + 2 * c, p(a), x.nb, n, n, heads, dh, 3 * c, 3 * c, 3 * c, c, scale, st));
     }
     release(qkv);
     // one context token: attn2(x) == to_out(to_v(ctx)) for every query row -> a row vector in this epilogue
@@ -316,8 +318,10 @@ struct Exec : ExecBase {
     if (ok() && !dry) {
       const float scale = (float)std::pow((double)dh, -0.5);
       const float* q = p(qkv);
-      auto fn = u.cfg.math == CS_MATH_F16X3 ? cs_attn_selfattn_f16x3 : cs_attn_selfattn;
-      chk(fn(q, q + c, q + 2 * c, p(a), x.nb, n, n, heads, dh, 3 * c, 3 * c, 3 * c, c, scale, st));
+      chk(u.cfg.math == CS_MATH_F16X3
+              ? cs_attn_selfattn_f16x3(q, q + c, q + 2 * c, p(a), x.nb, n, n, heads, dh, 3 * c, 3 * c, 3 * c, c, scale,
+                                       status, st)
+              : cs_attn_selfattn(q, q + c, q + 2 * c, p(a), x.nb, n, n, heads, dh, 3 * c, 3 * c, 3 * c, c, scale, st));
     }
     release(qkv);
     Act o = x;
@@ -516,7 +520,7 @@ extern "C" int64_t cs_unet_workspace_bytes(const cs_unet* u, int nb_x, int cfg_p
 }
 
 extern "C" int cs_unet_context(const cs_unet* u, const void* arena, const float* ctx, int nb_ctx, float* ctxvec,
-                               void* workspace, int64_t workspace_bytes, cs_stream_t stream) {
+                               int32_t* status, void* workspace, int64_t workspace_bytes, cs_stream_t stream) {
   if (!u || !u->packed || !arena || !ctx || !ctxvec || !workspace || nb_ctx <= 0) return CS_EINVAL;
   if (!u->cfg.use_spatial_transformer) return CS_EINVAL;      // the concat family has no context
   Exec e(*u, arena, workspace, workspace_bytes, false, (hipStream_t)stream);
@@ -545,6 +549,7 @@ extern "C" int cs_unet_context(const cs_unet* u, const void* arena, const float*
       q.lda = g.cin_pad; q.ldw = g.ldw; q.ldo = pass == 0 ? g.cout : u->ctx_total;
       q.kd = q.kh = q.kw = 1; q.sd = q.sh = q.sw = 1;
       q.rv_rows = 1; q.math = u->cfg.math;
+      q.status = status;
       e.chk(cs_conv_gemm(&q, e.st));
     }
     e.release(v2);
@@ -558,8 +563,8 @@ extern "C" int cs_unet_context(const cs_unet* u, const void* arena, const float*
 }
 
 extern "C" int cs_unet_step(const cs_unet* u, const void* arena, const float* x_ncdhw, const int64_t* t,
-                            const float* ctxvec, float* eps_ncdhw, int nb_x, int cfg_pairs, void* workspace,
-                            int64_t workspace_bytes, cs_stream_t stream) {
+                            const float* ctxvec, float* eps_ncdhw, int nb_x, int cfg_pairs, int32_t* status,
+                            void* workspace, int64_t workspace_bytes, cs_stream_t stream) {
   if (!u || !u->packed || !arena || !x_ncdhw || !t || !eps_ncdhw || !workspace || nb_x <= 0) return CS_EINVAL;
   // crossattn family: ctxvec (cs_unet_context) is required.  concat family (no transformer blocks): there is no
   // context, x carries the condition volume as its last channel(s) (network.py:25-27) and the guidance halves
@@ -567,5 +572,6 @@ extern "C" int cs_unet_step(const cs_unet* u, const void* arena, const float* x_
   if (u->cfg.use_spatial_transformer ? !ctxvec : (ctxvec != nullptr || cfg_pairs != 0)) return CS_EINVAL;
   if (((uintptr_t)workspace & 15) || ((uintptr_t)arena & 15) || ((uintptr_t)ctxvec & 15)) return CS_EINVAL;
   Exec e(*u, arena, workspace, workspace_bytes, false, (hipStream_t)stream);
+  e.status = status;
   return forward(e, x_ncdhw, t, ctxvec, eps_ncdhw, nb_x, cfg_pairs);
 }

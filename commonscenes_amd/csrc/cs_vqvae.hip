@@ -135,8 +135,9 @@ struct VExec : ExecBase {
     if (ok() && !dry) {
       const float scale = (float)std::pow((double)c, -0.5);
       const float* q = p(qkv);
-      auto fn = pl.math == CS_MATH_F16X3 ? cs_attn_selfattn_f16x3 : cs_attn_selfattn;
-      chk(fn(q, q + c, q + 2 * c, p(a), x.nb, n, n, 1, c, 3 * c, 3 * c, 3 * c, c, scale, st));
+      chk(pl.math == CS_MATH_F16X3
+              ? cs_attn_selfattn_f16x3(q, q + c, q + 2 * c, p(a), x.nb, n, n, 1, c, 3 * c, 3 * c, 3 * c, c, scale, status, st)
+              : cs_attn_selfattn(q, q + c, q + 2 * c, p(a), x.nb, n, n, 1, c, 3 * c, 3 * c, 3 * c, c, scale, st));
     }
     release(qkv);
     Act o = x;
@@ -239,8 +240,8 @@ extern "C" int64_t cs_vqvae_workspace_bytes(const cs_vqvae* u, int nb) {
 }
 
 extern "C" int cs_vqvae_decode(const cs_vqvae* u, const void* arena, const float* latent_ncdhw, float* sdf_ncdhw,
-                               int64_t* code_indices, int nb, int quantize, void* workspace, int64_t workspace_bytes,
-                               cs_stream_t stream) {
+                               int64_t* code_indices, int nb, int quantize, int32_t* status, void* workspace,
+                               int64_t workspace_bytes, cs_stream_t stream) {
   if (!u || !u->packed || !arena || !latent_ncdhw || !sdf_ncdhw || !workspace || nb <= 0) return CS_EINVAL;
   if (((uintptr_t)workspace & 15) || ((uintptr_t)arena & 15)) return CS_EINVAL;
   const CsVqvaeConfig& c = u->cfg;
@@ -249,6 +250,7 @@ extern "C" int cs_vqvae_decode(const cs_vqvae* u, const void* arena, const float
   for (int b0 = 0; b0 < nb; b0 += MAX_DECODE_BATCH) {
     const int n = nb - b0 < MAX_DECODE_BATCH ? nb - b0 : MAX_DECODE_BATCH;
     VExec e(*u, arena, workspace, workspace_bytes, false, (hipStream_t)stream);   // slices reuse the workspace in
+    e.status = status;
     const int rc = decode(e, latent_ncdhw + b0 * c.embed_dim * g3,              // stream order
                           sdf_ncdhw + b0 * c.out_ch * r3, code_indices ? code_indices + b0 * g3 : nullptr, n, quantize);
     if (rc != CS_OK) return rc;

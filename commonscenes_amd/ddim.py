@@ -82,7 +82,10 @@ class DDIMSampler(object):
                noise_dropout=0., score_corrector=None, corrector_kwargs=None, verbose=True, x_T=None,
                log_every_t=100, unconditional_guidance_scale=1., unconditional_conditioning=None,
                mm_cls_free=False, **kwargs):
-        if conditioning is not None and not isinstance(conditioning, dict):
+        if isinstance(conditioning, dict):
+            raise NotImplementedError("dict conditioning (ddim.py:85-88) is not on the rel2shape path: pass the "
+                                      "conditioning tensor ([B,1,1280] crossattn / [B,1,16,16,16] concat)")
+        if conditioning is not None:
             if conditioning.shape[0] != batch_size:
                 print(f"Warning: Got {conditioning.shape[0]} conditionings but batch-size is {batch_size}")
         for name, val, ok in (("mask", mask, None), ("x0", x0, None), ("score_corrector", score_corrector, None)):

@@ -39,44 +39,59 @@ def pack_conditioning(x_T: Tensor, uc: Tensor, c: Tensor) -> Tensor:
                       c.reshape(B, -1).float().reshape(-1)])
 
 
-def unpack_conditioning(buf: Tensor, n_obj: int, latent_shape=(3, 16, 16, 16), ctx_dim: int = 1280):
+def unpack_conditioning(buf: Tensor, n_obj: int, latent_shape=(3, 16, 16, 16), ctx_dim: int = 1280,
+                        cond_shape: Optional[Tuple[int, ...]] = None):
+    """cond_shape: per-object shape of uc / c -- (1, 1280) for the crossattn family (default), (1, 16, 16, 16) for the
+    concat family's condition volume; its element count is ctx_dim."""
     n_lat = 1
     for v in latent_shape:
         n_lat *= v
+    cs = tuple(cond_shape) if cond_shape is not None else (1, ctx_dim)
     x_T = buf[:n_lat].reshape(1, *latent_shape)
-    uc = buf[n_lat:n_lat + n_obj * ctx_dim].reshape(n_obj, 1, ctx_dim)
-    c = buf[n_lat + n_obj * ctx_dim:n_lat + 2 * n_obj * ctx_dim].reshape(n_obj, 1, ctx_dim)
+    uc = buf[n_lat:n_lat + n_obj * ctx_dim].reshape(n_obj, *cs)
+    c = buf[n_lat + n_obj * ctx_dim:n_lat + 2 * n_obj * ctx_dim].reshape(n_obj, *cs)
     return x_T, uc, c
 
 
 def broadcast_conditioning(x_T: Optional[Tensor], uc: Optional[Tensor], c: Optional[Tensor], n_obj: int,
-                           device, src: int = 0, latent_shape=(3, 16, 16, 16), ctx_dim: int = 1280):
-    """Rank `src` passes real tensors, the others None; everyone returns (x_T, uc, c) for ALL objects."""
+                           device, src: int = 0, latent_shape=(3, 16, 16, 16), ctx_dim: int = 1280,
+                           cond_shape: Optional[Tuple[int, ...]] = None):
+    """Every rank returns rank `src`'s (x_T, uc, c) for ALL objects; the other ranks' arguments are ignored (they may
+    pass None).  One collective over one packed fp32 buffer (49 KB + 10 KB per object)."""
     rank, ws = world()
     n_lat = 1
     for v in latent_shape:
         n_lat *= v
     if rank == src:
         buf = pack_conditioning(x_T, uc, c).to(device)
+        if buf.numel() != n_lat + 2 * n_obj * ctx_dim:
+            raise ValueError("broadcast_conditioning: tensor sizes do not match (n_obj, latent_shape, ctx_dim)")
     else:
         buf = torch.empty(n_lat + 2 * n_obj * ctx_dim, dtype=torch.float32, device=device)
     if ws > 1:
         dist.broadcast(buf, src=src)
-    return unpack_conditioning(buf, n_obj, latent_shape, ctx_dim)
+    return unpack_conditioning(buf, n_obj, latent_shape, ctx_dim, cond_shape)
 
 
 def all_gather_objects(local: Tensor, total: int) -> Tensor:
     """Concatenate per-rank object slabs (contiguous shard_range order).  Shards may differ by one object:
     pad to the largest shard so a single fixed-size all-gather moves everything."""
     rank, ws = world()
-    if ws == 1:
+    if ws == 1 or total == 0:
         return local
     sizes = [shard_range(total, ws, r)[1] - shard_range(total, ws, r)[0] for r in range(ws)]
-    mx = max(sizes)
+    mx = max(sizes)               # >= 1; a rank whose shard is empty (more ranks than objects) sends only padding
     pad = torch.zeros((mx, *local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[:local.shape[0]] = local
-    out = torch.empty((ws * mx, *local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, pad.contiguous())
+    if local.is_cuda and dist.get_backend() == "gloo":
+        # gloo has no device all-gather; only the single-GPU test rigs pair gloo with device tensors (RCCL needs one
+        # GPU per rank), so the slab makes a host round trip there.  RCCL ("nccl") gathers device to device.
+        host = torch.empty((ws * mx, *local.shape[1:]), dtype=local.dtype)
+        dist.all_gather_into_tensor(host, pad.cpu().contiguous())
+        out = host.to(local.device)
+    else:
+        out = torch.empty((ws * mx, *local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, pad.contiguous())
     return torch.cat([out[r * mx:r * mx + sizes[r]] for r in range(ws)], dim=0)
 
 
@@ -88,5 +103,11 @@ def sharded_rel2shape(sample_fn: Callable[[Tensor, Tensor, Tensor], Tensor], x_T
     rank, ws = world()
     total = c.shape[0]
     lo, hi = shard_range(total, ws, rank)
-    local = sample_fn(x_T, uc[lo:hi], c[lo:hi])
+    if hi > lo:
+        local = sample_fn(x_T, uc[lo:hi], c[lo:hi])
+    else:
+        # more ranks than objects: this rank has nothing to sample but must still join the collective; the slab's
+        # trailing shape comes from a peer-independent source -- the sampler's declared output shape
+        shp = getattr(sample_fn, "out_shape", (1, 64, 64, 64))
+        local = torch.empty((0, *shp), dtype=torch.float32, device=c.device)
     return all_gather_objects(local, total) if gather else local

@@ -17,7 +17,7 @@ import torch  # noqa: F401
 
 from .build import LIB_PATH
 
-ABI_VERSION = 7      # cs_abi_version() of the library this module's SIGNATURES table describes
+ABI_VERSION = 8      # cs_abi_version() of the library this module's SIGNATURES table describes
 CS_OK = 0
 CS_EINVAL = -22
 CS_ENOMEM = -12
@@ -51,7 +51,7 @@ class CsConvGemm(C.Structure):
         ("act", C.c_int32), ("rv_rows", C.c_int32), ("math", C.c_int32), ("tile", C.c_int32),
         ("w_lo", C.c_void_p), ("acc_scale", C.c_float), ("a_scale", C.c_float),
         ("x_lo", C.c_void_p), ("a_format", C.c_int32), ("splitk", C.c_int32),
-        ("splitk_ws", C.c_void_p),
+        ("splitk_ws", C.c_void_p), ("status", C.c_void_p),
     ]
 
 
@@ -88,12 +88,12 @@ SIGNATURES = {
     "cs_groupnorm_ws_bytes": (_l, [_i, _i]),
     "cs_groupnorm_stats": (_i, [_f, _i, _i, _i, _i, _i, _fl, _f, _f, _s]),
     "cs_groupnorm_apply": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),
-    "cs_groupnorm_apply_split16": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _fl, _s]),
+    "cs_groupnorm_apply_split16": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _fl, _f, _s]),
     "cs_groupnorm_silu_ndhwc": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _fl, _f, _f, _s]),
     "cs_layernorm": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _fl, _s]),
     "cs_attn_selfattn": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _s]),
-    "cs_attn_selfattn_f16x3": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _s]),
-    "cs_attn_selfattn_f16": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _s]),
+    "cs_attn_selfattn_f16x3": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _f, _s]),
+    "cs_attn_selfattn_f16": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _f, _s]),
     "cs_geglu": (_i, [_f, _f, _i, _i, _i, _i, _s]),
     "cs_copy_rows": (_i, [_f, _f, _l, _i, _i, _i, _s]),
     "cs_add_rowvec": (_i, [_f, _f, _l, _i, _i, _i, _i, _s]),
@@ -103,6 +103,7 @@ SIGNATURES = {
     "cs_ddim_cfg_update": (_i, [_f, _f, _f, _f, _f, _l, _l, _fl, _fl, _fl, _fl, _fl, _i, _s]),
     "cs_ddim_coefficients": (_i, [_fl, _fl, _fl, _fl, _f]),
     "cs_ddim_cfg_update_dev": (_i, [_f, _f, _f, _f, _f, _l, _l, _f, _fl, _i, _s]),
+    "cs_plms_update": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _l, _l, _i, _fl, _fl, _fl, _fl, _i, _s]),
     "cs_chamfer_nm_distance": (_i, [_f, _f, _f, _f, _i, _i, _i, _s]),
     "cs_unet_create": (_i, [C.POINTER(CsUnetConfig), _pp]),
     "cs_unet_destroy": (None, [C.c_void_p]),
@@ -114,8 +115,8 @@ SIGNATURES = {
     "cs_unet_context_floats": (_l, [C.c_void_p]),
     "cs_unet_pack": (_i, [C.c_void_p, _f, _f, _s]),
     "cs_unet_workspace_bytes": (_l, [C.c_void_p, _i, _i]),
-    "cs_unet_context": (_i, [C.c_void_p, _f, _f, _i, _f, _f, _l, _s]),
-    "cs_unet_step": (_i, [C.c_void_p, _f, _f, _f, _f, _f, _i, _i, _f, _l, _s]),
+    "cs_unet_context": (_i, [C.c_void_p, _f, _f, _i, _f, _f, _f, _l, _s]),
+    "cs_unet_step": (_i, [C.c_void_p, _f, _f, _f, _f, _f, _i, _i, _f, _f, _l, _s]),
     "cs_vq_argmin_lookup": (_i, [_f, _f, _f, _f, _l, _i, _i, _i, _i, _s]),
     "cs_gcn_gather_cat": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _f, _s]),
     "cs_gcn_segment_mean": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _f, _s]),
@@ -131,7 +132,7 @@ SIGNATURES = {
     "cs_vqvae_arena_bytes": (_l, [C.c_void_p]),
     "cs_vqvae_pack": (_i, [C.c_void_p, _f, _f, _s]),
     "cs_vqvae_workspace_bytes": (_l, [C.c_void_p, _i]),
-    "cs_vqvae_decode": (_i, [C.c_void_p, _f, _f, _f, _f, _i, _i, _f, _l, _s]),
+    "cs_vqvae_decode": (_i, [C.c_void_p, _f, _f, _f, _f, _i, _i, _f, _f, _l, _s]),
     "cs_abi_version": (_i, []),
 }
 
@@ -171,6 +172,13 @@ def load(path: Path | None = None) -> C.CDLL:
 
 class CsError(RuntimeError):
     pass
+
+
+class CsOverflowError(CsError):
+    """A CS_MATH_F16X3 kernel met an activation beyond the fp16 range (CS_STATUS_F16X3_OVERFLOW)."""
+
+
+STATUS_F16X3_OVERFLOW = 1
 
 
 def check(rc: int, what: str) -> None:

@@ -28,6 +28,64 @@ def _ptr(t: Optional[Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+# One sticky CS_STATUS_* word per device (include/commonscenes_hip.h): every F16X3 kernel launched from this module ORs
+# CS_STATUS_F16X3_OVERFLOW into it when an operand leaves the fp16 range.  Nothing reads it inside the sampling
+# loop; the model classes call check_overflow() once per sampling run / decode (one scalar read-back).
+_STATUS: dict = {}
+
+
+def status_word(device=None) -> Tensor:
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    t = _STATUS.get(dev.index)
+    if t is None:
+        t = _STATUS[dev.index] = torch.zeros((1,), dtype=torch.int32, device=dev)
+    return t
+
+
+def read_status(device=None, reset: bool = True) -> int:
+    """The device's status word (synchronises: one 4-byte read-back); cleared when `reset`."""
+    t = status_word(device)
+    v = int(t.item())
+    if v and reset:
+        t.zero_()
+    return v
+
+
+def check_overflow(device=None, what: str = "F16X3 kernels") -> None:
+    """Raise CsOverflowError if any F16X3 kernel since the last check met an activation beyond the fp16 range
+    (|a| >= 65504 / 16 ~ 4094): that launch's output is garbage; the caller re-runs with set_math('fp32')."""
+    if read_status(device) & L.STATUS_F16X3_OVERFLOW:
+        raise L.CsOverflowError(f"{what}: an activation left the fp16 range of CS_MATH_F16X3 (|a| * 16 >= 65504); "
+                                "results of this run are invalid -- use set_math('fp32')")
+
+
+# Index-error word per device: the gather kernels (cs_gcn_gather_cat, cs_gcn_segment_mean, cs_embedding) set it when an
+# edge endpoint / embedding index is out of range (and skip that entry).  The reference's nn.Embedding / tensor indexing
+# raise IndexError for the same input (VAEGAN_V2FULL.py:225-226, graph.py:146-147): check_index_errors() -- one
+# read-back per encoder / decoder call -- turns the flag into that exception.
+_INDEX_ERR: dict = {}
+
+
+def index_err_word(device=None) -> Tensor:
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    t = _INDEX_ERR.get(dev.index)
+    if t is None:
+        t = _INDEX_ERR[dev.index] = torch.zeros((1,), dtype=torch.int32, device=dev)
+    return t
+
+
+def check_index_errors(device=None, what: str = "scene-graph indices") -> None:
+    t = index_err_word(device)
+    if int(t.item()):
+        t.zero_()
+        raise IndexError(f"{what}: index out of range (an object / predicate id beyond the embedding table, or a "
+                         "triple endpoint beyond the node count)")
+
+
 def _chk(t: Tensor, name: str, dtype=torch.float32) -> None:
     if not t.is_cuda:
         raise L.CsError(f"{name}: expected a HIP device tensor (the HIP path has no CPU fallback)")
@@ -203,6 +261,7 @@ def conv_gemm(x: Tensor, w: PackedWeight, *, spatial: Optional[Tuple[int, int, i
         p.a_scale = A_SCALE
         if xs is not None:
             p.x_lo, p.a_format = xs.lo.data_ptr(), 1
+        p.status = status_word(x.device).data_ptr()
     else:
         p.x, p.w, p.out = x.data_ptr(), w.wt.data_ptr(), out.data_ptr()
     p.bias = _ptr(w.bias)
@@ -321,7 +380,8 @@ def groupnorm(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float, a
         yl = torch.empty(x.shape, dtype=torch.float16, device=x.device)
         L.check(lib.cs_groupnorm_apply_split16(x.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                                                yh.data_ptr(), yl.data_ptr(), nb, rows, c, ldx, c, groups, act,
-                                               A_SCALE, _stream()), "cs_groupnorm_apply_split16")
+                                               A_SCALE, status_word(x.device).data_ptr(), _stream()),
+                "cs_groupnorm_apply_split16")
         return Split16(yh, yl)
     if out is None:
         out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
@@ -362,9 +422,13 @@ def attention(q: Tensor, k: Tensor, v: Tensor, heads: int, scale: float, out: Op
         out = torch.empty((nb, nq, cq), dtype=torch.float32, device=q.device)
     _, _, ldo = rows_ld(out, "out")
     lib = L.load()
-    fn = {L.MATH_F16X3: lib.cs_attn_selfattn_f16x3, L.MATH_F16: lib.cs_attn_selfattn_f16}.get(math, lib.cs_attn_selfattn)
-    L.check(fn(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo,
-               scale, _stream()), "cs_attn_selfattn")
+    if math in (L.MATH_F16X3, L.MATH_F16):
+        fn = lib.cs_attn_selfattn_f16x3 if math == L.MATH_F16X3 else lib.cs_attn_selfattn_f16
+        L.check(fn(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo,
+                   scale, status_word(q.device).data_ptr(), _stream()), "cs_attn_selfattn_f16x3")
+    else:
+        L.check(lib.cs_attn_selfattn(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), nb, nq, nk, heads, dh,
+                                     ldq, ldk, ldv, ldo, scale, _stream()), "cs_attn_selfattn")
     return out
 
 
@@ -472,6 +536,34 @@ def ddim_cfg_update(x: Tensor, eps: Tensor, a_t: float, a_prev: float, sigma_t: 
     return xp, p0
 
 
+PLMS_PLAIN, PLMS_AB2, PLMS_AB3, PLMS_AB4, PLMS_EULER_AVG = 0, 1, 2, 3, 4
+
+
+def plms_update(x: Tensor, eps: Tensor, hist: Sequence[Tensor], mode: int, a_t: float, a_prev: float,
+                sqrt_one_minus_at: float, cfg_scale: float, cfg: bool, want_e: bool = True,
+                want_pred_x0: bool = True) -> Tuple[Tensor, Optional[Tensor], Optional[Tensor]]:
+    """cs_plms_update: (x_prev, pred_x0, e_t).  `hist` = earlier noise predictions, newest first."""
+    _chk(x, "x"); _chk(eps, "eps")
+    x = x.contiguous(); eps = eps.contiguous()
+    nb = x.shape[0]
+    per = x.numel() // nb
+    if eps.numel() != (2 if cfg else 1) * x.numel():
+        raise L.CsError("eps must hold [uc; c] halves when cfg is on")
+    hs = [h.contiguous() for h in hist]
+    for h in hs:
+        _chk(h, "hist")
+        if h.numel() != x.numel():
+            raise L.CsError("history entries must have x's shape")
+    hp = [h.data_ptr() for h in hs] + [None] * (3 - len(hs))
+    xp = torch.empty_like(x)
+    p0 = torch.empty_like(x) if want_pred_x0 else None
+    e = torch.empty_like(x) if want_e else None
+    L.check(L.load().cs_plms_update(x.data_ptr(), eps.data_ptr(), hp[0], hp[1], hp[2], _ptr(e), xp.data_ptr(), _ptr(p0),
+                                    nb, per, mode, a_t, a_prev, sqrt_one_minus_at, cfg_scale, 1 if cfg else 0,
+                                    _stream()), "cs_plms_update")
+    return xp, p0, e
+
+
 def ddim_coefficients(a_t: float, a_prev: float, sigma_t: float, sqrt_one_minus_at: float) -> Tuple[float, ...]:
     """Host helper: the five fp32 coefficients cs_ddim_cfg_update derives from its scalar arguments."""
     buf = (C.c_float * 5)()
@@ -518,7 +610,7 @@ def gcn_gather_cat(obj: Tensor, pred: Tensor, edges: Tensor) -> Tensor:
     n_obj, d_obj = obj.shape
     n_tri, d_pred = pred.shape
     out = torch.empty((n_tri, 2 * d_obj + d_pred), dtype=torch.float32, device=obj.device)
-    err = torch.zeros((1,), dtype=torch.int32, device=obj.device)
+    err = index_err_word(obj.device)
     L.check(L.load().cs_gcn_gather_cat(obj.data_ptr(), pred.data_ptr(), edges.data_ptr(), out.data_ptr(),
                                        n_obj, n_tri, d_obj, d_pred, err.data_ptr(), _stream()),
             "cs_gcn_gather_cat")
@@ -529,7 +621,7 @@ def gcn_segment_mean(new_t: Tensor, edges: Tensor, n_obj: int, h: int, off_o: in
     _chk(new_t, "new_t"); _chk(edges, "edges", torch.int64)
     n_tri, _, ld_t = rows_ld(new_t, "new_t")
     pooled = torch.empty((n_obj, h), dtype=torch.float32, device=new_t.device)
-    err = torch.zeros((1,), dtype=torch.int32, device=new_t.device)
+    err = index_err_word(new_t.device)
     L.check(L.load().cs_gcn_segment_mean(new_t.data_ptr(), edges.contiguous().data_ptr(), pooled.data_ptr(),
                                          n_obj, n_tri, h, off_o, ld_t, err.data_ptr(), _stream()),
             "cs_gcn_segment_mean")
@@ -543,7 +635,7 @@ def embedding(table: Tensor, idx: Tensor, out: Optional[Tensor] = None) -> Tenso
     if out is None:
         out = torch.empty((n, dim), dtype=torch.float32, device=table.device)
     _, oc, ldo = rows_ld(out, "out")
-    err = torch.zeros((1,), dtype=torch.int32, device=table.device)
+    err = index_err_word(table.device)
     L.check(L.load().cs_embedding(table.contiguous().data_ptr(), idx.contiguous().data_ptr(), out.data_ptr(),
                                   n, dim, n_rows, ldo, err.data_ptr(), _stream()), "cs_embedding")
     return out

@@ -167,6 +167,9 @@ class GraphTripleConvNet:
     def __call__(self, obj_vecs, pred_vecs, edges):
         for g in self.gconvs:
             obj_vecs, pred_vecs = g(obj_vecs, pred_vecs, edges)
+        # the gather kernels skip out-of-range indices and raise a device flag; the reference's indexing
+        # (graph.py:146-147, nn.Embedding) raises IndexError -- one read-back per GCN call keeps that behaviour
+        ops.check_index_errors(obj_vecs.device, "scene graph (object / predicate ids, triple endpoints)")
         return obj_vecs, pred_vecs
 
 
@@ -450,7 +453,7 @@ class Sg2ScVAEModel(BoxVAEMixin):
             return d3, ops.log_softmax(self._nets["angle"](obj_vecs_))
         return d3
 
-    def _shapes_for(self, z, objs, triples, text, rel, dec_sdfs, attributes, x_T, ddim_steps):
+    def _shapes_for(self, z, objs, triples, text, rel, dec_sdfs, attributes, x_T, ddim_steps, sharded=None):
         """the gen_shape branch shared by sample / decoder_with_changes / decoder_with_additions
         (VAEGAN_V2FULL.py:309-318, 367-376, 606-616)."""
         dev = self.device
@@ -460,7 +463,9 @@ class Sg2ScVAEModel(BoxVAEMixin):
         ids = torch.unique(torch.where(mask)[0])
         ids_d = ids.to(dev)
         diff_dict = {"sdf": dec_sdfs[ids], "rel": rel_feat[ids_d], "uc": un_rel_feat[ids_d]}
-        return self.Diff.rel2shape(diff_dict, ddim_steps=ddim_steps, uc_scale=3., x_T=x_T)
+        # under torch.distributed (one process per GPU) rel2shape shards the objects over the ranks: one broadcast of
+        # rank 0's conditioning in, one all-gather of the SDFs out; `sharded` None = automatic
+        return self.Diff.rel2shape(diff_dict, ddim_steps=ddim_steps, uc_scale=3., x_T=x_T, sharded=sharded)
 
     @torch.no_grad()
     def decoder_with_additions(self, z, objs, triples, encoded_dec_text_feat, encoded_dec_rel_feat, dec_sdfs,
@@ -502,15 +507,18 @@ class Sg2ScVAEModel(BoxVAEMixin):
     @torch.no_grad()
     def sample(self, point_classes_idx, mean_est, cov_est, dec_objs, dec_triplets, dec_sdfs,
                encoded_dec_text_feat, encoded_dec_rel_feat, attributes=None, gen_shape=False,
-               z: Optional[Tensor] = None, x_T: Optional[Tensor] = None, ddim_steps: int = 100):
+               z: Optional[Tensor] = None, x_T: Optional[Tensor] = None, ddim_steps: int = 100,
+               sharded: Optional[bool] = None):
         """VAEGAN_V2FULL.py:600-618.  Extensions: `z`, `x_T` and `ddim_steps` can be injected (the reference
-        draws z from numpy's global RNG and x_T from a time-seeded torch RNG)."""
+        draws z from numpy's global RNG and x_T from a time-seeded torch RNG); `sharded` (None = automatic when a
+        torch.distributed process group exists) splits the shaped objects over the ranks -- every rank calls sample()
+        with the same arguments and every rank gets all the SDFs back."""
         dev = self.device
         if z is None:
             z = torch.from_numpy(np.random.multivariate_normal(_np(mean_est), _np(cov_est), dec_objs.size(0))).float()
         z = z.to(dev)
         text = encoded_dec_text_feat.to(device=dev, dtype=torch.float32)
         rel = encoded_dec_rel_feat.to(device=dev, dtype=torch.float32)
-        gen_sdf = (self._shapes_for(z, dec_objs, dec_triplets, text, rel, dec_sdfs, attributes, x_T, ddim_steps)
+        gen_sdf = (self._shapes_for(z, dec_objs, dec_triplets, text, rel, dec_sdfs, attributes, x_T, ddim_steps, sharded)
                    if gen_shape else None)
         return self.decoder(z, dec_objs, dec_triplets, text, rel, attributes), gen_sdf

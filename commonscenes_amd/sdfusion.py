@@ -24,6 +24,9 @@ import numpy as np
 import torch
 import yaml
 
+from . import dist
+from . import lib as L
+from . import ops
 from .ddim import DDIMSampler
 from .unet import DiffusionUNet
 from .unet_native import NativeDiffusionUNet
@@ -179,13 +182,66 @@ class SDFusionText2ShapeModel:
         """[eps_uc; eps_c] for the guidance pair batch (ddim.py:206-209) without duplicating (x, t)."""
         return self.df.forward_cfg(x, t, c_in)
 
+    # ---- F16X3 overflow policy -------------------------------------------------------------------------------------
+    # CS_MATH_F16X3 carries activations as fp16 pairs of a * 16: |a| >= ~4094 cannot be represented.  Every F16X3
+    # kernel reports that in a sticky device word (CS_STATUS_F16X3_OVERFLOW); it is read back ONCE per sampler run /
+    # decode.  'fp32' (default): re-run that mini-batch on the fp32-input MFMA kernels and stay there;
+    # 'raise': propagate CsOverflowError.
+    overflow_policy = os.environ.get("CS_OVERFLOW_POLICY", "fp32")
+
+    def _sample_minibatch(self, sampler, ddim_steps, shape, c, uc, noise, uc_scale, ddim_eta, max_steps):
+        def run():
+            if hasattr(self.df, "reset_run_cache"):
+                self.df.reset_run_cache()           # per-run caches (one-token context vectors) never outlive a run
+            out, _ = sampler.sample(S=ddim_steps, batch_size=c.shape[0], shape=shape, conditioning=c, x_T=noise,
+                                    verbose=False, unconditional_guidance_scale=uc_scale,
+                                    unconditional_conditioning=uc, eta=ddim_eta, max_steps=max_steps)
+            ops.check_overflow(self.device, "DDIM sampling (UNet)")
+            return out
+        try:
+            return run()
+        except L.CsOverflowError:
+            if self.overflow_policy != "fp32" or getattr(self.df, "math", None) != L.MATH_F16X3:
+                raise
+            import warnings
+            warnings.warn("F16X3 activation overflow in the UNet: re-running this mini-batch (and continuing) on the "
+                          "fp32-input MFMA kernels (set_math('fp32'))")
+            self.df.set_math("fp32")
+            return run()
+
+    def _decode_checked(self, samples):
+        out = self.vqvae_module.decode_no_quant(samples)
+        try:
+            ops.check_overflow(self.device, "VQ-VAE decode")
+        except L.CsOverflowError:
+            if self.overflow_policy != "fp32" or getattr(self.vqvae, "math", None) != L.MATH_F16X3:
+                raise
+            import warnings
+            warnings.warn("F16X3 activation overflow in the VQ-VAE decoder: re-running on the fp32-input MFMA kernels")
+            self.vqvae.set_math("fp32")
+            out = self.vqvae_module.decode_no_quant(samples)
+        return out
+
     @torch.no_grad()
     def rel2shape(self, data, ddim_steps=100, ddim_eta=0.0, uc_scale=None, x_T: Optional[Tensor] = None,
-                  mini_B: Optional[int] = None, return_latents: bool = False, max_steps: Optional[int] = None):
-        """:459-516.  data = {'sdf': (B,...) only its batch size is used, 'rel': (B,1,1280), 'uc': (B,1,1280)}."""
+                  mini_B: Optional[int] = None, return_latents: bool = False, max_steps: Optional[int] = None,
+                  sharded: Optional[bool] = None, sampler: str = "ddim"):
+        """:459-516.  data = {'sdf': (B,...) only its batch size is used, 'rel': (B,1,1280), 'uc': (B,1,1280)}.
+
+        Extensions: `x_T` injection (the reference seeds from the clock), `mini_B` (reference: 7),
+        `sampler` ('ddim' | 'plms', samplers/plms.py), and `sharded`: with torch.distributed initialised (one process
+        per GPU, RCCL) the objects are split contiguously over the ranks -- rank 0's (x_T, uc, c) is broadcast once,
+        every rank samples + decodes its shard, one all-gather returns ALL objects on every rank.  No per-step
+        collective.  Default (None): shard iff a process group with more than one rank exists and CS_SHARD != 0."""
         self.switch_eval()
         self.set_input(data)
-        ddim_sampler = DDIMSampler(self)
+        if sampler == "ddim":
+            smp = DDIMSampler(self)
+        elif sampler == "plms":
+            from .plms import PLMSSampler
+            smp = PLMSSampler(self)
+        else:
+            raise ValueError(f"sampler must be 'ddim' or 'plms', got {sampler!r}")
         if ddim_steps is None:
             ddim_steps = self.ddim_steps
         if uc_scale is None:
@@ -200,21 +256,41 @@ class SDFusionText2ShapeModel:
             single_noise = torch.randn((1, C_, D, H, W), device=self.device)
         else:
             single_noise = x_T.to(device=self.device, dtype=torch.float32).reshape(1, C_, D, H, W)
-        noise = single_noise.repeat(B, 1, 1, 1, 1)                       # every object shares one x_T (:491)
+        rank, ws = dist.world()
+        if sharded is None:
+            sharded = ws > 1 and os.environ.get("CS_SHARD", "1") != "0"
+        lo, hi = 0, B
+        if sharded and ws > 1:
+            # one broadcast of the packed [x_T | uc | c] buffer: every rank then holds rank 0's bits (x_T is
+            # time-seeded, and the GCN that produced uc / c ran on every rank or only on rank 0 -- either way)
+            single_noise, uc, c_text = dist.broadcast_conditioning(
+                single_noise, uc, c_text, B, self.device, src=0, latent_shape=shape,
+                ctx_dim=int(c_text[0].numel()) if B else 0, cond_shape=tuple(c_text.shape[1:]))
+            lo, hi = dist.shard_range(B, ws, rank)
+        r = self.vqvae.cfg["resolution"] if hasattr(self.vqvae, "cfg") else 64
+        och = self.vqvae.cfg.get("out_ch", 1) if hasattr(self.vqvae, "cfg") else 1
         mb = int(mini_B or self.mini_B)
         gen, lats = [], []
-        for i in range(int(np.ceil(B / mb))):
-            sl = slice(i * mb, (i + 1) * mb)
-            num = c_text[sl].shape[0]
-            samples, _ = ddim_sampler.sample(S=ddim_steps, batch_size=num, shape=shape, conditioning=c_text[sl],
-                                             x_T=noise[sl], verbose=False,
-                                             unconditional_guidance_scale=uc_scale,
-                                             unconditional_conditioning=uc[sl], eta=ddim_eta, max_steps=max_steps)
+        for i in range(lo, hi, mb):                                      # ceil((hi - lo) / mb) sampler runs (:493-511)
+            sl = slice(i, min(i + mb, hi))
+            num = sl.stop - sl.start
+            noise = single_noise.repeat(num, 1, 1, 1, 1)                 # every object shares one x_T (:491)
+            samples = self._sample_minibatch(smp, ddim_steps, shape, c_text[sl], uc[sl], noise, uc_scale, ddim_eta,
+                                             max_steps)
             lats.append(samples)
-            gen.append(self.vqvae_module.decode_no_quant(samples))
-        self.gen_df = torch.cat(gen, dim=0)
+            gen.append(self._decode_checked(samples))
+        if gen:
+            local, llat = torch.cat(gen, dim=0), torch.cat(lats, dim=0)
+        else:       # an empty shard (more ranks than objects) or B == 0: nothing to sample, still join the gather
+            local = torch.empty((0, och, r, r, r), dtype=torch.float32, device=self.device)
+            llat = torch.empty((0, C_, D, H, W), dtype=torch.float32, device=self.device)
+        if sharded and ws > 1:
+            local = dist.all_gather_objects(local, B)
+            if return_latents:
+                llat = dist.all_gather_objects(llat, B)
+        self.gen_df = local
         if return_latents:
-            return self.gen_df, torch.cat(lats, dim=0)
+            return self.gen_df, llat
         return self.gen_df
 
     # ---- checkpoint surface (VAEGAN_V2FULL.py:687-699 stores these under 'df' / 'vqvae') ----

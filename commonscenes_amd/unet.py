@@ -192,6 +192,7 @@ class DiffusionUNet:
         self._sd: Dict[str, Tensor] = {}
         self._packed = None
         self.training = False
+        self._ctx_cache = None
         self.math = L.DEFAULT_MATH      # F16X3 unless CS_MATH=fp32
         self.attn_math: Optional[int] = None        # None: follow self.math; L.MATH_F16: plain-fp16 attention (opt-in)
         self.trace: Optional[Dict[str, Tensor]] = None   # set to {} to capture per-block outputs (tests)
@@ -252,6 +253,17 @@ class DiffusionUNet:
         outside the fp32 parity gates."""
         self.attn_math = {None: None, "same": None, "f16": L.MATH_F16}[mode]
         return self
+
+    def reset_run_cache(self) -> None:
+        """Drop per-sampling-run caches (the one-token context vectors).  The cache key is the context tensor's
+        identity + autograd version, which in-place writes through raw pointers (C-ABI kernels, collectives
+        refilling a reused buffer) do not bump: rel2shape calls this at the start of every sampler run."""
+        self._ctx_cache = None
+
+    def check_overflow(self) -> None:
+        """Raise CsOverflowError if an F16X3 kernel on this device met an activation beyond the fp16 range since the
+        last check (one 4-byte read-back; not called inside the sampling loop)."""
+        ops.check_overflow(self.device, "DiffusionUNet")
 
     def num_parameters(self) -> int:
         n = 0

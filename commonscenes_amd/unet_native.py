@@ -15,6 +15,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import lib as L
+from . import ops
 from .unet import _cfg
 
 Tensor = torch.Tensor
@@ -151,6 +152,13 @@ class NativeDiffusionUNet:
             self._ws_key = key
         return self._ws
 
+    def reset_run_cache(self) -> None:
+        """Drop the per-run context-vector cache (see DiffusionUNet.reset_run_cache)."""
+        self._ctx_cache = None
+
+    def check_overflow(self) -> None:
+        ops.check_overflow(self.device, "NativeDiffusionUNet")
+
     def context_vectors(self, ctx: Tensor, ws: Tensor) -> Tensor:
         """cs_unet_context, cached per conditioning tensor (the sampler passes the same [uc; c] every step)."""
         if ctx.dim() == 3:
@@ -163,7 +171,8 @@ class NativeDiffusionUNet:
         ctx = ctx.to(torch.float32).contiguous()
         vec = torch.empty((ctx.shape[0], self.ctx_floats), dtype=torch.float32, device=self.device)
         L.check(L.load().cs_unet_context(self._h, self._arena.data_ptr(), ctx.data_ptr(), ctx.shape[0], vec.data_ptr(),
-                                         ws.data_ptr(), ws.numel(), _stream()), "cs_unet_context")
+                                         ops.status_word(self.device).data_ptr(), ws.data_ptr(), ws.numel(),
+                                         _stream()), "cs_unet_context")
         self._ctx_cache = (key, vec, ctx)
         return vec
 
@@ -186,7 +195,8 @@ class NativeDiffusionUNet:
             vec_ptr = vec.data_ptr()
         out = torch.empty((nbo, self.cfg["out_channels"], *self.grid), dtype=torch.float32, device=self.device)
         L.check(L.load().cs_unet_step(self._h, self._arena.data_ptr(), x.data_ptr(), t.data_ptr(), vec_ptr,
-                                      out.data_ptr(), nb, 1 if cfg_pairs else 0, ws.data_ptr(), ws.numel(), _stream()),
+                                      out.data_ptr(), nb, 1 if cfg_pairs else 0,
+                                      ops.status_word(self.device).data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
                 "cs_unet_step")
         return out
 

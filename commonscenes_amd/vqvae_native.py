@@ -13,6 +13,7 @@ from typing import Dict, Optional, Tuple
 import torch
 
 from . import lib as L
+from . import ops
 from .vqvae import _dd
 
 Tensor = torch.Tensor
@@ -114,7 +115,8 @@ class NativeVQVAE:
         idx = torch.empty((nb * g ** 3,), dtype=torch.int64, device=self.device) if quantize else None
         L.check(lib.cs_vqvae_decode(self._h, self._arena.data_ptr(), h.data_ptr(), out.data_ptr(),
                                     idx.data_ptr() if idx is not None else None, nb, 1 if quantize else 0,
-                                    self._ws.data_ptr(), self._ws.numel(), _stream()), "cs_vqvae_decode")
+                                    ops.status_word(self.device).data_ptr(), self._ws.data_ptr(), self._ws.numel(),
+                                    _stream()), "cs_vqvae_decode")
         if quantize:
             self.last_indices = idx
         return out

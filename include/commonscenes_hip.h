@@ -43,6 +43,12 @@ typedef struct ihipStream_t* cs_stream_t; /* == hipStream_t */
 #define CS_ACT_GEGLU 4 /* CS_MATH_F16X3 only: weight columns packed per 224-column tile as [x(112) | gate(112)];
                           out[m][n/2] = (x + bias) * gelu(gate + bias), out has cout/2 columns (attention.py:39-46) */
 
+/* Sticky status bits a kernel may OR into a caller-owned device int32 (`status` arguments / CsConvGemm.status;
+ * NULL = not wanted).  The library never clears the word and never reads it back.
+ *   CS_STATUS_F16X3_OVERFLOW: a CS_MATH_F16X3 kernel met an operand with |a| * a_scale >= 65504 (fp16 range): its hi
+ *   half is +-inf and the result of that launch is garbage -- re-run on CS_MATH_FP32 (the host classes do). */
+#define CS_STATUS_F16X3_OVERFLOW 1
+
 /* GEMM numerics mode */
 #define CS_MATH_FP32 0     /* v_mfma_f32_32x32x2_f32, bit-equal to an fp32 fma chain  */
 #define CS_MATH_F16X3 1    /* 3x v_mfma_f32_32x32x16_f16 on hi/lo fp16 splits (~2^-21) */
@@ -100,6 +106,7 @@ typedef struct CsConvGemm {
    * epilogue.  0 or 1 = off.  cs_conv_gemm_plan proposes the value. */
   int32_t splitk;
   void* splitk_ws;
+  int32_t* status;   /* sticky CS_STATUS_* word (device), or NULL */
 } CsConvGemm;
 
 int cs_conv_gemm(const CsConvGemm* desc, cs_stream_t stream);
@@ -151,7 +158,7 @@ int cs_groupnorm_apply(const float* x, const float* stats, const float* gamma, c
  * half images), the A-operand format of CS_MATH_F16X3 GEMMs with a_format = 1. */
 int cs_groupnorm_apply_split16(const float* x, const float* stats, const float* gamma, const float* beta,
                                void* y_hi, void* y_lo, int nb, int rows, int c, int ldx, int ldy, int groups,
-                               int act, float a_scale, cs_stream_t stream);
+                               int act, float a_scale, int32_t* status, cs_stream_t stream);
 /* SURVEY name: both steps, SiLU epilogue. */
 int cs_groupnorm_silu_ndhwc(const float* x, const float* gamma, const float* beta, float* y,
                             int nb, int rows, int c, int groups, float eps, void* ws, float* stats,
@@ -176,14 +183,14 @@ int cs_attn_selfattn(const float* q, const float* k, const float* v, float* out,
  * fp16 MFMA (3 products per contraction, fp32 accumulate and fp32 softmax). */
 int cs_attn_selfattn_f16x3(const float* q, const float* k, const float* v, float* out, int nb, int nq,
                            int nk, int heads, int dh, int ldq, int ldk, int ldv, int ldo, float scale,
-                           cs_stream_t stream);
+                           int32_t* status, cs_stream_t stream);
 
 /* Same contract, PLAIN fp16 operands on the fp16 MFMA (one pass instead of three; fp32 softmax and accumulation):
  * the "fp16 MFMA attention" option BASELINE configs[4] names.  Reduced precision (~3e-4 relative on the attention
  * output) -- opt-in, outside the fp32 parity gates, never the default. */
 int cs_attn_selfattn_f16(const float* q, const float* k, const float* v, float* out, int nb, int nq,
                          int nk, int heads, int dh, int ldq, int ldk, int ldv, int ldo, float scale,
-                         cs_stream_t stream);
+                         int32_t* status, cs_stream_t stream);
 
 /* GEGLU gate: out[m][j] = x[m][j] * gelu(x[m][h + j])  (attention.py:44-46). */
 int cs_geglu(const float* x, float* out, int m, int h, int ldx, int ldo, cs_stream_t stream);
@@ -233,6 +240,28 @@ int cs_ddim_coefficients(float a_t, float a_prev, float sigma_t, float sqrt_one_
 int cs_ddim_cfg_update_dev(const float* x, const float* eps, const float* noise, float* x_prev,
                            float* pred_x0, int64_t nb, int64_t per, const float* coef5_dev,
                            float cfg_scale, int cfg, cs_stream_t stream);
+
+/*
+ * PLMS step (samplers/plms.py:175-236, the alternative sampler; eta must be 0 there, plms.py:29-30): fused guidance
+ * combine + pseudo linear multistep combination + x0 / x_{t-1} update.
+ *   e_t     = cfg ? e_uc + scale * (e_c - e_uc) : eps          -> e_out (optional: the history entry to keep)
+ *   e_t'    = CS_PLMS_PLAIN      e_t
+ *             CS_PLMS_AB2        (3 e_t - h1) / 2
+ *             CS_PLMS_AB3        (23 e_t - 16 h1 + 5 h2) / 12
+ *             CS_PLMS_AB4        (55 e_t - 59 h1 + 37 h2 - 9 h3) / 24        h1 = newest earlier prediction
+ *             CS_PLMS_EULER_AVG  (h1 + e_t) / 2      second half of the start-up step: h1 = e_t of the first half,
+ *                                                    eps = the model at (x_prev of the first half, t_next)
+ *   pred_x0 = (x - sqrt_one_minus_at * e_t') / sqrt(a_t);   x_prev = sqrt(a_prev) * pred_x0 + sqrt(1 - a_prev) * e_t'
+ * x_prev may alias x; pred_x0, e_out and unused history pointers may be NULL.
+ */
+#define CS_PLMS_PLAIN 0
+#define CS_PLMS_AB2 1
+#define CS_PLMS_AB3 2
+#define CS_PLMS_AB4 3
+#define CS_PLMS_EULER_AVG 4
+int cs_plms_update(const float* x, const float* eps, const float* h1, const float* h2, const float* h3,
+                   float* e_out, float* x_prev, float* pred_x0, int64_t nb, int64_t per, int mode, float a_t,
+                   float a_prev, float sqrt_one_minus_at, float cfg_scale, int cfg, cs_stream_t stream);
 
 /*
  * VQ nearest-code lookup (quantizer.py:76-84): z [m][ldz] (first edim entries of each row),
@@ -299,6 +328,7 @@ int cs_chamfer_nm_distance(const float* xyz1, const float* xyz2, float* dist, in
  *                         plan's math mode (q|k|v fused, all ResBlock emb_layers fused, GEGLU columns
  *                         interleaved per 224-column tile), biases, norm affine parameters.
  *   cs_unet_context       once per sampling run: ctx [nb_ctx][context_dim] -> ctxvec [nb_ctx][cs_unet_context_floats]
+ *   status                (cs_unet_context / cs_unet_step / cs_vqvae_decode) sticky CS_STATUS_* word on the device, or NULL.
  *   cs_unet_step          eps = UNet(x, t, ctx).  x: NCDHW [nb_x][in_channels][d][h][w]; t: int64 [nb_x];
  *                         cfg_pairs = 0: nb_ctx == nb_x.  cfg_pairs = 1 (classifier-free guidance, ddim.py:206-209):
  *                         the SAME (x, t) under two contexts, ctxvec holds 2*nb_x rows [uc; c], the context-free
@@ -333,9 +363,9 @@ int64_t cs_unet_context_floats(const cs_unet* u);
 int cs_unet_pack(cs_unet* u, const void* raw_dev, void* arena_dev, cs_stream_t stream);
 int64_t cs_unet_workspace_bytes(const cs_unet* u, int nb_x, int cfg_pairs);
 int cs_unet_context(const cs_unet* u, const void* arena, const float* ctx, int nb_ctx, float* ctxvec,
-                    void* workspace, int64_t workspace_bytes, cs_stream_t stream);
+                    int32_t* status, void* workspace, int64_t workspace_bytes, cs_stream_t stream);
 int cs_unet_step(const cs_unet* u, const void* arena, const float* x_ncdhw, const int64_t* t,
-                 const float* ctxvec, float* eps_ncdhw, int nb_x, int cfg_pairs, void* workspace,
+                 const float* ctxvec, float* eps_ncdhw, int nb_x, int cfg_pairs, int32_t* status, void* workspace,
                  int64_t workspace_bytes, cs_stream_t stream);
 
 /*
@@ -369,8 +399,8 @@ int64_t cs_vqvae_arena_bytes(const cs_vqvae* u);
 int cs_vqvae_pack(cs_vqvae* u, const void* raw_dev, void* arena_dev, cs_stream_t stream);
 int64_t cs_vqvae_workspace_bytes(const cs_vqvae* u, int nb);
 int cs_vqvae_decode(const cs_vqvae* u, const void* arena, const float* latent_ncdhw, float* sdf_ncdhw,
-                    int64_t* code_indices, int nb, int quantize, void* workspace, int64_t workspace_bytes,
-                    cs_stream_t stream);
+                    int64_t* code_indices, int nb, int quantize, int32_t* status, void* workspace,
+                    int64_t workspace_bytes, cs_stream_t stream);
 
 /* Library / device self-description. */
 int cs_abi_version(void);

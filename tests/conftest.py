@@ -32,3 +32,33 @@ def rel_l2(a, b):
 
 
 GOLDEN = ROOT / "tests" / "golden"
+
+
+def vq_flip_report(lat_mine, lat_ref, idx_mine, idx_ref, codebook):
+    """VQ code-flip accounting for an end-to-end fixture ("VQ indices: report flips, target 0").
+
+    lat_*: (B,3,g,g,g) latents handed to decode_no_quant (mine / the reference's), idx_*: (B,g,g,g) argmin indices,
+    codebook: (n_embed, 3).  Returns (flips_per_object, unexplained) where `unexplained` counts flipped voxels that are
+    NOT provable fp32 near-ties: with the reference's own latent z_ref, the code I picked must be at most
+        2 |z_mine - z_ref| |e_mine - e_ref|  +  8 eps32 (|z|^2 + |e|^2)
+    farther than the code the reference picked -- the first term is how much a latent perturbation can move the
+    difference of two squared distances, the second the rounding of quantizer.py:76-79's fp32 z^2 + e^2 - 2 z.e."""
+    import torch
+    zm = lat_mine.detach().double().cpu().permute(0, 2, 3, 4, 1).reshape(-1, 3)
+    zr = lat_ref.detach().double().cpu().permute(0, 2, 3, 4, 1).reshape(-1, 3)
+    im = idx_mine.detach().cpu().reshape(-1).long()
+    ir = idx_ref.detach().cpu().reshape(-1).long()
+    cb = codebook.detach().double().cpu()
+    B = lat_mine.shape[0]
+    per = zm.shape[0] // B
+    bad = (im != ir).nonzero().flatten()
+    flips = [int(((bad >= b * per) & (bad < (b + 1) * per)).sum()) for b in range(B)]
+    if bad.numel() == 0:
+        return flips, 0
+    em, er = cb[im[bad]], cb[ir[bad]]
+    z_r, z_m = zr[bad], zm[bad]
+    gap = ((z_r - em) ** 2).sum(1) - ((z_r - er) ** 2).sum(1)
+    eps32 = 2.0 ** -23
+    bound = 2 * (z_m - z_r).norm(dim=1) * (em - er).norm(dim=1) + 8 * eps32 * (
+        (z_r ** 2).sum(1) + torch.maximum((em ** 2).sum(1), (er ** 2).sum(1)))
+    return flips, int((gap > bound).sum())

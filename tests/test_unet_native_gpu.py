@@ -93,13 +93,13 @@ def test_native_driver_workspace_is_exact_and_checked():
     ws = torch.empty(need, dtype=torch.uint8, device="cuda")
     vec = torch.empty((4, nat.ctx_floats), dtype=torch.float32, device="cuda")
     s = torch.cuda.current_stream().cuda_stream
-    assert lib.cs_unet_context(nat._h, nat._arena.data_ptr(), ctx.data_ptr(), 4, vec.data_ptr(), ws.data_ptr(), need, s) == 0
+    assert lib.cs_unet_context(nat._h, nat._arena.data_ptr(), ctx.data_ptr(), 4, vec.data_ptr(), None, ws.data_ptr(), need, s) == 0
     out = torch.full((4, 3, 16, 16, 16), float("nan"), device="cuda")
     rc = lib.cs_unet_step(nat._h, nat._arena.data_ptr(), x.data_ptr(), t.data_ptr(), vec.data_ptr(), out.data_ptr(),
-                          2, 1, ws.data_ptr(), need - 256, s)
+                          2, 1, None, ws.data_ptr(), need - 256, s)
     assert rc == L.CS_ENOMEM
     rc = lib.cs_unet_step(nat._h, nat._arena.data_ptr(), x.data_ptr(), t.data_ptr(), vec.data_ptr(), out.data_ptr(),
-                          2, 1, ws.data_ptr(), need, s)
+                          2, 1, None, ws.data_ptr(), need, s)
     torch.cuda.synchronize()
     assert rc == 0 and torch.isfinite(out).all()
     assert torch.equal(out, nat.forward_cfg(x, t, ctx.view(4, 1, 1280)))

@@ -58,7 +58,7 @@ def test_native_vq_workspace_checked():
     out = torch.empty(1, 1, 64, 64, 64, device="cuda")
     ws = torch.empty(need, dtype=torch.uint8, device="cuda")
     s = torch.cuda.current_stream().cuda_stream
-    args = (nat._h, nat._arena.data_ptr(), lat.data_ptr(), out.data_ptr(), None, 1, 1, ws.data_ptr())
+    args = (nat._h, nat._arena.data_ptr(), lat.data_ptr(), out.data_ptr(), None, 1, 1, None, ws.data_ptr())
     assert lib.cs_vqvae_decode(*args, need - 4096, s) == L.CS_ENOMEM
     assert lib.cs_vqvae_decode(*args, need, s) == 0
     torch.cuda.synchronize()

@@ -113,22 +113,25 @@ int main(int argc, char** argv) {
   if (wsb <= 0) { fprintf(stderr, "workspace_bytes -> %lld\n", (long long)wsb); return 1; }
   void* ws;
   CHECK(hipMalloc(&ws, (size_t)wsb));
-  CHECK(cs_unet_context(u, arena, ctx, 2 * B, ctxvec, ws, wsb, st));
+  int32_t* status;                 /* sticky CS_STATUS_* word: F16X3 kernels report fp16-range overflow here */
+  CHECK(hipMalloc((void**)&status, sizeof(int32_t)));
+  CHECK(hipMemsetAsync(status, 0, sizeof(int32_t), st));
+  CHECK(cs_unet_context(u, arena, ctx, 2 * B, ctxvec, status, ws, wsb, st));
 
-  if (cs_unet_step(u, arena, x, t, ctxvec, eps, B, 1, ws, 4096, st) != CS_ENOMEM) {
+  if (cs_unet_step(u, arena, x, t, ctxvec, eps, B, 1, status, ws, 4096, st) != CS_ENOMEM) {
     fprintf(stderr, "a 4 KB workspace was not refused\n");
     return 1;
   }
   const size_t ne = (size_t)2 * B * per;
   float *h1 = (float*)malloc(sizeof(float) * ne), *h2 = (float*)malloc(sizeof(float) * ne);
-  CHECK(cs_unet_step(u, arena, x, t, ctxvec, eps, B, 1, ws, wsb, st));
+  CHECK(cs_unet_step(u, arena, x, t, ctxvec, eps, B, 1, status, ws, wsb, st));
   CHECK(hipMemcpyAsync(h1, eps, sizeof(float) * ne, hipMemcpyDeviceToHost, st));
-  CHECK(cs_unet_step(u, arena, x, t, ctxvec, eps, B, 1, ws, wsb, st));
+  CHECK(cs_unet_step(u, arena, x, t, ctxvec, eps, B, 1, status, ws, wsb, st));
   CHECK(hipMemcpyAsync(h2, eps, sizeof(float) * ne, hipMemcpyDeviceToHost, st));
   CHECK(hipStreamSynchronize(st));
   if (!all_finite(h1, ne)) { fprintf(stderr, "non-finite eps\n"); return 1; }
   if (memcmp(h1, h2, sizeof(float) * ne)) { fprintf(stderr, "two runs differ\n"); return 1; }
-  CHECK(cs_unet_step(u, arena, x2, t2, ctxvec, eps_dup, 2 * B, 0, ws, wsb, st));
+  CHECK(cs_unet_step(u, arena, x2, t2, ctxvec, eps_dup, 2 * B, 0, status, ws, wsb, st));
   CHECK(hipMemcpyAsync(h2, eps_dup, sizeof(float) * ne, hipMemcpyDeviceToHost, st));
   CHECK(hipStreamSynchronize(st));
   double num = 0, den = 0;
@@ -171,11 +174,14 @@ int main(int argc, char** argv) {
   float* sdf;
   const size_t nsdf = (size_t)B * 64 * 64 * 64;
   CHECK(hipMalloc((void**)&sdf, sizeof(float) * nsdf));
-  CHECK(cs_vqvae_decode(vq, varena, xprev, sdf, NULL, B, 1, vws, vwsb, st));
+  CHECK(cs_vqvae_decode(vq, varena, xprev, sdf, NULL, B, 1, status, vws, vwsb, st));
   float* hs = (float*)malloc(sizeof(float) * nsdf);
   CHECK(hipMemcpyAsync(hs, sdf, sizeof(float) * nsdf, hipMemcpyDeviceToHost, st));
   CHECK(hipStreamSynchronize(st));
   if (!all_finite(hs, nsdf)) { fprintf(stderr, "non-finite SDF\n"); return 1; }
+  int32_t hstatus = -1;
+  CHECK(hipMemcpy(&hstatus, status, sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (hstatus != 0) { fprintf(stderr, "status word %d (CS_STATUS_F16X3_OVERFLOW?)\n", (int)hstatus); return 1; }
   printf("decode: %d x 64^3 SDF, workspace %.1f MB\n", B, vwsb / 1e6);
   cs_vqvae_destroy(vq);
 

@@ -438,6 +438,7 @@ def g_e2e(tmp: Path, concat: bool = False, full: bool = False):
         lat.append(h.detach().clone())
         return dnq(h, *a, **k)
     model.Diff.vqvae_module.decode_no_quant = dnq_rec
+    idx_rec = _record_vq_indices(model.Diff.vqvae_module)
     np.random.seed(111)
     t0 = time.time()
     with torch.no_grad():
@@ -448,7 +449,7 @@ def g_e2e(tmp: Path, concat: bool = False, full: bool = False):
     arrs = dict(objs=g["objs"], triples=g["triples"], text_feats=g["text_feats"], rel_feats=g["rel_feats"],
                 dec_sdfs_nonzero=(dec_sdfs.flatten(1).abs().sum(1) > 0), z=rec["z"], uc=rec["uc"], c=rec["c"],
                 x_T=x_T, latents=torch.cat(lat, 0), gen_sdf_sub=gen_sdf[:, :, ::2, ::2, ::2].contiguous(),
-                gen_sdf_obj7=gen_sdf[7])
+                gen_sdf_obj7=gen_sdf[7], indices=torch.cat([i.reshape(-1, 16, 16, 16) for i in idx_rec], 0))
     if isinstance(boxes, tuple):
         arrs["boxes"], arrs["angles"] = boxes[0], boxes[1]
     else:
@@ -519,6 +520,14 @@ def g_full_manip(tmp: Path):
     z_in = torch.cat([z[:2], z[3:]], dim=0)
     x_T = synth.gaussian_like("fm:xT", (1, 3, 16, 16, 16))
     model.Diff.rel2shape = functools.partial(model.Diff.rel2shape, ddim_steps=2)
+    idx_rec = _record_vq_indices(model.Diff.vqvae_module)
+    lat = []
+    dnq = model.Diff.vqvae_module.decode_no_quant
+
+    def dnq_rec(h, *aa, **k):
+        lat.append(h.detach().clone())
+        return dnq(h, *aa, **k)
+    model.Diff.vqvae_module.decode_no_quant = dnq_rec
     with torch.no_grad():
         mu, logvar = model.encoder(*a, boxes_gt, None, tf, rf, angles_gt)
         INJECT["x_T"] = x_T
@@ -533,7 +542,78 @@ def g_full_manip(tmp: Path):
     save("full_manip_small", objs=g["objs"], triples=g["triples"], text_feats=tf, rel_feats=rf, boxes_gt=boxes_gt,
          angles_gt=angles_gt, dec_sdfs_nonzero=(dec_sdfs.flatten(1).abs().sum(1) > 0), mu=mu, logvar=logvar, z_in=z_in,
          x_T=x_T, d3_changes=d3c, angles_changes=angc, keep_changes=keepc,
-         gen_sdf_sub=gen_sdf[:, :, ::2, ::2, ::2].contiguous(), d3_add=d3a, angles_add=anga, keep_add=keepa)
+         gen_sdf_sub=gen_sdf[:, :, ::2, ::2, ::2].contiguous(), d3_add=d3a, angles_add=anga, keep_add=keepa,
+         latents=torch.cat(lat, 0), indices=torch.cat([i.reshape(-1, 16, 16, 16) for i in idx_rec], 0))
+
+
+def _record_vq_indices(vq):
+    """Wrap VQVAE.quantize (quantizer.py:68-119) so every call's argmin indices are kept: the e2e fixtures carry
+    them so that a test can tell a VQ code flip (an fp32 near-tie) from a decoder error."""
+    rec = []
+    fwd = vq.quantize.forward
+
+    def forward(z, *a, **k):
+        out = fwd(z, *a, **k)
+        rec.append(out[2][2].detach().clone())
+        return out
+    vq.quantize.forward = forward
+    return rec
+
+
+TRAJ_KEEP = (1, 2, 3, 5, 10, 15, 20, 25, 30, 35, 40, 45, 50)
+
+
+def g_traj(small: bool):
+    """BASELINE configs[1] (C2): ONE object, the whole 50-step classifier-free-guided DDIM run through the
+    reference's own DDIMSampler.sample() loop (ddim.py:60-179), reduced width (small) or the shipped 413.5 M-parameter
+    UNet (full).  x after the steps in TRAJ_KEEP is kept so a test can report the per-step growth of the deviation."""
+    from model.networks.diffusion_networks.samplers.ddim import DDIMSampler
+    name = "traj_small" if small else "traj_full"
+    df, p, sd = build_ref_unet(small)
+    m = _ref_model_for_sampler(df)
+    B, S = 1, 50
+    x_T = synth.gaussian_like(f"{name}:xT", (1, 3, 16, 16, 16))
+    c = synth.gaussian_like(f"{name}:c", (B, 1, 1280))
+    uc = synth.gaussian_like(f"{name}:uc", (B, 1, 1280))
+    t0 = time.time()
+    with torch.no_grad():
+        x, inter = DDIMSampler(m).sample(S=S, batch_size=B, shape=(3, 16, 16, 16), conditioning=c, x_T=x_T,
+                                         verbose=False, unconditional_guidance_scale=3.0,
+                                         unconditional_conditioning=uc, eta=0.0, log_every_t=1)
+    print(f"[{name}] {S} reference DDIM steps {time.time() - t0:.1f}s  final rms {x.pow(2).mean().sqrt():.4f}")
+    xi = inter["x_inter"]                      # [x_T, x after step 1, ..., x after step 50]
+    assert len(xi) == S + 1 and torch.equal(xi[-1], x)
+    save(name, x_T=x_T, c=c, uc=uc, S=np.int64(S), scale=np.float32(3.0), keep=np.asarray(TRAJ_KEEP, dtype=np.int64),
+         x=torch.stack([xi[k] for k in TRAJ_KEEP]), pred_x0_final=inter["pred_x0"][-1])
+
+
+def g_plms():
+    """N4: the reference PLMSSampler (samplers/plms.py:61-236) on the reduced-width UNet: B=2, S=50, CFG 3.0, the whole
+    50-step run (pseudo improved Euler start-up, then Adams-Bashforth orders 2-4).  plms.py imports from a package
+    called `models` (the tree has `model`): the harness aliases the name, no reference file is touched."""
+    import importlib
+    for sub in ("", ".networks", ".networks.diffusion_networks", ".networks.diffusion_networks.ldm_diffusion_util"):
+        sys.modules["models" + sub] = importlib.import_module("model" + sub)
+    from model.networks.diffusion_networks.samplers import plms as plms_mod
+    plms_mod.PLMSSampler.register_buffer = lambda self, n, a: setattr(self, n, a)
+    plms_mod.tqdm = lambda it, **k: it
+    name = "plms_small"
+    df, p, sd = build_ref_unet(True)
+    m = _ref_model_for_sampler(df)
+    B, S = 2, 50
+    x_T = synth.gaussian_like(f"{name}:xT", (1, 3, 16, 16, 16)).repeat(B, 1, 1, 1, 1)
+    c = synth.gaussian_like(f"{name}:c", (B, 1, 1280))
+    uc = synth.gaussian_like(f"{name}:uc", (B, 1, 1280))
+    t0 = time.time()
+    with torch.no_grad():
+        x, inter = plms_mod.PLMSSampler(m).sample(S=S, batch_size=B, shape=(3, 16, 16, 16), conditioning=c, x_T=x_T,
+                                                  verbose=False, unconditional_guidance_scale=3.0,
+                                                  unconditional_conditioning=uc, eta=0.0, log_every_t=1)
+    print(f"[{name}] {S} reference PLMS steps {time.time() - t0:.1f}s  final rms {x.pow(2).mean().sqrt():.4f}")
+    xi = inter["x_inter"]
+    assert len(xi) == S + 1 and torch.equal(xi[-1], x)
+    save(name, x_T=x_T, c=c, uc=uc, S=np.int64(S), scale=np.float32(3.0), keep=np.asarray(TRAJ_KEEP, dtype=np.int64),
+         x=torch.stack([xi[k] for k in TRAJ_KEEP]), pred_x0_final=inter["pred_x0"][-1])
 
 
 def main():
@@ -544,7 +624,7 @@ def main():
     install_patches()
     todo = a.only or ["schedule", "unet_small", "unet_full", "ddim_small", "ddim_full", "vq", "gcn", "e2e",
                       "unet_concat_small", "unet_concat_full", "ddim_concat_small", "gcn_concat", "e2e_concat", "box",
-                      "full_manip", "e2e_full"]
+                      "full_manip", "e2e_full", "traj_small", "traj_full", "plms"]
     with tempfile.TemporaryDirectory() as td:
         tmp = Path(td)
         for name in todo:
@@ -577,6 +657,12 @@ def main():
                 g_e2e(tmp, concat=True)
             elif name == "e2e_full":
                 g_e2e(tmp, full=True)
+            elif name == "traj_small":
+                g_traj(True)
+            elif name == "traj_full":
+                g_traj(False)
+            elif name == "plms":
+                g_plms()
             elif name == "box":
                 g_box()
             elif name == "full_manip":
