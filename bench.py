@@ -6,16 +6,21 @@
 
 One "step" = one classifier-free-guided DDIM step over this rank's 32 objects: a UNet forward at batch 64
 (413.5 M parameters, 3x16^3 latents, one 1280-d context token per sample) + the fused CFG/DDIM update
-(BASELINE.json configs[2], SURVEY 8d "C3").  Objects are independent, so N GPUs hold N x 32 objects
-(weak scaling, no per-step collective); rank 0 produces the conditioning with the scene-graph GCN and
-broadcasts the packed [x_T | c | uc] buffer over RCCL once, before the timed region.
-Inputs are resident in HBM when the timed region starts.  Weights and inputs are synthetic (deterministic
-hash, commonscenes_amd/synth.py) -- no checkpoints or datasets are reachable offline.
+(BASELINE.json configs[2], SURVEY 8d "C3").  Objects are independent, so N GPUs hold N x 32 objects (weak scaling, no
+per-step collective).  The multi-rank data path is the product's own (commonscenes_amd/dist.py): rank 0 runs the
+scene-graph GCN for all N x 32 objects, ONE broadcast of the packed [x_T | uc | c] buffer, every rank takes its
+contiguous shard, and -- outside the timed step loop, reported separately as `end_to_end` -- every rank decodes its
+latents to 64^3 SDFs and ONE all-gather returns all of them to every rank.
+Inputs are resident in HBM when the timed region starts.  Weights and inputs are synthetic (deterministic hash,
+commonscenes_amd/synth.py) -- no checkpoints or datasets are reachable offline.
 
-Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events around every launch of the
-dominant kernel (the 3x3x3 implicit-GEMM conv on fp32 MFMA) inside the timed region; `cpu_baseline` times
-the CPU oracle (oracle/ref_torch.py, plain PyTorch fp32 -- a port, the reference itself cannot travel)
-on a bounded sample of the same workload on this box's host cores.
+Prints ONE JSON line (rank 0):
+  value / ms_per_step   the metric: K timed steps between barrier + synchronize pairs, max over ranks;
+  roofline              the dominant kernel, HIP events around every one of its launches inside the timed region;
+  decode                VQ-VAE decode of the rank's 32 latents (quantise + Decoder3D, 723 GFLOP/object), own roofline block;
+  end_to_end            steps/s with decode + all-gather amortised over the S-step run (what a whole sample() costs);
+  c2                    BASELINE configs[1]: ONE object (N=1 only): ms/step and steps/s;
+  cpu_baseline          the CPU oracle (oracle/ref_torch.py -- a port; the reference cannot travel) on a bounded sample.
 """
 from __future__ import annotations
 
@@ -37,7 +42,8 @@ import torch.distributed as dist  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X dense fp32-input MFMA peak (MI355X_MICROARCH.md)
 F16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
-UNET_GFLOP_PER_SAMPLE = 557.9   # SURVEY App. A (conv3 471.3 + linear 62.0 + conv1 13.9 + attention 10.45 + norms)
+TILE_NAMES = {1: "<2,2,2,2,false> (128x128", 2: "<1,7,4,1,false> (128x224", 3: "<1,1,2,2,false> (64x64",
+              4: "<1,7,8,1,false> (256x224", 5: "persistent 256x224"}
 
 
 def parse():
@@ -48,6 +54,7 @@ def parse():
     ap.add_argument("--objects", type=int, default=32, help="objects per GPU (BASELINE metric: 32)")
     ap.add_argument("--ddim-steps", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the decode / end-to-end / C2 blocks (profiling runs)")
     ap.add_argument("--cpu-objects", type=int, default=7,
                     help="objects in the bounded CPU-baseline sample (7 = the reference's sampler mini-batch, "
                          "sdfusion_txt2shape_model.py:493)")
@@ -63,7 +70,7 @@ def parse():
 
 def cpu_baseline(df, cfg, n_obj: int, objects_per_step: int):
     """Oracle (port of the reference's PyTorch path) on the host cores: one warm-up + one timed CFG DDIM step
-    for n_obj objects, scaled to the 32-object step the metric is quoted on."""
+    for n_obj objects, scaled to the 32-object step the metric is quoted on.  The only use of oracle/ in this file."""
     from commonscenes_amd import synth
     from oracle import ref_torch as R
     # oneDNN's conv3d stops scaling (and regresses badly) far below this box's core count at CFG batch 4:
@@ -90,6 +97,42 @@ def cpu_baseline(df, cfg, n_obj: int, objects_per_step: int):
                        f"torch {torch.__version__} CPU fp32")
 
 
+def gemm_summary(prof, wall_ms, math):
+    """dominant tile instantiation of a HIP-event profile: achieved TF/s, both roofline conventions."""
+    by_tile = {}
+    for r in prof:
+        by_tile[r["tile"]] = by_tile.get(r["tile"], 0.0) + r["e0"].elapsed_time(r["e1"])
+    if not by_tile:
+        return None
+    dom = max(by_tile, key=by_tile.get)
+    sel = [r for r in prof if r["tile"] == dom]
+    ms = sum(r["e0"].elapsed_time(r["e1"]) for r in sel)
+    fl = sum(r["flops"] for r in sel)
+    all_ms = sum(r["e0"].elapsed_time(r["e1"]) for r in prof)
+    all_fl = sum(r["flops"] for r in prof)
+    achieved = fl / (ms * 1e-3) / 1e12
+    if math == "f16x3":
+        peak = F16_MFMA_PEAK_TFLOPS / 3.0
+        kname = (f"conv_gemm_f16x3_kernel{TILE_NAMES.get(dom, '(?')}-tile implicit GEMM, 3x v_mfma_f32_32x32x16_f16 "
+                 "per K=16 on hi/lo splits)")
+        peak_note = ("peak = dense fp16 MFMA peak (2500 TF/s) / 3: every fp32-grade product costs three fp16 MFMA "
+                     "passes, so 833 TF/s of ALGORITHMIC flops saturates the matrix pipe; frac_of_f16_dense_peak "
+                     "prices the same algorithmic flops against the raw 2500 TF/s, frac_of_fp32_matrix_peak against "
+                     "the 157.3 TF/s fp32-input MFMA the reference's dtype maps to")
+    else:
+        peak = FP32_MFMA_PEAK_TFLOPS
+        kname = "conv_gemm_f32_kernel<1,7,4,1> (128x224-tile implicit GEMM, v_mfma_f32_32x32x2_f32)"
+        peak_note = "peak = dense fp32-input MFMA peak"
+    return {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+            "peak_note": peak_note,
+            "frac_of_f16_dense_peak": achieved / F16_MFMA_PEAK_TFLOPS if math == "f16x3" else None,
+            "frac_of_fp32_matrix_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
+            "issued_mfma_tflops": 3.0 * achieved if math == "f16x3" else achieved,
+            "kernel": kname, "math": math, "launches": len(sel), "avg_launch_ms": ms / len(sel),
+            "algorithmic_gflop_per_launch": fl / len(sel) / 1e9, "share_of_wall_time": ms / wall_ms,
+            "all_gemm_tflops": all_fl / (all_ms * 1e-3) / 1e12, "all_gemm_share_of_wall_time": all_ms / wall_ms}
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -110,44 +153,33 @@ def main():
             dist.init_process_group(backend=backend)
     assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
+    from commonscenes_amd import configs as K
+    from commonscenes_amd import dist as D
     from commonscenes_amd import ops, synth
     from commonscenes_amd.ddim import DDIMSampler
-    from commonscenes_amd.scene import Sg2ScVAEModel, scene_param_shapes  # noqa: F401
+    from commonscenes_amd.scene import scene_param_shapes
     from commonscenes_amd.unet import DiffusionUNet, unet_param_shapes
-    from oracle.ref_torch import DIFFUSION, UNET_FULL, UNET_SMALL, register_schedule
+    from commonscenes_amd.vqvae import VQVAE, vqvae_param_shapes
 
-    cfg = dict(UNET_SMALL if a.small else UNET_FULL, dims=3, use_spatial_transformer=True)
+    cfg = K.reduced(K.UNET_CROSSATTN) if a.small else dict(K.UNET_CROSSATTN)
     if a.driver == "native":
         from commonscenes_amd.unet_native import NativeDiffusionUNet
         df = NativeDiffusionUNet(cfg, conditioning_key="crossattn", device=dev, math=a.math)
     else:
         df = DiffusionUNet(cfg, conditioning_key="crossattn", device=dev).set_math(a.math)
     df.load_state_dict(synth.synth_state_dict(unet_param_shapes(cfg), device=str(dev)))
-    sch = register_schedule(**DIFFUSION)
+    model = K.ScheduleModel(df, dev)
 
-    class M:
-        num_timesteps = 1000
-        device = dev
-        alphas_cumprod = sch["alphas_cumprod"]
-
-        def apply_model(self, x, t, c):
-            return df(x, t, c_crossattn=[c])
-
-        def apply_model_cfg(self, x, t, c_in):
-            return df.forward_cfg(x, t, c_in)
-
-    # ---- conditioning: rank 0 runs the scene-graph GCN for all world*B objects, broadcast over RCCL ----
+    # ---- conditioning: rank 0 runs the scene-graph GCN for all world*B objects, ONE broadcast (dist.py) ----
     B = a.objects
     total = B * world
-    packed = torch.empty((total, 2 * 1280), dtype=torch.float32, device=dev)
-    x_T = torch.empty((1, 3, 16, 16, 16), dtype=torch.float32, device=dev)
     t_cond0 = time.perf_counter()
+    x_T = uc_all = c_all = None
     if rank == 0:
         from commonscenes_amd.scene import GraphTripleConvNet, _MLP
         g = synth.random_scene_graph(total, seed=111)
         ssd = synth.synth_state_dict(scene_param_shapes(35, 16), device=str(dev))
         ec, relmlp = GraphTripleConvNet(ssd, "gconv_net_ec_rel", 5), _MLP(ssd, "rel_mlp", 2, False)
-        O, T = g["objs"].shape[0], g["triples"].shape[0]
         tri = g["triples"].to(dev)
         obj_vecs = torch.cat([g["text_feats"].to(dev), ops.embedding(ssd["obj_embeddings_dc.weight"], g["objs"].to(dev)),
                               g["z"].to(dev)], dim=1)
@@ -155,21 +187,19 @@ def main():
                                ops.embedding(ssd["pred_embeddings_dc.weight"], tri[:, 1].contiguous())], dim=1)
         edges = torch.stack([tri[:, 0], tri[:, 2]], dim=1).contiguous()
         rel2, _ = ec(obj_vecs, pred_vecs, edges)
-        packed[:, 1280:] = relmlp(rel2)[:total]          # c  (with GCN)
-        packed[:, :1280] = relmlp(obj_vecs)[:total]      # uc (without)
-        x_T.copy_(synth.gaussian_like("bench:xT", (1, 3, 16, 16, 16)))
-    if world > 1:
-        dist.broadcast(packed, src=0)
-        dist.broadcast(x_T, src=0)
+        c_all = relmlp(rel2)[:total].reshape(total, 1, 1280)          # with the GCN
+        uc_all = relmlp(obj_vecs)[:total].reshape(total, 1, 1280)     # without
+        x_T = synth.gaussian_like("bench:xT", (1, 3, 16, 16, 16)).to(dev)
+    x_T, uc_all, c_all = D.broadcast_conditioning(x_T, uc_all, c_all, total, dev, src=0)
     torch.cuda.synchronize()
     cond_ms = (time.perf_counter() - t_cond0) * 1e3
-    mine = packed[rank * B:(rank + 1) * B]
-    uc = mine[:, :1280].reshape(B, 1, 1280).contiguous()
-    c = mine[:, 1280:].reshape(B, 1, 1280).contiguous()
+    lo, hi = D.shard_range(total, world, rank)
+    uc = uc_all[lo:hi].contiguous()
+    c = c_all[lo:hi].contiguous()
     c_in = torch.cat([uc, c])
     x = x_T.repeat(B, 1, 1, 1, 1).contiguous()
 
-    sampler = DDIMSampler(M())
+    sampler = DDIMSampler(model)
     sampler.make_schedule(a.ddim_steps, ddim_eta=0.0, verbose=False)
     ts = np.flip(sampler.ddim_timesteps)
     S = a.ddim_steps
@@ -185,6 +215,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(v):
+        if world == 1:
+            return v
+        tt = torch.tensor([v], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
     run(0, a.warmup)
     barrier()
     ops.GEMM_PROFILE = prof = []
@@ -193,25 +230,67 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     ops.GEMM_PROFILE = None
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = max_over_ranks(dt)
     finite = bool(torch.isfinite(x).all().item())
+    overflow = ops.read_status(dev) != 0
+
+    # ---- extras, outside the timed region: decode of this rank's latents, the all-gather, one object (C2) ----
+    decode = e2e = c2 = None
+    if not a.no_extras and not a.small:
+        vq = VQVAE(K.VQVAE_DDCONFIG, K.VQVAE_N_EMBED, K.VQVAE_EMBED_DIM, device=dev).set_math(a.math)
+        vq.load_state_dict(synth.synth_state_dict(vqvae_param_shapes(K.VQVAE_DDCONFIG, K.VQVAE_N_EMBED,
+                                                                     K.VQVAE_EMBED_DIM), device=str(dev)))
+        lat = synth.gaussian_like("bench:lat", (B, 3, 16, 16, 16), scale=0.8).to(dev)   # code-book-scale latents
+        sdf = vq.decode_no_quant(lat)                                                   # warm-up (packs the weights)
+        barrier()
+        ops.GEMM_PROFILE = dprof = []
+        t0 = time.perf_counter()
+        sdf = vq.decode_no_quant(lat)
+        barrier()
+        dec_s = max_over_ranks(time.perf_counter() - t0)
+        ops.GEMM_PROFILE = None
+        t0 = time.perf_counter()
+        allsdf = D.all_gather_objects(sdf, total)
+        barrier()
+        gat_s = max_over_ranks(time.perf_counter() - t0)
+        dec_tf = B * K.VQ_DECODE_GFLOP_PER_OBJECT / dec_s / 1e3
+        if rank == 0:
+            decode = {"objects": B, "ms": dec_s * 1e3, "ms_per_object": dec_s * 1e3 / B,
+                      "algorithmic_gflop_per_object": K.VQ_DECODE_GFLOP_PER_OBJECT, "whole_decode_tflops": dec_tf,
+                      "whole_decode_frac_of_peak": dec_tf / (F16_MFMA_PEAK_TFLOPS / 3.0 if a.math == "f16x3"
+                                                             else FP32_MFMA_PEAK_TFLOPS),
+                      "finite": bool(torch.isfinite(allsdf).all().item()), "gathered_shape": list(allsdf.shape),
+                      "roofline": gemm_summary(dprof, dec_s * 1e3, a.math)}
+            step_s = dt / a.steps
+            e2e = {"all_gather_ms": gat_s * 1e3, "all_gather_bytes_per_rank": int(sdf.numel() * 4),
+                   "ddim_steps": S,
+                   "value": world / (step_s + (dec_s + gat_s) / S),
+                   "unit": "DDIM steps/s with decode + all-gather amortised over the S-step run",
+                   "whole_run_s": S * step_s + dec_s + gat_s}
+        del allsdf, sdf
+        if world == 1:
+            # BASELINE configs[1] (C2): ONE object; same sampler, CFG batch 2
+            x1 = x_T.clone()
+            c1 = torch.cat([uc[:1], c[:1]])
+            df.reset_run_cache() if hasattr(df, "reset_run_cache") else None
+            for j in range(3):
+                x1, _ = sampler._step(x1, c1, int(ts[j]), S - j - 1, True, 3.0, want_pred_x0=False)
+            torch.cuda.synchronize()
+            n1 = 20
+            t0 = time.perf_counter()
+            for j in range(3, 3 + n1):
+                x1, _ = sampler._step(x1, c1, int(ts[j]), S - j - 1, True, 3.0, want_pred_x0=False)
+            torch.cuda.synchronize()
+            d1 = (time.perf_counter() - t0) / n1
+            c2 = {"workload": "BASELINE configs[1]: 1 object, CFG batch 2", "ms_per_step": d1 * 1e3,
+                  "steps_per_s": 1.0 / d1, "whole_step_tflops": 2 * K.UNET_GFLOP_PER_SAMPLE / d1 / 1e3,
+                  "frac_of_peak": 2 * K.UNET_GFLOP_PER_SAMPLE / d1 / 1e3 / (F16_MFMA_PEAK_TFLOPS / 3.0 if a.math == "f16x3"
+                                                                            else FP32_MFMA_PEAK_TFLOPS)}
 
     if rank == 0:
-        # dominant kernel = the tile instantiation with the most time (3x3x3 convs + the token GEMMs that share it):
-        # every one of its launches counts, so the average matches rocprofv3's per-kernel average
-        by_tile = {}
-        for r in prof:
-            by_tile[r["tile"]] = by_tile.get(r["tile"], 0.0) + r["e0"].elapsed_time(r["e1"])
-        dom_tile = max(by_tile, key=by_tile.get) if by_tile else 0
-        conv = [r for r in prof if r["tile"] == dom_tile] or prof
-        conv_ms = sum(r["e0"].elapsed_time(r["e1"]) for r in conv)
-        conv_fl = sum(r["flops"] for r in conv)
-        all_ms = sum(r["e0"].elapsed_time(r["e1"]) for r in prof)
-        all_fl = sum(r["flops"] for r in prof)
-        achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else None   # None: --driver native (no hooks)
+        wall_ms = dt * 1e3
+        roof = gemm_summary(prof, wall_ms, a.math) or {"bound": "mfma", "achieved": None, "peak": None,
+                                                       "unit": "TFLOP/s", "frac": None}   # --driver native: no hooks
         if a.gemm_table:
             agg = {}
             for r in prof:
@@ -225,20 +304,16 @@ def main():
                 print(f"{k[0]:4d} {k[1]:7d} {k[2]:6d} {k[3]:6d} {k[4]:4d} {t[0]:5d} {t[1] / a.steps:8.3f} "
                       f"{t[2] / t[1] / 1e9:7.1f}", file=sys.stderr)
         traffic = None
-        tf = ROOT / "profiles" / ("r01_traffic_f16x3.json" if a.math == "f16x3" else "r01_traffic_fp32.json")
-        if tf.exists() and B == 32 and not a.small:       # PMC passes cannot run inside this process: the figure is
-            traffic = json.loads(tf.read_text())["hbm_bytes_per_launch"]   # the committed rocprofv3 --pmc result
-        if a.math == "f16x3":
-            # three fp16 MFMA passes per fp32-grade product: the pipe ceiling for ALGORITHMIC flops is 2.5 PF / 3
-            shape = {1: "<2,2,2,2,false> (128x128", 2: "<1,7,4,1,false> (128x224", 3: "<1,1,2,2,false> (64x64",
-                     4: "<1,7,8,1,false> (256x224"}.get(dom_tile, "(?")
-            peak, kname = F16_MFMA_PEAK_TFLOPS / 3.0, (f"conv_gemm_f16x3_kernel{shape}-tile implicit "
-                                                       "GEMM, 3x v_mfma_f32_32x32x16_f16 per K=16 on hi/lo splits)")
-            dtype = "f32 (operands as fp16 hi+lo pairs, fp32 accumulate)"
-        else:
-            peak, kname = FP32_MFMA_PEAK_TFLOPS, ("conv_gemm_f32_kernel<1,7,4,1> (128x224-tile implicit GEMM, "
-                                                  "v_mfma_f32_32x32x2_f32)")
-            dtype = "f32"
+        for cand in ("r02_traffic_f16x3.json", "r01_traffic_f16x3.json") if a.math == "f16x3" else ("r01_traffic_fp32.json",):
+            tf = ROOT / "profiles" / cand
+            if tf.exists() and B == 32 and not a.small:   # PMC passes cannot run inside this process: the figure is
+                traffic = json.loads(tf.read_text())["hbm_bytes_per_launch"]   # the committed rocprofv3 --pmc result
+                roof["traffic_source"] = f"profiles/{cand}"
+                break
+        roof["traffic"] = traffic
+        roof["traffic_note"] = ("HBM bytes per launch of the dominant kernel, FETCH_SIZE x2 (gfx950) + WRITE_SIZE, from "
+                                "separate rocprofv3 --pmc passes of this command (tools/pmc_traffic.sh)")
+        roof["whole_step_tflops"] = (2 * B * K.UNET_GFLOP_PER_SAMPLE * 1e9 * a.steps / dt / 1e12) if not a.small else None
         res = {
             "metric": "DDIM denoise steps/sec (32 objects, 16^3 latent)",
             "value": world * a.steps / dt,
@@ -246,25 +321,16 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": dtype, "data": "synthetic",
+            "dtype": "f32 (operands as fp16 hi+lo pairs, fp32 accumulate)" if a.math == "f16x3" else "f32",
+            "data": "synthetic",
             "config": {"workload": "v2_full shape branch (BASELINE configs[2]): 32 objects/GPU, CFG scale 3.0, "
                                    f"{S}-step DDIM schedule, 3x16^3 latents, UNet "
                                    f"{df.num_parameters() / 1e6:.1f}M params fp32, 1 context token",
                        "objects_per_gpu": B, "unet_batch": 2 * B, "ddim_steps": S,
-                       "parallelism": f"object-sharded x{world} (replicated weights, no per-step collective)"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak if achieved is not None else None, "traffic": traffic,
-                         "traffic_note": "HBM bytes per launch of the dominant kernel, FETCH_SIZE x2 (gfx950) + WRITE_SIZE, "
-                                         "from profiles/r01_traffic_*.json (separate rocprofv3 --pmc passes of this command)",
-                         "kernel": kname, "math": a.math,
-                         "launches": len(conv), "avg_launch_ms": conv_ms / max(len(conv), 1),
-                         "algorithmic_gflop_per_launch": conv_fl / max(len(conv), 1) / 1e9,
-                         "share_of_step_time": conv_ms / (dt * 1e3),
-                         "all_gemm_tflops": all_fl / (all_ms * 1e-3) / 1e12 if all_ms > 0 else 0.0,
-                         "all_gemm_share_of_step_time": all_ms / (dt * 1e3),
-                         "whole_step_tflops": (2 * B * UNET_GFLOP_PER_SAMPLE * 1e9 * a.steps / dt / 1e12)
-                         if not a.small else None},
-            "conditioning_ms": cond_ms, "finite": finite, "unet_driver": a.driver,
+                       "parallelism": f"object-sharded x{world} (replicated weights, no per-step collective; "
+                                      "1 broadcast in, 1 all-gather out)"},
+            "roofline": roof, "decode": decode, "end_to_end": e2e, "c2": c2,
+            "conditioning_ms": cond_ms, "finite": finite, "f16x3_overflow": overflow, "unet_driver": a.driver,
         }
         if not a.no_cpu_baseline and not a.small:
             res["cpu_baseline"] = cpu_baseline(df, cfg, a.cpu_objects, B)
