@@ -1,0 +1,42 @@
+// Shared pieces of the CS_MATH_F16X3 GEMM kernels (cs_gemm_f16x3.hip, cs_gemm_pw.hip).
+#pragma once
+#include "cs_common.h"
+
+namespace cs16 {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+constexpr int BKH = 16;                 // K elements per chunk
+constexpr float A_SCALE_DEFAULT = 16.0f;
+constexpr unsigned OOB = 0xFFF00000u;   // byte offset past every buffer (extents are < 0xFFE00000): reads 0
+
+// `amax` is the lane's running max |a * a_scale|: the kernel raises CS_STATUS_F16X3_OVERFLOW when it reaches the fp16
+// range (the hi half would be +-inf).  Four v_max3_f32 per eight elements, hidden under the MFMA stream.
+__device__ __forceinline__ void split8(const f32x4& x, const f32x4& y, float a_scale, h8& hi, h8& lo, float& amax) {
+  const float v[8] = {x[0] * a_scale, x[1] * a_scale, x[2] * a_scale, x[3] * a_scale,
+                      y[0] * a_scale, y[1] * a_scale, y[2] * a_scale, y[3] * a_scale};
+  amax = fmaxf(fmaxf(amax, fabsf(v[0])), fabsf(v[1]));
+  amax = fmaxf(fmaxf(amax, fabsf(v[2])), fabsf(v[3]));
+  amax = fmaxf(fmaxf(amax, fabsf(v[4])), fabsf(v[5]));
+  amax = fmaxf(fmaxf(amax, fabsf(v[6])), fabsf(v[7]));
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const _Float16 h = (_Float16)v[i];
+    hi[i] = h;
+    lo[i] = (_Float16)(v[i] - (float)h);
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+}
+
+}  // namespace cs16

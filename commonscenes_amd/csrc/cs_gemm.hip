@@ -248,6 +248,9 @@ __global__ void relayout_weight_kernel(const float* __restrict__ w, float* __res
 }  // namespace
 
 int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p, int M, int tile, int splits, hipStream_t s);  // cs_gemm_f16x3.hip
+bool cs_pw_gemm_f16x3_applicable(const CsConvGemm& p, int64_t M);                                   // cs_gemm_pw.hip
+bool cs_pw_gemm_f16x3_preferred(const CsConvGemm& p, int64_t M);
+int cs_pw_gemm_f16x3_launch(const CsConvGemm& p, int M, hipStream_t s);
 
 namespace {
 
@@ -322,6 +325,9 @@ extern "C" int cs_conv_gemm(const CsConvGemm* d, cs_stream_t stream) {
   if (M64 > 0x7fffffffLL) return CS_EINVAL;
   const int M = (int)M64;
   int tile = p.tile;
+  if (tile == 5 && !(f16x3 && cs_pw_gemm_f16x3_applicable(p, M))) return CS_EINVAL;
+  if (tile == 0 && f16x3 && cs_pw_gemm_f16x3_applicable(p, M) && cs_pw_gemm_f16x3_preferred(p, M))
+    tile = 5;                                        // short-K token GEMMs: persistent ping-pong kernel
   if (tile == 0) {
     // largest tile that still gives every one of the 256 CUs a workgroup; small problems take the 64x64 tile
     // (measured at CFG batch 2: 64x64 is ~2x the 128x224 tile, which leaves 3/4 of the chip idle)
@@ -336,6 +342,7 @@ extern "C" int cs_conv_gemm(const CsConvGemm* d, cs_stream_t stream) {
       tile = 1;
     else
       tile = 3;
+    if (p.act == CS_ACT_GEGLU && tile != 4) tile = 2;   // the fused gate needs whole [x | gate] 224-column tiles
   }
   hipStream_t s = (hipStream_t)stream;
   if (p.splitk > 1) {
@@ -360,6 +367,7 @@ extern "C" int cs_conv_gemm(const CsConvGemm* d, cs_stream_t stream) {
     CS_CHECK_LAUNCH();
     return CS_OK;
   }
+  if (tile == 5) return cs_pw_gemm_f16x3_launch(p, M, s);
   if (f16x3) return cs_conv_gemm_f16x3_dispatch(p, M, tile, 1, s);
   switch (tile) {
     case 1: return launch<2, 2, 2, 2>(p, M, s);

@@ -22,51 +22,23 @@
 // K order: channel chunk OUTER, tap INNER (the 27 taps of one 16-channel chunk re-touch only this tile's rows
 // + halo, so they hit L1/L2 instead of re-streaming the activation tensor per tap).
 // fp16 32x32x16 operand map: lane l holds row/col l&31 and k = 8*(l>>5) .. 8*(l>>5)+7; C/D as for fp32.
-#include "cs_common.h"
+#include "cs_f16x3.h"
 #include <type_traits>
 
 namespace {
 
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-
-constexpr int BKH = 16;       // K elements per chunk
-constexpr float A_SCALE_DEFAULT = 16.0f;
-constexpr unsigned OOB = 0xFFF00000u;   // byte offset past every buffer (extents are < 0xFFE00000): reads 0
+using cs16::h8;
+using cs16::split8;
+using cs16::wait_vmcnt;
+using cs16::BKH;
+using cs16::A_SCALE_DEFAULT;
+using cs16::OOB;
 constexpr int MAX_TAPS = 27;
 #ifndef CS_ABLATE
 #define CS_ABLATE 0   // debug builds, timing only (results are wrong): 1 = no DMA issue, 2 = DMAs fetch nothing (all
                       // offsets out of range -> zero fill), 4 = no vmcnt wait in the loop, 8 = no barrier,
                       // 16 = s_setprio around the MFMAs, 32 = scalar epilogue, 64 = all fetches from one 16 KB window
 #endif
-
-// `amax` is the lane's running max |a * a_scale|: the kernel raises CS_STATUS_F16X3_OVERFLOW when it reaches the fp16
-// range (the hi half would be +-inf).  Four v_max3_f32 per eight elements, hidden under the MFMA stream.
-__device__ __forceinline__ void split8(const f32x4& x, const f32x4& y, float a_scale, h8& hi, h8& lo, float& amax) {
-  const float v[8] = {x[0] * a_scale, x[1] * a_scale, x[2] * a_scale, x[3] * a_scale,
-                      y[0] * a_scale, y[1] * a_scale, y[2] * a_scale, y[3] * a_scale};
-  amax = fmaxf(fmaxf(amax, fabsf(v[0])), fabsf(v[1]));
-  amax = fmaxf(fmaxf(amax, fabsf(v[2])), fabsf(v[3]));
-  amax = fmaxf(fmaxf(amax, fabsf(v[4])), fabsf(v[5]));
-  amax = fmaxf(fmaxf(amax, fabsf(v[6])), fabsf(v[7]));
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const _Float16 h = (_Float16)v[i];
-    hi[i] = h;
-    lo[i] = (_Float16)(v[i] - (float)h);
-  }
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-}
 
 // PRE = the activations arrive already split: p.x / p.x_lo are fp16 hi / lo images [rows][lda halves] written by
 // the producer (cs_groupnorm_apply_split16) with the a_scale factor applied -- the split is then done once per

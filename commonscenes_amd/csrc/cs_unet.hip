@@ -288,9 +288,7 @@ struct Exec : ExecBase {
     Buf n3 = layernorm(t1, l.n[3]);
     Buf gg;
     if (l.fused_geglu) {
-      const Gemm& g = u.gemms[l.g[5]];
-      const bool big = ((rows + 255) / 256) * (int64_t)(g.cout / 224) >= 192;     // cs_conv_gemm's rule
-      gg = linear(n3, l.g[5], CS_ACT_GEGLU, nullptr, 0, 1, nullptr, 0, big ? 4 : 2);
+      gg = linear(n3, l.g[5], CS_ACT_GEGLU);           // tile 0: cs_conv_gemm picks a 224-column tile for the gate
     } else {
       Buf ff = linear(n3, l.g[5]);
       gg = alloc(rows, 4 * c);

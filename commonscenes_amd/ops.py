@@ -290,6 +290,9 @@ def conv_gemm(x: Tensor, w: PackedWeight, *, spatial: Optional[Tuple[int, int, i
     p.sd, p.sh, p.sw = stride
     p.pd, p.ph, p.pw = pd, ph, pw
     p.ud, p.uh, p.uw = up
+    if PINGPONG_OFF and tile == 0 and _pingpong_ok(mo, w.cin, w.cout, math, pointwise, scale is not None,
+                                                   rv_rows if rowvec is not None else 0):
+        tile = tile_for(mo, w.cout, 0, math, act=act)          # what the library picks without tile 5
     p.act, p.rv_rows, p.math, p.tile = act, rv_rows, math, tile
     lib = L.load()
     if math == L.MATH_F16X3 and tile == 0 and SPLITK:
@@ -309,7 +312,9 @@ def conv_gemm(x: Tensor, w: PackedWeight, *, spatial: Optional[Tuple[int, int, i
     if prof is not None:
         e1.record()
         prof.append(dict(e0=e0, e1=e1, flops=2.0 * mo * w.cout * w.cin * kd * kh * kw, taps=kd * kh * kw,
-                         m=mo, n=w.cout, k=w.cin * kd * kh * kw, tile=tile_for(mo, w.cout, tile, w.math)))
+                         m=mo, n=w.cout, k=w.cin * kd * kh * kw, tile=tile_for(mo, w.cout, tile, w.math, cin=w.cin, pointwise=pointwise,
+                                                                  bn=scale is not None, act=act,
+                                                                  rv_rows=rv_rows if rowvec is not None else 0)))
     return out
 
 
@@ -321,18 +326,35 @@ SPLITK = not os.environ.get("CS_NO_SPLITK")
 GEMM_PROFILE = None
 
 
-def tile_for(m: int, cout: int, tile: int = 0, math: int = L.MATH_FP32) -> int:
+# CS_NO_PINGPONG=1: token GEMMs on the one-tile-per-workgroup kernels (A/B runs; same bits either way)
+PINGPONG_OFF = bool(os.environ.get("CS_NO_PINGPONG"))
+
+
+def _pingpong_ok(m: int, cin: int, cout: int, math: int, pointwise: bool, bn: bool = False, rv_rows: int = 0) -> bool:
+    """cs_pw_gemm_f16x3_applicable (csrc/cs_gemm_pw.hip), alignment conditions aside.  rv_rows: rows per row-vector
+    entry when the GEMM has one (0: none)."""
+    return (math == L.MATH_F16X3 and pointwise and not bn and cout % 224 == 0 and (cin + 15) // 16 >= 28
+            and ((m + 127) // 128) * (cout // 224) >= 384 and rv_rows % 128 == 0)
+
+
+def tile_for(m: int, cout: int, tile: int = 0, math: int = L.MATH_FP32, cin: int = 0, pointwise: bool = False,
+             bn: bool = False, act: int = L.ACT_NONE, rv_rows: int = 0) -> int:
     """mirror of the tile auto-selection in cs_conv_gemm (csrc/cs_gemm.hip)."""
     if tile:
         return tile
+    if (not PINGPONG_OFF and _pingpong_ok(m, cin, cout, math, pointwise, bn, rv_rows) and (cin + 15) // 16 <= 42
+            and ((m + 127) // 128) * (cout // 224) >= 1024 and cout <= 448 and act != L.ACT_GEGLU):
+        return 5            # cs_pw_gemm_f16x3_preferred: where the ping-pong kernel measured faster
     mt = (m + 127) // 128
     if math == L.MATH_F16X3 and cout % 224 == 0 and ((m + 255) // 256) * (cout // 224) >= 192:
         return 4
     if cout % 224 == 0 and mt * (cout // 224) >= 256:
-        return 2
-    if cout > 64 and mt * ((cout + 127) // 128) >= 256:
-        return 1
-    return 3
+        t = 2
+    elif cout > 64 and mt * ((cout + 127) // 128) >= 256:
+        t = 1
+    else:
+        t = 3
+    return 2 if act == L.ACT_GEGLU else t
 
 
 def linear(x: Tensor, w: PackedWeight, **kw) -> Tensor:

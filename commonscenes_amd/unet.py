@@ -442,9 +442,7 @@ class DiffusionUNet:
             t1 = ops.linear(a2, pk[t + ".attn2.to_out.0"], res=t1a, math=self.math)
         n3 = ops.layernorm(t1, sd[t + ".norm3.weight"], sd[t + ".norm3.bias"])
         if (t + ".ff.geglu") in pk:      # GEGLU gate fused into the projection GEMM's epilogue
-            pg = pk[t + ".ff.geglu"]     # needs a 224-column tile: the 256-row one when the GEMM is big enough
-            gt = ops.tile_for(n3.numel() // n3.shape[-1], pg.cout, 0, pg.math)
-            gg = ops.linear(n3, pg, act=L.ACT_GEGLU, tile=gt if gt in (2, 4) else 2)
+            gg = ops.linear(n3, pk[t + ".ff.geglu"], act=L.ACT_GEGLU)    # the library picks a 224-column tile
         else:
             ff = ops.linear(n3, pk[t + ".ff.net.0.proj"], math=self.math)
             gg = ops.geglu(ff)

@@ -87,7 +87,9 @@ typedef struct CsConvGemm {
   int32_t act;
   int32_t rv_rows;    /* rows per rowvec entry (tokens / voxels per sample) */
   int32_t math;       /* CS_MATH_* */
-  int32_t tile;       /* 0 = auto, 1 = 128x128, 2 = 128x224, 3 = 64x64, 4 = 256x224 (F16X3; FP32 runs it as 2) */
+  int32_t tile;       /* 0 = auto, 1 = 128x128, 2 = 128x224, 3 = 64x64, 4 = 256x224 (F16X3; FP32 runs it as 2),
+                         5 = persistent ping-pong kernel (F16X3 pointwise GEMMs, cout % 224 == 0, cin >= 448, >= 384
+                         128x224 tiles; csrc/cs_gemm_pw.hip).  Every tile code gives the same bits. */
   /* CS_MATH_F16X3 only: w = hi halves, w_lo = lo halves, both laid out [tap][cin16/8][cout][8] by
    * cs_pack_weight_f16x3 (cin16 = cin rounded up to 16).  Activations are multiplied by a_scale (a power of
    * two; 0 means the default 16) before the fp16 split: |a| * a_scale must stay below 65504, and values
