@@ -1,6 +1,7 @@
 """Chamfer distance behind the reference's `extension/dist_chamfer.py` interface (`chamferDist()(a, b) ->
 (dist1, dist2)`), the metric kernel scripts/eval_3dfront.py:24-25,394-397 needs for `--evaluate_diversity`.
-Forward only: the reference's backward (chamfer.cu:136-182) serves training, which is out of scope."""
+Forward (chamfer.cu:11-151) and backward (chamfer.cu:155-185) as a torch.autograd.Function, like the reference's
+`chamferFunction` (dist_chamfer.py:12-47); the backward is a deterministic gather instead of atomicAdd scatters."""
 from __future__ import annotations
 
 from typing import Tuple
@@ -12,11 +13,15 @@ from . import lib as L
 Tensor = torch.Tensor
 
 
+def _check(t: Tensor, name: str):
+    if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 3 or t.shape[-1] != 3:
+        raise L.CsError(f"{name} must be a float32 [b, n, 3] tensor on the HIP device")
+
+
 def nm_distance(xyz1: Tensor, xyz2: Tensor) -> Tuple[Tensor, Tensor]:
     """(dist [b, n] fp32, idx [b, n] int32): nearest neighbour of every xyz1 point in xyz2 (squared distance)."""
-    for t, name in ((xyz1, "xyz1"), (xyz2, "xyz2")):
-        if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 3 or t.shape[-1] != 3:
-            raise L.CsError(f"{name} must be a float32 [b, n, 3] tensor on the HIP device")
+    _check(xyz1, "xyz1")
+    _check(xyz2, "xyz2")
     if xyz1.shape[0] != xyz2.shape[0]:
         raise L.CsError("batch sizes differ")
     xyz1, xyz2 = xyz1.contiguous(), xyz2.contiguous()
@@ -29,15 +34,47 @@ def nm_distance(xyz1: Tensor, xyz2: Tensor) -> Tuple[Tensor, Tensor]:
     return dist, idx
 
 
+def chamfer_backward(xyz1: Tensor, xyz2: Tensor, graddist1: Tensor, graddist2: Tensor, idx1: Tensor, idx2: Tensor):
+    """chamfer.backward (chamfer_cuda.cpp:28-31): (gradxyz1, gradxyz2)."""
+    _check(xyz1, "xyz1")
+    _check(xyz2, "xyz2")
+    xyz1, xyz2 = xyz1.contiguous(), xyz2.contiguous()
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    g1 = graddist1.to(torch.float32).contiguous()
+    g2 = graddist2.to(torch.float32).contiguous()
+    gx1, gx2 = torch.empty_like(xyz1), torch.empty_like(xyz2)
+    L.check(L.load().cs_chamfer_backward(xyz1.data_ptr(), xyz2.data_ptr(), g1.data_ptr(), g2.data_ptr(),
+                                         idx1.contiguous().data_ptr(), idx2.contiguous().data_ptr(), gx1.data_ptr(),
+                                         gx2.data_ptr(), b, n, m, torch.cuda.current_stream().cuda_stream),
+            "cs_chamfer_backward")
+    return gx1, gx2
+
+
+class chamferFunction(torch.autograd.Function):
+    """dist_chamfer.py:12-47."""
+
+    @staticmethod
+    def forward(ctx, xyz1, xyz2):
+        dist1, idx1 = nm_distance(xyz1, xyz2)
+        dist2, idx2 = nm_distance(xyz2, xyz1)
+        ctx.save_for_backward(xyz1, xyz2, idx1, idx2)
+        ctx.mark_non_differentiable(idx1, idx2)
+        return dist1, dist2, idx1, idx2
+
+    @staticmethod
+    def backward(ctx, graddist1, graddist2, _gi1, _gi2):
+        xyz1, xyz2, idx1, idx2 = ctx.saved_tensors
+        return chamfer_backward(xyz1, xyz2, graddist1, graddist2, idx1, idx2)
+
+
 class chamferDist:
-    """`chamferDist()(input1, input2) -> dist1, dist2` (extension/dist_chamfer.py:49-54); the neighbour indices of
-    the last call are kept as `.idx1`, `.idx2` (the reference saves them for its backward)."""
+    """`chamferDist()(input1, input2) -> dist1, dist2` (extension/dist_chamfer.py:49-54), differentiable; the neighbour
+    indices of the last call are kept as `.idx1`, `.idx2`."""
 
     def __call__(self, input1: Tensor, input2: Tensor) -> Tuple[Tensor, Tensor]:
         return self.forward(input1, input2)
 
-    @torch.no_grad()
     def forward(self, input1: Tensor, input2: Tensor) -> Tuple[Tensor, Tensor]:
-        dist1, self.idx1 = nm_distance(input1, input2)
-        dist2, self.idx2 = nm_distance(input2, input1)
+        dist1, dist2, self.idx1, self.idx2 = chamferFunction.apply(input1, input2)
         return dist1, dist2

@@ -104,6 +104,13 @@ SIGNATURES = {
     "cs_ddim_coefficients": (_i, [_fl, _fl, _fl, _fl, _f]),
     "cs_ddim_cfg_update_dev": (_i, [_f, _f, _f, _f, _f, _l, _l, _f, _fl, _i, _s]),
     "cs_plms_update": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _l, _l, _i, _fl, _fl, _fl, _fl, _i, _s]),
+    "cs_chamfer_backward": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _s]),
+    "cs_emd_approxmatch": (_i, [_f, _f, _f, _f, _i, _i, _i, _s]),
+    "cs_emd_matchcost": (_i, [_f, _f, _f, _f, _i, _i, _i, _s]),
+    "cs_emd_matchcost_grad": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _s]),
+    "cs_mc_blocks_per_object": (_i, [_i]),
+    "cs_mc_count": (_i, [_f, _i, _i, _fl, _f, _s]),
+    "cs_mc_emit": (_i, [_f, _i, _i, _fl, _f, _f, _f, _f, _f, _f, _fl, _fl, _s]),
     "cs_chamfer_nm_distance": (_i, [_f, _f, _f, _f, _i, _i, _i, _s]),
     "cs_unet_create": (_i, [C.POINTER(CsUnetConfig), _pp]),
     "cs_unet_destroy": (None, [C.c_void_p]),
@@ -120,6 +127,9 @@ SIGNATURES = {
     "cs_vq_argmin_lookup": (_i, [_f, _f, _f, _f, _l, _i, _i, _i, _i, _s]),
     "cs_gcn_gather_cat": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _f, _s]),
     "cs_gcn_segment_mean": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _f, _s]),
+    "cs_gcn_csr_ints": (_l, [_i, _i]),
+    "cs_gcn_csr_build": (_i, [_f, _f, _i, _i, _f, _s]),
+    "cs_gcn_segment_mean_csr": (_i, [_f, _f, _f, _i, _i, _i, _i, _s]),
     "cs_embedding": (_i, [_f, _f, _f, _i, _i, _i, _i, _f, _s]),
     "cs_log_softmax": (_i, [_f, _f, _i, _i, _i, _i, _s]),
     "cs_synth_fill": (_i, [_f, _l, C.c_uint64, C.c_double, C.c_double, _s]),

@@ -650,6 +650,27 @@ def gcn_segment_mean(new_t: Tensor, edges: Tensor, n_obj: int, h: int, off_o: in
     return pooled
 
 
+def gcn_csr(edges: Tensor, n_obj: int) -> Tensor:
+    """CSR-by-destination index of a scene graph's edges [T, 2] (built once, shared by every layer's pooling)."""
+    _chk(edges, "edges", torch.int64)
+    edges = edges.contiguous()
+    n_tri = edges.shape[0]
+    lib = L.load()
+    csr = torch.empty((int(lib.cs_gcn_csr_ints(n_obj, n_tri)),), dtype=torch.int32, device=edges.device)
+    L.check(lib.cs_gcn_csr_build(edges.data_ptr(), csr.data_ptr(), n_obj, n_tri, index_err_word(edges.device).data_ptr(),
+                                 _stream()), "cs_gcn_csr_build")
+    return csr
+
+
+def gcn_segment_mean_csr(new_t: Tensor, csr: Tensor, n_obj: int, h: int, off_o: int) -> Tensor:
+    _chk(new_t, "new_t"); _chk(csr, "csr", torch.int32)
+    _, _, ld_t = rows_ld(new_t, "new_t")
+    pooled = torch.empty((n_obj, h), dtype=torch.float32, device=new_t.device)
+    L.check(L.load().cs_gcn_segment_mean_csr(new_t.data_ptr(), csr.data_ptr(), pooled.data_ptr(), n_obj, h, off_o, ld_t,
+                                             _stream()), "cs_gcn_segment_mean_csr")
+    return pooled
+
+
 def embedding(table: Tensor, idx: Tensor, out: Optional[Tensor] = None) -> Tensor:
     _chk(table, "table"); _chk(idx, "idx", torch.int64)
     n_rows, dim = table.shape

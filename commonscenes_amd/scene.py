@@ -142,11 +142,17 @@ class GraphTripleConv:
             self.proj_pred = ops.pack_weight(sd[p + ".linear_projection_pred.weight"],
                                              sd[p + ".linear_projection_pred.bias"])
 
-    def __call__(self, obj_vecs: Tensor, pred_vecs: Tensor, edges: Tensor) -> Tuple[Tensor, Tensor]:
+    def __call__(self, obj_vecs: Tensor, pred_vecs: Tensor, edges: Tensor, csr: Optional[Tensor] = None
+                 ) -> Tuple[Tensor, Tensor]:
+        """`csr`: the graph's CSR-by-destination index (ops.gcn_csr), shared by the layers of a net; None -> the
+        index-free pooling kernel (same bits)."""
         H, Dout = self.H, self.Dout
         cur_t = ops.gcn_gather_cat(obj_vecs, pred_vecs, edges)            # [T, 2*Din + Dp]
         new_t = self.net1(cur_t)                                          # [T, 2H + Dout] = [s | p | o]
-        pooled = ops.gcn_segment_mean(new_t, edges, obj_vecs.shape[0], H, H + Dout)
+        if csr is not None:
+            pooled = ops.gcn_segment_mean_csr(new_t, csr, obj_vecs.shape[0], H, H + Dout)
+        else:
+            pooled = ops.gcn_segment_mean(new_t, edges, obj_vecs.shape[0], H, H + Dout)
         new_p = new_t[:, H:H + Dout]
         if self.residual:
             # new_obj = net2(pooled) + proj(obj): the projection GEMM takes net2's output as its residual
@@ -165,8 +171,9 @@ class GraphTripleConvNet:
         self.gconvs = [GraphTripleConv(sd, f"{p}.gconvs.{i}") for i in range(num_layers)]
 
     def __call__(self, obj_vecs, pred_vecs, edges):
+        csr = ops.gcn_csr(edges, obj_vecs.shape[0])         # the incidence lists depend on the edges only
         for g in self.gconvs:
-            obj_vecs, pred_vecs = g(obj_vecs, pred_vecs, edges)
+            obj_vecs, pred_vecs = g(obj_vecs, pred_vecs, edges, csr)
         # the gather kernels skip out-of-range indices and raise a device flag; the reference's indexing
         # (graph.py:146-147, nn.Embedding) raises IndexError -- one read-back per GCN call keeps that behaviour
         ops.check_index_errors(obj_vecs.device, "scene graph (object / predicate ids, triple endpoints)")

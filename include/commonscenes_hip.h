@@ -288,6 +288,16 @@ int cs_gcn_gather_cat(const float* obj, const float* pred, const int64_t* edges,
 int cs_gcn_segment_mean(const float* new_t, const int64_t* edges, float* pooled, int n_obj,
                         int n_tri, int h, int off_o, int ld_t, int32_t* err, cs_stream_t stream);
 
+/*
+ * The same pooling through a CSR-by-destination index built once per graph (the lists depend on the edges only; the
+ * five layers of a GraphTripleConvNet share it): O(T) per layer and channel instead of O(O T), same summation order,
+ * same bits.  csr: cs_gcn_csr_ints(n_obj, n_tri) int32 of caller-owned scratch.
+ */
+int64_t cs_gcn_csr_ints(int n_obj, int n_tri);
+int cs_gcn_csr_build(const int64_t* edges, int32_t* csr, int n_obj, int n_tri, int32_t* err, cs_stream_t stream);
+int cs_gcn_segment_mean_csr(const float* new_t, const int32_t* csr, float* pooled, int n_obj, int h, int off_o,
+                            int ld_t, cs_stream_t stream);
+
 /* Embedding row gather: out[i] = table[idx[i]] (nn.Embedding, VAEGAN_V2FULL.py:225-226). */
 int cs_embedding(const float* table, const int64_t* idx, float* out, int n, int dim, int n_rows,
                  int ldo, int32_t* err, cs_stream_t stream);
@@ -313,6 +323,54 @@ int cs_synth_fill(float* out, int64_t n, uint64_t base, double scale, double off
  */
 int cs_chamfer_nm_distance(const float* xyz1, const float* xyz2, float* dist, int32_t* idx, int b, int n, int m,
                            cs_stream_t stream);
+
+/*
+ * Chamfer backward (extension/chamfer.cu:155-185, bound by chamfer_cuda.cpp:28-31, dist_chamfer.py:35-47):
+ *   grad_xyz1[j] = 2 g1[j] (a_j - b_idx1[j]) + sum_{k: idx2[k] == j} 2 g2[k] (a_j - b_k), and symmetrically grad_xyz2.
+ * The reference scatters with atomicAdd (order-dependent rounding); this is a gather, k ascending: deterministic.
+ * Outputs are written, not accumulated (the reference's wrapper passes zero-filled tensors).
+ */
+int cs_chamfer_backward(const float* xyz1, const float* xyz2, const float* grad_dist1, const float* grad_dist2,
+                        const int32_t* idx1, const int32_t* idx2, float* grad_xyz1, float* grad_xyz2, int b, int n,
+                        int m, cs_stream_t stream);
+
+/*
+ * Approximate earth mover's distance (scripts/pytorch_structural_losses/src/approxmatch.cu, bound by
+ * structural_loss.cpp and wrapped by match_cost.py; used by scripts/compute_mmd_cov_1nn.py:56-62):
+ *   cs_emd_approxmatch     the nine-level auction (approxmatch.cu:3-182): match [b][m][n] (query-major, as the
+ *                          reference lays it out), temp [b][(n+m)*2] scratch (remainL | remainR | ratioL | ratioR)
+ *   cs_emd_matchcost       out[i] = sum_k sum_j match[i][k][j] |xyz2_k - xyz1_j|          (:184-224)
+ *   cs_emd_matchcost_grad  d cost / d xyz1 -> grad1 [b][n][3], d cost / d xyz2 -> grad2 [b][m][3]   (:229-320)
+ * xyz1 [b][n][3], xyz2 [b][m][3] fp32.  exp is the fast hardware exponential, as in the reference (__expf).
+ */
+int cs_emd_approxmatch(const float* xyz1, const float* xyz2, float* match, float* temp, int b, int n, int m,
+                       cs_stream_t stream);
+int cs_emd_matchcost(const float* xyz1, const float* xyz2, const float* match, float* out, int b, int n, int m,
+                     cs_stream_t stream);
+int cs_emd_matchcost_grad(const float* xyz1, const float* xyz2, const float* match, float* grad1, float* grad2, int b,
+                          int n, int m, cs_stream_t stream);
+
+/*
+ * SDF -> triangle mesh by marching cubes (model/diff_utils/util_3d.py:194-236 sdf_to_mesh, which runs
+ * PyMCubes' mcubes.marching_cubes(sdf_i, level) on the CPU per object).  sdf: [nb][n][n][n] fp32 (the decoder's
+ * (B,1,64,64,64) output as is), n <= 160.  A vertex per grid edge whose endpoints straddle `level` ((v < level) differs),
+ * linearly interpolated in fp64 like PyMCubes; vertices unique per edge, voxel-raster order (+x, +y, +z edge of each
+ * voxel); triangles from a 256-case table derived from the cube geometry (commonscenes_amd/mc_tables.py: ambiguous
+ * faces cut off the inside corners, so neighbouring cubes always agree -- watertight), normals towards increasing
+ * value, cube-raster order.  Deterministic, no atomics.
+ *   cs_mc_blocks_per_object(n)  B = ceil(n^3 / 4096)
+ *   cs_mc_count   -> block_sums [nb][B][2] int32: vertices and triangles per 4096-voxel block.  The caller reads them
+ *                  back (the library never synchronises), sizes the outputs and passes per-object bases:
+ *   cs_mc_emit    vert_base / face_base [nb] int64 (device): first vertex / triangle of each object in `verts`
+ *                  [total][3] fp32 and `faces` [total][3] int64 (vertex ids local to the object);
+ *                  voxel_ws: nb * n^3 int32 scratch;  vertex = index_coordinate / vert_div + vert_shift
+ *                  (n, -0.5 reproduce util_3d.py:218; 1, 0 give PyMCubes' raw index coordinates).
+ */
+int cs_mc_blocks_per_object(int n);
+int cs_mc_count(const float* sdf, int nb, int n, float level, int32_t* block_sums, cs_stream_t stream);
+int cs_mc_emit(const float* sdf, int nb, int n, float level, const int32_t* block_sums, const int64_t* vert_base,
+               const int64_t* face_base, float* verts, int64_t* faces, int32_t* voxel_ws, float vert_div,
+               float vert_shift, cs_stream_t stream);
 
 /*
  * Whole-forward driver (SURVEY 8b "cs_unet_step"): UNet3DModel.forward (openai_model_3d.py:752-789) with the

@@ -1,0 +1,110 @@
+"""SDF -> mesh: marching cubes behind util_3d.py's sdf_to_mesh.  PyMCubes is absent (parity unpinned,
+see oracle/ref_mesh.py), so the gates are (a) invariants of ANY correct marching cubes, checked on the oracle (CPU) and
+on the HIP path (GPU), and (b) HIP == oracle exactly (vertex order, face order, fp32 vertex values)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_mesh as RM
+
+
+def _sphere(n, c, r):
+    g = np.mgrid[0:n, 0:n, 0:n].astype(np.float32)
+    return (np.sqrt((g[0] - c[0]) ** 2 + (g[1] - c[1]) ** 2 + (g[2] - c[2]) ** 2) - r).astype(np.float32)
+
+
+def _noise(n, seed):
+    rng = np.random.default_rng(seed)
+    vol = np.full((n, n, n), 5.0, np.float32)                 # an "outside" shell closes every surface
+    vol[1:-1, 1:-1, 1:-1] = rng.standard_normal((n - 2,) * 3).astype(np.float32)
+    return vol
+
+
+def test_tables_product_generator_equals_oracle_derivation():
+    from commonscenes_amd import mc_tables as T
+    tab = RM.table()
+    assert T.MAX_TRIS == 5 and int(T.N_TRIS.sum()) == 820
+    for c in range(256):
+        mine = [tuple(int(v) for v in T.TRI_TABLE[c][3 * i:3 * i + 3]) for i in range(int(T.N_TRIS[c]))]
+        assert mine == tab[c], c
+    assert not tab[0] and not tab[255]
+    # the committed header is what the generator produces now
+    from pathlib import Path
+    hdr = (Path(__file__).resolve().parent.parent / "commonscenes_amd" / "csrc" / "cs_mc_tables.h").read_text()
+    for c in (1, 0x5A, 0xA5, 0x3C, 254):
+        assert "{" + ",".join(str(int(v)) for v in T.TRI_TABLE[c]) + "}" in hdr
+
+
+def test_oracle_marching_cubes_invariants():
+    c, r = (9.3, 10.1, 9.7), 6.2
+    v, f = RM.marching_cubes(_sphere(20, c, r), 0.02)
+    assert RM.mesh_invariants(v, f) == (0, 0, 0, 2)            # closed, manifold, consistently oriented, genus 0
+    tri = v[f]
+    nrm = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+    assert ((nrm * (tri.mean(1) - np.array(c))).sum(1) > 0).all()          # normals towards increasing SDF
+    assert np.abs(np.linalg.norm(v - np.array(c), axis=1) - (r + 0.02)).max() < 0.03   # linear interpolation error only
+    area = 0.5 * np.linalg.norm(nrm, axis=1).sum()
+    assert abs(area / (4 * np.pi * (r + 0.02) ** 2) - 1) < 0.02
+    # every ambiguous configuration at once: white noise, closed by an outside shell
+    v, f = RM.marching_cubes(_noise(14, 0), 0.02)
+    assert RM.mesh_invariants(v, f)[:3] == (0, 0, 0)
+    # nothing to extract
+    v, f = RM.marching_cubes(np.ones((6, 6, 6), np.float32), 0.02)
+    assert v.shape == (0, 3) and f.shape == (0, 3)
+
+
+@pytest.mark.gpu
+def test_hip_marching_cubes_equals_oracle_exactly():
+    from commonscenes_amd.mesh import marching_cubes
+    vols = [_sphere(20, (9.3, 10.1, 9.7), 6.2), _noise(14, 0), _noise(14, 1), np.ones((14, 14, 14), np.float32)]
+    vols[3][7, 7, 7] = -1.0                                                # one inside voxel: an octahedron
+    for level in (0.02, 0.0):
+        for group in ([vols[0]], vols[1:]):                               # batches of 1 and 3 (equal grid size)
+            sdf = torch.from_numpy(np.stack(group)).cuda()
+            v, f, nv, nf = marching_cubes(sdf, level)
+            torch.cuda.synchronize()
+            vs, fs = torch.split(v.cpu(), nv), torch.split(f.cpu(), nf)
+            for b, vol in enumerate(group):
+                rv, rf = RM.marching_cubes(vol, level)
+                assert vs[b].shape[0] == rv.shape[0] and fs[b].shape[0] == rf.shape[0]
+                assert np.array_equal(fs[b].numpy(), rf)
+                assert np.array_equal(vs[b].numpy(), rv.astype(np.float32))
+
+
+@pytest.mark.gpu
+def test_sdf_to_mesh_on_64_cubed_batch_properties():
+    """util_3d.py:194-236 at the decoder's size: 32 objects x 64^3 in one call (render_all=True, helpers/util.py:298):
+    every mesh closed / manifold / oriented, vertices in [-0.5, 0.5), vertex SDF == level by trilinear re-evaluation,
+    colours as given; only 16 meshes without render_all (util_3d.py:204-208)."""
+    from commonscenes_amd.mesh import sdf_to_mesh
+    n, B = 64, 32
+    rng = np.random.default_rng(5)
+    vols = []
+    for b in range(B):
+        c = 32 + rng.uniform(-6, 6, 3)
+        s = _sphere(n, c, rng.uniform(8, 20))
+        box = np.max(np.abs(np.mgrid[0:n, 0:n, 0:n].astype(np.float32) - c[:, None, None, None]) -
+                     rng.uniform(6, 18, 3).astype(np.float32)[:, None, None, None], axis=0)
+        vols.append(np.minimum(s, box).astype(np.float32) if b % 2 else s)          # union of a sphere and a box
+    sdf = torch.from_numpy(np.stack(vols))[:, None].cuda()
+    m = sdf_to_mesh(sdf, level=0.02, color=(0.2, 0.4, 0.6), render_all=True)
+    torch.cuda.synchronize()
+    assert len(m) == B and len(sdf_to_mesh(sdf)) == 16
+    for b in (0, 1, 7, 31):
+        v, f = m.verts_list()[b].cpu().numpy().astype(np.float64), m.faces_list()[b].cpu().numpy()
+        assert f.dtype == np.int64 and v.min() >= -0.5 and v.max() < 0.5
+        assert RM.mesh_invariants(v, f)[:3] == (0, 0, 0)
+        p = (v + 0.5) * n                                                    # back to index coordinates
+        i0 = np.floor(p).astype(int).clip(0, n - 2)
+        t = p - i0
+        val = np.zeros(len(p))
+        for dx in (0, 1):
+            for dy in (0, 1):
+                for dz in (0, 1):
+                    w = np.abs(1 - dx - t[:, 0]) * np.abs(1 - dy - t[:, 1]) * np.abs(1 - dz - t[:, 2])
+                    val += w * vols[b][i0[:, 0] + dx, i0[:, 1] + dy, i0[:, 2] + dz]
+        assert np.abs(val - 0.02).max() < 2e-4                               # on the isosurface (fp32 vertex rounding)
+        rgb = m.textures.verts_features_list()[b].cpu().numpy()
+        assert rgb.shape == v.shape and np.allclose(rgb, [[0.2, 0.4, 0.6]])
+    one = m[3]
+    assert len(one) == 1 and torch.equal(one.verts_list()[0], m.verts_list()[3])

@@ -342,6 +342,30 @@ def test_gcn_gather_and_pool(ops, R):
     torch.cuda.synchronize()
     assert torch.equal(pooled.cpu(), R.gcn_pool(new_t, edges, n_obj, H, H + 40))   # same summation order
     assert torch.all(pooled[8] == 0)
+    # the CSR-by-destination path (built once per graph, shared by the layers): same order, same bits
+    csr = ops.gcn_csr(_dev(edges), n_obj)
+    pooled2 = ops.gcn_segment_mean_csr(_dev(new_t), csr, n_obj, H, H + 40)
+    torch.cuda.synchronize()
+    assert torch.equal(pooled2, pooled)
+    c = csr.cpu()
+    assert int(c[3 * n_obj]) == 2 * n_tri                                            # every edge listed twice
+    assert int(c[n_obj + 9]) == 0 and int(c[n_obj + 8]) == 0 and int(c[2 * n_obj + 8]) == 0
+
+
+def test_gcn_csr_pooling_at_c4_graph_size(ops, R):
+    """BASELINE configs[3]'s 258-node graph (~1300 triples): CSR pooling == the reference's scatter_add order, bit for
+    bit, at H = 256 (the shipped GCN width)."""
+    from commonscenes_amd import synth
+    g = synth.random_scene_graph(256, seed=3)
+    O, T = g["objs"].shape[0], g["triples"].shape[0]
+    edges = torch.stack([g["triples"][:, 0], g["triples"][:, 2]], dim=1).contiguous()
+    H, Dout = 256, 640
+    new_t = _rand(T, 2 * H + Dout, seed=7)
+    csr = ops.gcn_csr(_dev(edges), O)
+    a = ops.gcn_segment_mean_csr(_dev(new_t), csr, O, H, H + Dout)
+    b = ops.gcn_segment_mean(_dev(new_t), _dev(edges), O, H, H + Dout)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.equal(a.cpu(), R.gcn_pool(new_t, edges, O, H, H + Dout))
 
 
 def test_embedding(ops):
