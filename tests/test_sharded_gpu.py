@@ -12,22 +12,22 @@ import pytest
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def _launch(nproc, port, objects):
+def _launch(nproc, port, objects, tmp_path):
     env = dict(os.environ, CS_ONE_DEVICE="1", CS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0",
-               CS_SHARD_OBJECTS=str(objects))
+               CS_SHARD_OBJECTS=str(objects), CS_SHARD_OUT=str(tmp_path))
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
                         "--master-addr", "127.0.0.1", "--master-port", str(port),
                         str(ROOT / "tests" / "_sharded_worker.py")],
                        capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    out = [json.loads(l.split(" ", 1)[1]) for l in r.stdout.splitlines() if l.startswith("SHARD_RESULT ")]
-    assert len(out) == nproc
+    out = [json.loads(p.read_text()) for p in sorted(tmp_path.glob("rank*.json"))]
+    assert len(out) == nproc, r.stdout[-2000:] + r.stderr[-2000:]
     return {d["rank"]: d for d in out}
 
 
 @pytest.mark.gpu
-def test_two_rank_sharded_rel2shape_equals_single_rank_bit_for_bit():
-    res = _launch(2, 29553, 9)                     # 9 objects -> shards of 5 + 4
+def test_two_rank_sharded_rel2shape_equals_single_rank_bit_for_bit(tmp_path):
+    res = _launch(2, 29553, 9, tmp_path)                     # 9 objects -> shards of 5 + 4
     for r in (0, 1):
         assert res[r]["shape"] == [9, 1, 64, 64, 64] and res[r]["finite"]      # every rank holds ALL objects
         assert res[r]["sample_shape"] == [6, 1, 64, 64, 64]
@@ -40,7 +40,7 @@ def test_two_rank_sharded_rel2shape_equals_single_rank_bit_for_bit():
 
 
 @pytest.mark.gpu
-def test_three_rank_sharded_rel2shape_uneven_shards():
-    res = _launch(3, 29557, 7)                     # 7 objects -> 3 + 2 + 2
+def test_three_rank_sharded_rel2shape_uneven_shards(tmp_path):
+    res = _launch(3, 29557, 7, tmp_path)                     # 7 objects -> 3 + 2 + 2
     assert all(res[r]["shape"] == [7, 1, 64, 64, 64] and res[r]["finite"] for r in range(3))
     assert res[0]["equal_same_minibatching"] and res[0]["rel_l2_single_call"] < 1e-5
