@@ -363,6 +363,121 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   constexpr int EPI_ROWS = 2 * PASS_R;                                       // rows staged per wave per pass
   constexpr int EPI_BYTES = EPI_ROWS * WCOLS * 4;                            // per wave, per pass
   static_assert(NW * EPI_BYTES <= NSTAGE * STAGE, "epilogue staging must fit in the ring");
+  // ---- pipelined residual epilogue -------------------------------------------------------------------------------
+  // A tile with a residual used to read it with one dependent global load per float4 of output: 28 serialized HBM
+  // latencies per wave (~30 us per 256x224 tile, as long as a 448-channel GEMM's whole K loop; tools/pw_ablate.sh and
+  // the 448->448 vs 448->1344 rows of profiles/r02_c_gemm_table_before_pingpong.txt).  Here the residual rows of pass
+  // q+1 are LDS-DMA'd into a second slab while pass q is staged, combined and stored; the tile's bias row and (one
+  // sample per tile) row-vector row are DMA'd once.  Stores are buffer stores whose inactive lanes carry an
+  // out-of-range offset, so every pass issues exactly KU of them and the counted vmcnt below is exact.
+  {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int QR = 2;                                    // accumulator registers per pass -> 4 rows per wave
+    constexpr int NQ = 16 / QR;
+    constexpr int UPR = WCOLS / 4;                           // float4 units per row
+    constexpr int UN = 2 * QR * UPR;                         // units per pass per wave
+    constexpr int KU = (UN + 63) / 64;                       // per lane
+    constexpr int EPB = 2 * QR * WCOLS * 4;                  // staging bytes per wave
+    constexpr int RSLAB = KU * 1024;                         // one residual slab per wave
+    constexpr int RES0 = NW * EPB;
+    constexpr int VEC0 = RES0 + NW * 2 * RSLAB;
+    constexpr int BNV = (BN + 63) / 64;                      // waves that fetch the bias / row-vector rows
+    static_assert(VEC0 + 2048 <= LDS_BYTES && BN <= 256 && BNV <= NW, "pipelined epilogue must fit in the kernel's LDS");
+    const int m_last = min(m0 + BM, M) - 1;
+    const bool piped = !(CS_ABLATE & 32) && vec_epilogue && p.res && !p.scale && p.act != CS_ACT_GEGLU && splits == 1 &&
+                       n0 + BN <= p.cout && (!p.rowvec || (m0 / p.rv_rows == m_last / p.rv_rows)) &&
+                       (long long)BM * p.ldo * 4 < 0x7FF00000LL && (long long)BM * p.ldr * 4 < 0x7FF00000LL;
+    if (piped) {
+      __syncthreads();                                       // every wave has left the ring
+      float* const ep = reinterpret_cast<float*>(smem + wave * EPB);
+      float* const rs = reinterpret_cast<float*>(smem + RES0 + wave * 2 * RSLAB);
+      float* const vb = reinterpret_cast<float*>(smem + VEC0);
+      float* const vr = vb + 256;
+      // per-tile descriptor windows (32-bit offsets inside BM rows)
+      const long long o_skip = (long long)m0 * p.ldo * 4, r_skip = (long long)m0 * p.ldr * 4;
+      const long long o_left = ((long long)(M - 1) * p.ldo + p.cout) * 4 - o_skip;
+      const long long r_left = ((long long)(M - 1) * p.ldr + p.cout) * 4 - r_skip;
+      const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)((char*)p.out + o_skip), 0, o_left > 0x7FF00000LL ? 0x7FF00000u : (unsigned)o_left, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)((const char*)p.res + r_skip), 0, r_left > 0x7FF00000LL ? 0x7FF00000u : (unsigned)r_left, 0x00020000);
+      if (wave < BNV) {                                      // bias / row-vector rows: 4 bytes per lane
+        const unsigned col = (unsigned)(64 * wave + lane);
+        const unsigned off = col < (unsigned)BN ? (unsigned)(n0 + (int)col) * 4u : OOB;
+        if (p.bias) {
+          const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, (unsigned)p.cout * 4u, 0x00020000);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, vb + 64 * wave, 4, off, 0, 0, 0);
+        }
+        if (p.rowvec) {
+          const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(
+              (void*)(p.rowvec + (int64_t)(m0 / p.rv_rows) * p.ldrv), 0, (unsigned)p.cout * 4u, 0x00020000);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, vr + 64 * wave, 4, off, 0, 0, 0);
+        }
+      }
+      auto pass_row = [&](int i, int q, int lrow) {
+        return wm0 + 32 * i + 2 * (q & 1) + 8 * (q >> 1) + (lrow & 1) + 4 * (lrow >> 1);
+      };
+      auto fetch_res = [&](int pass) {                       // pass = i * NQ + q -> slab pass & 1
+        const int i = pass / NQ, q = pass - i * NQ;
+#pragma unroll
+        for (int k = 0; k < KU; ++k) {
+          const int u = lane + 64 * k;
+          const int lrow = u / UPR, c4 = u - lrow * UPR;
+          const int row = pass_row(i, q, lrow & 3);
+          const unsigned off = (u < UN && m0 + row < M) ? (unsigned)(row * p.ldr + n0 + wn0 + 4 * c4) * 4u : OOB;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rrs, rs + (pass & 1) * (RSLAB / 4) + 256 * k, 16, off, 0, 0, 0);
+        }
+      };
+      fetch_res(0);
+      wait_vmcnt<KU>();                                      // the bias / row-vector rows (older) have landed ...
+      __syncthreads();                                       // ... for every wave
+      constexpr int NPASS = WMB * NQ;
+      auto do_pass = [&](auto i_c, auto q_c) {
+        constexpr int i = decltype(i_c)::value, q = decltype(q_c)::value, pass = i * NQ + q;
+        if constexpr (pass + 1 < NPASS) fetch_res(pass + 1);
+        // younger than this pass's residual fetch: the previous pass's KU stores and the KU fetches just issued
+        wait_vmcnt<(pass > 0 ? KU : 0) + (pass + 1 < NPASS ? KU : 0)>();
+#pragma unroll
+        for (int j = 0; j < WNB; ++j)
+#pragma unroll
+          for (int rr = 0; rr < QR; ++rr) ep[(rr + QR * half) * WCOLS + 32 * j + l31] = acc[i][j][QR * q + rr] * p.acc_scale;
+#pragma unroll
+        for (int k = 0; k < KU; ++k) {
+          const int u = lane + 64 * k;
+          const int lrow = u / UPR, c4 = u - lrow * UPR;
+          const int row = pass_row(i, q, lrow & 3);
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          unsigned off = OOB;
+          if (u < UN && m0 + row < M) {
+            v = *reinterpret_cast<const f32x4*>(ep + lrow * WCOLS + 4 * c4);
+            if (p.bias) v += *reinterpret_cast<const f32x4*>(vb + wn0 + 4 * c4);
+            if (p.rowvec) v += *reinterpret_cast<const f32x4*>(vr + wn0 + 4 * c4);
+            if (p.act != CS_ACT_NONE) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = cs_act(v[e], p.act);
+            }
+            v += *reinterpret_cast<const f32x4*>(rs + (pass & 1) * (RSLAB / 4) + 4 * u);
+            off = (unsigned)(row * p.ldo + n0 + wn0 + 4 * c4) * 4u;
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, off, 0, 0);   // OOB lanes: dropped
+        }
+      };
+      auto all_q = [&](auto i_c) {
+        do_pass(i_c, std::integral_constant<int, 0>{});
+        do_pass(i_c, std::integral_constant<int, 1>{});
+        do_pass(i_c, std::integral_constant<int, 2>{});
+        do_pass(i_c, std::integral_constant<int, 3>{});
+        do_pass(i_c, std::integral_constant<int, 4>{});
+        do_pass(i_c, std::integral_constant<int, 5>{});
+        do_pass(i_c, std::integral_constant<int, 6>{});
+        do_pass(i_c, std::integral_constant<int, 7>{});
+      };
+      all_q(std::integral_constant<int, 0>{});
+      if constexpr (WMB > 1) all_q(std::integral_constant<int, 1>{});
+      static_assert(WMB <= 2 && NQ == 8, "pass enumeration");
+      return;
+    }
+  }
   const bool vec_ok = !(CS_ABLATE & 32) && vec_epilogue && (n0 + wn0 + WCOLS <= p.cout);
   if (vec_ok) {
     __syncthreads();                                        // every wave has left the ring

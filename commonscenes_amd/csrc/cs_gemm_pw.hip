@@ -1,24 +1,33 @@
 // Persistent "ping-pong" pointwise GEMM for CS_MATH_F16X3 (tile code 5): the token / 1x1x1 GEMMs of the transformer
-// blocks (K = 448 ... 2688, N a multiple of 224) whose K loop is too short to amortise a tile's epilogue.
+// blocks (K = 448 ... 2688, N a multiple of 224).
 //
-// Why: with one 256x224 tile per workgroup the 28-chunk K loop of a 448-channel GEMM takes ~20 us and the tile's
-// epilogue (229 KB written + 229 KB of residual read per CU, every CU at the same moment) another ~17 us with the
-// matrix pipe idle (tools/gemm_ksweep.py): 155-290 TF/s where the 27-tap convs reach 400.  These GEMMs
-// sit at the chip's balance point (75 flop per HBM byte), so the fix is overlap, not fewer bytes.
+// Why.  With one 256x224 tile per workgroup these GEMMs ran at 155-290 TF/s where the 27-tap convs reach 400
+// (profiles/r02_c_gemm_table_before_pingpong.txt), for two reasons a conv does not have:
+//   * short K loops: a 448-channel GEMM's 28 chunks take ~20 us, and the tile's prologue (first operands from HBM) and
+//     epilogue (229 KB written + 229 KB of residual read per CU, every CU at the same moment) another ~20 us with the
+//     matrix pipe idle;
+//   * long K loops are latency-bound on the activation stream: a pointwise GEMM reads every A byte from HBM exactly
+//     once (a conv re-touches its rows 27 times from L1/L2), and two 16 KB chunks in flight per CU cover ~1 us of a
+//     ~2 us loaded HBM latency.
 //
-// How: one 512-thread workgroup per CU, persistent over tiles, split into two 4-wave GROUPS (one wave per SIMD each)
-// that each own a 128x224 output tile and run half a period out of phase on a common barrier cadence:
+// How.  One 512-thread workgroup per CU, persistent over its tiles, is two 4-wave GROUPS (one wave per SIMD each) that
+// own alternate 128x224 tiles and run half a period out of phase on a common barrier cadence (one s_barrier per
+// 16-wide K chunk = "slot"):
 //
 //     slot:      | 0 1 2 ...                nk-1 | 0 1 2 ...                nk-1 |
-//     group 0    |  K loop of tile a (MFMA)      |  epilogue of tile a (stores)  |  K loop of tile c ...
-//     group 1    |  epilogue of tile z           |  K loop of tile b (MFMA)      |  epilogue of tile b ...
+//     group 0    |  K loop of tile 0 (MFMA)      |  epilogue of tile 0 (stores)  |  K loop of tile 2 ...
+//     group 1    |  (idle)                       |  K loop of tile 1 (MFMA)      |  epilogue of tile 1 ...
 //
-// Every slot is one workgroup-wide s_barrier.  The computing group does one 16-wide K chunk per slot exactly like
-// conv_gemm_f16x3_kernel<1,7,4,1> (3-stage LDS-DMA ring, counted vmcnt, A split software-pipelined); the other group
-// spreads its epilogue over the same slots -- residual / row-vector loads issued `stride` slots before they are
-// consumed, so no slot ever waits on HBM latency -- and at the end prefetches the first two chunks of its next tile.
-// The matrix pipe therefore always has exactly one wave per SIMD feeding it, and the output / residual traffic is
-// spread evenly under the MFMA stream instead of arriving as a chip-wide burst.
+//   * The operands of ALL tiles form one continuous chunk stream through a shared LDS ring: six A stages (8 KB each:
+//     five chunks = 40 KB per CU in flight, enough for HBM latency at full bandwidth) and three B stages (14 KB,
+//     L2-resident weights).  The computing group issues the stream's LDS-DMAs -- chunk c+5's A and chunk c+2's B while it
+//     multiplies chunk c -- straight across tile boundaries, so the next tile (the OTHER group's) finds its first
+//     chunks in LDS: no prologue.
+//   * The group that is not computing spreads its tile's epilogue over the same slots: accumulators -> per-wave LDS
+//     staging -> float4 rows; bias / row-vector rows and the residual rows arrive by LDS-DMA `stride` slots before they
+//     are consumed, so no slot ever waits on HBM latency and no registers are held across slots.
+//   The matrix pipe therefore always has exactly one wave per SIMD feeding it, and the output / residual traffic is
+//   spread evenly under the MFMA stream instead of arriving as a chip-wide burst.
 //
 // Results are bit-identical to the one-tile-per-workgroup kernels: same chunk order, same three-MFMA sequence per
 // chunk, same epilogue expression.
@@ -29,53 +38,60 @@ namespace {
 
 using namespace cs16;
 
+#ifndef PW_ABLATE
+#define PW_ABLATE 0   // debug builds, timing only (results are wrong): 1 = no epilogue work, 2 = no stream DMAs,
+                      // 4 = no sched_barrier pinning, 8 = no A split (load_a skipped), 16 = no MFMAs
+#endif
+
 constexpr int BM = 128;                         // rows of a group's tile
 constexpr int BN = 224;                         // columns (7 MFMA blocks of 32)
 constexpr int WNB = 7;
-constexpr int A_BYTES = BM * 64;                // raw fp32 [BM][16]
-constexpr int B_BYTES = 2 * BN * 16;            // one fp16 image [2 k-groups][BN][8]
-constexpr int STAGE = A_BYTES + 2 * B_BYTES;    // 22528
-constexpr int NSTAGE = 3;
-constexpr int RING = NSTAGE * STAGE;            // 67584 per group
-constexpr int DUMP = 2 * RING;                  // surplus DMA wave-instructions land here
-constexpr int VECS = DUMP + 1024;               // per group: bias[224] then rowvec[224] of the tile in its epilogue
-constexpr int VEC_BYTES = 2 * 1024;
-constexpr int LDS_BYTES = VECS + 2 * VEC_BYTES; // 140288 of the CU's 163840
+constexpr int A_BYTES = BM * 64;                // raw fp32 [BM][16]                       8192
+constexpr int B_BYTES = 2 * BN * 16;            // one fp16 image [2 k-groups][BN][8]      7168
+constexpr int NA = 6, NB = 3;                   // ring depths
+constexpr int DA = NA - 1, DB = NB - 1;         // prefetch distances (chunks)
+constexpr int A_RING = 0;
+constexpr int B_RING = A_RING + NA * A_BYTES;                 // 49152
+constexpr int EP_STAGE = B_RING + NB * 2 * B_BYTES;           // 92160: per wave 4 rows x 224 floats (3584 B) x 8 waves
+constexpr int EP_BYTES = 4 * BN * 4;
+constexpr int RES_STAGE = EP_STAGE + 8 * EP_BYTES;            // 120832: per wave 4 KB of residual rows x 8 waves
+constexpr int VECS = RES_STAGE + 8 * 4096;                    // 153600: per group bias[256] | rowvec[256]
+constexpr int DUMP = VECS + 2 * 2048;                         // 157696: surplus DMA wave-instructions land here
+constexpr int LDS_BYTES = DUMP + 1024;                        // 158720 of the CU's 163840
 constexpr int B_WI = BN / 32;                   // 7 wave-instructions per B image
 constexpr int A_PW = 2;                         // A wave-instructions per wave per chunk (8 over 4 waves)
 constexpr int B_PW = 4;                         // hi + lo: 14 over 4 waves, 2 surplus
-constexpr int D = A_PW + B_PW;                  // DMA instructions per wave per chunk
-constexpr int EP_ROWS = 4;                      // rows a wave stages per epilogue pass (2 accumulator registers x 2 halves)
-constexpr int EP_BYTES = EP_ROWS * BN * 4;      // 3584 per wave, in the idle third ring stage
-constexpr int NPASS = 8;
-constexpr int MIN_NK = 28;                      // 8 passes x 3 slots + 4 slots of prefetch / hand-over
+constexpr int D = A_PW + B_PW;                  // DMA instructions per wave per slot
+constexpr int NPASS = 8;                        // epilogue passes per tile (2 accumulator registers x 7 blocks each)
+constexpr int MIN_NK = 28;                      // 2 hand-over slots + 8 passes x 3 slots + 2
 
 template <bool GEGLU>
 __global__ __launch_bounds__(512, 2) void pw_gemm_f16x3_kernel(const CsConvGemm p, int M, int tiles_n, int T, int nk,
-                                                              long long x_bytes, unsigned w_bytes, int iters,
-                                                              int rv_shift, long long res_bytes) {
+                                                              long long x_bytes, unsigned w_bytes, int rv_shift,
+                                                              long long res_bytes) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int group = wave >> 2;                  // 0 / 1: the two tile owners
+  const int group = wave >> 2;                  // 0 / 1: owners of the even / odd tiles of this workgroup
   const int wig = wave & 3;                     // wave in group: rows 32*wig .. 32*wig+31 of the tile
   const int l31 = lane & 31;
   const int half = lane >> 5;
   const int wm0 = wig * 32;
-  unsigned char* const ring = smem + group * RING;
 
   // block -> slot in the tile sequence: block b runs on XCD b % 8; give every XCD a contiguous run of tiles so the
   // n-tiles that share a 128-row A slab (and neighbouring slabs) meet in one L2
   const int G = gridDim.x;
   const int wq = (G & 7) == 0 ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int J = wq < T ? (T - wq + G - 1) / G : 0;       // tiles of this workgroup: wq, wq + G, ...
+  if (J == 0) return;
 
   const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, w_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_lo, 0, w_bytes, 0x00020000);
 
   // ---- per-lane DMA constants (tile independent) ----
-  // A wave-instruction v (0..7) of the group covers rows 16v .. 16v+15: row = 16v + lane/4, LDS slot q = lane&3
-  // holds global 16-byte piece q ^ ((row>>2)&3)
+  // A wave-instruction v (0..7) covers rows 16v .. 16v+15: row = 16v + lane/4, LDS slot q = lane&3 holds global
+  // 16-byte piece q ^ ((row>>2)&3)
   unsigned a_rowoff[A_PW];
   unsigned a_piece[A_PW];
 #pragma unroll
@@ -97,126 +113,100 @@ __global__ __launch_bounds__(512, 2) void pw_gemm_f16x3_kernel(const CsConvGemm 
   const float a_scale = p.a_scale;
   float amax = 0.f;
 
-  // the tile this group computes next / is computing (k*) and the one whose accumulators it holds (e*)
-  int m0k = 0, n0k = 0, m0e = 0, n0e = 0;
-  bool validk = false, valide = false;
-  __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, 0, 0x00020000);
-  auto setup_tile = [&](int t) {
-    validk = t < T;
-    const int tt = validk ? t : 0;
-    const int tn = tt % tiles_n;
-    m0k = (tt / tiles_n) * BM;
-    n0k = tn * BN;
+  // ---- the chunk stream: two cursors (next A chunk / next B chunk to fetch), kept in step by BOTH groups ----
+  auto tile_m0 = [&](int j) { return ((j * G + wq) / tiles_n) * BM; };
+  auto tile_n0 = [&](int j) { return ((j * G + wq) % tiles_n) * BN; };
+  int aj = 0, akc = 0, bj = 0, bkc = 0;         // tile (index into this workgroup's sequence) and chunk of each cursor
+  int sa_w = 0, sb_w = 0;                       // ring stages the cursors write next
+  __amdgpu_buffer_rsrc_t xrs;
+  int bn0 = 0;
+  auto set_a_tile = [&]() {
     // descriptor window based at the tile's first row: 32-bit offsets inside 128 rows, tensors of any size
-    const long long skip = (long long)m0k * p.lda * 4;
+    const long long skip = aj < J ? (long long)tile_m0(aj) * p.lda * 4 : x_bytes;
     const long long left = x_bytes - skip;
     const unsigned win = left > 0xFFE00000LL ? 0xFFE00000u : (left > 0 ? (unsigned)left : 0u);
-    xrs = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.x + skip), 0, win, 0x00020000);
+    xrs = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.x + (left > 0 ? skip : 0)), 0, win, 0x00020000);
   };
-  auto issue_dma = [&](int cc, int stage) {
-    unsigned char* st = ring + stage * STAGE;
-    const bool live = cc < nk;
+  auto set_b_tile = [&]() { bn0 = bj < J ? tile_n0(bj) : 0; };
+  set_a_tile();
+  set_b_tile();
+  auto issue_a = [&](bool doit) {               // fetch the A cursor's chunk into stage sa_w, then advance
+    if (doit) {
+      unsigned char* st = smem + A_RING + sa_w * A_BYTES;
 #pragma unroll
-    for (int i = 0; i < A_PW; ++i) {
-      const int c = cc * BKH + (int)a_piece[i];
-      const unsigned off = (live && c < p.cin) ? a_rowoff[i] + (unsigned)c * 4u : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, st + (wig * A_PW + i) * 1024, 16, off, 0, 0, 0);
+      for (int i = 0; i < A_PW; ++i) {
+        const int c = akc * BKH + (int)a_piece[i];
+        const unsigned off = (aj < J && c < p.cin) ? a_rowoff[i] + (unsigned)c * 4u : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, st + (wig * A_PW + i) * 1024, 16, off, 0, 0, 0);
+      }
     }
-    const unsigned kbase = (unsigned)(cc * 2 * p.cout + n0k) * 16u;
+    sa_w = sa_w + 1 == NA ? 0 : sa_w + 1;
+    if (++akc == nk) {
+      akc = 0;
+      ++aj;
+      set_a_tile();
+    }
+  };
+  auto issue_b = [&](bool doit) {
+    if (doit) {
+      unsigned char* st = smem + B_RING + sb_w * 2 * B_BYTES;
+      const unsigned kbase = (unsigned)(bkc * 2 * p.cout + bn0) * 16u;
 #pragma unroll
-    for (int i = 0; i < B_PW; ++i) {
-      const int v = wig * B_PW + i;                // wave-uniform
-      const int img = v / B_WI;
-      const unsigned off = (b_rel[i] == OOB || !live) ? OOB : b_rel[i] + kbase;
-      unsigned char* dst = v < 2 * B_WI ? st + A_BYTES + img * B_BYTES + (v - img * B_WI) * 1024 : smem + DUMP;
-      if (img == 1)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(lrs, dst, 16, off, 0, 0, 0);
-      else
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(hrs, dst, 16, off, 0, 0, 0);
+      for (int i = 0; i < B_PW; ++i) {
+        const int v = wig * B_PW + i;                // wave-uniform
+        const int img = v / B_WI;
+        const unsigned off = (b_rel[i] == OOB || bj >= J) ? OOB : b_rel[i] + kbase;
+        unsigned char* dst = v < 2 * B_WI ? st + img * B_BYTES + (v - img * B_WI) * 1024 : smem + DUMP;
+        if (img == 1)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(lrs, dst, 16, off, 0, 0, 0);
+        else
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(hrs, dst, 16, off, 0, 0, 0);
+      }
+    }
+    sb_w = sb_w + 1 == NB ? 0 : sb_w + 1;
+    if (++bkc == nk) {
+      bkc = 0;
+      ++bj;
+      set_b_tile();
     }
   };
 
-  // fragment addressing (same maps as conv_gemm_f16x3_kernel)
+  // fragment addressing (same maps as conv_gemm_f16x3_kernel); ring stage added per slot
   int a_frag[2];
   {
     const int row = wm0 + l31;
     const int s = (row >> 2) & 3;
-    a_frag[0] = row * 64 + (((2 * half) ^ s) * 16);
-    a_frag[1] = row * 64 + (((2 * half + 1) ^ s) * 16);
+    a_frag[0] = A_RING + row * 64 + (((2 * half) ^ s) * 16);
+    a_frag[1] = A_RING + row * 64 + (((2 * half + 1) ^ s) * 16);
   }
-  const int b_frag = A_BYTES + (half * BN + l31) * 16;
-  auto load_a = [&](int st, h8& hi, h8& lo) {
-    const unsigned char* s = ring + st * STAGE;
-    const f32x4 x0 = *reinterpret_cast<const f32x4*>(s + a_frag[0]);
-    const f32x4 x1 = *reinterpret_cast<const f32x4*>(s + a_frag[1]);
+  const int b_frag = B_RING + (half * BN + l31) * 16;
+  int sa_r = 0, sb_r = 0;                       // ring stages of the chunk consumed in the current slot
+  auto load_a = [&](int stage, h8& hi, h8& lo) {
+    const f32x4 x0 = *reinterpret_cast<const f32x4*>(smem + a_frag[0] + stage * A_BYTES);
+    const f32x4 x1 = *reinterpret_cast<const f32x4*>(smem + a_frag[1] + stage * A_BYTES);
     split8(x0, x1, a_scale, hi, lo, amax);
   };
 
   f32x16 acc[WNB];
   h8 ah, al;
-  int dcc = 0;
-  auto step = [&](auto stage_c) {
-    constexpr int stage = decltype(stage_c)::value;
-    constexpr int nstage = (stage + 1) % NSTAGE;
-    constexpr int dstage = (stage + 2) % NSTAGE;
-    wait_vmcnt<B_PW>();                            // everything up to A(k+1) has landed for this wave
-    __builtin_amdgcn_s_barrier();                  // ... and for every wave; the other group's slot boundary too
-    const unsigned char* s = ring + stage * STAGE;
-    h8 ah2, al2;
-    // this wave is alone on its SIMD's matrix pipe (its partner is in the epilogue): fetch column block j+1's B
-    // fragments before block j's MFMAs, so each LDS read has three MFMAs (96 cycles) of cover instead of one
-    h8 bh = *reinterpret_cast<const h8*>(s + b_frag);
-    h8 bl = *reinterpret_cast<const h8*>(s + b_frag + B_BYTES);
-#pragma unroll
-    for (int j = 0; j < WNB; ++j) {
-      h8 bhn = bh, bln = bl;
-      if (j + 1 < WNB) {
-        bhn = *reinterpret_cast<const h8*>(s + b_frag + (j + 1) * 512);
-        bln = *reinterpret_cast<const h8*>(s + b_frag + B_BYTES + (j + 1) * 512);
-      }
-      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[j], 0, 0, 0);
-      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[j], 0, 0, 0);
-      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[j], 0, 0, 0);
-      if (j == 0) {
-        issue_dma(dcc, dstage);
-        ++dcc;
-        load_a(nstage, ah2, al2);
-      }
-      bh = bhn;
-      bl = bln;
-    }
-    ah = ah2;
-    al = al2;
-  };
 
   // ---- epilogue pieces (the group that is NOT computing) ----
   constexpr int UPR = GEGLU ? BN / 8 : BN / 4;                   // float4 units per staged row: 28 / 56
-  constexpr int UNITS = EP_ROWS * UPR;                           // 112 / 224
+  constexpr int UNITS = 4 * UPR;                                 // 112 / 224
   constexpr int UPL = (UNITS + 63) / 64;                         // units per lane: 2 / 4
-  // The tile's bias row and (to_out GEMMs) its row-vector row -- a 128-row tile lies inside one sample, the host
-  // checks rv_rows % 128 == 0 -- are DMA'd into LDS at the first epilogue slot: no registers held, no load latency
-  // in a later slot.  Residual rows are DMA'd `stride` slots ahead into ring stage 0 (idle until the prefetch of the
-  // next tile at slot nk-3): one 4 KB slab per wave, unit u (16 bytes) of a pass at slab + 16 u.
-  float* const ep = reinterpret_cast<float*>(ring + 2 * STAGE + wig * EP_BYTES);
-  float* const ep_res = reinterpret_cast<float*>(ring + wig * 4096);
-  __amdgpu_buffer_rsrc_t rrs_res = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, 0, 0x00020000);
-  auto setup_res = [&]() {
-    if (!GEGLU && p.res) {
-      const long long skip = (long long)m0e * p.ldr * 4;
-      const long long left = res_bytes - skip;
-      const unsigned win = left > 0xFFE00000LL ? 0xFFE00000u : (left > 0 ? (unsigned)left : 0u);
-      rrs_res = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.res + skip), 0, win, 0x00020000);
-    }
-  };
-  float* const vec_bias = reinterpret_cast<float*>(smem + VECS + group * VEC_BYTES);
+  float* const ep = reinterpret_cast<float*>(smem + EP_STAGE + wave * EP_BYTES);
+  float* const ep_res = reinterpret_cast<float*>(smem + RES_STAGE + wave * 4096);
+  float* const vec_bias = reinterpret_cast<float*>(smem + VECS + group * 2048);
   float* const vec_rv = vec_bias + 256;
   float* const outp = p.out;
   const __amdgpu_buffer_rsrc_t brs =
       __builtin_amdgcn_make_buffer_rsrc((void*)(p.bias ? p.bias : p.out), 0, p.bias ? (unsigned)p.cout * 4u : 0u, 0x00020000);
+  __amdgpu_buffer_rsrc_t rrs_res = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, 0, 0x00020000);
+  int m0e = 0, n0e = 0;
   auto unit_row = [&](int q, int lrow) { return wm0 + 2 * (q & 1) + 8 * (q >> 1) + (lrow & 1) + 4 * (lrow >> 1); };
   auto epi_vectors = [&]() {
-    // wave `wig` fetches floats 64*wig .. 64*wig+63 of the tile's 224 columns (4 bytes per lane); columns past cout
-    // (the last wave's upper half) are outside the descriptor and read as zero
+    // The tile's bias row and (to_out GEMMs) its row-vector row -- a 128-row tile lies inside one sample, the host checks
+    // rv_rows % 128 == 0 -- by LDS-DMA: wave `wig` fetches floats 64 wig .. 64 wig + 63 of the 224 columns
     const unsigned col = (unsigned)(64 * wig + lane);
     const unsigned off = col < (unsigned)BN ? (unsigned)(n0e + (int)col) * 4u : OOB;
     if (p.bias) __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, vec_bias + 64 * wig, 4, off, 0, 0, 0);
@@ -227,9 +217,15 @@ __global__ __launch_bounds__(512, 2) void pw_gemm_f16x3_kernel(const CsConvGemm 
             (void*)(p.rowvec + (int64_t)rvr * p.ldrv), 0, (unsigned)p.cout * 4u, 0x00020000);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rrs, vec_rv + 64 * wig, 4, off, 0, 0, 0);
       }
+      if (p.res) {
+        const long long skip = (long long)m0e * p.ldr * 4;
+        const long long left = res_bytes - skip;
+        const unsigned win = left > 0xFFE00000LL ? 0xFFE00000u : (left > 0 ? (unsigned)left : 0u);
+        rrs_res = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.res + skip), 0, win, 0x00020000);
+      }
     }
   };
-  auto epi_issue = [&](int q) {
+  auto epi_issue = [&](int q) {                  // pass q's residual rows -> this wave's LDS slab (unit u at 16 u)
     if constexpr (!GEGLU) {
       if (p.res) {
 #pragma unroll
@@ -253,7 +249,7 @@ __global__ __launch_bounds__(512, 2) void pw_gemm_f16x3_kernel(const CsConvGemm 
 #pragma unroll
       for (int rr = 0; rr < 2; ++rr) ep[(rr + 2 * half) * BN + 32 * j + l31] = acc[j][2 * q + rr] * p.acc_scale;
   };
-  auto epi_finish_rt = [&](int q) {
+  auto epi_finish = [&](int q) {
     if (!GEGLU && p.res) wait_vmcnt<0>();          // this pass's residual rows (issued `stride` slots ago) are in LDS
     switch (q) {
       case 0: epi_stage(std::integral_constant<int, 0>{}); break;
@@ -301,76 +297,97 @@ __global__ __launch_bounds__(512, 2) void pw_gemm_f16x3_kernel(const CsConvGemm 
     }
   };
 
-  // ---- schedule ----
-  const int stride = max(3, (nk - 4) / NPASS);     // slots between an epilogue pass's loads and its stores
-  const int P = 2 * iters + 1;                     // phases; group g computes in the phases with (phase & 1) == g
-  if (group == 0) {
-    setup_tile(wq);
-    if (validk) {
-      issue_dma(0, 0);
-      issue_dma(1, 1);
-    }
-    wait_vmcnt<D>();
-  }
+  // ---- prologue: the stream's head (A chunks 0..4, B chunks 0..1), fetched by group 0, the first to compute ----
+#pragma unroll 1
+  for (int i = 0; i < DA; ++i) issue_a(group == 0);
+#pragma unroll 1
+  for (int i = 0; i < DB; ++i) issue_b(group == 0);
+  if (group == 0) wait_vmcnt<B_PW>();             // everything but B(1) has landed: A(0..4), B(0)
   __builtin_amdgcn_s_barrier();
-  if (group == 0 && validk) load_a(0, ah, al);
+  if (group == 0) load_a(0, ah, al);
 
-  for (int ph = 0; ph < P; ++ph) {
-    if ((ph & 1) == group) {
+  // ---- phases: in phase ph the owner of tile ph computes it, the other group finishes tile ph - 1 ----
+  const int stride = max(3, (nk - 4) / NPASS);     // slots between an epilogue pass's loads and its stores
+  for (int ph = 0; ph <= J; ++ph) {
+    if ((ph & 1) == group && ph < J) {
       // ------------------------------------------------ K phase ------------------------------------------------
-      if (validk) {
 #pragma unroll
-        for (int j = 0; j < WNB; ++j)
+      for (int j = 0; j < WNB; ++j)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-        dcc = 2;
-        for (int kc = 0; kc < nk; kc += NSTAGE) {
-          step(std::integral_constant<int, 0>{});
-          if (kc + 1 < nk) step(std::integral_constant<int, 1>{});
-          if (kc + 2 < nk) step(std::integral_constant<int, 2>{});
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll 1
+      for (int s = 0; s < nk; ++s) {
+        // Of this wave's stream fetches only the newest slot's may still fly: B(c) (fetched two slots ago) and
+        // A(c+1) (four slots ago) have landed.  During the first two slots of a phase they are the OTHER group's
+        // fetches: it waits for them in its own slots 0 and 1 (below).
+        wait_vmcnt<D>();
+        __builtin_amdgcn_s_barrier();
+        const unsigned char* sb = smem + sb_r * 2 * B_BYTES;
+        const int sa_n = sa_r + 1 == NA ? 0 : sa_r + 1;
+        h8 ah2, al2;
+        // this wave is alone on its SIMD's matrix pipe (its partner is in the epilogue): fetch column block j+1's B
+        // fragments before block j's MFMAs, so each LDS read has three MFMAs (96 cycles) of cover
+        h8 bh = *reinterpret_cast<const h8*>(sb + b_frag);
+        h8 bl = *reinterpret_cast<const h8*>(sb + b_frag + B_BYTES);
+#pragma unroll
+        for (int j = 0; j < WNB; ++j) {
+          h8 bhn = bh, bln = bl;
+          if (j + 1 < WNB) {
+            bhn = *reinterpret_cast<const h8*>(sb + b_frag + (j + 1) * 512);
+            bln = *reinterpret_cast<const h8*>(sb + b_frag + B_BYTES + (j + 1) * 512);
+          }
+          if (!(PW_ABLATE & 4)) __builtin_amdgcn_sched_barrier(0);       // keep the prefetch above the MFMAs it covers
+          if (!(PW_ABLATE & 16)) {
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[j], 0, 0, 0);
+          } else { acc[j][0] += (float)bh[0] + (float)bl[0]; }
+          if (j == 0) {
+            issue_a(!(PW_ABLATE & 2));               // chunk c + 5 (the stage chunk c - 1's fragments left two slots ago)
+            issue_b(!(PW_ABLATE & 2));               // chunk c + 2 (the stage chunk c - 1 left at this slot's barrier)
+            if (!(PW_ABLATE & 8)) load_a(sa_n, ah2, al2); else { ah2 = ah; al2 = al; }   // chunk c + 1's fragments
+          }
+          bh = bhn;
+          bl = bln;
         }
-      } else {
-        for (int s = 0; s < nk; ++s) __builtin_amdgcn_s_barrier();
+        ah = ah2;
+        al = al2;
+        sa_r = sa_n;
+        sb_r = sb_r + 1 == NB ? 0 : sb_r + 1;
       }
-      m0e = m0k;
-      n0e = n0k;
-      valide = validk;
+      m0e = tile_m0(ph);
+      n0e = tile_n0(ph);
     } else {
       // ------------------------------------------------ E phase ------------------------------------------------
-      // drain the two zero-fill prefetches the K loop issued past its end (they target ring stages the staging
-      // below shares with the other waves of this group): wait here, the slot-0 barrier publishes it
-      if (valide) wait_vmcnt<0>();
-      const bool more = ph + 1 < P;
-      int next_issue = 0, next_finish = stride, qi = 0, qf = 0;
+      const bool valide = (ph & 1) != group && ph >= 1;     // this group computed tile ph - 1 in the last phase
+      const bool next_mine = (ph & 1) != group && ph + 1 < J;   // ... and computes tile ph + 1 in the next one
+      int next_issue = 2, next_finish = 2 + stride, qi = 0, qf = 0;
+#pragma unroll 1
       for (int s = 0; s < nk; ++s) {
-        if (s == nk - 1) wait_vmcnt<D>();          // chunk 0 of the next tile has landed for this wave
+        // hand-over: the last stream fetches this group issued (as the computing group of the previous phase) feed the
+        // other group's first slots: B(c0) at its slot 0; B(c0+1), A(c0+2..4) at its slot 1
+        if (s == 0) wait_vmcnt<D>();
+        if (s == 1) wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
-        if (valide) {
-          if (s == 0) {
-            epi_vectors();                         // lands long before the first finish, `stride` (>= 3) slots on
-            setup_res();
-          }
+        issue_a(false);                              // keep the cursors and ring positions in step with the stream
+        issue_b(false);
+        sa_r = sa_r + 1 == NA ? 0 : sa_r + 1;
+        sb_r = sb_r + 1 == NB ? 0 : sb_r + 1;
+        if (valide && !(PW_ABLATE & 1)) {
           if (s == next_finish && qf < NPASS) {
-            epi_finish_rt(qf);
+            epi_finish(qf);
             ++qf;
             next_finish += stride;
           }
           if (s == next_issue && qi < NPASS) {
+            if (qi == 0) epi_vectors();              // bias / row-vector rows land long before the first finish
             epi_issue(qi);
             ++qi;
             next_issue += stride;
           }
         }
-        if (s == nk - 3) {
-          setup_tile(more ? (2 * ((ph + 1) >> 1) + group) * G + wq : T);
-          if (validk) issue_dma(0, 0);
-        } else if (s == nk - 2) {
-          if (validk) issue_dma(1, 1);
-        } else if (s == nk - 1) {
-          if (validk) load_a(0, ah, al);
-        }
+        if (s == nk - 1 && next_mine) load_a(sa_r, ah, al);   // first chunk of my next tile (landed: A(c+1) rule)
       }
-      valide = false;
     }
   }
   wait_vmcnt<0>();
@@ -379,16 +396,15 @@ __global__ __launch_bounds__(512, 2) void pw_gemm_f16x3_kernel(const CsConvGemm 
 
 }  // namespace
 
-// Does cs_conv_gemm's auto-selection (tile 0) take the ping-pong kernel?  Only where it measured faster than the
-// one-tile-per-workgroup kernels on the MI355X (tools/gemm_1tap.py, profiles/r02_pingpong_1tap.txt): short K loops
-// (K <= 672) with a plain epilogue and enough tiles for two full rounds -- the C x C token GEMMs and the level-0
-// skip projections.  Long-K shapes are latency-bound on the activation stream (two chunks in flight per group are
-// too few) and stay on the 256x224 tile.  Mirrors commonscenes_amd/ops.py::tile_for.
-bool cs_pw_gemm_f16x3_preferred(const CsConvGemm& p, int64_t M) {
-  const int nk = (p.cin + 15) / 16;
-  const int64_t T = ((M + BM - 1) / BM) * (p.cout / BN);
-  return nk <= 42 && T >= 1024 && p.cout <= 448 && p.act != CS_ACT_GEGLU;
-}
+// Does cs_conv_gemm's auto-selection (tile 0) take the ping-pong kernel?  No: measured on the MI355X
+// (tools/gemm_1tap.py, tools/pw_ablate.sh; profiles/r02_pingpong_*.txt) it loses to the 256x224 tile once that tile's
+// epilogue prefetches its residual rows (cs_gemm_f16x3.hip "pipelined residual epilogue").  What the ablations showed:
+// the 128-row tiles double the weight-operand LDS-DMA traffic per flop (the chunk stream alone -- no MFMA, no
+// epilogue -- takes 131-218 us on shapes the tile kernel finishes in 340-380 us), one wave per SIMD keeps the matrix
+// pipe ~55 % busy even with no DMA at all, and the two do not overlap well enough to pay for the hidden epilogue.
+// The real loss of the tile kernels was not the epilogue's traffic but its 28 serialized residual-load latencies.
+// The kernel stays available as tile = 5 (bit-identical, tested) for further work on it.
+bool cs_pw_gemm_f16x3_preferred(const CsConvGemm&, int64_t) { return false; }
 
 // Can the ping-pong kernel run this (validated) descriptor at all (explicit tile = 5)?
 bool cs_pw_gemm_f16x3_applicable(const CsConvGemm& p, int64_t M) {
@@ -419,7 +435,6 @@ int cs_pw_gemm_f16x3_launch(const CsConvGemm& p_in, int M, hipStream_t s) {
   if (T > 0x3fffffffLL) return CS_EINVAL;
   int G = 256;
   if (T < 2 * G) G = (int)((T + 1) / 2);           // every group gets a tile
-  const int iters = (int)((T + 2 * G - 1) / (2 * G));
   const int nk = (p.cin + 15) / 16;
   const int kg_per_tap = nk * 2;
   const int64_t x_bytes = ((int64_t)(M - 1) * p.lda + p.cin) * 4;
@@ -434,10 +449,10 @@ int cs_pw_gemm_f16x3_launch(const CsConvGemm& p_in, int M, hipStream_t s) {
   if (p.res && (int64_t)BM * p.ldr * 4 > 0x7FF00000LL) return CS_EINVAL;
   if (p.act == CS_ACT_GEGLU)
     CS_LAUNCH(pw_gemm_f16x3_kernel<true>, dim3(G), dim3(512), 0, s, p, M, tiles_n, (int)T, nk, (long long)x_bytes,
-              (unsigned)w_bytes, iters, rv_shift, (long long)res_bytes);
+              (unsigned)w_bytes, rv_shift, (long long)res_bytes);
   else
     CS_LAUNCH(pw_gemm_f16x3_kernel<false>, dim3(G), dim3(512), 0, s, p, M, tiles_n, (int)T, nk, (long long)x_bytes,
-              (unsigned)w_bytes, iters, rv_shift, (long long)res_bytes);
+              (unsigned)w_bytes, rv_shift, (long long)res_bytes);
   CS_CHECK_LAUNCH();
   return CS_OK;
 }

@@ -342,9 +342,7 @@ def tile_for(m: int, cout: int, tile: int = 0, math: int = L.MATH_FP32, cin: int
     """mirror of the tile auto-selection in cs_conv_gemm (csrc/cs_gemm.hip)."""
     if tile:
         return tile
-    if (not PINGPONG_OFF and _pingpong_ok(m, cin, cout, math, pointwise, bn, rv_rows) and (cin + 15) // 16 <= 42
-            and ((m + 127) // 128) * (cout // 224) >= 1024 and cout <= 448 and act != L.ACT_GEGLU):
-        return 5            # cs_pw_gemm_f16x3_preferred: where the ping-pong kernel measured faster
+    # tile 5 (the persistent ping-pong kernel) is never auto-selected: cs_pw_gemm_f16x3_preferred() is false
     mt = (m + 127) // 128
     if math == L.MATH_F16X3 and cout % 224 == 0 and ((m + 255) // 256) * (cout // 224) >= 192:
         return 4
