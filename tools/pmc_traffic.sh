@@ -8,7 +8,7 @@ REPO=$(pwd); D=$REPO/gpurun_out/pmc_traffic; mkdir -p "$D"
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$D/$c" -o p -- \
-    python "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$D/$c.log" 2>&1 || echo "pass $c failed"
+    python "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-extras > "$D/$c.log" 2>&1 || echo "pass $c failed"
 done
 cd "$REPO"
 python - "$D" "$OUT" "$KSUB" <<'PY'
