@@ -391,11 +391,17 @@ class Sg2ScVAEModel(BoxVAEMixin):
             if tuple(sd[k].shape) != tuple(shp):
                 raise RuntimeError(f"size mismatch for {k}: {tuple(sd[k].shape)} vs {shp}")
             self._sd[k] = sd[k].detach().to(device=self.device, dtype=torch.float32).contiguous()
+        # entries this implementation does not read (BatchNorm num_batches_tracked counters, training-only nets of other
+        # builds, ...) are kept as they came so that state_dict() round-trips a reference checkpoint and the reference's
+        # strict load_state_dict accepts what save() wrote
+        self._extra_sd = OrderedDict((k, v) for k, v in sd.items() if k not in self.shapes and torch.is_tensor(v))
         self._nets = None
         return self
 
     def state_dict(self):
-        return OrderedDict(self._sd)
+        out = OrderedDict(self._sd)
+        out.update(getattr(self, "_extra_sd", {}))
+        return out
 
     def eval(self):
         return self

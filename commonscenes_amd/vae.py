@@ -73,10 +73,12 @@ class VAE:
     def save(self, exp, outf, epoch, counter=None):
         if self.type_ == "v2_box":
             torch.save(self.vae_box.state_dict(), os.path.join(exp, outf, "model_box_{}.pth".format(epoch)))
-        else:                                       # VAEGAN_V2FULL.py:687-699 layout, without the optimiser entry
+        else:                                       # VAEGAN_V2FULL.py:687-699 layout
             sd = dict(self.vae_v2.state_dict())
             sd.update(self.vae_v2.Diff.state_dict())
-            sd.update(epoch=epoch, counter=counter)
+            # the reference's load_networks pops 'opt' unconditionally (model/VAE.py:118): an inference-only build has no
+            # optimiser state, so the entry is an empty placeholder
+            sd.update(opt={}, epoch=epoch, counter=counter)
             torch.save(sd, os.path.join(exp, outf, "model{}.pth".format(epoch)))
 
     def compute_statistics(self, exp, epoch, stats_dataloader, force=False):

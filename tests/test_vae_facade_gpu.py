@@ -104,6 +104,14 @@ def test_v2_full_facade_checkpoint_and_sample(tmp_path):
     # save() writes the same layout back
     m.save(str(tmp_path), "checkpoint", 13, counter=1)
     back = torch.load(tmp_path / "checkpoint" / "model13.pth", map_location="cpu")
-    assert "df" in back and "vqvae" in back and back["epoch"] == 13
+    assert "df" in back and "vqvae" in back and back["epoch"] == 13 and back["opt"] == {}
+    # entries this build does not read survive the round trip (the reference's strict load needs them)
+    ck2 = dict(ck)
+    ck2["gconv_net_ec_rel.gconvs.0.net1.1.num_batches_tracked"] = torch.tensor(7)
+    torch.save(ck2, tmp_path / "checkpoint" / "model14.pth")
+    m.load_networks(str(tmp_path), 14)
+    m.save(str(tmp_path), "checkpoint", 15, counter=2)
+    back2 = torch.load(tmp_path / "checkpoint" / "model15.pth", map_location="cpu")
+    assert int(back2["gconv_net_ec_rel.gconvs.0.net1.1.num_batches_tracked"]) == 7
     k = "gconv_net_ec_rel.gconvs.0.net1.0.weight"
     assert rel_l2(back[k], ck[k]) == 0.0
