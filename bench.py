@@ -43,7 +43,8 @@ import torch.distributed as dist  # noqa: E402
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X dense fp32-input MFMA peak (MI355X_MICROARCH.md)
 F16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
 TILE_NAMES = {1: "<2,2,2,2,false> (128x128", 2: "<1,7,4,1,false> (128x224", 3: "<1,1,2,2,false> (64x64",
-              4: "<1,7,8,1,false> (256x224", 5: "persistent 256x224"}
+              4: "<1,7,8,1,false> (256x224", 5: "persistent ping-pong 2x128x224", 6: "<1,4,8,1,false> (256x128",
+              7: "<1,2,8,1,false> (256x64"}
 
 
 def parse():

@@ -336,6 +336,12 @@ extern "C" int cs_conv_gemm(const CsConvGemm* d, cs_stream_t stream) {
     // over 128x224) and wins as soon as it still occupies ~3/4 of the CUs
     if (f16x3 && p.cout % 224 == 0 && ((M + 255) / 256) * (int64_t)(p.cout / 224) >= 192)
       tile = 4;
+    // the VQ-VAE decoder's channel counts (64 / 128 / 256) are not multiples of 224: 256-row tiles with 128 or 64
+    // columns move a quarter to a third fewer LDS-DMA bytes per flop than the 128x128 / 64x64 tiles
+    else if (f16x3 && p.cout % 128 == 0 && ((M + 255) / 256) * (int64_t)(p.cout / 128) >= 192)
+      tile = 6;
+    else if (f16x3 && p.cout == 64 && (M + 255) / 256 >= 192)
+      tile = 7;
     else if (p.cout % 224 == 0 && mt * (p.cout / 224) >= 256)
       tile = 2;
     else if (p.cout > 64 && mt * ((p.cout + 127) / 128) >= 256)
@@ -373,7 +379,9 @@ extern "C" int cs_conv_gemm(const CsConvGemm* d, cs_stream_t stream) {
     case 1: return launch<2, 2, 2, 2>(p, M, s);
     case 2: return launch<1, 7, 4, 1>(p, M, s);
     case 3: return launch<1, 1, 2, 2>(p, M, s);
-    case 4: return launch<1, 7, 4, 1>(p, M, s);   // the 256-row tile exists for F16X3 only; same N tiling here
+    case 4: return launch<1, 7, 4, 1>(p, M, s);   // the 256-row tiles exist for F16X3 only; same N tiling here
+    case 6: return launch<2, 2, 2, 2>(p, M, s);
+    case 7: return launch<1, 1, 2, 2>(p, M, s);
     default: return CS_EINVAL;
   }
 }

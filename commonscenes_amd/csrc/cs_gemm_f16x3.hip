@@ -647,6 +647,8 @@ int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p_in, int M, int tile, int spl
       case 2: return launch16<1, 7, 4, 1, true>(p, M, splits, s);
       case 3: return launch16<1, 1, 2, 2, true>(p, M, splits, s);
       case 4: return launch16<1, 7, 8, 1, true>(p, M, splits, s);
+      case 6: return launch16<1, 4, 8, 1, true>(p, M, splits, s);
+      case 7: return launch16<1, 2, 8, 1, true>(p, M, splits, s);
       default: return CS_EINVAL;
     }
   }
@@ -656,6 +658,8 @@ int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p_in, int M, int tile, int spl
     case 2: return launch16<1, 7, 4, 1, false>(p, M, splits, s);
     case 3: return launch16<1, 1, 2, 2, false>(p, M, splits, s);
     case 4: return launch16<1, 7, 8, 1, false>(p, M, splits, s);
+    case 6: return launch16<1, 4, 8, 1, false>(p, M, splits, s);     // 256x128: the VQ decoder's 128- / 256-channel convs
+    case 7: return launch16<1, 2, 8, 1, false>(p, M, splits, s);     // 256x64:  its 64-channel convs
     default: return CS_EINVAL;
   }
 }
