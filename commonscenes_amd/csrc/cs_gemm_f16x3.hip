@@ -363,13 +363,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   constexpr int EPI_ROWS = 2 * PASS_R;                                       // rows staged per wave per pass
   constexpr int EPI_BYTES = EPI_ROWS * WCOLS * 4;                            // per wave, per pass
   static_assert(NW * EPI_BYTES <= NSTAGE * STAGE, "epilogue staging must fit in the ring");
-  // ---- pipelined residual epilogue -------------------------------------------------------------------------------
-  // A tile with a residual used to read it with one dependent global load per float4 of output: 28 serialized HBM
-  // latencies per wave (~30 us per 256x224 tile, as long as a 448-channel GEMM's whole K loop; tools/pw_ablate.sh and
-  // the 448->448 vs 448->1344 rows of profiles/r02_c_gemm_table_before_pingpong.txt).  Here the residual rows of pass
-  // q+1 are LDS-DMA'd into a second slab while pass q is staged, combined and stored; the tile's bias row and (one
-  // sample per tile) row-vector row are DMA'd once.  Stores are buffer stores whose inactive lanes carry an
-  // out-of-range offset, so every pass issues exactly KU of them and the counted vmcnt below is exact.
+  // ---- pipelined epilogue ----------------------------------------------------------------------------------------
+  // The epilogue used to fetch its per-element operands with one dependent global load per float4 of output: for a
+  // tile with a residual, 28 serialized HBM latencies per wave (~30 us per 256x224 tile, as long as a 448-channel
+  // GEMM's whole K loop; the 448->448 vs 448->1344 rows of profiles/r02_c_gemm_table_before_pingpong.txt), and as many
+  // L2 latencies for the bias and the row vector.  Here the tile's bias row and (one sample per tile) row-vector row
+  // are LDS-DMA'd once, and the residual rows of pass q+1 are DMA'd into a second slab while pass q is staged,
+  // combined and stored.  Stores are buffer stores whose inactive lanes carry an out-of-range offset, so every pass
+  // issues exactly KU of them and the counted vmcnt below is exact.  The fused GEGLU gate takes the same route.
   {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     constexpr int QR = 2;                                    // accumulator registers per pass -> 4 rows per wave
@@ -384,9 +385,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
     constexpr int BNV = (BN + 63) / 64;                      // waves that fetch the bias / row-vector rows
     static_assert(VEC0 + 2048 <= LDS_BYTES && BN <= 256 && BNV <= NW, "pipelined epilogue must fit in the kernel's LDS");
     const int m_last = min(m0 + BM, M) - 1;
-    const bool piped = !(CS_ABLATE & 32) && vec_epilogue && p.res && !p.scale && p.act != CS_ACT_GEGLU && splits == 1 &&
+    const bool geglu = p.act == CS_ACT_GEGLU;
+    const bool has_res = p.res != nullptr;
+    const bool piped = !(CS_ABLATE & 32) && vec_epilogue && (p.res || p.bias || p.rowvec) && !p.scale && splits == 1 &&
                        n0 + BN <= p.cout && (!p.rowvec || (m0 / p.rv_rows == m_last / p.rv_rows)) &&
-                       (long long)BM * p.ldo * 4 < 0x7FF00000LL && (long long)BM * p.ldr * 4 < 0x7FF00000LL;
+                       (long long)BM * p.ldo * 4 < 0x7FF00000LL && (!p.res || (long long)BM * p.ldr * 4 < 0x7FF00000LL);
     if (piped) {
       __syncthreads();                                       // every wave has left the ring
       float* const ep = reinterpret_cast<float*>(smem + wave * EPB);
@@ -396,11 +399,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
       // per-tile descriptor windows (32-bit offsets inside BM rows)
       const long long o_skip = (long long)m0 * p.ldo * 4, r_skip = (long long)m0 * p.ldr * 4;
       const long long o_left = ((long long)(M - 1) * p.ldo + p.cout) * 4 - o_skip;
-      const long long r_left = ((long long)(M - 1) * p.ldr + p.cout) * 4 - r_skip;
+      const long long r_left = has_res ? ((long long)(M - 1) * p.ldr + p.cout) * 4 - r_skip : 0;
+      const long long o_cols = geglu ? p.cout / 2 : p.cout;
+      const long long o_left2 = ((long long)(M - 1) * p.ldo + o_cols) * 4 - o_skip;
+      (void)o_left;
       const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)((char*)p.out + o_skip), 0, o_left > 0x7FF00000LL ? 0x7FF00000u : (unsigned)o_left, 0x00020000);
+          (void*)((char*)p.out + o_skip), 0, o_left2 > 0x7FF00000LL ? 0x7FF00000u : (unsigned)o_left2, 0x00020000);
       const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)((const char*)p.res + r_skip), 0, r_left > 0x7FF00000LL ? 0x7FF00000u : (unsigned)r_left, 0x00020000);
+          (void*)(has_res ? (const char*)p.res + r_skip : (const char*)p.out), 0,
+          r_left > 0x7FF00000LL ? 0x7FF00000u : (r_left > 0 ? (unsigned)r_left : 0u), 0x00020000);
       if (wave < BNV) {                                      // bias / row-vector rows: 4 bytes per lane
         const unsigned col = (unsigned)(64 * wave + lane);
         const unsigned off = col < (unsigned)BN ? (unsigned)(n0 + (int)col) * 4u : OOB;
@@ -428,19 +435,51 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rrs, rs + (pass & 1) * (RSLAB / 4) + 256 * k, 16, off, 0, 0, 0);
         }
       };
-      fetch_res(0);
-      wait_vmcnt<KU>();                                      // the bias / row-vector rows (older) have landed ...
+      if (has_res) {
+        fetch_res(0);
+        wait_vmcnt<KU>();                                    // the bias / row-vector rows (older) have landed ...
+      } else {
+        wait_vmcnt<0>();
+      }
       __syncthreads();                                       // ... for every wave
       constexpr int NPASS = WMB * NQ;
       auto do_pass = [&](auto i_c, auto q_c) {
         constexpr int i = decltype(i_c)::value, q = decltype(q_c)::value, pass = i * NQ + q;
-        if constexpr (pass + 1 < NPASS) fetch_res(pass + 1);
-        // younger than this pass's residual fetch: the previous pass's KU stores and the KU fetches just issued
-        wait_vmcnt<(pass > 0 ? KU : 0) + (pass + 1 < NPASS ? KU : 0)>();
+        if (has_res) {
+          if constexpr (pass + 1 < NPASS) fetch_res(pass + 1);
+          // younger than this pass's residual fetch: the previous pass's KU stores and the KU fetches just issued
+          wait_vmcnt<(pass > 0 ? KU : 0) + (pass + 1 < NPASS ? KU : 0)>();
+        }
 #pragma unroll
         for (int j = 0; j < WNB; ++j)
 #pragma unroll
           for (int rr = 0; rr < QR; ++rr) ep[(rr + QR * half) * WCOLS + 32 * j + l31] = acc[i][j][QR * q + rr] * p.acc_scale;
+        if (geglu) {
+          // columns of this wave = [x (WCOLS/2) | gate (WCOLS/2)] (weights packed that way by the host):
+          // out[m][n/2 ..] = (x + bias_x) * gelu(gate + bias_g)   -- attention.py:44-46 fused into ff.net.0.proj
+          constexpr int HC = WCOLS / 2, UPG = HC / 4 > 0 ? HC / 4 : 1, UNG = 2 * QR * UPG, KG = (UNG + 63) / 64;
+#pragma unroll
+          for (int k = 0; k < KG; ++k) {
+            const int u = lane + 64 * k;
+            const int lrow = u / UPG, c4 = u - lrow * UPG;
+            const int row = pass_row(i, q, lrow & 3);
+            f32x4 xv = {0.f, 0.f, 0.f, 0.f};
+            unsigned off = OOB;
+            if (u < UNG && m0 + row < M) {
+              xv = *reinterpret_cast<const f32x4*>(ep + lrow * WCOLS + 4 * c4);
+              f32x4 gv = *reinterpret_cast<const f32x4*>(ep + lrow * WCOLS + HC + 4 * c4);
+              if (p.bias) {
+                xv += *reinterpret_cast<const f32x4*>(vb + wn0 + 4 * c4);
+                gv += *reinterpret_cast<const f32x4*>(vb + wn0 + HC + 4 * c4);
+              }
+#pragma unroll
+              for (int e = 0; e < 4; ++e) xv[e] = xv[e] * cs_gelu(gv[e]);
+              off = (unsigned)(row * p.ldo + (n0 + wn0) / 2 + 4 * c4) * 4u;
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xv), ors, off, 0, 0);
+          }
+          return;
+        }
 #pragma unroll
         for (int k = 0; k < KU; ++k) {
           const int u = lane + 64 * k;
@@ -456,7 +495,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = cs_act(v[e], p.act);
             }
-            v += *reinterpret_cast<const f32x4*>(rs + (pass & 1) * (RSLAB / 4) + 4 * u);
+            if (has_res) v += *reinterpret_cast<const f32x4*>(rs + (pass & 1) * (RSLAB / 4) + 4 * u);
             off = (unsigned)(row * p.ldo + n0 + wn0 + 4 * c4) * 4u;
           }
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, off, 0, 0);   // OOB lanes: dropped
