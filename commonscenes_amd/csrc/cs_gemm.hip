@@ -254,18 +254,31 @@ int cs_pw_gemm_f16x3_launch(const CsConvGemm& p, int M, hipStream_t s);
 
 namespace {
 
-// Split-K heuristic: F16X3 GEMMs on the 224-column tile whose output tiles would leave most of the 256 CUs idle
-// (small batches) and whose K loop is long enough to share: enough slices to reach ~256 workgroups, at least 16
-// K chunks per slice, at most 32 slices.
+// Split-K heuristic: F16X3 GEMMs on the 224-column tile whose output tiles would leave CUs idle (small and medium
+// batches) and whose K loop is long enough to share.  Tuned on the 1- / 4- / 7-object shapes (tools/gemm_smallm.py,
+// tools/plan_ab.sh, profiles/r02_smallm_sweep.txt): the 128x224 tile runs two workgroups per CU, so the slice count is
+// the largest POWER OF TWO that keeps tiles x slices <= 512 (odd counts fight the XCD-aware tile map: 11 slices of a
+// 48-tile GEMM ran 247 us, 8 slices 178), at least 8 K chunks per slice, at most 32 slices; K loops under 64 chunks
+// (the C x C token GEMMs) are not split -- the 64x64 tile fills the chip better there.
 int plan_splitk(const CsConvGemm& p, int64_t M) {
   if (p.math != CS_MATH_F16X3 || p.act == CS_ACT_GEGLU || p.tile != 0 || p.cout % 224) return 1;
   const int64_t wgs = ((M + 127) / 128) * (p.cout / 224);
-  if (wgs >= 160) return 1;
   const int64_t nk = (int64_t)p.kd * p.kh * p.kw * ((p.cin + 15) / 16);
-  int64_t s = (256 + wgs - 1) / wgs;
-  if (s > nk / 16) s = nk / 16;
-  if (s > 32) s = 32;
-  return s < 2 ? 1 : (int)s;
+#ifndef CS_PLAN_R1
+  if (wgs >= 384) return 1;
+#else
+  if (wgs >= 160) return 1;
+#endif
+#ifdef CS_PLAN_R1      // round-1 rule, for A/B timing builds (CS_EXTRA_HIPCC_FLAGS=-DCS_PLAN_R1)
+  int64_t s1 = (256 + wgs - 1) / wgs;
+  if (s1 > nk / 16) s1 = nk / 16;
+  if (s1 > 32) s1 = 32;
+  return s1 < 2 ? 1 : (int)s1;
+#endif
+  if (nk < 64) return 1;
+  int64_t s = 1;
+  while (2 * s * wgs <= 512 && 2 * s <= 32 && 2 * s <= nk / 8) s *= 2;
+  return (int)s;
 }
 
 // sums the split-K partial tiles in slice order and applies the epilogue of conv_gemm_* (bias, BN scale/shift,

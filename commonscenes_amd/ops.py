@@ -206,7 +206,8 @@ def conv_gemm(x: Tensor, w: PackedWeight, *, spatial: Optional[Tuple[int, int, i
               stride: Sequence[int] = (1, 1, 1), up: Sequence[int] = (0, 0, 0), act: int = L.ACT_NONE,
               rowvec: Optional[Tensor] = None, rv_rows: int = 1, res: Optional[Tensor] = None,
               scale: Optional[Tensor] = None, shift: Optional[Tensor] = None,
-              out: Optional[Tensor] = None, tile: int = 0, math: int = L.MATH_FP32) -> Tensor:
+              out: Optional[Tensor] = None, tile: int = 0, math: int = L.MATH_FP32,
+              splitk: Optional[int] = None) -> Tensor:
     """Conv3d (k in {1,3}, pad k//2) / Linear.  x: [nb,d,h,w,c] (conv) or [..., c] rows (linear).
 
     `spatial=(nb,d,h,w)` lets a row matrix be interpreted as a volume without reshaping.
@@ -295,7 +296,10 @@ def conv_gemm(x: Tensor, w: PackedWeight, *, spatial: Optional[Tuple[int, int, i
         tile = tile_for(mo, w.cout, 0, math, act=act)          # what the library picks without tile 5
     p.act, p.rv_rows, p.math, p.tile = act, rv_rows, math, tile
     lib = L.load()
-    if math == L.MATH_F16X3 and tile == 0 and SPLITK:
+    if splitk is not None and splitk > 1:            # explicit split-K factor (tuning / tests); the plan is bypassed
+        ws = torch.empty((splitk * mo * w.cout,), dtype=torch.float32, device=x.device)
+        p.splitk, p.splitk_ws = int(splitk), ws.data_ptr()
+    elif math == L.MATH_F16X3 and tile == 0 and SPLITK and splitk is None:
         # few output tiles (small batches): let the library cut the K loop into slices; the partial tiles live in a
         # scratch tensor that the stream-ordered allocator may reuse as soon as this call's kernels are queued
         sk, wsb = C.c_int32(1), C.c_int64(0)

@@ -204,7 +204,9 @@ def test_conv_gemm_descriptor_validation():
     assert dll.cs_conv_gemm_plan(C.byref(desc()), C.byref(sk), C.byref(ws)) == 0 and sk.value == 1 and ws.value == 0
     big = desc(nb=2, dout=16, hout=4, wout=4, cin=672, cout=672, kd=3, kh=3, kw=3, math=lib.MATH_F16X3)
     assert dll.cs_conv_gemm_plan(C.byref(big), C.byref(sk), C.byref(ws)) == 0
-    assert sk.value == 22 and ws.value == 22 * 512 * 672 * 4
+    assert sk.value == 32 and ws.value == 32 * 512 * 672 * 4
+    short = desc(nb=512, dout=1, hout=1, wout=1, cin=672, cout=672, kd=1, kh=1, kw=1, math=lib.MATH_F16X3)
+    assert dll.cs_conv_gemm_plan(C.byref(short), C.byref(sk), C.byref(ws)) == 0 and sk.value == 1   # 42 chunks: no split
 
 
 def test_vqvae_plan_is_host_only_and_lists_the_decode_side_state_dict():
