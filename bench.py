@@ -20,6 +20,7 @@ Prints ONE JSON line (rank 0):
   decode                VQ-VAE decode of the rank's 32 latents (quantise + Decoder3D, 723 GFLOP/object), own roofline block;
   end_to_end            steps/s with decode + all-gather amortised over the S-step run (what a whole sample() costs);
   c2                    BASELINE configs[1]: ONE object (N=1 only): ms/step and steps/s;
+  mesh                  sdf_to_mesh (HIP marching cubes) of 32 analytic 64^3 SDFs (N=1 only);
   cpu_baseline          the CPU oracle (oracle/ref_torch.py -- a port; the reference cannot travel) on a bounded sample.
 """
 from __future__ import annotations
@@ -236,7 +237,7 @@ def main():
     overflow = ops.read_status(dev) != 0
 
     # ---- extras, outside the timed region: decode of this rank's latents, the all-gather, one object (C2) ----
-    decode = e2e = c2 = None
+    decode = e2e = c2 = mesh = None
     if not a.no_extras and not a.small:
         vq = VQVAE(K.VQVAE_DDCONFIG, K.VQVAE_N_EMBED, K.VQVAE_EMBED_DIM, device=dev).set_math(a.math)
         vq.load_state_dict(synth.synth_state_dict(vqvae_param_shapes(K.VQVAE_DDCONFIG, K.VQVAE_N_EMBED,
@@ -269,6 +270,29 @@ def main():
                    "unit": "DDIM steps/s with decode + all-gather amortised over the S-step run",
                    "whole_run_s": S * step_s + dec_s + gat_s}
         del allsdf, sdf
+        if world == 1:
+            # the step right after the path: sdf_to_mesh of the 32 objects (render_all=True, as
+            # helpers/util.py:298 calls it) on analytic SDFs -- spheres of assorted radii; the synthetic decoder's output
+            # is noise-like and would mesh to an unrepresentative number of triangles
+            from commonscenes_amd.mesh import sdf_to_mesh
+            g = torch.arange(64, dtype=torch.float32, device=dev)
+            gx, gy, gz = torch.meshgrid(g, g, g, indexing="ij")
+            rad = torch.linspace(8.0, 26.0, B, device=dev).view(B, 1, 1, 1)
+            vol = (torch.sqrt((gx - 31.3) ** 2 + (gy - 32.1) ** 2 + (gz - 30.7) ** 2).unsqueeze(0) - rad).unsqueeze(1) / 64.0
+            m0 = sdf_to_mesh(vol, level=0.02, render_all=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            m0 = sdf_to_mesh(vol, level=0.02, render_all=True)
+            torch.cuda.synchronize()
+            msec = time.perf_counter() - t0
+            nv = sum(int(v.shape[0]) for v in m0.verts_list())
+            nf = sum(int(f.shape[0]) for f in m0.faces_list())
+            mbytes = B * 64 ** 3 * (3 * 4 + 8) + nv * 12 + nf * 24     # 3 volume reads + voxel word write/read + outputs
+            mesh = {"objects": B, "ms": msec * 1e3, "vertices": nv, "triangles": nf,
+                    "roofline": {"bound": "hbm", "achieved": mbytes / msec / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                 "frac": mbytes / msec / 1e9 / 8000.0,
+                                 "note": "algorithmic bytes / wall time of the whole call, including the one host "
+                                         "read-back of the per-block totals that sizes the outputs"}}
         if world == 1:
             # BASELINE configs[1] (C2): ONE object; same sampler, CFG batch 2
             x1 = x_T.clone()
@@ -330,7 +354,7 @@ def main():
                        "objects_per_gpu": B, "unet_batch": 2 * B, "ddim_steps": S,
                        "parallelism": f"object-sharded x{world} (replicated weights, no per-step collective; "
                                       "1 broadcast in, 1 all-gather out)"},
-            "roofline": roof, "decode": decode, "end_to_end": e2e, "c2": c2,
+            "roofline": roof, "decode": decode, "end_to_end": e2e, "c2": c2, "mesh": mesh,
             "conditioning_ms": cond_ms, "finite": finite, "f16x3_overflow": overflow, "unet_driver": a.driver,
         }
         if not a.no_cpu_baseline and not a.small:

@@ -108,3 +108,34 @@ def test_sdf_to_mesh_on_64_cubed_batch_properties():
         assert rgb.shape == v.shape and np.allclose(rgb, [[0.2, 0.4, 0.6]])
     one = m[3]
     assert len(one) == 1 and torch.equal(one.verts_list()[0], m.verts_list()[3])
+
+
+@pytest.mark.gpu
+def test_sdf_to_mesh_on_decoder_output_of_the_reference_golden():
+    """the product sequence decode -> mesh on a REAL decoder output: the reference's 64^3 SDF of the vq_decode fixture
+    (synthetic weights: a noise-like field, i.e. many ambiguous cubes) meshes to a surface that is manifold and
+    consistently oriented everywhere, open only where it leaves the volume, and equal to the numpy oracle."""
+    from pathlib import Path
+    from commonscenes_amd.mesh import marching_cubes, sdf_to_mesh
+    g = np.load(Path(__file__).resolve().parent / "golden" / "vq_decode.npz")
+    sdf = torch.from_numpy(g["dec"]).cuda()                      # (1, 1, 64, 64, 64)
+    level = float(np.median(g["dec"]))                           # a level the field actually crosses
+    v, f, nv, nf = marching_cubes(sdf[:, 0], level)
+    torch.cuda.synchronize()
+    rv, rf = RM.marching_cubes(g["dec"][0, 0], level)
+    assert nv[0] == rv.shape[0] and nf[0] == rf.shape[0] and nf[0] > 1000
+    assert np.array_equal(f.cpu().numpy(), rf) and np.array_equal(v.cpu().numpy(), rv.astype(np.float32))
+    open_e, nonman, bad, _ = RM.mesh_invariants(rv, rf)
+    assert nonman == 0 and bad == 0
+    # every open edge lies on the volume's boundary
+    from collections import Counter
+    und = Counter()
+    for t in rf:
+        for a, b in ((t[0], t[1]), (t[1], t[2]), (t[2], t[0])):
+            und[(min(a, b), max(a, b))] += 1
+    for (a, b), c in und.items():
+        if c == 1:
+            pa, pb = rv[a], rv[b]
+            assert any((pa[k] in (0.0, 63.0)) and (pb[k] in (0.0, 63.0)) and pa[k] == pb[k] for k in range(3)), (pa, pb)
+    m = sdf_to_mesh(sdf, level=level)
+    assert len(m) == 1 and m.verts_list()[0].shape[0] == nv[0]
