@@ -207,7 +207,7 @@ def conv_gemm(x: Tensor, w: PackedWeight, *, spatial: Optional[Tuple[int, int, i
               rowvec: Optional[Tensor] = None, rv_rows: int = 1, res: Optional[Tensor] = None,
               scale: Optional[Tensor] = None, shift: Optional[Tensor] = None,
               out: Optional[Tensor] = None, tile: int = 0, math: int = L.MATH_FP32,
-              splitk: Optional[int] = None) -> Tensor:
+              splitk: Optional[int] = None, out_fn=None) -> Tensor:
     """Conv3d (k in {1,3}, pad k//2) / Linear.  x: [nb,d,h,w,c] (conv) or [..., c] rows (linear).
 
     `spatial=(nb,d,h,w)` lets a row matrix be interpreted as a volume without reshaping.
@@ -249,7 +249,10 @@ def conv_gemm(x: Tensor, w: PackedWeight, *, spatial: Optional[Tuple[int, int, i
             oshape = (*x.shape[:-1], ocols)
         else:
             oshape = (nb, do, ho, wo, ocols)
-        out = torch.empty(oshape, dtype=torch.float32, device=x.device)
+        # out_fn: the caller places the result itself, e.g. as a channel slice of a wider (concatenation) buffer
+        out = out_fn(oshape) if out_fn is not None else torch.empty(oshape, dtype=torch.float32, device=x.device)
+        if tuple(out.shape) != tuple(oshape):
+            out = out.view(oshape)
     _chk(out, "out")
     om, oc, ldo = rows_ld(out, "out")
     if om != mo or oc != ocols:

@@ -360,7 +360,7 @@ class DiffusionUNet:
         self._ctx_cache = None
 
     # ---- forward --------------------------------------------------------------------------
-    def _res(self, p: str, l: dict, x: Tensor, semb: Tensor) -> Tensor:
+    def _res(self, p: str, l: dict, x: Tensor, semb: Tensor, out_fn=None) -> Tensor:
         sd, pk = self._sd, self._packed
         nb = x.shape[0]
         rows = x.shape[1] * x.shape[2] * x.shape[3]
@@ -373,7 +373,7 @@ class DiffusionUNet:
         hn2 = ops.groupnorm(h, sd[p + ".out_layers.0.weight"], sd[p + ".out_layers.0.bias"], 32, 1e-5, L.ACT_SILU,
                             split16=s16)
         skip = x if l["cin"] == l["cout"] else ops.conv_gemm(x, pk[p + ".skip_connection"], math=self.math)
-        return ops.conv_gemm(hn2, pk[p + ".out_layers.3"], res=skip, math=self.math)
+        return ops.conv_gemm(hn2, pk[p + ".out_layers.3"], res=skip, math=self.math, out_fn=out_fn)
 
     def _context_vectors(self, ctx: Tensor):
         """One-token context: every transformer block's cross-attention output is the per-sample
@@ -401,7 +401,7 @@ class DiffusionUNet:
         self._ctx_cache = (key, cached)
         return cached
 
-    def _attnblock(self, p: str, l: dict, x: Tensor) -> Tensor:
+    def _attnblock(self, p: str, l: dict, x: Tensor, out_fn=None) -> Tensor:
         """AttentionBlock._forward (openai_model_3d.py:360-366): GN -> qkv (Conv1d k=1) -> QKVAttentionLegacy ->
         proj_out + x.  The reference scales q and k by ch^-1/4 each; the flash kernel scales the logits by ch^-1/2."""
         sd, pk = self._sd, self._packed
@@ -412,10 +412,11 @@ class DiffusionUNet:
         qkv = ops.linear(xn.view(nb, n, c), pk[p + ".qkv"], math=self.math)
         a = ops.attention(qkv[..., 0:c], qkv[..., c:2 * c], qkv[..., 2 * c:3 * c], heads, (c // heads) ** -0.5,
                           math=self.attn_math if self.attn_math is not None else self.math)
-        out = ops.linear(a, pk[p + ".proj_out"], res=x.view(nb, n, c), math=self.math)
+        dst = out_fn((nb, d, h, w, c)).view(nb, n, c) if out_fn is not None else None
+        out = ops.linear(a, pk[p + ".proj_out"], res=x.view(nb, n, c), math=self.math, out=dst)
         return out.view(nb, d, h, w, c)
 
-    def _attn(self, p: str, l: dict, x: Tensor, ctx) -> Tensor:
+    def _attn(self, p: str, l: dict, x: Tensor, ctx, out_fn=None) -> Tensor:
         sd, pk = self._sd, self._packed
         heads = self.cfg["num_heads"]
         nb, d, h, w, c = x.shape
@@ -447,26 +448,31 @@ class DiffusionUNet:
             ff = ops.linear(n3, pk[t + ".ff.net.0.proj"], math=self.math)
             gg = ops.geglu(ff)
         t2 = ops.linear(gg, pk[t + ".ff.net.2"], res=t1, math=self.math)
-        out = ops.linear(t2, pk[p + ".proj_out"], res=x.view(nb, n, c), math=self.math)
+        dst = out_fn((nb, d, h, w, c)).view(nb, n, c) if out_fn is not None else None
+        out = ops.linear(t2, pk[p + ".proj_out"], res=x.view(nb, n, c), math=self.math, out=dst)
         return out.view(nb, d, h, w, c)
 
-    def _run(self, bp: str, layers, h: Tensor, semb: Tensor, ctx: Tensor) -> Tensor:
+    def _run(self, bp: str, layers, h: Tensor, semb: Tensor, ctx: Tensor, out_fn=None) -> Tensor:
+        """`out_fn(shape) -> tensor`: where the block's LAST layer writes its result (a channel slice of the
+        concatenation buffer of the output block that consumes it: torch.cat([h, hs.pop()], 1) then costs no copy)."""
         pk = self._packed
-        for l in layers:
+        for li, l in enumerate(layers):
             p = f"{bp}.{l['idx']}"
             k = l["kind"]
+            of = out_fn if li == len(layers) - 1 else None
             if k == "conv_in":
-                h = ops.conv_gemm(h, pk[p], math=self.math)
+                h = ops.conv_gemm(h, pk[p], math=self.math, out_fn=of)
             elif k == "res":
-                h = self._res(p, l, h, semb)
+                h = self._res(p, l, h, semb, of)
             elif k == "attn":
-                h = self._attn(p, l, h, ctx) if self.cfg["use_spatial_transformer"] else self._attnblock(p, l, h)
+                h = (self._attn(p, l, h, ctx, of) if self.cfg["use_spatial_transformer"]
+                     else self._attnblock(p, l, h, of))
             elif k == "down":      # dims == 3: inner two dims only (openai_model_3d.py:188); dims == 4: all three
                 h = ops.conv_gemm(h, pk[p + ".op"], stride=(1, 2, 2) if self.cfg["dims"] == 3 else (2, 2, 2),
-                                  math=self.math)
+                                  math=self.math, out_fn=of)
             elif k == "up":        # nearest x2 folded into the conv's addressing (openai_model_3d.py:148-157)
                 h = ops.conv_gemm(h, pk[p + ".conv"], up=(0, 1, 1) if self.cfg["dims"] == 3 else (1, 1, 1),
-                                  math=self.math)
+                                  math=self.math, out_fn=of)
         return h
 
     @torch.no_grad()
@@ -488,27 +494,59 @@ class DiffusionUNet:
         semb = ops.linear(e1, pk[P + "time_embed.2"], act=L.ACT_SILU, math=self.math)
         semb = ops.linear(semb, pk["emb_all"], math=self.math)          # [nb, sum(cout)] for all ResBlocks
         ctx = self._context_vectors(ctx) if ctx is not None else None
+        # torch.cat([h, hs.pop()], dim=1) (openai_model_3d.py:781) without copies: output block j reads ONE buffer
+        # cats[j] = [h (ch_h) | skip (ch_skip)]; the layer that produces h (middle block / previous output block) and
+        # the input block that produces the skip both write straight into their channel slice.  Only the skips of the
+        # context-free prefix, which one copy serves for both guidance halves, are still copied (duplicated) in.
         hs: List[Tensor] = []
         tr = self.trace
+        nout = len(out)
+        ch_skip = [layers[-1]["cout"] for layers in inp][::-1]               # skip channels of output block j
+        ch_h = [out[j][0]["cin"] - ch_skip[j] for j in range(nout)]
+        cats: List[Optional[Tensor]] = [None] * nout
+        nocopy = not os.environ.get("CS_CONCAT_COPY")                        # A/B switch: the copying form
+
+        def slot(j: int, left: bool):
+            def fn(shape):
+                want = (*shape[:-1], ch_h[j] + ch_skip[j])
+                if cats[j] is None:
+                    cats[j] = torch.empty(want, dtype=torch.float32, device=h.device)
+                elif tuple(cats[j].shape) != want:
+                    raise L.CsError(f"concat buffer {j}: {tuple(cats[j].shape)} vs {want}")
+                return cats[j][..., :ch_h[j]] if left else cats[j][..., ch_h[j]:]
+            return fn
+
         shared = cfg_pairs          # True while h still holds one copy per (x, t) pair
         for i, layers in enumerate(inp):
             if shared and any(l["kind"] == "attn" for l in layers):
                 h = torch.cat([h, h], dim=0)          # first context-dependent block: split into [uc; c]
                 semb = torch.cat([semb, semb], dim=0)
                 shared = False
-            h = self._run(f"{P}input_blocks.{i}", layers, h, semb, ctx)
-            hs.append(h)
+            direct = nocopy and not shared            # a skip at the full batch goes straight into its slice
+            h = self._run(f"{P}input_blocks.{i}", layers, h, semb, ctx, slot(nout - 1 - i, False) if direct else None)
+            hs.append(None if direct else h)
             if tr is not None:
                 tr[f"input_blocks.{i}"] = h
         if shared:
             h = torch.cat([h, h], dim=0)
             semb = torch.cat([semb, semb], dim=0)
-        h = self._run(P + "middle_block", mid, h, semb, ctx)
+        h = self._run(P + "middle_block", mid, h, semb, ctx, slot(0, True) if nocopy else None)
         if tr is not None:
             tr["middle_block"] = h
         for i, layers in enumerate(out):
-            h = ops.concat_channels(h, hs.pop())      # a shared (B-sized) skip tensor feeds both halves
-            h = self._run(f"{P}output_blocks.{i}", layers, h, semb, ctx)
+            skip = hs.pop()
+            if not nocopy:
+                h = ops.concat_channels(h, skip)
+            else:
+                if skip is not None:                  # prefix skip: B-sized, feeds both guidance halves
+                    right = slot(i, False)((h.shape[0], *skip.shape[1:]))
+                    nbs = skip.shape[0]
+                    for g in range(h.shape[0] // nbs):
+                        ops.copy_rows(skip, right[g * nbs:(g + 1) * nbs])
+                h = cats[i]
+                cats[i] = None
+            h = self._run(f"{P}output_blocks.{i}", layers, h, semb, ctx,
+                          slot(i + 1, True) if nocopy and i + 1 < nout else None)
             if tr is not None:
                 tr[f"output_blocks.{i}"] = h
         hn = ops.groupnorm(h, sd[P + "out.0.weight"], sd[P + "out.0.bias"], 32, 1e-5, L.ACT_SILU,
