@@ -355,7 +355,7 @@ def tile_for(m: int, cout: int, tile: int = 0, math: int = L.MATH_FP32, cin: int
         return 4
     if math == L.MATH_F16X3 and cout % 128 == 0 and ((m + 255) // 256) * (cout // 128) >= 192:
         return 6 if act != L.ACT_GEGLU else 2
-    if math == L.MATH_F16X3 and cout == 64 and (m + 255) // 256 >= 192:
+    if math == L.MATH_F16X3 and (cout == 64 or cout <= 4) and (m + 255) // 256 >= 192:
         return 7 if act != L.ACT_GEGLU else 2
     if cout % 224 == 0 and mt * (cout // 224) >= 256:
         t = 2
