@@ -477,8 +477,7 @@ struct ExecBase {
     Buf stats = alloc((int64_t)nb * groups * 2, 1);
     if (ok() && !dry) {
       const int rows = (int)(x.rows / nb);
-      chk(cs_groupnorm_stats(p(x), nb, rows, x.c, x.c, groups, eps, p(wsb), p(stats), st));
-      chk(cs_groupnorm_apply(p(x), p(stats), wf(n.g_off), wf(n.b_off), p(y), nb, rows, x.c, x.c, x.c, groups, act, st));
+      chk(cs_groupnorm(p(x), wf(n.g_off), wf(n.b_off), p(y), nb, rows, x.c, x.c, x.c, groups, eps, act, p(wsb), p(stats), st));
     }
     release(wsb);
     release(stats);

@@ -56,7 +56,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   constexpr int A_BYTES = BM * 64;                 // raw fp32 [BM][16], or (PRE) fp16 hi [BM][16] + lo [BM][16]
   constexpr int B_BYTES = 2 * BN * 16;             // one fp16 image [2 k-groups][BN][8]
   constexpr int STAGE = A_BYTES + 2 * B_BYTES;
+  // ring depth: the DMA stream runs PF = NSTAGE - 1 chunks ahead of the MFMAs.  Two chunks cover the latency behind
+  // the big tiles' 21-MFMA chunks; the 64x64 tile (small launches: a few hundred short K loops of 3 MFMAs per chunk)
+  // is pure DMA latency at that depth, and its 8 KB stages leave room for five chunks in flight
+#ifdef CS_RING3      // A/B timing builds (tools/ring_ab.sh): the round-1 depth everywhere
   constexpr int NSTAGE = 3;
+#else
+  constexpr int NSTAGE = (BM == 64 && BN == 64) ? 6 : 3;
+#endif
+  constexpr int PF = NSTAGE - 1;
   constexpr int DUMP = NSTAGE * STAGE;             // 1 KB: where surplus DMA wave-instructions land
   constexpr int ROWBASE = DUMP + 1024;             // int32 [BM]: source row of the window origin
   constexpr int DELTA = ROWBASE + BM * 4;          // int16 [MAX_TAPS][BM]: source row - rowbase, or INVALID
@@ -257,10 +265,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
       ++dcc;
     }
   };
-  issue_dma(dtap, dcc, 0);
-  advance();
-  issue_dma(dtap, dcc, 1);
-  advance();
+#pragma unroll
+  for (int q = 0; q < PF; ++q) {
+    issue_dma(dtap, dcc, q);
+    advance();
+  }
 
   // fragment addressing
   int a_frag[WMB][2];
@@ -279,10 +288,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   const int b_frag = A_BYTES + (half * BN + wn0 + l31) * 16;
 
   // Software pipeline: the hi/lo split of chunk k+1's A fragment runs inside chunk k's MFMA stream.
-  //   top of iteration k : outstanding DMAs (oldest first) = [B(k) leftovers] A(k+1) B(k+1)
-  //   wait vmcnt(B_PW)   : everything up to A(k+1) has landed, only B(k+1) may still fly
+  //   top of iteration k : outstanding DMAs (oldest first) = A(k+1) B(k+1) ... A(k+PF-1) B(k+PF-1)
+  //   wait vmcnt((PF-2)*D + B_PW) : everything up to A(k+1) has landed, B(k+1) and the later chunks may still fly
   //   s_barrier          : ... for every wave; every wave has also left iteration k-1
-  //   issue A(k+2), B(k+2) into the stage iteration k-1 vacated (A first, so the next wait covers it)
+  //   issue A(k+PF), B(k+PF) into the stage iteration k-1 vacated (A first, so the next wait covers it)
   //   MFMAs on B(k) with the already-split A(k)  ||  read + split A(k+1)
   float amax = 0.f;
   auto load_a = [&](int st, h8 (&hi)[WMB], h8 (&lo)[WMB]) {
@@ -300,7 +309,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
     }
   };
   h8 ah[WMB], al[WMB];
-  wait_vmcnt<D>();                     // chunk 0 (issued first) has landed for this wave
+  wait_vmcnt<(PF - 1) * D>();          // chunk 0 (issued first) has landed for this wave
   __builtin_amdgcn_s_barrier();
   load_a(0, ah, al);
 
@@ -309,8 +318,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   auto step = [&](auto stage_c) {
     constexpr int stage = decltype(stage_c)::value;
     constexpr int nstage = (stage + 1) % NSTAGE;
-    constexpr int dstage = (stage + 2) % NSTAGE;
-    if (!(CS_ABLATE & 4)) wait_vmcnt<B_PW>();
+    constexpr int dstage = (stage + PF) % NSTAGE;
+    if (!(CS_ABLATE & 4)) wait_vmcnt<(PF - 2) * D + B_PW>();
     if (!(CS_ABLATE & 8)) __builtin_amdgcn_s_barrier();
     const unsigned char* s = smem + stage * STAGE;
     h8 ah2[WMB], al2[WMB];
@@ -346,8 +355,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
     step(std::integral_constant<int, 0>{});
     if (kc + 1 < nk) step(std::integral_constant<int, 1>{});
     if (kc + 2 < nk) step(std::integral_constant<int, 2>{});
+    if constexpr (NSTAGE == 6) {
+      if (kc + 3 < nk) step(std::integral_constant<int, 3>{});
+      if (kc + 4 < nk) step(std::integral_constant<int, 4>{});
+      if (kc + 5 < nk) step(std::integral_constant<int, 5>{});
+    }
   }
-  wait_vmcnt<0>();   // drain the two zero-fill prefetches issued past the end before LDS is released
+  wait_vmcnt<0>();   // drain the prefetches issued past the end before LDS is released
   if constexpr (!PRE) {
     // an activation at or beyond the fp16 range became +-inf in its hi half: tell the host (sticky flag)
     if (p.status && amax >= 65504.f) atomicOr(p.status, CS_STATUS_F16X3_OVERFLOW);

@@ -1,12 +1,16 @@
 // GroupNorm (NDHWC) and LayerNorm for gfx950.  Both are HBM-bound streaming kernels:
 // float4 coalesced loads, fp64 accumulation for GroupNorm statistics (a group spans up to
 // 4096*42 elements), wave64 shuffles for LayerNorm rows.
+#include <cstdlib>
+
 #include "cs_common.h"
 
 namespace {
 
 constexpr int GN_MIN_SPLIT_ROWS = 16;  // minimum rows handled by one statistics block
 constexpr int GN_MAX_SPLITS = 256;
+constexpr int64_t GN_SMALL_BYTES = 16 << 20;   // single-launch path: whole tensor at most this (L2 / MALL resident)
+constexpr int64_t GN_SMALL_GROUP = 4096;       // ... and at most this many elements per (sample, group) workgroup
 
 // Pass 1: partial[n][split][g] = (sum, sumsq) in fp64.  Each thread owns fixed channel chunks so
 // its accumulation order is fixed; the cross-thread reduction runs in a fixed order too, so the
@@ -250,6 +254,94 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x,
   }
 }
 
+// Small tensors (one or two objects: a few MB, L2-resident): statistics and normalisation in ONE launch, one workgroup
+// per (sample, group).  The three-launch path costs ~23 us per GroupNorm there (6.8 + 4.6 + 11.5 us, each at its launch
+// floor), 61 times a step.  Threads walk the group's rows x cpg elements in a fixed stride, accumulate in fp64, and a
+// fixed LDS tree adds the 256 partials, so the statistics are reproducible; the second sweep re-reads the group from
+// L2 and applies the same expression as gn_apply_kernel.
+__global__ __launch_bounds__(256) void gn_small_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float* __restrict__ y,
+                                                       float* __restrict__ stats, int rows, int c, int ldx, int ldy,
+                                                       int groups, float eps, int act) {
+  __shared__ double red[2][256];
+  const int n = blockIdx.x / groups, g = blockIdx.x - n * groups;
+  const int cpg = c / groups;
+  const int tid = threadIdx.x;
+  const float* xb = x + (int64_t)n * rows * ldx + g * cpg;
+  float* yb = y + (int64_t)n * rows * ldy + g * cpg;
+  const int dr = 256 / cpg, dk = 256 - dr * cpg;          // element index + 256  ->  (row + dr, k + dk) with carry
+  auto next = [&](int& r, int& k) {
+    r += dr;
+    k += dk;
+    if (k >= cpg) {
+      k -= cpg;
+      ++r;
+    }
+  };
+  double s = 0, q = 0;
+  {
+    int r = tid / cpg, k = tid - r * cpg;
+    while (r < rows) {                                      // four loads in flight, accumulated in element order
+      float v[4];
+      int rr[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        rr[u] = r;
+        v[u] = r < rows ? xb[(int64_t)r * ldx + k] : 0.f;
+        next(r, k);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (rr[u] < rows) {
+          s += v[u];
+          q += (double)v[u] * v[u];
+        }
+    }
+  }
+  red[0][tid] = s;
+  red[1][tid] = q;
+  __syncthreads();
+#pragma unroll
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) {
+      red[0][tid] += red[0][tid + o];
+      red[1][tid] += red[1][tid + o];
+    }
+    __syncthreads();
+  }
+  const double count = (double)rows * cpg;
+  const double mean_d = red[0][0] / count;
+  double var = red[1][0] / count - mean_d * mean_d;
+  if (var < 0) var = 0;
+  const float mean = (float)mean_d;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  if (tid == 0 && stats) {
+    stats[2 * blockIdx.x] = mean;
+    stats[2 * blockIdx.x + 1] = rstd;
+  }
+  {
+    int r = tid / cpg, k = tid - r * cpg;
+    while (r < rows) {
+      float v[4], ga[4], be[4];
+      int rr[4], kk[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        rr[u] = r;
+        kk[u] = k;
+        if (r < rows) {
+          v[u] = xb[(int64_t)r * ldx + k];
+          ga[u] = gamma[g * cpg + k];
+          be[u] = beta[g * cpg + k];
+        }
+        next(r, k);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (rr[u] < rows) yb[(int64_t)rr[u] * ldy + kk[u]] = cs_act((v[u] - mean) * rstd * ga[u] + be[u], act);
+    }
+  }
+}
+
 // row slices per sample: enough workgroups to fill the chip (~2048 in total) but no slice shorter than
 // GN_MIN_SPLIT_ROWS rows (each workgroup ends in a serial LDS reduction that longer slices amortise)
 int gn_nsplit(int rows, int nb) {
@@ -331,13 +423,35 @@ extern "C" int cs_groupnorm_apply_split16(const float* x, const float* stats, co
   return CS_OK;
 }
 
+extern "C" int cs_groupnorm(const float* x, const float* gamma, const float* beta, float* y, int nb, int rows, int c,
+                            int ldx, int ldy, int groups, float eps, int act, void* ws, float* stats,
+                            cs_stream_t stream) {
+  if (!x || !gamma || !beta || !y || !stats || nb <= 0 || rows <= 0 || c <= 0 || groups <= 0) return CS_EINVAL;
+  if (c % groups || ldx < c || ldy < c) return CS_EINVAL;
+  const int cpg = c / groups;
+  static const int64_t small_group = [] {                 // CS_GN_SMALL_GROUP: tuning override (tools/gn_bench.py)
+    const char* e = getenv("CS_GN_SMALL_GROUP");
+    return e ? (int64_t)atoll(e) : GN_SMALL_GROUP;
+  }();
+  // one launch while the tensor is a few MB (it stays in L2 between the two sweeps) and a group is a handful of
+  // elements per thread; otherwise statistics (two launches) + apply
+  if ((int64_t)nb * rows * c * 4 <= GN_SMALL_BYTES && cpg <= 256 && (int64_t)rows * cpg <= small_group &&
+      (int64_t)nb * groups <= 65535) {
+    CS_LAUNCH(gn_small_kernel, dim3((unsigned)(nb * groups)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y,
+              stats, rows, c, ldx, ldy, groups, eps, act);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+  }
+  if (!ws) return CS_EINVAL;
+  int rc = cs_groupnorm_stats(x, nb, rows, c, ldx, groups, eps, ws, stats, stream);
+  if (rc) return rc;
+  return cs_groupnorm_apply(x, stats, gamma, beta, y, nb, rows, c, ldx, ldy, groups, act, stream);
+}
+
 extern "C" int cs_groupnorm_silu_ndhwc(const float* x, const float* gamma, const float* beta,
                                        float* y, int nb, int rows, int c, int groups, float eps,
                                        void* ws, float* stats, cs_stream_t stream) {
-  int rc = cs_groupnorm_stats(x, nb, rows, c, c, groups, eps, ws, stats, stream);
-  if (rc) return rc;
-  return cs_groupnorm_apply(x, stats, gamma, beta, y, nb, rows, c, c, c, groups, CS_ACT_SILU,
-                            stream);
+  return cs_groupnorm(x, gamma, beta, y, nb, rows, c, c, c, groups, eps, CS_ACT_SILU, ws, stats, stream);
 }
 
 extern "C" int cs_layernorm(const float* x, const float* gamma, const float* beta, float* y, int m,

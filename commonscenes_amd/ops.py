@@ -404,9 +404,9 @@ def groupnorm(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float, a
     lib = L.load()
     ws = torch.empty(lib.cs_groupnorm_ws_bytes(nb, groups) // 8, dtype=torch.float64, device=x.device)
     stats = torch.empty((nb, groups, 2), dtype=torch.float32, device=x.device)
-    L.check(lib.cs_groupnorm_stats(x.data_ptr(), nb, rows, c, ldx, groups, eps, ws.data_ptr(),
-                                   stats.data_ptr(), _stream()), "cs_groupnorm_stats")
     if split16 and SPLIT16_PRODUCERS:
+        L.check(lib.cs_groupnorm_stats(x.data_ptr(), nb, rows, c, ldx, groups, eps, ws.data_ptr(),
+                                       stats.data_ptr(), _stream()), "cs_groupnorm_stats")
         yh = torch.empty(x.shape, dtype=torch.float16, device=x.device)
         yl = torch.empty(x.shape, dtype=torch.float16, device=x.device)
         L.check(lib.cs_groupnorm_apply_split16(x.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
@@ -419,9 +419,9 @@ def groupnorm(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float, a
     om, oc, ldy = rows_ld(out, "out")
     if om != m or oc != c:
         raise L.CsError("groupnorm out shape mismatch")
-    L.check(lib.cs_groupnorm_apply(x.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                   out.data_ptr(), nb, rows, c, ldx, ldy, groups, act, _stream()),
-            "cs_groupnorm_apply")
+    # one launch for small tensors (one or two objects), statistics + apply otherwise: cs_groupnorm decides
+    L.check(lib.cs_groupnorm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), nb, rows, c, ldx, ldy,
+                             groups, eps, act, ws.data_ptr(), stats.data_ptr(), _stream()), "cs_groupnorm")
     return out
 
 

@@ -37,7 +37,7 @@ def R():
 
 def test_library_loads():
     from commonscenes_amd import lib
-    assert lib.load().cs_abi_version() == lib.ABI_VERSION == 8
+    assert lib.load().cs_abi_version() == lib.ABI_VERSION == 9
 
 
 # ---- implicit-GEMM conv / linear ----------------------------------------------------------------
@@ -170,7 +170,8 @@ def test_conv_gemm_rejects_bad_args(ops):
 # ---- norms ---------------------------------------------------------------------------------------
 @pytest.mark.parametrize("c,groups,rows,act", [(224, 32, (4, 4, 4), "silu"), (1120, 32, (2, 4, 4), "silu"),
                                                 (1344, 32, (2, 2, 4), None), (64, 32, (8, 8, 8), "gelu"),
-                                                (256, 32, (4, 4, 4), "swish"), (672, 32, (16, 4, 4), None)])
+                                                (256, 32, (4, 4, 4), "swish"), (672, 32, (16, 4, 4), None),
+                                                (448, 32, (16, 16, 16), "silu")])       # 3 x 7.3 MB: the three-launch path
 def test_groupnorm(ops, R, c, groups, rows, act):
     from commonscenes_amd import lib as L
     nb = 3
@@ -187,6 +188,38 @@ def test_groupnorm(ops, R, c, groups, rows, act):
     out = ops.groupnorm(_dev(x), _dev(g), _dev(b), groups, eps, code)
     torch.cuda.synchronize()
     assert rel_l2(out, ref) < TOL
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 16, 16, 224), (2, 8, 8, 8, 1344), (2, 4, 4, 4, 672), (1, 16, 16, 16, 64)])
+def test_groupnorm_single_launch_equals_three_launch_path(ops, shape):
+    """cs_groupnorm takes the one-launch kernel for tensors of one or two objects; it must agree with the
+    statistics + apply launches it replaces (fp64 sums in a different fixed order: the fp32 statistics are expected to
+    round identically, the gate allows one ulp)."""
+    from commonscenes_amd import lib as L
+    lib = L.load()
+    nb, c, groups = shape[0], shape[-1], 32
+    rows = shape[1] * shape[2] * shape[3]
+    assert nb * rows * c * 4 <= 16 << 20 and rows * (c // groups) <= 32768          # the single-launch conditions
+    x = _dev(_rand(*shape, seed=27) * 1.7 + 0.4)
+    g, b = _dev(_rand(c, seed=28) * 0.2 + 1.0), _dev(_rand(c, seed=29) * 0.1)
+    ws = torch.empty(lib.cs_groupnorm_ws_bytes(nb, groups) // 8, dtype=torch.float64, device="cuda")
+    st1, st3 = torch.empty(nb, groups, 2, device="cuda"), torch.empty(nb, groups, 2, device="cuda")
+    y1, y3 = torch.empty_like(x), torch.empty_like(x)
+    s = torch.cuda.current_stream().cuda_stream
+    L.check(lib.cs_groupnorm(x.data_ptr(), g.data_ptr(), b.data_ptr(), y1.data_ptr(), nb, rows, c, c, c, groups, 1e-5,
+                             L.ACT_SILU, ws.data_ptr(), st1.data_ptr(), s), "cs_groupnorm")
+    L.check(lib.cs_groupnorm_stats(x.data_ptr(), nb, rows, c, c, groups, 1e-5, ws.data_ptr(), st3.data_ptr(), s), "stats")
+    L.check(lib.cs_groupnorm_apply(x.data_ptr(), st3.data_ptr(), g.data_ptr(), b.data_ptr(), y3.data_ptr(), nb, rows, c,
+                                   c, c, groups, L.ACT_SILU, s), "apply")
+    torch.cuda.synchronize()
+    assert float(((st1 - st3).abs() / st3.abs().clamp_min(1e-30)).max()) <= 1.2e-7
+    print(f"groupnorm {shape}: stats bit-equal {torch.equal(st1, st3)}, output bit-equal {torch.equal(y1, y3)}")
+    assert rel_l2(y1, y3) < 2e-7
+    y1b = torch.empty_like(x)
+    L.check(lib.cs_groupnorm(x.data_ptr(), g.data_ptr(), b.data_ptr(), y1b.data_ptr(), nb, rows, c, c, c, groups, 1e-5,
+                             L.ACT_SILU, ws.data_ptr(), st1.data_ptr(), s), "cs_groupnorm")
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y1b)                                                     # reproducible run to run
 
 
 def test_groupnorm_large_rows(ops, R):
