@@ -27,6 +27,28 @@ __device__ __forceinline__ void split8(const f32x4& x, const f32x4& y, float a_s
   }
 }
 
+// split8 with a per-lane scale that may be 0 (a masked-out conv tap): the scaling multiply follows the "legacy" rule
+// 0 * x = 0 for EVERY x, so a NaN or Inf sitting in a masked slab row (another sample's data) cannot leak through.
+// For a non-zero scale the product is the IEEE one: results equal split8's.
+__device__ __forceinline__ void split8_masked(const f32x4& x, const f32x4& y, float sc, h8& hi, h8& lo, float& amax) {
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float in = i < 4 ? x[i] : y[i - 4];
+    asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(v[i]) : "v"(in), "v"(sc));
+  }
+  amax = fmaxf(fmaxf(amax, fabsf(v[0])), fabsf(v[1]));
+  amax = fmaxf(fmaxf(amax, fabsf(v[2])), fabsf(v[3]));
+  amax = fmaxf(fmaxf(amax, fabsf(v[4])), fabsf(v[5]));
+  amax = fmaxf(fmaxf(amax, fabsf(v[6])), fabsf(v[7]));
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const _Float16 h = (_Float16)v[i];
+    hi[i] = h;
+    lo[i] = (_Float16)(v[i] - (float)h);
+  }
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -43,7 +43,16 @@ constexpr int MAX_TAPS = 27;
 // PRE = the activations arrive already split: p.x / p.x_lo are fp16 hi / lo images [rows][lda halves] written by
 // the producer (cs_groupnorm_apply_split16) with the a_scale factor applied -- the split is then done once per
 // element instead of once per tap per N-tile, and the K loop carries no conversion VALU at all.
-template <int WMB, int WNB, int WAVES_M, int WAVES_N, bool PRE>
+//
+// SLAB (3x3x3, stride 1, "same" padding, no upsampling, 256-row tiles, one K slice): consecutive output voxels read
+// consecutive source rows, and the nine (kh, kw) taps of one kd read the SAME rows shifted by kh*W + kw.  The A operand
+// is therefore staged once per (kd, 16-channel chunk) as a slab of BM + 2W + 2 source rows, and the nine taps' fragment
+// reads address it at their row shift; out-of-volume taps are zeroed per lane from a 27-bit validity mask held in a
+// register.  That replaces nine 16 KB gathers (16 scattered 64-byte pieces per wave-instruction, the expensive half of
+// the DMA stream: dropping them in a timing-only build moved the conv shapes from 385-388 to 448-450 TF/s,
+// tools/slab_whatif.sh) by one ~18 KB sequential one.  The chunk order, and with it every accumulation order, is the
+// same as without the slab: results are bit-identical.
+template <int WMB, int WNB, int WAVES_M, int WAVES_N, bool PRE, int SLAB = 0>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_kernel(const CsConvGemm p, int M, int tiles_n,
                                                               int taps_hw, int kw_, int kg_per_tap,
                                                               long long x_bytes, unsigned w_bytes, int vec_epilogue,
@@ -53,7 +62,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   constexpr int NW = WAVES_M * WAVES_N;            // waves per workgroup (4, or 8 for the 256-row tile)
   constexpr int NT = 64 * NW;
   // ---- LDS map (bytes) ----
-  constexpr int A_BYTES = BM * 64;                 // raw fp32 [BM][16], or (PRE) fp16 hi [BM][16] + lo [BM][16]
+  static_assert(!SLAB || (!PRE && WMB == 1 && WAVES_N == 1), "slab path: fp32 activations, one row block per wave");
+  constexpr int SLAB_WI = (BM + 2 * SLAB + 2 + 15) / 16;   // wave-instructions (16 rows each) per slab; SLAB = widest line W
+  constexpr int SLAB_BYTES = SLAB ? SLAB_WI * 1024 : 0;
+  constexpr int RING0 = 2 * SLAB_BYTES;            // two slabs, then the ring
+  constexpr int A_BYTES = SLAB ? 0 : BM * 64;      // raw fp32 [BM][16], or (PRE) fp16 hi [BM][16] + lo [BM][16]
   constexpr int B_BYTES = 2 * BN * 16;             // one fp16 image [2 k-groups][BN][8]
   constexpr int STAGE = A_BYTES + 2 * B_BYTES;
   // ring depth: the DMA stream runs PF = NSTAGE - 1 chunks ahead of the MFMAs.  Two chunks cover the latency behind
@@ -65,16 +78,20 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   constexpr int NSTAGE = (BM == 64 && BN == 64) ? 6 : 3;
 #endif
   constexpr int PF = NSTAGE - 1;
-  constexpr int DUMP = NSTAGE * STAGE;             // 1 KB: where surplus DMA wave-instructions land
+  constexpr int DUMP = RING0 + NSTAGE * STAGE;     // 1 KB: where surplus DMA wave-instructions land
   constexpr int ROWBASE = DUMP + 1024;             // int32 [BM]: source row of the window origin
-  constexpr int DELTA = ROWBASE + BM * 4;          // int16 [MAX_TAPS][BM]: source row - rowbase, or INVALID
-  constexpr int ROWMIN = DELTA + MAX_TAPS * BM * 2;   // int32: smallest source row of the tile (descriptor window base)
-  constexpr int LDS_BYTES = ROWMIN + 16;
+  constexpr int DELTA = ROWBASE + (SLAB ? 0 : BM * 4);   // int16 [MAX_TAPS][BM]: source row - rowbase, or INVALID
+  constexpr int ROWMIN = DELTA + (SLAB ? 0 : MAX_TAPS * BM * 2);   // int32: smallest source row of the tile (descriptor window base)
+  // the pipelined epilogue re-uses the LDS from offset 0 (staging + two residual slabs per wave + the vector rows)
+  constexpr int EP_KU = (4 * (32 * WNB / 4) + 63) / 64;
+  constexpr int EPI_NEED = NW * (16 * 32 * WNB) + NW * 2 * EP_KU * 1024 + 2048;
+  constexpr int LDS_BYTES = (ROWMIN + 16 > EPI_NEED) ? ROWMIN + 16 : EPI_NEED;
   constexpr short INVALID = (short)0x8000;
   // ---- DMA schedule: wave-instructions of 64 x 16 B ----
   constexpr int A_WI = BM / 16;                    // A wave-instructions per chunk
   constexpr int B_WI = BN / 32;                    // per B image
-  constexpr int A_PW = A_WI / NW;                  // per wave
+  constexpr int A_PW = SLAB ? 0 : A_WI / NW;       // per wave (slab: the A operand is not part of the chunk stream)
+  constexpr int A_PWN = A_PW > 0 ? A_PW : 1;
   constexpr int B_PW = (2 * B_WI + NW - 1) / NW;   // per wave, hi + lo together (surplus ones go to DUMP)
   constexpr int D = A_PW + B_PW;                   // DMA instructions per wave per chunk
   static_assert(A_WI % NW == 0, "A tile must split evenly over the waves");
@@ -110,9 +127,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   const int ntaps = p.kd * taps_hw;
   int* rowbase = reinterpret_cast<int*>(smem + ROWBASE);
   int* rowmin = reinterpret_cast<int*>(smem + ROWMIN);
+  short* delta = reinterpret_cast<short*>(smem + DELTA);
+  if constexpr (!SLAB) {
   if (tid == 0) *rowmin = 0x7fffffff;
   __syncthreads();
-  short* delta = reinterpret_cast<short*>(smem + DELTA);
   {
     // NT / BM threads per output row: the row's (n, od, oh, ow) decomposition -- three integer divisions -- is done
     // once, the taps are then walked with adds and compares only
@@ -155,12 +173,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
     }
   }
   __syncthreads();
+  }
 
   // The activation buffer descriptors are per workgroup: based at the smallest source row this tile can touch (every
   // valid tap sits at or after its row's clamped window origin, so that is the minimum of rowbase over the tile's
   // rows), with 32-bit offsets inside a window of a few MB.  The tensor itself may therefore be larger than
   // the 4 GiB a single descriptor spans (288 GB of HBM: 200+ objects per batch at the 16^3 x 672-channel level).
-  const int row_lo = __builtin_amdgcn_readfirstlane(*rowmin);
+  // (slab: the lowest row any of the three kd slabs can start at)
+  const int row_lo = SLAB ? max(0, m0 - p.hin * p.win - p.win - 1) : __builtin_amdgcn_readfirstlane(*rowmin);
   const long long x_skip = (long long)row_lo * p.lda * (PRE ? 2 : 4);
   const long long x_left = x_bytes - x_skip;
   const unsigned x_win = x_left > 0xFFE00000LL ? 0xFFE00000u : (unsigned)x_left;
@@ -179,9 +199,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   // ---- per-lane DMA constants ----
   // A wave-instruction w (0..A_WI-1) covers units 64w..64w+63: row = 16w + lane/4, LDS slot q = lane&3 holds
   // global 16-byte piece q ^ ((row>>2)&3).
-  int a_rowbase[A_PW];
-  unsigned a_piece[A_PW];
-  int a_rowidx[A_PW];
+  int a_rowbase[A_PWN];
+  unsigned a_piece[A_PWN];
+  int a_rowidx[A_PWN];
 #pragma unroll
   for (int i = 0; i < A_PW; ++i) {
     const int w = wave * A_PW + i;
@@ -212,9 +232,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   }
 
   auto issue_dma = [&](int tap, int cc, int stage) {
-    unsigned char* st = smem + stage * STAGE;
+    unsigned char* st = smem + RING0 + stage * STAGE;
+    const bool skip_a = ((CS_ABLATE & 128) && tap % 3 != 0) || ((CS_ABLATE & 256) && tap % 9 != 0);   // slab what-if
 #pragma unroll
     for (int i = 0; i < A_PW; ++i) {
+      if (skip_a) break;
       const short dl = delta[tap * BM + a_rowidx[i]];
       const int c = cc * BKH + (int)a_piece[i];
       constexpr unsigned ESZ = PRE ? 2u : 4u;
@@ -295,7 +317,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   //   MFMAs on B(k) with the already-split A(k)  ||  read + split A(k+1)
   float amax = 0.f;
   auto load_a = [&](int st, h8 (&hi)[WMB], h8 (&lo)[WMB]) {
-    const unsigned char* s = smem + st * STAGE;
+    const unsigned char* s = smem + RING0 + st * STAGE;
 #pragma unroll
     for (int i = 0; i < WMB; ++i) {
       if constexpr (PRE) {
@@ -308,10 +330,88 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
       }
     }
   };
+  // ---- slab path: per-lane validity mask, slab DMA, shifted fragment reads ----
+  constexpr int SLAB_PW = (SLAB_WI + NW - 1) / NW;        // slab wave-instructions per wave (every wave issues all of
+                                                          // them, surplus ones as zero-fills: the counts below are exact)
+  const int s_w = p.win, s_hw = p.hin * p.win;
+  const int s_rows = p.nb * p.din * s_hw;                  // source rows in the tensor
+  const int s_need = BM + 2 * s_w + 2;                     // slab rows this problem uses
+  const int rowl = wm0 + l31;                              // the lane's fragment row inside the tile
+  unsigned vmask = 0;                                      // bit tap: that tap of this lane's output voxel is inside the volume
+  int sl_row[SLAB_PW];
+  unsigned sl_piece[SLAB_PW];
+  int sl_a0[9];                                            // fragment byte offset inside the slab, per (kh, kw)
+  if constexpr (SLAB != 0) {
+#pragma unroll
+    for (int t9 = 0; t9 < 9; ++t9) {
+      const int prow = rowl + (t9 / 3) * s_w + t9 % 3;
+      sl_a0[t9] = prow * 64 + ((((2 * half) ^ (prow >> 2)) & 3) << 4);
+    }
+    const int m = m0 + rowl;
+    if (m < M) {
+      int mm = m;
+      const int ow = mm % p.win;
+      mm /= p.win;
+      const int oh = mm % p.hin;
+      mm /= p.hin;
+      const int od = mm % p.din;
+#pragma unroll
+      for (int t = 0; t < 27; ++t) {
+        const int kd_ = t / 9, kh_ = (t / 3) % 3, kwi = t % 3;
+        if ((unsigned)(od + kd_ - 1) < (unsigned)p.din && (unsigned)(oh + kh_ - 1) < (unsigned)p.hin &&
+            (unsigned)(ow + kwi - 1) < (unsigned)p.win)
+          vmask |= 1u << t;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < SLAB_PW; ++i) {
+      const int j = 16 * (wave + NW * i) + (lane >> 2);   // slab row of this lane in its i-th instruction
+      sl_row[i] = j;
+      sl_piece[i] = (unsigned)(((lane & 3) ^ ((j >> 2) & 3)) * 4);
+    }
+  }
+  // slab of super-chunk sc (= channel chunk sc / 3, kd = sc % 3): source rows m0 + (kd-1)*H*W - W - 1 ... in order
+  auto issue_slab = [&](int sc) {
+    const int cc = sc / 3, kd_ = sc - 3 * cc;
+    const int src0 = m0 + (kd_ - 1) * s_hw - s_w - 1;
+    unsigned char* dst = smem + (sc & 1) * SLAB_BYTES;
+#pragma unroll
+    for (int i = 0; i < SLAB_PW; ++i) {
+      const int q = wave + NW * i;                          // wave-uniform
+      const int src = src0 + sl_row[i];
+      const int c = cc * BKH + (int)sl_piece[i];
+      const unsigned off = (q < SLAB_WI && sl_row[i] < s_need && src >= 0 && src < s_rows && c < p.cin && cc < chunks_per_tap)
+                               ? (unsigned)(src - row_lo) * ((unsigned)p.lda * 4u) + (unsigned)c * 4u
+                               : OOB;
+      // (through a variable: a conditional expression as the LDS argument makes the HOST pass drop the kernel's stub
+      // without a diagnostic)
+      unsigned char* d2 = q < SLAB_WI ? dst + q * 1024 : smem + DUMP;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, d2, 16, off, 0, 0, 0);
+    }
+  };
+  // fragment of the chunk at (kh, kw) = T9 of the super-chunk whose slab sits in buffer `buf`: the lane's row shifted by
+  // kh*W + kw, zeroed (scale 0, legacy multiply) if that tap falls outside the volume for this output voxel
+  // (m9 = the kd's nine mask bits)
+  auto load_a_slab = [&](auto t9_c, int buf, unsigned m9, h8& hi, h8& lo) {
+    constexpr int t9 = decltype(t9_c)::value;
+    const unsigned char* sb = smem + buf * SLAB_BYTES;
+    const f32x4 x0 = *reinterpret_cast<const f32x4*>(sb + sl_a0[t9]);
+    const f32x4 x1 = *reinterpret_cast<const f32x4*>(sb + (sl_a0[t9] ^ 16));
+    cs16::split8_masked(x0, x1, ((m9 >> t9) & 1u) ? a_scale : 0.f, hi, lo, amax);
+  };
+
   h8 ah[WMB], al[WMB];
+  if constexpr (SLAB != 0) {
+    // the prologue above issued B(0), B(1); the first slab goes out now and is the youngest: wait for everything
+    issue_slab(0);
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    load_a_slab(std::integral_constant<int, 0>{}, 0, vmask & 0x1FFu, ah[0], al[0]);
+  } else {
   wait_vmcnt<(PF - 1) * D>();          // chunk 0 (issued first) has landed for this wave
   __builtin_amdgcn_s_barrier();
   load_a(0, ah, al);
+  }
 
   // One ring position per call, with the stage a compile-time constant: every LDS address (fragment reads and
   // the DMA destinations that go through M0) folds to an immediate instead of per-iteration scalar arithmetic.
@@ -321,7 +421,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
     constexpr int dstage = (stage + PF) % NSTAGE;
     if (!(CS_ABLATE & 4)) wait_vmcnt<(PF - 2) * D + B_PW>();
     if (!(CS_ABLATE & 8)) __builtin_amdgcn_s_barrier();
-    const unsigned char* s = smem + stage * STAGE;
+    const unsigned char* s = smem + RING0 + stage * STAGE;
     h8 ah2[WMB], al2[WMB];
 #if CS_ABLATE & 16
     __builtin_amdgcn_s_setprio(1);
@@ -351,6 +451,59 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
       al[i] = al2[i];
     }
   };
+  // Slab path: one super-chunk (a kd and a 16-channel chunk: nine taps) per loop iteration, fully unrolled -- which tap a
+  // step computes, whether it sends the next slab, and every vmcnt are compile-time, so each step stays one
+  // straight-line block the scheduler can interleave (a first version with run-time tap bookkeeping and a switch
+  // over the wait count gained 3 %, this one ... see DESIGN).
+  //   iteration k (tap T9 of super-chunk sc), after its barrier: [T9 == 0: slab(sc + 1)]  B(k + 2)
+  //   top of iteration k: only what iteration k - 1 issued may still fly
+  auto sstep = [&](auto stage_c, auto t9_c, int sc, unsigned m9_this, unsigned m9_next) {
+    constexpr int stage = decltype(stage_c)::value;
+    constexpr int t9 = decltype(t9_c)::value;
+    constexpr int dstage = (stage + PF) % NSTAGE;
+    wait_vmcnt<(t9 == 1 ? SLAB_PW : 0) + B_PW>();
+    __builtin_amdgcn_s_barrier();
+    const unsigned char* s = smem + RING0 + stage * STAGE;
+    h8 ah2, al2;
+#pragma unroll
+    for (int j = 0; j < WNB; ++j) {
+      const h8 bh = *reinterpret_cast<const h8*>(s + b_frag + j * 512);
+      const h8 bl = *reinterpret_cast<const h8*>(s + b_frag + B_BYTES + j * 512);
+      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[0], bh, acc[0][j], 0, 0, 0);
+      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0], bl, acc[0][j], 0, 0, 0);
+      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0], bh, acc[0][j], 0, 0, 0);
+      if (j == 0) {
+        if constexpr (t9 == 0) issue_slab(sc + 1);       // its buffer was last read while chunk k-2 was computed
+        issue_dma(dtap, dcc, dstage);
+        advance();
+        if constexpr (t9 == 8)
+          load_a_slab(std::integral_constant<int, 0>{}, (sc + 1) & 1, m9_next, ah2, al2);
+        else
+          load_a_slab(std::integral_constant<int, t9 + 1>{}, sc & 1, m9_this, ah2, al2);
+      }
+    }
+    ah[0] = ah2;
+    al[0] = al2;
+  };
+  if constexpr (SLAB != 0) {
+    static_assert(NSTAGE == 3 && PF == 2, "nine taps = three turns of the ring");
+    const int nsc = nk / 9;
+    int kdc = 0;                                            // kd of the super-chunk
+    for (int sc = 0; sc < nsc; ++sc) {
+      const int kdn = kdc == 2 ? 0 : kdc + 1;
+      const unsigned m9 = (vmask >> (9 * kdc)) & 0x1FFu, m9n = (vmask >> (9 * kdn)) & 0x1FFu;
+      sstep(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, sc, m9, m9n);
+      sstep(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, sc, m9, m9n);
+      sstep(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, sc, m9, m9n);
+      sstep(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, sc, m9, m9n);
+      sstep(std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{}, sc, m9, m9n);
+      sstep(std::integral_constant<int, 2>{}, std::integral_constant<int, 5>{}, sc, m9, m9n);
+      sstep(std::integral_constant<int, 0>{}, std::integral_constant<int, 6>{}, sc, m9, m9n);
+      sstep(std::integral_constant<int, 1>{}, std::integral_constant<int, 7>{}, sc, m9, m9n);
+      sstep(std::integral_constant<int, 2>{}, std::integral_constant<int, 8>{}, sc, m9, m9n);
+      kdc = kdn;
+    }
+  } else
   for (int kc = 0; kc < nk; kc += NSTAGE) {
     step(std::integral_constant<int, 0>{});
     if (kc + 1 < nk) step(std::integral_constant<int, 1>{});
@@ -373,10 +526,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   // 16 rows x (32*WNB) columns per wave through the (now idle) LDS ring and write whole rows as float4.
   float* const outp = p.out + (int64_t)split * M * p.ldo;      // split-K: slice s owns rows [s*M, (s+1)*M) of the ws
   constexpr int WCOLS = 32 * WNB;
-  constexpr int PASS_R = (NW * 16 * WCOLS * 4 <= NSTAGE * STAGE) ? 8 : 4;   // accumulator registers per pass
+  constexpr int PASS_R = (NW * 16 * WCOLS * 4 <= DUMP) ? 8 : 4;             // accumulator registers per pass
   constexpr int EPI_ROWS = 2 * PASS_R;                                       // rows staged per wave per pass
   constexpr int EPI_BYTES = EPI_ROWS * WCOLS * 4;                            // per wave, per pass
-  static_assert(NW * EPI_BYTES <= NSTAGE * STAGE, "epilogue staging must fit in the ring");
+  static_assert(NW * EPI_BYTES <= DUMP, "epilogue staging must fit in the ring");
   // ---- pipelined epilogue ----------------------------------------------------------------------------------------
   // The epilogue used to fetch its per-element operands with one dependent global load per float4 of output: for a
   // tile with a residual, 28 serialized HBM latencies per wave (~30 us per 256x224 tile, as long as a 448-channel
@@ -629,7 +782,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   }
 }
 
-template <int WMB, int WNB, int WAVES_M, int WAVES_N, bool PRE>
+template <int WMB, int WNB, int WAVES_M, int WAVES_N, bool PRE, int SLAB = 0>
 int launch16(const CsConvGemm& p, int M, int splits, hipStream_t stream) {
   constexpr int BM = 32 * WMB * WAVES_M;
   constexpr int BN = 32 * WNB * WAVES_N;
@@ -653,7 +806,7 @@ int launch16(const CsConvGemm& p, int M, int splits, hipStream_t stream) {
     constexpr int WCOLS = 32 * WNB;
     if (!vec || (WCOLS / 2) % 4 || p.cout % WCOLS || p.scale || p.rowvec || p.res) return CS_EINVAL;
   }
-  CS_LAUNCH((conv_gemm_f16x3_kernel<WMB, WNB, WAVES_M, WAVES_N, PRE>), dim3((unsigned)nblk), dim3(64 * WAVES_M * WAVES_N), 0,
+  CS_LAUNCH((conv_gemm_f16x3_kernel<WMB, WNB, WAVES_M, WAVES_N, PRE, SLAB>), dim3((unsigned)nblk), dim3(64 * WAVES_M * WAVES_N), 0,
             stream, p, M, tiles_n, p.kh * p.kw, p.kw, kg_per_tap, (long long)x_bytes, (unsigned)w_bytes, vec, splits);
   CS_CHECK_LAUNCH();
   return CS_OK;
@@ -706,6 +859,23 @@ int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p_in, int M, int tile, int spl
     }
   }
   if (p.a_format != 0) return CS_EINVAL;
+#ifndef CS_NO_SLAB      // (A/B timing builds: -DCS_NO_SLAB keeps the per-tap gather everywhere)
+  // 3x3x3, stride 1, "same" padding, no upsampling, one K slice, 256-row tiles: the A operand comes from a slab
+  // shared by the nine (kh, kw) taps of each kd (see the kernel's header)
+  const bool slab = splits == 1 && p.kd == 3 && p.kh == 3 && p.kw == 3 && p.sd == 1 && p.sh == 1 && p.sw == 1 &&
+                    p.pd == 1 && p.ph == 1 && p.pw == 1 && p.ud == 0 && p.uh == 0 && p.uw == 0 && p.din == p.dout &&
+                    p.hin == p.hout && p.win == p.wout && p.win <= 64 && (p.win <= 32 || tile == 7) &&
+                    (256 + 2LL * p.hin * p.win + 2 * p.win + 32) * p.lda * 4 < 0x7FF00000LL;
+  if (slab) {
+    switch (tile) {
+      case 4: return launch16<1, 7, 8, 1, false, 32>(p, M, splits, s);
+      case 6: return launch16<1, 4, 8, 1, false, 32>(p, M, splits, s);
+      case 7: return p.win <= 32 ? launch16<1, 2, 8, 1, false, 32>(p, M, splits, s)
+                                 : launch16<1, 2, 8, 1, false, 64>(p, M, splits, s);   // the decoder's 64^3 level
+      default: break;
+    }
+  }
+#endif
   switch (tile) {
     case 1: return launch16<2, 2, 2, 2, false>(p, M, splits, s);
     case 2: return launch16<1, 7, 4, 1, false>(p, M, splits, s);

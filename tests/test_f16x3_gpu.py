@@ -54,6 +54,66 @@ def test_f16x3_conv_is_fp32_grade(case):
     assert e16 < 4 * e32 + 3e-7, (e16, e32)          # no worse than a few x the fp32 fma chain's own rounding
 
 
+SLAB_CASES = [
+    # nb, d, h, w, cin, cout, tile, epilogue
+    (2, 16, 16, 16, 32, 224, 4, "plain"),          # level-0 geometry (W = 16)
+    (3, 16, 8, 8, 48, 448, 4, "res"),              # level 1 (W = 8), residual epilogue
+    (5, 16, 4, 4, 64, 672, 4, "rowvec"),           # level 2 (W = 4): a 256-row tile spans four samples
+    (1, 5, 7, 3, 20, 224, 4, "plain"),             # ragged M (105 rows), cin not a multiple of 16, W = 3
+    (1, 3, 5, 64, 16, 64, 7, "plain"),             # the decoder's widest line (W = 64): the wide-slab variant
+    (1, 4, 9, 32, 16, 128, 6, "rowvec"),           # W = 32, 256x128 tile
+    (2, 6, 9, 11, 24, 64, 7, "res"),               # 256x64 tile, odd extents
+    (1, 1, 1, 1, 16, 224, 4, "plain"),             # a single voxel: every tap but the centre is padding
+]
+
+
+@pytest.mark.parametrize("case", SLAB_CASES)
+def test_f16x3_slab_conv_is_bit_identical_to_the_gather_path(case):
+    """3x3x3 stride-1 convs on the 256-row tiles stage their A operand as one slab per (kd, channel chunk) shared by
+    the nine (kh, kw) taps (cs_gemm_f16x3.hip, SLAB).  The chunk order is unchanged, so the result must equal the
+    per-tap gather path (the 128x224 / 64x64 tiles, which have no slab variant) bit for bit -- and be fp32-grade."""
+    from commonscenes_amd import lib as L, ops
+    from oracle import ref_ops as R
+    nb, d, h, w, cin, cout, tile, epi = case
+    x = _rand(nb, d, h, w, cin, seed=31)
+    wt = _rand(cout, cin, 3, 3, 3, seed=32, scale=(cin * 27) ** -0.5)
+    b = _rand(cout, seed=33)
+    kw, rkw = {}, {}
+    if epi == "res":
+        r = _rand(nb, d, h, w, cout, seed=34)
+        kw, rkw = dict(res=r.cuda(), act=L.ACT_SILU), dict(res=r.double(), act="silu")
+    elif epi == "rowvec":
+        rv = _rand(nb, cout, seed=35)
+        kw, rkw = dict(rowvec=rv.cuda(), rv_rows=d * h * w), dict(rowvec=rv.double())
+    ref = R.conv_ndhwc(x.double(), wt.double(), b.double(), **rkw)
+    pk = ops.pack_weight(wt.cuda(), b.cuda(), math=L.MATH_F16X3)
+    xd = x.cuda()
+    out_slab = ops.conv_gemm(xd, pk, tile=tile, **kw)
+    out_gather = ops.conv_gemm(xd, pk, tile=2 if cout % 224 == 0 else 3, **kw)
+    again = ops.conv_gemm(xd, pk, tile=tile, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(out_slab, out_gather)
+    assert torch.equal(out_slab, again)
+    assert rel_l2(out_slab, ref) < 2e-6
+
+
+def test_f16x3_slab_conv_keeps_samples_independent():
+    """the slab holds rows of neighbouring samples (a 256-row tile at the 4^3 level spans four of them): a NaN in one
+    sample must not leak into the others through the zeroed-by-mask taps."""
+    from commonscenes_amd import lib as L, ops
+    x = _rand(6, 4, 4, 4, 32, seed=41)
+    wt = _rand(224, 32, 3, 3, 3, seed=42, scale=(32 * 27) ** -0.5)
+    pk = ops.pack_weight(wt.cuda(), None, math=L.MATH_F16X3)
+    clean = ops.conv_gemm(x.cuda(), pk, tile=4)
+    x2 = x.clone()
+    x2[2] = float("nan")
+    dirty = ops.conv_gemm(x2.cuda(), pk, tile=4)
+    torch.cuda.synchronize()
+    keep = [0, 1, 3, 4, 5]
+    assert torch.equal(dirty[keep], clean[keep])
+    assert torch.isnan(dirty[2]).all()
+
+
 def test_f16x3_wide_dynamic_range():
     """weights spanning 1e-5..1, activations with outliers and tiny values: the split keeps absolute accuracy."""
     from commonscenes_amd import lib as L, ops
