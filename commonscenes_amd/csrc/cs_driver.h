@@ -37,6 +37,11 @@ struct Gemm {        // one packed GEMM weight (possibly several reference tenso
   int cout = 0, cin = 0, cin_pad = 0, k = 1, taps = 1, ldw = 0;
   int64_t w_off = 0, wlo_off = 0, b_off = -1;
   float acc_scale = 1.f;
+  // Upsample's conv folded onto the source grid (cs_conv_gemm_up2): bit 2 / 1 / 0 = D / H / W doubled.  The packed
+  // weights are then one image (pair) per output parity class, built from the folded fp32 taps kept at fold_off.
+  int up_mask = 0, ncls = 0, fkd = 3, fkh = 3, fkw = 3, amax_slot = -1;
+  int64_t fold_off = 0, cls_w_off[8] = {0}, cls_wlo_off[8] = {0};
+  float cls_acc_scale[8] = {0};
 };
 
 struct Norm {
@@ -60,6 +65,7 @@ struct Plan {
   std::vector<Norm> norms;
   std::vector<RawCopy> copies;
   int64_t raw_bytes = 0, arena_bytes = 0, amax_off = 0;
+  int amax_slots = 0;      // per-parameter |w| maxima, then one per parity class of every folded upsample conv
   bool packed = false;
 };
 
@@ -118,12 +124,23 @@ int add_gemm(Plan& u, std::vector<Piece> w, std::vector<Piece> b, int cout, int 
 }
 
 // conv (k = 3 or 1) or Linear (k = 0) as a single-tensor GEMM
-int add_layer_gemm(Plan& u, const std::string& p, int o, int i, int k, bool bias = true, int cin_pad = 0) {
+int add_layer_gemm(Plan& u, const std::string& p, int o, int i, int k, bool bias = true, int cin_pad = 0,
+                   int up_mask = 0) {
   int wp, bp;
   add_wb(u, p, o, i, k, bias, wp, bp);
   std::vector<Piece> b;
   if (bp >= 0) b.push_back({bp, 0, o});
-  return add_gemm(u, {{wp, 0, o}}, b, o, i, k, cin_pad);
+  const int gi = add_gemm(u, {{wp, 0, o}}, b, o, i, k, cin_pad);
+  if (up_mask && k == 3) {      // the conv of an Upsample: folded per output parity class (cs_fold_upsample_weight)
+    Gemm& g = u.gemms[gi];
+    int32_t n, a, bb, c;
+    if (cs_conv_up2_info((up_mask >> 2) & 1, (up_mask >> 1) & 1, up_mask & 1, &n, &a, &bb, &c) == CS_OK) {
+      g.up_mask = up_mask;
+      g.ncls = n;
+      g.fkd = a; g.fkh = bb; g.fkw = c;
+    }
+  }
+  return gi;
 }
 
 int add_copy(Plan& u, int param) {
@@ -134,7 +151,33 @@ int add_copy(Plan& u, int param) {
 void layout_arena(Plan& u) {
   const bool f16 = u.math == CS_MATH_F16X3;
   int64_t off = 0;
+  int slots = (int)u.params.size();
   for (Gemm& g : u.gemms) {
+    if (g.up_mask) {
+      const int ftaps = g.fkd * g.fkh * g.fkw;
+      g.ldw = f16 ? g.cout : (g.cout + 3) / 4 * 4;
+      g.fold_off = off;
+      off += align_up((int64_t)g.ncls * g.cout * g.cin * ftaps * 4);
+      for (int c = 0; c < g.ncls; ++c) {
+        if (f16) {
+          const int64_t img = (int64_t)ftaps * ((g.cin + 15) / 16 * 2) * g.cout * 16;
+          g.cls_w_off[c] = off;
+          off += align_up(img);
+          g.cls_wlo_off[c] = off;
+          off += align_up(img);
+        } else {
+          g.cls_w_off[c] = off;
+          off += align_up((int64_t)ftaps * g.cin_pad * g.ldw * 4);
+        }
+      }
+      g.amax_slot = slots;
+      slots += g.ncls;
+      if (!g.b.empty()) {
+        g.b_off = off;
+        off += align_up((int64_t)g.cout * 4);
+      }
+      continue;
+    }
     if (f16) {
       const int64_t kg = (int64_t)(g.cin + 15) / 16 * 2;
       const int64_t img = (int64_t)g.taps * kg * g.cout * 16;
@@ -164,7 +207,8 @@ void layout_arena(Plan& u) {
     off += align_up(u.params[rc.param].numel * 4);
   }
   u.amax_off = off;
-  off += align_up((int64_t)u.params.size() * 4);
+  u.amax_slots = slots;
+  off += align_up((int64_t)slots * 4);
   u.arena_bytes = off;
 }
 
@@ -248,12 +292,29 @@ int pack_plan(Plan* u, const void* raw_dev, void* arena_dev, cs_stream_t stream)
   char* arena = (char*)arena_dev;
   const bool f16 = u->math == CS_MATH_F16X3;
   auto src = [&](int param) { return reinterpret_cast<const float*>(raw + u->params[param].raw_off); };
-  std::vector<float> amax(u->params.size(), 0.f);
+  std::vector<float> amax((size_t)u->amax_slots, 0.f);
+  // Upsample convs: fold the 27 taps into the per-parity-class taps first (their maxima are taken over the folded values)
+  for (const Gemm& g : u->gemms) {
+    if (!g.up_mask) continue;
+    if (g.w.size() != 1 || g.w[0].param < 0 || g.w[0].row0 != 0 || g.w[0].rows != g.cout) return CS_EINVAL;
+    const int rc = cs_fold_upsample_weight(src(g.w[0].param), reinterpret_cast<float*>(arena + g.fold_off), g.cout, g.cin,
+                                           (g.up_mask >> 2) & 1, (g.up_mask >> 1) & 1, g.up_mask & 1, stream);
+    if (rc != CS_OK) return rc;
+  }
   if (f16) {
     // per-tensor |w| maxima for the power-of-two operand scales: one device pass, ONE host sync (load time)
     float* d_amax = reinterpret_cast<float*>(arena + u->amax_off);
-    if (hipMemsetAsync(d_amax, 0, u->params.size() * 4, st) != hipSuccess) return CS_EINVAL;
-    for (const Gemm& g : u->gemms)
+    if (hipMemsetAsync(d_amax, 0, (size_t)u->amax_slots * 4, st) != hipSuccess) return CS_EINVAL;
+    for (const Gemm& g : u->gemms) {
+      if (g.up_mask) {
+        const int64_t n = (int64_t)g.cout * g.cin * g.fkd * g.fkh * g.fkw;
+        for (int c = 0; c < g.ncls; ++c) {
+          CS_LAUNCH(absmax_kernel, dim3(cs_grid_for(n, 256, 256)), dim3(256), 0, st,
+                    reinterpret_cast<const float*>(arena + g.fold_off) + c * n, n, d_amax + g.amax_slot + c);
+          CS_CHECK_LAUNCH();
+        }
+        continue;
+      }
       for (const Piece& pc : g.w) {
         if (pc.param < 0) continue;
         const Param& p = u->params[pc.param];
@@ -261,11 +322,54 @@ int pack_plan(Plan* u, const void* raw_dev, void* arena_dev, cs_stream_t stream)
                   d_amax + pc.param);
         CS_CHECK_LAUNCH();
       }
+    }
     if (hipMemcpyAsync(amax.data(), d_amax, amax.size() * 4, hipMemcpyDeviceToHost, st) != hipSuccess)
       return CS_EINVAL;
     if (hipStreamSynchronize(st) != hipSuccess) return CS_EINVAL;
   }
+  auto copy_bias = [&](const Gemm& g) -> int {
+    int n_off = 0;
+    for (const Piece& pc : g.b) {
+      if (pc.param < 0) {
+        if (hipMemsetAsync(arena + g.b_off + (int64_t)n_off * 4, 0, (size_t)pc.rows * 4, st) != hipSuccess)
+          return CS_EINVAL;
+      } else if (hipMemcpyAsync(arena + g.b_off + (int64_t)n_off * 4, src(pc.param) + pc.row0, (size_t)pc.rows * 4,
+                                hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return CS_EINVAL;
+      n_off += pc.rows;
+    }
+    return CS_OK;
+  };
   for (Gemm& g : u->gemms) {
+    if (g.up_mask) {      // one packed image (pair) per parity class, each with its own power-of-two scale
+      const int ftaps = g.fkd * g.fkh * g.fkw;
+      const int64_t n = (int64_t)g.cout * g.cin * ftaps;
+      for (int c = 0; c < g.ncls; ++c) {
+        const float* w = reinterpret_cast<const float*>(arena + g.fold_off) + c * n;
+        if (f16) {
+          const float m = amax[(size_t)g.amax_slot + c];
+          int ex = 0;
+          if (m > 0.f && std::isfinite(m)) (void)std::frexp((double)m, &ex);
+          const float scale = (float)std::ldexp(1.0, 14 - ex);
+          g.cls_acc_scale[c] = 1.0f / (scale * 16.0f);
+          const int kg = (g.cin + 15) / 16 * 2;
+          const int64_t total = (int64_t)ftaps * kg * g.cout * 8;
+          CS_LAUNCH(pack_part_f16x3_kernel, dim3(cs_grid_for(total, 256, 256 * 32)), dim3(256), 0, st, w,
+                    (_Float16*)(arena + g.cls_w_off[c]), (_Float16*)(arena + g.cls_wlo_off[c]), g.cout, 0, g.cout,
+                    g.cin, ftaps, kg, scale);
+        } else {
+          if (hipMemsetAsync(arena + g.cls_w_off[c], 0, (size_t)ftaps * g.cin_pad * g.ldw * 4, st) != hipSuccess)
+            return CS_EINVAL;
+          const int64_t total = (int64_t)ftaps * g.cin_pad * g.cout;
+          CS_LAUNCH(pack_part_f32_kernel, dim3(cs_grid_for(total, 256)), dim3(256), 0, st, w,
+                    (float*)(arena + g.cls_w_off[c]), g.cout, 0, g.cin, ftaps, g.cin_pad, g.ldw);
+        }
+        CS_CHECK_LAUNCH();
+      }
+      const int rc = copy_bias(g);
+      if (rc != CS_OK) return rc;
+      continue;
+    }
     const int cols = g.cin * g.taps;    // row length of the reference tensor seen as [cout][cin * taps]
     float scale = 1.f;
     if (f16) {
@@ -451,6 +555,31 @@ struct ExecBase {
     q.pd = q.ph = q.pw = pad;
     q.ud = up_d; q.uh = q.uw = up_hw;
     q.act = act; q.rv_rows = rv_rows; q.math = pl.math; q.tile = tile;
+    if (g.up_mask) {
+      // Upsample's conv on the source grid: one GEMM per output parity class + interleave (cs_conv_gemm_up2)
+      if (g.up_mask != ((up_d << 2) | (up_hw << 1) | up_hw) || s_hw != 1 || s_d != 1 || res || rowvec || tile) {
+        chk(CS_EINVAL);
+        return out;
+      }
+      const int64_t ub = cs_conv_gemm_up2_ws_bytes(&q);
+      if (ub <= 0) {
+        chk(CS_EINVAL);
+        return out;
+      }
+      Buf uws = alloc(ub / 4, 1);
+      if (!ok()) return out;
+      if (!dry) {
+        const void* wc[8];
+        const void* wl[8];
+        for (int c = 0; c < g.ncls; ++c) {
+          wc[c] = arena + g.cls_w_off[c];
+          wl[c] = arena + g.cls_wlo_off[c];
+        }
+        chk(cs_conv_gemm_up2(&q, wc, wl, g.cls_acc_scale, p(uws), st));
+      }
+      release(uws);
+      return out;
+    }
     // small batches: few output tiles -> cut the K loop into slices (same plan function the Python host calls)
     int32_t sk = 1;
     int64_t wsb = 0;

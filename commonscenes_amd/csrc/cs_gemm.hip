@@ -402,6 +402,151 @@ extern "C" int cs_conv_gemm(const CsConvGemm* d, cs_stream_t stream) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Nearest x2 upsampling followed by a 3x3x3 stride-1 conv (Upsample: openai_model_3d.py:150-153, vqvae_modules.py:
+// 35-39), computed on the SOURCE grid.  An output voxel 2h'+ph reads upsampled rows 2h'+ph-1 .. 2h'+ph+1, i.e. source
+// rows {h'-1, h', h'} (ph = 0) or {h', h', h'+1} (ph = 1): per output parity the three taps of an upsampled dim
+// collapse to TWO source taps with pre-summed weights ([w0, w1+w2] at offsets {-1, 0}; [w0+w1, w2] at {0, +1}), with the
+// same zero padding.  So the op is 4 (H, W doubled) or 8 (D too) ordinary convs with 3x2x2 / 2x2x2 kernels whose
+// outputs interleave: 12/27 resp. 8/27 of the multiply-adds of the direct form.  Sums of two fp32 weights round once
+// (2^-24 relative), the same order as the fp32 accumulation they replace.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+// w [cout*cin][3][3][3]  ->  wf [cls][cout*cin][kd'][kh'][kw'];  cls = (pd * nh + ph) * nw + pw over the doubled dims
+__global__ __launch_bounds__(256) void fold_upsample_kernel(const float* __restrict__ w, float* __restrict__ wf,
+                                                            int64_t cc, int ud, int uh, int uw) {
+  const int kd = ud ? 2 : 3, kh = uh ? 2 : 3, kw = uw ? 2 : 3;
+  const int nh = uh ? 2 : 1, nw = uw ? 2 : 1;
+  const int taps = kd * kh * kw;
+  const int ncls = (ud ? 2 : 1) * nh * nw;
+  const int64_t total = (int64_t)ncls * cc * taps;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int t = (int)(i % taps);
+    int64_t r = i / taps;
+    const int64_t oc = r % cc;
+    const int cls = (int)(r / cc);
+    const int c = t % kw;
+    t /= kw;
+    const int b = t % kh;
+    const int a = t / kh;
+    const int pw = cls % nw, ph = (cls / nw) % nh, pd = cls / (nw * nh);
+    // source taps of folded tap k at parity p: doubled dim -> (p == 0 ? k == 0 ? {0} : {1, 2} : k == 0 ? {0, 1} : {2})
+    auto lo = [](int u, int p, int k) { return !u ? k : (p == 0 ? (k == 0 ? 0 : 1) : (k == 0 ? 0 : 2)); };
+    auto hi = [](int u, int p, int k) { return !u ? k : (p == 0 ? (k == 0 ? 0 : 2) : (k == 0 ? 1 : 2)); };
+    float acc = 0.f;
+    for (int x = lo(ud, pd, a); x <= hi(ud, pd, a); ++x)
+      for (int y = lo(uh, ph, b); y <= hi(uh, ph, b); ++y)
+        for (int z = lo(uw, pw, c); z <= hi(uw, pw, c); ++z) acc += w[oc * 27 + (x * 3 + y) * 3 + z];
+    wf[i] = acc;
+  }
+}
+
+// tmp [cls][M1][cout] (source-grid outputs per parity class)  ->  out rows of the doubled grid
+__global__ __launch_bounds__(256) void up2_interleave_kernel(const float* __restrict__ tmp, float* __restrict__ out,
+                                                             int64_t m1, int cout, int ldo, int D, int H, int W, int ud,
+                                                             int uh, int uw) {
+  const int nh = uh ? 2 : 1, nw = uw ? 2 : 1;
+  const int cls = blockIdx.y;
+  const int pw = cls % nw, ph = (cls / nw) % nh, pd = cls / (nw * nh);
+  const int c4n = cout >> 2;
+  const int64_t total = m1 * c4n;
+  const float* src = tmp + (int64_t)cls * m1 * cout;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % c4n);
+    int64_t m = i / c4n;
+    const int64_t mm = m;
+    const int w_ = (int)(m % W);
+    m /= W;
+    const int h_ = (int)(m % H);
+    m /= H;
+    const int d_ = (int)(m % D);
+    const int64_t n = m / D;
+    const int64_t orow = ((n * (D << ud) + ((d_ << ud) + pd)) * (H << uh) + ((h_ << uh) + ph)) * (W << uw) + ((w_ << uw) + pw);
+    *reinterpret_cast<f32x4*>(out + orow * ldo + c4 * 4) = *reinterpret_cast<const f32x4*>(src + mm * cout + c4 * 4);
+  }
+}
+
+bool up2_ok(const CsConvGemm& p) {
+  return p.kd == 3 && p.kh == 3 && p.kw == 3 && p.sd == 1 && p.sh == 1 && p.sw == 1 && p.pd == 1 && p.ph == 1 &&
+         p.pw == 1 && (p.ud | p.uh | p.uw) != 0 && p.ud >= 0 && p.ud <= 1 && p.uh >= 0 && p.uh <= 1 && p.uw >= 0 &&
+         p.uw <= 1 && p.dout == (p.din << p.ud) && p.hout == (p.hin << p.uh) && p.wout == (p.win << p.uw) &&
+         !p.res && !p.rowvec && !p.scale && p.act != CS_ACT_GEGLU && (p.cout & 3) == 0 && (p.ldo & 3) == 0 &&
+         p.splitk <= 1;
+}
+
+}  // namespace
+
+extern "C" int cs_conv_up2_info(int ud, int uh, int uw, int32_t* ncls, int32_t* kd, int32_t* kh, int32_t* kw) {
+  if (ud < 0 || ud > 1 || uh < 0 || uh > 1 || uw < 0 || uw > 1 || !(ud | uh | uw)) return CS_EINVAL;
+  if (ncls) *ncls = (ud ? 2 : 1) * (uh ? 2 : 1) * (uw ? 2 : 1);
+  if (kd) *kd = ud ? 2 : 3;
+  if (kh) *kh = uh ? 2 : 3;
+  if (kw) *kw = uw ? 2 : 3;
+  return CS_OK;
+}
+
+extern "C" int cs_fold_upsample_weight(const float* w_torch, float* w_folded, int cout, int cin, int ud, int uh, int uw,
+                                       cs_stream_t stream) {
+  int32_t ncls, kd, kh, kw;
+  if (!w_torch || !w_folded || cout <= 0 || cin <= 0 || cs_conv_up2_info(ud, uh, uw, &ncls, &kd, &kh, &kw)) return CS_EINVAL;
+  const int64_t cc = (int64_t)cout * cin;
+  CS_LAUNCH(fold_upsample_kernel, dim3(cs_grid_for((int64_t)ncls * cc * kd * kh * kw, 256, 256 * 32)), dim3(256), 0,
+            (hipStream_t)stream, w_torch, w_folded, cc, ud, uh, uw);
+  CS_CHECK_LAUNCH();
+  return CS_OK;
+}
+
+extern "C" int64_t cs_conv_gemm_up2_ws_bytes(const CsConvGemm* d) {
+  if (!d || !up2_ok(*d)) return -1;
+  const int64_t m1 = (int64_t)d->nb * d->din * d->hin * d->win;
+  const int ncls = (d->ud ? 2 : 1) * (d->uh ? 2 : 1) * (d->uw ? 2 : 1);
+  CsConvGemm q = *d;
+  q.kd = d->ud ? 2 : 3; q.kh = d->uh ? 2 : 3; q.kw = d->uw ? 2 : 3;
+  q.ud = q.uh = q.uw = 0;
+  q.dout = d->din; q.hout = d->hin; q.wout = d->win;
+  q.tile = 0;
+  const int s = plan_splitk(q, m1);
+  return ((int64_t)ncls + (s > 1 ? s : 0)) * m1 * d->cout * 4;
+}
+
+extern "C" int cs_conv_gemm_up2(const CsConvGemm* d, const void* const* w_cls, const void* const* w_lo_cls,
+                                const float* acc_scale_cls, void* ws, cs_stream_t stream) {
+  if (!d || !w_cls || !ws || !d->x || !d->out || !up2_ok(*d) || ((uintptr_t)ws & 15) || ((uintptr_t)d->out & 15))
+    return CS_EINVAL;
+  const bool f16x3 = d->math == CS_MATH_F16X3;
+  if (f16x3 && (!w_lo_cls || !acc_scale_cls)) return CS_EINVAL;
+  const int64_t m1 = (int64_t)d->nb * d->din * d->hin * d->win;
+  if (m1 > 0x7fffffffLL) return CS_EINVAL;
+  const int nh = d->uh ? 2 : 1, nw = d->uw ? 2 : 1;
+  const int ncls = (d->ud ? 2 : 1) * nh * nw;
+  float* tmp = reinterpret_cast<float*>(ws);
+  for (int cls = 0; cls < ncls; ++cls) {
+    const int pw = cls % nw, ph = (cls / nw) % nh, pd = cls / (nw * nh);
+    CsConvGemm q = *d;
+    q.kd = d->ud ? 2 : 3; q.kh = d->uh ? 2 : 3; q.kw = d->uw ? 2 : 3;
+    q.pd = d->ud ? 1 - pd : 1; q.ph = d->uh ? 1 - ph : 1; q.pw = d->uw ? 1 - pw : 1;
+    q.ud = q.uh = q.uw = 0;
+    q.dout = d->din; q.hout = d->hin; q.wout = d->win;
+    q.w = reinterpret_cast<const float*>(w_cls[cls]);
+    q.w_lo = f16x3 ? w_lo_cls[cls] : nullptr;
+    if (f16x3) q.acc_scale = acc_scale_cls[cls];
+    q.out = tmp + (int64_t)cls * m1 * d->cout;
+    q.ldo = d->cout;
+    q.tile = 0;
+    const int s = plan_splitk(q, m1);
+    q.splitk = s > 1 ? s : 0;
+    q.splitk_ws = s > 1 ? (void*)(tmp + (int64_t)ncls * m1 * d->cout) : nullptr;
+    const int rc = cs_conv_gemm(&q, stream);
+    if (rc != CS_OK) return rc;
+  }
+  const int64_t units = m1 * (d->cout >> 2);
+  CS_LAUNCH(up2_interleave_kernel, dim3(cs_grid_for(units, 256, 256 * 8), ncls), dim3(256), 0, (hipStream_t)stream, tmp,
+            d->out, m1, d->cout, d->ldo, d->din, d->hin, d->win, d->ud, d->uh, d->uw);
+  CS_CHECK_LAUNCH();
+  return CS_OK;
+}
+
 static void fill_conv(CsConvGemm& p, const float* x, const float* w, const float* bias, float* out,
                       int nb, int d, int h, int w_, int cin, int cout, int sh, int sw) {
   p = CsConvGemm{};
@@ -454,4 +599,4 @@ extern "C" int cs_relayout_weight(const float* w_torch, float* w_out, int cout, 
   return CS_OK;
 }
 
-extern "C" int cs_abi_version(void) { return 9; }
+extern "C" int cs_abi_version(void) { return 10; }

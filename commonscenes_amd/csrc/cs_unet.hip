@@ -221,7 +221,8 @@ int build(cs_unet& u) {
         Layer l{};
         l.kind = UP;
         l.cin = l.cout = ch;
-        l.g[0] = add_layer_gemm(u, bp + "." + std::to_string(layers.size()) + ".conv", ch, ch, 3);
+        l.g[0] = add_layer_gemm(u, bp + "." + std::to_string(layers.size()) + ".conv", ch, ch, 3, true, 0,
+                                c.dims == 3 ? 3 : 7);      // Upsample: H, W doubled (dims = 3) or D, H, W
         layers.push_back(l);
         ds /= 2;
       }

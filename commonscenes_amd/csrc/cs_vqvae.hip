@@ -82,7 +82,8 @@ int build(cs_vqvae& u) {
       block_in = block_out;
     }
     if (lvl != 0)
-      u.up_conv[lvl] = add_layer_gemm(u, D + "up." + std::to_string(lvl) + ".upsample.conv", block_in, block_in, 3);
+      u.up_conv[lvl] = add_layer_gemm(u, D + "up." + std::to_string(lvl) + ".upsample.conv", block_in, block_in, 3,
+                                      true, 0, 7);
   }
   u.c_final = block_in;
   u.n_out = add_norm(u, D + "norm_out", block_in);

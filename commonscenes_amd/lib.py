@@ -17,7 +17,7 @@ import torch  # noqa: F401
 
 from .build import LIB_PATH
 
-ABI_VERSION = 9      # cs_abi_version() of the library this module's SIGNATURES table describes
+ABI_VERSION = 10     # cs_abi_version() of the library this module's SIGNATURES table describes
 CS_OK = 0
 CS_EINVAL = -22
 CS_ENOMEM = -12
@@ -80,6 +80,11 @@ _pp = C.POINTER(C.c_void_p)
 SIGNATURES = {
     "cs_conv_gemm": (_i, [C.POINTER(CsConvGemm), _s]),
     "cs_conv_gemm_plan": (_i, [C.POINTER(CsConvGemm), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    "cs_conv_up2_info": (_i, [_i, _i, _i, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                              C.POINTER(C.c_int32)]),
+    "cs_fold_upsample_weight": (_i, [_f, _f, _i, _i, _i, _i, _i, _s]),
+    "cs_conv_gemm_up2_ws_bytes": (_l, [C.POINTER(CsConvGemm)]),
+    "cs_conv_gemm_up2": (_i, [C.POINTER(CsConvGemm), _pp, _pp, C.POINTER(C.c_float), C.c_void_p, _s]),
     "cs_conv3d_3x3x3_s111": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _s]),
     "cs_conv3d_3x3x3_s122": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _s]),
     "cs_gemm_tokens": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _s]),

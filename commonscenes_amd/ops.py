@@ -128,11 +128,19 @@ class PackedWeight:
     wh: Optional[Tensor] = None      # CS_MATH_F16X3: hi / lo fp16 halves, [tap][cin16/8][cout][8]
     wl: Optional[Tensor] = None
     acc_scale: float = 1.0
+    # nearest-x2-upsample + 3x3x3 conv folded onto the source grid (cs_conv_gemm_up2): the doubled dims and one
+    # PackedWeight per output parity class (3x2x2 / 2x2x2 kernels with pre-summed taps); wt / wh / wl are then unused
+    up: Optional[Tuple[int, int, int]] = None
+    classes: Optional[list] = None
 
 
 def pack_weight(w: Tensor, bias: Optional[Tensor] = None, cin_pad: Optional[int] = None,
-                math: int = L.MATH_FP32) -> PackedWeight:
-    """torch Conv3d (cout,cin,kd,kh,kw) or Linear (out,in) weight -> PackedWeight (device op)."""
+                math: int = L.MATH_FP32, fold_up: Optional[Sequence[int]] = None) -> PackedWeight:
+    """torch Conv3d (cout,cin,kd,kh,kw) or Linear (out,in) weight -> PackedWeight (device op).
+    fold_up=(ud,uh,uw): the conv follows a nearest x2 upsampling of the flagged dims; its taps are pre-summed per output
+    parity class (cs_fold_upsample_weight) and conv_gemm(..., up=fold_up) runs on the source grid."""
+    if fold_up is not None and any(fold_up) and FOLD_UPSAMPLE:
+        return _pack_weight_folded(w, bias, cin_pad, math, tuple(int(u) for u in fold_up))
     if math == L.MATH_F16X3:
         return _pack_weight_f16x3(w, bias, cin_pad)
     _chk(w, "weight")
@@ -158,6 +166,27 @@ def pack_weight(w: Tensor, bias: Optional[Tensor] = None, cin_pad: Optional[int]
 
 
 A_SCALE = 16.0      # activation pre-scale of the f16x3 mode (CsConvGemm.a_scale); power of two
+
+
+# CS_NO_UPFOLD=1: upsample convs take the direct form (27 taps on the doubled grid) -- A/B runs
+FOLD_UPSAMPLE = not os.environ.get("CS_NO_UPFOLD")
+
+
+def _pack_weight_folded(w: Tensor, bias: Optional[Tensor], cin_pad: Optional[int], math: int,
+                        up: Tuple[int, int, int]) -> PackedWeight:
+    _chk(w, "weight")
+    if w.dim() != 5 or tuple(w.shape[2:]) != (3, 3, 3):
+        raise L.CsError("fold_up needs a 3x3x3 conv weight")
+    lib = L.load()
+    cout, cin = w.shape[:2]
+    n, kd, kh, kw = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    L.check(lib.cs_conv_up2_info(*up, C.byref(n), C.byref(kd), C.byref(kh), C.byref(kw)), "cs_conv_up2_info")
+    wf = torch.empty((n.value, cout, cin, kd.value, kh.value, kw.value), dtype=torch.float32, device=w.device)
+    L.check(lib.cs_fold_upsample_weight(w.contiguous().data_ptr(), wf.data_ptr(), cout, cin, *up, _stream()),
+            "cs_fold_upsample_weight")
+    classes = [pack_weight(wf[c], bias, cin_pad, math) for c in range(n.value)]
+    c0 = classes[0]
+    return PackedWeight(None, c0.bias, cout, cin, c0.cin_pad, c0.ldw, (3, 3, 3), math, None, None, 1.0, up, classes)
 
 
 def _pack_weight_f16x3(w: Tensor, bias: Optional[Tensor], cin_pad: Optional[int]) -> PackedWeight:
@@ -259,7 +288,17 @@ def conv_gemm(x: Tensor, w: PackedWeight, *, spatial: Optional[Tuple[int, int, i
         raise L.CsError(f"out has shape {tuple(out.shape)}, expected {mo} rows x {w.cout}")
     p = L.CsConvGemm()
     math = w.math                      # the numerics mode is a property of how the weight was packed
-    if math == L.MATH_F16X3:
+    folded = w.classes is not None
+    if folded and (tuple(up) != tuple(w.up) or tuple(stride) != (1, 1, 1) or tile or splitk):
+        raise L.CsError(f"weight was folded for up={w.up}: conv_gemm must be called with that up, stride 1, no tile / splitk")
+    if folded:
+        p.x, p.out = x.data_ptr(), out.data_ptr()
+        if math == L.MATH_F16X3:
+            p.a_scale = A_SCALE
+            if xs is not None:
+                p.x_lo, p.a_format = xs.lo.data_ptr(), 1
+            p.status = status_word(x.device).data_ptr()
+    elif math == L.MATH_F16X3:
         p.x, p.w, p.w_lo, p.out = x.data_ptr(), w.wh.data_ptr(), w.wl.data_ptr(), out.data_ptr()
         p.acc_scale = w.acc_scale
         p.a_scale = A_SCALE
@@ -299,6 +338,8 @@ def conv_gemm(x: Tensor, w: PackedWeight, *, spatial: Optional[Tuple[int, int, i
         tile = tile_for(mo, w.cout, 0, math, act=act)          # what the library picks without tile 5
     p.act, p.rv_rows, p.math, p.tile = act, rv_rows, math, tile
     lib = L.load()
+    if folded:
+        return _conv_gemm_up2(lib, p, w, x, out, mo)
     if splitk is not None and splitk > 1:            # explicit split-K factor (tuning / tests); the plan is bypassed
         ws = torch.empty((splitk * mo * w.cout,), dtype=torch.float32, device=x.device)
         p.splitk, p.splitk_ws = int(splitk), ws.data_ptr()
@@ -322,6 +363,34 @@ def conv_gemm(x: Tensor, w: PackedWeight, *, spatial: Optional[Tuple[int, int, i
                          m=mo, n=w.cout, k=w.cin * kd * kh * kw, tile=tile_for(mo, w.cout, tile, w.math, cin=w.cin, pointwise=pointwise,
                                                                   bn=scale is not None, act=act,
                                                                   rv_rows=rv_rows if rowvec is not None else 0)))
+    return out
+
+
+def _conv_gemm_up2(lib, p, w: PackedWeight, x: Tensor, out: Tensor, mo: int) -> Tensor:
+    """upsample + conv on the source grid: one GEMM per output parity class into a scratch tensor, then the interleave
+    (cs_conv_gemm_up2); the library splits K per class where the plan says so."""
+    n = len(w.classes)
+    wsb = lib.cs_conv_gemm_up2_ws_bytes(C.byref(p))
+    if wsb <= 0:
+        raise L.CsError("cs_conv_gemm_up2: descriptor not supported (residual / row vector / BN / odd cout)")
+    ws = torch.empty((wsb // 4,), dtype=torch.float32, device=x.device)
+    f16 = w.math == L.MATH_F16X3
+    w_arr = (C.c_void_p * n)(*[(c.wh if f16 else c.wt).data_ptr() for c in w.classes])
+    lo_arr = (C.c_void_p * n)(*[(c.wl.data_ptr() if f16 else 0) for c in w.classes])
+    sc_arr = (C.c_float * n)(*[c.acc_scale for c in w.classes])
+    prof = GEMM_PROFILE
+    if prof is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+    L.check(lib.cs_conv_gemm_up2(C.byref(p), w_arr, lo_arr, sc_arr, ws.data_ptr(), _stream()), "cs_conv_gemm_up2")
+    if prof is not None:
+        e1.record()
+        kd, kh, kw = w.classes[0].k
+        m1 = mo // n
+        # executed multiply-adds (all classes); the direct form's 27-tap count is 27 / (kd * kh * kw) times this
+        prof.append(dict(e0=e0, e1=e1, flops=2.0 * mo * w.cout * w.cin * kd * kh * kw, taps=kd * kh * kw, m=m1,
+                         n=w.cout, k=w.cin * kd * kh * kw, tile=tile_for(m1, w.cout, 0, w.math, cin=w.cin)))
     return out
 
 

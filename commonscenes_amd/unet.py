@@ -275,6 +275,11 @@ class DiffusionUNet:
         return n
 
     # ---- weight packing -------------------------------------------------------------------
+    @property
+    def _up(self):
+        """dims == 3: Upsample doubles the inner two dims only (openai_model_3d.py:150-153); dims == 4: all three."""
+        return (0, 1, 1) if self.cfg["dims"] == 3 else (1, 1, 1)
+
     def _pack(self):
         if self.device.type != "cuda":
             raise L.CsError("DiffusionUNet: weights must be on the HIP device (no CPU path)")
@@ -284,8 +289,9 @@ class DiffusionUNet:
             raise RuntimeError(f"DiffusionUNet: weights not loaded ({len(missing)} tensors missing)")
         pk: Dict[str, object] = {}
 
-        def pw(p, cin_pad=None):
-            pk[p] = ops.pack_weight(sd[p + ".weight"], sd.get(p + ".bias"), cin_pad=cin_pad, math=self.math)
+        def pw(p, cin_pad=None, fold_up=None):
+            pk[p] = ops.pack_weight(sd[p + ".weight"], sd.get(p + ".bias"), cin_pad=cin_pad, math=self.math,
+                                    fold_up=fold_up)
 
         pw(P + "time_embed.0")
         pw(P + "time_embed.2")
@@ -332,8 +338,8 @@ class DiffusionUNet:
                     pw(t + ".ff.net.2")
                 elif k == "down":
                     pw(p + ".op")
-                elif k == "up":
-                    pw(p + ".conv")
+                elif k == "up":        # Upsample's conv runs on the source grid with per-parity pre-summed taps
+                    pw(p + ".conv", fold_up=self._up)
 
         for i, layers in enumerate(inp):
             pack_block(f"{P}input_blocks.{i}", layers)
@@ -471,8 +477,7 @@ class DiffusionUNet:
                 h = ops.conv_gemm(h, pk[p + ".op"], stride=(1, 2, 2) if self.cfg["dims"] == 3 else (2, 2, 2),
                                   math=self.math, out_fn=of)
             elif k == "up":        # nearest x2 folded into the conv's addressing (openai_model_3d.py:148-157)
-                h = ops.conv_gemm(h, pk[p + ".conv"], up=(0, 1, 1) if self.cfg["dims"] == 3 else (1, 1, 1),
-                                  math=self.math, out_fn=of)
+                h = ops.conv_gemm(h, pk[p + ".conv"], up=self._up, math=self.math, out_fn=of)
         return h
 
     @torch.no_grad()

@@ -166,7 +166,10 @@ class VQVAE:
                     pk[p] = ops.pack_weight(wz, bz, cin_pad=(wz.shape[1] + 3) // 4 * 4, math=self.math)
                     continue
                 cin = sd[k].shape[1]
-                pk[p] = ops.pack_weight(sd[k], sd.get(p + ".bias"), cin_pad=(cin + 3) // 4 * 4, math=self.math)
+                # Upsample's conv (vqvae_modules.py:35-39: nearest x2 in D, H, W) runs on the source grid
+                fold = (1, 1, 1) if p.endswith(".upsample.conv") else None
+                pk[p] = ops.pack_weight(sd[k], sd.get(p + ".bias"), cin_pad=(cin + 3) // 4 * 4, math=self.math,
+                                        fold_up=fold)
         a = "decoder.mid.attn_1."
         wqkv = torch.cat([sd[a + "q.weight"], sd[a + "k.weight"], sd[a + "v.weight"]], dim=0)
         bqkv = torch.cat([sd[a + "q.bias"], sd[a + "k.bias"], sd[a + "v.bias"]], dim=0)

@@ -118,6 +118,29 @@ int cs_conv_gemm(const CsConvGemm* desc, cs_stream_t stream);
  * needs; host-only, no device work.  A caller that wants it sets desc->splitk / desc->splitk_ws accordingly. */
 int cs_conv_gemm_plan(const CsConvGemm* desc, int32_t* splitk, int64_t* splitk_ws_bytes);
 
+/*
+ * Nearest x2 upsampling (in the dims flagged by ud / uh / uw, each 0 or 1) followed by a 3x3x3 stride-1 "same" conv
+ * (Upsample: openai_model_3d.py:150-153 doubles H and W for dims=3, all three for dims=4; vqvae_modules.py:35-39 all
+ * three), evaluated on the source grid: per output parity class the three taps of a doubled dim collapse to two source
+ * taps with pre-summed weights, so the op is 4 / 8 convs with 3x2x2 / 2x2x2 kernels -- 12/27 resp. 8/27 of the direct
+ * form's multiply-adds -- whose outputs interleave.
+ *   cs_conv_up2_info         class count and folded kernel extents for a choice of doubled dims
+ *   cs_fold_upsample_weight  w_torch [cout][cin][3][3][3] -> w_folded [cls][cout][cin][kd'][kh'][kw'] (fp32 sums in a
+ *                            fixed order); class = (pd * nh + ph) * nw + pw.  Each class is then packed like any conv
+ *                            weight (cs_relayout_weight / cs_pack_weight_f16x3 with taps = kd' * kh' * kw')
+ *   cs_conv_gemm_up2         desc describes the WHOLE op exactly as cs_conv_gemm would take it (x on the source grid,
+ *                            ud/uh/uw, dout = din << ud ..., out / ldo on the doubled grid, bias and activation
+ *                            allowed; no residual / row vector / BN); desc->w, w_lo, acc_scale are ignored in favour
+ *                            of the per-class arrays (host arrays of device pointers; w_lo_cls and acc_scale_cls only
+ *                            for CS_MATH_F16X3).  ws: cs_conv_gemm_up2_ws_bytes(desc) bytes, 16-byte aligned.
+ */
+int cs_conv_up2_info(int ud, int uh, int uw, int32_t* ncls, int32_t* kd, int32_t* kh, int32_t* kw);
+int cs_fold_upsample_weight(const float* w_torch, float* w_folded, int cout, int cin, int ud, int uh, int uw,
+                            cs_stream_t stream);
+int64_t cs_conv_gemm_up2_ws_bytes(const CsConvGemm* desc);
+int cs_conv_gemm_up2(const CsConvGemm* desc, const void* const* w_cls, const void* const* w_lo_cls,
+                     const float* acc_scale_cls, void* ws, cs_stream_t stream);
+
 /* Convenience entries named in SURVEY.md section 8b (thin wrappers over cs_conv_gemm). */
 int cs_conv3d_3x3x3_s111(const float* x, const float* w, const float* bias, float* out,
                          int nb, int d, int h, int w_, int cin, int cout, cs_stream_t stream);

@@ -114,6 +114,48 @@ def test_f16x3_slab_conv_keeps_samples_independent():
     assert torch.isnan(dirty[2]).all()
 
 
+@pytest.mark.parametrize("case", [
+    # nb, d, h, w (source grid), cin, cout, up, math
+    (2, 6, 5, 7, 24, 224, (0, 1, 1), "f16x3"),       # the UNet's Upsample (dims = 3: H and W doubled)
+    (2, 6, 5, 7, 24, 224, (0, 1, 1), "fp32"),
+    (1, 4, 5, 3, 16, 64, (1, 1, 1), "f16x3"),        # the VQ decoder's / dims = 4 (all three doubled)
+    (3, 2, 2, 2, 20, 36, (1, 1, 1), "fp32"),         # cin not a multiple of 16, cout of 4 only
+    (1, 1, 1, 1, 8, 8, (1, 1, 1), "f16x3"),          # a single source voxel
+    (1, 16, 8, 8, 32, 448, (0, 1, 1), "f16x3"),      # enough rows for the 256-row tile and the slab-less 12-tap path
+])
+def test_upsample_conv_folded_onto_the_source_grid(case):
+    """nearest x2 + 3x3x3 conv == per output parity class a conv with two pre-summed taps per doubled dim on the source
+    grid (cs_conv_gemm_up2).  Against the fp64 direct form, next to the direct kernel path (27 taps, upsampling as
+    addressing) it replaces."""
+    from commonscenes_amd import lib as L, ops
+    from oracle import ref_ops as R
+    nb, d, h, w, cin, cout, up, math = case
+    m = L.MATH_F16X3 if math == "f16x3" else L.MATH_FP32
+    x = _rand(nb, d, h, w, cin, seed=51)
+    wt = _rand(cout, cin, 3, 3, 3, seed=52, scale=(cin * 27) ** -0.5)
+    b = _rand(cout, seed=53)
+    ref = R.conv_ndhwc(x.double(), wt.double(), b.double(), (1, 1, 1), up)
+    xd = x.cuda()
+    pk = ops.pack_weight(wt.cuda(), b.cuda(), math=m, fold_up=up)
+    assert pk.classes is not None and len(pk.classes) == 2 ** sum(up)
+    out = ops.conv_gemm(xd, pk, up=up)
+    out2 = ops.conv_gemm(xd, pk, up=up)
+    direct = ops.conv_gemm(xd, ops.pack_weight(wt.cuda(), b.cuda(), math=m), up=up)
+    torch.cuda.synchronize()
+    assert out.shape == direct.shape == ref.shape
+    assert torch.equal(out, out2)
+    e, ed = rel_l2(out, ref), rel_l2(direct, ref)
+    print(f"upsample conv {case}: folded {e:.2e}, direct {ed:.2e}")
+    assert e < 2e-6 and e < 3 * ed + 3e-7
+    # placement into a wider (concatenation) buffer: only the slice's columns are written
+    wide = torch.full((*out.shape[:-1], cout + 8), 7.0, device="cuda")
+    ops.conv_gemm(xd, pk, up=up, out=wide[..., 4:4 + cout])
+    torch.cuda.synchronize()
+    assert torch.equal(wide[..., 4:4 + cout], out) and bool((wide[..., :4] == 7).all()) and bool((wide[..., -4:] == 7).all())
+    with pytest.raises(L.CsError):
+        ops.conv_gemm(xd, pk)                      # a folded weight only serves the upsampling it was folded for
+
+
 def test_f16x3_wide_dynamic_range():
     """weights spanning 1e-5..1, activations with outliers and tiny values: the split keeps absolute accuracy."""
     from commonscenes_amd import lib as L, ops
