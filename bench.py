@@ -43,9 +43,13 @@ import torch.distributed as dist  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X dense fp32-input MFMA peak (MI355X_MICROARCH.md)
 F16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
-TILE_NAMES = {1: "<2,2,2,2,false> (128x128", 2: "<1,7,4,1,false> (128x224", 3: "<1,1,2,2,false> (64x64",
-              4: "<1,7,8,1,false> (256x224", 5: "persistent ping-pong 2x128x224", 6: "<1,4,8,1,false> (256x128",
-              7: "<1,2,8,1,false> (256x64"}
+# kernel instantiation per (tile code, slab): the last template argument is the slab width (0 = per-tap A gather; 32 / 64 =
+# A operand of 3x3x3 stride-1 convs staged as one slab per (kd, channel chunk), cs_gemm_f16x3.hip)
+TILE_NAMES = {(1, 0): "<2,2,2,2,false,0> (128x128", (2, 0): "<1,7,4,1,false,0> (128x224", (3, 0): "<1,1,2,2,false,0> (64x64",
+              (4, 0): "<1,7,8,1,false,0> (256x224", (5, 0): "persistent ping-pong 2x128x224",
+              (6, 0): "<1,4,8,1,false,0> (256x128", (7, 0): "<1,2,8,1,false,0> (256x64",
+              (4, 32): "<1,7,8,1,false,32> (256x224, A slab", (6, 32): "<1,4,8,1,false,32> (256x128, A slab",
+              (7, 32): "<1,2,8,1,false,32> (256x64, A slab", (7, 64): "<1,2,8,1,false,64> (256x64, A slab"}
 
 
 def parse():
@@ -103,11 +107,12 @@ def gemm_summary(prof, wall_ms, math):
     """dominant tile instantiation of a HIP-event profile: achieved TF/s, both roofline conventions."""
     by_tile = {}
     for r in prof:
-        by_tile[r["tile"]] = by_tile.get(r["tile"], 0.0) + r["e0"].elapsed_time(r["e1"])
+        k = (r["tile"], r.get("slab", 0))
+        by_tile[k] = by_tile.get(k, 0.0) + r["e0"].elapsed_time(r["e1"])
     if not by_tile:
         return None
     dom = max(by_tile, key=by_tile.get)
-    sel = [r for r in prof if r["tile"] == dom]
+    sel = [r for r in prof if (r["tile"], r.get("slab", 0)) == dom]
     ms = sum(r["e0"].elapsed_time(r["e1"]) for r in sel)
     fl = sum(r["flops"] for r in sel)
     all_ms = sum(r["e0"].elapsed_time(r["e1"]) for r in prof)
@@ -259,6 +264,10 @@ def main():
         if rank == 0:
             decode = {"objects": B, "ms": dec_s * 1e3, "ms_per_object": dec_s * 1e3 / B,
                       "algorithmic_gflop_per_object": K.VQ_DECODE_GFLOP_PER_OBJECT, "whole_decode_tflops": dec_tf,
+                      "executed_gflop_per_object": (K.VQ_DECODE_GFLOP_EXECUTED_PER_OBJECT if ops.FOLD_UPSAMPLE
+                                                    else K.VQ_DECODE_GFLOP_PER_OBJECT),
+                      "flop_note": "whole_decode_tflops prices the reference's direct-form work; the two Upsample convs "
+                                   "run folded onto the source grid (8/27 of their multiply-adds, cs_conv_gemm_up2)",
                       "whole_decode_frac_of_peak": dec_tf / (F16_MFMA_PEAK_TFLOPS / 3.0 if a.math == "f16x3"
                                                              else FP32_MFMA_PEAK_TFLOPS),
                       "finite": bool(torch.isfinite(allsdf).all().item()), "gathered_shape": list(allsdf.shape),
@@ -319,7 +328,7 @@ def main():
         if a.gemm_table:
             agg = {}
             for r in prof:
-                k = (r["taps"], r["m"], r["k"], r["n"], r["tile"])
+                k = (r["taps"], r["m"], r["k"], r["n"], r["tile"] + (100 if r.get("slab") else 0))
                 t = agg.setdefault(k, [0, 0.0, 0.0])
                 t[0] += 1
                 t[1] += r["e0"].elapsed_time(r["e1"])
@@ -339,6 +348,11 @@ def main():
         roof["traffic_note"] = ("HBM bytes per launch of the dominant kernel, FETCH_SIZE x2 (gfx950) + WRITE_SIZE, from "
                                 "separate rocprofv3 --pmc passes of this command (tools/pmc_traffic.sh)")
         roof["whole_step_tflops"] = (2 * B * K.UNET_GFLOP_PER_SAMPLE * 1e9 * a.steps / dt / 1e12) if not a.small else None
+        ex = K.UNET_GFLOP_EXECUTED_PER_SAMPLE if ops.FOLD_UPSAMPLE else K.UNET_GFLOP_PER_SAMPLE
+        roof["whole_step_executed_tflops"] = (2 * B * ex * 1e9 * a.steps / dt / 1e12) if not a.small else None
+        roof["whole_step_note"] = ("whole_step_tflops prices the reference's direct-form work (557.9 GFLOP per UNet sample); "
+                                   "the two Upsample convs run folded onto the source grid (12/27 of their multiply-adds, "
+                                   "cs_conv_gemm_up2), so the issued algorithmic work is whole_step_executed_tflops")
         res = {
             "metric": "DDIM denoise steps/sec (32 objects, 16^3 latent)",
             "value": world * a.steps / dt,

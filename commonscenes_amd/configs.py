@@ -22,6 +22,11 @@ DIFFUSION = dict(linear_start=0.00085, linear_end=0.012, timesteps=1000)
 # algorithmic work, used by bench.py's roofline blocks
 UNET_GFLOP_PER_SAMPLE = 557.9        # conv3 471.3 + linear 62.0 + conv1 13.9 + self-attention 10.45 + norms 0.3
 VQ_DECODE_GFLOP_PER_OBJECT = 723.4   # conv3 696.9 + conv1 8.6 + GroupNorm 0.7 + attention 17.2
+# ... of which the Upsample convs (69.4 / 347.9 GFLOP in the direct, 27-tap form) are EXECUTED on the source grid with
+# pre-summed taps (cs_conv_gemm_up2): 12/27 of their multiply-adds in the UNet (H, W doubled), 8/27 in the decoder.
+# Throughput figures quoted on the algorithmic numbers above therefore overstate the issued arithmetic by these ratios:
+UNET_GFLOP_EXECUTED_PER_SAMPLE = 557.9 - 38.5        # 519.4
+VQ_DECODE_GFLOP_EXECUTED_PER_OBJECT = 723.4 - 244.8  # 478.6
 
 
 def reduced(cfg: dict, model_channels: int = 32) -> dict:

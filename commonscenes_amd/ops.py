@@ -359,10 +359,11 @@ def conv_gemm(x: Tensor, w: PackedWeight, *, spatial: Optional[Tuple[int, int, i
     L.check(lib.cs_conv_gemm(C.byref(p), _stream()), "cs_conv_gemm")
     if prof is not None:
         e1.record()
+        tl = tile_for(mo, w.cout, tile, w.math, cin=w.cin, pointwise=pointwise, bn=scale is not None, act=act,
+                      rv_rows=rv_rows if rowvec is not None else 0)
         prof.append(dict(e0=e0, e1=e1, flops=2.0 * mo * w.cout * w.cin * kd * kh * kw, taps=kd * kh * kw,
-                         m=mo, n=w.cout, k=w.cin * kd * kh * kw, tile=tile_for(mo, w.cout, tile, w.math, cin=w.cin, pointwise=pointwise,
-                                                                  bn=scale is not None, act=act,
-                                                                  rv_rows=rv_rows if rowvec is not None else 0)))
+                         m=mo, n=w.cout, k=w.cin * kd * kh * kw, tile=tl,
+                         slab=slab_width(tl, (kd, kh, kw), stride, up, wd, math, xs is not None, p.splitk)))
     return out
 
 
@@ -433,6 +434,16 @@ def tile_for(m: int, cout: int, tile: int = 0, math: int = L.MATH_FP32, cin: int
     else:
         t = 3
     return 2 if act == L.ACT_GEGLU else t
+
+
+def slab_width(tile: int, k, stride, up, win: int, math: int, presplit: bool, splitk: int) -> int:
+    """mirror of the slab dispatch in cs_conv_gemm_f16x3_dispatch (csrc/cs_gemm_f16x3.hip): 0 = per-tap gather."""
+    if (math != L.MATH_F16X3 or presplit or splitk > 1 or tuple(k) != (3, 3, 3) or tuple(stride) != (1, 1, 1)
+            or tuple(up) != (0, 0, 0) or tile not in (4, 6, 7) or win > 64):
+        return 0
+    if win <= 32:
+        return 32
+    return 64 if tile == 7 else 0
 
 
 def linear(x: Tensor, w: PackedWeight, **kw) -> Tensor:
