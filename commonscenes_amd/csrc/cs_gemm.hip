@@ -260,10 +260,23 @@ namespace {
 // the largest POWER OF TWO that keeps tiles x slices <= 512 (odd counts fight the XCD-aware tile map: 11 slices of a
 // 48-tile GEMM ran 247 us, 8 slices 178), at least 8 K chunks per slice, at most 32 slices; K loops under 64 chunks
 // (the C x C token GEMMs) are not split -- the 64x64 tile fills the chip better there.
+// Large batches: a 3x3x3 conv whose 256x224 tiles fill the chip's 256 CUs unevenly (the 4^3 level has three column
+// tiles: 64 x 3 = 192 workgroups at 32 objects, a quarter of the CUs idle) is cut into FOUR K slices -- 768 workgroups,
+// three even rounds -- whenever it has an odd number of column tiles and a long K loop.  The rule looks at K and N only
+// (not at the batch beyond "large"), so a shard of a batch and the whole batch add their products in the same order.
+bool split4_large(const CsConvGemm& p, int64_t M) {
+  return p.kd == 3 && p.kh == 3 && p.kw == 3 && p.sd == 1 && p.sh == 1 && p.sw == 1 && !(p.ud | p.uh | p.uw) &&
+         p.a_format == 0 && ((p.cout / 224) & 1) && p.cout / 224 >= 3 && (p.cin + 15) / 16 >= 16 &&
+         ((M + 255) / 256) * (int64_t)(p.cout / 224) >= 192;
+}
+
 int plan_splitk(const CsConvGemm& p, int64_t M) {
   if (p.math != CS_MATH_F16X3 || p.act == CS_ACT_GEGLU || p.tile != 0 || p.cout % 224) return 1;
   const int64_t wgs = ((M + 127) / 128) * (p.cout / 224);
   const int64_t nk = (int64_t)p.kd * p.kh * p.kw * ((p.cin + 15) / 16);
+#ifndef CS_NO_SPLIT4
+  if (split4_large(p, M)) return 4;
+#endif
 #ifndef CS_PLAN_R1
   if (wgs >= 384) return 1;
 #else
@@ -382,7 +395,8 @@ extern "C" int cs_conv_gemm(const CsConvGemm* d, cs_stream_t stream) {
     part.ldo = p.cout;
     part.bias = part.scale = part.shift = part.rowvec = part.res = nullptr;
     part.act = CS_ACT_NONE;
-    const int rc = cs_conv_gemm_f16x3_dispatch(part, M, 2, p.splitk, s);
+    // small batches: 128x224 tiles; the large-batch four-way cut (plan_splitk) keeps the 256x224 slab kernel
+    const int rc = cs_conv_gemm_f16x3_dispatch(part, M, split4_large(p, M) ? 4 : 2, p.splitk, s);
     if (rc != CS_OK) return rc;
     CS_LAUNCH(splitk_reduce_kernel, dim3(cs_grid_for((int64_t)M * (p.cout >> 2), 256)), dim3(256), 0, s, p,
               reinterpret_cast<const float*>(p.splitk_ws), M, p.splitk);

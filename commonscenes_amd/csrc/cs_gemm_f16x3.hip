@@ -192,8 +192,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   const float a_scale = p.a_scale;
   const int chunks_per_tap = kg_per_tap >> 1;   // cin16 / 16
   const int nk_all = ntaps * chunks_per_tap;
-  const int per_split = (nk_all + splits - 1) / splits;
-  const int k_first = split * per_split;                        // this workgroup's slice of the chunk sequence
+  // this workgroup's slice of the chunk sequence (slab path: whole super-chunks of nine taps)
+  constexpr int KGRAN = SLAB ? 9 : 1;
+  const int per_split = ((nk_all / KGRAN + splits - 1) / splits) * KGRAN;
+  const int k_first = split * per_split;
   const int nk = max(0, min(nk_all, k_first + per_split) - k_first);
 
   // ---- per-lane DMA constants ----
@@ -403,10 +405,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   h8 ah[WMB], al[WMB];
   if constexpr (SLAB != 0) {
     // the prologue above issued B(0), B(1); the first slab goes out now and is the youngest: wait for everything
-    issue_slab(0);
+    const int sc0 = k_first / 9;
+    issue_slab(sc0);
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-    load_a_slab(std::integral_constant<int, 0>{}, 0, vmask & 0x1FFu, ah[0], al[0]);
+    load_a_slab(std::integral_constant<int, 0>{}, sc0 & 1, (vmask >> (9 * (sc0 % 3))) & 0x1FFu, ah[0], al[0]);
   } else {
   wait_vmcnt<(PF - 1) * D>();          // chunk 0 (issued first) has landed for this wave
   __builtin_amdgcn_s_barrier();
@@ -487,9 +490,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   };
   if constexpr (SLAB != 0) {
     static_assert(NSTAGE == 3 && PF == 2, "nine taps = three turns of the ring");
-    const int nsc = nk / 9;
-    int kdc = 0;                                            // kd of the super-chunk
-    for (int sc = 0; sc < nsc; ++sc) {
+    const int sc_first = k_first / 9, sc_end = sc_first + nk / 9;
+    int kdc = sc_first % 3;                                 // kd of the super-chunk
+    for (int sc = sc_first; sc < sc_end; ++sc) {
       const int kdn = kdc == 2 ? 0 : kdc + 1;
       const unsigned m9 = (vmask >> (9 * kdc)) & 0x1FFu, m9n = (vmask >> (9 * kdn)) & 0x1FFu;
       sstep(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, sc, m9, m9n);
@@ -862,7 +865,7 @@ int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p_in, int M, int tile, int spl
 #ifndef CS_NO_SLAB      // (A/B timing builds: -DCS_NO_SLAB keeps the per-tap gather everywhere)
   // 3x3x3, stride 1, "same" padding, no upsampling, one K slice, 256-row tiles: the A operand comes from a slab
   // shared by the nine (kh, kw) taps of each kd (see the kernel's header)
-  const bool slab = splits == 1 && p.kd == 3 && p.kh == 3 && p.kw == 3 && p.sd == 1 && p.sh == 1 && p.sw == 1 &&
+  const bool slab = (splits == 1 || tile == 4) && p.kd == 3 && p.kh == 3 && p.kw == 3 && p.sd == 1 && p.sh == 1 && p.sw == 1 &&
                     p.pd == 1 && p.ph == 1 && p.pw == 1 && p.ud == 0 && p.uh == 0 && p.uw == 0 && p.din == p.dout &&
                     p.hin == p.hout && p.win == p.wout && p.win <= 64 && (p.win <= 32 || tile == 7) &&
                     (256 + 2LL * p.hin * p.win + 2 * p.win + 32) * p.lda * 4 < 0x7FF00000LL;

@@ -438,7 +438,7 @@ def tile_for(m: int, cout: int, tile: int = 0, math: int = L.MATH_FP32, cin: int
 
 def slab_width(tile: int, k, stride, up, win: int, math: int, presplit: bool, splitk: int) -> int:
     """mirror of the slab dispatch in cs_conv_gemm_f16x3_dispatch (csrc/cs_gemm_f16x3.hip): 0 = per-tap gather."""
-    if (math != L.MATH_F16X3 or presplit or splitk > 1 or tuple(k) != (3, 3, 3) or tuple(stride) != (1, 1, 1)
+    if (math != L.MATH_F16X3 or presplit or (splitk > 1 and tile != 4) or tuple(k) != (3, 3, 3) or tuple(stride) != (1, 1, 1)
             or tuple(up) != (0, 0, 0) or tile not in (4, 6, 7) or win > 64):
         return 0
     if win <= 32:

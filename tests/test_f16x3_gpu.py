@@ -97,6 +97,35 @@ def test_f16x3_slab_conv_is_bit_identical_to_the_gather_path(case):
     assert rel_l2(out_slab, ref) < 2e-6
 
 
+def test_f16x3_four_way_k_split_of_the_three_column_tile_convs(monkeypatch):
+    """4^3-level convs at large batch (cout = 672: three column tiles, 64 x 3 = 192 workgroups of 256x224 at 32 objects)
+    are cut into four K slices by the plan (cs_gemm.hip::split4_large) and keep the slab kernel.  Against the unsplit
+    slab kernel; and the rule does not look at the batch size, so a shard's rows equal the whole batch's bit for bit."""
+    from commonscenes_amd import lib as L, ops
+    import ctypes as C
+    nb, cin, cout = 64, 256, 672
+    x = _rand(2 * nb, 16, 4, 4, cin, seed=61).cuda()
+    wt = _rand(cout, cin, 3, 3, 3, seed=62, scale=(cin * 27) ** -0.5)
+    b, rv = _rand(cout, seed=63), _rand(2 * nb, cout, seed=64).cuda()
+    pk = ops.pack_weight(wt.cuda(), b.cuda(), math=L.MATH_F16X3)
+    p = L.CsConvGemm()
+    p.nb, p.din, p.hin, p.win, p.dout, p.hout, p.wout = nb, 16, 4, 4, 16, 4, 4
+    p.cin, p.cout, p.kd, p.kh, p.kw, p.sd, p.sh, p.sw, p.pd, p.ph, p.pw = cin, cout, 3, 3, 3, 1, 1, 1, 1, 1, 1
+    p.math = L.MATH_F16X3
+    sk, wsb = C.c_int32(0), C.c_int64(0)
+    assert L.load().cs_conv_gemm_plan(C.byref(p), C.byref(sk), C.byref(wsb)) == 0 and sk.value == 4
+    p.nb = 8 * nb
+    assert L.load().cs_conv_gemm_plan(C.byref(p), C.byref(sk), C.byref(wsb)) == 0 and sk.value == 4
+    kw = dict(rv_rows=256, act=L.ACT_SILU)
+    half = ops.conv_gemm(x[:nb], pk, rowvec=rv[:nb], **kw)
+    whole = ops.conv_gemm(x, pk, rowvec=rv, **kw)
+    monkeypatch.setattr(ops, "SPLITK", False)
+    unsplit = ops.conv_gemm(x[:nb], pk, rowvec=rv[:nb], **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(whole[:nb], half)
+    assert not torch.equal(half, unsplit) and rel_l2(half, unsplit) < 1e-6      # another summation partition, same grade
+
+
 def test_f16x3_slab_conv_keeps_samples_independent():
     """the slab holds rows of neighbouring samples (a 256-row tile at the 4^3 level spans four of them): a NaN in one
     sample must not leak into the others through the zeroed-by-mask taps."""
