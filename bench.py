@@ -43,13 +43,20 @@ import torch.distributed as dist  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X dense fp32-input MFMA peak (MI355X_MICROARCH.md)
 F16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
-# kernel instantiation per (tile code, slab): the last template argument is the slab width (0 = per-tap A gather; 32 / 64 =
-# A operand of 3x3x3 stride-1 convs staged as one slab per (kd, channel chunk), cs_gemm_f16x3.hip)
-TILE_NAMES = {(1, 0): "<2,2,2,2,false,0> (128x128", (2, 0): "<1,7,4,1,false,0> (128x224", (3, 0): "<1,1,2,2,false,0> (64x64",
-              (4, 0): "<1,7,8,1,false,0> (256x224", (5, 0): "persistent ping-pong 2x128x224",
-              (6, 0): "<1,4,8,1,false,0> (256x128", (7, 0): "<1,2,8,1,false,0> (256x64",
-              (4, 32): "<1,7,8,1,false,32> (256x224, A slab", (6, 32): "<1,4,8,1,false,32> (256x128, A slab",
-              (7, 32): "<1,2,8,1,false,32> (256x64, A slab", (7, 64): "<1,2,8,1,false,64> (256x64, A slab"}
+# kernel instantiation per (tile code, slab width, pre-split activations): conv_gemm_f16x3_kernel<WMB, WNB, WAVES_M, WAVES_N,
+# PRE, SLAB>.  SLAB 0 = per-tap A gather; 32 / 64 = A operand of 3x3x3 stride-1 convs staged as one slab per (kd, channel
+# chunk); PRE = the GroupNorm producer already emitted the fp16 hi / lo operand pair (no conversion in the K loop)
+TILE_SHAPES = {1: ("2,2,2,2", "128x128"), 2: ("1,7,4,1", "128x224"), 3: ("1,1,2,2", "64x64"), 4: ("1,7,8,1", "256x224"),
+               6: ("1,4,8,1", "256x128"), 7: ("1,2,8,1", "256x64")}
+
+
+def kernel_label(key):
+    tile, slab, pre = key
+    if tile == 5:
+        return "pw_gemm_f16x3_kernel (persistent ping-pong 2x128x224"
+    wv, shape = TILE_SHAPES.get(tile, ("?", "?"))
+    return (f"conv_gemm_f16x3_kernel<{wv},{'true' if pre else 'false'},{slab}> ({shape}"
+            f"{', A slab' if slab else ''}{', pre-split activations' if pre else ''}")
 
 
 def parse():
@@ -107,12 +114,12 @@ def gemm_summary(prof, wall_ms, math):
     """dominant tile instantiation of a HIP-event profile: achieved TF/s, both roofline conventions."""
     by_tile = {}
     for r in prof:
-        k = (r["tile"], r.get("slab", 0))
+        k = (r["tile"], r.get("slab", 0), bool(r.get("pre", False)))
         by_tile[k] = by_tile.get(k, 0.0) + r["e0"].elapsed_time(r["e1"])
     if not by_tile:
         return None
     dom = max(by_tile, key=by_tile.get)
-    sel = [r for r in prof if (r["tile"], r.get("slab", 0)) == dom]
+    sel = [r for r in prof if (r["tile"], r.get("slab", 0), bool(r.get("pre", False))) == dom]
     ms = sum(r["e0"].elapsed_time(r["e1"]) for r in sel)
     fl = sum(r["flops"] for r in sel)
     all_ms = sum(r["e0"].elapsed_time(r["e1"]) for r in prof)
@@ -120,8 +127,7 @@ def gemm_summary(prof, wall_ms, math):
     achieved = fl / (ms * 1e-3) / 1e12
     if math == "f16x3":
         peak = F16_MFMA_PEAK_TFLOPS / 3.0
-        kname = (f"conv_gemm_f16x3_kernel{TILE_NAMES.get(dom, '(?')}-tile implicit GEMM, 3x v_mfma_f32_32x32x16_f16 "
-                 "per K=16 on hi/lo splits)")
+        kname = f"{kernel_label(dom)}; implicit GEMM, 3x v_mfma_f32_32x32x16_f16 per K=16 on hi/lo splits)"
         peak_note = ("peak = dense fp16 MFMA peak (2500 TF/s) / 3: every fp32-grade product costs three fp16 MFMA "
                      "passes, so 833 TF/s of ALGORITHMIC flops saturates the matrix pipe; frac_of_f16_dense_peak "
                      "prices the same algorithmic flops against the raw 2500 TF/s, frac_of_fp32_matrix_peak against "

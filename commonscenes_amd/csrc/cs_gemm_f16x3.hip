@@ -62,8 +62,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   constexpr int NW = WAVES_M * WAVES_N;            // waves per workgroup (4, or 8 for the 256-row tile)
   constexpr int NT = 64 * NW;
   // ---- LDS map (bytes) ----
-  static_assert(!SLAB || (!PRE && WMB == 1 && WAVES_N == 1), "slab path: fp32 activations, one row block per wave");
-  constexpr int SLAB_WI = (BM + 2 * SLAB + 2 + 15) / 16;   // wave-instructions (16 rows each) per slab; SLAB = widest line W
+  static_assert(!SLAB || (WMB == 1 && WAVES_N == 1), "slab path: one row block per wave");
+  // wave-instructions per slab (SLAB = widest line W): fp32 rows of 64 B, 16 per instruction; PRE: a hi and a lo image
+  // of 32 B rows, 32 per instruction each
+  constexpr int SLAB_IMG_WI = (BM + 2 * SLAB + 2 + 31) / 32;
+  constexpr int SLAB_WI = PRE ? 2 * SLAB_IMG_WI : (BM + 2 * SLAB + 2 + 15) / 16;
+  constexpr int SLAB_IMG = SLAB_IMG_WI * 1024;     // PRE: byte offset of the lo image inside a slab
   constexpr int SLAB_BYTES = SLAB ? SLAB_WI * 1024 : 0;
   constexpr int RING0 = 2 * SLAB_BYTES;            // two slabs, then the ring
   constexpr int A_BYTES = SLAB ? 0 : BM * 64;      // raw fp32 [BM][16], or (PRE) fp16 hi [BM][16] + lo [BM][16]
@@ -112,11 +116,23 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
     const int q = nblk >> 3, r = nblk & 7, xcd = b & 7, within = b >> 3;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
   }
-  // split-K: consecutive virtual tiles are the K slices of one output tile (same XCD: they share the A rows)
-  const int split = tile % splits;
-  tile /= splits;
-  const int tn = tile % tiles_n;
-  const int tm = tile / tiles_n;
+  // split-K: consecutive virtual tiles are the K slices of one output tile (same XCD: they share the A rows).
+  // Slab kernel with K slices (the large-batch four-way cut of the 4^3-level convs: 49 MB of weights per conv, far
+  // beyond an XCD's L2): row tiles fastest instead, so the workgroups an XCD runs together stream the SAME weight
+  // slice (one or two (column tile, K slice) pairs per XCD instead of twelve).
+  int split, tn, tm;
+  if (SLAB != 0 && splits > 1) {
+    const int tiles_m = (M + BM - 1) / BM;
+    tm = tile % tiles_m;
+    tile /= tiles_m;
+    split = tile % splits;
+    tn = tile / splits;
+  } else {
+    split = tile % splits;
+    tile /= splits;
+    tn = tile % tiles_n;
+    tm = tile / tiles_n;
+  }
   const int m0 = tm * BM;
   const int n0 = tn * BN;
 
@@ -347,7 +363,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
 #pragma unroll
     for (int t9 = 0; t9 < 9; ++t9) {
       const int prow = rowl + (t9 / 3) * s_w + t9 % 3;
-      sl_a0[t9] = prow * 64 + ((((2 * half) ^ (prow >> 2)) & 3) << 4);
+      if constexpr (PRE)
+        sl_a0[t9] = prow * 32 + (((half ^ (prow >> 3)) & 1) << 4);      // same swizzle as the ring's fp16 images
+      else
+        sl_a0[t9] = prow * 64 + ((((2 * half) ^ (prow >> 2)) & 3) << 4);
+    }
+    if constexpr (PRE) {
+      if (tid < 4) reinterpret_cast<int*>(smem + ROWMIN)[tid] = 0;     // 16 zero bytes: what a masked-out tap reads
+      __syncthreads();
     }
     const int m = m0 + rowl;
     if (m < M) {
@@ -367,6 +390,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
     }
 #pragma unroll
     for (int i = 0; i < SLAB_PW; ++i) {
+      if constexpr (PRE) {
+        const int j = 32 * ((wave + NW * i) % SLAB_IMG_WI) + (lane >> 1);
+        sl_row[i] = j;
+        sl_piece[i] = (unsigned)(((lane & 1) ^ ((j >> 3) & 1)) * 8);
+        continue;
+      }
       const int j = 16 * (wave + NW * i) + (lane >> 2);   // slab row of this lane in its i-th instruction
       sl_row[i] = j;
       sl_piece[i] = (unsigned)(((lane & 3) ^ ((j >> 2) & 3)) * 4);
@@ -382,13 +411,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
       const int q = wave + NW * i;                          // wave-uniform
       const int src = src0 + sl_row[i];
       const int c = cc * BKH + (int)sl_piece[i];
+      constexpr unsigned ESZ = PRE ? 2u : 4u;
       const unsigned off = (q < SLAB_WI && sl_row[i] < s_need && src >= 0 && src < s_rows && c < p.cin && cc < chunks_per_tap)
-                               ? (unsigned)(src - row_lo) * ((unsigned)p.lda * 4u) + (unsigned)c * 4u
+                               ? (unsigned)(src - row_lo) * ((unsigned)p.lda * ESZ) + (unsigned)c * ESZ
                                : OOB;
       // (through a variable: a conditional expression as the LDS argument makes the HOST pass drop the kernel's stub
       // without a diagnostic)
       unsigned char* d2 = q < SLAB_WI ? dst + q * 1024 : smem + DUMP;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, d2, 16, off, 0, 0, 0);
+      if (PRE && q >= SLAB_IMG_WI)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xlrs, d2, 16, off, 0, 0, 0);        // lo image
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, d2, 16, off, 0, 0, 0);
     }
   };
   // fragment of the chunk at (kh, kw) = T9 of the super-chunk whose slab sits in buffer `buf`: the lane's row shifted by
@@ -396,10 +429,24 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   // (m9 = the kd's nine mask bits)
   auto load_a_slab = [&](auto t9_c, int buf, unsigned m9, h8& hi, h8& lo) {
     constexpr int t9 = decltype(t9_c)::value;
+    if constexpr (PRE) {
+      // already split by the producer: two 16-byte reads; a masked-out tap reads the zero block instead
+      const bool ok = (m9 >> t9) & 1u;
+      const int a = buf * SLAB_BYTES + sl_a0[t9];
+      hi = *reinterpret_cast<const h8*>(smem + (ok ? a : ROWMIN));
+      lo = *reinterpret_cast<const h8*>(smem + (ok ? a + SLAB_IMG : ROWMIN));
+      return;
+    }
     const unsigned char* sb = smem + buf * SLAB_BYTES;
     const f32x4 x0 = *reinterpret_cast<const f32x4*>(sb + sl_a0[t9]);
     const f32x4 x1 = *reinterpret_cast<const f32x4*>(sb + (sl_a0[t9] ^ 16));
+#if CS_ABLATE & 512      // what-if "activations arrive split": no conversion VALU (timing only)
+    hi = __builtin_bit_cast(h8, x0);
+    lo = __builtin_bit_cast(h8, x1);
+    (void)m9;
+#else
     cs16::split8_masked(x0, x1, ((m9 >> t9) & 1u) ? a_scale : 0.f, hi, lo, amax);
+#endif
   };
 
   h8 ah[WMB], al[WMB];
@@ -849,8 +896,24 @@ int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p_in, int M, int tile, int spl
   // 16-bit row deltas: the farthest tap is (kd-1) planes + (kh-1) rows + (kw-1) voxels from the window origin
   if ((int64_t)(p.kd - 1) * p.hin * p.win + (int64_t)(p.kh - 1) * p.win + p.kw > 32000) return CS_EINVAL;
   if (((uintptr_t)p.w & 15) || ((uintptr_t)p.w_lo & 15)) return CS_EINVAL;
+  const bool slab_geom = (splits == 1 || tile == 4) && p.kd == 3 && p.kh == 3 && p.kw == 3 && p.sd == 1 && p.sh == 1 &&
+                         p.sw == 1 && p.pd == 1 && p.ph == 1 && p.pw == 1 && p.ud == 0 && p.uh == 0 && p.uw == 0 &&
+                         p.din == p.dout && p.hin == p.hout && p.win == p.wout && p.win <= 64 &&
+                         (p.win <= 32 || tile == 7) &&
+                         (256 + 2LL * p.hin * p.win + 2 * p.win + 32) * p.lda * 4 < 0x7FF00000LL;
   if (p.a_format == 1) {
     if (!p.x_lo || ((uintptr_t)p.x_lo & 15) || (p.cin & 7) || (p.lda & 7)) return CS_EINVAL;
+#ifndef CS_NO_SLAB
+    if (slab_geom) {
+      switch (tile) {
+        case 4: return launch16<1, 7, 8, 1, true, 32>(p, M, splits, s);
+        case 6: return launch16<1, 4, 8, 1, true, 32>(p, M, splits, s);
+        case 7: return p.win <= 32 ? launch16<1, 2, 8, 1, true, 32>(p, M, splits, s)
+                                   : launch16<1, 2, 8, 1, true, 64>(p, M, splits, s);
+        default: break;
+      }
+    }
+#endif
     switch (tile) {
       case 1: return launch16<2, 2, 2, 2, true>(p, M, splits, s);
       case 2: return launch16<1, 7, 4, 1, true>(p, M, splits, s);
@@ -865,10 +928,7 @@ int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p_in, int M, int tile, int spl
 #ifndef CS_NO_SLAB      // (A/B timing builds: -DCS_NO_SLAB keeps the per-tap gather everywhere)
   // 3x3x3, stride 1, "same" padding, no upsampling, one K slice, 256-row tiles: the A operand comes from a slab
   // shared by the nine (kh, kw) taps of each kd (see the kernel's header)
-  const bool slab = (splits == 1 || tile == 4) && p.kd == 3 && p.kh == 3 && p.kw == 3 && p.sd == 1 && p.sh == 1 && p.sw == 1 &&
-                    p.pd == 1 && p.ph == 1 && p.pw == 1 && p.ud == 0 && p.uh == 0 && p.uw == 0 && p.din == p.dout &&
-                    p.hin == p.hout && p.win == p.wout && p.win <= 64 && (p.win <= 32 || tile == 7) &&
-                    (256 + 2LL * p.hin * p.win + 2 * p.win + 32) * p.lda * 4 < 0x7FF00000LL;
+  const bool slab = slab_geom;
   if (slab) {
     switch (tile) {
       case 4: return launch16<1, 7, 8, 1, false, 32>(p, M, splits, s);

@@ -363,7 +363,8 @@ def conv_gemm(x: Tensor, w: PackedWeight, *, spatial: Optional[Tuple[int, int, i
                       rv_rows=rv_rows if rowvec is not None else 0)
         prof.append(dict(e0=e0, e1=e1, flops=2.0 * mo * w.cout * w.cin * kd * kh * kw, taps=kd * kh * kw,
                          m=mo, n=w.cout, k=w.cin * kd * kh * kw, tile=tl,
-                         slab=slab_width(tl, (kd, kh, kw), stride, up, wd, math, xs is not None, p.splitk)))
+                         slab=slab_width(tl, (kd, kh, kw), stride, up, wd, math, xs is not None, p.splitk),
+                         pre=xs is not None))
     return out
 
 
@@ -436,9 +437,18 @@ def tile_for(m: int, cout: int, tile: int = 0, math: int = L.MATH_FP32, cin: int
     return 2 if act == L.ACT_GEGLU else t
 
 
+def wants_split16(m: int, w: "PackedWeight") -> bool:
+    """Should the GroupNorm feeding the conv `w` over m output rows emit the fp16 hi / lo operand pair?  Yes where the conv
+    will run the slab kernel (3x3x3 on a 256-row tile: large batches) -- there the in-loop conversion is what is left
+    to remove.  Small batches (128-row / 64-row tiles, split-K) measured slightly slower with it (7.85 vs 7.58 ms per
+    one-object step), 1-tap GEMMs neutral: both keep fp32 activations."""
+    return (SPLIT16_PRODUCERS and w.math == L.MATH_F16X3 and w.classes is None and tuple(w.k) == (3, 3, 3)
+            and w.cin % 8 == 0 and tile_for(m, w.cout, 0, w.math, cin=w.cin) in (4, 6, 7))
+
+
 def slab_width(tile: int, k, stride, up, win: int, math: int, presplit: bool, splitk: int) -> int:
     """mirror of the slab dispatch in cs_conv_gemm_f16x3_dispatch (csrc/cs_gemm_f16x3.hip): 0 = per-tap gather."""
-    if (math != L.MATH_F16X3 or presplit or (splitk > 1 and tile != 4) or tuple(k) != (3, 3, 3) or tuple(stride) != (1, 1, 1)
+    if (math != L.MATH_F16X3 or (splitk > 1 and tile != 4) or tuple(k) != (3, 3, 3) or tuple(stride) != (1, 1, 1)
             or tuple(up) != (0, 0, 0) or tile not in (4, 6, 7) or win > 64):
         return 0
     if win <= 32:
@@ -467,10 +477,13 @@ class Split16:
         return Split16(self.hi.view(*shape), self.lo.view(*shape))
 
 
-# Producer-side operand split (GroupNorm writes the fp16 hi/lo pair, the GEMM DMA-loads it with a_format=1).
-# Measured on MI355X (same box, 32 objects): 108.0 ms/step with it vs 107.5 without - the in-loop conversion is
-# already hidden under the MFMA stream, so the path stays opt-in (CS_SPLIT16=1) and is kept parity-tested.
-SPLIT16_PRODUCERS = bool(os.environ.get("CS_SPLIT16"))
+# Producer-side operand split: GroupNorm writes the fp16 hi/lo pair of y * A_SCALE (same bytes as fp32 y) and the GEMM
+# DMA-loads it with a_format=1, so its K loop carries no conversion VALU.  With the per-tap gather kernels this was
+# neutral (108.0 vs 107.5 ms/step in round 1: the conversion hid under the DMA-bound loop); on the slab kernel the
+# conversion is what is left -- a timing-only build without it ran the conv shapes at 472-475 instead of 402-405 TF/s
+# (tools/slab_whatif2.sh) -- so it is the default.  Results are bit-identical either way (y * 16 is exact).
+# CS_NO_SPLIT16=1 turns it off (A/B runs).
+SPLIT16_PRODUCERS = not os.environ.get("CS_NO_SPLIT16")
 
 
 def groupnorm(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float, act: int = L.ACT_NONE,

@@ -370,14 +370,14 @@ class DiffusionUNet:
         sd, pk = self._sd, self._packed
         nb = x.shape[0]
         rows = x.shape[1] * x.shape[2] * x.shape[3]
-        s16 = self.math == L.MATH_F16X3        # GN output goes straight to a GEMM: emit its fp16 hi/lo operand form
+        # GN output goes straight to a conv: emit its fp16 hi/lo operand form where that conv runs the slab kernel
         hn = ops.groupnorm(x, sd[p + ".in_layers.0.weight"], sd[p + ".in_layers.0.bias"], 32, 1e-5, L.ACT_SILU,
-                           split16=s16)
+                           split16=ops.wants_split16(nb * rows, pk[p + ".in_layers.2"]))
         lo, hi = self._emb_slices[p]
         embo = semb[:, lo:hi]                         # slice of the batched emb projection (row stride = total)
         h = ops.conv_gemm(hn, pk[p + ".in_layers.2"], rowvec=embo, rv_rows=rows, math=self.math)
         hn2 = ops.groupnorm(h, sd[p + ".out_layers.0.weight"], sd[p + ".out_layers.0.bias"], 32, 1e-5, L.ACT_SILU,
-                            split16=s16)
+                            split16=ops.wants_split16(nb * rows, pk[p + ".out_layers.3"]))
         skip = x if l["cin"] == l["cout"] else ops.conv_gemm(x, pk[p + ".skip_connection"], math=self.math)
         return ops.conv_gemm(hn2, pk[p + ".out_layers.3"], res=skip, math=self.math, out_fn=out_fn)
 
@@ -429,8 +429,7 @@ class DiffusionUNet:
         n = d * h * w
         dh = c // heads
         t = p + ".transformer_blocks.0"
-        xn = ops.groupnorm(x, sd[p + ".norm.weight"], sd[p + ".norm.bias"], 32, 1e-6, L.ACT_NONE,
-                           split16=self.math == L.MATH_F16X3)
+        xn = ops.groupnorm(x, sd[p + ".norm.weight"], sd[p + ".norm.bias"], 32, 1e-6, L.ACT_NONE)
         t0 = ops.linear(xn.view(nb, n, c), pk[p + ".proj_in"], math=self.math)
         n1 = ops.layernorm(t0, sd[t + ".norm1.weight"], sd[t + ".norm1.bias"])
         qkv = ops.linear(n1, pk[t + ".attn1.qkv"], math=self.math)
@@ -555,7 +554,7 @@ class DiffusionUNet:
             if tr is not None:
                 tr[f"output_blocks.{i}"] = h
         hn = ops.groupnorm(h, sd[P + "out.0.weight"], sd[P + "out.0.bias"], 32, 1e-5, L.ACT_SILU,
-                           split16=self.math == L.MATH_F16X3)
+                           split16=ops.wants_split16(h.shape[0] * h.shape[1] * h.shape[2] * h.shape[3], pk[P + "out.2"]))
         return ops.conv_gemm(hn, pk[P + "out.2"], math=self.math)
 
     @torch.no_grad()

@@ -180,13 +180,13 @@ class VQVAE:
     def _res(self, p: str, x: Tensor) -> Tensor:
         sd, pk = self._sd, self._packed
         c = x.shape[-1]
-        s16 = self.math == L.MATH_F16X3
+        m = x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3]
         h = ops.groupnorm(x, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], _vq_groups(c), 1e-6, L.ACT_SILU,
-                          split16=s16)
+                          split16=ops.wants_split16(m, pk[p + ".conv1"]))
         h = ops.conv_gemm(h, pk[p + ".conv1"], math=self.math)
         co = h.shape[-1]
         h = ops.groupnorm(h, sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], _vq_groups(co), 1e-6, L.ACT_SILU,
-                          split16=s16)
+                          split16=ops.wants_split16(m, pk[p + ".conv2"]))
         skip = x if (p + ".nin_shortcut") not in pk else ops.conv_gemm(x, pk[p + ".nin_shortcut"], math=self.math)
         return ops.conv_gemm(h, pk[p + ".conv2"], res=skip, math=self.math)
 
@@ -194,8 +194,7 @@ class VQVAE:
         sd, pk = self._sd, self._packed
         nb, d, h, w, c = x.shape
         n = d * h * w
-        hn = ops.groupnorm(x, sd[p + ".norm.weight"], sd[p + ".norm.bias"], _vq_groups(c), 1e-6, L.ACT_NONE,
-                           split16=self.math == L.MATH_F16X3)
+        hn = ops.groupnorm(x, sd[p + ".norm.weight"], sd[p + ".norm.bias"], _vq_groups(c), 1e-6, L.ACT_NONE)
         qkv = ops.linear(hn.view(nb, n, c), pk[p + ".qkv"], math=self.math)
         a = ops.attention(qkv[..., 0:c], qkv[..., c:2 * c], qkv[..., 2 * c:], 1, int(c) ** (-0.5), math=self.math)
         out = ops.linear(a, pk[p + ".proj_out"], res=x.view(nb, n, c), math=self.math)
@@ -218,7 +217,7 @@ class VQVAE:
                 h = ops.conv_gemm(h, pk[f"{D}up.{i_level}.upsample.conv"], up=(1, 1, 1), math=self.math)
         c = h.shape[-1]
         h = ops.groupnorm(h, sd[D + "norm_out.weight"], sd[D + "norm_out.bias"], _vq_groups(c), 1e-6, L.ACT_GELU,
-                          split16=self.math == L.MATH_F16X3)
+                          split16=ops.wants_split16(h.shape[0] * h.shape[1] * h.shape[2] * h.shape[3], pk[D + "conv_out"]))
         return ops.conv_gemm(h, pk[D + "conv_out"], math=self.math)
 
     # ---- reference API ----

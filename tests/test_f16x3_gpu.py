@@ -361,6 +361,39 @@ def test_f16x3_presplit_activation_path(shape, cin, cout, tile, monkeypatch):
     assert rel_l2(out, ref) < 2e-6
 
 
+@pytest.mark.parametrize("shape,cin,cout,tile", [((2, 16, 16, 16), 32, 224, 4), ((5, 16, 4, 4), 64, 672, 4),
+                                                 ((1, 5, 7, 3), 24, 224, 4), ((1, 3, 5, 64), 16, 64, 7),
+                                                 ((1, 4, 9, 32), 16, 128, 6), ((6, 4, 4, 4), 32, 224, 4)])
+def test_f16x3_presplit_slab_path_is_bit_identical(shape, cin, cout, tile, monkeypatch):
+    """the slab kernel fed by the split16 GroupNorm producer (a_format = 1: no conversion in the K loop, masked taps read
+    a zero block) equals the same conv on the fp32 GroupNorm output bit for bit (y * 16 is exact), for every slab tile;
+    a NaN sample stays confined to itself."""
+    from commonscenes_amd import lib as L, ops
+    nb, d, h, w = shape
+    x = _rand(nb, d, h, w, cin, seed=66) * 1.5 + 0.3
+    if nb == 6:
+        x[2] = float("nan")
+    g, b = _rand(cin, seed=67) * 0.2 + 1.0, _rand(cin, seed=68) * 0.1
+    wt = _rand(cout, cin, 3, 3, 3, seed=69, scale=(cin * 27) ** -0.5)
+    pk = ops.pack_weight(wt.cuda(), _rand(cout, seed=70).cuda(), math=L.MATH_F16X3)
+    groups = 8 if cin % 32 else 32
+    monkeypatch.setattr(ops, "SPLIT16_PRODUCERS", True)
+    hn16 = ops.groupnorm(x.cuda(), g.cuda(), b.cuda(), groups, 1e-5, L.ACT_SILU, split16=True)
+    assert isinstance(hn16, ops.Split16)
+    hn32 = ops.groupnorm(x.cuda(), g.cuda(), b.cuda(), groups, 1e-5, L.ACT_SILU)
+    o16 = ops.conv_gemm(hn16, pk, tile=tile)
+    o32 = ops.conv_gemm(hn32, pk, tile=tile)
+    og = ops.conv_gemm(hn16, pk, tile=2 if cout % 224 == 0 else 3)        # pre-split, per-tap gather tiles
+    torch.cuda.synchronize()
+    if nb == 6:
+        keep = [0, 1, 3, 4, 5]
+        assert torch.isnan(o16[2]).all() and torch.isfinite(o16[keep]).all()
+        assert torch.equal(o16[keep], o32[keep]) and torch.equal(o16[keep], og[keep])
+    else:
+        assert torch.isfinite(o16).all()
+        assert torch.equal(o16, o32) and torch.equal(o16, og)
+
+
 @pytest.mark.parametrize("nb,shape,cin,cout,k,extras", [
     (2, (16, 4, 4), 672, 672, 3, True),      # one object's 256-voxel level: 12 output tiles -> 32 K slices
     (2, (16, 8, 8), 448, 448, 3, False),
