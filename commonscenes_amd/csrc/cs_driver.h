@@ -6,6 +6,7 @@
 #include "cs_common.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -446,6 +447,8 @@ struct Buf {
   int64_t off = -1, bytes = 0;
   int64_t rows = 0;
   int c = 0;
+  bool half = false;   // fp16 hi image [rows][c] followed by the lo image (the F16X3 GEMMs' pre-split A operand);
+                       // same footprint as fp32 [rows][c]
 };
 
 struct Act {   // an activation volume, channels-last
@@ -534,6 +537,10 @@ struct ExecBase {
     memset(&q, 0, sizeof(q));
     if (!dry) {
       q.x = p(x);
+      if (x.half) {
+        q.x_lo = reinterpret_cast<const char*>(p(x)) + x.rows * x.c * 2;
+        q.a_format = 1;
+      }
       q.out = p(out);
       q.w = reinterpret_cast<const float*>(arena + g.w_off);
       if (pl.math == CS_MATH_F16X3) {
@@ -599,11 +606,38 @@ struct ExecBase {
     return gemm(x, gi, (int)x.rows, 1, 1, 1, 1, 0, act, rowvec, ldrv, rv_rows, res, ldr, tile);
   }
 
-  Buf groupnorm(const Buf& x, int ni, int nb, float eps, int act, int groups = 32) {
+  // mirror of ops.wants_split16: the GroupNorm feeding conv `gi` emits the fp16 hi / lo operand pair where that conv
+  // runs the slab kernel (3x3x3 on a 256-row tile); bit-identical to the fp32 route either way
+  bool wants_split16(int64_t m, int gi) const {
+    static const bool off = getenv("CS_NO_SPLIT16") != nullptr;
+    if (off || gi < 0 || pl.math != CS_MATH_F16X3) return false;
+    const Gemm& g = pl.gemms[gi];
+    if (g.up_mask || g.k != 3 || (g.cin & 7) || g.cin_pad != g.cin) return false;
+    const int64_t t256 = (m + 255) / 256;
+    if (g.cout % 224 == 0) return t256 * (g.cout / 224) >= 192;
+    if (g.cout % 128 == 0) return t256 * (g.cout / 128) >= 192;
+    return (g.cout == 64 || g.cout <= 4) && t256 >= 192;
+  }
+
+  // conv_gi: the 3x3x3 conv that consumes the result (decides the output format), or -1
+  Buf groupnorm(const Buf& x, int ni, int nb, float eps, int act, int groups = 32, int conv_gi = -1) {
     const Norm& n = pl.norms[ni];
     Buf y = alloc(x.rows, x.c);
     Buf wsb = alloc((cs_groupnorm_ws_bytes(nb, groups) + 3) / 4, 1);
     Buf stats = alloc((int64_t)nb * groups * 2, 1);
+    if (wants_split16(x.rows, conv_gi)) {
+      y.half = true;
+      if (ok() && !dry) {
+        const int rows = (int)(x.rows / nb);
+        chk(cs_groupnorm_stats(p(x), nb, rows, x.c, x.c, groups, eps, p(wsb), p(stats), st));
+        char* yh = reinterpret_cast<char*>(p(y));
+        chk(cs_groupnorm_apply_split16(p(x), p(stats), wf(n.g_off), wf(n.b_off), yh, yh + x.rows * x.c * 2, nb, rows, x.c,
+                                       x.c, x.c, groups, act, 16.0f, status, st));
+      }
+      release(wsb);
+      release(stats);
+      return y;
+    }
     if (ok() && !dry) {
       const int rows = (int)(x.rows / nb);
       chk(cs_groupnorm(p(x), wf(n.g_off), wf(n.b_off), p(y), nb, rows, x.c, x.c, x.c, groups, eps, act, p(wsb), p(stats), st));

@@ -378,6 +378,9 @@ extern "C" int cs_conv_gemm(const CsConvGemm* d, cs_stream_t stream) {
     else
       tile = 3;
     if (p.act == CS_ACT_GEGLU && tile != 4) tile = 2;   // the fused gate needs whole [x | gate] 224-column tiles
+    // ... and with a short K loop (the 448-channel level: 28 chunks) two 128-row workgroups per CU overlap one's gate
+    // epilogue with the other's K loop: 805 vs 867 us at 65536 x 448 -> 3584 (the 672-channel one prefers 256 rows)
+    if (p.act == CS_ACT_GEGLU && tile == 4 && (p.cin + 15) / 16 <= 32) tile = 2;
   }
   hipStream_t s = (hipStream_t)stream;
   if (p.splitk > 1) {

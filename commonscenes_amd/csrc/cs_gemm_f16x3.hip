@@ -344,7 +344,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
       } else {
         const f32x4 x0 = *reinterpret_cast<const f32x4*>(s + a_frag[i][0]);
         const f32x4 x1 = *reinterpret_cast<const f32x4*>(s + a_frag[i][1]);
+#if CS_ABLATE & 512      // what-if "activations arrive split" (timing only)
+        hi[i] = __builtin_bit_cast(h8, x0);
+        lo[i] = __builtin_bit_cast(h8, x1);
+#else
         split8(x0, x1, a_scale, hi[i], lo[i], amax);
+#endif
       }
     }
   };

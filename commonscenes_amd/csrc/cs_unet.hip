@@ -247,10 +247,10 @@ struct Exec : ExecBase {
 
   Act res_block(const Layer& l, const Act& x, const Buf& semb) {
     const int rows = x.d * x.h * x.w;
-    Buf hn = groupnorm(x.b, l.n[0], x.nb, 1e-5f, CS_ACT_SILU);
+    Buf hn = groupnorm(x.b, l.n[0], x.nb, 1e-5f, CS_ACT_SILU, 32, l.g[0]);
     Buf h1 = gemm(hn, l.g[0], x.nb, x.d, x.h, x.w, 1, 0, CS_ACT_NONE, dry ? nullptr : p(semb) + l.emb_lo, semb.c, rows);
     release(hn);
-    Buf hn2 = groupnorm(h1, l.n[1], x.nb, 1e-5f, CS_ACT_SILU);
+    Buf hn2 = groupnorm(h1, l.n[1], x.nb, 1e-5f, CS_ACT_SILU, 32, l.g[1]);
     release(h1);
     Buf skip = x.b;
     if (l.g[2] >= 0) skip = gemm(x.b, l.g[2], x.nb, x.d, x.h, x.w);
@@ -459,7 +459,7 @@ int forward(Exec& e, const float* x_ncdhw, const int64_t* t, const float* ctxvec
     h = e.run(layers, cat, semb, ctxvec, false);
     if (!e.ok()) return e.rc;
   }
-  Buf hn = e.groupnorm(h.b, u.n_out, h.nb, 1e-5f, CS_ACT_SILU);
+  Buf hn = e.groupnorm(h.b, u.n_out, h.nb, 1e-5f, CS_ACT_SILU, 32, u.g_out);
   e.release(h.b);
   Buf eps = e.gemm(hn, u.g_out, h.nb, h.d, h.h, h.w);
   e.release(hn);

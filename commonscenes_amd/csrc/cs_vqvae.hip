@@ -111,10 +111,10 @@ struct VExec : ExecBase {
 
   // ResnetBlock.forward (vqvae_modules.py:103-123): GN+swish -> conv -> GN+swish -> conv, + (1x1-projected) input
   Act res(const ResP& r, const Act& x) {
-    Buf h = groupnorm(x.b, r.n1, x.nb, 1e-6f, CS_ACT_SILU, vq_groups(r.cin));
+    Buf h = groupnorm(x.b, r.n1, x.nb, 1e-6f, CS_ACT_SILU, vq_groups(r.cin), r.c1);
     Buf h1 = gemm(h, r.c1, x.nb, x.d, x.h, x.w);
     release(h);
-    Buf h2 = groupnorm(h1, r.n2, x.nb, 1e-6f, CS_ACT_SILU, vq_groups(r.cout));
+    Buf h2 = groupnorm(h1, r.n2, x.nb, 1e-6f, CS_ACT_SILU, vq_groups(r.cout), r.c2);
     release(h1);
     Buf skip = x.b;
     if (r.nin >= 0) skip = gemm(x.b, r.nin, x.nb, x.d, x.h, x.w);
@@ -190,7 +190,7 @@ int decode(VExec& e, const float* latent_ncdhw, float* sdf_ncdhw, int64_t* idx_o
       step(o);
     }
   }
-  Buf hn = e.groupnorm(h.b, u.n_out, h.nb, 1e-6f, CS_ACT_GELU, vq_groups(u.c_final));
+  Buf hn = e.groupnorm(h.b, u.n_out, h.nb, 1e-6f, CS_ACT_GELU, vq_groups(u.c_final), u.g_conv_out);
   e.release(h.b);
   Buf out = e.gemm(hn, u.g_conv_out, h.nb, h.d, h.h, h.w);
   e.release(hn);

@@ -423,7 +423,7 @@ def tile_for(m: int, cout: int, tile: int = 0, math: int = L.MATH_FP32, cin: int
     # tile 5 (the persistent ping-pong kernel) is never auto-selected: cs_pw_gemm_f16x3_preferred() is false
     mt = (m + 127) // 128
     if math == L.MATH_F16X3 and cout % 224 == 0 and ((m + 255) // 256) * (cout // 224) >= 192:
-        return 4
+        return 2 if (act == L.ACT_GEGLU and 0 < (cin + 15) // 16 <= 32) else 4
     if math == L.MATH_F16X3 and cout % 128 == 0 and ((m + 255) // 256) * (cout // 128) >= 192:
         return 6 if act != L.ACT_GEGLU else 2
     if math == L.MATH_F16X3 and (cout == 64 or cout <= 4) and (m + 255) // 256 >= 192:

@@ -1,0 +1,8 @@
+# What-if on the token (1-tap) GEMMs: CS_ABLATE=512 = no fp32 -> hi/lo conversion in the K loop (timing only)
+cd $GRAFT_REPO_ROOT
+for ab in 0 512; do
+  CS_EXTRA_HIPCC_FLAGS="-DCS_ABLATE=$ab" python -m commonscenes_amd.build --force > /dev/null 2>&1
+  echo "== CS_ABLATE=$ab"
+  python tools/gemm_1tap.py 2>&1 | grep -v amdgpu.ids | cut -c1-70
+done
+python -m commonscenes_amd.build --force > /dev/null 2>&1
