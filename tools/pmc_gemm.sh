@@ -1,6 +1,8 @@
 #!/bin/bash
 # PMC passes over one GEMM shape (tools/gemm_bench.py --only N): where the dominant kernel's cycles go.
 # usage (on the GPU box): tools/pmc_gemm.sh <shape-index> <tile> <outdir>
+#   PMC_CMD overrides the benchmark command (default: tools/gemm_bench.py on the shape; e.g.
+#   PMC_CMD="tools/conv_pre_bench.py --only 3 --iters 3 --pre-only" profiles the slab kernel on pre-split operands)
 # Counter passes are separate runs with --kernel-trace only (no other trace domain), as the pool requires.
 set -u
 SHAPE=${1:-3}; TILE=${2:-0}; OUT=${3:-gpurun_out/pmc}
@@ -17,7 +19,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE" \
            "SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC"; do
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$REPO/$OUT/p$i" -- \
-    python "$REPO/tools/gemm_bench.py" --math f16x3 --only "$SHAPE" --tile "$TILE" --iters 3 > "$REPO/$OUT/p$i.log" 2>&1 || echo "pass $i failed"
+    python $REPO/${PMC_CMD:-tools/gemm_bench.py --math f16x3 --only $SHAPE --tile $TILE --iters 3} > "$REPO/$OUT/p$i.log" 2>&1 || echo "pass $i failed"
 done
 cd "$REPO"
 python - "$OUT" <<'PY'
