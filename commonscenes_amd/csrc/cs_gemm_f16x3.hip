@@ -901,15 +901,19 @@ int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p_in, int M, int tile, int spl
   // 16-bit row deltas: the farthest tap is (kd-1) planes + (kh-1) rows + (kw-1) voxels from the window origin
   if ((int64_t)(p.kd - 1) * p.hin * p.win + (int64_t)(p.kh - 1) * p.win + p.kw > 32000) return CS_EINVAL;
   if (((uintptr_t)p.w & 15) || ((uintptr_t)p.w_lo & 15)) return CS_EINVAL;
-  const bool slab_geom = (splits == 1 || tile == 4) && p.kd == 3 && p.kh == 3 && p.kw == 3 && p.sd == 1 && p.sh == 1 &&
+  const bool slab_geom = (splits == 1 || tile == 4 || tile == 2) && p.kd == 3 && p.kh == 3 && p.kw == 3 && p.sd == 1 && p.sh == 1 &&
                          p.sw == 1 && p.pd == 1 && p.ph == 1 && p.pw == 1 && p.ud == 0 && p.uh == 0 && p.uw == 0 &&
                          p.din == p.dout && p.hin == p.hout && p.win == p.wout && p.win <= 64 &&
                          (p.win <= 32 || tile == 7) &&
                          (256 + 2LL * p.hin * p.win + 2 * p.win + 32) * p.lda * 4 < 0x7FF00000LL;
+  // K slices of the slab kernel are whole super-chunks (nine taps): take it only where that granularity pads the slices
+  // by at most a tenth (42 super-chunks over 32 slices would leave a third of the workgroups idle)
+  const int64_t nsc_all = 3LL * ((p.cin + 15) / 16);
+  const bool slab_slices_ok = splits == 1 || ((nsc_all + splits - 1) / splits) * splits * 10 <= nsc_all * 11;
   if (p.a_format == 1) {
     if (!p.x_lo || ((uintptr_t)p.x_lo & 15) || (p.cin & 7) || (p.lda & 7)) return CS_EINVAL;
 #ifndef CS_NO_SLAB
-    if (slab_geom) {
+    if (slab_geom && slab_slices_ok) {
       switch (tile) {
         case 4: return launch16<1, 7, 8, 1, true, 32>(p, M, splits, s);
         case 6: return launch16<1, 4, 8, 1, true, 32>(p, M, splits, s);
@@ -933,9 +937,10 @@ int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p_in, int M, int tile, int spl
 #ifndef CS_NO_SLAB      // (A/B timing builds: -DCS_NO_SLAB keeps the per-tap gather everywhere)
   // 3x3x3, stride 1, "same" padding, no upsampling, one K slice, 256-row tiles: the A operand comes from a slab
   // shared by the nine (kh, kw) taps of each kd (see the kernel's header)
-  const bool slab = slab_geom;
+  const bool slab = slab_geom && slab_slices_ok;
   if (slab) {
     switch (tile) {
+      case 2: return launch16<1, 7, 4, 1, false, 32>(p, M, splits, s);   // small batches: 128-row tiles, K slices
       case 4: return launch16<1, 7, 8, 1, false, 32>(p, M, splits, s);
       case 6: return launch16<1, 4, 8, 1, false, 32>(p, M, splits, s);
       case 7: return p.win <= 32 ? launch16<1, 2, 8, 1, false, 32>(p, M, splits, s)

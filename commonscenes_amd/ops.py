@@ -448,8 +448,10 @@ def wants_split16(m: int, w: "PackedWeight") -> bool:
 
 def slab_width(tile: int, k, stride, up, win: int, math: int, presplit: bool, splitk: int) -> int:
     """mirror of the slab dispatch in cs_conv_gemm_f16x3_dispatch (csrc/cs_gemm_f16x3.hip): 0 = per-tap gather."""
-    if (math != L.MATH_F16X3 or (splitk > 1 and tile != 4) or tuple(k) != (3, 3, 3) or tuple(stride) != (1, 1, 1)
-            or tuple(up) != (0, 0, 0) or tile not in (4, 6, 7) or win > 64):
+    if splitk > 1 and tile != 4:
+        tile = 2                                     # the K-sliced path runs 128x224 tiles (cs_conv_gemm)
+    if (math != L.MATH_F16X3 or tuple(k) != (3, 3, 3) or tuple(stride) != (1, 1, 1)
+            or tuple(up) != (0, 0, 0) or tile not in (2, 4, 6, 7) or win > 64 or (tile == 2 and presplit)):
         return 0
     if win <= 32:
         return 32
