@@ -1,4 +1,4 @@
-"""Times the tiny-cout stencil kernel (cs_gemm.hip::conv_small_n_kernel) against the MFMA tiles it replaces, on the two
+"""Times the library's automatic choice (the 256x64 tile) against the 64x64 tile for convs with <= 4 output channels, on the two
 shapes of the hot path: the UNet's 224 -> 3 output conv (batch 64, 16^3) and the VQ decoder's 64 -> 1 (per object,
 64^3).  usage (GPU box): python tools/small_n_bench.py [objects]"""
 import sys, os
@@ -27,7 +27,7 @@ def main():
         m = nb * s ** 3
         row = [f"{name}: M={m}"]
         ref = None
-        for label, tile in (("stencil", 0), ("tile3 64x64", 3), ("tile7 256x64", 7)):
+        for label, tile in (("auto", 0), ("tile3 64x64", 3), ("tile7 256x64", 7)):
             try:
                 o = ops.conv_gemm(x, pk, tile=tile)
             except Exception as e:          # tile 7 wants cout == 64-column tiles only where it applies
