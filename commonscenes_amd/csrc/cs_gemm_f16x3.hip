@@ -516,8 +516,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
     constexpr int stage = decltype(stage_c)::value;
     constexpr int t9 = decltype(t9_c)::value;
     constexpr int dstage = (stage + PF) % NSTAGE;
-    wait_vmcnt<(t9 == 1 ? SLAB_PW : 0) + B_PW>();
-    __builtin_amdgcn_s_barrier();
+    if (!(CS_ABLATE & 4)) wait_vmcnt<(t9 == 1 ? SLAB_PW : 0) + B_PW>();
+    if (!(CS_ABLATE & 8)) __builtin_amdgcn_s_barrier();
     const unsigned char* s = smem + RING0 + stage * STAGE;
     h8 ah2, al2;
 #pragma unroll
