@@ -186,8 +186,8 @@ int cs_groupnorm_apply_split16(const float* x, const float* stats, const float* 
                                void* y_hi, void* y_lo, int nb, int rows, int c, int ldx, int ldy, int groups,
                                int act, float a_scale, int32_t* status, cs_stream_t stream);
 /* Statistics + normalisation + activation in one call (what the hosts use): a single launch (one workgroup per
- * (sample, group), fp64 sums in a fixed order) while the tensor is at most 16 MB and a group at most 4096 elements
- * (the 4^3 level: there the three launches above sit at their launch floors), otherwise cs_groupnorm_stats +
+ * (sample, group), fp64 sums in a fixed order) while the tensor is at most 16 MB and a group at most 11264 elements
+ * (one or two objects at the 16x4x4 level: there the three launches above sit at their launch floors), otherwise cs_groupnorm_stats +
  * cs_groupnorm_apply.  `stats` is written either way; `ws` as for cs_groupnorm_stats. */
 int cs_groupnorm(const float* x, const float* gamma, const float* beta, float* y, int nb, int rows, int c, int ldx,
                  int ldy, int groups, float eps, int act, void* ws, float* stats, cs_stream_t stream);

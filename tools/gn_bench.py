@@ -23,8 +23,8 @@ def main():
     lib = L.load()
     s = torch.cuda.current_stream().cuda_stream
     print(f"nb={nb}: rows x channels | cs_groupnorm (auto) us | stats + apply us")
-    for rows, c in ((4096, 224), (4096, 448), (4096, 672), (512, 448), (512, 896), (512, 1120), (512, 1344),
-                    (64, 672), (64, 1344)):
+    for rows, c in ((4096, 224), (4096, 448), (4096, 672), (1024, 448), (1024, 896), (1024, 1120), (1024, 1344),
+                    (256, 672), (256, 1344), (256, 2016), (64, 672), (64, 1344)):
         x = synth.tensor_device("gnb:x", (nb, rows, c), 1.0)
         g = synth.tensor_device("gnb:g", (c,), 1.0)
         b = synth.tensor_device("gnb:b", (c,), 1.0)
