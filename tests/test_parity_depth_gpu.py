@@ -280,3 +280,55 @@ def test_256_objects_properties_on_one_gpu(tmp_path):
                                   x_T=x_T, mini_B=32, return_latents=True, max_steps=2)
         torch.cuda.synchronize()
         assert torch.equal(l2, lat[sl]) and torch.equal(s2, sdf[sl]), r
+
+
+def test_full_size_conv_paths_agree_at_the_benchmark_shapes():
+    """BASELINE configs[2]'s own shapes (CFG batch 64), as size-independent properties: (1) the 16^3 x 224 -> 224 ResBlock
+    conv through GroupNorm's pre-split operand pair and the slab kernel equals the per-tap gather kernel on fp32 GroupNorm
+    output bit for bit (same accumulation order by construction); (2) the level-1 -> level-0 Upsample conv folded onto the
+    source grid equals the direct 27-tap form to fp32 accumulation noise (each is 1-2e-7 from fp64 at small K, test_f16x3_gpu.py); (3) the 4^3-level conv's four K slices match the unsplit
+    slab kernel to rounding, and a 32-object batch reproduces the first half of a 64-object one bit for bit."""
+    import torch
+    from commonscenes_amd import lib as L, ops, synth
+    from conftest import rel_l2
+    nb = 64
+    # (1)
+    x = synth.tensor_device("fs:x0", (nb, 16, 16, 16, 224), 1.0)
+    g, b = synth.tensor_device("fs:g", (224,), 0.3) + 1.0, synth.tensor_device("fs:b", (224,), 0.1)
+    w = synth.tensor_device("fs:w0", (224, 224, 3, 3, 3), (224 * 27) ** -0.5)
+    pk = ops.pack_weight(w, synth.tensor_device("fs:c0", (224,), 0.1), math=L.MATH_F16X3)
+    assert ops.wants_split16(nb * 4096, pk)
+    h16 = ops.groupnorm(x, g, b, 32, 1e-5, L.ACT_SILU, split16=True)
+    assert isinstance(h16, ops.Split16)
+    h32 = ops.groupnorm(x, g, b, 32, 1e-5, L.ACT_SILU)
+    slab = ops.conv_gemm(h16, pk, res=x)                  # auto: 256x224 tile, slab, pre-split operands
+    gather = ops.conv_gemm(h32, pk, res=x, tile=3)        # 64x64 tiles: per-tap gather, in-loop operand split
+    torch.cuda.synchronize()
+    assert torch.isfinite(slab).all() and torch.equal(slab, gather)
+    del h16, h32, slab, gather, x
+    # (2)
+    xs = synth.tensor_device("fs:x1", (nb, 16, 8, 8, 448), 1.0)
+    w1 = synth.tensor_device("fs:w1", (448, 448, 3, 3, 3), (448 * 27) ** -0.5)
+    b1 = synth.tensor_device("fs:c1", (448,), 0.1)
+    folded = ops.conv_gemm(xs, ops.pack_weight(w1, b1, math=L.MATH_F16X3, fold_up=(0, 1, 1)), up=(0, 1, 1))
+    direct = ops.conv_gemm(xs, ops.pack_weight(w1, b1, math=L.MATH_F16X3), up=(0, 1, 1))
+    torch.cuda.synchronize()
+    assert folded.shape == (nb, 16, 16, 16, 448)
+    e = rel_l2(folded, direct)
+    print(f"full-size Upsample conv, folded vs direct: rel-L2 {e:.2e}")
+    assert e < 3e-6          # two fp32-accumulated sums over K = 12096 / 5376 terms in different orders
+    del folded, direct, xs
+    # (3)
+    x2 = synth.tensor_device("fs:x2", (2 * nb, 16, 4, 4, 672), 1.0)
+    pk2 = ops.pack_weight(synth.tensor_device("fs:w2", (672, 672, 3, 3, 3), (672 * 27) ** -0.5),
+                          synth.tensor_device("fs:c2", (672,), 0.1), math=L.MATH_F16X3)
+    whole = ops.conv_gemm(x2, pk2)
+    half = ops.conv_gemm(x2[:nb], pk2)
+    ops.SPLITK = False
+    try:
+        unsplit = ops.conv_gemm(x2[:nb], pk2)
+    finally:
+        ops.SPLITK = True
+    torch.cuda.synchronize()
+    assert torch.equal(whole[:nb], half)
+    assert rel_l2(half, unsplit) < 3e-6          # K = 18144 summed in four slices vs one chain
