@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Benchmark: DDIM denoise steps/sec of the CommonScenes shape branch on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1 without a launcher: bench.py re-executes itself under
+                                                              torch.distributed.run -- N ranks, one GPU each, RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One "step" = one classifier-free-guided DDIM step over this rank's 32 objects: a UNet forward at batch 64
@@ -59,6 +60,15 @@ def kernel_label(key):
             f"{', A slab' if slab else ''}{', pre-split activations' if pre else ''}")
 
 
+def rocprof_name(key):
+    """the instantiation's name as rocprofv3 prints it"""
+    tile, slab, pre = key
+    if tile == 5:
+        return "pw_gemm_f16x3_kernel"
+    wv = TILE_SHAPES.get(tile, ("?",))[0].replace(",", ", ")
+    return f"conv_gemm_f16x3_kernel<{wv}, {'true' if pre else 'false'}, {slab}>"
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -68,9 +78,13 @@ def parse():
     ap.add_argument("--ddim-steps", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the decode / end-to-end / C2 blocks (profiling runs)")
-    ap.add_argument("--cpu-objects", type=int, default=7,
-                    help="objects in the bounded CPU-baseline sample (7 = the reference's sampler mini-batch, "
-                         "sdfusion_txt2shape_model.py:493)")
+    ap.add_argument("--cpu-baseline", choices=["full", "quick"], default=os.environ.get("CS_CPU_BASELINE", "full"),
+                    help="full = BASELINE.md section 4 (B=1 x 5 steps, B=32 x 2 steps as mini-batches of 7 and as one "
+                         "batch; ~1-2 min of host time); quick = one mini-batch of 7, one step, scaled")
+    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the fp32-input-MFMA comparison steps")
+    ap.add_argument("--traffic", action="store_true",
+                    help="measure the dominant kernel's HBM bytes per launch now: two rocprofv3 --pmc passes "
+                         "(FETCH_SIZE, WRITE_SIZE) of a short run of this script (tools/pmc_traffic.sh)")
     ap.add_argument("--math", choices=["fp32", "f16x3"], default=os.environ.get("CS_MATH", "f16x3"),
                     help="GEMM numerics: fp32-input MFMA, or fp32 carried as fp16 hi/lo pairs on the fp16 MFMA")
     ap.add_argument("--driver", choices=["python", "native"], default="python",
@@ -81,33 +95,117 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(df, cfg, n_obj: int, objects_per_step: int):
-    """Oracle (port of the reference's PyTorch path) on the host cores: one warm-up + one timed CFG DDIM step
-    for n_obj objects, scaled to the 32-object step the metric is quoted on.  The only use of oracle/ in this file."""
+def cpu_baseline(df, cfg, objects_per_step: int, quick: bool = False):
+    """The CPU oracle (oracle/ref_torch.py: a PORT of the reference's PyTorch path, pinned on the reference's goldens;
+    the reference itself cannot travel) on this box's host cores, following BASELINE.md section 4:
+      B = 1  : 5 full CFG DDIM steps (after 1 warm-up)                                  -> `b1`
+      B = 32 : 2 steps on the reference's schedule of sampler mini-batches of 7 objects  -> `b32_minibatch7`
+               (sdfusion_txt2shape_model.py:493-511: 7+7+7+7+4, CFG batch 14 / 8)
+      B = 32 : 2 steps as ONE batch (CFG batch 64)                                       -> `b32_one_batch`
+    `value` = the better of the two B = 32 rates (DDIM steps/s for 32 objects).  `quick` (CS_CPU_BASELINE=quick, or
+    --cpu-baseline quick) times one mini-batch of 7 for one step and scales.  The only use of oracle/ in this file."""
     from commonscenes_amd import synth
     from oracle import ref_torch as R
-    # oneDNN's conv3d stops scaling (and regresses badly) far below this box's core count at CFG batch 4:
-    # 16 threads was the fastest setting measured on the 256-core host (profiles/r01_cpu_threads.txt:
-    # 16 -> 0.42, 32 -> 0.43, 64 -> 0.75, 128 -> 1.77 s/sample)
-    cores = int(os.environ.get("CS_CPU_THREADS", min(os.cpu_count() or 1, 16)))
-    torch.set_num_threads(cores)
+    host_cores = os.cpu_count() or 1
+    # oneDNN's conv3d stops scaling (and regresses) far below this box's core count at small CFG batches: 16 threads was
+    # the fastest setting measured on the 256-core host at CFG batch 4 (profiles/r01_cpu_threads.txt: 16 -> 0.42,
+    # 32 -> 0.43, 64 -> 0.75, 128 -> 1.77 s/sample); the one-batch leg (CFG batch 64) also tries 64 threads
+    cores = int(os.environ.get("CS_CPU_THREADS", min(host_cores, 16)))
     sd = {k: v.detach().cpu() for k, v in df.state_dict().items()}
     sch = R.register_schedule(**R.DIFFUSION)
-    x_T = synth.gaussian_like("bench:xT", (1, 3, 16, 16, 16)).repeat(n_obj, 1, 1, 1, 1)
-    c = synth.gaussian_like("bench:cpu:c", (n_obj, 1, 1280))
-    uc = synth.gaussian_like("bench:cpu:uc", (n_obj, 1, 1280))
     fn = lambda a, t, cc: R.unet_forward(sd, cfg, a, t, cc)
-    with torch.no_grad():
-        R.ddim_sample(fn, sch["alphas_cumprod"], 100, x_T, c, uc, 3.0, max_steps=1)       # warm-up
+
+    def steps(n_obj, n_steps, tag):
+        x_T = synth.gaussian_like("bench:xT", (1, 3, 16, 16, 16)).repeat(n_obj, 1, 1, 1, 1)
+        c = synth.gaussian_like(f"bench:cpu:c{tag}", (n_obj, 1, 1280))
+        uc = synth.gaussian_like(f"bench:cpu:uc{tag}", (n_obj, 1, 1280))
         t0 = time.perf_counter()
-        R.ddim_sample(fn, sch["alphas_cumprod"], 100, x_T, c, uc, 3.0, max_steps=1)
-        dt = time.perf_counter() - t0
-    per_obj = dt / n_obj
-    return dict(value=1.0 / (per_obj * objects_per_step), unit="DDIM steps/s (32 objects)", cores=cores,
-                kind="port",
-                sample=f"{n_obj} of {objects_per_step} objects (CFG batch {2 * n_obj}), 1 timed DDIM step after 1 "
-                       f"warm-up = {dt:.2f} s, scaled x{objects_per_step / n_obj:g}; oracle/ref_torch.py on "
-                       f"torch {torch.__version__} CPU fp32")
+        with torch.no_grad():
+            R.ddim_sample(fn, sch["alphas_cumprod"], 100, x_T, c, uc, 3.0, max_steps=n_steps)
+        return time.perf_counter() - t0
+
+    torch.set_num_threads(cores)
+    out = dict(unit="DDIM steps/s (32 objects)", kind="port", cores=cores, host_cores=host_cores,
+               torch=torch.__version__, oracle="oracle/ref_torch.py (CPU fp32, pinned on the reference's goldens)")
+    if quick:
+        steps(7, 1, "w")
+        dt = steps(7, 1, "q")
+        out.update(value=1.0 / (dt / 7 * objects_per_step),
+                   sample=f"quick: 7 of {objects_per_step} objects (CFG batch 14), 1 timed DDIM step after 1 warm-up = "
+                          f"{dt:.2f} s, scaled x{objects_per_step / 7:g}")
+        return out
+    steps(1, 1, "w1")
+    t1 = steps(1, 5, "b1")
+    out["b1"] = dict(steps=5, seconds=t1, steps_per_s=5.0 / t1, cores=cores,
+                     workload="BASELINE configs[1] shape: 1 object, CFG batch 2")
+    # the reference's own schedule at 32 objects: mini-batches of 7 (each runs its 2 steps before the next starts)
+    sizes = [min(7, objects_per_step - i) for i in range(0, objects_per_step, 7)]
+    steps(7, 1, "w7")
+    t7 = sum(steps(n, 2, f"mb{i}") for i, n in enumerate(sizes))
+    out["b32_minibatch7"] = dict(steps=2, seconds=t7, steps_per_s=2.0 / t7, cores=cores,
+                                 workload=f"{objects_per_step} objects as sampler mini-batches {sizes} "
+                                          "(sdfusion_txt2shape_model.py:493-511)")
+    best = None
+    for thr in sorted({cores, min(host_cores, 64)}):
+        torch.set_num_threads(thr)
+        tb = steps(objects_per_step, 1, f"one{thr}")
+        if best is None or tb < best[0]:
+            best = (tb, thr)
+    torch.set_num_threads(best[1])
+    tb2 = steps(objects_per_step, 2, "one")
+    out["b32_one_batch"] = dict(steps=2, seconds=tb2, steps_per_s=2.0 / tb2, cores=best[1],
+                                workload=f"{objects_per_step} objects as one batch (CFG batch {2 * objects_per_step}); "
+                                         f"thread count = the faster of {sorted({cores, min(host_cores, 64)})} on one step")
+    v7, v1 = out["b32_minibatch7"]["steps_per_s"], out["b32_one_batch"]["steps_per_s"]
+    out["value"] = max(v7, v1)
+    out["cores"] = best[1] if v1 >= v7 else cores
+    out["sample"] = (f"BASELINE.md section 4: B=1 x 5 steps = {t1:.1f} s; B={objects_per_step} x 2 steps as mini-batches "
+                     f"of 7 = {t7:.1f} s ({v7:.4f} steps/s) and as one batch = {tb2:.1f} s ({v1:.4f} steps/s); value = "
+                     f"the better one; {host_cores} host cores, {out['cores']} threads used")
+    return out
+
+
+def measure_traffic(ksub: str, a):
+    """HBM bytes per launch of kernel `ksub`, as MI355X_MICROARCH.md prescribes: two separate rocprofv3 passes
+    (--kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, nothing else) around a short child run of this script; FETCH_SIZE is
+    calibrated (x2 on gfx950) in the same pass on ln_kernel<2>, which reads a known 65536 x 448 fp32 = 112 MiB."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None
+    res = {}
+    with tempfile.TemporaryDirectory(dir="/tmp") as td:
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", c, "--output-format", "csv", "-d", f"{td}/{c}", "-o", "p", "--",
+                   sys.executable, str(Path(__file__).resolve()), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                   "--no-extras", "--no-fp32-leg", "--objects", str(a.objects), "--math", a.math]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True)
+            files = glob.glob(f"{td}/{c}/**/*counter_collection.csv", recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            k_sum = k_n = l_sum = l_n = 0
+            for row in csv.DictReader(open(files[0])):
+                if row["Counter_Name"] != c:
+                    continue
+                v = float(row["Counter_Value"])
+                if ksub in row["Kernel_Name"]:
+                    k_sum += v
+                    k_n += 1
+                if "ln_kernel<2>" in row["Kernel_Name"]:
+                    l_sum += v
+                    l_n += 1
+            res[c] = dict(launches=k_n, per_launch_bytes=k_sum * 1024 / max(k_n, 1),
+                          ln2_per_launch_mib=l_sum / max(l_n, 1) / 1024)
+    cal = res["FETCH_SIZE"]["ln2_per_launch_mib"]
+    corr = 112.0 / cal if cal else 2.0
+    fb, wb = res["FETCH_SIZE"]["per_launch_bytes"] * corr, res["WRITE_SIZE"]["per_launch_bytes"]
+    return dict(kernel=ksub, hbm_bytes_per_launch=fb + wb, fetch_bytes_per_launch=fb, write_bytes_per_launch=wb,
+                fetch_correction=corr, raw=res,
+                note=f"measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE, separate passes around "
+                     f"`bench.py --steps 2 --warmup 1`; FETCH_SIZE x{corr:.3f} (calibrated on ln_kernel<2>'s 112 MiB read)")
 
 
 def gemm_summary(prof, wall_ms, math):
@@ -141,30 +239,58 @@ def gemm_summary(prof, wall_ms, math):
             "frac_of_f16_dense_peak": achieved / F16_MFMA_PEAK_TFLOPS if math == "f16x3" else None,
             "frac_of_fp32_matrix_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
             "issued_mfma_tflops": 3.0 * achieved if math == "f16x3" else achieved,
-            "kernel": kname, "math": math, "launches": len(sel), "avg_launch_ms": ms / len(sel),
+            "kernel": kname, "rocprof_kernel": rocprof_name(dom) if math == "f16x3" else "conv_gemm_f32_kernel<1, 7, 4, 1>",
+            "math": math, "launches": len(sel), "avg_launch_ms": ms / len(sel),
             "algorithmic_gflop_per_launch": fl / len(sel) / 1e9, "share_of_wall_time": ms / wall_ms,
             "all_gemm_tflops": all_fl / (all_ms * 1e-3) / 1e12, "all_gemm_share_of_wall_time": all_ms / wall_ms}
 
 
+def spawn_ranks(a) -> int:
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): re-execute this file under torch.distributed.run
+    with N ranks on 127.0.0.1, one GPU each, and hand back its exit code -- never a silent one-rank fallback."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()
+    if ndev < a.gpus and not os.environ.get("CS_BENCH_ONE_DEVICE"):
+        print(f"bench.py: --gpus {a.gpus} but only {ndev} HIP device(s) are visible -- refusing to run fewer ranks than "
+              "asked", file=sys.stderr, flush=True)
+        return 2
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    env = dict(os.environ, CS_BENCH_SPAWNED="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(spawn_ranks(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs the MI355X (the HIP path has no CPU fallback)"
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
     # test hooks (a 1-GPU box cannot host two RCCL ranks): CS_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and
     # CS_DIST_BACKEND=gloo swaps the process-group backend, so the multi-rank control flow can be exercised there
     if os.environ.get("CS_BENCH_ONE_DEVICE"):
         local = 0
+    elif world > 1 and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: {world} ranks but {torch.cuda.device_count()} visible HIP devices")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    backend = None
     if world > 1:
         backend = os.environ.get("CS_DIST_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
             dist.init_process_group(backend=backend)
-    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+        if dist.get_world_size() != a.gpus:
+            raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {a.gpus}")
 
     from commonscenes_amd import configs as K
     from commonscenes_amd import dist as D
@@ -186,13 +312,18 @@ def main():
     # ---- conditioning: rank 0 runs the scene-graph GCN for all world*B objects, ONE broadcast (dist.py) ----
     B = a.objects
     total = B * world
-    t_cond0 = time.perf_counter()
-    x_T = uc_all = c_all = None
-    if rank == 0:
+
+    def conditioning():
+        """(x_T, uc, c) for all objects on rank 0 (None elsewhere): graph synthesis + embeddings + 5 GCN layers + rel_mlp."""
+        if rank != 0:
+            return None, None, None
         from commonscenes_amd.scene import GraphTripleConvNet, _MLP
         g = synth.random_scene_graph(total, seed=111)
-        ssd = synth.synth_state_dict(scene_param_shapes(35, 16), device=str(dev))
-        ec, relmlp = GraphTripleConvNet(ssd, "gconv_net_ec_rel", 5), _MLP(ssd, "rel_mlp", 2, False)
+        ssd = conditioning.ssd
+        if ssd is None:
+            ssd = conditioning.ssd = synth.synth_state_dict(scene_param_shapes(35, 16), device=str(dev))
+            conditioning.nets = (GraphTripleConvNet(ssd, "gconv_net_ec_rel", 5), _MLP(ssd, "rel_mlp", 2, False))
+        ec, relmlp = conditioning.nets
         tri = g["triples"].to(dev)
         obj_vecs = torch.cat([g["text_feats"].to(dev), ops.embedding(ssd["obj_embeddings_dc.weight"], g["objs"].to(dev)),
                               g["z"].to(dev)], dim=1)
@@ -202,10 +333,23 @@ def main():
         rel2, _ = ec(obj_vecs, pred_vecs, edges)
         c_all = relmlp(rel2)[:total].reshape(total, 1, 1280)          # with the GCN
         uc_all = relmlp(obj_vecs)[:total].reshape(total, 1, 1280)     # without
-        x_T = synth.gaussian_like("bench:xT", (1, 3, 16, 16, 16)).to(dev)
+        return synth.gaussian_like("bench:xT", (1, 3, 16, 16, 16)).to(dev), uc_all, c_all
+
+    conditioning.ssd = conditioning.nets = None
+    cond_ms = {}
+    for leg in ("cold", "warm"):        # cold = + synthetic weights, weight packing, first-launch code loading
+        torch.cuda.synchronize()
+        t_c = time.perf_counter()
+        x_T, uc_all, c_all = conditioning()
+        torch.cuda.synchronize()
+        cond_ms[leg] = (time.perf_counter() - t_c) * 1e3
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_b = time.perf_counter()
     x_T, uc_all, c_all = D.broadcast_conditioning(x_T, uc_all, c_all, total, dev, src=0)
     torch.cuda.synchronize()
-    cond_ms = (time.perf_counter() - t_cond0) * 1e3
+    bcast_ms = (time.perf_counter() - t_b) * 1e3
     lo, hi = D.shard_range(total, world, rank)
     uc = uc_all[lo:hi].contiguous()
     c = c_all[lo:hi].contiguous()
@@ -243,12 +387,18 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     ops.GEMM_PROFILE = None
+    rank_ms = [dt / a.steps * 1e3]
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        allt = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(allt, tt)
+        rank_ms = [float(v.item()) / a.steps * 1e3 for v in allt]
     dt = max_over_ranks(dt)
     finite = bool(torch.isfinite(x).all().item())
     overflow = ops.read_status(dev) != 0
 
     # ---- extras, outside the timed region: decode of this rank's latents, the all-gather, one object (C2) ----
-    decode = e2e = c2 = mesh = None
+    decode = e2e = c2 = c7 = mesh = fp32_leg = None
     if not a.no_extras and not a.small:
         vq = VQVAE(K.VQVAE_DDCONFIG, K.VQVAE_N_EMBED, K.VQVAE_EMBED_DIM, device=dev).set_math(a.math)
         vq.load_state_dict(synth.synth_state_dict(vqvae_param_shapes(K.VQVAE_DDCONFIG, K.VQVAE_N_EMBED,
@@ -326,6 +476,41 @@ def main():
                   "steps_per_s": 1.0 / d1, "whole_step_tflops": 2 * K.UNET_GFLOP_PER_SAMPLE / d1 / 1e3,
                   "frac_of_peak": 2 * K.UNET_GFLOP_PER_SAMPLE / d1 / 1e3 / (F16_MFMA_PEAK_TFLOPS / 3.0 if a.math == "f16x3"
                                                                             else FP32_MFMA_PEAK_TFLOPS)}
+            # the reference's sampler mini-batch (sdfusion_txt2shape_model.py:493): 7 objects, CFG batch 14
+            nb7 = min(7, B)
+            x7 = x_T.repeat(nb7, 1, 1, 1, 1).contiguous()
+            c7in = torch.cat([uc[:nb7], c[:nb7]])
+            df.reset_run_cache() if hasattr(df, "reset_run_cache") else None
+            for j in range(3):
+                x7, _ = sampler._step(x7, c7in, int(ts[j]), S - j - 1, True, 3.0, want_pred_x0=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for j in range(3, 3 + 10):
+                x7, _ = sampler._step(x7, c7in, int(ts[j]), S - j - 1, True, 3.0, want_pred_x0=False)
+            torch.cuda.synchronize()
+            d7 = (time.perf_counter() - t0) / 10
+            c7 = {"workload": f"the reference's sampler mini-batch: {nb7} objects, CFG batch {2 * nb7}",
+                  "ms_per_step": d7 * 1e3, "ms_per_object_step": d7 * 1e3 / nb7,
+                  "whole_step_tflops": 2 * nb7 * K.UNET_GFLOP_PER_SAMPLE / d7 / 1e3}
+            df.reset_run_cache() if hasattr(df, "reset_run_cache") else None
+        if world == 1 and a.math == "f16x3" and not a.no_fp32_leg:
+            # the same workload on the fp32-input MFMA kernels (the reference's dtype on the matrix pipe it maps to), so
+            # that what CS_MATH_F16X3 buys is on the record next to the metric; 1 warm-up + 2 timed steps
+            df.set_math("fp32")
+            xf = x_T.repeat(B, 1, 1, 1, 1).contiguous()
+            xf, _ = sampler._step(xf, c_in, int(ts[0]), S - 1, True, 3.0, want_pred_x0=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for j in (1, 2):
+                xf, _ = sampler._step(xf, c_in, int(ts[j]), S - j - 1, True, 3.0, want_pred_x0=False)
+            torch.cuda.synchronize()
+            dfp = (time.perf_counter() - t0) / 2
+            fp32_leg = {"math": "fp32 (v_mfma_f32_32x32x2_f32 on fp32 operands)", "value": 1.0 / dfp,
+                        "ms_per_step": dfp * 1e3, "steps": 2,
+                        "whole_step_tflops": 2 * B * K.UNET_GFLOP_PER_SAMPLE / dfp / 1e3,
+                        "frac_of_fp32_matrix_peak": 2 * B * K.UNET_GFLOP_PER_SAMPLE / dfp / 1e3 / FP32_MFMA_PEAK_TFLOPS}
+            df.set_math("f16x3")
+            del xf
 
     if rank == 0:
         wall_ms = dt * 1e3
@@ -343,16 +528,18 @@ def main():
             for k, t in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                 print(f"{k[0]:4d} {k[1]:7d} {k[2]:6d} {k[3]:6d} {k[4]:4d} {t[0]:5d} {t[1] / a.steps:8.3f} "
                       f"{t[2] / t[1] / 1e9:7.1f}", file=sys.stderr)
-        traffic = None
-        for cand in ("r02_traffic_f16x3.json", "r01_traffic_f16x3.json") if a.math == "f16x3" else ("r01_traffic_fp32.json",):
-            tf = ROOT / "profiles" / cand
-            if tf.exists() and B == 32 and not a.small:   # PMC passes cannot run inside this process: the figure is
-                traffic = json.loads(tf.read_text())["hbm_bytes_per_launch"]   # the committed rocprofv3 --pmc result
-                roof["traffic_source"] = f"profiles/{cand}"
-                break
-        roof["traffic"] = traffic
-        roof["traffic_note"] = ("HBM bytes per launch of the dominant kernel, FETCH_SIZE x2 (gfx950) + WRITE_SIZE, from "
-                                "separate rocprofv3 --pmc passes of this command (tools/pmc_traffic.sh)")
+        # HBM bytes per launch of the dominant kernel come from PMC counters, which cannot be collected from inside this
+        # process: --traffic runs the two rocprofv3 --pmc passes NOW (child runs of this script); without it the field
+        # is null and the figure measured for this round's kernels is the committed profiles/r03_traffic.json
+        roof["traffic"] = None
+        roof["traffic_note"] = ("null: not measured in this run (PMC counters need rocprofv3 around the process; "
+                                "`bench.py --traffic` measures it, tools/pmc_traffic.sh wrote profiles/r03_traffic.json)")
+        if a.traffic and world == 1 and roof.get("rocprof_kernel"):
+            tr = measure_traffic(roof["rocprof_kernel"], a)
+            if tr:
+                roof["traffic"] = tr["hbm_bytes_per_launch"]
+                roof["traffic_note"] = tr["note"]
+                roof["traffic_detail"] = tr
         roof["whole_step_tflops"] = (2 * B * K.UNET_GFLOP_PER_SAMPLE * 1e9 * a.steps / dt / 1e12) if not a.small else None
         ex = K.UNET_GFLOP_EXECUTED_PER_SAMPLE if ops.FOLD_UPSAMPLE else K.UNET_GFLOP_PER_SAMPLE
         roof["whole_step_executed_tflops"] = (2 * B * ex * 1e9 * a.steps / dt / 1e12) if not a.small else None
@@ -374,11 +561,22 @@ def main():
                        "objects_per_gpu": B, "unet_batch": 2 * B, "ddim_steps": S,
                        "parallelism": f"object-sharded x{world} (replicated weights, no per-step collective; "
                                       "1 broadcast in, 1 all-gather out)"},
-            "roofline": roof, "decode": decode, "end_to_end": e2e, "c2": c2, "mesh": mesh,
-            "conditioning_ms": cond_ms, "finite": finite, "f16x3_overflow": overflow, "unet_driver": a.driver,
+            "roofline": roof, "decode": decode, "end_to_end": e2e, "c2": c2, "c7": c7, "fp32_mfma": fp32_leg,
+            "mesh": mesh,
+            "conditioning_ms": cond_ms["warm"], "conditioning_cold_ms": cond_ms["cold"],
+            "conditioning_note": "rank 0: graph synthesis + embeddings + 5 GCN layers + rel_mlp for all objects; cold = the "
+                                 "first call (synthetic scene weights, weight packing, code loading), warm = the second",
+            "ranks": {"world_size": world, "backend": ("rccl (torch 'nccl')" if backend == "nccl" else backend),
+                      "rccl_ranks": world if backend == "nccl" else (1 if world == 1 else 0),
+                      "ms_per_step_min": min(rank_ms), "ms_per_step_max": max(rank_ms), "ms_per_step_by_rank": rank_ms,
+                      "broadcast_ms": bcast_ms, "broadcast_bytes": int(4 * (3 * 16 ** 3 + 2 * total * 1280)),
+                      "all_gather_ms": e2e["all_gather_ms"] if e2e else None,
+                      "launched_by": "bench.py (self-spawned torch.distributed.run)" if os.environ.get("CS_BENCH_SPAWNED")
+                                     else ("external launcher" if world > 1 else "single process")},
+            "finite": finite, "f16x3_overflow": overflow, "unet_driver": a.driver,
         }
         if not a.no_cpu_baseline and not a.small:
-            res["cpu_baseline"] = cpu_baseline(df, cfg, a.cpu_objects, B)
+            res["cpu_baseline"] = cpu_baseline(df, cfg, B, quick=a.cpu_baseline == "quick")
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

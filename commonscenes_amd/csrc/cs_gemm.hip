@@ -264,9 +264,14 @@ namespace {
 // tiles: 64 x 3 = 192 workgroups at 32 objects, a quarter of the CUs idle) is cut into FOUR K slices -- 768 workgroups,
 // three even rounds -- whenever it has an odd number of column tiles and a long K loop.  The rule looks at K and N only
 // (not at the batch beyond "large"), so a shard of a batch and the whole batch add their products in the same order.
+// (r3: also with pre-split activations, a_format = 1 -- the GroupNorm producers feed exactly these convs in that form,
+// so the r2 rule "a_format == 0" had switched the cut off on the model path; -DCS_SPLIT4_FP32_ONLY restores it for A/B.)
 bool split4_large(const CsConvGemm& p, int64_t M) {
+#ifdef CS_SPLIT4_FP32_ONLY
+  if (p.a_format != 0) return false;
+#endif
   return p.kd == 3 && p.kh == 3 && p.kw == 3 && p.sd == 1 && p.sh == 1 && p.sw == 1 && !(p.ud | p.uh | p.uw) &&
-         p.a_format == 0 && ((p.cout / 224) & 1) && p.cout / 224 >= 3 && (p.cin + 15) / 16 >= 16 &&
+         ((p.cout / 224) & 1) && p.cout / 224 >= 3 && (p.cin + 15) / 16 >= 16 &&
          ((M + 255) / 256) * (int64_t)(p.cout / 224) >= 192;
 }
 

@@ -95,6 +95,28 @@ def all_gather_objects(local: Tensor, total: int) -> Tensor:
     return torch.cat([out[r * mx:r * mx + sizes[r]] for r in range(ws)], dim=0)
 
 
+def all_reduce_max(t: Tensor) -> Tensor:
+    """Element-wise max over the ranks (identity without a process group); gloo reduces on the host."""
+    rank, ws = world()
+    if ws == 1:
+        return t
+    if t.is_cuda and dist.get_backend() == "gloo":
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.MAX)
+        return h.to(t.device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t
+
+
+def any_rank_failed(failed: bool, device) -> bool:
+    """One 4-byte all-reduce that every rank reaches whether or not its shard raised: lets a failing rank tell its peers
+    BEFORE the data collective, so nobody blocks in an all-gather that will never complete."""
+    rank, ws = world()
+    if ws == 1:
+        return bool(failed)
+    return bool(all_reduce_max(torch.tensor([1.0 if failed else 0.0], device=device))[0] > 0)
+
+
 def sharded_rel2shape(sample_fn: Callable[[Tensor, Tensor, Tensor], Tensor], x_T: Tensor, uc: Tensor, c: Tensor,
                       gather: bool = True) -> Tensor:
     """Run `sample_fn(x_T, uc_slice, c_slice) -> sdf_slice` on this rank's contiguous object shard and

@@ -99,7 +99,10 @@ def sdf_to_mesh(sdf: Tensor, level: float = 0.02, color: Optional[Sequence[float
         nimg = min(bs, 16)
     if nimg == 0:
         return Meshes([], [], Textures([]))
-    v, f, nv, nf = marching_cubes(sdf[:nimg, 0].to(torch.float32), level, vert_div=float(n_cell), vert_shift=-0.5)
+    vol = sdf[:nimg, 0]
+    if not vol.is_cuda:       # the reference takes the SDF wherever it lives (util_3d.py:211 copies it to the host);
+        vol = vol.to(torch.device("cuda", torch.cuda.current_device()))     # here the work is on the device: upload it
+    v, f, nv, nf = marching_cubes(vol.to(torch.float32), level, vert_div=float(n_cell), vert_shift=-0.5)
     verts = list(torch.split(v, nv))
     faces = list(torch.split(f, nf))
     rgb = []

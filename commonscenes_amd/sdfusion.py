@@ -8,8 +8,10 @@ Like the reference's BaseModel (model/base_model.py:31) this is a plain class, n
 
 Extensions over the reference (SURVEY 8b "Extension the build adds"):
   * rel2shape(..., x_T=None, mini_B=None): inject the shared initial noise (the reference seeds it from
-    time.time(), F7) and choose the sampler mini-batch (the reference hard-codes 7; objects are
-    independent, so any mini-batch gives the same per-object result -- the default here is 32).
+    time.time(), F7) and choose the sampler mini-batch.  The DEFAULT is the reference's hard-coded 7
+    (sdfusion_txt2shape_model.py:493), so a drop-in run reproduces its batching; objects are independent, so a
+    larger mini-batch (`mini_B=32`, `model.mini_B = 32` or CS_MINI_B=32: 2.7 instead of 3.6 ms per object-step on
+    an MI355X) gives the same per-object result to ~1e-5 (different GEMM tilings add in a different order).
 """
 from __future__ import annotations
 
@@ -121,7 +123,7 @@ class SDFusionText2ShapeModel:
         self.df_module = self.df
         self.vqvae_module = self.vqvae
         self.ddim_steps = 100                                           # :128 (hard-coded in the reference)
-        self.mini_B = 32
+        self.mini_B = int(os.environ.get("CS_MINI_B", "7"))               # :493 (hard-coded 7 in the reference)
 
     def name(self):
         return "SDFusion-Text2Shape-Model"
@@ -193,6 +195,9 @@ class SDFusionText2ShapeModel:
         def run():
             if hasattr(self.df, "reset_run_cache"):
                 self.df.reset_run_cache()           # per-run caches (one-token context vectors) never outlive a run
+            # the status word is sticky per device: clear what earlier, unchecked F16X3 launches (a direct decode, a
+            # bench loop, a call that raised before its own check) may have left, so only THIS run is attributed
+            ops.read_status(self.device)
             out, _ = sampler.sample(S=ddim_steps, batch_size=c.shape[0], shape=shape, conditioning=c, x_T=noise,
                                     verbose=False, unconditional_guidance_scale=uc_scale,
                                     unconditional_conditioning=uc, eta=ddim_eta, max_steps=max_steps)
@@ -210,17 +215,31 @@ class SDFusionText2ShapeModel:
             return run()
 
     def _decode_checked(self, samples):
+        ops.read_status(self.device)                # see _sample_minibatch: attribute only this decode's kernels
         out = self.vqvae_module.decode_no_quant(samples)
         try:
             ops.check_overflow(self.device, "VQ-VAE decode")
         except L.CsOverflowError:
-            if self.overflow_policy != "fp32" or getattr(self.vqvae, "math", None) != L.MATH_F16X3:
+            if (self.overflow_policy != "fp32" or getattr(self.vqvae, "math", None) != L.MATH_F16X3
+                    or not hasattr(self.vqvae, "set_math")):
                 raise
             import warnings
             warnings.warn("F16X3 activation overflow in the VQ-VAE decoder: re-running on the fp32-input MFMA kernels")
             self.vqvae.set_math("fp32")
             out = self.vqvae_module.decode_no_quant(samples)
         return out
+
+    def _sync_math_across_ranks(self):
+        """Sharded runs: the fp32 fall-back is decided per rank (only the rank whose shard overflowed switches), which
+        would leave the ranks on different numerics for every later call -- shards then stop matching the single-rank
+        run bit for bit.  One tiny all-reduce after the shard is done: if ANY rank fell back, all do."""
+        flags = torch.tensor([float(getattr(self.df, "math", 0) == L.MATH_FP32),
+                              float(getattr(self.vqvae, "math", 0) == L.MATH_FP32)], device=self.device)
+        flags = dist.all_reduce_max(flags)
+        if flags[0] > 0 and getattr(self.df, "math", None) == L.MATH_F16X3:
+            self.df.set_math("fp32")
+        if flags[1] > 0 and getattr(self.vqvae, "math", None) == L.MATH_F16X3 and hasattr(self.vqvae, "set_math"):
+            self.vqvae.set_math("fp32")
 
     @torch.no_grad()
     def rel2shape(self, data, ddim_steps=100, ddim_eta=0.0, uc_scale=None, x_T: Optional[Tensor] = None,
@@ -271,14 +290,29 @@ class SDFusionText2ShapeModel:
         och = self.vqvae.cfg.get("out_ch", 1) if hasattr(self.vqvae, "cfg") else 1
         mb = int(mini_B or self.mini_B)
         gen, lats = [], []
-        for i in range(lo, hi, mb):                                      # ceil((hi - lo) / mb) sampler runs (:493-511)
-            sl = slice(i, min(i + mb, hi))
-            num = sl.stop - sl.start
-            noise = single_noise.repeat(num, 1, 1, 1, 1)                 # every object shares one x_T (:491)
-            samples = self._sample_minibatch(smp, ddim_steps, shape, c_text[sl], uc[sl], noise, uc_scale, ddim_eta,
-                                             max_steps)
-            lats.append(samples)
-            gen.append(self._decode_checked(samples))
+        failure: Optional[BaseException] = None
+        try:
+            for i in range(lo, hi, mb):                                  # ceil((hi - lo) / mb) sampler runs (:493-511)
+                sl = slice(i, min(i + mb, hi))
+                num = sl.stop - sl.start
+                noise = single_noise.repeat(num, 1, 1, 1, 1)             # every object shares one x_T (:491)
+                samples = self._sample_minibatch(smp, ddim_steps, shape, c_text[sl], uc[sl], noise, uc_scale, ddim_eta,
+                                                 max_steps)
+                lats.append(samples)
+                gen.append(self._decode_checked(samples))
+        except Exception as e:              # noqa: BLE001 -- re-raised below, after the other ranks have been told
+            if not (sharded and ws > 1):
+                raise
+            failure = e
+        if sharded and ws > 1:
+            # a rank that raised must not leave its peers blocked in the all-gather: agree on failure first
+            bad = dist.any_rank_failed(failure is not None, self.device)
+            if failure is not None:
+                raise failure
+            if bad:
+                raise RuntimeError("rel2shape: another rank failed while sampling its shard (see its traceback); "
+                                   "no SDFs were gathered")
+            self._sync_math_across_ranks()
         if gen:
             local, llat = torch.cat(gen, dim=0), torch.cat(lats, dim=0)
         else:       # an empty shard (more ranks than objects) or B == 0: nothing to sample, still join the gather
@@ -288,6 +322,7 @@ class SDFusionText2ShapeModel:
             local = dist.all_gather_objects(local, B)
             if return_latents:
                 llat = dist.all_gather_objects(llat, B)
+        self.last_latents = llat            # this rank's (or, with return_latents, all) sampled latents: diagnostics
         self.gen_df = local
         if return_latents:
             return self.gen_df, llat

@@ -35,6 +35,10 @@ class NativeVQVAE:
         self._sd: Dict[str, Tensor] = {}
         self._ws: Optional[Tensor] = None
         self.last_indices: Optional[Tensor] = None
+        self.grid = self.cfg["resolution"] >> (len(self.cfg["ch_mult"]) - 1)
+        self._create()
+
+    def _create(self):
         cfg = self.cfg
         c = L.CsVqvaeConfig()
         c.ch, c.out_ch, c.n_mult = cfg["ch"], cfg["out_ch"], len(cfg["ch_mult"])
@@ -52,7 +56,24 @@ class NativeVQVAE:
             L.check(lib.cs_vqvae_param_info(h, i, C.byref(name), C.byref(shape), C.byref(nd), C.byref(off)),
                     "cs_vqvae_param_info")
             self.params[name.value.decode()] = (tuple(int(shape[k]) for k in range(nd.value)), int(off.value))
-        self.grid = cfg["resolution"] >> (len(cfg["ch_mult"]) - 1)
+
+    def set_math(self, mode) -> "NativeVQVAE":
+        """GEMM numerics ('fp32' | 'f16x3'): a property of the plan, so switching rebuilds it and re-packs the weights
+        (as NativeDiffusionUNet.set_math does) -- what rel2shape's F16X3-overflow fall-back calls."""
+        m = {"fp32": L.MATH_FP32, "f16x3": L.MATH_F16X3}.get(mode, mode)
+        if m not in (L.MATH_FP32, L.MATH_F16X3):
+            raise ValueError(f"unknown math mode {mode!r}")
+        if m != self.math:
+            self.math = m
+            sd = {k: v.clone() for k, v in self._sd.items()}      # the entries are views into the raw buffer being replaced
+            self.__del__()
+            self._arena = None
+            self._ws = None
+            self._sd = {}
+            self._create()
+            if sd:
+                self.load_state_dict(sd)
+        return self
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None

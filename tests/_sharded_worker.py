@@ -73,6 +73,29 @@ def main():
         s1 = m.Diff.rel2shape(tiny, sharded=True, ddim_steps=50, uc_scale=3.0, x_T=x_T, max_steps=1)
         res["tiny_shape"] = list(s1.shape)
         res["tiny_finite"] = bool(torch.isfinite(s1).all())
+        # a failure on ONE rank (an F16X3 overflow in the shard that holds the last object: its context is
+        # 1e4) must reach every rank before the all-gather -- policy 'raise': the owner raises CsOverflowError, its
+        # peers RuntimeError, nobody hangs; policy 'fp32': the owner falls back and ALL ranks switch math together
+        from commonscenes_amd import lib as L
+        cbad = c.clone()
+        cbad[nobj - 1] = 1.0e4
+        bad = {"sdf": torch.zeros(nobj, 1), "rel": cbad, "uc": uc}
+        kwb = dict(ddim_steps=50, uc_scale=3.0, x_T=x_T, mini_B=32, max_steps=1, sharded=True)
+        m.Diff.overflow_policy = "raise"
+        try:
+            m.Diff.rel2shape(bad, **kwb)
+            res["raise_policy"] = "no exception"
+        except L.CsOverflowError:
+            res["raise_policy"] = "CsOverflowError"
+        except RuntimeError as e:
+            res["raise_policy"] = "RuntimeError" if "another rank failed" in str(e) else f"RuntimeError: {e}"
+        m.Diff.overflow_policy = "fp32"
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            sb = m.Diff.rel2shape(bad, **kwb)
+        res["fallback_finite"] = bool(torch.isfinite(sb).all())
+        res["math_after_fallback"] = int(m.Diff.df.math)
     td.barrier()
     # one file per rank: the ranks share stdout and their lines can interleave
     Path(os.environ["CS_SHARD_OUT"], f"rank{rank}.json").write_text(json.dumps(res))

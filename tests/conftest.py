@@ -25,10 +25,17 @@ def pytest_collection_modifyitems(config, items):
 
 
 def rel_l2(a, b):
+    """rel-L2 of a against b in fp64.  CS_PARITY_LOG=<file>: every measured value is appended with the id of the test that
+    took it (how profiles/r03_parity_per_op.txt -- the record the per-op gates were set from -- is produced)."""
     import torch
     a = a.detach().double().cpu().flatten()
     b = b.detach().double().cpu().flatten()
-    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+    v = float((a - b).norm() / b.norm().clamp_min(1e-30))
+    log = os.environ.get("CS_PARITY_LOG")
+    if log:
+        with open(log, "a") as f:
+            f.write(f"{v:.3e}\t{os.environ.get('PYTEST_CURRENT_TEST', '?')}\n")
+    return v
 
 
 GOLDEN = ROOT / "tests" / "golden"

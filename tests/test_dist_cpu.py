@@ -95,3 +95,35 @@ def test_pack_unpack_roundtrip():
     assert buf.numel() == 3 * 16 ** 3 + 2 * 5 * 1280
     a, b, cc = D.unpack_conditioning(buf, 5)
     assert torch.equal(a, x_T) and torch.equal(b, uc) and torch.equal(cc, c)
+
+
+def _fail_worker(rank, ws, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(ws))
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        # rank 1 "fails": every rank must learn it from ONE small collective it reaches either way
+        told = D.any_rank_failed(rank == 1, "cpu")
+        nobody = D.any_rank_failed(False, "cpu")
+        mx = D.all_reduce_max(torch.tensor([float(rank), 1.0 - rank]))
+        q.put((rank, told, nobody, mx.tolist()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_failure_flag_reaches_every_rank():
+    """a rank that raises inside its shard must not leave its peers blocked in the all-gather -- rel2shape
+    all-reduces a failure flag first (dist.any_rank_failed); the same reduction carries the fp32 fall-back decision."""
+    ws, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fail_worker, args=(r, ws, port, q)) for r in range(ws)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(ws))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, told, nobody, mx in got:
+        assert told is True and nobody is False and mx == [1.0, 1.0]
+    assert D.any_rank_failed(True, "cpu") is True and D.any_rank_failed(False, "cpu") is False     # no process group

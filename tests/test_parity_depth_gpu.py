@@ -219,6 +219,67 @@ def test_rel2shape_reruns_an_overflowing_minibatch_in_fp32(tmp_path):
     assert ops.read_status() == 0
 
 
+def test_native_vqvae_overflow_falls_back_to_fp32(tmp_path, monkeypatch):
+    """with unet_driver='native' the decode runs on NativeVQVAE, whose F16X3 overflow fall-back needs
+    set_math().  A decoder whose conv_in bias puts one channel at 1e4 overflows the first raw-activation consumer
+    (nin_shortcut / Upsample conv); policy 'fp32' re-runs the decode on the fp32 kernels and equals the Python-sequenced
+    fp32 decode bit for bit; policy 'raise' propagates CsOverflowError (not an AttributeError)."""
+    import warnings
+    from commonscenes_amd import lib as L
+    from commonscenes_amd import ops, synth
+    from test_model_gpu import _scene
+    monkeypatch.setenv("CS_UNET_DRIVER", "native")
+    m = _scene(tmp_path)
+    assert type(m.Diff.vqvae).__name__ == "NativeVQVAE"
+    vsd = {k: v.clone() for k, v in m.Diff.vqvae.state_dict().items()}
+    vsd["decoder.conv_in.bias"][0] = 1.0e4
+    m.Diff.vqvae.load_state_dict(vsd)
+    B = 2
+    data = {"sdf": torch.zeros(B, 1), "rel": synth.gaussian_like("nvo:c", (B, 1, 1280)).cuda(),
+            "uc": synth.gaussian_like("nvo:uc", (B, 1, 1280)).cuda()}
+    kw = dict(ddim_steps=50, uc_scale=3.0, x_T=synth.gaussian_like("nvo:xT", (1, 3, 16, 16, 16)), return_latents=True,
+              max_steps=1)
+    m.Diff.overflow_policy = "raise"
+    with pytest.raises(L.CsOverflowError):
+        m.Diff.rel2shape(data, **kw)
+    assert m.Diff.vqvae.math == L.MATH_F16X3
+    m.Diff.overflow_policy = "fp32"
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter("always")
+        sdf_a, lat_a = m.Diff.rel2shape(data, **kw)
+    torch.cuda.synchronize()
+    assert any("VQ-VAE decoder" in str(w.message) for w in wlist)
+    assert m.Diff.vqvae.math == L.MATH_FP32 and m.Diff.df.math == L.MATH_F16X3 and torch.isfinite(sdf_a).all()
+    monkeypatch.setenv("CS_UNET_DRIVER", "python")
+    from commonscenes_amd.vqvae import VQVAE
+    from oracle.ref_torch import VQ_FULL
+    py = VQVAE(VQ_FULL, 8192, 3, device="cuda").set_math("fp32")
+    py.load_state_dict(vsd)
+    assert torch.equal(py.decode_no_quant(lat_a), sdf_a)
+    assert ops.read_status() == 0
+
+
+def test_a_stale_overflow_flag_is_not_attributed_to_the_next_run(tmp_path):
+    """the status word is sticky per device; a bit left by an earlier, unchecked launch must not make the next
+    rel2shape switch the UNet to the fp32 kernels (5x slower) with a misleading warning."""
+    import warnings
+    from commonscenes_amd import lib as L
+    from commonscenes_amd import ops, synth
+    from test_model_gpu import _scene
+    m = _scene(tmp_path)
+    B = 2
+    data = {"sdf": torch.zeros(B, 1), "rel": synth.gaussian_like("st:c", (B, 1, 1280)).cuda(),
+            "uc": synth.gaussian_like("st:uc", (B, 1, 1280)).cuda()}
+    ops.status_word().fill_(L.STATUS_F16X3_OVERFLOW)                    # what an unchecked direct call would leave
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter("always")
+        sdf = m.Diff.rel2shape(data, ddim_steps=50, uc_scale=3.0, x_T=synth.gaussian_like("st:xT", (1, 3, 16, 16, 16)),
+                               max_steps=1)
+    torch.cuda.synchronize()
+    assert not any("overflow" in str(w.message) for w in wlist)
+    assert m.Diff.df.math == L.MATH_F16X3 and m.Diff.vqvae.math == L.MATH_F16X3 and torch.isfinite(sdf).all()
+
+
 def test_scene_graph_index_errors_raise_like_the_reference(tmp_path):
     """an object id beyond the embedding table or a triple endpoint beyond the node count raised IndexError
     in the reference (nn.Embedding / tensor indexing); the HIP gather kernels skip the entry and set a device flag,
@@ -280,6 +341,41 @@ def test_256_objects_properties_on_one_gpu(tmp_path):
                                   x_T=x_T, mini_B=32, return_latents=True, max_steps=2)
         torch.cuda.synchronize()
         assert torch.equal(l2, lat[sl]) and torch.equal(s2, sdf[sl]), r
+
+
+def test_c4_full_width_256_objects_on_one_gpu(tmp_path):
+    """BASELINE configs[3] (C4) at its real size: the SHIPPED 413.5 M-parameter UNet, 256 objects (what eight ranks of 32
+    hold together), a 258-node scene graph, the product API -- encoder_2 -> rel2shape (two DDIM steps of the 100-step
+    schedule, mini-batch 32) -> decode to 64^3.  The oracle cannot run this size; the properties that make the 8 x 32
+    sharding exact are checked instead: everything finite; any 32-object rank shard computed on its own equals the same
+    rows of the 256-object run bit for bit; objects with identical conditioning get identical shapes (shared x_T)."""
+    from commonscenes_amd import synth
+    from test_model_gpu import _scene
+    m = _scene(tmp_path, small=False)
+    nobj = 256
+    g = synth.random_scene_graph(nobj, seed=3)
+    uc, c = m.encoder_2(g["z"].cuda(), g["objs"].cuda(), g["triples"].cuda(), g["text_feats"].cuda(),
+                        g["rel_feats"].cuda())
+    assert uc.shape == (nobj + 2, 1, 1280) and torch.isfinite(c).all() and torch.isfinite(uc).all()
+    c, uc = c[:nobj].clone(), uc[:nobj].clone()
+    c[255], uc[255] = c[0], uc[0]
+    x_T = synth.gaussian_like("c4:xT", (1, 3, 16, 16, 16))
+    kw = dict(ddim_steps=100, uc_scale=3.0, x_T=x_T, mini_B=32, return_latents=True, max_steps=2)
+    sdf, lat = m.Diff.rel2shape({"sdf": torch.zeros(nobj, 1), "rel": c, "uc": uc}, **kw)
+    torch.cuda.synchronize()
+    assert sdf.shape == (nobj, 1, 64, 64, 64) and torch.isfinite(sdf).all() and torch.isfinite(lat).all()
+    assert torch.equal(lat[0], lat[255]) and torch.equal(sdf[0], sdf[255])
+    assert not torch.equal(lat[0], lat[1])
+    for r in (0, 5):                                                    # two of the eight rank shards
+        sl = slice(32 * r, 32 * r + 32)
+        s2, l2 = m.Diff.rel2shape({"sdf": torch.zeros(32, 1), "rel": c[sl], "uc": uc[sl]}, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(l2, lat[sl]) and torch.equal(s2, sdf[sl]), r
+    # the reference's own mini-batching (7) of the same objects: same shapes to fp32 summation-order noise
+    s7, l7 = m.Diff.rel2shape({"sdf": torch.zeros(9, 1), "rel": c[:9], "uc": uc[:9]}, **dict(kw, mini_B=7))
+    torch.cuda.synchronize()
+    from conftest import rel_l2
+    assert rel_l2(l7, lat[:9]) < 1e-4
 
 
 def test_full_size_conv_paths_agree_at_the_benchmark_shapes():

@@ -54,11 +54,14 @@ def normalize(vertices, scale=1):                            # scripts/eval_3dfr
     return vertices / np.max(vertices, axis=0) * scale
 
 
-def synthetic_loader(n_scenes, seed):
+def synthetic_loader(n_scenes, seed, objects=None):
+    """`objects`: shaped objects per scene (default 4, 5, ...).  32 gives an SG-FRONT-livingroom-sized graph: 34 nodes
+    (objects + floor + _scene_) and ~160 triples (dataset/threedfront_dataset.py:448-452: an `in` edge from every node
+    to `_scene_` plus the typed relations)."""
     from commonscenes_amd import synth
     out = []
     for s in range(n_scenes):
-        nobj = 4 + s
+        nobj = (4 + s) if objects is None else objects
         g = synth.random_scene_graph(nobj, seed=seed + s)
         O = g["objs"].shape[0]
         sdfs = torch.zeros(O, 1, 4, 4, 4)
@@ -78,6 +81,7 @@ def build_experiment(tmp: Path, width: int):
     from commonscenes_amd.unet import unet_param_shapes
     from commonscenes_amd.vqvae import vqvae_param_shapes
     ucfg = K.reduced(K.UNET_CROSSATTN, width) if width != 224 else dict(K.UNET_CROSSATTN)
+    gen = "cuda" if torch.cuda.is_available() else "cpu"      # same values either way (synth.py); the device is faster
     df_yaml = dict(model=dict(params=dict(conditioning_key="crossattn", **K.DIFFUSION)),
                    unet=dict(params={k: (list(v) if isinstance(v, tuple) else v) for k, v in ucfg.items()}))
     vq_yaml = dict(model=dict(params=dict(embed_dim=K.VQVAE_EMBED_DIM, n_embed=K.VQVAE_N_EMBED,
@@ -87,9 +91,10 @@ def build_experiment(tmp: Path, width: int):
     (tmp / "vq.yaml").write_text(yaml.safe_dump(vq_yaml))
     opt = dict(hyper=dict(device="cuda", batch_size=4),
                network=dict(df_cfg=str(tmp / "df.yaml"), vq_cfg=str(tmp / "vq.yaml"), vq_ckpt=None), misc=dict(seed=111))
+    cpu = lambda sd: {k: v.cpu() for k, v in sd.items()}
     ck = dict(synth.synth_state_dict(scene_param_shapes(35, 16)))
     ck["vqvae"] = synth.synth_state_dict(vqvae_param_shapes(K.VQVAE_DDCONFIG, K.VQVAE_N_EMBED, K.VQVAE_EMBED_DIM))
-    ck["df"] = synth.synth_state_dict(unet_param_shapes(ucfg))
+    ck["df"] = cpu(synth.synth_state_dict(unet_param_shapes(ucfg), device=gen))
     ck.update(opt={}, epoch=100, counter=0)
     (tmp / "checkpoint").mkdir(exist_ok=True)
     torch.save(ck, tmp / "checkpoint" / "model100.pth")
@@ -104,6 +109,14 @@ def main():
     ap.add_argument("--ddim-steps", type=int, default=2)
     ap.add_argument("--attention", choices=["same", "f16"], default="same")
     ap.add_argument("--points", type=int, default=5000)
+    ap.add_argument("--objects", type=int, default=None,
+                    help="shaped objects per scene (default 4, 5, ...; 32 = a livingroom-sized SG-FRONT graph: 34 nodes)")
+    ap.add_argument("--mini-b", type=int, default=None,
+                    help="sampler mini-batch (default: the reference's 7, sdfusion_txt2shape_model.py:493)")
+    ap.add_argument("--compare-attention", action="store_true",
+                    help="additionally sample the first scene once with the default (fp32-grade F16X3) attention and once "
+                         "with the fp16 MFMA attention from the SAME z / x_T and report the latent / SDF deviation "
+                         "(SURVEY 8d: fp16-attention mode is report-only)")
     a = ap.parse_args()
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -118,18 +131,48 @@ def main():
     from commonscenes_amd.mesh import sdf_to_mesh
     from commonscenes_amd.vae import VAE
     chamfer = chamferDist()
-    res = dict(scenes=[], world=world, attention=a.attention, width=a.width, ddim_steps=a.ddim_steps)
+    res = dict(scenes=[], world=world, attention=a.attention, width=a.width, ddim_steps=a.ddim_steps,
+               mini_B=a.mini_b or 7)
     with tempfile.TemporaryDirectory() as td:
         tmp = Path(td)
         opt = build_experiment(tmp, a.width)
         model = VAE(type="v2_full", diff_opt=opt, vocab=VOCAB, replace_latent=True, with_changes=True, residual=True,
                     with_angles=True, clip=True, with_E2=True)
         model.load_networks(str(tmp), 100)
+        if a.mini_b:
+            model.vae_v2.Diff.mini_B = a.mini_b
         if a.attention == "f16":
             model.vae_v2.Diff.df.set_attention_math("f16")
         model.compute_statistics(str(tmp), 100, synthetic_loader(3, seed=900))
         model.eval()
-        loader = synthetic_loader(a.scenes, seed=500)
+        loader = synthetic_loader(a.scenes, seed=500, objects=a.objects)
+        if a.compare_attention:
+            from commonscenes_amd import synth
+            d = loader[0]["decoder"]
+            O = d["objs"].shape[0]
+            z = synth.gaussian_like("ev:cmp:z", (O, 64))
+            x_T = synth.gaussian_like("ev:cmp:xT", (1, 3, 16, 16, 16))
+            got = {}
+            for mode in ("same", "f16"):
+                model.vae_v2.Diff.df.set_attention_math(mode)
+                t0 = time.perf_counter()
+                with torch.no_grad():
+                    _, sdf = model.sample_box_and_shape(None, d["objs"].cuda(), d["tripltes"].cuda(), d["sdfs"],
+                                                        d["text_feats"].cuda(), d["rel_feats"].cuda(), attributes=None,
+                                                        gen_shape=True, ddim_steps=a.ddim_steps, z=z, x_T=x_T)
+                torch.cuda.synchronize()
+                got[mode] = (sdf.double(), model.vae_v2.Diff.last_latents.double(), time.perf_counter() - t0)
+            rl2 = lambda x, y: float((x - y).norm() / y.norm().clamp_min(1e-30))
+            per_obj = [(rl2(got["f16"][1][i], got["same"][1][i])) for i in range(got["same"][1].shape[0])]
+            res["attention_compare"] = dict(
+                objects=int(got["same"][0].shape[0]), ddim_steps=a.ddim_steps,
+                latent_rel_l2=rl2(got["f16"][1], got["same"][1]), latent_rel_l2_worst_object=max(per_obj),
+                sdf_rel_l2=rl2(got["f16"][0], got["same"][0]),
+                sdf_sign_flips=int(((got["f16"][0] > 0.02) != (got["same"][0] > 0.02)).sum()),
+                sdf_voxels=int(got["same"][0].numel()), sample_s_default=got["same"][2], sample_s_f16=got["f16"][2],
+                note="fp16 MFMA attention (one fp16 pass, fp32 softmax/accumulate) vs the default fp32-grade F16X3 "
+                     "attention, same z / x_T / weights; report-only (SURVEY 8d)")
+            model.vae_v2.Diff.df.set_attention_math("f16" if a.attention == "f16" else "same")
         x_T = None                                            # like the reference: fresh noise per call
         all_div_boxes, all_div_angles, all_div_chamfer = [], [], []
         t_all = time.perf_counter()
@@ -171,6 +214,7 @@ def main():
                     seq.append(float((torch.mean(d1) + torch.mean(d2)).cpu()))
                 all_div_chamfer.append(float(np.mean(seq)))
             res["scenes"].append(dict(scan=data["scan_id"][0], nodes=int(dec_objs.shape[0]), shapes=int(nshape),
+                                      triples=int(dec_triples.shape[0]),
                                       sample_s=t_scene, verts=[int(v.shape[0]) for v in meshes.verts_list()],
                                       finite=bool(torch.isfinite(shapes_pred).all() and torch.isfinite(boxes_pred).all()),
                                       angle_range=[float(angles_pred.min()), float(angles_pred.max())]))
