@@ -541,11 +541,21 @@ def main():
                 roof["traffic_note"] = tr["note"]
                 roof["traffic_detail"] = tr
         roof["whole_step_tflops"] = (2 * B * K.UNET_GFLOP_PER_SAMPLE * 1e9 * a.steps / dt / 1e12) if not a.small else None
-        ex = K.UNET_GFLOP_EXECUTED_PER_SAMPLE if ops.FOLD_UPSAMPLE else K.UNET_GFLOP_PER_SAMPLE
-        roof["whole_step_executed_tflops"] = (2 * B * ex * 1e9 * a.steps / dt / 1e12) if not a.small else None
-        roof["whole_step_note"] = ("whole_step_tflops prices the reference's direct-form work (557.9 GFLOP per UNet sample); "
-                                   "the two Upsample convs run folded onto the source grid (12/27 of their multiply-adds, "
-                                   "cs_conv_gemm_up2), so the issued algorithmic work is whole_step_executed_tflops")
+        # executed work = what the launches of the timed region actually issued (HIP-event records of every GEMM) + the
+        # self-attention and norm terms of SURVEY App. A; it is below the reference's direct form because (a) the two
+        # Upsample convs run folded onto the source grid (12/27 of their multiply-adds) and (b) under classifier-free
+        # guidance the skip half of output blocks 5-8 is shared by the two halves and its part of the convs runs once
+        if prof and not a.small:
+            ex_step = sum(r["flops"] for r in prof) / a.steps + 2 * B * (10.45 + 0.3) * 1e9
+            roof["whole_step_executed_tflops"] = ex_step / (dt / a.steps) / 1e12
+            roof["executed_gflop_per_step"] = ex_step / 1e9
+        else:
+            roof["whole_step_executed_tflops"] = None
+        roof["whole_step_note"] = ("whole_step_tflops prices the reference's direct-form work (557.9 GFLOP per UNet sample: "
+                                   f"{2 * B * K.UNET_GFLOP_PER_SAMPLE:.0f} GFLOP per step); whole_step_executed_tflops "
+                                   "counts what was issued: the Upsample convs run folded onto the source grid (12/27 of "
+                                   "their multiply-adds, cs_conv_gemm_up2) and the skip half of output blocks 5-8, identical "
+                                   "for the two guidance halves, is convolved once (unet.py::_res_split)")
         res = {
             "metric": "DDIM denoise steps/sec (32 objects, 16^3 latent)",
             "value": world * a.steps / dt,

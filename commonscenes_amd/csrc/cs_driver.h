@@ -36,6 +36,10 @@ struct Piece {       // rows [row0, row0 + rows) of parameter `param` seen as a 
 struct Gemm {        // one packed GEMM weight (possibly several reference tensors concatenated along cout)
   std::vector<Piece> w, b;
   int cout = 0, cin = 0, cin_pad = 0, k = 1, taps = 1, ldw = 0;
+  // input-channel range [c0, c0 + cin) of source tensors that have src_cin input channels (0 = all of them): the two
+  // halves of a channel-split conv (cs_unet.hip: res_block_split); the operand scale is the WHOLE tensor's either way
+  int c0 = 0, src_cin = 0;
+  bool unused = false;   // registered (its parameters are part of the state_dict) but never launched: not packed
   int64_t w_off = 0, wlo_off = 0, b_off = -1;
   float acc_scale = 1.f;
   // Upsample's conv folded onto the source grid (cs_conv_gemm_up2): bit 2 / 1 / 0 = D / H / W doubled.  The packed
@@ -144,6 +148,16 @@ int add_layer_gemm(Plan& u, const std::string& p, int o, int i, int k, bool bias
   return gi;
 }
 
+// input channels [c0, c1) of an already registered conv / linear weight (wp; bias bp or -1) as a GEMM of its own
+int add_gemm_cin_range(Plan& u, int wp, int bp, int o, int i_total, int k, int c0, int c1) {
+  std::vector<Piece> b;
+  if (bp >= 0) b.push_back({bp, 0, o});
+  const int gi = add_gemm(u, {{wp, 0, o}}, b, o, c1 - c0, k);
+  u.gemms[gi].c0 = c0;
+  u.gemms[gi].src_cin = i_total;
+  return gi;
+}
+
 int add_copy(Plan& u, int param) {
   u.copies.push_back({param, 0});
   return (int)u.copies.size() - 1;
@@ -154,6 +168,7 @@ void layout_arena(Plan& u) {
   int64_t off = 0;
   int slots = (int)u.params.size();
   for (Gemm& g : u.gemms) {
+    if (g.unused) continue;
     if (g.up_mask) {
       const int ftaps = g.fkd * g.fkh * g.fkw;
       g.ldw = f16 ? g.cout : (g.cout + 3) / 4 * 4;
@@ -245,7 +260,8 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ w
 __global__ __launch_bounds__(256) void pack_part_f16x3_kernel(const float* __restrict__ w, _Float16* __restrict__ wh,
                                                               _Float16* __restrict__ wl, int rows, int n_off,
                                                               int cout_total, int cin, int taps, int kg_per_tap,
-                                                              float scale) {
+                                                              float scale, int src_cin = 0, int c0 = 0) {
+  if (src_cin == 0) src_cin = cin;
   const int64_t total = (int64_t)taps * kg_per_tap * rows * 8;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int j = (int)(i & 7);
@@ -256,7 +272,7 @@ __global__ __launch_bounds__(256) void pack_part_f16x3_kernel(const float* __res
     const int tap = (int)(t / kg_per_tap);
     const int c = kg * 8 + j;
     float v = 0.f;
-    if (c < cin) v = w[((int64_t)n * cin + c) * taps + tap] * scale;
+    if (c < cin) v = w[((int64_t)n * src_cin + c0 + c) * taps + tap] * scale;
     const _Float16 h = (_Float16)v;
     const int64_t o = (((int64_t)tap * kg_per_tap + kg) * cout_total + n_off + n) * 8 + j;
     wh[o] = h;
@@ -266,7 +282,8 @@ __global__ __launch_bounds__(256) void pack_part_f16x3_kernel(const float* __res
 
 __global__ __launch_bounds__(256) void pack_part_f32_kernel(const float* __restrict__ w, float* __restrict__ o,
                                                             int rows, int n_off, int cin, int taps, int cin_pad,
-                                                            int ldw) {
+                                                            int ldw, int src_cin = 0, int c0 = 0) {
+  if (src_cin == 0) src_cin = cin;
   // w: rows of a (cout, cin, taps) torch tensor; o: [tap][cin_pad][ldw], columns n_off .. n_off + rows
   const int64_t total = (int64_t)taps * cin_pad * rows;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -275,7 +292,7 @@ __global__ __launch_bounds__(256) void pack_part_f32_kernel(const float* __restr
     const int c = (int)(t % cin_pad);
     const int tap = (int)(t / cin_pad);
     float v = 0.f;
-    if (c < cin) v = w[((int64_t)n * cin + c) * taps + tap];
+    if (c < cin) v = w[((int64_t)n * src_cin + c0 + c) * taps + tap];
     o[((int64_t)tap * cin_pad + c) * ldw + n_off + n] = v;
   }
 }
@@ -307,6 +324,7 @@ int pack_plan(Plan* u, const void* raw_dev, void* arena_dev, cs_stream_t stream)
     float* d_amax = reinterpret_cast<float*>(arena + u->amax_off);
     if (hipMemsetAsync(d_amax, 0, (size_t)u->amax_slots * 4, st) != hipSuccess) return CS_EINVAL;
     for (const Gemm& g : u->gemms) {
+      if (g.unused) continue;
       if (g.up_mask) {
         const int64_t n = (int64_t)g.cout * g.cin * g.fkd * g.fkh * g.fkw;
         for (int c = 0; c < g.ncls; ++c) {
@@ -342,6 +360,7 @@ int pack_plan(Plan* u, const void* raw_dev, void* arena_dev, cs_stream_t stream)
     return CS_OK;
   };
   for (Gemm& g : u->gemms) {
+    if (g.unused) continue;
     if (g.up_mask) {      // one packed image (pair) per parity class, each with its own power-of-two scale
       const int ftaps = g.fkd * g.fkh * g.fkw;
       const int64_t n = (int64_t)g.cout * g.cin * ftaps;
@@ -357,13 +376,13 @@ int pack_plan(Plan* u, const void* raw_dev, void* arena_dev, cs_stream_t stream)
           const int64_t total = (int64_t)ftaps * kg * g.cout * 8;
           CS_LAUNCH(pack_part_f16x3_kernel, dim3(cs_grid_for(total, 256, 256 * 32)), dim3(256), 0, st, w,
                     (_Float16*)(arena + g.cls_w_off[c]), (_Float16*)(arena + g.cls_wlo_off[c]), g.cout, 0, g.cout,
-                    g.cin, ftaps, kg, scale);
+                    g.cin, ftaps, kg, scale, 0, 0);
         } else {
           if (hipMemsetAsync(arena + g.cls_w_off[c], 0, (size_t)ftaps * g.cin_pad * g.ldw * 4, st) != hipSuccess)
             return CS_EINVAL;
           const int64_t total = (int64_t)ftaps * g.cin_pad * g.cout;
           CS_LAUNCH(pack_part_f32_kernel, dim3(cs_grid_for(total, 256)), dim3(256), 0, st, w,
-                    (float*)(arena + g.cls_w_off[c]), g.cout, 0, g.cin, ftaps, g.cin_pad, g.ldw);
+                    (float*)(arena + g.cls_w_off[c]), g.cout, 0, g.cin, ftaps, g.cin_pad, g.ldw, 0, 0);
         }
         CS_CHECK_LAUNCH();
       }
@@ -371,7 +390,7 @@ int pack_plan(Plan* u, const void* raw_dev, void* arena_dev, cs_stream_t stream)
       if (rc != CS_OK) return rc;
       continue;
     }
-    const int cols = g.cin * g.taps;    // row length of the reference tensor seen as [cout][cin * taps]
+    const int cols = (g.src_cin ? g.src_cin : g.cin) * g.taps;    // row length of the reference tensor seen as [cout][cin * taps]
     float scale = 1.f;
     if (f16) {
       // scale by the whole tensor's maximum even when only a row range is used (GEGLU pieces): what
@@ -405,11 +424,11 @@ int pack_plan(Plan* u, const void* raw_dev, void* arena_dev, cs_stream_t stream)
         const int64_t total = (int64_t)g.taps * kg * pc.rows * 8;
         CS_LAUNCH(pack_part_f16x3_kernel, dim3(cs_grid_for(total, 256, 256 * 32)), dim3(256), 0, st, w,
                   (_Float16*)(arena + g.w_off), (_Float16*)(arena + g.wlo_off), pc.rows, n_off, g.cout, g.cin,
-                  g.taps, kg, scale);
+                  g.taps, kg, scale, g.src_cin, g.c0);
       } else {
         const int64_t total = (int64_t)g.taps * g.cin_pad * pc.rows;
         CS_LAUNCH(pack_part_f32_kernel, dim3(cs_grid_for(total, 256)), dim3(256), 0, st, w,
-                  (float*)(arena + g.w_off), pc.rows, n_off, g.cin, g.taps, g.cin_pad, g.ldw);
+                  (float*)(arena + g.w_off), pc.rows, n_off, g.cin, g.taps, g.cin_pad, g.ldw, g.src_cin, g.c0);
       }
       CS_CHECK_LAUNCH();
       n_off += pc.rows;
@@ -601,6 +620,85 @@ struct ExecBase {
     release(skws);      // stream-ordered: later kernels that reuse the region run after the reduce
     return out;
   }
+  // stride-1 conv / pointwise GEMM on explicit operand views: x (+ x_lo for the pre-split pair) with row stride lda,
+  // out with row stride ldo -- channel ranges of wider buffers, sample ranges of a batch (res_block_split)
+  void gemm_view(const float* x, const void* x_lo, int lda, int gi, int nb, int d, int h, int w, float* out, int ldo,
+                 const float* rowvec = nullptr, int ldrv = 0, int rv_rows = 1, const float* res = nullptr, int ldr = 0) {
+    const Gemm& g = pl.gemms[gi];
+    CsConvGemm q;
+    memset(&q, 0, sizeof(q));
+    if (!dry) {
+      q.x = x;
+      if (x_lo) {
+        q.x_lo = x_lo;
+        q.a_format = 1;
+      }
+      q.out = out;
+      q.w = reinterpret_cast<const float*>(arena + g.w_off);
+      if (pl.math == CS_MATH_F16X3) {
+        q.w_lo = arena + g.wlo_off;
+        q.acc_scale = g.acc_scale;
+        q.a_scale = 16.0f;
+      }
+      q.bias = g.b_off >= 0 ? wf(g.b_off) : nullptr;
+      q.rowvec = rowvec;
+      q.res = res;
+      q.status = status;
+    } else if (x_lo) {
+      q.a_format = 1;           // the plan looks at it
+    }
+    const int k = g.k, pad = k / 2;
+    q.nb = nb; q.din = d; q.hin = h; q.win = w;
+    q.dout = d; q.hout = h; q.wout = w;
+    q.cin = g.cin_pad; q.cout = g.cout;
+    q.lda = lda; q.ldw = g.ldw; q.ldo = ldo; q.ldr = res ? ldr : 0; q.ldrv = rowvec ? ldrv : 0;
+    q.kd = q.kh = q.kw = k;
+    q.sd = q.sh = q.sw = 1;
+    q.pd = q.ph = q.pw = pad;
+    q.act = CS_ACT_NONE; q.rv_rows = rv_rows; q.math = pl.math; q.tile = 0;
+    int32_t sk = 1;
+    int64_t wsb = 0;
+    Buf skws;
+    if (cs_conv_gemm_plan(&q, &sk, &wsb) == CS_OK && sk > 1) {
+      skws = alloc(wsb / 4, 1);
+      if (!ok()) return;
+      q.splitk = sk;
+      q.splitk_ws = dry ? nullptr : p(skws);
+    }
+    if (!dry) chk(cs_conv_gemm(&q, st));
+    release(skws);
+  }
+
+  Buf gn_stats(const Buf& x, int nb, float eps, int groups = 32) {
+    Buf wsb = alloc((cs_groupnorm_ws_bytes(nb, groups) + 3) / 4, 1);
+    Buf stats = alloc((int64_t)nb * groups * 2, 1);
+    if (ok() && !dry) chk(cs_groupnorm_stats(p(x), nb, (int)(x.rows / nb), x.c, x.c, groups, eps, p(wsb), p(stats), st));
+    release(wsb);
+    return stats;
+  }
+  // GroupNorm apply of channels [ch0, ch0 + c) (x already points at channel ch0, row stride ldx) -> a fresh [rows][c]
+  // buffer, fp32 or the pre-split pair depending on the consuming conv
+  Buf gn_apply_range(const float* x, int ldx, int64_t rows_total, int nb, const Buf& stats, int ni, int groups, int cpg,
+                     int ch0, int c, int act, int conv_gi, int64_t m_launch) {
+    const Norm& n = pl.norms[ni];
+    Buf y = alloc(rows_total, c);
+    const int rows = (int)(rows_total / nb);
+    if (wants_split16(m_launch, conv_gi)) {      // m_launch: rows per launch of the consuming conv
+      y.half = true;
+      if (ok() && !dry) {
+        char* yh = reinterpret_cast<char*>(p(y));
+        chk(cs_groupnorm_apply_split16_range(x, p(stats), wf(n.g_off) + ch0, wf(n.b_off) + ch0, yh,
+                                             yh + rows_total * c * 2, nb, rows, c, ldx, c, groups, cpg, ch0, act, 16.0f,
+                                             status, st));
+      }
+      return y;
+    }
+    if (ok() && !dry)
+      chk(cs_groupnorm_apply_range(x, p(stats), wf(n.g_off) + ch0, wf(n.b_off) + ch0, p(y), nb, rows, c, ldx, c, groups,
+                                   cpg, ch0, act, st));
+    return y;
+  }
+
   Buf linear(const Buf& x, int gi, int act = CS_ACT_NONE, const float* rowvec = nullptr, int ldrv = 0,
              int rv_rows = 1, const float* res = nullptr, int ldr = 0, int tile = 0) {
     return gemm(x, gi, (int)x.rows, 1, 1, 1, 1, 0, act, rowvec, ldrv, rv_rows, res, ldr, tile);

@@ -113,9 +113,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta,
                                                        float* __restrict__ y, int rows, int c, int ldx, int ldy,
-                                                       int groups, int act, int rows_per_block) {
+                                                       int groups, int act, int rows_per_block, int cpg, int ch0) {
+  // (`groups` = row length of `stats`; the c channels handled here are channels ch0 .. ch0 + c of the normalised
+  // tensor -- x, gamma, beta and y already point at channel ch0 -- so channel k belongs to group (ch0 + k) / cpg)
   const int ch4 = c >> 2;
-  const int cpg = c / groups;
   const int tpr = ch4 < 256 ? ch4 : 256;   // threads per row
   const int rowlanes = 256 / tpr;
   const int tid = threadIdx.x;
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     float mean[4], rstd[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int grp = (c4 * 4 + k) / cpg;
+      const int grp = (ch0 + c4 * 4 + k) / cpg;
       mean[k] = st[grp * 2];
       rstd[k] = st[grp * 2 + 1];
     }
@@ -176,9 +177,8 @@ __global__ __launch_bounds__(256) void gn_apply_split16_kernel(const float* __re
                                                                _Float16* __restrict__ yh, _Float16* __restrict__ yl,
                                                                int rows, int c, int ldx, int ldy, int groups,
                                                                int act, float a_scale, int rows_per_block,
-                                                               int32_t* __restrict__ status) {
+                                                               int32_t* __restrict__ status, int cpg, int ch0) {
   const int ch4 = c >> 2;
-  const int cpg = c / groups;
   const int tpr = ch4 < 256 ? ch4 : 256;   // threads per row
   const int rowlanes = 256 / tpr;
   const int tid = threadIdx.x;
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void gn_apply_split16_kernel(const float* __re
     float mean[4], rstd[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int grp = (c4 * 4 + k) / cpg;
+      const int grp = (ch0 + c4 * 4 + k) / cpg;
       mean[k] = st[grp * 2];
       rstd[k] = st[grp * 2 + 1];
     }
@@ -412,12 +412,16 @@ extern "C" int cs_groupnorm_stats(const float* x, int nb, int rows, int c, int l
   return CS_OK;
 }
 
-extern "C" int cs_groupnorm_apply(const float* x, const float* stats, const float* gamma,
-                                  const float* beta, float* y, int nb, int rows, int c, int ldx,
-                                  int ldy, int groups, int act, cs_stream_t stream) {
-  if (!x || !stats || !gamma || !beta || !y || nb <= 0 || rows <= 0 || c <= 0 || groups <= 0)
+// Channel-range form of the two apply entries: the c channels handled are channels ch0 .. ch0 + c of a tensor that was
+// normalised over `groups` groups of `cpg` channels each (stats: [nb][groups][2]); x, gamma, beta and y point AT channel
+// ch0.  Lets one statistics pass over a concatenated tensor [h | skip] feed two separate operand tensors (the channel
+// split of the classifier-free-guidance output blocks, unet.py::_res_split).
+extern "C" int cs_groupnorm_apply_range(const float* x, const float* stats, const float* gamma, const float* beta,
+                                        float* y, int nb, int rows, int c, int ldx, int ldy, int groups, int cpg,
+                                        int ch0, int act, cs_stream_t stream) {
+  if (!x || !stats || !gamma || !beta || !y || nb <= 0 || rows <= 0 || c <= 0 || groups <= 0 || cpg <= 0 || ch0 < 0)
     return CS_EINVAL;
-  if ((c & 3) || (ldx & 3) || (ldy & 3) || ldx < c || ldy < c || c % groups) return CS_EINVAL;
+  if ((c & 3) || (ldx & 3) || (ldy & 3) || ldx < c || ldy < c || (int64_t)ch0 + c > (int64_t)groups * cpg) return CS_EINVAL;
   if (((uintptr_t)x & 15) || ((uintptr_t)y & 15) || ((uintptr_t)gamma & 15) ||
       ((uintptr_t)beta & 15))
     return CS_EINVAL;
@@ -431,18 +435,28 @@ extern "C" int cs_groupnorm_apply(const float* x, const float* stats, const floa
   if (blocks_per_sample < 1) blocks_per_sample = 1;
   const int rpb = (rows + blocks_per_sample - 1) / blocks_per_sample;
   CS_LAUNCH(gn_apply_kernel, dim3((unsigned)((rows + rpb - 1) / rpb), (unsigned)nb), dim3(256), 0,
-            (hipStream_t)stream, x, stats, gamma, beta, y, rows, c, ldx, ldy, groups, act, rpb);
+            (hipStream_t)stream, x, stats, gamma, beta, y, rows, c, ldx, ldy, groups, act, rpb, cpg, ch0);
   CS_CHECK_LAUNCH();
   return CS_OK;
 }
 
-extern "C" int cs_groupnorm_apply_split16(const float* x, const float* stats, const float* gamma,
-                                          const float* beta, void* y_hi, void* y_lo, int nb, int rows, int c,
-                                          int ldx, int ldy, int groups, int act, float a_scale,
-                                          int32_t* status, cs_stream_t stream) {
-  if (!x || !stats || !gamma || !beta || !y_hi || !y_lo || nb <= 0 || rows <= 0 || c <= 0 || groups <= 0)
+extern "C" int cs_groupnorm_apply(const float* x, const float* stats, const float* gamma,
+                                  const float* beta, float* y, int nb, int rows, int c, int ldx,
+                                  int ldy, int groups, int act, cs_stream_t stream) {
+  if (groups <= 0 || c <= 0 || c % groups) return CS_EINVAL;
+  return cs_groupnorm_apply_range(x, stats, gamma, beta, y, nb, rows, c, ldx, ldy, groups, c / groups, 0, act, stream);
+}
+
+extern "C" int cs_groupnorm_apply_split16_range(const float* x, const float* stats, const float* gamma,
+                                                const float* beta, void* y_hi, void* y_lo, int nb, int rows, int c,
+                                                int ldx, int ldy, int groups, int cpg, int ch0, int act, float a_scale,
+                                                int32_t* status, cs_stream_t stream) {
+  if (!x || !stats || !gamma || !beta || !y_hi || !y_lo || nb <= 0 || rows <= 0 || c <= 0 || groups <= 0 || cpg <= 0 ||
+      ch0 < 0)
     return CS_EINVAL;
-  if ((c & 7) || (ldx & 3) || (ldy & 7) || ldx < c || ldy < c || c % groups || !(a_scale > 0.f)) return CS_EINVAL;
+  if ((c & 7) || (ldx & 3) || (ldy & 7) || ldx < c || ldy < c || (int64_t)ch0 + c > (int64_t)groups * cpg ||
+      !(a_scale > 0.f))
+    return CS_EINVAL;
   if (((uintptr_t)x & 15) || ((uintptr_t)y_hi & 15) || ((uintptr_t)y_lo & 15) || ((uintptr_t)gamma & 15) ||
       ((uintptr_t)beta & 15))
     return CS_EINVAL;
@@ -456,9 +470,18 @@ extern "C" int cs_groupnorm_apply_split16(const float* x, const float* stats, co
   const int rpb = (rows + blocks_per_sample - 1) / blocks_per_sample;
   CS_LAUNCH(gn_apply_split16_kernel, dim3((unsigned)((rows + rpb - 1) / rpb), (unsigned)nb), dim3(256), 0,
             (hipStream_t)stream, x, stats, gamma, beta, (_Float16*)y_hi, (_Float16*)y_lo, rows, c, ldx, ldy, groups, act,
-            a_scale, rpb, status);
+            a_scale, rpb, status, cpg, ch0);
   CS_CHECK_LAUNCH();
   return CS_OK;
+}
+
+extern "C" int cs_groupnorm_apply_split16(const float* x, const float* stats, const float* gamma,
+                                          const float* beta, void* y_hi, void* y_lo, int nb, int rows, int c,
+                                          int ldx, int ldy, int groups, int act, float a_scale,
+                                          int32_t* status, cs_stream_t stream) {
+  if (groups <= 0 || c <= 0 || c % groups) return CS_EINVAL;
+  return cs_groupnorm_apply_split16_range(x, stats, gamma, beta, y_hi, y_lo, nb, rows, c, ldx, ldy, groups, c / groups, 0,
+                                          act, a_scale, status, stream);
 }
 
 extern "C" int cs_groupnorm(const float* x, const float* gamma, const float* beta, float* y, int nb, int rows, int c,

@@ -25,6 +25,10 @@ struct Layer {
   int g[8];
   int n[4];
   int emb_lo = 0;      // RES: column offset into the batched emb_layers projection
+  // RES of an output block whose skip half is shared by the guidance halves (unet.py::_pack "channel-split ResBlocks"):
+  // split channel ks (> 0), channels of h, and the GEMMs {in_layers.2 h, in_layers.2 s, skip_connection h, skip_connection s}
+  int ks = 0, ch_h = 0;
+  int gsp[4] = {-1, -1, -1, -1};
   int ctx_off = 0;     // ATTN: column offset into the context-vector block
   bool fused_geglu = false;
 };
@@ -229,6 +233,42 @@ int build(cs_unet& u) {
       u.out.push_back(layers);
     }
   }
+  // channel-split ResBlocks: output block j reads the skip of input block (n_in - 1 - j); the ones from the context-free
+  // prefix of the input path (before the first attention block) are shared by the guidance halves.  Same rule and same
+  // split point as unet.py::_pack.
+  if (c.use_spatial_transformer && !getenv("CS_NO_CFG_SPLIT")) {
+    size_t n_prefix = 0;
+    while (n_prefix < u.inp.size()) {
+      bool attn = false;
+      for (const Layer& l : u.inp[n_prefix]) attn |= (l.kind == ATTN || l.kind == ATTNBLOCK);
+      if (attn) break;
+      ++n_prefix;
+    }
+    for (size_t j = 0; j < u.out.size(); ++j) {
+      const size_t src = u.inp.size() - 1 - j;
+      Layer& l = u.out[j][0];
+      if (src >= n_prefix || l.kind != RES || l.g[2] < 0) continue;
+      const int ch_s = u.inp[src].back().cout, C = l.cin, ch_h = C - ch_s, cpg = C / 32;
+      if (C % 32) continue;
+      int ks = 0;
+      for (int k = (ch_h + 15) / 16 * 16; k < C; k += 16)
+        if ((k / cpg) * cpg >= ch_h) {
+          ks = k;
+          break;
+        }
+      if (!ks || (C - ks) % 16) continue;
+      for (int which = 0; which < 2; ++which) {          // in_layers.2 (3x3x3), skip_connection (1x1x1)
+        const int gi = l.g[which == 0 ? 0 : 2];
+        const int wp = u.gemms[gi].w[0].param, bp = u.gemms[gi].b.empty() ? -1 : u.gemms[gi].b[0].param;
+        const int k = u.gemms[gi].k;
+        u.gemms[gi].unused = true;
+        l.gsp[2 * which] = add_gemm_cin_range(u, wp, bp, l.cout, C, k, 0, ks);
+        l.gsp[2 * which + 1] = add_gemm_cin_range(u, wp, -1, l.cout, C, k, ks, C);
+      }
+      l.ks = ks;
+      l.ch_h = ch_h;
+    }
+  }
   u.ch_final = ch;
   u.n_out = add_norm(u, P + "out.0", ch);
   u.g_out = add_layer_gemm(u, P + "out.2", c.out_channels, mc, 3);
@@ -258,6 +298,62 @@ struct Exec : ExecBase {
     o.b = gemm(hn2, l.g[1], x.nb, x.d, x.h, x.w, 1, 0, CS_ACT_NONE, nullptr, 0, 1, dry ? nullptr : p(skip), skip.c);
     release(hn2);
     if (l.g[2] >= 0) release(skip);
+    return o;
+  }
+
+  // ResBlock whose input is the concatenation x = [h | skip] with the skip half shared by nb / sk.nb groups of samples
+  // (the guidance halves): in_layers' conv and skip_connection are each evaluated as a GEMM over channels [0, ks) at the
+  // full batch plus a GEMM over channels [ks, C) -- whole GroupNorm groups of skip channels -- at batch sk.nb, which
+  // enters the first one's epilogue as a residual.  Same launches, in the same order, as unet.py::_res_split.
+  Act res_block_split(const Layer& l, const Act& x, const Act& sk, const Buf& semb) {
+    const int rows = x.d * x.h * x.w, C = x.b.c, ks = l.ks, cs = C - ks, off = ks - l.ch_h, cpg = C / 32;
+    const int nb = x.nb, nbs = sk.nb, ch_s = sk.b.c, cout = l.cout;
+    Act o = x;
+    if (nbs <= 0 || nb % nbs || ch_s != C - l.ch_h) {
+      chk(CS_EINVAL);
+      return o;
+    }
+    const int64_t m_launch = (int64_t)nbs * rows;
+    Buf stats = gn_stats(x.b, nb, 1e-5f);
+    const float* xs = dry ? nullptr : p(sk.b) + off;           // the shared channels of the skip tensor
+    Buf a_h = gn_apply_range(dry ? nullptr : p(x.b), C, x.b.rows, nb, stats, l.n[0], 32, cpg, 0, ks, CS_ACT_SILU, l.gsp[0],
+                             m_launch);
+    Buf a_s = gn_apply_range(xs, ch_s, sk.b.rows, nbs, stats, l.n[0], 32, cpg, ks, cs, CS_ACT_SILU, l.gsp[1], m_launch);
+    release(stats);
+    auto lo_of = [&](const Buf& b) -> const void* {            // lo image of a pre-split pair
+      return (b.half && !dry) ? reinterpret_cast<const char*>(p(b)) + b.rows * b.c * 2 : nullptr;
+    };
+    Buf y_s = alloc(sk.b.rows, cout);
+    if (ok()) gemm_view(dry ? nullptr : p(a_s), a_s.half ? (dry ? (const void*)1 : lo_of(a_s)) : nullptr, cs, l.gsp[1], nbs,
+                        x.d, x.h, x.w, dry ? nullptr : p(y_s), cout);
+    release(a_s);
+    Buf h1 = alloc(x.b.rows, cout);
+    Buf skc = alloc(x.b.rows, cout);
+    Buf s_s = alloc(sk.b.rows, cout);
+    if (ok()) gemm_view(xs, nullptr, ch_s, l.gsp[3], nbs, x.d, x.h, x.w, dry ? nullptr : p(s_s), cout);
+    for (int g = 0; g < nb / nbs && ok(); ++g) {
+      const int64_t r0 = (int64_t)g * nbs * rows;
+      const float* ah = nullptr;
+      const void* al = a_h.half ? (const void*)1 : nullptr;
+      if (!dry) {
+        // fp32: rows of ks floats; pre-split: two fp16 images of ks halves per row
+        ah = a_h.half ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(p(a_h)) + r0 * ks * 2) : p(a_h) + r0 * ks;
+        if (a_h.half) al = reinterpret_cast<const char*>(lo_of(a_h)) + r0 * ks * 2;
+      }
+      gemm_view(ah, al, ks, l.gsp[0], nbs, x.d, x.h, x.w, dry ? nullptr : p(h1) + r0 * cout, cout,
+                dry ? nullptr : p(semb) + (int64_t)g * nbs * semb.c + l.emb_lo, semb.c, rows, dry ? nullptr : p(y_s), cout);
+      if (ok())
+        gemm_view(dry ? nullptr : p(x.b) + r0 * C, nullptr, C, l.gsp[2], nbs, x.d, x.h, x.w,
+                  dry ? nullptr : p(skc) + r0 * cout, cout, nullptr, 0, 1, dry ? nullptr : p(s_s), cout);
+    }
+    release(a_h);
+    release(y_s);
+    release(s_s);
+    Buf hn2 = groupnorm(h1, l.n[1], nb, 1e-5f, CS_ACT_SILU, 32, l.g[1]);
+    release(h1);
+    o.b = gemm(hn2, l.g[1], nb, x.d, x.h, x.w, 1, 0, CS_ACT_NONE, nullptr, 0, 1, dry ? nullptr : p(skc), cout);
+    release(hn2);
+    release(skc);
     return o;
   }
 
@@ -330,10 +426,18 @@ struct Exec : ExecBase {
   }
 
   // runs the layers of one block; `keep_in` says whether the caller still needs the input buffer
-  Act run(const std::vector<Layer>& layers, Act h, const Buf& semb, const float* ctxvec, bool keep_in) {
+  Act run(const std::vector<Layer>& layers, Act h, const Buf& semb, const float* ctxvec, bool keep_in,
+          const Act* split_skip = nullptr) {
     bool owned = !keep_in;
     for (const Layer& l : layers) {
       Act o;
+      if (l.kind == RES && l.ks > 0 && split_skip && &l == &layers[0]) {
+        o = res_block_split(l, h, *split_skip, semb);
+        if (owned) release(h.b);
+        h = o;
+        owned = true;
+        continue;
+      }
       switch (l.kind) {
         case CONV_IN:
           o = h;
@@ -455,8 +559,13 @@ int forward(Exec& e, const float* x_ncdhw, const int64_t* t, const float* ctxvec
                            sk.b.c, cat.b.c, e.st));
     }
     e.release(h.b);
-    e.release(sk.b);
-    h = e.run(layers, cat, semb, ctxvec, false);
+    if (layers[0].kind == RES && layers[0].ks > 0) {
+      h = e.run(layers, cat, semb, ctxvec, false, &sk);      // the skip tensor itself feeds the shared GEMMs
+      e.release(sk.b);
+    } else {
+      e.release(sk.b);
+      h = e.run(layers, cat, semb, ctxvec, false);
+    }
     if (!e.ok()) return e.rc;
   }
   Buf hn = e.groupnorm(h.b, u.n_out, h.nb, 1e-5f, CS_ACT_SILU, 32, u.g_out);

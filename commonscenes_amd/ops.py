@@ -135,14 +135,15 @@ class PackedWeight:
 
 
 def pack_weight(w: Tensor, bias: Optional[Tensor] = None, cin_pad: Optional[int] = None,
-                math: int = L.MATH_FP32, fold_up: Optional[Sequence[int]] = None) -> PackedWeight:
+                math: int = L.MATH_FP32, fold_up: Optional[Sequence[int]] = None,
+                amax: Optional[float] = None) -> PackedWeight:
     """torch Conv3d (cout,cin,kd,kh,kw) or Linear (out,in) weight -> PackedWeight (device op).
     fold_up=(ud,uh,uw): the conv follows a nearest x2 upsampling of the flagged dims; its taps are pre-summed per output
     parity class (cs_fold_upsample_weight) and conv_gemm(..., up=fold_up) runs on the source grid."""
     if fold_up is not None and any(fold_up) and FOLD_UPSAMPLE:
         return _pack_weight_folded(w, bias, cin_pad, math, tuple(int(u) for u in fold_up))
     if math == L.MATH_F16X3:
-        return _pack_weight_f16x3(w, bias, cin_pad)
+        return _pack_weight_f16x3(w, bias, cin_pad, amax)
     _chk(w, "weight")
     w = w.contiguous()
     if w.dim() == 5:
@@ -189,8 +190,11 @@ def _pack_weight_folded(w: Tensor, bias: Optional[Tensor], cin_pad: Optional[int
     return PackedWeight(None, c0.bias, cout, cin, c0.cin_pad, c0.ldw, (3, 3, 3), math, None, None, 1.0, up, classes)
 
 
-def _pack_weight_f16x3(w: Tensor, bias: Optional[Tensor], cin_pad: Optional[int]) -> PackedWeight:
-    """fp32 weight -> (hi, lo) fp16 halves of w * 2^s with max|w| * 2^s < 2^14 (cs_pack_weight_f16x3)."""
+def _pack_weight_f16x3(w: Tensor, bias: Optional[Tensor], cin_pad: Optional[int],
+                       amax: Optional[float] = None) -> PackedWeight:
+    """fp32 weight -> (hi, lo) fp16 halves of w * 2^s with max|w| * 2^s < 2^14 (cs_pack_weight_f16x3).
+    `amax`: take the power-of-two scale from this magnitude instead of max|w| -- an input-channel slice of a tensor packed
+    with the WHOLE tensor's scale (both hosts do that for the channel-split convs, so they stay bit-identical)."""
     import math as _m
     _chk(w, "weight")
     w = w.contiguous()
@@ -203,7 +207,8 @@ def _pack_weight_f16x3(w: Tensor, bias: Optional[Tensor], cin_pad: Optional[int]
         raise L.CsError("weight must be 2-D (Linear) or 5-D (Conv3d)")
     taps = kd * kh * kw
     cp = cin_pad if cin_pad is not None else (cin + 3) // 4 * 4
-    amax = float(w.abs().max().item())            # weight preparation (load time), not the sampling loop
+    if amax is None:
+        amax = float(w.abs().max().item())        # weight preparation (load time), not the sampling loop
     e = _m.frexp(amax)[1] if amax > 0 and _m.isfinite(amax) else 0
     scale = 2.0 ** (14 - e)
     kg = (cin + 15) // 16 * 2
@@ -478,6 +483,9 @@ class Split16:
     def view(self, *shape):
         return Split16(self.hi.view(*shape), self.lo.view(*shape))
 
+    def __getitem__(self, idx):
+        return Split16(self.hi[idx], self.lo[idx])
+
 
 # Producer-side operand split: GroupNorm writes the fp16 hi/lo pair of y * A_SCALE (same bytes as fp32 y) and the GEMM
 # DMA-loads it with a_format=1, so its K loop carries no conversion VALU.  With the per-tap gather kernels this was
@@ -518,6 +526,46 @@ def groupnorm(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float, a
     L.check(lib.cs_groupnorm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), nb, rows, c, ldx, ldy,
                              groups, eps, act, ws.data_ptr(), stats.data_ptr(), _stream()), "cs_groupnorm")
     return out
+
+
+def groupnorm_stats(x: Tensor, groups: int, eps: float) -> Tensor:
+    """(mean, rstd) per (sample, group) of a channels-last tensor: [nb, groups, 2] fp32 (fp64 accumulation)."""
+    _chk(x, "x")
+    nb = x.shape[0]
+    m, c, ldx = rows_ld(x, "x")
+    lib = L.load()
+    ws = torch.empty(lib.cs_groupnorm_ws_bytes(nb, groups) // 8, dtype=torch.float64, device=x.device)
+    stats = torch.empty((nb, groups, 2), dtype=torch.float32, device=x.device)
+    L.check(lib.cs_groupnorm_stats(x.data_ptr(), nb, m // nb, c, ldx, groups, eps, ws.data_ptr(), stats.data_ptr(),
+                                   _stream()), "cs_groupnorm_stats")
+    return stats
+
+
+def groupnorm_apply_range(x: Tensor, stats: Tensor, gamma: Tensor, beta: Tensor, cpg: int, ch0: int,
+                          act: int = L.ACT_NONE, split16: bool = False):
+    """Normalise + affine + activation of a CHANNEL RANGE: x (and gamma / beta) hold channels ch0 .. ch0 + c of a tensor
+    whose statistics `stats` [nb', groups, 2] were taken over groups of cpg channels (cs_groupnorm_apply_range); sample n
+    of x uses stats[n].  split16=True returns the Split16 operand pair."""
+    _chk(x, "x"); _chk(stats, "stats")
+    nb = x.shape[0]
+    m, c, ldx = rows_ld(x, "x")
+    groups = stats.shape[1]
+    if stats.shape[0] < nb or not stats.is_contiguous() or gamma.numel() != c or beta.numel() != c:
+        raise L.CsError("groupnorm_apply_range: stats / gamma / beta do not match x")
+    lib = L.load()
+    if split16 and SPLIT16_PRODUCERS:
+        yh = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+        yl = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+        L.check(lib.cs_groupnorm_apply_split16_range(x.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                                     yh.data_ptr(), yl.data_ptr(), nb, m // nb, c, ldx, c, groups, cpg,
+                                                     ch0, act, A_SCALE, status_word(x.device).data_ptr(), _stream()),
+                "cs_groupnorm_apply_split16_range")
+        return Split16(yh, yl)
+    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    L.check(lib.cs_groupnorm_apply_range(x.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+                                         nb, m // nb, c, ldx, c, groups, cpg, ch0, act, _stream()),
+            "cs_groupnorm_apply_range")
+    return y
 
 
 def layernorm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5, out: Optional[Tensor] = None) -> Tensor:

@@ -347,6 +347,38 @@ class DiffusionUNet:
         for i, layers in enumerate(out):
             pack_block(f"{P}output_blocks.{i}", layers)
         pw(P + "out.2")
+        # Channel-split ResBlocks (r3).  Output block j concatenates [h | skip_j]; for the blocks whose skip comes from
+        # the CONTEXT-FREE PREFIX of the input path (everything before the first attention block: conv_in, two
+        # ResBlocks, the first Downsample) that skip is the same tensor for both classifier-free-guidance halves
+        # (samplers/ddim.py:206-209 duplicates x).  The part of in_layers' conv / skip_connection that reads whole
+        # GroupNorm groups of skip channels is therefore the same for both halves: it is evaluated as its own GEMM
+        # (K = the shared channels, at batch B under forward_cfg) and enters the other part's epilogue as a residual.
+        # The split point Ks is the first multiple of 16 channels from which every GroupNorm group lies inside the
+        # skip (672 = 448 + 224 channels in 21-channel groups: Ks = 464; 448 = 224 + 224: Ks = 224).  The same
+        # decomposition runs without guidance pairs (then at the full batch), so per-sample results do not depend on it.
+        self._split_info = {}
+        n_prefix = next((i for i, layers in enumerate(inp) if any(l["kind"] == "attn" for l in layers)), len(inp))
+        if self.cfg["use_spatial_transformer"] and not os.environ.get("CS_NO_CFG_SPLIT"):
+            for j, layers in enumerate(out):
+                src = len(inp) - 1 - j
+                l = layers[0]
+                if src >= n_prefix or l["kind"] != "res":
+                    continue
+                ch_s = inp[src][-1]["cout"]
+                C = l["cin"]
+                ch_h, cpg = C - ch_s, C // 32
+                ks = next((k for k in range((ch_h + 15) // 16 * 16, C, 16) if (k // cpg) * cpg >= ch_h), None)
+                if ks is None or C % 32 or (C - ks) % 16 or l["cin"] == l["cout"]:
+                    continue
+                q = f"{P}output_blocks.{j}.0"
+                for name in (".in_layers.2", ".skip_connection"):
+                    wfull = sd[q + name + ".weight"]
+                    am = float(wfull.abs().max().item())
+                    pk[q + name + ":h"] = ops.pack_weight(wfull[:, :ks].contiguous(), sd[q + name + ".bias"],
+                                                          math=self.math, amax=am)
+                    pk[q + name + ":s"] = ops.pack_weight(wfull[:, ks:].contiguous(), None, math=self.math, amax=am)
+                    del pk[q + name]
+                self._split_info[q] = (ks, ch_h)
         # all 17 ResBlock `emb_layers` Linears read the same SiLU(emb): one GEMM [B,896] x [896, sum(cout)]
         # instead of 17 launch-bound ones; each ResBlock takes its column slice as the conv's row vector.
         names, off, ws, bs = [], 0, [], []
@@ -380,6 +412,42 @@ class DiffusionUNet:
                             split16=ops.wants_split16(nb * rows, pk[p + ".out_layers.3"]))
         skip = x if l["cin"] == l["cout"] else ops.conv_gemm(x, pk[p + ".skip_connection"], math=self.math)
         return ops.conv_gemm(hn2, pk[p + ".out_layers.3"], res=skip, math=self.math, out_fn=out_fn)
+
+    def _res_split(self, p: str, l: dict, x: Tensor, skip: Tensor, semb: Tensor, out_fn=None) -> Tensor:
+        """ResBlock of an output block whose skip half is shared by the guidance halves (see _pack): x = the
+        concatenation [h | skip] at the full batch nb, `skip` = the skip tensor itself at batch nbs (nb / 2 under
+        forward_cfg, nb otherwise; a view into x's right half in the latter case).
+            in_layers:  conv(SiLU(GN(x)))       = conv_h(GN(x)[:, :Ks]) + conv_s(GN(x)[:, Ks:])    -- conv_s at batch nbs
+            skip_connection (1x1x1):  W x + b   = W_h x[:, :Ks] + b + W_s skip[:, Ks - ch_h:]      -- likewise
+        GroupNorm statistics are taken over the whole concatenation (one pass, as before); channels >= Ks lie in groups
+        made of skip channels only, so sample n and sample n + nbs normalise them identically."""
+        sd, pk = self._sd, self._packed
+        ks, ch_h = self._split_info[p]
+        nb, d, h, w, C = x.shape
+        nbs = skip.shape[0]
+        rows, cpg, off = d * h * w, C // 32, ks - ch_h
+        if nb % nbs or skip.shape[-1] != C - ch_h:
+            raise L.CsError("channel-split ResBlock: skip tensor does not match the concatenation")
+        gam, bet = sd[p + ".in_layers.0.weight"], sd[p + ".in_layers.0.bias"]
+        wh, ws = pk[p + ".in_layers.2:h"], pk[p + ".in_layers.2:s"]
+        stats = ops.groupnorm_stats(x, 32, 1e-5)
+        a_h = ops.groupnorm_apply_range(x[..., :ks], stats, gam[:ks], bet[:ks], cpg, 0, L.ACT_SILU,
+                                        split16=ops.wants_split16(nbs * rows, wh))
+        a_s = ops.groupnorm_apply_range(skip[..., off:], stats, gam[ks:], bet[ks:], cpg, ks, L.ACT_SILU,
+                                        split16=ops.wants_split16(nbs * rows, ws))
+        y_s = ops.conv_gemm(a_s, ws, math=self.math)
+        lo, hi = self._emb_slices[p]
+        cout = l["cout"]
+        h1 = torch.empty((nb, d, h, w, cout), dtype=torch.float32, device=x.device)
+        sk = torch.empty((nb, d, h, w, cout), dtype=torch.float32, device=x.device)
+        s_s = ops.conv_gemm(skip[..., off:], pk[p + ".skip_connection:s"], math=self.math)
+        for g in range(nb // nbs):                    # one launch per guidance half: both read the shared term
+            sl = slice(g * nbs, (g + 1) * nbs)
+            ops.conv_gemm(a_h[sl], wh, rowvec=semb[sl, lo:hi], rv_rows=rows, res=y_s, out=h1[sl], math=self.math)
+            ops.conv_gemm(x[sl][..., :ks], pk[p + ".skip_connection:h"], res=s_s, out=sk[sl], math=self.math)
+        hn2 = ops.groupnorm(h1, sd[p + ".out_layers.0.weight"], sd[p + ".out_layers.0.bias"], 32, 1e-5, L.ACT_SILU,
+                            split16=ops.wants_split16(nb * rows, pk[p + ".out_layers.3"]))
+        return ops.conv_gemm(hn2, pk[p + ".out_layers.3"], res=sk, math=self.math, out_fn=out_fn)
 
     def _context_vectors(self, ctx: Tensor):
         """One-token context: every transformer block's cross-attention output is the per-sample
@@ -457,7 +525,7 @@ class DiffusionUNet:
         out = ops.linear(t2, pk[p + ".proj_out"], res=x.view(nb, n, c), math=self.math, out=dst)
         return out.view(nb, d, h, w, c)
 
-    def _run(self, bp: str, layers, h: Tensor, semb: Tensor, ctx: Tensor, out_fn=None) -> Tensor:
+    def _run(self, bp: str, layers, h: Tensor, semb: Tensor, ctx: Tensor, out_fn=None, split_skip=None) -> Tensor:
         """`out_fn(shape) -> tensor`: where the block's LAST layer writes its result (a channel slice of the
         concatenation buffer of the output block that consumes it: torch.cat([h, hs.pop()], 1) then costs no copy)."""
         pk = self._packed
@@ -468,7 +536,10 @@ class DiffusionUNet:
             if k == "conv_in":
                 h = ops.conv_gemm(h, pk[p], math=self.math, out_fn=of)
             elif k == "res":
-                h = self._res(p, l, h, semb, of)
+                if li == 0 and split_skip is not None and p in self._split_info:
+                    h = self._res_split(p, l, h, split_skip, semb, of)
+                else:
+                    h = self._res(p, l, h, semb, of)
             elif k == "attn":
                 h = (self._attn(p, l, h, ctx, of) if self.cfg["use_spatial_transformer"]
                      else self._attnblock(p, l, h, of))
@@ -549,8 +620,13 @@ class DiffusionUNet:
                         ops.copy_rows(skip, right[g * nbs:(g + 1) * nbs])
                 h = cats[i]
                 cats[i] = None
+            # channel-split blocks take the skip tensor itself: the shared (B-sized) one under guidance pairs, else the
+            # right half of the concatenation
+            split_skip = None
+            if f"{P}output_blocks.{i}.0" in self._split_info:
+                split_skip = skip if skip is not None else h[..., ch_h[i]:]
             h = self._run(f"{P}output_blocks.{i}", layers, h, semb, ctx,
-                          slot(i + 1, True) if nocopy and i + 1 < nout else None)
+                          slot(i + 1, True) if nocopy and i + 1 < nout else None, split_skip=split_skip)
             if tr is not None:
                 tr[f"output_blocks.{i}"] = h
         hn = ops.groupnorm(h, sd[P + "out.0.weight"], sd[P + "out.0.bias"], 32, 1e-5, L.ACT_SILU,

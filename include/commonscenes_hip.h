@@ -17,8 +17,13 @@
  *   - activations are channels-last: NDHWC, i.e. [n][d][h][w][c] with c contiguous and an
  *     explicit row stride `ld*` (in floats) so a tensor can live inside a wider
  *     (concatenated) buffer.  Token matrices [n][tokens][c] are the same memory.
- *   - all arithmetic is fp32 (fp32-input MFMA v_mfma_f32_32x32x2_f32, fp32 accumulate);
- *     GroupNorm statistics accumulate in fp64.
+ *   - all tensors are fp32 and every contraction accumulates in fp32.  The GEMM-shaped entries (cs_conv_gemm and its
+ *     wrappers, cs_attn_selfattn_f16x3, the cs_unet_* / cs_vqvae_* drivers) have two numerics modes: CS_MATH_FP32
+ *     (fp32 operands on v_mfma_f32_32x32x2_f32: bit-equal to an fp32 fma chain) and CS_MATH_F16X3 -- the mode the host
+ *     classes and bench.py START in -- which carries every fp32 operand as an fp16 hi/lo pair and issues three
+ *     v_mfma_f32_32x32x16_f16 per K = 16 step (~2^-22 per product, fp32-grade by measurement; operands must satisfy
+ *     |a| * a_scale < 65504, reported through the CS_STATUS_F16X3_OVERFLOW word below).  cs_attn_selfattn_f16 (plain
+ *     fp16 operands) is an opt-in reduced-precision mode.  GroupNorm statistics accumulate in fp64.
  */
 #ifndef COMMONSCENES_HIP_H
 #define COMMONSCENES_HIP_H
@@ -185,6 +190,18 @@ int cs_groupnorm_apply(const float* x, const float* stats, const float* gamma, c
 int cs_groupnorm_apply_split16(const float* x, const float* stats, const float* gamma, const float* beta,
                                void* y_hi, void* y_lo, int nb, int rows, int c, int ldx, int ldy, int groups,
                                int act, float a_scale, int32_t* status, cs_stream_t stream);
+/* Channel-range forms of the two apply entries (ABI 11): the c channels handled are channels ch0 .. ch0 + c of a tensor
+ * whose statistics were taken over `groups` groups of `cpg` channels (stats: [nb][groups][2]); x, gamma, beta and the
+ * outputs point AT channel ch0 (ch0 % 4 == 0).  One statistics pass over a channel concatenation [h | skip]
+ * (openai_model_3d.py:781 followed by in_layers, :294-300) can then feed separate GEMM operands per channel range:
+ * under classifier-free guidance the skip half of output blocks 5-8 is the same tensor for both guidance halves
+ * (samplers/ddim.py:206-209 duplicates x), so its part of the convolution is evaluated once (unet.py::_res_split). */
+int cs_groupnorm_apply_range(const float* x, const float* stats, const float* gamma, const float* beta, float* y,
+                             int nb, int rows, int c, int ldx, int ldy, int groups, int cpg, int ch0, int act,
+                             cs_stream_t stream);
+int cs_groupnorm_apply_split16_range(const float* x, const float* stats, const float* gamma, const float* beta,
+                                     void* y_hi, void* y_lo, int nb, int rows, int c, int ldx, int ldy, int groups,
+                                     int cpg, int ch0, int act, float a_scale, int32_t* status, cs_stream_t stream);
 /* Statistics + normalisation + activation in one call (what the hosts use): a single launch (one workgroup per
  * (sample, group), fp64 sums in a fixed order) while the tensor is at most 16 MB and a group at most 11264 elements
  * (one or two objects at the 16x4x4 level: there the three launches above sit at their launch floors), otherwise cs_groupnorm_stats +

@@ -53,6 +53,85 @@ def test_oracle_marching_cubes_invariants():
     assert v.shape == (0, 3) and f.shape == (0, 3)
 
 
+def _torus(n, c, R, r):
+    g = np.mgrid[0:n, 0:n, 0:n].astype(np.float64)
+    q = np.sqrt((g[0] - c[0]) ** 2 + (g[1] - c[1]) ** 2) - R
+    return np.sqrt(q ** 2 + (g[2] - c[2]) ** 2) - r
+
+
+def _geometry(v, f):
+    """(area, enclosed volume by the divergence theorem, max edge length) of a closed triangle mesh"""
+    tri = v[f].astype(np.float64)
+    area = 0.5 * np.linalg.norm(np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]), axis=1).sum()
+    vol = abs(np.einsum("ij,ij->i", tri[:, 0], np.cross(tri[:, 1], tri[:, 2])).sum()) / 6.0
+    edge = max(np.linalg.norm(tri[:, i] - tri[:, (i + 1) % 3], axis=1).max() for i in range(3))
+    return area, vol, edge
+
+
+# analytic shapes at the decoder's resolution, in the product's units: SDF = distance / 64, level 0.02 (util_3d.py:215)
+# -> the extracted surface is the offset surface at +1.28 voxels.  Geometry ANY correct marching cubes -- the reference's
+# PyMCubes included -- must reproduce (VERDICT r2 next #7d): area, enclosed volume, Hausdorff distance, genus.
+_SHAPES = [
+    ("sphere r=20", lambda n: _sphere(n, (31.3, 32.1, 30.7), 20.0).astype(np.float64), "sphere", (31.3, 32.1, 30.7), (20.0,), 2),
+    ("sphere r=9", lambda n: _sphere(n, (30.2, 33.4, 31.9), 9.0).astype(np.float64), "sphere", (30.2, 33.4, 31.9), (9.0,), 2),
+    ("torus R=17 r=6", lambda n: _torus(n, (31.6, 32.2, 31.1), 17.0, 6.0), "torus", (31.6, 32.2, 31.1), (17.0, 6.0), 0),
+]
+
+
+def _check_analytic(name, v, f, kind, c, prm, chi, off):
+    """v in INDEX coordinates.  off = level * 64 (the offset of the extracted surface from the shape's)."""
+    c = np.asarray(c)
+    assert RM.mesh_invariants(v, f) == (0, 0, 0, chi), name            # closed, manifold, oriented, right genus
+    area, vol, edge = _geometry(v, f)
+    if kind == "sphere":
+        R = prm[0] + off
+        a0, v0 = 4 * np.pi * R * R, 4.0 / 3.0 * np.pi * R ** 3
+        dist = lambda p: np.abs(np.linalg.norm(p - c, axis=1) - R)
+        th, ph = np.random.default_rng(1).uniform(0, np.pi, 4000), np.random.default_rng(2).uniform(0, 2 * np.pi, 4000)
+        surf = c + R * np.stack([np.sin(th) * np.cos(ph), np.sin(th) * np.sin(ph), np.cos(th)], 1)
+    else:
+        R, r = prm[0], prm[1] + off
+        a0, v0 = 4 * np.pi ** 2 * R * r, 2 * np.pi ** 2 * R * r * r
+        dist = lambda p: np.abs(np.sqrt((np.sqrt((p[:, 0] - c[0]) ** 2 + (p[:, 1] - c[1]) ** 2) - R) ** 2 +
+                                        (p[:, 2] - c[2]) ** 2) - r)
+        u, w = np.random.default_rng(1).uniform(0, 2 * np.pi, 4000), np.random.default_rng(2).uniform(0, 2 * np.pi, 4000)
+        surf = c + np.stack([(R + r * np.cos(w)) * np.cos(u), (R + r * np.cos(w)) * np.sin(u), r * np.sin(w)], 1)
+    tri = v[f].astype(np.float64)
+    # mesh -> surface, over vertices AND triangle interiors (centroids / edge midpoints carry the sagitta)
+    pts = np.concatenate([v.astype(np.float64), tri.mean(1), 0.5 * (tri[:, 0] + tri[:, 1])])
+    h_ms = float(dist(pts).max())
+    # surface -> mesh, bounded through the nearest mesh vertex (<= the distance to the nearest triangle + an edge)
+    from scipy.spatial import cKDTree
+    h_sm = float(cKDTree(v.astype(np.float64)).query(surf)[0].max())
+    print(f"{name}: area {area / a0 - 1:+.2e} volume {vol / v0 - 1:+.2e} Hausdorff mesh->surface {h_ms:.3f} voxel, "
+          f"surface->nearest vertex {h_sm:.3f} voxel, max edge {edge:.2f}")
+    assert abs(area / a0 - 1) < 4e-3 and abs(vol / v0 - 1) < 6e-3, name      # faceting: O((h / R)^2)
+    assert h_ms < 0.06 and h_sm < 1.0 and edge < 2.0, name
+
+
+@pytest.mark.parametrize("shape", _SHAPES, ids=[s[0] for s in _SHAPES])
+def test_oracle_mesh_geometry_against_analytic_shapes(shape):
+    name, fn, kind, c, prm, chi = shape
+    v, f = RM.marching_cubes((fn(64) / 64.0).astype(np.float32), 0.02)
+    _check_analytic(name, v, f, kind, c, prm, chi, 0.02 * 64)
+
+
+@pytest.mark.gpu
+def test_sdf_to_mesh_geometry_against_analytic_shapes():
+    """the same geometry gates on the PRODUCT entry (sdf_to_mesh: batch of three 64^3 SDFs, level 0.02, vertices
+    normalised verts / 64 - .5 as util_3d.py:216 does), plus exact equality with the oracle at this size."""
+    from commonscenes_amd.mesh import sdf_to_mesh
+    vols = np.stack([(s[1](64) / 64.0).astype(np.float32) for s in _SHAPES])
+    m = sdf_to_mesh(torch.from_numpy(vols)[:, None], level=0.02, render_all=True)      # a CPU tensor: uploaded, like the
+    torch.cuda.synchronize()                                                            # reference accepts either
+    for b, (name, fn, kind, c, prm, chi) in enumerate(_SHAPES):
+        v = (m.verts_list()[b].cpu().numpy().astype(np.float64) + 0.5) * 64.0
+        f = m.faces_list()[b].cpu().numpy()
+        _check_analytic(name, v, f, kind, c, prm, chi, 0.02 * 64)
+        rv, rf = RM.marching_cubes(vols[b], 0.02)
+        assert np.array_equal(f, rf) and np.abs(v - rv).max() < 1e-4
+
+
 @pytest.mark.gpu
 def test_hip_marching_cubes_equals_oracle_exactly():
     from commonscenes_amd.mesh import marching_cubes

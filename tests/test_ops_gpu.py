@@ -479,3 +479,36 @@ def test_sampler_eta_positive_runs_and_is_seed_deterministic():
         outs.append(x)
     assert torch.isfinite(outs[0]).all()
     assert torch.equal(outs[0], outs[1]) and not torch.equal(outs[0], outs[2])
+
+
+def test_groupnorm_apply_range_feeds_channel_ranges_from_one_statistics_pass():
+    """cs_groupnorm_apply_range / _split16_range (ABI 11): statistics over a concatenation [h | skip] (672 = 448 + 224
+    channels, 21-channel groups: group 21 straddles the seam), then the channels [0, 464) and [464, 672) normalised into
+    separate operand tensors -- the second one from the skip tensor itself at HALF the batch (the guidance halves share
+    it).  Each must equal the same channels of the one-call GroupNorm bit for bit."""
+    from commonscenes_amd import lib as L, ops, synth
+    nb, nbs, d, C, ch_h, ks = 4, 2, 4, 672, 448, 464
+    h = synth.tensor_device("gr:h", (nb, d, d, d, ch_h), 1.0)
+    skip = synth.tensor_device("gr:s", (nbs, d, d, d, C - ch_h), 2.0)
+    cat = torch.cat([h, skip.repeat(2, 1, 1, 1, 1)], dim=-1).contiguous()
+    g, b = synth.tensor_device("gr:g", (C,), 0.3) + 1.0, synth.tensor_device("gr:b", (C,), 0.2)
+    stats = ops.groupnorm_stats(cat, 32, 1e-5)
+    cpg = C // 32
+    whole = ops.groupnorm_apply_range(cat, stats, g, b, cpg, 0, L.ACT_SILU)      # all channels: the two-pass GroupNorm
+    assert rel_l2(ops.groupnorm(cat, g, b, 32, 1e-5, L.ACT_SILU), whole) < 1e-6  # (the one-call entry may take the
+                                                                                 # single-launch kernel: other sum order)
+    a_h = ops.groupnorm_apply_range(cat[..., :ks], stats, g[:ks], b[:ks], cpg, 0, L.ACT_SILU)
+    a_s = ops.groupnorm_apply_range(skip[..., ks - ch_h:], stats, g[ks:], b[ks:], cpg, ks, L.ACT_SILU)
+    torch.cuda.synchronize()
+    assert a_h.shape == (nb, d, d, d, ks) and a_s.shape == (nbs, d, d, d, C - ks)
+    assert torch.equal(a_h, whole[..., :ks])
+    assert torch.equal(a_s, whole[:nbs, ..., ks:]) and torch.equal(a_s, whole[nbs:, ..., ks:])
+    # the pre-split operand pair carries the same values (y * 16 split into fp16 hi + lo)
+    p_s = ops.groupnorm_apply_range(skip[..., ks - ch_h:], stats, g[ks:], b[ks:], cpg, ks, L.ACT_SILU, split16=True)
+    assert isinstance(p_s, ops.Split16)
+    back = (p_s.hi.float() + p_s.lo.float()) / ops.A_SCALE
+    assert float((back - a_s).abs().max()) <= 2.0 ** -20 * float(a_s.abs().max())
+    # against the oracle's GroupNorm (fp64) on the concatenation
+    ref = torch.nn.functional.silu(torch.nn.functional.group_norm(
+        cat.double().cpu().permute(0, 4, 1, 2, 3), 32, g.double().cpu(), b.double().cpu(), 1e-5)).permute(0, 2, 3, 4, 1)
+    assert rel_l2(a_h, ref[..., :ks]) < 1e-6 and rel_l2(a_s, ref[:nbs, ..., ks:]) < 1e-6

@@ -428,3 +428,144 @@ def test_full_size_conv_paths_agree_at_the_benchmark_shapes():
     torch.cuda.synchronize()
     assert torch.equal(whole[:nb], half)
     assert rel_l2(half, unsplit) < 3e-6          # K = 18144 summed in four slices vs one chain
+
+
+def test_benchmark_conv_instantiation_against_an_independent_fp64_evaluation_at_full_size():
+    """the benchmarked instantiation conv_gemm_f16x3_kernel<1,7,8,1,true,32> (256x224 tile, A slab,
+    GroupNorm-pre-split operands) was compared with the fp64 oracle on small geometries only; at the CFG-batch-64 shapes
+    it was checked HIP-vs-HIP.  Here: the heaviest ResBlock conv of BASELINE configs[2] at its own size -- batch 64,
+    672 -> 224 channels at 16^3 (M = 262 144 rows, K = 18 144) -- through GroupNorm(split16) + the slab kernel, and 4 096
+    random output elements re-evaluated independently: GroupNorm + SiLU in fp64 by plain torch ops (no kernel of this
+    package), the 27 x 672-term dot products in fp64 with numpy on the HOST."""
+    import numpy as np
+    from commonscenes_amd import lib as L, ops, synth
+    nb, D, C, N = 64, 16, 672, 224
+    x = synth.tensor_device("fsp:x", (nb, D, D, D, C), 1.0)
+    x[:, :, :, :, :40] *= 3.0                                            # unequal group statistics
+    g, b = synth.tensor_device("fsp:g", (C,), 0.3) + 1.0, synth.tensor_device("fsp:b", (C,), 0.1)
+    w = synth.tensor_device("fsp:w", (N, C, 3, 3, 3), (C * 27) ** -0.5)
+    bias = synth.tensor_device("fsp:c", (N,), 0.1)
+    pk = ops.pack_weight(w, bias, math=L.MATH_F16X3)
+    assert ops.wants_split16(nb * D ** 3, pk)
+    prof = ops.GEMM_PROFILE = []
+    try:
+        out = ops.conv_gemm(ops.groupnorm(x, g, b, 32, 1e-5, L.ACT_SILU, split16=True), pk)
+    finally:
+        ops.GEMM_PROFILE = None
+    torch.cuda.synchronize()
+    assert (prof[0]["tile"], prof[0]["slab"], prof[0]["pre"]) == (4, 32, True)      # the benchmarked instantiation
+    # independent evaluation: GroupNorm + SiLU in fp64 with torch ops, one sample at a time (memory)
+    rs = np.random.RandomState(7)
+    pick = np.stack([rs.randint(0, nb, 4096), rs.randint(0, D, 4096), rs.randint(0, D, 4096), rs.randint(0, D, 4096),
+                     rs.randint(0, N, 4096)], 1)
+    pick[:64, 1:4] = rs.choice([0, D - 1], size=(64, 3))                 # corners / faces: the zero-padded taps
+    ref = np.zeros(4096)
+    w64 = w.double().cpu().numpy()                                       # [N, C, 3, 3, 3]
+    b64 = bias.double().cpu().numpy()
+    for n in np.unique(pick[:, 0]):
+        xs = x[n].double().reshape(D ** 3, 32, C // 32)
+        mu = xs.mean(dim=(0, 2), keepdim=True)
+        var = ((xs - mu) ** 2).mean(dim=(0, 2), keepdim=True)
+        y = ((xs - mu) / torch.sqrt(var + 1e-5)).reshape(D, D, D, C) * g.double() + b.double()
+        y = (y * torch.sigmoid(y))
+        ypad = torch.zeros((D + 2, D + 2, D + 2, C), dtype=torch.float64, device=y.device)
+        ypad[1:-1, 1:-1, 1:-1] = y
+        for i in np.nonzero(pick[:, 0] == n)[0]:
+            _, d_, h_, w_, co = pick[i]
+            patch = ypad[d_:d_ + 3, h_:h_ + 3, w_:w_ + 3].cpu().numpy()          # [3, 3, 3, C] -> the host
+            ref[i] = float(np.einsum("dhwc,cdhw->", patch, w64[co])) + b64[co]
+    got = out[torch.from_numpy(pick[:, 0]).cuda(), torch.from_numpy(pick[:, 1]).cuda(), torch.from_numpy(pick[:, 2]).cuda(),
+              torch.from_numpy(pick[:, 3]).cuda(), torch.from_numpy(pick[:, 4]).cuda()].double().cpu().numpy()
+    err = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+    worst = float(np.max(np.abs(got - ref)) / np.sqrt(np.mean(ref ** 2)))
+    # the same conv on the fp32-input MFMA kernel (bit-equal to an fp32 fma chain): what fp32 accumulation of K = 18 144
+    # products of a non-centred operand (SiLU output: the partial sums drift) costs by itself
+    sel = tuple(torch.from_numpy(pick[:, j]).cuda() for j in range(5))
+    o32 = ops.conv_gemm(ops.groupnorm(x, g, b, 32, 1e-5, L.ACT_SILU), ops.pack_weight(w, bias, math=L.MATH_FP32))
+    got32 = o32[sel].double().cpu().numpy()
+    e32 = float(np.linalg.norm(got32 - ref) / np.linalg.norm(ref))
+    print(f"full-size <1,7,8,1,true,32> vs independent fp64: rel-L2 {err:.2e} over 4096 elements (fp32 fma chain: "
+          f"{e32:.2e}), worst |d|/rms {worst:.2e}")
+    # r3 measurement: 1.44e-6 / worst 1.03e-5 -- fp32 accumulation noise of an 18 144-term chain, not the operand split
+    assert err < 3e-6 and worst < 2.5e-5 and err < 3 * e32 + 3e-7
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# F16X3 range story beyond the PyTorch-default synthetic weights (VERDICT r2 weak #3 / next #7c)
+# ----------------------------------------------------------------------------------------------------------------------
+def test_f16x3_uniformly_tiny_operand_keeps_its_absolute_floor():
+    """CS_MATH_F16X3 carries an activation a as the fp16 pair of 16 a, so operands with 16 |a| below fp16's normal range
+    (|a| < 3.8e-6) keep an ABSOLUTE accuracy of 2^-29 per element instead of a relative one.  Mixed-scale tensors are
+    covered by test_f16x3_wide_dynamic_range; here the WHOLE tensor sits at 1e-6 / 1e-7 / 1e-9: the error must stay under
+    the documented floor (2^-29 * sum_k |w_k| per output element) -- harmless wherever the result joins an O(1)
+    residual stream, which is every raw-activation consumer of the UNet / decoder -- and its size relative to the tiny
+    result is REPORTED.  GroupNorm / LayerNorm-fed GEMMs never see such tensors: the norm rescales its input."""
+    from commonscenes_amd import lib as L, ops, synth
+    m, k, n = 512, 512, 224
+    w = synth.gaussian_like("tiny:w", (n, k), scale=k ** -0.5)
+    pk = ops.pack_weight(w.cuda(), math=L.MATH_F16X3)
+    for mag in (1e-6, 1e-7, 1e-9):
+        x = synth.gaussian_like(f"tiny:x{mag}", (m, k)) * mag
+        ref = x.double() @ w.double().t()
+        out = ops.linear(x.cuda(), pk).cpu().double()
+        torch.cuda.synchronize()
+        floor = 2.0 ** -29 * w.double().abs().sum(1)                     # per output column
+        worst = float(((out - ref).abs() / floor).max())
+        rel = float((out - ref).norm() / ref.norm())
+        print(f"uniformly {mag:g}: max |err| = {worst:.2f} x the 2^-29 floor, rel-L2 of the tiny result {rel:.2e}")
+        assert worst <= 1.0 + 1e-3 and ops.read_status() == 0
+    # the same tensor through a GroupNorm first (what every 3x3x3 conv of a ResBlock sees): scale-free, fp32-grade
+    x5 = synth.gaussian_like("tiny:x5", (2, 4, 8, 8, 64))
+    g, b = torch.ones(64).cuda(), torch.zeros(64).cuda()
+    w3 = synth.gaussian_like("tiny:w3", (224, 64, 3, 3, 3), scale=(64 * 27) ** -0.5).cuda()
+    pk3 = ops.pack_weight(w3, None, math=L.MATH_F16X3)
+    big = ops.conv_gemm(ops.groupnorm(x5.cuda(), g, b, 32, 0.0, L.ACT_NONE), pk3)
+    small = ops.conv_gemm(ops.groupnorm((x5 * 2.0 ** -20).cuda(), g, b, 32, 0.0, L.ACT_NONE), pk3)
+    torch.cuda.synchronize()
+    assert torch.equal(big, small)                                       # a power-of-two input scale changes nothing
+
+
+def test_unet_with_heavy_tailed_weights_and_latent_outliers():
+    """the reduced-width UNet with Student-t (3 degrees of freedom) conv / linear weights -- the heavy-tailed shape trained
+    networks have, which the PyTorch-default uniform synthetic weights lack -- and a latent with +-30 outliers, against the
+    fp64 oracle on the same weights.  Activations reach the hundreds to thousands here; F16X3 must stay fp32-grade while
+    they are below its range (|a| < 4094) and say so when they are not (the overflow flag; then the fp32 path is gated)."""
+    import numpy as np
+    from commonscenes_amd import lib as L, ops, synth
+    from commonscenes_amd.unet import DiffusionUNet, unet_param_shapes
+    from oracle import ref_torch as R
+    from test_model_gpu import _unet_cfg
+    cfg = _unet_cfg(True)
+    shapes = unet_param_shapes(cfg)
+    sd = synth.synth_state_dict(shapes)
+    rs = np.random.RandomState(11)
+    for k, v in sd.items():
+        if k.endswith(".weight") and v.dim() >= 2:
+            fan_in = int(np.prod(v.shape[1:]))
+            t3 = rs.standard_t(3, size=tuple(v.shape)) / np.sqrt(3.0)                         # unit variance, heavy tails
+            sd[k] = torch.from_numpy((t3 * fan_in ** -0.5).astype(np.float32))
+    B = 2
+    x = synth.gaussian_like("ht:x", (B, 3, 16, 16, 16))
+    x[0, 1, 3, 4, 5], x[1, 2, 9, 9, 9] = 30.0, -30.0
+    ctx = synth.gaussian_like("ht:ctx", (B, 1, 1280))
+    t = torch.tensor([981, 21], dtype=torch.long)
+    with torch.no_grad():
+        ref = R.unet_forward({k: v.double() for k, v in sd.items()}, cfg, x.double(), t, ctx.double())
+    df = DiffusionUNet(cfg, conditioning_key="crossattn", device="cuda").set_math("f16x3")
+    df.load_state_dict(sd)
+    df.trace = {}
+    ops.read_status()
+    eps = df(x.cuda(), t.cuda(), c_crossattn=[ctx.cuda()])
+    torch.cuda.synchronize()
+    amax = max(float(v.abs().max()) for v in df.trace.values())
+    flagged = bool(ops.read_status() & L.STATUS_F16X3_OVERFLOW)
+    e16 = rel_l2(eps, ref)
+    df.set_math("fp32")
+    e32 = rel_l2(df(x.cuda(), t.cuda(), c_crossattn=[ctx.cuda()]), ref)
+    print(f"heavy-tailed UNet: largest block activation {amax:.0f}, F16X3 rel-L2 vs fp64 {e16:.2e} (fp32 MFMA {e32:.2e}), "
+          f"overflow flag {flagged}")
+    assert e32 < 2e-5
+    if flagged:
+        assert amax > 1000.0            # the flag is raised only by genuinely large activations ...
+    else:
+        assert e16 < 2e-5 and e16 < 4 * e32 + 2e-6      # ... and without it F16X3 is as good as the fp32 chain
