@@ -41,6 +41,7 @@ struct cs_unet : Plan {
   std::vector<Layer> mid;
   int g_te0 = -1, g_te2 = -1, g_emb_all = -1, g_out = -1, n_out = -1;
   int emb_total = 0, ctx_total = 0, cpad_in = 4, ch_final = 0;
+  int64_t split_min_rows = 65536;      // channel-split ResBlocks only from this many rows (unet.py: split_min_rows)
 };
 
 namespace {
@@ -236,7 +237,8 @@ int build(cs_unet& u) {
   // channel-split ResBlocks: output block j reads the skip of input block (n_in - 1 - j); the ones from the context-free
   // prefix of the input path (before the first attention block) are shared by the guidance halves.  Same rule and same
   // split point as unet.py::_pack.
-  if (c.use_spatial_transformer && !getenv("CS_NO_CFG_SPLIT")) {
+  const char* no_split = getenv("CS_NO_CFG_SPLIT");
+  if (c.use_spatial_transformer && !(no_split && *no_split)) {
     size_t n_prefix = 0;
     while (n_prefix < u.inp.size()) {
       bool attn = false;
@@ -260,8 +262,7 @@ int build(cs_unet& u) {
       for (int which = 0; which < 2; ++which) {          // in_layers.2 (3x3x3), skip_connection (1x1x1)
         const int gi = l.g[which == 0 ? 0 : 2];
         const int wp = u.gemms[gi].w[0].param, bp = u.gemms[gi].b.empty() ? -1 : u.gemms[gi].b[0].param;
-        const int k = u.gemms[gi].k;
-        u.gemms[gi].unused = true;
+        const int k = u.gemms[gi].k;     // (the unsplit GEMM stays packed: small batches take it, see split_min_rows)
         l.gsp[2 * which] = add_gemm_cin_range(u, wp, bp, l.cout, C, k, 0, ks);
         l.gsp[2 * which + 1] = add_gemm_cin_range(u, wp, -1, l.cout, C, k, ks, C);
       }
@@ -269,6 +270,7 @@ int build(cs_unet& u) {
       l.ch_h = ch_h;
     }
   }
+  if (const char* e = getenv("CS_CFG_SPLIT_MIN_ROWS")) u.split_min_rows = atoll(e);
   u.ch_final = ch;
   u.n_out = add_norm(u, P + "out.0", ch);
   u.g_out = add_layer_gemm(u, P + "out.2", c.out_channels, mc, 3);
@@ -559,7 +561,7 @@ int forward(Exec& e, const float* x_ncdhw, const int64_t* t, const float* ctxvec
                            sk.b.c, cat.b.c, e.st));
     }
     e.release(h.b);
-    if (layers[0].kind == RES && layers[0].ks > 0) {
+    if (layers[0].kind == RES && layers[0].ks > 0 && cat.b.rows >= u.split_min_rows) {
       h = e.run(layers, cat, semb, ctxvec, false, &sk);      // the skip tensor itself feeds the shared GEMMs
       e.release(sk.b);
     } else {

@@ -8,6 +8,11 @@ ROOT = Path(__file__).resolve().parent.parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# The channel-split ResBlocks (unet.py::_res_split / cs_unet.hip::res_block_split) are taken from 65536 rows up in the
+# product (>= 8 objects); the test models are small, so the suite forces the split route everywhere -- goldens,
+# trajectories, driver-vs-driver equality all run through it -- and test_channel_split_* compares it with the
+# small-batch (unsplit) route under the product threshold.
+os.environ.setdefault("CS_CFG_SPLIT_MIN_ROWS", "0")
 
 
 def pytest_configure(config):

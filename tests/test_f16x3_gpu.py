@@ -9,6 +9,14 @@ from conftest import GOLDEN, rel_l2
 pytestmark = pytest.mark.gpu
 
 
+def gate(k_terms: int) -> float:
+    """SURVEY 8d's per-op gate is 1e-6 rel-L2 against fp64.  It holds for every op measured here (r3 record:
+    profiles/r03_parity_per_op.txt) EXCEPT contractions of >= 10 000 terms: the fp32 accumulation chain itself is then
+    at 0.9-1e-6 (fp32-input MFMA kernel, bit-equal to an fma chain: 9.4e-7 at K = 18 144) and F16X3 at 1.5e-6 -- the gate
+    there is 2e-6 and "no worse than a few x the fp32 chain"."""
+    return 1e-6 if k_terms < 10000 else 2e-6
+
+
 def _rand(*shape, seed=0, scale=1.0):
     g = torch.Generator().manual_seed(seed + sum(shape))
     return torch.randn(*shape, generator=g) * scale
@@ -50,7 +58,7 @@ def test_f16x3_conv_is_fp32_grade(case):
     o32 = ops.conv_gemm(xd, ops.pack_weight(wt.cuda(), b.cuda(), cin_pad=cin), stride=stride, up=up, tile=tile)
     torch.cuda.synchronize()
     e16, e32 = rel_l2(o16, ref), rel_l2(o32, ref)
-    assert e16 < 2e-6, (e16, e32)
+    assert e16 < gate(cin_real * k ** 3), (e16, e32)
     assert e16 < 4 * e32 + 3e-7, (e16, e32)          # no worse than a few x the fp32 fma chain's own rounding
 
 
@@ -94,7 +102,7 @@ def test_f16x3_slab_conv_is_bit_identical_to_the_gather_path(case):
     torch.cuda.synchronize()
     assert torch.equal(out_slab, out_gather)
     assert torch.equal(out_slab, again)
-    assert rel_l2(out_slab, ref) < 2e-6
+    assert rel_l2(out_slab, ref) < gate(cin * 27)
 
 
 def test_f16x3_four_way_k_split_of_the_three_column_tile_convs(monkeypatch):
@@ -175,7 +183,7 @@ def test_upsample_conv_folded_onto_the_source_grid(case):
     assert torch.equal(out, out2)
     e, ed = rel_l2(out, ref), rel_l2(direct, ref)
     print(f"upsample conv {case}: folded {e:.2e}, direct {ed:.2e}")
-    assert e < 2e-6 and e < 3 * ed + 3e-7
+    assert e < 1e-6 and e < 3 * ed + 3e-7
     # placement into a wider (concatenation) buffer: only the slice's columns are written
     wide = torch.full((*out.shape[:-1], cout + 8), 7.0, device="cuda")
     ops.conv_gemm(xd, pk, up=up, out=wide[..., 4:4 + cout])
@@ -216,7 +224,7 @@ def test_f16x3_epilogue_matches_fp32_contract():
     out = ops.conv_gemm(x.cuda(), ops.pack_weight(wt.cuda(), b.cuda(), math=L.MATH_F16X3), rowvec=rv.cuda(),
                         rv_rows=d * h * w, res=res.cuda(), act=L.ACT_SILU)
     torch.cuda.synchronize()
-    assert rel_l2(out, ref) < 2e-6
+    assert rel_l2(out, ref) < 1e-6
 
 
 def _g(name):
@@ -302,7 +310,7 @@ def test_f16x3_attention_is_fp32_grade(nb, nq, nk, heads, dh):
     o32 = ops.attention(q.cuda(), k.cuda(), v.cuda(), heads, dh ** -0.5)
     torch.cuda.synchronize()
     e16, e32 = rel_l2(o16, ref), rel_l2(o32, ref)
-    assert e16 < 2e-6, (e16, e32)
+    assert e16 < 1e-6, (e16, e32)
 
 
 def test_f16x3_attention_spiked_logits():
@@ -317,7 +325,7 @@ def test_f16x3_attention_spiked_logits():
     out = ops.attention(q.cuda(), k.cuda(), v.cuda(), heads, dh ** -0.5, math=L.MATH_F16X3)
     torch.cuda.synchronize()
     assert torch.isfinite(out).all()
-    assert rel_l2(out, ref) < 2e-6
+    assert rel_l2(out, ref) < 1e-6
 
 
 @pytest.mark.parametrize("tile", [2, 4])
@@ -334,7 +342,7 @@ def test_f16x3_fused_geglu_projection(tile):
     out = ops.linear(x.cuda(), ops.pack_geglu_weight(w.cuda(), b.cuda()), act=L.ACT_GEGLU, tile=tile)
     torch.cuda.synchronize()
     assert out.shape == (m, h)
-    assert rel_l2(out, ref) < 2e-6
+    assert rel_l2(out, ref) < 1e-6
 
 
 @pytest.mark.parametrize("shape,cin,cout,tile", [((2, 4, 8, 8), 32, 224, 2), ((1, 5, 7, 3), 24, 36, 3),
@@ -358,7 +366,7 @@ def test_f16x3_presplit_activation_path(shape, cin, cout, tile, monkeypatch):
     assert isinstance(hn, ops.Split16) and hn.hi.dtype == torch.float16
     out = ops.conv_gemm(hn, ops.pack_weight(wt.cuda(), bias.cuda(), math=L.MATH_F16X3), tile=tile)
     torch.cuda.synchronize()
-    assert rel_l2(out, ref) < 2e-6
+    assert rel_l2(out, ref) < 1e-6
 
 
 @pytest.mark.parametrize("shape,cin,cout,tile", [((2, 16, 16, 16), 32, 224, 4), ((5, 16, 4, 4), 64, 672, 4),
@@ -434,7 +442,7 @@ def test_f16x3_splitk_matches_fp64_and_unsplit(nb, shape, cin, cout, k, extras):
     assert L.load().cs_conv_gemm_plan(C.byref(p), C.byref(sk), C.byref(wsb)) == 0
     assert sk.value > 1 and wsb.value == sk.value * m * cout * 4
     assert torch.isfinite(split).all()
-    assert rel_l2(split, ref) < 2e-6
+    assert rel_l2(split, ref) < gate(cin * k ** 3)
     assert rel_l2(split, whole) < 1.5e-6        # two fp32 summation orders over K up to 18144
     # deterministic: same bits on a second run
     again = ops.conv_gemm(xd, pw, **kw)
@@ -455,7 +463,7 @@ def test_plain_fp16_attention_option_is_reported_not_gated():
     torch.cuda.synchronize()
     e16, e3 = rel_l2(o16, ref), rel_l2(o3, ref)
     print(f"attention rel-L2 vs fp64: plain fp16 {e16:.2e}, F16X3 {e3:.2e}")
-    assert e3 < 2e-6 and 1e-5 < e16 < 2e-3
+    assert e3 < 1e-6 and 1e-5 < e16 < 2e-3
     # whole UNet with the option on: report the drift against the reference golden
     g = _g("unet_small")
     df = _unet(True)
@@ -551,7 +559,7 @@ def test_pingpong_gemm_is_bit_identical_to_the_tile_kernels(case):
             y = y * torch.sigmoid(y)
         if case.get("res"):
             y = y + r.double()
-        assert rel_l2(got, y) < 2e-6
+        assert rel_l2(got, y) < 1e-6
 
 
 def test_pingpong_gemm_reports_overflow_and_rejects_what_it_cannot_do():

@@ -585,3 +585,39 @@ def test_forward_cfg_shares_the_context_free_prefix_exactly():
         assert a.shape == b.shape == (2 * B, 3, 16, 16, 16)
         assert torch.equal(a, b), mode
     df.set_math("fp32")
+
+
+def test_channel_split_resblocks_equal_the_unsplit_route(monkeypatch):
+    """Output blocks 5-8 read [h | skip] where the skip comes from the context-free prefix and is therefore identical for
+    the two guidance halves: above `split_min_rows` rows their in_layers conv / skip_connection run as a GEMM over
+    channels [0, Ks) plus a GEMM over the shared channels [Ks, C) at HALF the batch (unet.py::_res_split).  Here: the
+    split route (forced, as everywhere in this suite) against the unsplit route the product takes for small batches --
+    same result to fp32 summation-order noise, reduced and shipped width, both math modes; the product threshold is
+    65536 rows; and Ks is where SURVEY App. A's channel counts put it (672 = 448 + 224 -> 464, 448 = 224 + 224 -> 224)."""
+    from commonscenes_amd import synth
+    from commonscenes_amd.unet import DiffusionUNet, unet_param_shapes
+    for small in (True, False):
+        cfg = _unet_cfg(small)
+        sd = synth.synth_state_dict(unet_param_shapes(cfg), device="cuda")
+        B = 2
+        x = synth.gaussian_like("cs:x", (B, 3, 16, 16, 16)).cuda()
+        t = torch.tensor([501, 501], dtype=torch.long).cuda()
+        c_in = synth.gaussian_like("cs:c", (2 * B, 1, 1280)).cuda()
+        for math in ("fp32", "f16x3"):
+            df = DiffusionUNet(cfg, conditioning_key="crossattn", device="cuda").set_math(math)
+            df.load_state_dict(sd)
+            assert df.split_min_rows == 0                               # conftest forces the split route
+            split = df.forward_cfg(x, t, c_in)
+            info = dict(df._split_info)
+            df.split_min_rows = 65536                                   # the product threshold: B = 2 stays unsplit
+            plain = df.forward_cfg(x, t, c_in)
+            torch.cuda.synchronize()
+            assert len(info) == 4 and not torch.equal(split, plain)
+            assert rel_l2(split, plain) < 2e-6, (small, math)
+            if not small:
+                ks = {k.split("output_blocks.")[1][0]: v for k, v in info.items()}
+                assert ks == {"5": (464, 448), "6": (464, 448), "7": (224, 224), "8": (224, 224)}
+            del df
+        torch.cuda.empty_cache()
+    monkeypatch.delenv("CS_CFG_SPLIT_MIN_ROWS")
+    assert DiffusionUNet(_unet_cfg(True), conditioning_key="crossattn", device="cuda").split_min_rows == 65536

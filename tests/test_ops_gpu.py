@@ -11,7 +11,7 @@ from conftest import rel_l2
 
 pytestmark = pytest.mark.gpu
 
-TOL = 2e-6
+TOL = 1e-6      # SURVEY 8d per-op gate (r3: every op of this file measured <= 9.2e-7, profiles/r03_parity_per_op.txt)
 
 
 def _dev(t):
@@ -37,7 +37,7 @@ def R():
 
 def test_library_loads():
     from commonscenes_amd import lib
-    assert lib.load().cs_abi_version() == lib.ABI_VERSION == 10
+    assert lib.load().cs_abi_version() == lib.ABI_VERSION == 11
 
 
 # ---- implicit-GEMM conv / linear ----------------------------------------------------------------
