@@ -48,7 +48,7 @@ F16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X dense fp16/bf16 MFMA peak (MI355X_MICRO
 # PRE, SLAB>.  SLAB 0 = per-tap A gather; 32 / 64 = A operand of 3x3x3 stride-1 convs staged as one slab per (kd, channel
 # chunk); PRE = the GroupNorm producer already emitted the fp16 hi / lo operand pair (no conversion in the K loop)
 TILE_SHAPES = {1: ("2,2,2,2", "128x128"), 2: ("1,7,4,1", "128x224"), 3: ("1,1,2,2", "64x64"), 4: ("1,7,8,1", "256x224"),
-               6: ("1,4,8,1", "256x128"), 7: ("1,2,8,1", "256x64")}
+               6: ("1,4,8,1", "256x128"), 7: ("1,2,8,1", "256x64"), 8: ("2,2,8,1", "512x64"), 9: ("2,4,8,1", "512x128")}
 
 
 def kernel_label(key):

@@ -52,7 +52,22 @@ struct Gemm {        // one packed GEMM weight (possibly several reference tenso
 struct Norm {
   int gp, bp, c;
   int64_t g_off, b_off;
+  float gmax = 1.f, bmax = 0.f;   // max |gamma|, max |beta| (filled by pack_plan in F16X3 mode): norm_a_scale
 };
+
+// F16X3 operand scale of a GEMM fed by a normalisation over n elements per statistic: |y| <= gmax * sqrt(n - 1) + bmax,
+// so the largest power of two that keeps that bound below the fp16 range can never overflow (ops.py::norm_a_scale --
+// the same IEEE double operations in the same order, so both hosts derive the same scale)
+inline float norm_a_scale(float gmax, float bmax, int64_t n) {
+  const double bound = (double)gmax * std::sqrt((double)(n > 1 ? n - 1 : 1)) + (double)bmax;
+  if (!(bound > 0.0) || !std::isfinite(bound)) return 16384.f;
+  int ex = 0;
+  (void)std::frexp(65000.0 / bound, &ex);
+  int k = ex - 1;
+  if (k < -8) k = -8;
+  if (k > 14) k = 14;
+  return (float)std::ldexp(1.0, k);
+}
 
 struct RawCopy {     // a parameter copied verbatim into the arena (e.g. the VQ codebook)
   int param;
@@ -342,9 +357,19 @@ int pack_plan(Plan* u, const void* raw_dev, void* arena_dev, cs_stream_t stream)
         CS_CHECK_LAUNCH();
       }
     }
+    for (const Norm& n : u->norms) {
+      CS_LAUNCH(absmax_kernel, dim3(1), dim3(256), 0, st, src(n.gp), (int64_t)n.c, d_amax + n.gp);
+      CS_CHECK_LAUNCH();
+      CS_LAUNCH(absmax_kernel, dim3(1), dim3(256), 0, st, src(n.bp), (int64_t)n.c, d_amax + n.bp);
+      CS_CHECK_LAUNCH();
+    }
     if (hipMemcpyAsync(amax.data(), d_amax, amax.size() * 4, hipMemcpyDeviceToHost, st) != hipSuccess)
       return CS_EINVAL;
     if (hipStreamSynchronize(st) != hipSuccess) return CS_EINVAL;
+    for (Norm& n : u->norms) {
+      n.gmax = amax[(size_t)n.gp];
+      n.bmax = amax[(size_t)n.bp];
+    }
   }
   auto copy_bias = [&](const Gemm& g) -> int {
     int n_off = 0;
@@ -468,6 +493,8 @@ struct Buf {
   int c = 0;
   bool half = false;   // fp16 hi image [rows][c] followed by the lo image (the F16X3 GEMMs' pre-split A operand);
                        // same footprint as fp32 [rows][c]
+  float a_scale = 16.f;   // F16X3 operand scale a GEMM reading this buffer uses: the default for activations of unknown
+                          // range, the producer's bound for normalisation outputs (norm_a_scale)
 };
 
 struct Act {   // an activation volume, channels-last
@@ -564,8 +591,8 @@ struct ExecBase {
       q.w = reinterpret_cast<const float*>(arena + g.w_off);
       if (pl.math == CS_MATH_F16X3) {
         q.w_lo = arena + g.wlo_off;
-        q.acc_scale = g.acc_scale;
-        q.a_scale = 16.0f;
+        q.acc_scale = g.acc_scale * (16.0f / x.a_scale);      // g.acc_scale = 1 / (weight scale * 16); powers of two
+        q.a_scale = x.a_scale;
       }
       q.bias = g.b_off >= 0 ? wf(g.b_off) : nullptr;
       q.rowvec = rowvec;
@@ -583,7 +610,8 @@ struct ExecBase {
     q.act = act; q.rv_rows = rv_rows; q.math = pl.math; q.tile = tile;
     if (g.up_mask) {
       // Upsample's conv on the source grid: one GEMM per output parity class + interleave (cs_conv_gemm_up2)
-      if (g.up_mask != ((up_d << 2) | (up_hw << 1) | up_hw) || s_hw != 1 || s_d != 1 || res || rowvec || tile) {
+      if (g.up_mask != ((up_d << 2) | (up_hw << 1) | up_hw) || s_hw != 1 || s_d != 1 || res || rowvec || tile ||
+          x.a_scale != 16.f) {
         chk(CS_EINVAL);
         return out;
       }
@@ -623,7 +651,8 @@ struct ExecBase {
   // stride-1 conv / pointwise GEMM on explicit operand views: x (+ x_lo for the pre-split pair) with row stride lda,
   // out with row stride ldo -- channel ranges of wider buffers, sample ranges of a batch (res_block_split)
   void gemm_view(const float* x, const void* x_lo, int lda, int gi, int nb, int d, int h, int w, float* out, int ldo,
-                 const float* rowvec = nullptr, int ldrv = 0, int rv_rows = 1, const float* res = nullptr, int ldr = 0) {
+                 const float* rowvec = nullptr, int ldrv = 0, int rv_rows = 1, const float* res = nullptr, int ldr = 0,
+                 float a_scale = 16.f) {
     const Gemm& g = pl.gemms[gi];
     CsConvGemm q;
     memset(&q, 0, sizeof(q));
@@ -637,8 +666,8 @@ struct ExecBase {
       q.w = reinterpret_cast<const float*>(arena + g.w_off);
       if (pl.math == CS_MATH_F16X3) {
         q.w_lo = arena + g.wlo_off;
-        q.acc_scale = g.acc_scale;
-        q.a_scale = 16.0f;
+        q.acc_scale = g.acc_scale * (16.0f / a_scale);
+        q.a_scale = a_scale;
       }
       q.bias = g.b_off >= 0 ? wf(g.b_off) : nullptr;
       q.rowvec = rowvec;
@@ -683,13 +712,14 @@ struct ExecBase {
     const Norm& n = pl.norms[ni];
     Buf y = alloc(rows_total, c);
     const int rows = (int)(rows_total / nb);
+    if (pl.math == CS_MATH_F16X3) y.a_scale = norm_a_scale(n.gmax, n.bmax, (int64_t)rows * cpg);
     if (wants_split16(m_launch, conv_gi)) {      // m_launch: rows per launch of the consuming conv
       y.half = true;
       if (ok() && !dry) {
         char* yh = reinterpret_cast<char*>(p(y));
         chk(cs_groupnorm_apply_split16_range(x, p(stats), wf(n.g_off) + ch0, wf(n.b_off) + ch0, yh,
-                                             yh + rows_total * c * 2, nb, rows, c, ldx, c, groups, cpg, ch0, act, 16.0f,
-                                             status, st));
+                                             yh + rows_total * c * 2, nb, rows, c, ldx, c, groups, cpg, ch0, act,
+                                             y.a_scale, status, st));
       }
       return y;
     }
@@ -723,6 +753,7 @@ struct ExecBase {
     Buf y = alloc(x.rows, x.c);
     Buf wsb = alloc((cs_groupnorm_ws_bytes(nb, groups) + 3) / 4, 1);
     Buf stats = alloc((int64_t)nb * groups * 2, 1);
+    if (pl.math == CS_MATH_F16X3) y.a_scale = norm_a_scale(n.gmax, n.bmax, (x.rows / nb) * (int64_t)(x.c / groups));
     if (wants_split16(x.rows, conv_gi)) {
       y.half = true;
       if (ok() && !dry) {
@@ -730,7 +761,7 @@ struct ExecBase {
         chk(cs_groupnorm_stats(p(x), nb, rows, x.c, x.c, groups, eps, p(wsb), p(stats), st));
         char* yh = reinterpret_cast<char*>(p(y));
         chk(cs_groupnorm_apply_split16(p(x), p(stats), wf(n.g_off), wf(n.b_off), yh, yh + x.rows * x.c * 2, nb, rows, x.c,
-                                       x.c, x.c, groups, act, 16.0f, status, st));
+                                       x.c, x.c, groups, act, y.a_scale, status, st));
       }
       release(wsb);
       release(stats);
@@ -747,6 +778,7 @@ struct ExecBase {
   Buf layernorm(const Buf& x, int ni) {
     const Norm& n = pl.norms[ni];
     Buf y = alloc(x.rows, x.c);
+    if (pl.math == CS_MATH_F16X3) y.a_scale = norm_a_scale(n.gmax, n.bmax, x.c);
     if (ok() && !dry) chk(cs_layernorm(p(x), wf(n.g_off), wf(n.b_off), p(y), (int)x.rows, x.c, x.c, x.c, 1e-5f, st));
     return y;
   }

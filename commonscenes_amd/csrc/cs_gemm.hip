@@ -12,6 +12,7 @@
 // MFMA operand maps (cdna_hip_programming.md section 3):
 //   A[i = lane&31][k = lane>>5], B[k = lane>>5][j = lane&31],
 //   D: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5), r in [0,16).
+#include <cstdlib>
 #include "cs_common.h"
 
 namespace {
@@ -382,6 +383,19 @@ extern "C" int cs_conv_gemm(const CsConvGemm* d, cs_stream_t stream) {
       tile = 1;
     else
       tile = 3;
+    // r3: 3x3x3 stride-1 convs of the VQ-VAE decoder's upper levels (N = 64 / 128, millions of rows): the 256-row tiles
+    // give a wave only 6 / 12 MFMAs per K chunk and barrier; 512-row tiles (two row blocks per wave, same slab) double
+    // that and halve the weight-operand DMA and the per-chunk synchronisation per flop
+    {
+      // CS_NO_TILE512 = 1: neither; = 8 / 9: without that tile (A/B runs)
+      static const char* e512 = getenv("CS_NO_TILE512");
+      static const bool no512 = e512 && *e512 == '1', no8 = e512 && *e512 == '8', no9 = e512 && *e512 == '9';
+      const bool conv3 = p.kd == 3 && p.kh == 3 && p.kw == 3 && p.sd == 1 && p.sh == 1 && p.sw == 1 &&
+                         !(p.ud | p.uh | p.uw) && p.pd == 1 && p.ph == 1 && p.pw == 1;
+      const int64_t t512 = (M + 511) / 512;
+      if (!no512 && !no8 && conv3 && tile == 7 && p.cout == 64 && p.win <= 64 && t512 >= 512) tile = 8;
+      if (!no512 && !no9 && conv3 && tile == 6 && p.win <= 32 && t512 * (p.cout / 128) >= 512) tile = 9;
+    }
     if (p.act == CS_ACT_GEGLU && tile != 4) tile = 2;   // the fused gate needs whole [x | gate] 224-column tiles
     // ... and with a short K loop (the 448-channel level: 28 chunks) two 128-row workgroups per CU overlap one's gate
     // epilogue with the other's K loop: 805 vs 867 us at 65536 x 448 -> 3584 (the 672-channel one prefers 256 rows)
@@ -420,6 +434,8 @@ extern "C" int cs_conv_gemm(const CsConvGemm* d, cs_stream_t stream) {
     case 4: return launch<1, 7, 4, 1>(p, M, s);   // the 256-row tiles exist for F16X3 only; same N tiling here
     case 6: return launch<2, 2, 2, 2>(p, M, s);
     case 7: return launch<1, 1, 2, 2>(p, M, s);
+    case 8: return launch<1, 1, 2, 2>(p, M, s);
+    case 9: return launch<2, 2, 2, 2>(p, M, s);
     default: return CS_EINVAL;
   }
 }

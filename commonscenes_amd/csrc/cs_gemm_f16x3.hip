@@ -62,7 +62,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   constexpr int NW = WAVES_M * WAVES_N;            // waves per workgroup (4, or 8 for the 256-row tile)
   constexpr int NT = 64 * NW;
   // ---- LDS map (bytes) ----
-  static_assert(!SLAB || (WMB == 1 && WAVES_N == 1), "slab path: one row block per wave");
+  static_assert(!SLAB || (WMB <= 2 && WAVES_N == 1), "slab path: one or two row blocks per wave");
   // wave-instructions per slab (SLAB = widest line W): fp32 rows of 64 B, 16 per instruction; PRE: a hi and a lo image
   // of 32 B rows, 32 per instruction each
   constexpr int SLAB_IMG_WI = (BM + 2 * SLAB + 2 + 31) / 32;
@@ -359,39 +359,44 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   const int s_w = p.win, s_hw = p.hin * p.win;
   const int s_rows = p.nb * p.din * s_hw;                  // source rows in the tensor
   const int s_need = BM + 2 * s_w + 2;                     // slab rows this problem uses
-  const int rowl = wm0 + l31;                              // the lane's fragment row inside the tile
-  unsigned vmask = 0;                                      // bit tap: that tap of this lane's output voxel is inside the volume
+  // (per row block i of the wave -- one for the 256-row tiles, two for the 512-row ones)
+  unsigned vmask[WMB];                                     // bit tap: that tap of this lane's output voxel is inside the volume
   int sl_row[SLAB_PW];
   unsigned sl_piece[SLAB_PW];
-  int sl_a0[9];                                            // fragment byte offset inside the slab, per (kh, kw)
+  int sl_a0[WMB][9];                                       // fragment byte offset inside the slab, per (kh, kw)
   if constexpr (SLAB != 0) {
 #pragma unroll
-    for (int t9 = 0; t9 < 9; ++t9) {
-      const int prow = rowl + (t9 / 3) * s_w + t9 % 3;
-      if constexpr (PRE)
-        sl_a0[t9] = prow * 32 + (((half ^ (prow >> 3)) & 1) << 4);      // same swizzle as the ring's fp16 images
-      else
-        sl_a0[t9] = prow * 64 + ((((2 * half) ^ (prow >> 2)) & 3) << 4);
+    for (int i = 0; i < WMB; ++i) {
+      const int rowl = wm0 + 32 * i + l31;                 // the lane's fragment row inside the tile
+#pragma unroll
+      for (int t9 = 0; t9 < 9; ++t9) {
+        const int prow = rowl + (t9 / 3) * s_w + t9 % 3;
+        if constexpr (PRE)
+          sl_a0[i][t9] = prow * 32 + (((half ^ (prow >> 3)) & 1) << 4);      // same swizzle as the ring's fp16 images
+        else
+          sl_a0[i][t9] = prow * 64 + ((((2 * half) ^ (prow >> 2)) & 3) << 4);
+      }
+      vmask[i] = 0;
+      const int m = m0 + rowl;
+      if (m < M) {
+        int mm = m;
+        const int ow = mm % p.win;
+        mm /= p.win;
+        const int oh = mm % p.hin;
+        mm /= p.hin;
+        const int od = mm % p.din;
+#pragma unroll
+        for (int t = 0; t < 27; ++t) {
+          const int kd_ = t / 9, kh_ = (t / 3) % 3, kwi = t % 3;
+          if ((unsigned)(od + kd_ - 1) < (unsigned)p.din && (unsigned)(oh + kh_ - 1) < (unsigned)p.hin &&
+              (unsigned)(ow + kwi - 1) < (unsigned)p.win)
+            vmask[i] |= 1u << t;
+        }
+      }
     }
     if constexpr (PRE) {
       if (tid < 4) reinterpret_cast<int*>(smem + ROWMIN)[tid] = 0;     // 16 zero bytes: what a masked-out tap reads
       __syncthreads();
-    }
-    const int m = m0 + rowl;
-    if (m < M) {
-      int mm = m;
-      const int ow = mm % p.win;
-      mm /= p.win;
-      const int oh = mm % p.hin;
-      mm /= p.hin;
-      const int od = mm % p.din;
-#pragma unroll
-      for (int t = 0; t < 27; ++t) {
-        const int kd_ = t / 9, kh_ = (t / 3) % 3, kwi = t % 3;
-        if ((unsigned)(od + kd_ - 1) < (unsigned)p.din && (unsigned)(oh + kh_ - 1) < (unsigned)p.hin &&
-            (unsigned)(ow + kwi - 1) < (unsigned)p.win)
-          vmask |= 1u << t;
-      }
     }
 #pragma unroll
     for (int i = 0; i < SLAB_PW; ++i) {
@@ -432,19 +437,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   // fragment of the chunk at (kh, kw) = T9 of the super-chunk whose slab sits in buffer `buf`: the lane's row shifted by
   // kh*W + kw, zeroed (scale 0, legacy multiply) if that tap falls outside the volume for this output voxel
   // (m9 = the kd's nine mask bits)
-  auto load_a_slab = [&](auto t9_c, int buf, unsigned m9, h8& hi, h8& lo) {
+  auto load_a_slab = [&](auto t9_c, int i, int buf, unsigned m9, h8& hi, h8& lo) {
     constexpr int t9 = decltype(t9_c)::value;
     if constexpr (PRE) {
       // already split by the producer: two 16-byte reads; a masked-out tap reads the zero block instead
       const bool ok = (m9 >> t9) & 1u;
-      const int a = buf * SLAB_BYTES + sl_a0[t9];
+      const int a = buf * SLAB_BYTES + sl_a0[i][t9];
       hi = *reinterpret_cast<const h8*>(smem + (ok ? a : ROWMIN));
       lo = *reinterpret_cast<const h8*>(smem + (ok ? a + SLAB_IMG : ROWMIN));
       return;
     }
     const unsigned char* sb = smem + buf * SLAB_BYTES;
-    const f32x4 x0 = *reinterpret_cast<const f32x4*>(sb + sl_a0[t9]);
-    const f32x4 x1 = *reinterpret_cast<const f32x4*>(sb + (sl_a0[t9] ^ 16));
+    const f32x4 x0 = *reinterpret_cast<const f32x4*>(sb + sl_a0[i][t9]);
+    const f32x4 x1 = *reinterpret_cast<const f32x4*>(sb + (sl_a0[i][t9] ^ 16));
 #if CS_ABLATE & 512      // what-if "activations arrive split": no conversion VALU (timing only)
     hi = __builtin_bit_cast(h8, x0);
     lo = __builtin_bit_cast(h8, x1);
@@ -461,7 +466,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
     issue_slab(sc0);
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-    load_a_slab(std::integral_constant<int, 0>{}, sc0 & 1, (vmask >> (9 * (sc0 % 3))) & 0x1FFu, ah[0], al[0]);
+#pragma unroll
+    for (int i = 0; i < WMB; ++i)
+      load_a_slab(std::integral_constant<int, 0>{}, i, sc0 & 1, (vmask[i] >> (9 * (sc0 % 3))) & 0x1FFu, ah[i], al[i]);
   } else {
   wait_vmcnt<(PF - 1) * D>();          // chunk 0 (issued first) has landed for this wave
   __builtin_amdgcn_s_barrier();
@@ -512,33 +519,42 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   // over the wait count gained 3 % over the gather kernel, this one 8.5 %: DESIGN 4.4).
   //   iteration k (tap T9 of super-chunk sc), after its barrier: [T9 == 0: slab(sc + 1)]  B(k + 2)
   //   top of iteration k: only what iteration k - 1 issued may still fly
-  auto sstep = [&](auto stage_c, auto t9_c, int sc, unsigned m9_this, unsigned m9_next) {
+  auto sstep = [&](auto stage_c, auto t9_c, int sc, const unsigned (&m9_this)[WMB], const unsigned (&m9_next)[WMB]) {
     constexpr int stage = decltype(stage_c)::value;
     constexpr int t9 = decltype(t9_c)::value;
     constexpr int dstage = (stage + PF) % NSTAGE;
     if (!(CS_ABLATE & 4)) wait_vmcnt<(t9 == 1 ? SLAB_PW : 0) + B_PW>();
     if (!(CS_ABLATE & 8)) __builtin_amdgcn_s_barrier();
     const unsigned char* s = smem + RING0 + stage * STAGE;
-    h8 ah2, al2;
+    h8 ah2[WMB], al2[WMB];
 #pragma unroll
     for (int j = 0; j < WNB; ++j) {
       const h8 bh = *reinterpret_cast<const h8*>(s + b_frag + j * 512);
       const h8 bl = *reinterpret_cast<const h8*>(s + b_frag + B_BYTES + j * 512);
-      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[0], bh, acc[0][j], 0, 0, 0);
-      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0], bl, acc[0][j], 0, 0, 0);
-      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0], bh, acc[0][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < WMB; ++i) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh, acc[i][j], 0, 0, 0);
+      }
       if (j == 0) {
         if constexpr (t9 == 0) issue_slab(sc + 1);       // its buffer was last read while chunk k-2 was computed
         issue_dma(dtap, dcc, dstage);
         advance();
-        if constexpr (t9 == 8)
-          load_a_slab(std::integral_constant<int, 0>{}, (sc + 1) & 1, m9_next, ah2, al2);
-        else
-          load_a_slab(std::integral_constant<int, t9 + 1>{}, sc & 1, m9_this, ah2, al2);
+#pragma unroll
+        for (int i = 0; i < WMB; ++i) {
+          if constexpr (t9 == 8)
+            load_a_slab(std::integral_constant<int, 0>{}, i, (sc + 1) & 1, m9_next[i], ah2[i], al2[i]);
+          else
+            load_a_slab(std::integral_constant<int, t9 + 1>{}, i, sc & 1, m9_this[i], ah2[i], al2[i]);
+        }
       }
     }
-    ah[0] = ah2;
-    al[0] = al2;
+#pragma unroll
+    for (int i = 0; i < WMB; ++i) {
+      ah[i] = ah2[i];
+      al[i] = al2[i];
+    }
   };
   if constexpr (SLAB != 0) {
     static_assert(NSTAGE == 3 && PF == 2, "nine taps = three turns of the ring");
@@ -546,7 +562,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
     int kdc = sc_first % 3;                                 // kd of the super-chunk
     for (int sc = sc_first; sc < sc_end; ++sc) {
       const int kdn = kdc == 2 ? 0 : kdc + 1;
-      const unsigned m9 = (vmask >> (9 * kdc)) & 0x1FFu, m9n = (vmask >> (9 * kdn)) & 0x1FFu;
+      unsigned m9[WMB], m9n[WMB];
+#pragma unroll
+      for (int i = 0; i < WMB; ++i) {
+        m9[i] = (vmask[i] >> (9 * kdc)) & 0x1FFu;
+        m9n[i] = (vmask[i] >> (9 * kdn)) & 0x1FFu;
+      }
       sstep(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, sc, m9, m9n);
       sstep(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, sc, m9, m9n);
       sstep(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, sc, m9, m9n);
@@ -901,11 +922,15 @@ int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p_in, int M, int tile, int spl
   // 16-bit row deltas: the farthest tap is (kd-1) planes + (kh-1) rows + (kw-1) voxels from the window origin
   if ((int64_t)(p.kd - 1) * p.hin * p.win + (int64_t)(p.kh - 1) * p.win + p.kw > 32000) return CS_EINVAL;
   if (((uintptr_t)p.w & 15) || ((uintptr_t)p.w_lo & 15)) return CS_EINVAL;
-  const bool slab_geom = (splits == 1 || tile == 4 || tile == 2) && p.kd == 3 && p.kh == 3 && p.kw == 3 && p.sd == 1 && p.sh == 1 &&
-                         p.sw == 1 && p.pd == 1 && p.ph == 1 && p.pw == 1 && p.ud == 0 && p.uh == 0 && p.uw == 0 &&
-                         p.din == p.dout && p.hin == p.hout && p.win == p.wout && p.win <= 64 &&
-                         (p.win <= 32 || tile == 7) &&
-                         (256 + 2LL * p.hin * p.win + 2 * p.win + 32) * p.lda * 4 < 0x7FF00000LL;
+  // tiles 8 / 9 (512 x 64 / 512 x 128: two row blocks per wave) exist for the slab path only; elsewhere they run as 7 / 6
+  const bool slab_geom0 = p.kd == 3 && p.kh == 3 && p.kw == 3 && p.sd == 1 && p.sh == 1 &&
+                          p.sw == 1 && p.pd == 1 && p.ph == 1 && p.pw == 1 && p.ud == 0 && p.uh == 0 && p.uw == 0 &&
+                          p.din == p.dout && p.hin == p.hout && p.win == p.wout && p.win <= 64 &&
+                          (512 + 2LL * p.hin * p.win + 2 * p.win + 32) * p.lda * 4 < 0x7FF00000LL;
+  // (pre-split operands only: with the in-loop fp32 -> hi/lo conversion two row blocks x nine unrolled taps spill)
+  if (tile == 8 && !(slab_geom0 && splits == 1 && p.a_format == 1)) tile = 7;
+  if (tile == 9 && !(slab_geom0 && splits == 1 && p.win <= 32 && p.a_format == 1)) tile = 6;
+  const bool slab_geom = (splits == 1 || tile == 4 || tile == 2) && slab_geom0 && (p.win <= 32 || tile == 7 || tile == 8);
   // K slices of the slab kernel are whole super-chunks (nine taps): take it only where that granularity pads the slices
   // by at most a tenth (42 super-chunks over 32 slices would leave a third of the workgroups idle)
   const int64_t nsc_all = 3LL * ((p.cin + 15) / 16);
@@ -919,10 +944,15 @@ int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p_in, int M, int tile, int spl
         case 6: return launch16<1, 4, 8, 1, true, 32>(p, M, splits, s);
         case 7: return p.win <= 32 ? launch16<1, 2, 8, 1, true, 32>(p, M, splits, s)
                                    : launch16<1, 2, 8, 1, true, 64>(p, M, splits, s);
+        case 8: return p.win <= 32 ? launch16<2, 2, 8, 1, true, 32>(p, M, splits, s)
+                                   : launch16<2, 2, 8, 1, true, 64>(p, M, splits, s);
+        case 9: return launch16<2, 4, 8, 1, true, 32>(p, M, splits, s);
         default: break;
       }
     }
 #endif
+    if (tile == 8) tile = 7;      // (only reachable in -DCS_NO_SLAB builds)
+    if (tile == 9) tile = 6;
     switch (tile) {
       case 1: return launch16<2, 2, 2, 2, true>(p, M, splits, s);
       case 2: return launch16<1, 7, 4, 1, true>(p, M, splits, s);

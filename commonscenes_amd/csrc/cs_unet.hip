@@ -259,7 +259,7 @@ int build(cs_unet& u) {
           break;
         }
       if (!ks || (C - ks) % 16) continue;
-      for (int which = 0; which < 2; ++which) {          // in_layers.2 (3x3x3), skip_connection (1x1x1)
+      for (int which = 0; which < 1; ++which) {          // in_layers.2 (3x3x3); the 1x1x1 skip_connection stays whole
         const int gi = l.g[which == 0 ? 0 : 2];
         const int wp = u.gemms[gi].w[0].param, bp = u.gemms[gi].b.empty() ? -1 : u.gemms[gi].b[0].param;
         const int k = u.gemms[gi].k;     // (the unsplit GEMM stays packed: small batches take it, see split_min_rows)
@@ -304,9 +304,10 @@ struct Exec : ExecBase {
   }
 
   // ResBlock whose input is the concatenation x = [h | skip] with the skip half shared by nb / sk.nb groups of samples
-  // (the guidance halves): in_layers' conv and skip_connection are each evaluated as a GEMM over channels [0, ks) at the
-  // full batch plus a GEMM over channels [ks, C) -- whole GroupNorm groups of skip channels -- at batch sk.nb, which
-  // enters the first one's epilogue as a residual.  Same launches, in the same order, as unet.py::_res_split.
+  // (the guidance halves): in_layers' conv is evaluated as a GEMM over channels [0, ks) at the full batch plus a GEMM
+  // over channels [ks, C) -- whole GroupNorm groups of skip channels -- at batch sk.nb, which enters the first one's
+  // epilogue as a residual (the 1x1x1 skip_connection stays whole).  Same launches, in the same order, as
+  // unet.py::_res_split.
   Act res_block_split(const Layer& l, const Act& x, const Act& sk, const Buf& semb) {
     const int rows = x.d * x.h * x.w, C = x.b.c, ks = l.ks, cs = C - ks, off = ks - l.ch_h, cpg = C / 32;
     const int nb = x.nb, nbs = sk.nb, ch_s = sk.b.c, cout = l.cout;
@@ -327,12 +328,9 @@ struct Exec : ExecBase {
     };
     Buf y_s = alloc(sk.b.rows, cout);
     if (ok()) gemm_view(dry ? nullptr : p(a_s), a_s.half ? (dry ? (const void*)1 : lo_of(a_s)) : nullptr, cs, l.gsp[1], nbs,
-                        x.d, x.h, x.w, dry ? nullptr : p(y_s), cout);
+                        x.d, x.h, x.w, dry ? nullptr : p(y_s), cout, nullptr, 0, 1, nullptr, 0, a_s.a_scale);
     release(a_s);
     Buf h1 = alloc(x.b.rows, cout);
-    Buf skc = alloc(x.b.rows, cout);
-    Buf s_s = alloc(sk.b.rows, cout);
-    if (ok()) gemm_view(xs, nullptr, ch_s, l.gsp[3], nbs, x.d, x.h, x.w, dry ? nullptr : p(s_s), cout);
     for (int g = 0; g < nb / nbs && ok(); ++g) {
       const int64_t r0 = (int64_t)g * nbs * rows;
       const float* ah = nullptr;
@@ -343,14 +341,12 @@ struct Exec : ExecBase {
         if (a_h.half) al = reinterpret_cast<const char*>(lo_of(a_h)) + r0 * ks * 2;
       }
       gemm_view(ah, al, ks, l.gsp[0], nbs, x.d, x.h, x.w, dry ? nullptr : p(h1) + r0 * cout, cout,
-                dry ? nullptr : p(semb) + (int64_t)g * nbs * semb.c + l.emb_lo, semb.c, rows, dry ? nullptr : p(y_s), cout);
-      if (ok())
-        gemm_view(dry ? nullptr : p(x.b) + r0 * C, nullptr, C, l.gsp[2], nbs, x.d, x.h, x.w,
-                  dry ? nullptr : p(skc) + r0 * cout, cout, nullptr, 0, 1, dry ? nullptr : p(s_s), cout);
+                dry ? nullptr : p(semb) + (int64_t)g * nbs * semb.c + l.emb_lo, semb.c, rows, dry ? nullptr : p(y_s), cout,
+                a_h.a_scale);
     }
     release(a_h);
     release(y_s);
-    release(s_s);
+    Buf skc = gemm(x.b, l.g[2], nb, x.d, x.h, x.w);
     Buf hn2 = groupnorm(h1, l.n[1], nb, 1e-5f, CS_ACT_SILU, 32, l.g[1]);
     release(h1);
     o.b = gemm(hn2, l.g[1], nb, x.d, x.h, x.w, 1, 0, CS_ACT_NONE, nullptr, 0, 1, dry ? nullptr : p(skc), cout);

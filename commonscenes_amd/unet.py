@@ -198,6 +198,7 @@ class DiffusionUNet:
         self.trace: Optional[Dict[str, Tensor]] = None   # set to {} to capture per-block outputs (tests)
         self.split_min_rows = int(os.environ.get("CS_CFG_SPLIT_MIN_ROWS", "65536"))     # see _pack: channel-split ResBlocks
         self._split_info: Dict[str, Tuple[int, int]] = {}
+        self._ngb: Dict[str, Tuple[float, float]] = {}
 
     # ---- nn.Module-like surface -----------------------------------------------------------
     def state_dict(self) -> "OrderedDict[str, Tensor]":
@@ -377,7 +378,8 @@ class DiffusionUNet:
                 if ks is None or C % 32 or (C - ks) % 16 or l["cin"] == l["cout"]:
                     continue
                 q = f"{P}output_blocks.{j}.0"
-                for name in (".in_layers.2", ".skip_connection"):
+                for name in (".in_layers.2",):      # (skip_connection stays whole: splitting the 1x1x1 conv -- K = 224 /
+                    # 208 / 464 -- measured slower than the unsplit one, its pieces run at 115-190 TF/s: r03_c_gemm_table)
                     wfull = sd[q + name + ".weight"]
                     am = float(wfull.abs().max().item())
                     pk[q + name + ":h"] = ops.pack_weight(wfull[:, :ks].contiguous(), sd[q + name + ".bias"],
@@ -398,32 +400,48 @@ class DiffusionUNet:
                     self._emb_slices[q] = (off, off + l["cout"])
                     off += l["cout"]
         pk["emb_all"] = ops.pack_weight(torch.cat(ws, dim=0), torch.cat(bs, dim=0), math=self.math)
+        # |gamma|, |beta| maxima of every normalisation layer: with them a norm-fed GEMM's F16X3 operand scale is derived
+        # from the producer's bound instead of guessed (ops.norm_a_scale).  One reduction + one read-back, at load time.
+        norms = [k[:-7] for k in self.shapes if k.endswith(".weight") and len(self.shapes[k]) == 1]
+        if self.math == L.MATH_F16X3 and norms:
+            mx = torch.stack([torch.stack([sd[n + ".weight"].abs().max(), sd[n + ".bias"].abs().max()]) for n in norms]).cpu()
+            self._ngb = {n: (float(mx[i, 0]), float(mx[i, 1])) for i, n in enumerate(norms)}
+        else:
+            self._ngb = {}
         self._packed = pk
         self._blocks = (inp, mid, out)
         self._ctx_cache = None
 
     # ---- forward --------------------------------------------------------------------------
+    def _nas(self, norm: str, n: int) -> Optional[float]:
+        """F16X3 operand scale for the GEMM fed by normalisation layer `norm` taking its statistics over n elements
+        (None in fp32 mode: the default is used and ignored)."""
+        gb = self._ngb.get(norm)
+        return ops.norm_a_scale(gb[0], gb[1], n) if gb is not None else None
+
     def _res(self, p: str, l: dict, x: Tensor, semb: Tensor, out_fn=None) -> Tensor:
         sd, pk = self._sd, self._packed
         nb = x.shape[0]
         rows = x.shape[1] * x.shape[2] * x.shape[3]
         # GN output goes straight to a conv: emit its fp16 hi/lo operand form where that conv runs the slab kernel
+        s1 = self._nas(p + ".in_layers.0", rows * (l["cin"] // 32))
         hn = ops.groupnorm(x, sd[p + ".in_layers.0.weight"], sd[p + ".in_layers.0.bias"], 32, 1e-5, L.ACT_SILU,
-                           split16=ops.wants_split16(nb * rows, pk[p + ".in_layers.2"]))
+                           split16=ops.wants_split16(nb * rows, pk[p + ".in_layers.2"]), a_scale=s1)
         lo, hi = self._emb_slices[p]
         embo = semb[:, lo:hi]                         # slice of the batched emb projection (row stride = total)
-        h = ops.conv_gemm(hn, pk[p + ".in_layers.2"], rowvec=embo, rv_rows=rows, math=self.math)
+        h = ops.conv_gemm(hn, pk[p + ".in_layers.2"], rowvec=embo, rv_rows=rows, math=self.math, a_scale=s1)
+        s2 = self._nas(p + ".out_layers.0", rows * (l["cout"] // 32))
         hn2 = ops.groupnorm(h, sd[p + ".out_layers.0.weight"], sd[p + ".out_layers.0.bias"], 32, 1e-5, L.ACT_SILU,
-                            split16=ops.wants_split16(nb * rows, pk[p + ".out_layers.3"]))
+                            split16=ops.wants_split16(nb * rows, pk[p + ".out_layers.3"]), a_scale=s2)
         skip = x if l["cin"] == l["cout"] else ops.conv_gemm(x, pk[p + ".skip_connection"], math=self.math)
-        return ops.conv_gemm(hn2, pk[p + ".out_layers.3"], res=skip, math=self.math, out_fn=out_fn)
+        return ops.conv_gemm(hn2, pk[p + ".out_layers.3"], res=skip, math=self.math, out_fn=out_fn, a_scale=s2)
 
     def _res_split(self, p: str, l: dict, x: Tensor, skip: Tensor, semb: Tensor, out_fn=None) -> Tensor:
         """ResBlock of an output block whose skip half is shared by the guidance halves (see _pack): x = the
         concatenation [h | skip] at the full batch nb, `skip` = the skip tensor itself at batch nbs (nb / 2 under
         forward_cfg, nb otherwise; a view into x's right half in the latter case).
             in_layers:  conv(SiLU(GN(x)))       = conv_h(GN(x)[:, :Ks]) + conv_s(GN(x)[:, Ks:])    -- conv_s at batch nbs
-            skip_connection (1x1x1):  W x + b   = W_h x[:, :Ks] + b + W_s skip[:, Ks - ch_h:]      -- likewise
+        (the 1x1x1 skip_connection is left whole: its shared part is too small a GEMM to pay for a second launch)
         GroupNorm statistics are taken over the whole concatenation (one pass, as before); channels >= Ks lie in groups
         made of skip channels only, so sample n and sample n + nbs normalise them identically."""
         sd, pk = self._sd, self._packed
@@ -436,23 +454,24 @@ class DiffusionUNet:
         gam, bet = sd[p + ".in_layers.0.weight"], sd[p + ".in_layers.0.bias"]
         wh, ws = pk[p + ".in_layers.2:h"], pk[p + ".in_layers.2:s"]
         stats = ops.groupnorm_stats(x, 32, 1e-5)
+        s1 = self._nas(p + ".in_layers.0", rows * cpg)
         a_h = ops.groupnorm_apply_range(x[..., :ks], stats, gam[:ks], bet[:ks], cpg, 0, L.ACT_SILU,
-                                        split16=ops.wants_split16(nbs * rows, wh))
+                                        split16=ops.wants_split16(nbs * rows, wh), a_scale=s1)
         a_s = ops.groupnorm_apply_range(skip[..., off:], stats, gam[ks:], bet[ks:], cpg, ks, L.ACT_SILU,
-                                        split16=ops.wants_split16(nbs * rows, ws))
-        y_s = ops.conv_gemm(a_s, ws, math=self.math)
+                                        split16=ops.wants_split16(nbs * rows, ws), a_scale=s1)
+        y_s = ops.conv_gemm(a_s, ws, math=self.math, a_scale=s1)
         lo, hi = self._emb_slices[p]
         cout = l["cout"]
         h1 = torch.empty((nb, d, h, w, cout), dtype=torch.float32, device=x.device)
-        sk = torch.empty((nb, d, h, w, cout), dtype=torch.float32, device=x.device)
-        s_s = ops.conv_gemm(skip[..., off:], pk[p + ".skip_connection:s"], math=self.math)
         for g in range(nb // nbs):                    # one launch per guidance half: both read the shared term
             sl = slice(g * nbs, (g + 1) * nbs)
-            ops.conv_gemm(a_h[sl], wh, rowvec=semb[sl, lo:hi], rv_rows=rows, res=y_s, out=h1[sl], math=self.math)
-            ops.conv_gemm(x[sl][..., :ks], pk[p + ".skip_connection:h"], res=s_s, out=sk[sl], math=self.math)
+            ops.conv_gemm(a_h[sl], wh, rowvec=semb[sl, lo:hi], rv_rows=rows, res=y_s, out=h1[sl], math=self.math,
+                          a_scale=s1)
+        sk = ops.conv_gemm(x, pk[p + ".skip_connection"], math=self.math)
+        s2 = self._nas(p + ".out_layers.0", rows * (cout // 32))
         hn2 = ops.groupnorm(h1, sd[p + ".out_layers.0.weight"], sd[p + ".out_layers.0.bias"], 32, 1e-5, L.ACT_SILU,
-                            split16=ops.wants_split16(nb * rows, pk[p + ".out_layers.3"]))
-        return ops.conv_gemm(hn2, pk[p + ".out_layers.3"], res=sk, math=self.math, out_fn=out_fn)
+                            split16=ops.wants_split16(nb * rows, pk[p + ".out_layers.3"]), a_scale=s2)
+        return ops.conv_gemm(hn2, pk[p + ".out_layers.3"], res=sk, math=self.math, out_fn=out_fn, a_scale=s2)
 
     def _context_vectors(self, ctx: Tensor):
         """One-token context: every transformer block's cross-attention output is the per-sample
@@ -488,7 +507,7 @@ class DiffusionUNet:
         nb, d, h, w, c = x.shape
         n = d * h * w
         xn = ops.groupnorm(x, sd[p + ".norm.weight"], sd[p + ".norm.bias"], 32, 1e-5, L.ACT_NONE)
-        qkv = ops.linear(xn.view(nb, n, c), pk[p + ".qkv"], math=self.math)
+        qkv = ops.linear(xn.view(nb, n, c), pk[p + ".qkv"], math=self.math, a_scale=self._nas(p + ".norm", n * (c // 32)))
         a = ops.attention(qkv[..., 0:c], qkv[..., c:2 * c], qkv[..., 2 * c:3 * c], heads, (c // heads) ** -0.5,
                           math=self.attn_math if self.attn_math is not None else self.math)
         dst = out_fn((nb, d, h, w, c)).view(nb, n, c) if out_fn is not None else None
@@ -503,9 +522,9 @@ class DiffusionUNet:
         dh = c // heads
         t = p + ".transformer_blocks.0"
         xn = ops.groupnorm(x, sd[p + ".norm.weight"], sd[p + ".norm.bias"], 32, 1e-6, L.ACT_NONE)
-        t0 = ops.linear(xn.view(nb, n, c), pk[p + ".proj_in"], math=self.math)
+        t0 = ops.linear(xn.view(nb, n, c), pk[p + ".proj_in"], math=self.math, a_scale=self._nas(p + ".norm", n * (c // 32)))
         n1 = ops.layernorm(t0, sd[t + ".norm1.weight"], sd[t + ".norm1.bias"])
-        qkv = ops.linear(n1, pk[t + ".attn1.qkv"], math=self.math)
+        qkv = ops.linear(n1, pk[t + ".attn1.qkv"], math=self.math, a_scale=self._nas(t + ".norm1", c))
         a = ops.attention(qkv[..., 0:c], qkv[..., c:2 * c], qkv[..., 2 * c:3 * c], heads, dh ** -0.5, math=self.attn_math if self.attn_math is not None else self.math)
         if isinstance(ctx, tuple):
             # one context token: softmax over one key == 1, attn2(x) = to_out(to_v(ctx)) for every
@@ -514,16 +533,17 @@ class DiffusionUNet:
         else:
             t1a = ops.linear(a, pk[t + ".attn1.to_out.0"], res=t0, math=self.math)
             n2 = ops.layernorm(t1a, sd[t + ".norm2.weight"], sd[t + ".norm2.bias"])
-            q2 = ops.linear(n2, pk[t + ".attn2.to_q"], math=self.math)
+            q2 = ops.linear(n2, pk[t + ".attn2.to_q"], math=self.math, a_scale=self._nas(t + ".norm2", c))
             k2 = ops.linear(ctx, pk[t + ".attn2.to_k"], math=self.math)
             vv2 = ops.linear(ctx, pk[t + ".attn2.to_v"], math=self.math)
             a2 = ops.attention(q2, k2, vv2, heads, dh ** -0.5, math=self.attn_math if self.attn_math is not None else self.math)
             t1 = ops.linear(a2, pk[t + ".attn2.to_out.0"], res=t1a, math=self.math)
         n3 = ops.layernorm(t1, sd[t + ".norm3.weight"], sd[t + ".norm3.bias"])
+        s3 = self._nas(t + ".norm3", c)
         if (t + ".ff.geglu") in pk:      # GEGLU gate fused into the projection GEMM's epilogue
-            gg = ops.linear(n3, pk[t + ".ff.geglu"], act=L.ACT_GEGLU)    # the library picks a 224-column tile
+            gg = ops.linear(n3, pk[t + ".ff.geglu"], act=L.ACT_GEGLU, a_scale=s3)    # the library picks a 224-column tile
         else:
-            ff = ops.linear(n3, pk[t + ".ff.net.0.proj"], math=self.math)
+            ff = ops.linear(n3, pk[t + ".ff.net.0.proj"], math=self.math, a_scale=s3)
             gg = ops.geglu(ff)
         t2 = ops.linear(gg, pk[t + ".ff.net.2"], res=t1, math=self.math)
         dst = out_fn((nb, d, h, w, c)).view(nb, n, c) if out_fn is not None else None
@@ -635,9 +655,11 @@ class DiffusionUNet:
                           slot(i + 1, True) if nocopy and i + 1 < nout else None, split_skip=split_skip)
             if tr is not None:
                 tr[f"output_blocks.{i}"] = h
+        so = self._nas(P + "out.0", h.shape[1] * h.shape[2] * h.shape[3] * (h.shape[4] // 32))
         hn = ops.groupnorm(h, sd[P + "out.0.weight"], sd[P + "out.0.bias"], 32, 1e-5, L.ACT_SILU,
-                           split16=ops.wants_split16(h.shape[0] * h.shape[1] * h.shape[2] * h.shape[3], pk[P + "out.2"]))
-        return ops.conv_gemm(hn, pk[P + "out.2"], math=self.math)
+                           split16=ops.wants_split16(h.shape[0] * h.shape[1] * h.shape[2] * h.shape[3], pk[P + "out.2"]),
+                           a_scale=so)
+        return ops.conv_gemm(hn, pk[P + "out.2"], math=self.math, a_scale=so)
 
     @torch.no_grad()
     def forward_cfg(self, x: Tensor, t: Tensor, c_in: Tensor) -> Tensor:

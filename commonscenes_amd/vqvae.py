@@ -174,28 +174,44 @@ class VQVAE:
         wqkv = torch.cat([sd[a + "q.weight"], sd[a + "k.weight"], sd[a + "v.weight"]], dim=0)
         bqkv = torch.cat([sd[a + "q.bias"], sd[a + "k.bias"], sd[a + "v.bias"]], dim=0)
         pk[a + "qkv"] = ops.pack_weight(wqkv, bqkv, math=self.math)
+        # |gamma|, |beta| maxima of the Normalize layers: norm-fed GEMMs take their F16X3 operand scale from the
+        # producer's bound (ops.norm_a_scale), one read-back at load time
+        norms = [k[:-7] for k in sd if k.startswith("decoder.") and k.endswith(".weight") and sd[k].dim() == 1]
+        if self.math == L.MATH_F16X3 and norms:
+            mx = torch.stack([torch.stack([sd[n + ".weight"].abs().max(), sd[n + ".bias"].abs().max()]) for n in norms]).cpu()
+            self._ngb = {n: (float(mx[i, 0]), float(mx[i, 1])) for i, n in enumerate(norms)}
+        else:
+            self._ngb = {}
         self._packed = pk
 
     # ---- building blocks ----
+    def _nas(self, norm: str, n: int):
+        gb = getattr(self, "_ngb", {}).get(norm)
+        return ops.norm_a_scale(gb[0], gb[1], n) if gb is not None else None
+
     def _res(self, p: str, x: Tensor) -> Tensor:
         sd, pk = self._sd, self._packed
         c = x.shape[-1]
         m = x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3]
+        rows = m // x.shape[0]
+        s1 = self._nas(p + ".norm1", rows * (c // _vq_groups(c)))
         h = ops.groupnorm(x, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], _vq_groups(c), 1e-6, L.ACT_SILU,
-                          split16=ops.wants_split16(m, pk[p + ".conv1"]))
-        h = ops.conv_gemm(h, pk[p + ".conv1"], math=self.math)
+                          split16=ops.wants_split16(m, pk[p + ".conv1"]), a_scale=s1)
+        h = ops.conv_gemm(h, pk[p + ".conv1"], math=self.math, a_scale=s1)
         co = h.shape[-1]
+        s2 = self._nas(p + ".norm2", rows * (co // _vq_groups(co)))
         h = ops.groupnorm(h, sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], _vq_groups(co), 1e-6, L.ACT_SILU,
-                          split16=ops.wants_split16(m, pk[p + ".conv2"]))
+                          split16=ops.wants_split16(m, pk[p + ".conv2"]), a_scale=s2)
         skip = x if (p + ".nin_shortcut") not in pk else ops.conv_gemm(x, pk[p + ".nin_shortcut"], math=self.math)
-        return ops.conv_gemm(h, pk[p + ".conv2"], res=skip, math=self.math)
+        return ops.conv_gemm(h, pk[p + ".conv2"], res=skip, math=self.math, a_scale=s2)
 
     def _attn(self, p: str, x: Tensor) -> Tensor:
         sd, pk = self._sd, self._packed
         nb, d, h, w, c = x.shape
         n = d * h * w
         hn = ops.groupnorm(x, sd[p + ".norm.weight"], sd[p + ".norm.bias"], _vq_groups(c), 1e-6, L.ACT_NONE)
-        qkv = ops.linear(hn.view(nb, n, c), pk[p + ".qkv"], math=self.math)
+        qkv = ops.linear(hn.view(nb, n, c), pk[p + ".qkv"], math=self.math,
+                         a_scale=self._nas(p + ".norm", n * (c // _vq_groups(c))))
         a = ops.attention(qkv[..., 0:c], qkv[..., c:2 * c], qkv[..., 2 * c:], 1, int(c) ** (-0.5), math=self.math)
         out = ops.linear(a, pk[p + ".proj_out"], res=x.view(nb, n, c), math=self.math)
         return out.view(nb, d, h, w, c)
@@ -216,9 +232,11 @@ class VQVAE:
             if i_level != 0:
                 h = ops.conv_gemm(h, pk[f"{D}up.{i_level}.upsample.conv"], up=(1, 1, 1), math=self.math)
         c = h.shape[-1]
+        so = self._nas(D + "norm_out", h.shape[1] * h.shape[2] * h.shape[3] * (c // _vq_groups(c)))
         h = ops.groupnorm(h, sd[D + "norm_out.weight"], sd[D + "norm_out.bias"], _vq_groups(c), 1e-6, L.ACT_GELU,
-                          split16=ops.wants_split16(h.shape[0] * h.shape[1] * h.shape[2] * h.shape[3], pk[D + "conv_out"]))
-        return ops.conv_gemm(h, pk[D + "conv_out"], math=self.math)
+                          split16=ops.wants_split16(h.shape[0] * h.shape[1] * h.shape[2] * h.shape[3], pk[D + "conv_out"]),
+                          a_scale=so)
+        return ops.conv_gemm(h, pk[D + "conv_out"], math=self.math, a_scale=so)
 
     # ---- reference API ----
     @torch.no_grad()

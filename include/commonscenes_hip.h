@@ -94,6 +94,8 @@ typedef struct CsConvGemm {
   int32_t math;       /* CS_MATH_* */
   int32_t tile;       /* 0 = auto, 1 = 128x128, 2 = 128x224, 3 = 64x64, 4 = 256x224 (F16X3; FP32 runs it as 2),
                          6 = 256x128, 7 = 256x64 (F16X3: channel counts that are not multiples of 224; FP32 runs them as 1 / 3),
+                         8 = 512x64, 9 = 512x128 (F16X3, 3x3x3 stride-1 convs on pre-split operands: two row blocks per wave
+                         over one A slab; any other call runs them as 7 / 6),
                          5 = persistent ping-pong kernel (F16X3 pointwise GEMMs, cout % 224 == 0, cin >= 448, >= 384
                          128x224 tiles; csrc/cs_gemm_pw.hip).  Every tile code gives the same bits. */
   /* CS_MATH_F16X3 only: w = hi halves, w_lo = lo halves, both laid out [tap][cin16/8][cout][8] by

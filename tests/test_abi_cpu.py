@@ -198,7 +198,7 @@ def test_conv_gemm_descriptor_validation():
 
     for bad in (dict(cin=3), dict(lda=2), dict(ldo=2), dict(kd=0), dict(sd=0), dict(ud=5), dict(math=7),
                 dict(x=base + 4), dict(scale=base), dict(rowvec=base, rv_rows=0), dict(act=lib.ACT_GEGLU),
-                dict(math=lib.MATH_F16X3), dict(splitk=2), dict(tile=9, math=lib.MATH_F16X3, w_lo=base, acc_scale=1.0)):
+                dict(math=lib.MATH_F16X3), dict(splitk=2), dict(tile=11, math=lib.MATH_F16X3, w_lo=base, acc_scale=1.0)):
         assert dll.cs_conv_gemm(C.byref(desc(**bad)), None) == lib.CS_EINVAL, bad
     sk, ws = C.c_int32(-1), C.c_int64(-1)
     assert dll.cs_conv_gemm_plan(C.byref(desc()), C.byref(sk), C.byref(ws)) == 0 and sk.value == 1 and ws.value == 0

@@ -371,7 +371,12 @@ def test_f16x3_presplit_activation_path(shape, cin, cout, tile, monkeypatch):
 
 @pytest.mark.parametrize("shape,cin,cout,tile", [((2, 16, 16, 16), 32, 224, 4), ((5, 16, 4, 4), 64, 672, 4),
                                                  ((1, 5, 7, 3), 24, 224, 4), ((1, 3, 5, 64), 16, 64, 7),
-                                                 ((1, 4, 9, 32), 16, 128, 6), ((6, 4, 4, 4), 32, 224, 4)])
+                                                 ((1, 4, 9, 32), 16, 128, 6), ((6, 4, 4, 4), 32, 224, 4),
+                                                 # r3: the 512-row slab tiles (two row blocks per wave)
+                                                 ((1, 3, 5, 64), 16, 64, 8), ((2, 6, 9, 11), 24, 64, 8),
+                                                 ((3, 8, 16, 16), 32, 64, 8), ((1, 5, 7, 3), 16, 64, 8),
+                                                 ((6, 4, 4, 4), 32, 64, 8), ((1, 4, 9, 32), 16, 128, 9),
+                                                 ((2, 8, 16, 16), 32, 256, 9)])
 def test_f16x3_presplit_slab_path_is_bit_identical(shape, cin, cout, tile, monkeypatch):
     """the slab kernel fed by the split16 GroupNorm producer (a_format = 1: no conversion in the K loop, masked taps read
     a zero block) equals the same conv on the fp32 GroupNorm output bit for bit (y * 16 is exact), for every slab tile;
@@ -579,3 +584,33 @@ def test_pingpong_gemm_reports_overflow_and_rejects_what_it_cannot_do():
     out = ops.linear(small, pw)
     torch.cuda.synchronize()
     assert torch.isfinite(out).all()
+
+
+@pytest.mark.parametrize("shape,cin,cout,tile", [((2, 4, 12, 64), 32, 64, 8), ((3, 8, 8, 16), 48, 128, 9)])
+def test_f16x3_512_row_slab_tiles_with_residual_epilogue(shape, cin, cout, tile, monkeypatch):
+    """tiles 8 / 9 (512 x 64 / 512 x 128: two row blocks per wave over the same slab; the VQ-VAE decoder's 64^3 and 32^3
+    levels, r3) with the pipelined residual epilogue: bit for bit against the per-tap gather tile, fp32-grade against
+    fp64, deterministic."""
+    from commonscenes_amd import lib as L, ops
+    from oracle import ref_ops as R
+    nb, d, h, w = shape
+    x = _rand(nb, d, h, w, cin, seed=91) * 1.5 + 0.3
+    g, b = _rand(cin, seed=92) * 0.2 + 1.0, _rand(cin, seed=93) * 0.1
+    wt = _rand(cout, cin, 3, 3, 3, seed=94, scale=(cin * 27) ** -0.5)
+    bias, res = _rand(cout, seed=95), _rand(nb, d, h, w, cout, seed=96)
+    pk = ops.pack_weight(wt.cuda(), bias.cuda(), math=L.MATH_F16X3)
+    monkeypatch.setattr(ops, "SPLIT16_PRODUCERS", True)
+    hn = ops.groupnorm(x.cuda(), g.cuda(), b.cuda(), 8 if cin % 32 else 32, 1e-6, L.ACT_SILU, split16=True)
+    prof = ops.GEMM_PROFILE = []
+    try:
+        o = ops.conv_gemm(hn, pk, res=res.cuda(), tile=tile)
+    finally:
+        ops.GEMM_PROFILE = None
+    o2 = ops.conv_gemm(hn, pk, res=res.cuda(), tile=tile)
+    og = ops.conv_gemm(hn, pk, res=res.cuda(), tile=3)
+    torch.cuda.synchronize()
+    assert prof[0]["tile"] == tile and prof[0]["slab"] in (32, 64) and prof[0]["pre"]
+    assert torch.equal(o, o2) and torch.equal(o, og)
+    ref = R.conv_ndhwc(R.groupnorm_ndhwc(x.double(), g.double(), b.double(), 8 if cin % 32 else 32, 1e-6, "silu"),
+                       wt.double(), bias.double(), res=res.double())
+    assert rel_l2(o, ref) < 1e-6

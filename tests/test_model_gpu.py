@@ -613,7 +613,7 @@ def test_channel_split_resblocks_equal_the_unsplit_route(monkeypatch):
             plain = df.forward_cfg(x, t, c_in)
             torch.cuda.synchronize()
             assert len(info) == 4 and not torch.equal(split, plain)
-            assert rel_l2(split, plain) < 2e-6, (small, math)
+            assert rel_l2(split, plain) < 5e-6, (small, math)      # two fp32 summation partitions through the whole UNet
             if not small:
                 ks = {k.split("output_blocks.")[1][0]: v for k, v in info.items()}
                 assert ks == {"5": (464, 448), "6": (464, 448), "7": (224, 224), "8": (224, 224)}

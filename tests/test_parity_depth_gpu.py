@@ -525,6 +525,43 @@ def test_f16x3_uniformly_tiny_operand_keeps_its_absolute_floor():
     assert torch.equal(big, small)                                       # a power-of-two input scale changes nothing
 
 
+def test_norm_fed_gemms_take_their_operand_scale_from_the_producer():
+    """VERDICT r2 next #7c: a_scale was the constant 16 everywhere.  A GroupNorm / LayerNorm bounds its output --
+    |y| <= max|gamma| sqrt(n - 1) + max|beta| -- so the GEMM it feeds takes the largest power of two that keeps that bound
+    inside the fp16 range (ops.norm_a_scale): overflow is impossible there whatever the input, and a layer whose affine
+    parameters are uniformly tiny (gamma = 1e-6) keeps RELATIVE fp32-grade accuracy, which the fixed scale loses."""
+    from commonscenes_amd import lib as L, ops, synth
+    from oracle import ref_ops as R
+    assert ops.norm_a_scale(1.2, 0.1, 28672) == 256.0 and ops.norm_a_scale(1.2, 0.1, 448) == 2048.0
+    for g_, b_, n in ((1.2, 0.1, 28672), (37.0, 5.0, 172032), (1e-6, 1e-7, 1024), (3e4, 0.0, 7), (0.0, 0.0, 9)):
+        s_ = ops.norm_a_scale(g_, b_, n)
+        assert s_ == 2.0 ** round(__import__("math").log2(s_)) and 2.0 ** -8 <= s_ <= 2.0 ** 14
+        if s_ > 2.0 ** -8:
+            assert (g_ * (n - 1) ** 0.5 + b_) * s_ <= 65000.0
+    nb, d, c, co = 2, 8, 64, 224
+    x = synth.gaussian_like("ns:x", (nb, d, d, d, c))
+    x[0, 0, 0, 0, :2] = 4000.0                                     # an outlier GroupNorm turns into x^ ~ 30
+    gam = (synth.gaussian_like("ns:g", (c,)) * 0.1 + 1.0) * 1e-6
+    bet = synth.gaussian_like("ns:b", (c,)) * 1e-7
+    w = synth.gaussian_like("ns:w", (co, c, 3, 3, 3), scale=(c * 27) ** -0.5)
+    ref = R.conv_ndhwc(R.groupnorm_ndhwc(x.double(), gam.double(), bet.double(), 32, 1e-5, "silu"), w.double(), None)
+    pk = ops.pack_weight(w.cuda(), None, math=L.MATH_F16X3)
+    s = ops.norm_a_scale(float(gam.abs().max()), float(bet.abs().max()), d ** 3 * (c // 32))
+    assert s == 2.0 ** 14
+    ops.read_status()
+    errs = {}
+    for name, sc in (("derived", s), ("fixed16", None)):
+        for split in (False, True):
+            hn = ops.groupnorm(x.cuda(), gam.cuda(), bet.cuda(), 32, 1e-5, L.ACT_SILU, split16=split, a_scale=sc)
+            out = ops.conv_gemm(hn, pk, a_scale=sc)
+            torch.cuda.synchronize()
+            errs[(name, split)] = rel_l2(out, ref)
+    print("tiny-gamma GroupNorm -> conv, rel-L2 vs fp64:", {k: f"{v:.1e}" for k, v in errs.items()})
+    assert ops.read_status() == 0
+    assert errs[("derived", False)] < 1e-6 and errs[("derived", True)] < 1e-6
+    assert errs[("fixed16", False)] > 10 * errs[("derived", False)]          # what the constant scale gave up
+
+
 def test_unet_with_heavy_tailed_weights_and_latent_outliers():
     """the reduced-width UNet with Student-t (3 degrees of freedom) conv / linear weights -- the heavy-tailed shape trained
     networks have, which the PyTorch-default uniform synthetic weights lack -- and a latent with +-30 outliers, against the
