@@ -585,7 +585,7 @@ def main():
                                      else ("external launcher" if world > 1 else "single process")},
             "finite": finite, "f16x3_overflow": overflow, "unet_driver": a.driver,
         }
-        if not a.no_cpu_baseline and not a.small:
+        if not a.no_cpu_baseline and not a.small and world == 1:      # rank 0 at N = 1 only: the other ranks would idle
             res["cpu_baseline"] = cpu_baseline(df, cfg, B, quick=a.cpu_baseline == "quick")
         print(json.dumps(res), flush=True)
     if world > 1:

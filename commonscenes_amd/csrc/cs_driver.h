@@ -60,12 +60,12 @@ struct Norm {
 // the same IEEE double operations in the same order, so both hosts derive the same scale)
 inline float norm_a_scale(float gmax, float bmax, int64_t n) {
   const double bound = (double)gmax * std::sqrt((double)(n > 1 ? n - 1 : 1)) + (double)bmax;
-  if (!(bound > 0.0) || !std::isfinite(bound)) return 16384.f;
+  if (!(bound > 0.0) || !std::isfinite(bound)) return (float)std::ldexp(1.0, 40);
   int ex = 0;
   (void)std::frexp(65000.0 / bound, &ex);
   int k = ex - 1;
   if (k < -8) k = -8;
-  if (k > 14) k = 14;
+  if (k > 40) k = 40;
   return (float)std::ldexp(1.0, k);
 }
 

@@ -383,18 +383,16 @@ extern "C" int cs_conv_gemm(const CsConvGemm* d, cs_stream_t stream) {
       tile = 1;
     else
       tile = 3;
-    // r3: 3x3x3 stride-1 convs of the VQ-VAE decoder's upper levels (N = 64 / 128, millions of rows): the 256-row tiles
-    // give a wave only 6 / 12 MFMAs per K chunk and barrier; 512-row tiles (two row blocks per wave, same slab) double
-    // that and halve the weight-operand DMA and the per-chunk synchronisation per flop
+    // (r3: tiles 8 / 9 -- 512 x 64 / 512 x 128, two row blocks per wave over one slab -- exist and are bit-identical, but
+    // are NOT auto-selected: on the VQ-VAE decoder's 64^3 / 32^3 convs they measured 334-360 / 405-443 TF/s against
+    // 366-377 / 434-451 for the 256-row tiles, profiles/r03_g_decode_tables.txt.  CS_TILE512=1 selects them for A/B runs.)
     {
-      // CS_NO_TILE512 = 1: neither; = 8 / 9: without that tile (A/B runs)
-      static const char* e512 = getenv("CS_NO_TILE512");
-      static const bool no512 = e512 && *e512 == '1', no8 = e512 && *e512 == '8', no9 = e512 && *e512 == '9';
+      static const char* e512 = getenv("CS_TILE512");
       const bool conv3 = p.kd == 3 && p.kh == 3 && p.kw == 3 && p.sd == 1 && p.sh == 1 && p.sw == 1 &&
                          !(p.ud | p.uh | p.uw) && p.pd == 1 && p.ph == 1 && p.pw == 1;
       const int64_t t512 = (M + 511) / 512;
-      if (!no512 && !no8 && conv3 && tile == 7 && p.cout == 64 && p.win <= 64 && t512 >= 512) tile = 8;
-      if (!no512 && !no9 && conv3 && tile == 6 && p.win <= 32 && t512 * (p.cout / 128) >= 512) tile = 9;
+      if (e512 && *e512 == '1' && conv3 && tile == 7 && p.cout == 64 && p.win <= 64 && t512 >= 512) tile = 8;
+      if (e512 && *e512 == '1' && conv3 && tile == 6 && p.win <= 32 && t512 * (p.cout / 128) >= 512) tile = 9;
     }
     if (p.act == CS_ACT_GEGLU && tile != 4) tile = 2;   // the fused gate needs whole [x | gate] 224-column tiles
     // ... and with a short K loop (the 448-channel level: 28 chunks) two 128-row workgroups per CU overlap one's gate

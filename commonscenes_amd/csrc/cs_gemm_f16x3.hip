@@ -37,7 +37,8 @@ constexpr int MAX_TAPS = 27;
 #ifndef CS_ABLATE
 #define CS_ABLATE 0   // debug builds, timing only (results are wrong): 1 = no DMA issue, 2 = DMAs fetch nothing (all
                       // offsets out of range -> zero fill), 4 = no vmcnt wait in the loop, 8 = no barrier,
-                      // 16 = s_setprio around the MFMAs, 32 = scalar epilogue, 64 = all fetches from one 16 KB window
+                      // 16 = s_setprio around the MFMAs, 32 = scalar epilogue, 64 = all fetches from one 16 KB window,
+                      // 1024 = no epilogue (K loop + prologue only), 2048 = no K loop (prologue + epilogue only)
 #endif
 
 // PRE = the activations arrive already split: p.x / p.x_lo are fp16 hi / lo images [rows][lda halves] written by
@@ -212,7 +213,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   constexpr int KGRAN = SLAB ? 9 : 1;
   const int per_split = ((nk_all / KGRAN + splits - 1) / splits) * KGRAN;
   const int k_first = split * per_split;
+#if CS_ABLATE & 2048
+  const int nk = 0;
+#else
   const int nk = max(0, min(nk_all, k_first + per_split) - k_first);
+#endif
 
   // ---- per-lane DMA constants ----
   // A wave-instruction w (0..A_WI-1) covers units 64w..64w+63: row = 16w + lane/4, LDS slot q = lane&3 holds
@@ -596,6 +601,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
     if (p.status && amax >= 65504.f) atomicOr(p.status, CS_STATUS_F16X3_OVERFLOW);
   }
 
+#if CS_ABLATE & 1024      // what-if "no epilogue": keep the accumulators live behind a never-true store
+  {
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < WMB; ++i)
+#pragma unroll
+      for (int j = 0; j < WNB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
+    if (M == -12345) p.out[tid] = sum;
+    return;
+  }
+#endif
   // ---- epilogue (identical contract to the fp32 kernel, after undoing the operand scales) ----
   // Fast path: the C/D layout gives a lane one column and 16 scattered rows, i.e. 112 dword stores (+112 dword
   // residual loads) per lane -- issue-bound, and for the short-K token GEMMs as long as the main loop.  Stage

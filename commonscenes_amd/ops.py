@@ -174,15 +174,17 @@ def norm_a_scale(gmax: float, bmax: float, n: int) -> float:
     statistic.  A normalised value obeys |x^| <= sqrt(n - 1), so |y| <= gmax * sqrt(n - 1) + bmax =: bound (|silu(y)|,
     |gelu(y)| <= |y|): the largest power of two 2^k with bound * 2^k <= 65000 < 65504 cannot overflow the fp16 range
     WHATEVER the input -- the producer's bound replaces the fixed guess of 16 (r3; VERDICT r2 next #7c) -- and is 16-128x
-    larger for the shipped layers, so the absolute floor 2^-24 / a_scale of tiny operands drops accordingly.  k is
-    clamped to [-8, 14].  Every step is an IEEE double operation, mirrored in csrc/cs_driver.h::norm_a_scale: both
+    larger for the shipped layers, so the absolute floor 2^-25 / a_scale of tiny operands (the lo half leaves fp16's
+    normal range below a_scale * |a| = 2^-3) drops accordingly; a layer whose affine parameters are uniformly tiny gets a
+    correspondingly huge scale and keeps full relative precision.  k is clamped to [-8, 40] (products stay below
+    2^16 * 2^14 by construction, acc_scale = 2^-(k + weight exponent) stays a normal fp32).  Every step is an IEEE double operation, mirrored in csrc/cs_driver.h::norm_a_scale: both
     hosts derive the same scale."""
     import math as _m
     bound = float(gmax) * _m.sqrt(float(max(n - 1, 1))) + float(bmax)
     if not (bound > 0.0) or not _m.isfinite(bound):
-        return 2.0 ** 14
+        return 2.0 ** 40
     k = _m.frexp(65000.0 / bound)[1] - 1
-    return 2.0 ** max(-8, min(14, k))
+    return 2.0 ** max(-8, min(40, k))
 
 
 # CS_NO_UPFOLD=1: upsample convs take the direct form (27 taps on the doubled grid) -- A/B runs
@@ -444,7 +446,7 @@ def _pingpong_ok(m: int, cin: int, cout: int, math: int, pointwise: bool, bn: bo
             and ((m + 127) // 128) * (cout // 224) >= 384 and rv_rows % 128 == 0)
 
 
-NO_TILE512 = os.environ.get("CS_NO_TILE512", "")      # "1": neither 512-row tile, "8" / "9": without that one (A/B runs)
+TILE512 = os.environ.get("CS_TILE512", "") == "1"      # auto-select the 512-row slab tiles (A/B runs; off: they lost)
 
 
 def tile_for(m: int, cout: int, tile: int = 0, math: int = L.MATH_FP32, cin: int = 0, pointwise: bool = False,
@@ -454,13 +456,12 @@ def tile_for(m: int, cout: int, tile: int = 0, math: int = L.MATH_FP32, cin: int
     if tile:
         return tile
     t = _tile_for(m, cout, math, cin, act)
-    # the 512-row slab tiles (two row blocks per wave) of the VQ-VAE decoder's upper levels: cs_gemm.hip picks them,
-    # cs_gemm_f16x3.hip runs them on pre-split operands only
-    if conv3_win and presplit and NO_TILE512 != "1" and math == L.MATH_F16X3:
+    # the 512-row slab tiles (two row blocks per wave): only with CS_TILE512=1 (cs_gemm.hip), pre-split operands only
+    if conv3_win and presplit and TILE512 and math == L.MATH_F16X3:
         t512 = (m + 511) // 512
-        if t == 7 and cout == 64 and conv3_win <= 64 and t512 >= 512 and NO_TILE512 != "8":
+        if t == 7 and cout == 64 and conv3_win <= 64 and t512 >= 512:
             return 8
-        if t == 6 and conv3_win <= 32 and t512 * (cout // 128) >= 512 and NO_TILE512 != "9":
+        if t == 6 and conv3_win <= 32 and t512 * (cout // 128) >= 512:
             return 9
     return t
 

@@ -535,7 +535,7 @@ def test_norm_fed_gemms_take_their_operand_scale_from_the_producer():
     assert ops.norm_a_scale(1.2, 0.1, 28672) == 256.0 and ops.norm_a_scale(1.2, 0.1, 448) == 2048.0
     for g_, b_, n in ((1.2, 0.1, 28672), (37.0, 5.0, 172032), (1e-6, 1e-7, 1024), (3e4, 0.0, 7), (0.0, 0.0, 9)):
         s_ = ops.norm_a_scale(g_, b_, n)
-        assert s_ == 2.0 ** round(__import__("math").log2(s_)) and 2.0 ** -8 <= s_ <= 2.0 ** 14
+        assert s_ == 2.0 ** round(__import__("math").log2(s_)) and 2.0 ** -8 <= s_ <= 2.0 ** 40
         if s_ > 2.0 ** -8:
             assert (g_ * (n - 1) ** 0.5 + b_) * s_ <= 65000.0
     nb, d, c, co = 2, 8, 64, 224
@@ -547,7 +547,7 @@ def test_norm_fed_gemms_take_their_operand_scale_from_the_producer():
     ref = R.conv_ndhwc(R.groupnorm_ndhwc(x.double(), gam.double(), bet.double(), 32, 1e-5, "silu"), w.double(), None)
     pk = ops.pack_weight(w.cuda(), None, math=L.MATH_F16X3)
     s = ops.norm_a_scale(float(gam.abs().max()), float(bet.abs().max()), d ** 3 * (c // 32))
-    assert s == 2.0 ** 14
+    assert s >= 2.0 ** 28          # (1.3e-6 * 32 + 3e-7) * 2^30 = 45000
     ops.read_status()
     errs = {}
     for name, sc in (("derived", s), ("fixed16", None)):
