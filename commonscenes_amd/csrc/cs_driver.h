@@ -742,7 +742,9 @@ struct ExecBase {
     const Gemm& g = pl.gemms[gi];
     if (g.up_mask || g.k != 3 || (g.cin & 7) || g.cin_pad != g.cin) return false;
     const int64_t t256 = (m + 255) / 256;
-    if (g.cout % 224 == 0) return t256 * (g.cout / 224) >= 192;
+    // (r3: ... and the 128-row slab tile of medium batches, from CS_SPLIT16_MIN_ROWS rows; ops.py::wants_split16)
+    static const int64_t min_rows = getenv("CS_SPLIT16_MIN_ROWS") ? atoll(getenv("CS_SPLIT16_MIN_ROWS")) : 8192;
+    if (g.cout % 224 == 0) return t256 * (g.cout / 224) >= 192 || (min_rows > 0 && m >= min_rows);
     if (g.cout % 128 == 0) return t256 * (g.cout / 128) >= 192;
     return (g.cout == 64 || g.cout <= 4) && t256 >= 192;
   }

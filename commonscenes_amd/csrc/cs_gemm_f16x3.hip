@@ -958,6 +958,7 @@ int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p_in, int M, int tile, int spl
 #ifndef CS_NO_SLAB
     if (slab_geom && slab_slices_ok) {
       switch (tile) {
+        case 2: return launch16<1, 7, 4, 1, true, 32>(p, M, splits, s);    // r3: small batches (128-row tiles, K slices)
         case 4: return launch16<1, 7, 8, 1, true, 32>(p, M, splits, s);
         case 6: return launch16<1, 4, 8, 1, true, 32>(p, M, splits, s);
         case 7: return p.win <= 32 ? launch16<1, 2, 8, 1, true, 32>(p, M, splits, s)

@@ -489,8 +489,13 @@ def wants_split16(m: int, w: "PackedWeight") -> bool:
     will run the slab kernel (3x3x3 on a 256-row tile: large batches) -- there the in-loop conversion is what is left
     to remove.  Small batches (128-row / 64-row tiles, split-K) measured slightly slower with it (7.85 vs 7.58 ms per
     one-object step), 1-tap GEMMs neutral: both keep fp32 activations."""
-    return (SPLIT16_PRODUCERS and w.math == L.MATH_F16X3 and w.classes is None and tuple(w.k) == (3, 3, 3)
-            and w.cin % 8 == 0 and _tile_for(m, w.cout, w.math, w.cin, L.ACT_NONE) in (4, 6, 7))
+    if not (SPLIT16_PRODUCERS and w.math == L.MATH_F16X3 and w.classes is None and tuple(w.k) == (3, 3, 3)
+            and w.cin % 8 == 0):
+        return False
+    if _tile_for(m, w.cout, w.math, w.cin, L.ACT_NONE) in (4, 6, 7):
+        return True
+    # r3: also where the conv runs the 128-row slab tile (224-column convs of medium batches, with or without K slices)
+    return SPLIT16_MIN_ROWS > 0 and w.cout % 224 == 0 and m >= SPLIT16_MIN_ROWS
 
 
 def slab_width(tile: int, k, stride, up, win: int, math: int, presplit: bool, splitk: int) -> int:
@@ -498,7 +503,7 @@ def slab_width(tile: int, k, stride, up, win: int, math: int, presplit: bool, sp
     if splitk > 1 and tile != 4:
         tile = 2                                     # the K-sliced path runs 128x224 tiles (cs_conv_gemm)
     if (math != L.MATH_F16X3 or tuple(k) != (3, 3, 3) or tuple(stride) != (1, 1, 1)
-            or tuple(up) != (0, 0, 0) or tile not in (2, 4, 6, 7, 8, 9) or win > 64 or (tile == 2 and presplit)):
+            or tuple(up) != (0, 0, 0) or tile not in (2, 4, 6, 7, 8, 9) or win > 64):
         return 0
     if win <= 32:
         return 32
@@ -537,6 +542,10 @@ class Split16:
 # (tools/slab_whatif2.sh) -- so it is the default.  Results are bit-identical either way (y * 16 is exact).
 # CS_NO_SPLIT16=1 turns it off (A/B runs).
 SPLIT16_PRODUCERS = not os.environ.get("CS_NO_SPLIT16")
+# ... and (r3) where it runs the 128-row slab tile, from this many rows (4 objects at 16x8x8): 7 objects 27.34 -> 26.94
+# ms/step, 4 objects 17.61 -> 17.41, 16 objects 49.11 -> 48.75; below it slower (1 object 8.58 -> 8.73): the three-launch
+# GroupNorm replaces the single-launch one there (profiles/r03_j_split16_small_ab.txt).  0 = never.
+SPLIT16_MIN_ROWS = int(os.environ.get("CS_SPLIT16_MIN_ROWS", "8192"))
 
 
 def groupnorm(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float, act: int = L.ACT_NONE,

@@ -328,6 +328,47 @@ class SDFusionText2ShapeModel:
             return self.gen_df, llat
         return self.gen_df
 
+    # ---- the other callers of the same sampler (sdfusion_txt2shape_model.py:368-457) -----------------------------------
+    # The reference runs these over ALL objects in one sampler call (no mini-batching) with fresh noise per object
+    # (DDIMSampler draws torch.randn when x_T is None); same here, plus the x_T / max_steps injection of rel2shape.
+    def _sample_all(self, c, uc, ddim_steps, ddim_eta, uc_scale, x_T=None, max_steps=None):
+        if ddim_steps is None:
+            ddim_steps = self.ddim_steps
+        if uc_scale is None:
+            uc_scale = self.uc_scale
+        c = c.to(device=self.device, dtype=torch.float32)
+        uc = None if uc is None else uc.to(device=self.device, dtype=torch.float32)
+        samples = self._sample_minibatch(self.ddim_sampler, ddim_steps, self.z_shape, c, uc, x_T, uc_scale, ddim_eta,
+                                         max_steps)
+        self.last_latents = samples
+        self.gen_df = self._decode_checked(samples)
+        return self.gen_df
+
+    @torch.no_grad()
+    def inference(self, data, ddim_steps=None, ddim_eta=0., uc_scale=None, infer_all=False, max_sample=16,
+                  x_T: Optional[Tensor] = None, max_steps: Optional[int] = None):
+        """:423-457: set_input (at most `max_sample` objects unless infer_all), one guided sampler run over all of them,
+        decode into self.gen_df.  (The reference then calls switch_train(): training is out of scope here.)"""
+        self.switch_eval()
+        self.set_input(data, max_sample=None if infer_all else max_sample)
+        return self._sample_all(self.rel, self.uc_rel, ddim_steps, ddim_eta, uc_scale, x_T, max_steps)
+
+    @torch.no_grad()
+    def graph2shape(self, num_obj=6, ddim_steps=100, ddim_eta=0.0, uc_scale=None, x_T: Optional[Tensor] = None,
+                    max_steps: Optional[int] = None):
+        """:390-421: the first num_obj objects of the CURRENT input (set_input must have run), sampled with
+        unconditional_conditioning=None -- i.e. WITHOUT classifier-free guidance, whatever uc_scale says (ddim.py:200-201)
+        -- and decoded.  Returns gen_df."""
+        self.switch_eval()
+        return self._sample_all(self.rel[:num_obj], None, ddim_steps, ddim_eta, uc_scale, x_T, max_steps)
+
+    @torch.no_grad()
+    def gen_shape_after_foward(self, num_obj, ddim_steps=None, uc_scale=None, ddim_eta=0., x_T: Optional[Tensor] = None,
+                               max_steps: Optional[int] = None):
+        """:368-386 (sic): guided sampling of the first num_obj objects of the current input, decode into self.gen_df."""
+        self.switch_eval()
+        return self._sample_all(self.rel[:num_obj], self.uc_rel[:num_obj], ddim_steps, ddim_eta, uc_scale, x_T, max_steps)
+
     # ---- checkpoint surface (VAEGAN_V2FULL.py:687-699 stores these under 'df' / 'vqvae') ----
     def state_dict(self):
         return {"df": self.df.state_dict(), "vqvae": self.vqvae.state_dict()}

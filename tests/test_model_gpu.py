@@ -621,3 +621,42 @@ def test_channel_split_resblocks_equal_the_unsplit_route(monkeypatch):
         torch.cuda.empty_cache()
     monkeypatch.delenv("CS_CFG_SPLIT_MIN_ROWS")
     assert DiffusionUNet(_unet_cfg(True), conditioning_key="crossattn", device="cuda").split_min_rows == 65536
+
+
+def test_inference_graph2shape_gen_shape_after_foward(tmp_path):
+    """the other callers of the same sampler the reference keeps next to rel2shape
+    (sdfusion_txt2shape_model.py:368-457; VERDICT r2 missing #6): one sampler run over ALL objects, then decode.
+    `inference` / `gen_shape_after_foward` are guided runs -- equal to rel2shape with one mini-batch, bit for bit, when
+    handed the same noise; `graph2shape` passes unconditional_conditioning=None, i.e. runs WITHOUT guidance (ddim.py:
+    200-201): its latents are checked against the oracle's unguided sampler."""
+    from commonscenes_amd import synth
+    from oracle import ref_torch as R
+    m = _scene(tmp_path).Diff
+    B = 5
+    c, uc = synth.gaussian_like("oc:c", (B, 1, 1280)).cuda(), synth.gaussian_like("oc:uc", (B, 1, 1280)).cuda()
+    x1 = synth.gaussian_like("oc:xT", (1, 3, 16, 16, 16))
+    data = {"sdf": torch.zeros(B, 1), "rel": c, "uc": uc}
+    ref_sdf, ref_lat = m.rel2shape(data, ddim_steps=50, uc_scale=3.0, x_T=x1, mini_B=B, return_latents=True, max_steps=2)
+    xB = x1.repeat(B, 1, 1, 1, 1).cuda()
+    out = m.inference(data, ddim_steps=50, uc_scale=3.0, infer_all=True, x_T=xB, max_steps=2)
+    torch.cuda.synchronize()
+    assert out is m.gen_df and torch.equal(out, ref_sdf) and torch.equal(m.last_latents, ref_lat)
+    out16 = m.inference(data, ddim_steps=50, uc_scale=3.0, max_sample=3, x_T=xB[:3], max_steps=2)     # :431-433
+    assert out16.shape[0] == 3 and torch.equal(out16, ref_sdf[:3])
+    m.set_input(data)
+    g3 = m.gen_shape_after_foward(3, ddim_steps=50, uc_scale=3.0, x_T=xB[:3], max_steps=2)
+    assert torch.equal(g3, ref_sdf[:3])
+    # graph2shape: no guidance
+    g2 = m.graph2shape(num_obj=4, ddim_steps=50, x_T=xB[:4], max_steps=2)
+    torch.cuda.synchronize()
+    assert g2.shape == (4, 1, 64, 64, 64) and not torch.equal(g2, ref_sdf[:4])
+    sd = {k: v.cpu() for k, v in m.df.state_dict().items()}
+    cfg = _unet_cfg(True)
+    with torch.no_grad():
+        lat_ref, _ = R.ddim_sample(lambda a, t, cc: R.unet_forward(sd, cfg, a, t, cc), R.register_schedule(**R.DIFFUSION)[
+            "alphas_cumprod"], 50, xB[:4].cpu(), c[:4].cpu(), None, 3.0, max_steps=2)
+    assert rel_l2(m.last_latents, lat_ref) < 1e-4
+    # fresh noise when none is injected: two runs differ (the reference draws torch.randn per call)
+    a = m.graph2shape(num_obj=2, ddim_steps=50, max_steps=1)
+    b = m.graph2shape(num_obj=2, ddim_steps=50, max_steps=1)
+    assert torch.isfinite(a).all() and not torch.equal(a, b)
