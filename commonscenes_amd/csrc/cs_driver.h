@@ -493,6 +493,8 @@ struct Buf {
   int c = 0;
   bool half = false;   // fp16 hi image [rows][c] followed by the lo image (the F16X3 GEMMs' pre-split A operand);
                        // same footprint as fp32 [rows][c]
+  bool pair = false;   // the INTERLEAVED operand pair (CsConvGemm.a_format = 2): bytes / row stride of fp32 [rows][c],
+                       // written by cs_layernorm_pair16
   float a_scale = 16.f;   // F16X3 operand scale a GEMM reading this buffer uses: the default for activations of unknown
                           // range, the producer's bound for normalisation outputs (norm_a_scale)
 };
@@ -586,6 +588,8 @@ struct ExecBase {
       if (x.half) {
         q.x_lo = reinterpret_cast<const char*>(p(x)) + x.rows * x.c * 2;
         q.a_format = 1;
+      } else if (x.pair) {
+        q.a_format = 2;
       }
       q.out = p(out);
       q.w = reinterpret_cast<const float*>(arena + g.w_off);
@@ -781,6 +785,16 @@ struct ExecBase {
     const Norm& n = pl.norms[ni];
     Buf y = alloc(x.rows, x.c);
     if (pl.math == CS_MATH_F16X3) y.a_scale = norm_a_scale(n.gmax, n.bmax, x.c);
+    // LayerNorm outputs only ever feed GEMMs: in F16X3 mode they are written as the interleaved operand pair
+    // (ops.py::layernorm pair_scale; CS_NO_PAIR16=1 keeps fp32 for A/B runs)
+    static const bool no_pair = getenv("CS_NO_PAIR16") != nullptr && *getenv("CS_NO_PAIR16");
+    if (pl.math == CS_MATH_F16X3 && !no_pair && x.c % 16 == 0) {
+      y.pair = true;
+      if (ok() && !dry)
+        chk(cs_layernorm_pair16(p(x), wf(n.g_off), wf(n.b_off), p(y), (int)x.rows, x.c, x.c, x.c, 1e-5f, y.a_scale,
+                                status, st));
+      return y;
+    }
     if (ok() && !dry) chk(cs_layernorm(p(x), wf(n.g_off), wf(n.b_off), p(y), (int)x.rows, x.c, x.c, x.c, 1e-5f, st));
     return y;
   }

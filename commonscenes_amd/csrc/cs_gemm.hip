@@ -635,4 +635,4 @@ extern "C" int cs_relayout_weight(const float* w_torch, float* w_out, int cout, 
   return CS_OK;
 }
 
-extern "C" int cs_abi_version(void) { return 11; }
+extern "C" int cs_abi_version(void) { return 12; }

@@ -53,7 +53,13 @@ constexpr int MAX_TAPS = 27;
 // the DMA stream: dropping them in a timing-only build moved the conv shapes from 385-388 to 448-450 TF/s,
 // tools/slab_whatif.sh) by one ~18 KB sequential one.  The chunk order, and with it every accumulation order, is the
 // same as without the slab: results are bit-identical.
-template <int WMB, int WNB, int WAVES_M, int WAVES_N, bool PRE, int SLAB = 0>
+//
+// PAIR (r3, a_format = 2): the activations arrive as the INTERLEAVED operand pair -- per row and 16-channel chunk the 64
+// bytes [hi c0-7 | lo c0-7 | hi c8-15 | lo c8-15] (fp16 halves of value * a_scale), written by cs_layernorm_pair16 and the
+// pair-emitting GEMM epilogues.  Same bytes, row stride and 64-byte gather pieces as the fp32 tensor it replaces (the
+// separate hi / lo images of PRE halve the piece size: measured neutral on the per-tap gather path in r2), and the two
+// 16-byte pieces a lane reads are exactly its hi and lo fragments: the K loop carries no conversion VALU.
+template <int WMB, int WNB, int WAVES_M, int WAVES_N, bool PRE, int SLAB = 0, bool PAIR = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_kernel(const CsConvGemm p, int M, int tiles_n,
                                                               int taps_hw, int kw_, int kg_per_tap,
                                                               long long x_bytes, unsigned w_bytes, int vec_epilogue,
@@ -64,6 +70,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   constexpr int NT = 64 * NW;
   // ---- LDS map (bytes) ----
   static_assert(!SLAB || (WMB <= 2 && WAVES_N == 1), "slab path: one or two row blocks per wave");
+  static_assert(!PAIR || (!PRE && SLAB == 0), "interleaved operand pairs: per-tap gather path only");
   // wave-instructions per slab (SLAB = widest line W): fp32 rows of 64 B, 16 per instruction; PRE: a hi and a lo image
   // of 32 B rows, 32 per instruction each
   constexpr int SLAB_IMG_WI = (BM + 2 * SLAB + 2 + 31) / 32;
@@ -353,7 +360,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
         hi[i] = __builtin_bit_cast(h8, x0);
         lo[i] = __builtin_bit_cast(h8, x1);
 #else
-        split8(x0, x1, a_scale, hi[i], lo[i], amax);
+        if constexpr (PAIR) {          // the producer already split: the two pieces ARE the hi / lo fragments
+          hi[i] = __builtin_bit_cast(h8, x0);
+          lo[i] = __builtin_bit_cast(h8, x1);
+        } else {
+          split8(x0, x1, a_scale, hi[i], lo[i], amax);
+        }
 #endif
       }
     }
@@ -596,7 +608,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
     }
   }
   wait_vmcnt<0>();   // drain the prefetches issued past the end before LDS is released
-  if constexpr (!PRE) {
+  if constexpr (!PRE && !PAIR) {
     // an activation at or beyond the fp16 range became +-inf in its hi half: tell the host (sticky flag)
     if (p.status && amax >= 65504.f) atomicOr(p.status, CS_STATUS_F16X3_OVERFLOW);
   }
@@ -876,7 +888,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   }
 }
 
-template <int WMB, int WNB, int WAVES_M, int WAVES_N, bool PRE, int SLAB = 0>
+template <int WMB, int WNB, int WAVES_M, int WAVES_N, bool PRE, int SLAB = 0, bool PAIR = false>
 int launch16(const CsConvGemm& p, int M, int splits, hipStream_t stream) {
   constexpr int BM = 32 * WMB * WAVES_M;
   constexpr int BN = 32 * WNB * WAVES_N;
@@ -900,7 +912,7 @@ int launch16(const CsConvGemm& p, int M, int splits, hipStream_t stream) {
     constexpr int WCOLS = 32 * WNB;
     if (!vec || (WCOLS / 2) % 4 || p.cout % WCOLS || p.scale || p.rowvec || p.res) return CS_EINVAL;
   }
-  CS_LAUNCH((conv_gemm_f16x3_kernel<WMB, WNB, WAVES_M, WAVES_N, PRE, SLAB>), dim3((unsigned)nblk), dim3(64 * WAVES_M * WAVES_N), 0,
+  CS_LAUNCH((conv_gemm_f16x3_kernel<WMB, WNB, WAVES_M, WAVES_N, PRE, SLAB, PAIR>), dim3((unsigned)nblk), dim3(64 * WAVES_M * WAVES_N), 0,
             stream, p, M, tiles_n, p.kh * p.kw, p.kw, kg_per_tap, (long long)x_bytes, (unsigned)w_bytes, vec, splits);
   CS_CHECK_LAUNCH();
   return CS_OK;
@@ -979,6 +991,20 @@ int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p_in, int M, int tile, int spl
       case 4: return launch16<1, 7, 8, 1, true>(p, M, splits, s);
       case 6: return launch16<1, 4, 8, 1, true>(p, M, splits, s);
       case 7: return launch16<1, 2, 8, 1, true>(p, M, splits, s);
+      default: return CS_EINVAL;
+    }
+  }
+  if (p.a_format == 2) {      // interleaved operand pair: same addressing as fp32, no conversion in the K loop
+    if ((p.cin & 15) || (p.lda & 15)) return CS_EINVAL;
+    if (tile == 8) tile = 7;
+    if (tile == 9) tile = 6;
+    switch (tile) {
+      case 1: return launch16<2, 2, 2, 2, false, 0, true>(p, M, splits, s);
+      case 2: return launch16<1, 7, 4, 1, false, 0, true>(p, M, splits, s);
+      case 3: return launch16<1, 1, 2, 2, false, 0, true>(p, M, splits, s);
+      case 4: return launch16<1, 7, 8, 1, false, 0, true>(p, M, splits, s);
+      case 6: return launch16<1, 4, 8, 1, false, 0, true>(p, M, splits, s);
+      case 7: return launch16<1, 2, 8, 1, false, 0, true>(p, M, splits, s);
       default: return CS_EINVAL;
     }
   }

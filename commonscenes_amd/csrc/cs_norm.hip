@@ -284,6 +284,68 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x,
   }
 }
 
+// LayerNorm emitting the interleaved F16X3 operand pair (CsConvGemm.a_format = 2): per row and 16-channel chunk the 64
+// bytes [hi c0-7 | lo c0-7 | hi c8-15 | lo c8-15], halves of y * a_scale -- same bytes and row stride as the fp32 output
+// it replaces, so the consuming GEMM gathers the same 64-byte pieces and its K loop carries no conversion.
+template <int MAXV>
+__global__ __launch_bounds__(256) void ln_pair_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, _Float16* __restrict__ y, int m,
+                                                      int c, int ldx, int ldy, float eps, float a_scale,
+                                                      int32_t* __restrict__ status) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int ch4 = c >> 2;
+  float amax = 0.f;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < m; row += (int64_t)gridDim.x * 4) {
+    float4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const int c4 = lane + 64 * k;
+      v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c4 < ch4) v[k] = *reinterpret_cast<const float4*>(x + row * ldx + c4 * 4);
+      s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    }
+    const float mean = wave_sum(s) / (float)c;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const int c4 = lane + 64 * k;
+      if (c4 < ch4) {
+        const float a = v[k].x - mean, b = v[k].y - mean, cc = v[k].z - mean, d = v[k].w - mean;
+        q += (a * a + b * b) + (cc * cc + d * d);
+      }
+    }
+    const float var = wave_sum(q) / (float)c;
+    const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const int c4 = lane + 64 * k;
+      if (c4 < ch4) {
+        const float4 g = *reinterpret_cast<const float4*>(gamma + c4 * 4);
+        const float4 b = *reinterpret_cast<const float4*>(beta + c4 * 4);
+        // the fp32 LayerNorm's expression, then the operand scale (a power of two: exact)
+        const float o[4] = {((v[k].x - mean) * rstd * g.x + b.x) * a_scale, ((v[k].y - mean) * rstd * g.y + b.y) * a_scale,
+                            ((v[k].z - mean) * rstd * g.z + b.z) * a_scale, ((v[k].w - mean) * rstd * g.w + b.w) * a_scale};
+        h4v hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          amax = fmaxf(amax, fabsf(o[e]));
+          const _Float16 h = (_Float16)o[e];
+          hi[e] = h;
+          lo[e] = (_Float16)(o[e] - (float)h);
+        }
+        // channel 4*c4 + e sits in chunk (4*c4) / 16 at j = (4*c4) % 16: hi at halves (j < 8 ? 0 : 16) + j % 8, lo 8 further
+        const int cch = c4 >> 2, j = (c4 & 3) * 4;
+        _Float16* dst = y + row * (int64_t)ldy * 2 + cch * 32 + (j < 8 ? 0 : 16) + (j & 7);
+        *reinterpret_cast<h4v*>(dst) = hi;
+        *reinterpret_cast<h4v*>(dst + 8) = lo;
+      }
+    }
+  }
+  if (status && amax >= 65504.f) atomicOr(status, CS_STATUS_F16X3_OVERFLOW);
+}
+
 // Small tensors (one or two objects: a few MB, L2-resident): statistics and normalisation in ONE launch, one workgroup
 // per (sample, group).  The three-launch path costs ~23 us per GroupNorm there (6.8 + 4.6 + 11.5 us, each at its launch
 // floor), 61 times a step.  Threads walk the group's rows x cpg elements in a fixed stride, accumulate in fp64, and a
@@ -531,6 +593,29 @@ extern "C" int cs_layernorm(const float* x, const float* gamma, const float* bet
     CS_LAUNCH(ln_kernel<4>, dim3(grid), dim3(256), 0, s, x, gamma, beta, y, m, c, ldx, ldy, eps);
   else if (ch4 <= 64 * 8)
     CS_LAUNCH(ln_kernel<8>, dim3(grid), dim3(256), 0, s, x, gamma, beta, y, m, c, ldx, ldy, eps);
+  else
+    return CS_EINVAL;
+  CS_CHECK_LAUNCH();
+  return CS_OK;
+}
+
+// LayerNorm whose output is the interleaved F16X3 operand pair of y * a_scale (see ln_pair_kernel): y has the bytes of an
+// fp32 [m][ldy] tensor (ldy in floats, c and ldy multiples of 16).  Feeds cs_conv_gemm with a_format = 2.
+extern "C" int cs_layernorm_pair16(const float* x, const float* gamma, const float* beta, void* y, int m, int c, int ldx,
+                                   int ldy, float eps, float a_scale, int32_t* status, cs_stream_t stream) {
+  if (!x || !gamma || !beta || !y || m <= 0 || c <= 0 || !(a_scale > 0.f)) return CS_EINVAL;
+  if ((c & 15) || (ldx & 3) || (ldy & 15) || ldx < c || ldy < c) return CS_EINVAL;
+  if (((uintptr_t)x & 15) || ((uintptr_t)y & 15) || ((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15)) return CS_EINVAL;
+  const int ch4 = c >> 2;
+  const int grid = cs_grid_for(((int64_t)m + 3) / 4, 1, 256 * 32);
+  hipStream_t s = (hipStream_t)stream;
+  _Float16* yo = (_Float16*)y;
+  if (ch4 <= 64 * 2)
+    CS_LAUNCH(ln_pair_kernel<2>, dim3(grid), dim3(256), 0, s, x, gamma, beta, yo, m, c, ldx, ldy, eps, a_scale, status);
+  else if (ch4 <= 64 * 4)
+    CS_LAUNCH(ln_pair_kernel<4>, dim3(grid), dim3(256), 0, s, x, gamma, beta, yo, m, c, ldx, ldy, eps, a_scale, status);
+  else if (ch4 <= 64 * 8)
+    CS_LAUNCH(ln_pair_kernel<8>, dim3(grid), dim3(256), 0, s, x, gamma, beta, yo, m, c, ldx, ldy, eps, a_scale, status);
   else
     return CS_EINVAL;
   CS_CHECK_LAUNCH();

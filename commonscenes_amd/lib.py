@@ -17,7 +17,7 @@ import torch  # noqa: F401
 
 from .build import LIB_PATH
 
-ABI_VERSION = 11     # cs_abi_version() of the library this module's SIGNATURES table describes
+ABI_VERSION = 12     # cs_abi_version() of the library this module's SIGNATURES table describes
 CS_OK = 0
 CS_EINVAL = -22
 CS_ENOMEM = -12
@@ -94,6 +94,7 @@ SIGNATURES = {
     "cs_groupnorm_stats": (_i, [_f, _i, _i, _i, _i, _i, _fl, _f, _f, _s]),
     "cs_groupnorm_apply": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),
     "cs_groupnorm_apply_split16": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _fl, _f, _s]),
+    "cs_layernorm_pair16": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _fl, _fl, _f, _s]),
     "cs_groupnorm_apply_range": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _s]),
     "cs_groupnorm_apply_split16_range": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _f, _s]),
     "cs_groupnorm": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _fl, _i, _f, _f, _s]),

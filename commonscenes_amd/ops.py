@@ -264,8 +264,13 @@ def conv_gemm(x: Tensor, w: PackedWeight, *, spatial: Optional[Tuple[int, int, i
 
     `spatial=(nb,d,h,w)` lets a row matrix be interpreted as a volume without reshaping.
     """
-    xs = None
-    if isinstance(x, Split16):
+    xs = xp = None
+    if isinstance(x, Pair16):
+        if w.math != L.MATH_F16X3 or w.classes is not None:
+            raise L.CsError("a Pair16 activation needs an (unfolded) F16X3-packed weight")
+        xp, x = x, x.t
+        _chk(x, "x")
+    elif isinstance(x, Split16):
         if w.math != L.MATH_F16X3:
             raise L.CsError("a Split16 activation needs an F16X3-packed weight")
         xs, x = x, x.hi
@@ -314,7 +319,7 @@ def conv_gemm(x: Tensor, w: PackedWeight, *, spatial: Optional[Tuple[int, int, i
     folded = w.classes is not None
     # F16X3 operand scale: the producer's (a Split16 carries it; `a_scale` for fp32 activations that come from a
     # normalisation, norm_a_scale) or the default 16 for operands of unknown range
-    a_sc = float(xs.a_scale) if xs is not None else float(a_scale or A_SCALE)
+    a_sc = float(xs.a_scale) if xs is not None else float(xp.a_scale) if xp is not None else float(a_scale or A_SCALE)
     if folded and a_sc != A_SCALE:
         raise L.CsError("folded Upsample convs read raw activations: operand scale must be the default")
     if folded and (tuple(up) != tuple(w.up) or tuple(stride) != (1, 1, 1) or tile or splitk):
@@ -332,6 +337,8 @@ def conv_gemm(x: Tensor, w: PackedWeight, *, spatial: Optional[Tuple[int, int, i
         p.a_scale = a_sc
         if xs is not None:
             p.x_lo, p.a_format = xs.lo.data_ptr(), 1
+        elif xp is not None:
+            p.a_format = 2
         p.status = status_word(x.device).data_ptr()
     else:
         p.x, p.w, p.out = x.data_ptr(), w.wt.data_ptr(), out.data_ptr()
@@ -535,6 +542,31 @@ class Split16:
         return Split16(self.hi[idx], self.lo[idx], self.a_scale)
 
 
+@dataclass
+class Pair16:
+    """An activation tensor as the INTERLEAVED F16X3 operand pair (CsConvGemm.a_format = 2): `t` has the shape, dtype tag
+    (float32) and bytes of the fp32 tensor it replaces; per row and 16-channel chunk it holds [hi c0-7 | lo c0-7 |
+    hi c8-15 | lo c8-15] fp16 halves of value * a_scale.  Only a GEMM may read it."""
+    t: Tensor
+    a_scale: float = 16.0
+
+    @property
+    def shape(self):
+        return self.t.shape
+
+    def dim(self):
+        return self.t.dim()
+
+    def view(self, *shape):
+        if shape[-1] != self.t.shape[-1]:
+            raise L.CsError("Pair16.view: the channel dimension cannot be reshaped")
+        return Pair16(self.t.view(*shape), self.a_scale)
+
+
+# CS_NO_PAIR16=1: LayerNorm keeps emitting fp32 (A/B runs; bit-identical either way)
+PAIR16_PRODUCERS = not os.environ.get("CS_NO_PAIR16", "")
+
+
 # Producer-side operand split: GroupNorm writes the fp16 hi/lo pair of y * A_SCALE (same bytes as fp32 y) and the GEMM
 # DMA-loads it with a_format=1, so its K loop carries no conversion VALU.  With the per-tap gather kernels this was
 # neutral (108.0 vs 107.5 ms/step in round 1: the conversion hid under the DMA-bound loop); on the slab kernel the
@@ -622,9 +654,18 @@ def groupnorm_apply_range(x: Tensor, stats: Tensor, gamma: Tensor, beta: Tensor,
     return y
 
 
-def layernorm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5, out: Optional[Tensor] = None) -> Tensor:
+def layernorm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5, out: Optional[Tensor] = None,
+              pair_scale: Optional[float] = None):
+    """nn.LayerNorm over the last dim.  pair_scale=s: return the result as the Pair16 operand pair of y * s (for an F16X3
+    GEMM; c % 16 == 0) instead of an fp32 tensor."""
     _chk(x, "x")
     m, c, ldx = rows_ld(x, "x")
+    if pair_scale is not None and PAIR16_PRODUCERS and c % 16 == 0:
+        y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        L.check(L.load().cs_layernorm_pair16(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), m, c, ldx, c,
+                                             eps, float(pair_scale), status_word(x.device).data_ptr(), _stream()),
+                "cs_layernorm_pair16")
+        return Pair16(y, float(pair_scale))
     if out is None:
         out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
     _, _, ldy = rows_ld(out, "out")

@@ -523,8 +523,10 @@ class DiffusionUNet:
         t = p + ".transformer_blocks.0"
         xn = ops.groupnorm(x, sd[p + ".norm.weight"], sd[p + ".norm.bias"], 32, 1e-6, L.ACT_NONE)
         t0 = ops.linear(xn.view(nb, n, c), pk[p + ".proj_in"], math=self.math, a_scale=self._nas(p + ".norm", n * (c // 32)))
-        n1 = ops.layernorm(t0, sd[t + ".norm1.weight"], sd[t + ".norm1.bias"])
-        qkv = ops.linear(n1, pk[t + ".attn1.qkv"], math=self.math, a_scale=self._nas(t + ".norm1", c))
+        # LayerNorm feeding an F16X3 GEMM writes the interleaved operand pair (same bytes as fp32; no split in the K loop)
+        s1 = self._nas(t + ".norm1", c)
+        n1 = ops.layernorm(t0, sd[t + ".norm1.weight"], sd[t + ".norm1.bias"], pair_scale=s1)
+        qkv = ops.linear(n1, pk[t + ".attn1.qkv"], math=self.math, a_scale=s1)
         a = ops.attention(qkv[..., 0:c], qkv[..., c:2 * c], qkv[..., 2 * c:3 * c], heads, dh ** -0.5, math=self.attn_math if self.attn_math is not None else self.math)
         if isinstance(ctx, tuple):
             # one context token: softmax over one key == 1, attn2(x) = to_out(to_v(ctx)) for every
@@ -538,8 +540,8 @@ class DiffusionUNet:
             vv2 = ops.linear(ctx, pk[t + ".attn2.to_v"], math=self.math)
             a2 = ops.attention(q2, k2, vv2, heads, dh ** -0.5, math=self.attn_math if self.attn_math is not None else self.math)
             t1 = ops.linear(a2, pk[t + ".attn2.to_out.0"], res=t1a, math=self.math)
-        n3 = ops.layernorm(t1, sd[t + ".norm3.weight"], sd[t + ".norm3.bias"])
         s3 = self._nas(t + ".norm3", c)
+        n3 = ops.layernorm(t1, sd[t + ".norm3.weight"], sd[t + ".norm3.bias"], pair_scale=s3)
         if (t + ".ff.geglu") in pk:      # GEGLU gate fused into the projection GEMM's epilogue
             gg = ops.linear(n3, pk[t + ".ff.geglu"], act=L.ACT_GEGLU, a_scale=s3)    # the library picks a 224-column tile
         else:

@@ -106,7 +106,9 @@ typedef struct CsConvGemm {
   float acc_scale;
   float a_scale;
   /* CS_MATH_F16X3, a_format = 1: the activations are already split -- x = fp16 hi image, x_lo = fp16 lo image,
-   * both [rows][lda] halves holding value * a_scale (written by cs_groupnorm_apply_split16); cin, lda % 8 == 0. */
+   * both [rows][lda] halves holding value * a_scale (written by cs_groupnorm_apply_split16); cin, lda % 8 == 0.
+   * a_format = 2 (ABI 12): x is the INTERLEAVED pair -- same bytes and lda (in floats) as the fp32 tensor, per row and
+   * 16-channel chunk [hi c0-7 | lo c0-7 | hi c8-15 | lo c8-15] (cs_layernorm_pair16); cin, lda % 16 == 0; x_lo unused. */
   const void* x_lo;
   int32_t a_format;
   /* Split-K (CS_MATH_F16X3, 224-column tiles): splitk > 1 cuts the K loop (taps x channel chunks) into that many
@@ -218,6 +220,14 @@ int cs_groupnorm_silu_ndhwc(const float* x, const float* gamma, const float* bet
 /* LayerNorm over the last dim of [m][c] (nn.LayerNorm, attention.py:229-231). */
 int cs_layernorm(const float* x, const float* gamma, const float* beta, float* y, int m, int c,
                  int ldx, int ldy, float eps, cs_stream_t stream);
+
+/* LayerNorm whose output is the INTERLEAVED F16X3 operand pair of y * a_scale (ABI 12): y has the bytes and row stride of
+ * the fp32 [m][ldy] tensor it replaces -- per row and 16-channel chunk the 64 bytes [hi c0-7 | lo c0-7 | hi c8-15 |
+ * lo c8-15] (fp16 halves) -- and feeds cs_conv_gemm with CsConvGemm.a_format = 2 (x = y, same lda, a_scale as here):
+ * the consuming GEMM (the fused q|k|v and GEGLU projections behind attention.py:229-231,237-245) then gathers the same
+ * 64-byte pieces as from an fp32 tensor and its K loop carries no fp32 -> hi/lo conversion.  c, ldy % 16 == 0. */
+int cs_layernorm_pair16(const float* x, const float* gamma, const float* beta, void* y, int m, int c, int ldx, int ldy,
+                        float eps, float a_scale, int32_t* status, cs_stream_t stream);
 
 /*
  * Multi-head attention, flash style (no score matrix in HBM), fp32.

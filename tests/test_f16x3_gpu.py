@@ -614,3 +614,48 @@ def test_f16x3_512_row_slab_tiles_with_residual_epilogue(shape, cin, cout, tile,
     ref = R.conv_ndhwc(R.groupnorm_ndhwc(x.double(), g.double(), b.double(), 8 if cin % 32 else 32, 1e-6, "silu"),
                        wt.double(), bias.double(), res=res.double())
     assert rel_l2(o, ref) < 1e-6
+
+
+@pytest.mark.parametrize("m,c,n,tile,kind", [(300, 448, 448, 4, "res"), (300, 448, 1344, 2, ""), (130, 96, 64, 3, ""),
+                                              (257, 64, 128, 1, "res"), (520, 448, 896, 2, "geglu"), (300, 672, 224, 0, ""),
+                                              (512, 672, 672, 0, "splitk"), (300, 64, 128, 6, ""), (300, 64, 64, 7, "")])
+def test_layernorm_pair16_feeds_the_gemm_bit_identically(m, c, n, tile, kind):
+    """cs_layernorm_pair16 (ABI 12) writes LayerNorm's output as the INTERLEAVED F16X3 operand pair -- per row and
+    16-channel chunk [hi c0-7 | lo c0-7 | hi c8-15 | lo c8-15] -- and the GEMM reads it with a_format = 2: no conversion in
+    its K loop, the same 64-byte gather pieces.  Must equal fp32 LayerNorm -> in-loop split at the same operand scale bit
+    for bit (the split is the same arithmetic, done once by the producer), on every gather tile, with the residual /
+    GEGLU epilogues and under split-K; and stay fp32-grade against fp64."""
+    from commonscenes_amd import lib as L, ops
+    x = _rand(m, c, seed=101) * 2.0 + 0.5
+    g, b = _rand(c, seed=102) * 0.2 + 1.0, _rand(c, seed=103) * 0.1
+    w = _rand(2 * n if kind == "geglu" else n, c, seed=104, scale=c ** -0.5)
+    bias = _rand(w.shape[0], seed=105) * 0.1
+    res = _rand(m, n, seed=106)
+    sc = ops.norm_a_scale(float(g.abs().max()), float(b.abs().max()), c)
+    y32 = ops.layernorm(x.cuda(), g.cuda(), b.cuda())
+    yp = ops.layernorm(x.cuda(), g.cuda(), b.cuda(), pair_scale=sc)
+    assert isinstance(yp, ops.Pair16) and yp.t.shape == y32.shape and yp.a_scale == sc
+    # the pair holds hi + lo of y * scale: reassemble it on the host
+    raw = yp.t.view(torch.float16).view(m, c // 16, 4, 8).float()
+    back = torch.stack([raw[:, :, 0] + raw[:, :, 1], raw[:, :, 2] + raw[:, :, 3]], dim=2).reshape(m, c) / sc
+    assert float((back - y32).abs().max()) <= 2.0 ** -21 * float(y32.abs().max())
+    if kind == "geglu":
+        pk, kw = ops.pack_geglu_weight(w.cuda(), bias.cuda()), dict(act=L.ACT_GEGLU)
+    else:
+        pk = ops.pack_weight(w.cuda(), bias.cuda(), math=L.MATH_F16X3)
+        kw = dict(res=res.cuda()) if kind == "res" else (dict(splitk=4, tile=2) if kind == "splitk" else {})
+    if tile and kind != "splitk":
+        kw["tile"] = tile
+    o_pair = ops.linear(yp, pk, **kw)
+    o_f32 = ops.linear(y32, pk, a_scale=sc, **kw)
+    torch.cuda.synchronize()
+    assert torch.isfinite(o_pair).all() and torch.equal(o_pair, o_f32)
+    mu = x.double().mean(1, keepdim=True)
+    yr = (x.double() - mu) / torch.sqrt(x.double().var(1, unbiased=False, keepdim=True) + 1e-5) * g.double() + b.double()
+    ref = yr @ w.double().t() + bias.double()
+    if kind == "geglu":
+        a_, g_ = ref.chunk(2, dim=-1)
+        ref = a_ * torch.nn.functional.gelu(g_)
+    elif kind == "res":
+        ref = ref + res.double()
+    assert rel_l2(o_pair, ref) < 1e-6
