@@ -533,7 +533,8 @@ def main():
         # is null and the figure measured for this round's kernels is the committed profiles/r03_traffic.json
         roof["traffic"] = None
         roof["traffic_note"] = ("null: not measured in this run (PMC counters need rocprofv3 around the process; "
-                                "`bench.py --traffic` measures it, tools/pmc_traffic.sh wrote profiles/r03_traffic.json)")
+                                "`bench.py --traffic` measures it in the run that prints it: profiles/r03_traffic.json is "
+                                "that measurement for this round's kernels, 562 MB per launch)")
         if a.traffic and world == 1 and roof.get("rocprof_kernel"):
             tr = measure_traffic(roof["rocprof_kernel"], a)
             if tr:
