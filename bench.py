@@ -52,21 +52,24 @@ TILE_SHAPES = {1: ("2,2,2,2", "128x128"), 2: ("1,7,4,1", "128x224"), 3: ("1,1,2,
 
 
 def kernel_label(key):
-    tile, slab, pre = key
+    tile, slab, pre = key[:3]
     if tile == 5:
         return "pw_gemm_f16x3_kernel (persistent ping-pong 2x128x224"
     wv, shape = TILE_SHAPES.get(tile, ("?", "?"))
+    pair = len(key) > 3 and key[3]
     return (f"conv_gemm_f16x3_kernel<{wv},{'true' if pre else 'false'},{slab}> ({shape}"
-            f"{', A slab' if slab else ''}{', pre-split activations' if pre else ''}")
+            f"{', A slab' if slab else ''}{', pre-split activations' if pre else ''}"
+            f"{', interleaved operand pair' if pair else ''}")
 
 
 def rocprof_name(key):
-    """the instantiation's name as rocprofv3 prints it"""
-    tile, slab, pre = key
+    """the instantiation's name as rocprofv3 prints it: conv_gemm_f16x3_kernel<WMB, WNB, WAVES_M, WAVES_N, PRE, SLAB, PAIR>"""
+    tile, slab, pre = key[:3]
+    pair = bool(key[3]) if len(key) > 3 else False
     if tile == 5:
         return "pw_gemm_f16x3_kernel"
     wv = TILE_SHAPES.get(tile, ("?",))[0].replace(",", ", ")
-    return f"conv_gemm_f16x3_kernel<{wv}, {'true' if pre else 'false'}, {slab}>"
+    return f"conv_gemm_f16x3_kernel<{wv}, {'true' if pre else 'false'}, {slab}, {'true' if pair else 'false'}>"
 
 
 def parse():
@@ -211,13 +214,14 @@ def measure_traffic(ksub: str, a):
 def gemm_summary(prof, wall_ms, math):
     """dominant tile instantiation of a HIP-event profile: achieved TF/s, both roofline conventions."""
     by_tile = {}
+    keyf = lambda r: (r["tile"], r.get("slab", 0), bool(r.get("pre", False)), bool(r.get("pair", False)))
     for r in prof:
-        k = (r["tile"], r.get("slab", 0), bool(r.get("pre", False)))
+        k = keyf(r)
         by_tile[k] = by_tile.get(k, 0.0) + r["e0"].elapsed_time(r["e1"])
     if not by_tile:
         return None
     dom = max(by_tile, key=by_tile.get)
-    sel = [r for r in prof if (r["tile"], r.get("slab", 0), bool(r.get("pre", False))) == dom]
+    sel = [r for r in prof if keyf(r) == dom]
     ms = sum(r["e0"].elapsed_time(r["e1"]) for r in sel)
     fl = sum(r["flops"] for r in sel)
     all_ms = sum(r["e0"].elapsed_time(r["e1"]) for r in prof)

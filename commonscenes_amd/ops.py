@@ -402,7 +402,7 @@ def conv_gemm(x: Tensor, w: PackedWeight, *, spatial: Optional[Tuple[int, int, i
         prof.append(dict(e0=e0, e1=e1, flops=2.0 * mo * w.cout * w.cin * kd * kh * kw, taps=kd * kh * kw,
                          m=mo, n=w.cout, k=w.cin * kd * kh * kw, tile=tl,
                          slab=slab_width(tl, (kd, kh, kw), stride, up, wd, math, xs is not None, p.splitk),
-                         pre=xs is not None))
+                         pre=xs is not None, pair=xp is not None))
     return out
 
 

@@ -3,7 +3,7 @@
 # (FETCH_SIZE, WRITE_SIZE) with --kernel-trace only, as MI355X_MICROARCH.md prescribes; FETCH_SIZE is corrected x2
 # on gfx950 after calibrating on ln_kernel<2> (reads 65536 x 448 fp32 = 112 MiB) in the same pass.
 # usage (GPU box, repo root):  tools/pmc_traffic.sh <out.json> [kernel-substring]
-OUT=${1:-gpurun_out/traffic.json}; KSUB=${2:-"conv_gemm_f16x3_kernel<1, 7, 8, 1, false, 32>"}
+OUT=${1:-gpurun_out/traffic.json}; KSUB=${2:-"conv_gemm_f16x3_kernel<1, 7, 8, 1, true, 32,"}
 REPO=$(pwd); D=$REPO/gpurun_out/pmc_traffic; mkdir -p "$D"
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
