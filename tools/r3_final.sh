@@ -12,7 +12,7 @@ timeout 600 rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/prof_r03z -o be
 timeout 600 rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/prof_r03z2 -o bench -- python $REPO/bench.py --no-cpu-baseline --no-extras > $REPO/gpurun_out/r03_z_bench_steploop_under_rocprof.json 2> /dev/null
 cd $REPO
 DB=$(find gpurun_out/prof_r03z -name "*.db" | head -1)
-[ -n "$DB" ] && python tools/rocpd_summary.py $DB > gpurun_out/r03_z_kernel_stats.txt && python tools/rocpd_by_grid.py $DB "conv_gemm_f16x3_kernel<1, 7, 8, 1, true, 32>" > gpurun_out/r03_z_dominant_kernel_by_grid.txt
+[ -n "$DB" ] && python tools/rocpd_summary.py $DB > gpurun_out/r03_z_kernel_stats.txt && python tools/rocpd_by_grid.py $DB "conv_gemm_f16x3_kernel<1, 7, 8, 1, true, 32," > gpurun_out/r03_z_dominant_kernel_by_grid.txt
 DB=$(find gpurun_out/prof_r03z2 -name "*.db" | head -1)
 [ -n "$DB" ] && python tools/rocpd_summary.py $DB > gpurun_out/r03_z_kernel_stats_steploop.txt && head -6 gpurun_out/r03_z_kernel_stats_steploop.txt
 rm -rf gpurun_out/prof_r03z gpurun_out/prof_r03z2
