@@ -295,8 +295,12 @@ int plan_splitk(const CsConvGemm& p, int64_t M) {
   return s1 < 2 ? 1 : (int)s1;
 #endif
   if (nk < 64) return 1;
+  // r3: long K loops (>= 1024 chunks: the 4^3-level 3x3x3 convs) take one more doubling, up to 704 workgroups -- at 7
+  // objects (84 tiles) eight slices ran 268 / 491 us against 287 / 541 for four (profiles/r03_d_smallm_sweep.txt)
+  static const char* e_lim = getenv("CS_PLAN_LONGK_LIMIT");      // A/B runs: 512 = the round-2 rule
+  const int64_t limit = nk >= 1024 ? (e_lim ? atoll(e_lim) : 704) : 512;
   int64_t s = 1;
-  while (2 * s * wgs <= 512 && 2 * s <= 32 && 2 * s <= nk / 8) s *= 2;
+  while (2 * s * wgs <= limit && 2 * s <= 32 && 2 * s <= nk / 8) s *= 2;
   return (int)s;
 }
 
