@@ -22,6 +22,7 @@
 // K order: channel chunk OUTER, tap INNER (the 27 taps of one 16-channel chunk re-touch only this tile's rows
 // + halo, so they hit L1/L2 instead of re-streaming the activation tensor per tap).
 // fp16 32x32x16 operand map: lane l holds row/col l&31 and k = 8*(l>>5) .. 8*(l>>5)+7; C/D as for fp32.
+#include <cstdlib>
 #include "cs_f16x3.h"
 #include <type_traits>
 
@@ -59,7 +60,14 @@ constexpr int MAX_TAPS = 27;
 // pair-emitting GEMM epilogues.  Same bytes, row stride and 64-byte gather pieces as the fp32 tensor it replaces (the
 // separate hi / lo images of PRE halve the piece size: measured neutral on the per-tap gather path in r2), and the two
 // 16-byte pieces a lane reads are exactly its hi and lo fragments: the K loop carries no conversion VALU.
-template <int WMB, int WNB, int WAVES_M, int WAVES_N, bool PRE, int SLAB = 0, bool PAIR = false>
+//
+// TPK (r3) = taps per kd of the slab path: 9 for the 3x3x3 convs; 4 for the 3x2x2 / 2x2x2 kernels of the Upsample convs
+// folded onto the source grid (cs_conv_gemm_up2: per output parity class two source taps per doubled dim, with the window
+// starting at -pad where pad = 1 - parity), which ran on the per-tap gather path at 320-375 TF/s.  The slab then holds
+// BM + W + 1 rows starting at (kd - pd) planes - ph lines - pw voxels from the tile's first row, the (kh, kw) tap reads it
+// at shift kh * W + kw, and the weight ring has FOUR stages so that a chunk's stage is its tap index (nine taps = three
+// turns of a three-stage ring; four taps = one turn of a four-stage one): every address stays a compile-time constant.
+template <int WMB, int WNB, int WAVES_M, int WAVES_N, bool PRE, int SLAB = 0, bool PAIR = false, int TPK = 9>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_kernel(const CsConvGemm p, int M, int tiles_n,
                                                               int taps_hw, int kw_, int kg_per_tap,
                                                               long long x_bytes, unsigned w_bytes, int vec_epilogue,
@@ -71,10 +79,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   // ---- LDS map (bytes) ----
   static_assert(!SLAB || (WMB <= 2 && WAVES_N == 1), "slab path: one or two row blocks per wave");
   static_assert(!PAIR || (!PRE && SLAB == 0), "interleaved operand pairs: per-tap gather path only");
+  static_assert(TPK == 9 || (TPK == 4 && SLAB != 0), "taps per kd: 3x3 or (slab path only) 2x2");
+  constexpr int KW_ = TPK == 9 ? 3 : 2;            // (kh, kw) extent of a slab super-chunk
   // wave-instructions per slab (SLAB = widest line W): fp32 rows of 64 B, 16 per instruction; PRE: a hi and a lo image
   // of 32 B rows, 32 per instruction each
-  constexpr int SLAB_IMG_WI = (BM + 2 * SLAB + 2 + 31) / 32;
-  constexpr int SLAB_WI = PRE ? 2 * SLAB_IMG_WI : (BM + 2 * SLAB + 2 + 15) / 16;
+  constexpr int SLAB_ROWS = BM + (KW_ - 1) * (SLAB + 1);      // 3x3 taps: BM + 2W + 2 rows; 2x2 taps: BM + W + 1
+  constexpr int SLAB_IMG_WI = (SLAB_ROWS + 31) / 32;
+  constexpr int SLAB_WI = PRE ? 2 * SLAB_IMG_WI : (SLAB_ROWS + 15) / 16;
   constexpr int SLAB_IMG = SLAB_IMG_WI * 1024;     // PRE: byte offset of the lo image inside a slab
   constexpr int SLAB_BYTES = SLAB ? SLAB_WI * 1024 : 0;
   constexpr int RING0 = 2 * SLAB_BYTES;            // two slabs, then the ring
@@ -87,7 +98,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
 #ifdef CS_RING3      // A/B timing builds (tools/ring_ab.sh): the round-1 depth everywhere
   constexpr int NSTAGE = 3;
 #else
-  constexpr int NSTAGE = (BM == 64 && BN == 64) ? 6 : 3;
+  constexpr int NSTAGE = (BM == 64 && BN == 64) ? 6 : (TPK == 4 ? 4 : 3);
 #endif
   constexpr int PF = NSTAGE - 1;
   constexpr int DUMP = RING0 + NSTAGE * STAGE;     // 1 KB: where surplus DMA wave-instructions land
@@ -204,7 +215,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   // rows), with 32-bit offsets inside a window of a few MB.  The tensor itself may therefore be larger than
   // the 4 GiB a single descriptor spans (288 GB of HBM: 200+ objects per batch at the 16^3 x 672-channel level).
   // (slab: the lowest row any of the three kd slabs can start at)
-  const int row_lo = SLAB ? max(0, m0 - p.hin * p.win - p.win - 1) : __builtin_amdgcn_readfirstlane(*rowmin);
+  const int row_lo = SLAB ? max(0, m0 - p.pd * p.hin * p.win - p.ph * p.win - p.pw)
+                          : __builtin_amdgcn_readfirstlane(*rowmin);
   const long long x_skip = (long long)row_lo * p.lda * (PRE ? 2 : 4);
   const long long x_left = x_bytes - x_skip;
   const unsigned x_win = x_left > 0xFFE00000LL ? 0xFFE00000u : (unsigned)x_left;
@@ -217,7 +229,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   const int chunks_per_tap = kg_per_tap >> 1;   // cin16 / 16
   const int nk_all = ntaps * chunks_per_tap;
   // this workgroup's slice of the chunk sequence (slab path: whole super-chunks of nine taps)
-  constexpr int KGRAN = SLAB ? 9 : 1;
+  constexpr int KGRAN = SLAB ? TPK : 1;
   const int per_split = ((nk_all / KGRAN + splits - 1) / splits) * KGRAN;
   const int k_first = split * per_split;
 #if CS_ABLATE & 2048
@@ -375,19 +387,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
                                                           // them, surplus ones as zero-fills: the counts below are exact)
   const int s_w = p.win, s_hw = p.hin * p.win;
   const int s_rows = p.nb * p.din * s_hw;                  // source rows in the tensor
-  const int s_need = BM + 2 * s_w + 2;                     // slab rows this problem uses
+  const int s_need = BM + (KW_ - 1) * (s_w + 1);           // slab rows this problem uses
   // (per row block i of the wave -- one for the 256-row tiles, two for the 512-row ones)
   unsigned vmask[WMB];                                     // bit tap: that tap of this lane's output voxel is inside the volume
   int sl_row[SLAB_PW];
   unsigned sl_piece[SLAB_PW];
-  int sl_a0[WMB][9];                                       // fragment byte offset inside the slab, per (kh, kw)
+  int sl_a0[WMB][TPK];                                     // fragment byte offset inside the slab, per (kh, kw)
   if constexpr (SLAB != 0) {
 #pragma unroll
     for (int i = 0; i < WMB; ++i) {
       const int rowl = wm0 + 32 * i + l31;                 // the lane's fragment row inside the tile
 #pragma unroll
-      for (int t9 = 0; t9 < 9; ++t9) {
-        const int prow = rowl + (t9 / 3) * s_w + t9 % 3;
+      for (int t9 = 0; t9 < TPK; ++t9) {
+        const int prow = rowl + (t9 / KW_) * s_w + t9 % KW_;
         if constexpr (PRE)
           sl_a0[i][t9] = prow * 32 + (((half ^ (prow >> 3)) & 1) << 4);      // same swizzle as the ring's fp16 images
         else
@@ -403,10 +415,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
         mm /= p.hin;
         const int od = mm % p.din;
 #pragma unroll
-        for (int t = 0; t < 27; ++t) {
-          const int kd_ = t / 9, kh_ = (t / 3) % 3, kwi = t % 3;
-          if ((unsigned)(od + kd_ - 1) < (unsigned)p.din && (unsigned)(oh + kh_ - 1) < (unsigned)p.hin &&
-              (unsigned)(ow + kwi - 1) < (unsigned)p.win)
+        for (int t = 0; t < 3 * TPK; ++t) {               // (kd >= p.kd: never used)
+          const int kd_ = t / TPK, kh_ = (t / KW_) % KW_, kwi = t % KW_;
+          if ((unsigned)(od + kd_ - p.pd) < (unsigned)p.din && (unsigned)(oh + kh_ - p.ph) < (unsigned)p.hin &&
+              (unsigned)(ow + kwi - p.pw) < (unsigned)p.win)
             vmask[i] |= 1u << t;
         }
       }
@@ -429,9 +441,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
     }
   }
   // slab of super-chunk sc (= channel chunk sc / 3, kd = sc % 3): source rows m0 + (kd-1)*H*W - W - 1 ... in order
+  const int KD = p.kd;                                     // 3, or 2 for a folded depth dimension
   auto issue_slab = [&](int sc) {
-    const int cc = sc / 3, kd_ = sc - 3 * cc;
-    const int src0 = m0 + (kd_ - 1) * s_hw - s_w - 1;
+    const int cc = sc / KD, kd_ = sc - KD * cc;
+    const int src0 = m0 + (kd_ - p.pd) * s_hw - p.ph * s_w - p.pw;
     unsigned char* dst = smem + (sc & 1) * SLAB_BYTES;
 #pragma unroll
     for (int i = 0; i < SLAB_PW; ++i) {
@@ -479,13 +492,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   h8 ah[WMB], al[WMB];
   if constexpr (SLAB != 0) {
     // the prologue above issued B(0), B(1); the first slab goes out now and is the youngest: wait for everything
-    const int sc0 = k_first / 9;
+    const int sc0 = k_first / TPK;
     issue_slab(sc0);
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int i = 0; i < WMB; ++i)
-      load_a_slab(std::integral_constant<int, 0>{}, i, sc0 & 1, (vmask[i] >> (9 * (sc0 % 3))) & 0x1FFu, ah[i], al[i]);
+      load_a_slab(std::integral_constant<int, 0>{}, i, sc0 & 1, (vmask[i] >> (TPK * (sc0 % KD))) & ((1u << TPK) - 1u), ah[i],
+                  al[i]);
   } else {
   wait_vmcnt<(PF - 1) * D>();          // chunk 0 (issued first) has landed for this wave
   __builtin_amdgcn_s_barrier();
@@ -540,7 +554,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
     constexpr int stage = decltype(stage_c)::value;
     constexpr int t9 = decltype(t9_c)::value;
     constexpr int dstage = (stage + PF) % NSTAGE;
-    if (!(CS_ABLATE & 4)) wait_vmcnt<(t9 == 1 ? SLAB_PW : 0) + B_PW>();
+    // top of iteration k: B(k) -- issued PF iterations ago -- must have landed; what the PF - 1 iterations in between
+    // issued (their weight chunks, and the slab if one of them was a tap-0 iteration) may still fly
+    if (!(CS_ABLATE & 4)) wait_vmcnt<((t9 >= 1 && t9 <= PF - 1) ? SLAB_PW : 0) + (PF - 1) * B_PW>();
     if (!(CS_ABLATE & 8)) __builtin_amdgcn_s_barrier();
     const unsigned char* s = smem + RING0 + stage * STAGE;
     h8 ah2[WMB], al2[WMB];
@@ -560,7 +576,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
         advance();
 #pragma unroll
         for (int i = 0; i < WMB; ++i) {
-          if constexpr (t9 == 8)
+          if constexpr (t9 == TPK - 1)
             load_a_slab(std::integral_constant<int, 0>{}, i, (sc + 1) & 1, m9_next[i], ah2[i], al2[i]);
           else
             load_a_slab(std::integral_constant<int, t9 + 1>{}, i, sc & 1, m9_this[i], ah2[i], al2[i]);
@@ -574,26 +590,34 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
     }
   };
   if constexpr (SLAB != 0) {
-    static_assert(NSTAGE == 3 && PF == 2, "nine taps = three turns of the ring");
-    const int sc_first = k_first / 9, sc_end = sc_first + nk / 9;
-    int kdc = sc_first % 3;                                 // kd of the super-chunk
+    static_assert((TPK == 9 && NSTAGE == 3) || (TPK == 4 && NSTAGE == 4), "a chunk's ring stage is its tap index mod NSTAGE");
+    const int sc_first = k_first / TPK, sc_end = sc_first + nk / TPK;
+    int kdc = sc_first % KD;                                // kd of the super-chunk
+    constexpr unsigned TMASK = (1u << TPK) - 1u;
     for (int sc = sc_first; sc < sc_end; ++sc) {
-      const int kdn = kdc == 2 ? 0 : kdc + 1;
+      const int kdn = kdc == KD - 1 ? 0 : kdc + 1;
       unsigned m9[WMB], m9n[WMB];
 #pragma unroll
       for (int i = 0; i < WMB; ++i) {
-        m9[i] = (vmask[i] >> (9 * kdc)) & 0x1FFu;
-        m9n[i] = (vmask[i] >> (9 * kdn)) & 0x1FFu;
+        m9[i] = (vmask[i] >> (TPK * kdc)) & TMASK;
+        m9n[i] = (vmask[i] >> (TPK * kdn)) & TMASK;
       }
-      sstep(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, sc, m9, m9n);
-      sstep(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, sc, m9, m9n);
-      sstep(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, sc, m9, m9n);
-      sstep(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, sc, m9, m9n);
-      sstep(std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{}, sc, m9, m9n);
-      sstep(std::integral_constant<int, 2>{}, std::integral_constant<int, 5>{}, sc, m9, m9n);
-      sstep(std::integral_constant<int, 0>{}, std::integral_constant<int, 6>{}, sc, m9, m9n);
-      sstep(std::integral_constant<int, 1>{}, std::integral_constant<int, 7>{}, sc, m9, m9n);
-      sstep(std::integral_constant<int, 2>{}, std::integral_constant<int, 8>{}, sc, m9, m9n);
+      if constexpr (TPK == 9) {
+        sstep(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, sc, m9, m9n);
+        sstep(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, sc, m9, m9n);
+        sstep(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, sc, m9, m9n);
+        sstep(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, sc, m9, m9n);
+        sstep(std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{}, sc, m9, m9n);
+        sstep(std::integral_constant<int, 2>{}, std::integral_constant<int, 5>{}, sc, m9, m9n);
+        sstep(std::integral_constant<int, 0>{}, std::integral_constant<int, 6>{}, sc, m9, m9n);
+        sstep(std::integral_constant<int, 1>{}, std::integral_constant<int, 7>{}, sc, m9, m9n);
+        sstep(std::integral_constant<int, 2>{}, std::integral_constant<int, 8>{}, sc, m9, m9n);
+      } else {
+        sstep(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, sc, m9, m9n);
+        sstep(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, sc, m9, m9n);
+        sstep(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, sc, m9, m9n);
+        sstep(std::integral_constant<int, 3>{}, std::integral_constant<int, 3>{}, sc, m9, m9n);
+      }
       kdc = kdn;
     }
   } else
@@ -888,7 +912,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   }
 }
 
-template <int WMB, int WNB, int WAVES_M, int WAVES_N, bool PRE, int SLAB = 0, bool PAIR = false>
+template <int WMB, int WNB, int WAVES_M, int WAVES_N, bool PRE, int SLAB = 0, bool PAIR = false, int TPK = 9>
 int launch16(const CsConvGemm& p, int M, int splits, hipStream_t stream) {
   constexpr int BM = 32 * WMB * WAVES_M;
   constexpr int BN = 32 * WNB * WAVES_N;
@@ -912,7 +936,7 @@ int launch16(const CsConvGemm& p, int M, int splits, hipStream_t stream) {
     constexpr int WCOLS = 32 * WNB;
     if (!vec || (WCOLS / 2) % 4 || p.cout % WCOLS || p.scale || p.rowvec || p.res) return CS_EINVAL;
   }
-  CS_LAUNCH((conv_gemm_f16x3_kernel<WMB, WNB, WAVES_M, WAVES_N, PRE, SLAB, PAIR>), dim3((unsigned)nblk), dim3(64 * WAVES_M * WAVES_N), 0,
+  CS_LAUNCH((conv_gemm_f16x3_kernel<WMB, WNB, WAVES_M, WAVES_N, PRE, SLAB, PAIR, TPK>), dim3((unsigned)nblk), dim3(64 * WAVES_M * WAVES_N), 0,
             stream, p, M, tiles_n, p.kh * p.kw, p.kw, kg_per_tap, (long long)x_bytes, (unsigned)w_bytes, vec, splits);
   CS_CHECK_LAUNCH();
   return CS_OK;
@@ -1009,6 +1033,20 @@ int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p_in, int M, int tile, int spl
     }
   }
   if (p.a_format != 0) return CS_EINVAL;
+#ifndef CS_NO_SLAB
+  {
+    // r3: the 3x2x2 / 2x2x2 kernels of the Upsample convs folded onto the source grid (cs_conv_gemm_up2): slab path with
+    // four taps per kd.  CS_NO_SLAB4=1 keeps them on the per-tap gather (A/B runs, and the reference of the equality test).
+    static const char* e4 = getenv("CS_NO_SLAB4");
+    const bool slab4 = !(e4 && *e4 == '1') && splits == 1 && p.kh == 2 && p.kw == 2 && (p.kd == 2 || p.kd == 3) &&
+                       p.sd == 1 && p.sh == 1 && p.sw == 1 && p.ud == 0 && p.uh == 0 && p.uw == 0 &&
+                       (unsigned)p.pd <= 1u && (unsigned)p.ph <= 1u && (unsigned)p.pw <= 1u && (p.kd == 2 || p.pd == 1) &&
+                       p.din == p.dout && p.hin == p.hout && p.win == p.wout && p.win <= 32 &&
+                       (256 + 2LL * p.hin * p.win + 2 * p.win + 32) * p.lda * 4 < 0x7FF00000LL;
+    if (slab4 && tile == 4) return launch16<1, 7, 8, 1, false, 32, false, 4>(p, M, splits, s);
+    if (slab4 && tile == 6) return launch16<1, 4, 8, 1, false, 32, false, 4>(p, M, splits, s);
+  }
+#endif
 #ifndef CS_NO_SLAB      // (A/B timing builds: -DCS_NO_SLAB keeps the per-tap gather everywhere)
   // 3x3x3, stride 1, "same" padding, no upsampling, one K slice, 256-row tiles: the A operand comes from a slab
   // shared by the nine (kh, kw) taps of each kd (see the kernel's header)
