@@ -67,7 +67,11 @@ constexpr int MAX_TAPS = 27;
 // BM + W + 1 rows starting at (kd - pd) planes - ph lines - pw voxels from the tile's first row, the (kh, kw) tap reads it
 // at shift kh * W + kw, and the weight ring has FOUR stages so that a chunk's stage is its tap index (nine taps = three
 // turns of a three-stage ring; four taps = one turn of a four-stage one): every address stays a compile-time constant.
-template <int WMB, int WNB, int WAVES_M, int WAVES_N, bool PRE, int SLAB = 0, bool PAIR = false, int TPK = 9>
+//
+// PW (r3) = pointwise: 1x1x1, stride 1, no upsampling -- every token / Linear GEMM and skip convolution.  Output row m reads
+// source row m, so the per-workgroup source-row tables (three integer divisions per row, an atomicMin, two barriers in the
+// prologue) and the per-DMA-instruction table look-up in the K loop are replaced by one validity bit per lane.
+template <int WMB, int WNB, int WAVES_M, int WAVES_N, bool PRE, int SLAB = 0, bool PAIR = false, int TPK = 9, bool PW = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_kernel(const CsConvGemm p, int M, int tiles_n,
                                                               int taps_hw, int kw_, int kg_per_tap,
                                                               long long x_bytes, unsigned w_bytes, int vec_epilogue,
@@ -80,6 +84,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   static_assert(!SLAB || (WMB <= 2 && WAVES_N == 1), "slab path: one or two row blocks per wave");
   static_assert(!PAIR || (!PRE && SLAB == 0), "interleaved operand pairs: per-tap gather path only");
   static_assert(TPK == 9 || (TPK == 4 && SLAB != 0), "taps per kd: 3x3 or (slab path only) 2x2");
+  static_assert(!PW || SLAB == 0, "pointwise GEMMs take the gather path (there is one tap)");
   constexpr int KW_ = TPK == 9 ? 3 : 2;            // (kh, kw) extent of a slab super-chunk
   // wave-instructions per slab (SLAB = widest line W): fp32 rows of 64 B, 16 per instruction; PRE: a hi and a lo image
   // of 32 B rows, 32 per instruction each
@@ -163,7 +168,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   int* rowbase = reinterpret_cast<int*>(smem + ROWBASE);
   int* rowmin = reinterpret_cast<int*>(smem + ROWMIN);
   short* delta = reinterpret_cast<short*>(smem + DELTA);
-  if constexpr (!SLAB) {
+  if constexpr (!SLAB && !PW) {
   if (tid == 0) *rowmin = 0x7fffffff;
   __syncthreads();
   {
@@ -216,7 +221,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   // the 4 GiB a single descriptor spans (288 GB of HBM: 200+ objects per batch at the 16^3 x 672-channel level).
   // (slab: the lowest row any of the three kd slabs can start at)
   const int row_lo = SLAB ? max(0, m0 - p.pd * p.hin * p.win - p.ph * p.win - p.pw)
-                          : __builtin_amdgcn_readfirstlane(*rowmin);
+                     : PW ? m0 : __builtin_amdgcn_readfirstlane(*rowmin);
   const long long x_skip = (long long)row_lo * p.lda * (PRE ? 2 : 4);
   const long long x_left = x_bytes - x_skip;
   const unsigned x_win = x_left > 0xFFE00000LL ? 0xFFE00000u : (unsigned)x_left;
@@ -252,12 +257,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
       const int within = w % (A_WI / 2);
       const int row = 32 * within + (lane >> 1);
       a_rowidx[i] = row;
-      a_rowbase[i] = rowbase[row] - row_lo;
+      if constexpr (PW) a_rowbase[i] = (m0 + row < M) ? row : -1;       // pointwise: source row = output row; -1 = past M
+      else a_rowbase[i] = rowbase[row] - row_lo;
       a_piece[i] = (unsigned)(((lane & 1) ^ ((row >> 3) & 1)) * 8);
     } else {
       const int row = 16 * w + (lane >> 2);
       a_rowidx[i] = row;
-      a_rowbase[i] = rowbase[row] - row_lo;
+      if constexpr (PW) a_rowbase[i] = (m0 + row < M) ? row : -1;
+      else a_rowbase[i] = rowbase[row] - row_lo;
       a_piece[i] = (unsigned)(((lane & 3) ^ ((row >> 2) & 3)) * 4);   // first channel of the piece
     }
   }
@@ -279,12 +286,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
 #pragma unroll
     for (int i = 0; i < A_PW; ++i) {
       if (skip_a) break;
-      const short dl = delta[tap * BM + a_rowidx[i]];
       const int c = cc * BKH + (int)a_piece[i];
       constexpr unsigned ESZ = PRE ? 2u : 4u;
-      unsigned off = (dl != INVALID && c < p.cin)
-                         ? (unsigned)(a_rowbase[i] + (int)dl) * ((unsigned)p.lda * ESZ) + (unsigned)c * ESZ
-                         : OOB;
+      unsigned off;
+      if constexpr (PW) {
+        off = (a_rowbase[i] >= 0 && c < p.cin) ? (unsigned)a_rowbase[i] * ((unsigned)p.lda * ESZ) + (unsigned)c * ESZ : OOB;
+      } else {
+        const short dl = delta[tap * BM + a_rowidx[i]];
+        off = (dl != INVALID && c < p.cin)
+                  ? (unsigned)(a_rowbase[i] + (int)dl) * ((unsigned)p.lda * ESZ) + (unsigned)c * ESZ
+                  : OOB;
+      }
       if (CS_ABLATE & 2) off = OOB;
       if ((CS_ABLATE & 64) && off != OOB) off &= 0x3FF0u;      // every fetch from one 16 KB window (cache hits)
       const int w = wave * A_PW + i;                      // wave-uniform
@@ -912,7 +924,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   }
 }
 
-template <int WMB, int WNB, int WAVES_M, int WAVES_N, bool PRE, int SLAB = 0, bool PAIR = false, int TPK = 9>
+template <int WMB, int WNB, int WAVES_M, int WAVES_N, bool PRE, int SLAB = 0, bool PAIR = false, int TPK = 9, bool PW = false>
 int launch16(const CsConvGemm& p, int M, int splits, hipStream_t stream) {
   constexpr int BM = 32 * WMB * WAVES_M;
   constexpr int BN = 32 * WNB * WAVES_N;
@@ -936,7 +948,7 @@ int launch16(const CsConvGemm& p, int M, int splits, hipStream_t stream) {
     constexpr int WCOLS = 32 * WNB;
     if (!vec || (WCOLS / 2) % 4 || p.cout % WCOLS || p.scale || p.rowvec || p.res) return CS_EINVAL;
   }
-  CS_LAUNCH((conv_gemm_f16x3_kernel<WMB, WNB, WAVES_M, WAVES_N, PRE, SLAB, PAIR, TPK>), dim3((unsigned)nblk), dim3(64 * WAVES_M * WAVES_N), 0,
+  CS_LAUNCH((conv_gemm_f16x3_kernel<WMB, WNB, WAVES_M, WAVES_N, PRE, SLAB, PAIR, TPK, PW>), dim3((unsigned)nblk), dim3(64 * WAVES_M * WAVES_N), 0,
             stream, p, M, tiles_n, p.kh * p.kw, p.kw, kg_per_tap, (long long)x_bytes, (unsigned)w_bytes, vec, splits);
   CS_CHECK_LAUNCH();
   return CS_OK;
@@ -1018,10 +1030,25 @@ int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p_in, int M, int tile, int spl
       default: return CS_EINVAL;
     }
   }
+  // pointwise (1x1x1, stride 1, no upsampling): no source-row tables (template argument PW); CS_NO_PW=1 for A/B runs
+  static const char* e_pw = getenv("CS_NO_PW");
+  const bool pw = !(e_pw && *e_pw == '1') && p.kd == 1 && p.kh == 1 && p.kw == 1 && p.sd == 1 && p.sh == 1 && p.sw == 1 &&
+                  p.ud == 0 && p.uh == 0 && p.uw == 0 && p.pd == 0 && p.ph == 0 && p.pw == 0 &&
+                  (int64_t)p.dout * p.hout * p.wout == (int64_t)p.din * p.hin * p.win &&
+                  256LL * p.lda * 4 < 0x7FF00000LL;
   if (p.a_format == 2) {      // interleaved operand pair: same addressing as fp32, no conversion in the K loop
     if ((p.cin & 15) || (p.lda & 15)) return CS_EINVAL;
     if (tile == 8) tile = 7;
     if (tile == 9) tile = 6;
+    if (pw) {
+      switch (tile) {
+        case 1: return launch16<2, 2, 2, 2, false, 0, true, 9, true>(p, M, splits, s);
+        case 2: return launch16<1, 7, 4, 1, false, 0, true, 9, true>(p, M, splits, s);
+        case 3: return launch16<1, 1, 2, 2, false, 0, true, 9, true>(p, M, splits, s);
+        case 4: return launch16<1, 7, 8, 1, false, 0, true, 9, true>(p, M, splits, s);
+        default: break;
+      }
+    }
     switch (tile) {
       case 1: return launch16<2, 2, 2, 2, false, 0, true>(p, M, splits, s);
       case 2: return launch16<1, 7, 4, 1, false, 0, true>(p, M, splits, s);
@@ -1062,6 +1089,17 @@ int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p_in, int M, int tile, int spl
     }
   }
 #endif
+  if (pw) {
+    switch (tile) {
+      case 1: return launch16<2, 2, 2, 2, false, 0, false, 9, true>(p, M, splits, s);
+      case 2: return launch16<1, 7, 4, 1, false, 0, false, 9, true>(p, M, splits, s);
+      case 3: return launch16<1, 1, 2, 2, false, 0, false, 9, true>(p, M, splits, s);
+      case 4: return launch16<1, 7, 8, 1, false, 0, false, 9, true>(p, M, splits, s);
+      case 6: return launch16<1, 4, 8, 1, false, 0, false, 9, true>(p, M, splits, s);
+      case 7: return launch16<1, 2, 8, 1, false, 0, false, 9, true>(p, M, splits, s);
+      default: break;
+    }
+  }
   switch (tile) {
     case 1: return launch16<2, 2, 2, 2, false>(p, M, splits, s);
     case 2: return launch16<1, 7, 4, 1, false>(p, M, splits, s);
