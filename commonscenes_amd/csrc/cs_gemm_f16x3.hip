@@ -103,7 +103,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
 #ifdef CS_RING3      // A/B timing builds (tools/ring_ab.sh): the round-1 depth everywhere
   constexpr int NSTAGE = 3;
 #else
+  // (r3: the pointwise 256x224 tile -- one workgroup per CU either way -- runs a four-stage ring, three chunks of DMA in
+  // flight: 448->448 117.4 -> 114.4 us, 1792->448 317.5 -> 309.2, 81.41 -> 81.14 ms/step same box; -DCS_PW_RING3 for A/B)
+#ifdef CS_PW_RING3
   constexpr int NSTAGE = (BM == 64 && BN == 64) ? 6 : (TPK == 4 ? 4 : 3);
+#else
+  constexpr int NSTAGE = (BM == 64 && BN == 64) ? 6 : ((TPK == 4 || (PW && BM == 256 && BN == 224)) ? 4 : 3);
+#endif
 #endif
   constexpr int PF = NSTAGE - 1;
   constexpr int DUMP = RING0 + NSTAGE * STAGE;     // 1 KB: where surplus DMA wave-instructions land
@@ -637,6 +643,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
     step(std::integral_constant<int, 0>{});
     if (kc + 1 < nk) step(std::integral_constant<int, 1>{});
     if (kc + 2 < nk) step(std::integral_constant<int, 2>{});
+    if constexpr (NSTAGE == 4) {
+      if (kc + 3 < nk) step(std::integral_constant<int, 3>{});
+    }
     if constexpr (NSTAGE == 6) {
       if (kc + 3 < nk) step(std::integral_constant<int, 3>{});
       if (kc + 4 < nk) step(std::integral_constant<int, 4>{});
