@@ -63,13 +63,14 @@ def kernel_label(key):
 
 
 def rocprof_name(key):
-    """the instantiation's name as rocprofv3 prints it: conv_gemm_f16x3_kernel<WMB, WNB, WAVES_M, WAVES_N, PRE, SLAB, PAIR>"""
+    """prefix of the instantiation's name as rocprofv3 prints it: conv_gemm_f16x3_kernel<WMB, WNB, WAVES_M, WAVES_N, PRE,
+    SLAB, PAIR, ...> -- further template arguments (taps per kd, pointwise) follow; the prefix identifies the launches"""
     tile, slab, pre = key[:3]
     pair = bool(key[3]) if len(key) > 3 else False
     if tile == 5:
         return "pw_gemm_f16x3_kernel"
     wv = TILE_SHAPES.get(tile, ("?",))[0].replace(",", ", ")
-    return f"conv_gemm_f16x3_kernel<{wv}, {'true' if pre else 'false'}, {slab}, {'true' if pair else 'false'}>"
+    return f"conv_gemm_f16x3_kernel<{wv}, {'true' if pre else 'false'}, {slab}, {'true' if pair else 'false'},"
 
 
 def parse():
