@@ -40,6 +40,10 @@ struct Gemm {        // one packed GEMM weight (possibly several reference tenso
   // halves of a channel-split conv (cs_unet.hip: res_block_split); the operand scale is the WHOLE tensor's either way
   int c0 = 0, src_cin = 0;
   bool unused = false;   // registered (its parameters are part of the state_dict) but never launched: not packed
+  // > 0: a thin-output 3x3x3 conv (tap_cout <= 4 output channels) run as "taps as columns": the packed weight is the
+  // POINTWISE one with cout = 27 * tap_cout (+ pad) columns (cs_pack_weight_f16x3_tapcol; k = 1 here), and cs_tapsum27
+  // adds the 27 shifted columns of every output channel and the bias (ops.py::pack_weight_tapcol)
+  int tap_cout = 0;
   int64_t w_off = 0, wlo_off = 0, b_off = -1;
   float acc_scale = 1.f;
   // Upsample's conv folded onto the source grid (cs_conv_gemm_up2): bit 2 / 1 / 0 = D / H / W doubled.  The packed
@@ -150,6 +154,15 @@ int add_layer_gemm(Plan& u, const std::string& p, int o, int i, int k, bool bias
   add_wb(u, p, o, i, k, bias, wp, bp);
   std::vector<Piece> b;
   if (bp >= 0) b.push_back({bp, 0, o});
+  {
+    // ops.py::tapcol_ok -- the same rule on both hosts (CS_NO_TAPCOL=1: A/B runs)
+    const char* e = getenv("CS_NO_TAPCOL");
+    if (k == 3 && !up_mask && o <= 4 && (i & 3) == 0 && cin_pad == 0 && u.math == CS_MATH_F16X3 && !(e && *e)) {
+      const int gi = add_gemm(u, {{wp, 0, o}}, b, (27 * o + 3) / 4 * 4, i, 1);
+      u.gemms[gi].tap_cout = o;
+      return gi;
+    }
+  }
   const int gi = add_gemm(u, {{wp, 0, o}}, b, o, i, k, cin_pad);
   if (up_mask && k == 3) {      // the conv of an Upsample: folded per output parity class (cs_fold_upsample_weight)
     Gemm& g = u.gemms[gi];
@@ -415,6 +428,19 @@ int pack_plan(Plan* u, const void* raw_dev, void* arena_dev, cs_stream_t stream)
       if (rc != CS_OK) return rc;
       continue;
     }
+    if (g.tap_cout) {     // taps as columns: the whole (tap_cout, cin, 3, 3, 3) tensor -> one pointwise image pair
+      if (!f16 || g.w.size() != 1 || g.w[0].param < 0 || g.w[0].row0 != 0 || g.w[0].rows != g.tap_cout) return CS_EINVAL;
+      const float m = amax[(size_t)g.w[0].param];
+      int ex = 0;
+      if (m > 0.f && std::isfinite(m)) (void)std::frexp((double)m, &ex);
+      const float scale = (float)std::ldexp(1.0, 14 - ex);
+      g.acc_scale = 1.0f / (scale * 16.0f);
+      int rc = cs_pack_weight_f16x3_tapcol(src(g.w[0].param), arena + g.w_off, arena + g.wlo_off, g.tap_cout, g.cin,
+                                           g.cout, scale, stream);
+      if (rc == CS_OK && !g.b.empty()) rc = copy_bias(g);
+      if (rc != CS_OK) return rc;
+      continue;
+    }
     const int cols = (g.src_cin ? g.src_cin : g.cin) * g.taps;    // row length of the reference tensor seen as [cout][cin * taps]
     float scale = 1.f;
     if (f16) {
@@ -568,6 +594,15 @@ struct ExecBase {
            const float* rowvec = nullptr, int ldrv = 0, int rv_rows = 1, const float* res = nullptr, int ldr = 0,
            int tile = 0, int s_d = 1, int up_d = 0) {
     const Gemm& g = pl.gemms[gi];
+    const bool tc = g.tap_cout > 0;      // taps as columns: the pointwise GEMM below, then cs_tapsum27
+    if (tc) {
+      if (s_hw != 1 || s_d != 1 || up_hw || up_d || act != CS_ACT_NONE || rowvec || res || tile || x.half) {
+        chk(CS_EINVAL);
+        return Buf();
+      }
+      const int64_t t256 = ((int64_t)nb * d * h * w + 255) / 256;
+      tile = t256 < 192 ? 0 : (g.cout <= 64 ? 7 : 6);      // ops.py::tapcol_tile
+    }
     const int k = g.k, pad = k / 2;
     const int vh = h << up_hw, vw = w << up_hw;
     const int dout = ((d << up_d) + 2 * pad - k) / s_d + 1;
@@ -598,7 +633,7 @@ struct ExecBase {
         q.acc_scale = g.acc_scale * (16.0f / x.a_scale);      // g.acc_scale = 1 / (weight scale * 16); powers of two
         q.a_scale = x.a_scale;
       }
-      q.bias = g.b_off >= 0 ? wf(g.b_off) : nullptr;
+      q.bias = (g.b_off >= 0 && !tc) ? wf(g.b_off) : nullptr;
       q.rowvec = rowvec;
       q.res = res;
       q.status = status;
@@ -650,6 +685,13 @@ struct ExecBase {
     }
     if (!dry) chk(cs_conv_gemm(&q, st));
     release(skws);      // stream-ordered: later kernels that reuse the region run after the reduce
+    if (tc) {
+      Buf o2 = alloc(mo, g.tap_cout);
+      if (ok() && !dry)
+        chk(cs_tapsum27(p(out), g.b_off >= 0 ? wf(g.b_off) : nullptr, p(o2), nb, d, h, w, g.tap_cout, g.cout, g.tap_cout, st));
+      release(out);
+      return o2;
+    }
     return out;
   }
   // stride-1 conv / pointwise GEMM on explicit operand views: x (+ x_lo for the pre-split pair) with row stride lda,

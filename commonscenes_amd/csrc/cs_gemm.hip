@@ -639,4 +639,4 @@ extern "C" int cs_relayout_weight(const float* w_torch, float* w_out, int cout, 
   return CS_OK;
 }
 
-extern "C" int cs_abi_version(void) { return 12; }
+extern "C" int cs_abi_version(void) { return 13; }

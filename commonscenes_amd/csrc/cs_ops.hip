@@ -384,6 +384,70 @@ __global__ __launch_bounds__(256) void synth_fill_kernel(float* __restrict__ out
 
 inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+// ---------------------------------------------------------------------------------------------------------
+// Thin-output 3x3x3 convs (cout <= 4: the UNet's eps head, the VQ decoder's conv_out) as "taps as columns":
+//   Y[m'][o * 27 + t] = sum_c A[m'][c] * W[o][c][t]        -- ONE pointwise GEMM with 27 * cout columns (K = cin)
+//   out[m][o] = bias[o] + sum_t Y[m + off_t][o * 27 + t]    -- this kernel; taps that leave the volume contribute 0
+// The implicit GEMM spends a 64-column tile on 1-4 real columns (7 TF/s for the decoder's conv_out); this form does
+// 27 * cout useful columns of MFMA work per row and is bound by the Y round trip instead.
+// Fixed summation order (t = 0 .. 26, then the bias), one thread per output row: bit-reproducible.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tapsum27_kernel(const float* __restrict__ y, const float* __restrict__ bias,
+                                                       float* __restrict__ out, int64_t m_total, int D, int H, int W,
+                                                       int cout, int ldy, int ldo) {
+  const int64_t m = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (m >= m_total) return;
+  const int w = (int)(m % W);
+  int64_t t0 = m / W;
+  const int h = (int)(t0 % H);
+  t0 /= H;
+  const int d = (int)(t0 % D);
+  int64_t off[27];
+  bool in[27];
+#pragma unroll
+  for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int t = (kd * 3 + kh) * 3 + kw;
+        in[t] = (unsigned)(d + kd - 1) < (unsigned)D && (unsigned)(h + kh - 1) < (unsigned)H &&
+                (unsigned)(w + kw - 1) < (unsigned)W;
+        off[t] = (m + ((int64_t)(kd - 1) * H + (kh - 1)) * W + (kw - 1)) * ldy + t;
+      }
+  for (int o = 0; o < cout; ++o) {
+    float v[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) v[t] = in[t] ? y[off[t] + o * 27] : 0.f;
+    float acc = 0.f;
+#pragma unroll
+    for (int t = 0; t < 27; ++t) acc += v[t];
+    out[m * ldo + o] = bias ? acc + bias[o] : acc;
+  }
+}
+
+// W[o][c][t] (torch Conv3d (cout, cin, 3, 3, 3)) -> the F16X3 pack of the pointwise weight [ncolp][cin] whose row
+// o * 27 + t is W[o][:][t]; rows >= 27 * cout are zero.  Layout as cs_pack_weight_f16x3 with taps = 1.
+__global__ __launch_bounds__(256) void pack_tapcol_f16x3_kernel(const float* __restrict__ w, _Float16* __restrict__ wh,
+                                                                _Float16* __restrict__ wl, int cout, int cin, int ncolp,
+                                                                int kg, float scale) {
+  const int64_t total = (int64_t)kg * ncolp * 8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 7);
+    const int n = (int)((i >> 3) % ncolp);
+    const int g = (int)((i >> 3) / ncolp);
+    const int c = g * 8 + j;
+    float v = 0.f;
+    if (c < cin && n < cout * 27) {
+      const int o = n / 27, t = n - o * 27;
+      v = w[((int64_t)o * cin + c) * 27 + t] * scale;
+    }
+    const _Float16 hh = (_Float16)v;
+    wh[i] = hh;
+    wl[i] = (_Float16)(v - (float)hh);
+  }
+}
+
 }  // namespace
 
 extern "C" int cs_geglu(const float* x, float* out, int m, int h, int ldx, int ldo, cs_stream_t stream) {
@@ -672,6 +736,31 @@ extern "C" int cs_synth_fill(float* out, int64_t n, uint64_t base, double scale,
   if (!out || n <= 0) return CS_EINVAL;
   CS_LAUNCH(synth_fill_kernel, dim3(cs_grid_for(n, 256, 256 * 32)), dim3(256), 0, (hipStream_t)stream,
                      out, n, base, scale, offset);
+  CS_CHECK_LAUNCH();
+  return CS_OK;
+}
+
+extern "C" int cs_tapsum27(const float* y, const float* bias, float* out, int nb, int d, int h, int w, int cout,
+                           int ldy, int ldo, cs_stream_t stream) {
+  if (!y || !out || nb <= 0 || d <= 0 || h <= 0 || w <= 0 || cout <= 0 || cout > 4) return CS_EINVAL;
+  if (ldy < 27 * cout || ldo < cout) return CS_EINVAL;
+  const int64_t m = (int64_t)nb * d * h * w;
+  if (m * ldy > 0x7fffffffffffLL || (m + 255) / 256 > 0x7fffffffLL) return CS_EINVAL;
+  CS_LAUNCH(tapsum27_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, bias, out, m, d, h,
+            w, cout, ldy, ldo);
+  CS_CHECK_LAUNCH();
+  return CS_OK;
+}
+
+extern "C" int cs_pack_weight_f16x3_tapcol(const float* w_torch, void* w_hi, void* w_lo, int cout, int cin, int ncolp,
+                                           float scale, cs_stream_t stream) {
+  if (!w_torch || !w_hi || !w_lo || cout <= 0 || cout > 4 || cin <= 0 || ncolp < 27 * cout || (ncolp & 3) ||
+      !(scale > 0.f))
+    return CS_EINVAL;
+  const int kg = ((cin + 15) / 16) * 2;
+  const int64_t total = (int64_t)kg * ncolp * 8;
+  CS_LAUNCH(pack_tapcol_f16x3_kernel, dim3(cs_grid_for(total, 256, 256 * 32)), dim3(256), 0, (hipStream_t)stream,
+            w_torch, (_Float16*)w_hi, (_Float16*)w_lo, cout, cin, ncolp, kg, scale);
   CS_CHECK_LAUNCH();
   return CS_OK;
 }

@@ -17,7 +17,7 @@ import torch  # noqa: F401
 
 from .build import LIB_PATH
 
-ABI_VERSION = 12     # cs_abi_version() of the library this module's SIGNATURES table describes
+ABI_VERSION = 13     # cs_abi_version() of the library this module's SIGNATURES table describes
 CS_OK = 0
 CS_EINVAL = -22
 CS_ENOMEM = -12
@@ -90,6 +90,8 @@ SIGNATURES = {
     "cs_gemm_tokens": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _s]),
     "cs_relayout_weight": (_i, [_f, _f, _i, _i, _i, _i, _i, _s]),
     "cs_pack_weight_f16x3": (_i, [_f, _f, _f, _i, _i, _i, _fl, _s]),
+    "cs_pack_weight_f16x3_tapcol": (_i, [_f, _f, _f, _i, _i, _i, _fl, _s]),
+    "cs_tapsum27": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),
     "cs_groupnorm_ws_bytes": (_l, [_i, _i]),
     "cs_groupnorm_stats": (_i, [_f, _i, _i, _i, _i, _i, _fl, _f, _f, _s]),
     "cs_groupnorm_apply": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),

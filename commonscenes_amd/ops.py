@@ -132,6 +132,9 @@ class PackedWeight:
     # PackedWeight per output parity class (3x2x2 / 2x2x2 kernels with pre-summed taps); wt / wh / wl are then unused
     up: Optional[Tuple[int, int, int]] = None
     classes: Optional[list] = None
+    # thin-output 3x3x3 conv as "taps as columns" (pack_weight_tapcol): the pointwise pack with 27 * cout (+ pad)
+    # columns; wt / wh / wl are then unused and `bias` is added by cs_tapsum27
+    tapcol: Optional["PackedWeight"] = None
 
 
 def pack_weight(w: Tensor, bias: Optional[Tensor] = None, cin_pad: Optional[int] = None,
@@ -241,6 +244,80 @@ def _pack_weight_f16x3(w: Tensor, bias: Optional[Tensor], cin_pad: Optional[int]
     return PackedWeight(None, b, cout, cin, cp, cout, (kd, kh, kw), L.MATH_F16X3, wh, wl, 1.0 / (scale * A_SCALE))
 
 
+# CS_NO_TAPCOL=1: thin-output convs stay on the implicit GEMM (A/B runs)
+TAPCOL = not os.environ.get("CS_NO_TAPCOL")
+
+
+def tapcol_ok(w: Tensor, math: int) -> bool:
+    """the rule both hosts apply (csrc/cs_driver.h::add_layer_gemm): F16X3, 3x3x3, at most 4 output channels"""
+    return (TAPCOL and math == L.MATH_F16X3 and w.dim() == 5 and tuple(w.shape[2:]) == (3, 3, 3) and w.shape[0] <= 4
+            and w.shape[1] % 4 == 0)
+
+
+def pack_weight_tapcol(w: Tensor, bias: Optional[Tensor] = None) -> PackedWeight:
+    """Conv3d (cout <= 4, cin, 3, 3, 3) weight -> "taps as columns" pack: the pointwise F16X3 weight [ncolp][cin] with row
+    o * 27 + t = w[o, :, t] (cs_pack_weight_f16x3_tapcol); conv_gemm then runs ONE 1x1x1 GEMM with 27 * cout columns and
+    cs_tapsum27 adds the 27 shifted columns of every output channel (+ bias).  Same power-of-two weight scale as the
+    ordinary pack (the tensor's max |w|)."""
+    import math as _m
+    _chk(w, "weight")
+    w = w.contiguous()
+    cout, cin = int(w.shape[0]), int(w.shape[1])
+    if w.dim() != 5 or tuple(w.shape[2:]) != (3, 3, 3) or cout > 4:
+        raise L.CsError("pack_weight_tapcol: (cout <= 4, cin, 3, 3, 3) weights only")
+    amax = float(w.abs().max().item())
+    e = _m.frexp(amax)[1] if amax > 0 and _m.isfinite(amax) else 0
+    scale = 2.0 ** (14 - e)
+    ncolp = (27 * cout + 3) // 4 * 4
+    kg = (cin + 15) // 16 * 2
+    wh = torch.empty((1, kg, ncolp, 8), dtype=torch.float16, device=w.device)
+    wl = torch.empty_like(wh)
+    L.check(L.load().cs_pack_weight_f16x3_tapcol(w.data_ptr(), wh.data_ptr(), wl.data_ptr(), cout, cin, ncolp, scale,
+                                                 _stream()), "cs_pack_weight_f16x3_tapcol")
+    b = None
+    if bias is not None:
+        _chk(bias, "bias")
+        b = bias.contiguous()
+    cp = (cin + 3) // 4 * 4
+    pw = PackedWeight(None, None, ncolp, cin, cp, ncolp, (1, 1, 1), L.MATH_F16X3, wh, wl, 1.0 / (scale * A_SCALE))
+    return PackedWeight(None, b, cout, cin, cp, cout, (3, 3, 3), L.MATH_F16X3, None, None, pw.acc_scale, None, None, pw)
+
+
+def tapcol_tile(m: int, ncolp: int) -> int:
+    """tile of the taps-as-columns GEMM (mirrored in cs_driver.h): 256-row tiles once they fill the chip"""
+    if os.environ.get("CS_TAPCOL_TILE"):               # tuning runs (Python host only)
+        return int(os.environ["CS_TAPCOL_TILE"])
+    if (m + 255) // 256 < 192:
+        return 0
+    return 7 if ncolp <= 64 else 6
+
+
+def _conv_tapcol(x, w: PackedWeight, spatial, a_scale, out, out_fn) -> Tensor:
+    xt = x.hi if isinstance(x, Split16) else x.t if isinstance(x, Pair16) else x
+    if spatial is None:
+        if xt.dim() != 5:
+            raise L.CsError("conv needs x as [nb,d,h,w,c] or an explicit spatial=")
+        nb, d, h, wd = (int(v) for v in xt.shape[:4])
+    else:
+        nb, d, h, wd = (int(v) for v in spatial)
+    m = nb * d * h * wd
+    pw = w.tapcol
+    y = conv_gemm(x, pw, spatial=(nb, d, h, wd), tile=tapcol_tile(m, pw.cout), a_scale=a_scale)
+    oshape = (nb, d, h, wd, w.cout)
+    if out is None:
+        out = out_fn(oshape) if out_fn is not None else torch.empty(oshape, dtype=torch.float32, device=xt.device)
+        if tuple(out.shape) != oshape:
+            out = out.view(oshape)
+    _chk(out, "out")
+    om, oc, ldo = rows_ld(out, "out")
+    if om != m or oc != w.cout:
+        raise L.CsError(f"out has shape {tuple(out.shape)}, expected {m} rows x {w.cout}")
+    ym, yc, ldy = rows_ld(y, "y")
+    L.check(L.load().cs_tapsum27(y.data_ptr(), _ptr(w.bias), out.data_ptr(), nb, d, h, wd, w.cout, ldy, ldo, _stream()),
+            "cs_tapsum27")
+    return out
+
+
 def pack_geglu_weight(w: Tensor, bias: Tensor, group: int = 112) -> PackedWeight:
     """GEGLU.proj (attention.py:42) weight (2H, C) -> f16x3 pack whose output columns are interleaved per
     `2*group`-column GEMM tile as [x (group) | gate (group)], so the gate is applied in the GEMM epilogue
@@ -264,6 +341,11 @@ def conv_gemm(x: Tensor, w: PackedWeight, *, spatial: Optional[Tuple[int, int, i
 
     `spatial=(nb,d,h,w)` lets a row matrix be interpreted as a volume without reshaping.
     """
+    if w.tapcol is not None:
+        if (tuple(stride) != (1, 1, 1) or tuple(up) != (0, 0, 0) or act != L.ACT_NONE or rowvec is not None
+                or res is not None or scale is not None or tile or splitk):
+            raise L.CsError("taps-as-columns weights: plain 3x3x3 conv only (no stride / up / act / residual / tile)")
+        return _conv_tapcol(x, w, spatial, a_scale, out, out_fn)
     xs = xp = None
     if isinstance(x, Pair16):
         if w.math != L.MATH_F16X3 or w.classes is not None:
@@ -496,8 +578,8 @@ def wants_split16(m: int, w: "PackedWeight") -> bool:
     will run the slab kernel (3x3x3 on a 256-row tile: large batches) -- there the in-loop conversion is what is left
     to remove.  Small batches (128-row / 64-row tiles, split-K) measured slightly slower with it (7.85 vs 7.58 ms per
     one-object step), 1-tap GEMMs neutral: both keep fp32 activations."""
-    if not (SPLIT16_PRODUCERS and w.math == L.MATH_F16X3 and w.classes is None and tuple(w.k) == (3, 3, 3)
-            and w.cin % 8 == 0):
+    if not (SPLIT16_PRODUCERS and w.math == L.MATH_F16X3 and w.classes is None and w.tapcol is None
+            and tuple(w.k) == (3, 3, 3) and w.cin % 8 == 0):
         return False
     if _tile_for(m, w.cout, w.math, w.cin, L.ACT_NONE) in (4, 6, 7):
         return True

@@ -349,7 +349,11 @@ class DiffusionUNet:
         pack_block(P + "middle_block", mid)
         for i, layers in enumerate(out):
             pack_block(f"{P}output_blocks.{i}", layers)
-        pw(P + "out.2")
+        # the eps head (openai_model_3d.py:733-737: 3x3x3 conv to out_channels = 3): taps as columns, see ops.py
+        if ops.tapcol_ok(sd[P + "out.2.weight"], self.math):
+            pk[P + "out.2"] = ops.pack_weight_tapcol(sd[P + "out.2.weight"], sd.get(P + "out.2.bias"))
+        else:
+            pw(P + "out.2")
         # Channel-split ResBlocks (r3).  Output block j concatenates [h | skip_j]; for the blocks whose skip comes from
         # the CONTEXT-FREE PREFIX of the input path (everything before the first attention block: conv_in, two
         # ResBlocks, the first Downsample) that skip is the same tensor for both classifier-free-guidance halves

@@ -166,6 +166,10 @@ class VQVAE:
                     pk[p] = ops.pack_weight(wz, bz, cin_pad=(wz.shape[1] + 3) // 4 * 4, math=self.math)
                     continue
                 cin = sd[k].shape[1]
+                if p == "decoder.conv_out" and ops.tapcol_ok(sd[k], self.math):
+                    # vqvae_modules.py:473 (3x3x3 conv to out_ch = 1): taps as columns, see ops.py
+                    pk[p] = ops.pack_weight_tapcol(sd[k], sd.get(p + ".bias"))
+                    continue
                 # Upsample's conv (vqvae_modules.py:35-39: nearest x2 in D, H, W) runs on the source grid
                 fold = (1, 1, 1) if p.endswith(".upsample.conv") else None
                 pk[p] = ops.pack_weight(sd[k], sd.get(p + ".bias"), cin_pad=(cin + 3) // 4 * 4, math=self.math,

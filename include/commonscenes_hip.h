@@ -177,6 +177,21 @@ int cs_pack_weight_f16x3(const float* w_torch, void* w_hi, void* w_lo, int cout,
                          float scale, cs_stream_t stream);
 
 /*
+ * Thin-output 3x3x3 convs (cout <= 4, stride 1, "same" padding: openai_model_3d.py:733-737 `self.out`,
+ * vqvae_modules.py:473 `conv_out`) as "taps as columns" (r3): one POINTWISE GEMM with 27 * cout columns,
+ *   Y[m'][o * 27 + t] = sum_c A[m'][c] * W[o][c][t],  then  out[m][o] = bias[o] + sum_t Y[m + off_t][o * 27 + t]
+ * with taps that leave the volume contributing 0.  The implicit GEMM would spend a 64-column tile on 1-4 real columns.
+ *   cs_pack_weight_f16x3_tapcol: torch (cout, cin, 3, 3, 3) weight -> the cs_pack_weight_f16x3 layout (taps = 1) of
+ *     the [ncolp][cin] pointwise weight, row o * 27 + t = W[o][:][t]; ncolp >= 27 * cout, a multiple of 4, extra rows 0.
+ *   cs_tapsum27: y [nb*d*h*w][ldy] (the GEMM's output, no bias) -> out [nb*d*h*w][ldo]; bias [cout] or NULL.  Sum in
+ *     tap order t = 0 .. 26 (kd, kh, kw row-major), then the bias: bit-reproducible.
+ */
+int cs_pack_weight_f16x3_tapcol(const float* w_torch, void* w_hi, void* w_lo, int cout, int cin, int ncolp, float scale,
+                                cs_stream_t stream);
+int cs_tapsum27(const float* y, const float* bias, float* out, int nb, int d, int h, int w, int cout, int ldy, int ldo,
+                cs_stream_t stream);
+
+/*
  * GroupNorm over NDHWC. Two entries: statistics (fp64 accumulation), then normalise+affine+act.
  *   ws: workspace of cs_groupnorm_ws_bytes(nb, groups) bytes.
  *   stats: [nb][groups][2] floats (mean, rstd).

@@ -695,3 +695,41 @@ def test_folded_upsample_convs_on_the_four_tap_slab_path(tmp_path):
     direct = ops.conv_gemm(x, ops.pack_weight(w, bb, math=L.MATH_F16X3), up=(0, 1, 1))
     torch.cuda.synchronize()
     assert rel_l2(a["unet_hw"], direct) < 1e-6
+
+
+@pytest.mark.parametrize("nb,shape,cin,cout", [
+    (2, (4, 6, 8), 64, 1),          # the VQ decoder's conv_out shape class
+    (3, (5, 7, 3), 224, 3),         # the UNet's eps head, ragged volume
+    (1, (4, 4, 4), 32, 4),
+    (1, (32, 40, 40), 64, 1),       # enough rows for the 256-row tile (ops.tapcol_tile)
+    (2, (16, 40, 40), 224, 3),
+])
+def test_thin_output_conv_as_tap_columns(nb, shape, cin, cout):
+    """3x3x3 convs with <= 4 output channels run as ONE pointwise GEMM with 27 * cout columns + cs_tapsum27 (ABI 13;
+    openai_model_3d.py:733-737, vqvae_modules.py:473).  Gates: fp64 conv at the per-op gate, and no worse than the
+    implicit-GEMM form of the same conv; borders (zero padding) and sample boundaries are where a wrong tap offset or a
+    missing mask shows, hence the ragged / multi-sample volumes."""
+    from commonscenes_amd import lib as L, ops
+    from oracle import ref_ops as R
+    d, h, w = shape
+    x = _rand(nb, d, h, w, cin, seed=11)
+    wt = _rand(cout, cin, 3, 3, 3, seed=12, scale=(cin * 27) ** -0.5)
+    b = _rand(cout, seed=13)
+    ref = R.conv_ndhwc(x.double(), wt.double(), b.double(), (1, 1, 1), (0, 0, 0))
+    assert ops.tapcol_ok(wt, L.MATH_F16X3)
+    pk = ops.pack_weight_tapcol(wt.cuda(), b.cuda())
+    assert pk.tapcol is not None and pk.tapcol.cout == (27 * cout + 3) // 4 * 4 and pk.cout == cout
+    o_tc = ops.conv_gemm(x.cuda(), pk)
+    o_ig = ops.conv_gemm(x.cuda(), ops.pack_weight(wt.cuda(), b.cuda(), math=L.MATH_F16X3))
+    torch.cuda.synchronize()
+    assert o_tc.shape == o_ig.shape == (nb, d, h, w, cout)
+    e_tc, e_ig = rel_l2(o_tc, ref), rel_l2(o_ig, ref)
+    print(f"thin conv cin={cin} cout={cout}: taps-as-columns {e_tc:.2e}, implicit GEMM {e_ig:.2e}")
+    assert e_tc < gate(27 * cin) and e_tc < 2 * e_ig + 1e-7
+    assert (o_tc - ref.float().cuda()).abs().max().item() < 2e-5 * ref.abs().max().item()
+    # an operand scale from the producer and a strided (channel-slice) output go through the same route
+    buf = torch.zeros((nb, d, h, w, 8), device="cuda")
+    o2 = ops.conv_gemm(x.cuda(), pk, a_scale=4.0, out=buf[..., 4:4 + cout])
+    assert rel_l2(o2, ref) < gate(27 * cin) and float(buf[..., :4].abs().max()) == 0.0
+    with pytest.raises(L.CsError):
+        ops.conv_gemm(x.cuda(), pk, stride=(1, 2, 2))
