@@ -11,6 +11,8 @@
 // key 32*jb + ((8q+e)&3) + 8*((8q+e)>>2) + 4*h; the V^T image stores key j at column pos(j) = j with bits 2 and 3
 // swapped, which makes those 8 keys one contiguous 16-byte read.
 #include "cs_common.h"
+#include "cs_f16x3.h"
+#include <cstdlib>
 
 namespace {
 
@@ -319,6 +321,302 @@ __global__ __launch_bounds__(64 * NW) void attn_f16x3_kernel(const float* __rest
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// r3: K / V split ONCE per call.  The kernel above converts every K / V tile to its fp16 hi / lo LDS images inside
+// every workgroup -- qtiles-fold redundant VALU work and (V^T) two-byte scattered LDS stores: for the VQ decoder's
+// single 256-channel head over 4096 tokens that staging was ~7/8 of the kernel (95 TF/s).  Here a pre-pass writes,
+// per (sample, head, key tile), the EXACT LDS image the MFMA loop reads ([Kh | Kl | Vh | Vl], padding included), and
+// the attention kernel pulls whole images into a two-deep LDS ring with buffer_load ... lds (no registers, no VALU),
+// the next tile in flight under the current tile's MFMAs.  Same operand values, same MFMA order: bit-identical
+// output (tests/test_f16x3_gpu.py).
+// ---------------------------------------------------------------------------------------------------------
+template <int DB, int KT>
+struct AttnImg {
+  static constexpr int DP = 32 * DB, LDK = DP + 8, LDV = KT + 8;
+  static constexpr int TILE_HALVES = 2 * (KT * LDK + DP * LDV);
+  static constexpr int TILE_BYTES = TILE_HALVES * 2;
+  static_assert(TILE_BYTES % 1024 == 0, "whole 1 KB DMA chunks");
+};
+
+template <int DB, int KT>
+__global__ __launch_bounds__(256) void attn_presplit_kernel(const float* __restrict__ k, const float* __restrict__ v,
+                                                            _Float16* __restrict__ img, int nk, int heads, int dh,
+                                                            int ldk, int ldv, int ntiles, int32_t* __restrict__ status) {
+  using I = AttnImg<DB, KT>;
+  constexpr int LDK = I::LDK, LDV = I::LDV, DP = I::DP;
+  extern __shared__ __attribute__((aligned(16))) _Float16 sm[];
+  _Float16* Kh = sm;
+  _Float16* Kl = Kh + KT * LDK;
+  _Float16* Vh = Kl + KT * LDK;
+  _Float16* Vl = Vh + DP * LDV;
+  const int tid = threadIdx.x;
+  int bid = blockIdx.x;
+  const int tile = bid % ntiles;
+  bid /= ntiles;
+  const int h = bid % heads;
+  const int b = bid / heads;
+  const int kt0 = tile * KT;
+  const float* kb = k + (int64_t)b * nk * ldk + h * dh;
+  const float* vb = v + (int64_t)b * nk * ldv + h * dh;
+  float amax = 0.f;
+  for (int u = tid; u < I::TILE_BYTES / 16; u += 256) reinterpret_cast<uint4*>(sm)[u] = make_uint4(0u, 0u, 0u, 0u);
+  __syncthreads();
+  const int dh4 = dh >> 2;
+  for (int u = tid; u < KT * dh4; u += 256) {          // K: unit = (key j, 4 channels)
+    const int j = u / dh4;
+    const int c4 = u - j * dh4;
+    float4 kv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (kt0 + j < nk) kv = *reinterpret_cast<const float4*>(kb + (int64_t)(kt0 + j) * ldk + c4 * 4);
+    h4 hi, lo;
+    _Float16 a, c;
+    split1m(kv.x * QK_SCALE, a, c, amax); hi[0] = a; lo[0] = c;
+    split1m(kv.y * QK_SCALE, a, c, amax); hi[1] = a; lo[1] = c;
+    split1m(kv.z * QK_SCALE, a, c, amax); hi[2] = a; lo[2] = c;
+    split1m(kv.w * QK_SCALE, a, c, amax); hi[3] = a; lo[3] = c;
+    *reinterpret_cast<h4*>(Kh + j * LDK + c4 * 4) = hi;
+    *reinterpret_cast<h4*>(Kl + j * LDK + c4 * 4) = lo;
+  }
+  for (int u = tid; u < KT * dh4; u += 256) {          // V: unit = (key j, 4 channels) too -- coalesced reads
+    const int j = u / dh4;
+    const int c4 = u - j * dh4;
+    float4 vv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (kt0 + j < nk) vv = *reinterpret_cast<const float4*>(vb + (int64_t)(kt0 + j) * ldv + c4 * 4);
+    const int pj = vpos(j);
+    const float x[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      _Float16 a, c;
+      split1m(x[i] * QK_SCALE, a, c, amax);
+      Vh[(c4 * 4 + i) * LDV + pj] = a;
+      Vl[(c4 * 4 + i) * LDV + pj] = c;
+    }
+  }
+  __syncthreads();
+  uint4* dst = reinterpret_cast<uint4*>(img + (int64_t)blockIdx.x * I::TILE_HALVES);
+  for (int u = tid; u < I::TILE_BYTES / 16; u += 256) dst[u] = reinterpret_cast<const uint4*>(sm)[u];
+  if (status && amax >= 65504.f) atomicOr(status, CS_STATUS_F16X3_OVERFLOW);
+}
+
+template <int DB, int KT, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_f16x3_img_kernel(const float* __restrict__ q,
+                                                                 const _Float16* __restrict__ img,
+                                                                 float* __restrict__ out, int nq, int nk, int heads,
+                                                                 int dh, int ldq, int ldo, float scale, int qtiles,
+                                                                 int ntiles, int32_t* __restrict__ status) {
+  using I = AttnImg<DB, KT>;
+  constexpr int DP = I::DP, LDK = I::LDK, LDV = I::LDV;
+  constexpr int JB = KT / 32;
+  constexpr int KS = DP / 16;
+  constexpr int NCH = I::TILE_BYTES / 1024;            // 1 KB (one wave-wide 16-byte DMA) chunks per tile image
+  extern __shared__ __attribute__((aligned(16))) unsigned char smb[];
+  float amax = 0.f;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: the DMA chunk loop branches on it
+  const int l31 = lane & 31;
+  const int half = lane >> 5;
+
+  int bid = blockIdx.x;
+  const int qt = bid % qtiles;
+  bid /= qtiles;
+  const int h = bid % heads;
+  const int b = bid / heads;
+
+  const int q0 = qt * (32 * NW) + wave * 32;
+  const int qi = min(q0 + l31, nq - 1);
+  const float* qp = q + ((int64_t)b * nq + qi) * ldq + h * dh;
+
+  // this (sample, head)'s tile images: one buffer window, 32-bit offsets (host checks ntiles * TILE_BYTES < 2^31)
+  const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(img + ((int64_t)b * heads + h) * ntiles * I::TILE_HALVES), 0, (unsigned)ntiles * (unsigned)I::TILE_BYTES,
+      0x00020000);
+  auto dma_tile = [&](int t) {                         // image t -> ring slot t & 1; chunk c by wave c % NW
+    unsigned char* dst = smb + (t & 1) * I::TILE_BYTES;
+    const unsigned base = (unsigned)t * (unsigned)I::TILE_BYTES + (unsigned)lane * 16u;
+#pragma unroll
+    for (int i = 0; i < (NCH + NW - 1) / NW; ++i) {
+      const int c = wave + NW * i;                     // wave-uniform
+      if (c < NCH) __builtin_amdgcn_raw_ptr_buffer_load_lds(irs, dst + c * 1024, 16, base + (unsigned)c * 1024u, 0, 0, 0);
+    }
+  };
+  dma_tile(0);
+
+  h8 qh[KS], ql[KS];
+#pragma unroll
+  for (int t = 0; t < KS; ++t)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int d = 16 * t + 8 * half + e;
+      const float x = d < dh ? qp[d] * (scale * QK_SCALE) : 0.f;
+      _Float16 a, c;
+      split1m(x, a, c, amax);
+      qh[t][e] = a;
+      ql[t][e] = c;
+    }
+
+  f32x16 oacc[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+  float mrun = -INFINITY;
+  float lrun = 0.f;
+  const float cexp = 1.44269504088896340736f / (QK_SCALE * QK_SCALE);
+  const float lp = 10.0f;             // log2(P_SCALE)
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int kt0 = t * KT;
+    cs16::wait_vmcnt<0>();            // this wave's chunks of image t have landed ...
+    __syncthreads();                  // ... everyone's have, and everyone is done reading slot (t + 1) & 1
+    if (t + 1 < ntiles) dma_tile(t + 1);
+    const _Float16* Kh = reinterpret_cast<const _Float16*>(smb + (t & 1) * I::TILE_BYTES);
+    const _Float16* Kl = Kh + KT * LDK;
+    const _Float16* Vh = Kl + KT * LDK;
+    const _Float16* Vl = Vh + DP * LDV;
+
+    // ---- S^T = K Q^T ----
+    f32x16 sacc[JB];
+#pragma unroll
+    for (int jb = 0; jb < JB; ++jb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[jb][r] = 0.f;
+#pragma unroll
+    for (int tt = 0; tt < KS; ++tt)
+#pragma unroll
+      for (int jb = 0; jb < JB; ++jb) {
+        const int off = (jb * 32 + l31) * LDK + 16 * tt + 8 * half;
+        const h8 kh = *reinterpret_cast<const h8*>(Kh + off);
+        const h8 kl = *reinterpret_cast<const h8*>(Kl + off);
+        sacc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[tt], sacc[jb], 0, 0, 0);
+        sacc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[tt], sacc[jb], 0, 0, 0);
+        sacc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[tt], sacc[jb], 0, 0, 0);
+      }
+
+    __builtin_amdgcn_sched_barrier(0);      // (keeps the V^T fragment reads from being hoisted over the K phase: spills)
+    // ---- online softmax (per query i = lane&31) ----
+    if (kt0 + KT > nk) {               // ragged last tile only (wave-uniform): keys past nk take no weight
+#pragma unroll
+      for (int jb = 0; jb < JB; ++jb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = kt0 + jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (j >= nk) sacc[jb][r] = -INFINITY;
+        }
+    }
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int jb = 0; jb < JB; ++jb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, sacc[jb][r]);
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float mnew = fmaxf(mrun, mloc);
+    const float alpha = (mrun == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((mrun - mnew) * cexp);
+    float psum = 0.f;
+#pragma unroll
+    for (int jb = 0; jb < JB; ++jb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[jb][r] - mnew, cexp, lp));   // = p * P_SCALE
+        sacc[jb][r] = pv;
+        psum += pv;
+      }
+    lrun = lrun * alpha + psum;
+    mrun = mnew;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- O^T += V^T P^T ----
+#pragma unroll
+    for (int jb = 0; jb < JB; ++jb)
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) {
+        h8 ph, pl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          _Float16 a, c;
+          split1(sacc[jb][8 * qq + e], a, c);
+          ph[e] = a;
+          pl[e] = c;
+        }
+#pragma unroll
+        for (int d = 0; d < DB; ++d) {
+          const int off = (32 * d + l31) * LDV + 32 * jb + 16 * qq + 8 * half;
+          const h8 vh = *reinterpret_cast<const h8*>(Vh + off);
+          const h8 vl = *reinterpret_cast<const h8*>(Vl + off);
+          oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, oacc[d], 0, 0, 0);
+          oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, oacc[d], 0, 0, 0);
+          oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, oacc[d], 0, 0, 0);
+        }
+      }
+  }
+
+  if (status && amax >= 65504.f) atomicOr(status, CS_STATUS_F16X3_OVERFLOW);
+  const float ltot = lrun + __shfl_xor(lrun, 32, 64);
+  const float inv = 1.0f / (ltot * QK_SCALE);       // ltot already carries P_SCALE
+  if (q0 + l31 < nq) {
+    float* op = out + ((int64_t)b * nq + q0 + l31) * ldo + h * dh;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int dd = 32 * d + 8 * g + 4 * half;
+        if (dd < dh) {
+          float4 o;
+          o.x = oacc[d][4 * g + 0] * inv;
+          o.y = oacc[d][4 * g + 1] * inv;
+          o.z = oacc[d][4 * g + 2] * inv;
+          o.w = oacc[d][4 * g + 3] * inv;
+          *reinterpret_cast<float4*>(op + dd) = o;
+        }
+      }
+  }
+}
+
+template <int DB, int KT, int NW>
+int launch_attn16_img(const float* q, const float* k, const float* v, float* out, int nb, int nq, int nk, int heads,
+                      int dh, int ldq, int ldk, int ldv, int ldo, float scale, int32_t* status, void* ws, hipStream_t s) {
+  using I = AttnImg<DB, KT>;
+  const int ntiles = (nk + KT - 1) / KT;
+  if ((int64_t)ntiles * I::TILE_BYTES >= 0x7FF00000LL) return CS_EINVAL;
+  const int64_t pgrid = (int64_t)nb * heads * ntiles;
+  const int qtiles = (nq + 32 * NW - 1) / (32 * NW);
+  const int64_t grid = (int64_t)qtiles * heads * nb;
+  if (pgrid > 0x7fffffffLL || grid > 0x7fffffffLL) return CS_EINVAL;
+  auto pk = attn_presplit_kernel<DB, KT>;
+  auto kern = attn_f16x3_img_kernel<DB, KT, NW>;
+  static bool once = false;      // (per instantiation) raise the dynamic-LDS limits
+  if (!once) {
+    hipError_t e = hipFuncSetAttribute((const void*)pk, hipFuncAttributeMaxDynamicSharedMemorySize, I::TILE_BYTES);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * I::TILE_BYTES);
+    if (e != hipSuccess) return (int)e;
+    once = true;
+  }
+  CS_LAUNCH(pk, dim3((unsigned)pgrid), dim3(256), (size_t)I::TILE_BYTES, s, k, v, (_Float16*)ws, nk, heads, dh, ldk, ldv,
+            ntiles, status);
+  CS_CHECK_LAUNCH();
+  CS_LAUNCH(kern, dim3((unsigned)grid), dim3(64 * NW), (size_t)2 * I::TILE_BYTES, s, q, (const _Float16*)ws, out, nq, nk,
+            heads, dh, ldq, ldo, scale, qtiles, ntiles, status);
+  CS_CHECK_LAUNCH();
+  return CS_OK;
+}
+
+// which (DB, KT, NW) the image path runs for a head width / query count, 0 = none (the in-kernel split above)
+inline int img_variant(int nq, int nk, int dh) {
+  static const char* e = getenv("CS_NO_ATTN_IMG");
+  if (e && *e == '1') return 0;
+  // Only where the pre-pass is amortised over many query tiles AND the in-kernel split dominates: the 256-wide variant
+  // (one wave per SIMD, nothing overlaps its staging) from 8 query tiles up -- the VQ decoder's mid attention, 4096 tokens:
+  // 2385 -> 1005 us per 16 objects (115 -> 270 TF/s).  Measured and left on the in-kernel split: dh 56 at 1024 tokens
+  // (4 query tiles per head: 640 -> 668 us, the pre-pass costs more than the staging it removes).
+  if (dh > 128 && dh <= 256 && nq >= 1024 && nk >= 128) return 8;
+  return 0;
+}
+
 template <int DB, int KT, bool X1, int NW = 4>
 int launch_attn16(const float* q, const float* k, const float* v, float* out, int nb, int nq, int nk, int heads,
                   int dh, int ldq, int ldk, int ldv, int ldo, float scale, int32_t* status, hipStream_t s) {
@@ -374,4 +672,30 @@ extern "C" int cs_attn_selfattn_f16(const float* q, const float* k, const float*
                                     int nk, int heads, int dh, int ldq, int ldk, int ldv, int ldo, float scale,
                                     int32_t* status, cs_stream_t stream) {
   return attn16_dispatch<true>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, stream);
+}
+
+// Workspace form of cs_attn_selfattn_f16x3: with `ws` (cs_attn_f16x3_ws_bytes(...) bytes, 16-byte aligned) K and V are
+// split into their fp16 hi / lo tile images once per call and the kernel streams those (see attn_presplit_kernel);
+// ws == NULL, or a shape the image path does not cover (ws_bytes == 0), runs the in-kernel split.  Same results, bit
+// for bit.
+extern "C" int64_t cs_attn_f16x3_ws_bytes(int nb, int nq, int nk, int heads, int dh) {
+  if (nb <= 0 || nq <= 0 || nk <= 0 || heads <= 0 || dh <= 0) return 0;
+  const int var = img_variant(nq, nk, dh);
+  if (var == 8) return (int64_t)nb * heads * ((nk + 31) / 32) * AttnImg<8, 32>::TILE_BYTES;
+  return 0;
+}
+
+extern "C" int cs_attn_selfattn_f16x3_ws(const float* q, const float* k, const float* v, float* out, int nb, int nq,
+                                         int nk, int heads, int dh, int ldq, int ldk, int ldv, int ldo, float scale,
+                                         int32_t* status, void* ws, cs_stream_t stream) {
+  const int var = ws ? img_variant(nq, nk, dh) : 0;
+  if (var == 0)
+    return attn16_dispatch<false>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, stream);
+  if (!q || !k || !v || !out || nb <= 0 || nq <= 0 || nk <= 0 || heads <= 0 || dh <= 0) return CS_EINVAL;
+  if ((dh & 3) || (ldq & 3) || (ldk & 3) || (ldv & 3) || (ldo & 3)) return CS_EINVAL;
+  if (ldq < heads * dh || ldk < heads * dh || ldv < heads * dh || ldo < heads * dh) return CS_EINVAL;
+  if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || ((uintptr_t)out & 15) || ((uintptr_t)ws & 15))
+    return CS_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  return launch_attn16_img<8, 32, 4>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, ws, s);
 }

@@ -795,6 +795,22 @@ struct ExecBase {
     return (g.cout == 64 || g.cout <= 4) && t256 >= 192;
   }
 
+  // self-attention over a fused [rows][3c] q | k | v buffer -> a [rows][c]; F16X3: K / V tile images in a scratch buffer
+  // where the library has that path (cs_attn_f16x3_ws_bytes > 0)
+  void self_attention(const Buf& qkv, const Buf& a, int nb, int n, int heads, int dh, int c, float scale) {
+    Buf ws;
+    const int64_t wsb = pl.math == CS_MATH_F16X3 ? cs_attn_f16x3_ws_bytes(nb, n, n, heads, dh) : 0;
+    if (wsb > 0) ws = alloc(wsb / 4, 1);
+    if (ok() && !dry) {
+      const float* q = p(qkv);
+      chk(pl.math == CS_MATH_F16X3
+              ? cs_attn_selfattn_f16x3_ws(q, q + c, q + 2 * c, p(a), nb, n, n, heads, dh, 3 * c, 3 * c, 3 * c, c, scale,
+                                          status, wsb > 0 ? (void*)p(ws) : nullptr, st)
+              : cs_attn_selfattn(q, q + c, q + 2 * c, p(a), nb, n, n, heads, dh, 3 * c, 3 * c, 3 * c, c, scale, st));
+    }
+    if (wsb > 0) release(ws);
+  }
+
   // conv_gi: the 3x3x3 conv that consumes the result (decides the output format), or -1
   Buf groupnorm(const Buf& x, int ni, int nb, float eps, int act, int groups = 32, int conv_gi = -1) {
     const Norm& n = pl.norms[ni];

@@ -366,14 +366,7 @@ struct Exec : ExecBase {
     Buf qkv = linear(n1, l.g[1]);
     release(n1);
     Buf a = alloc(rows, c);
-    if (ok() && !dry) {
-      const float scale = (float)std::pow((double)dh, -0.5);
-      const float* q = p(qkv);
-      chk(u.cfg.math == CS_MATH_F16X3
-              ? cs_attn_selfattn_f16x3(q, q + c, q + 2 * c, p(a), x.nb, n, n, heads, dh, 3 * c, 3 * c, 3 * c, c, scale,
-                                       status, st)
-              : cs_attn_selfattn(q, q + c, q + 2 * c, p(a), x.nb, n, n, heads, dh, 3 * c, 3 * c, 3 * c, c, scale, st));
-    }
+    self_attention(qkv, a, x.nb, n, heads, dh, c, (float)std::pow((double)dh, -0.5));
     release(qkv);
     // one context token: attn2(x) == to_out(to_v(ctx)) for every query row -> a row vector in this epilogue
     Buf t1 = linear(a, l.g[2], CS_ACT_NONE, ctxvec ? ctxvec + l.ctx_off : nullptr, u.ctx_total, n,
@@ -408,14 +401,7 @@ struct Exec : ExecBase {
     Buf qkv = linear(xn, l.g[0]);
     release(xn);
     Buf a = alloc(rows, c);
-    if (ok() && !dry) {
-      const float scale = (float)std::pow((double)dh, -0.5);
-      const float* q = p(qkv);
-      chk(u.cfg.math == CS_MATH_F16X3
-              ? cs_attn_selfattn_f16x3(q, q + c, q + 2 * c, p(a), x.nb, n, n, heads, dh, 3 * c, 3 * c, 3 * c, c, scale,
-                                       status, st)
-              : cs_attn_selfattn(q, q + c, q + 2 * c, p(a), x.nb, n, n, heads, dh, 3 * c, 3 * c, 3 * c, c, scale, st));
-    }
+    self_attention(qkv, a, x.nb, n, heads, dh, c, (float)std::pow((double)dh, -0.5));
     release(qkv);
     Act o = x;
     o.b = linear(a, l.g[1], CS_ACT_NONE, nullptr, 0, 1, dry ? nullptr : p(x.b), c);

@@ -133,13 +133,7 @@ struct VExec : ExecBase {
     Buf qkv = linear(hn, u.g_qkv);
     release(hn);
     Buf a = alloc(rows, c);
-    if (ok() && !dry) {
-      const float scale = (float)std::pow((double)c, -0.5);
-      const float* q = p(qkv);
-      chk(pl.math == CS_MATH_F16X3
-              ? cs_attn_selfattn_f16x3(q, q + c, q + 2 * c, p(a), x.nb, n, n, 1, c, 3 * c, 3 * c, 3 * c, c, scale, status, st)
-              : cs_attn_selfattn(q, q + c, q + 2 * c, p(a), x.nb, n, n, 1, c, 3 * c, 3 * c, 3 * c, c, scale, st));
-    }
+    self_attention(qkv, a, x.nb, n, 1, c, c, (float)std::pow((double)c, -0.5));
     release(qkv);
     Act o = x;
     o.b = linear(a, u.g_proj, CS_ACT_NONE, nullptr, 0, 1, dry ? nullptr : p(x.b), c);

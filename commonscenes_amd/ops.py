@@ -773,10 +773,17 @@ def attention(q: Tensor, k: Tensor, v: Tensor, heads: int, scale: float, out: Op
         out = torch.empty((nb, nq, cq), dtype=torch.float32, device=q.device)
     _, _, ldo = rows_ld(out, "out")
     lib = L.load()
-    if math in (L.MATH_F16X3, L.MATH_F16):
-        fn = lib.cs_attn_selfattn_f16x3 if math == L.MATH_F16X3 else lib.cs_attn_selfattn_f16
-        L.check(fn(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo,
-                   scale, status_word(q.device).data_ptr(), _stream()), "cs_attn_selfattn_f16x3")
+    if math == L.MATH_F16X3:
+        # K / V split once per call into their LDS tile images where the library has that path (ws_bytes > 0)
+        wsb = lib.cs_attn_f16x3_ws_bytes(nb, nq, nk, heads, dh)
+        ws = torch.empty((wsb // 4,), dtype=torch.float32, device=q.device) if wsb > 0 else None
+        L.check(lib.cs_attn_selfattn_f16x3_ws(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), nb, nq, nk, heads,
+                                              dh, ldq, ldk, ldv, ldo, scale, status_word(q.device).data_ptr(), _ptr(ws),
+                                              _stream()), "cs_attn_selfattn_f16x3_ws")
+    elif math == L.MATH_F16:
+        L.check(lib.cs_attn_selfattn_f16(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), nb, nq, nk, heads, dh,
+                                         ldq, ldk, ldv, ldo, scale, status_word(q.device).data_ptr(), _stream()),
+                "cs_attn_selfattn_f16")
     else:
         L.check(lib.cs_attn_selfattn(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), nb, nq, nk, heads, dh,
                                      ldq, ldk, ldv, ldo, scale, _stream()), "cs_attn_selfattn")

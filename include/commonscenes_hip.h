@@ -261,6 +261,16 @@ int cs_attn_selfattn_f16x3(const float* q, const float* k, const float* v, float
                            int nk, int heads, int dh, int ldq, int ldk, int ldv, int ldo, float scale,
                            int32_t* status, cs_stream_t stream);
 
+/* Workspace form (r3, ABI 13): with `ws` (cs_attn_f16x3_ws_bytes(...) bytes, 16-byte aligned) K and V are split into
+ * their fp16 hi / lo tile images ONCE per call by a pre-pass and the attention kernel streams whole images into LDS with
+ * buffer_load ... lds -- the plain entry converts every K / V tile inside every workgroup.  Covers 128 < dh <= 256 from
+ * 1024 queries up (the VQ decoder's single 256-channel head over 4096 tokens: 2.3x); cs_attn_f16x3_ws_bytes returns 0
+ * for every other shape, and ws == NULL or such a shape runs the plain kernel.  Bit-identical results either way. */
+int64_t cs_attn_f16x3_ws_bytes(int nb, int nq, int nk, int heads, int dh);
+int cs_attn_selfattn_f16x3_ws(const float* q, const float* k, const float* v, float* out, int nb, int nq,
+                              int nk, int heads, int dh, int ldq, int ldk, int ldv, int ldo, float scale,
+                              int32_t* status, void* ws, cs_stream_t stream);
+
 /* Same contract, PLAIN fp16 operands on the fp16 MFMA (one pass instead of three; fp32 softmax and accumulation):
  * the "fp16 MFMA attention" option BASELINE configs[4] names.  Reduced precision (~3e-4 relative on the attention
  * output) -- opt-in, outside the fp32 parity gates, never the default. */

@@ -733,3 +733,38 @@ def test_thin_output_conv_as_tap_columns(nb, shape, cin, cout):
     assert rel_l2(o2, ref) < gate(27 * cin) and float(buf[..., :4].abs().max()) == 0.0
     with pytest.raises(L.CsError):
         ops.conv_gemm(x.cuda(), pk, stride=(1, 2, 2))
+
+
+@pytest.mark.parametrize("nb,n,heads,dh", [
+    (1, 4096, 1, 256),     # the VQ decoder's mid attention
+    (2, 1100, 1, 256),     # ragged last key tile (32-key tiles), ragged query tile
+    (1, 1030, 2, 132),     # dh < 256 on the 256-wide variant: zero padding of the images; two heads
+])
+def test_attention_on_presplit_tile_images_is_bit_identical(nb, n, heads, dh):
+    """cs_attn_selfattn_f16x3_ws (ABI 13): K / V split into their LDS tile images once per call, streamed by LDS-DMA --
+    the same operand values through the same MFMA sequence as the plain entry (in-kernel split): equal bit for bit, and
+    fp32-grade against fp64; the overflow report moves to the pre-pass."""
+    from commonscenes_amd import lib as L, ops
+    from oracle import ref_ops as R
+    lib = L.load()
+    c = heads * dh
+    assert lib.cs_attn_f16x3_ws_bytes(nb, n, n, heads, dh) > 0
+    qkv = _rand(nb, n, 3 * c, seed=41).cuda()                 # the fused q | k | v buffer, as the hosts pass it
+    q, k, v = qkv[..., 0:c], qkv[..., c:2 * c], qkv[..., 2 * c:]
+    ops.read_status()
+    new = ops.attention(q, k, v, heads, dh ** -0.5, math=L.MATH_F16X3)
+    old = torch.empty_like(new)
+    L.check(lib.cs_attn_selfattn_f16x3(q.data_ptr(), k.data_ptr(), v.data_ptr(), old.data_ptr(), nb, n, n, heads, dh,
+                                       3 * c, 3 * c, 3 * c, c, dh ** -0.5, ops.status_word().data_ptr(), None),
+            "cs_attn_selfattn_f16x3")
+    torch.cuda.synchronize()
+    assert ops.read_status() == 0
+    assert torch.equal(new, old)
+    if n <= 1100:
+        ref = R.attention(q.double().cpu(), k.double().cpu(), v.double().cpu(), heads, dh ** -0.5)
+        assert rel_l2(new, ref) < 1e-6
+    # a key beyond the fp16 range of the scaled operands (|k| * 16 >= 65504) is reported by the pre-pass
+    k2 = k.clone()
+    k2[0, n // 2, 3] = 5000.0
+    ops.attention(q, k2, v, heads, dh ** -0.5, math=L.MATH_F16X3)
+    assert ops.read_status() & L.STATUS_F16X3_OVERFLOW

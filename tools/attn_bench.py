@@ -13,11 +13,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--iters", type=int, default=10)
 a = ap.parse_args()
-for n, c, heads in ((1024, 448, 8), (256, 672, 8), (512, 448, 8), (64, 672, 8)):
-    qkv = synth.tensor_device(f"qkv{n}", (a.batch, n, 3 * c), 1.0)
+for n, c, heads, nb in ((1024, 448, 8, 0), (256, 672, 8, 0), (512, 448, 8, 0), (64, 672, 8, 0), (4096, 256, 1, 16)):
+    nb = nb or a.batch                      # (the last row: the VQ decoder's mid attention, 16 objects per call)
+    qkv = synth.tensor_device(f"qkv{n}", (nb, n, 3 * c), 1.0)
     q, k, v = qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:]
     dh = c // heads
-    line = f"N={n:5d} dh={dh:3d} nb={a.batch}: "
+    line = f"N={n:5d} dh={dh:3d} nb={nb}: "
     for name, math in (("fp32", L.MATH_FP32), ("f16x3", L.MATH_F16X3), ("f16(opt-in)", L.MATH_F16)):
         ops.attention(q, k, v, heads, dh ** -0.5, math=math)
         torch.cuda.synchronize()
@@ -28,5 +29,5 @@ for n, c, heads in ((1024, 448, 8), (256, 672, 8), (512, 448, 8), (64, 672, 8)):
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / a.iters
-        line += f"{name} {ms * 1e3:8.1f} us {4.0 * a.batch * heads * n * n * dh / ms / 1e9:7.1f} TF/s | "
+        line += f"{name} {ms * 1e3:8.1f} us {4.0 * nb * heads * n * n * dh / ms / 1e9:7.1f} TF/s | "
     print(line, flush=True)

@@ -1,0 +1,14 @@
+# round-3: attention on pre-split K / V tile images -- tests, kernel timings, decode + bench A/B (CS_NO_ATTN_IMG=1 = before)
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+( timeout 900 python -m pytest tests/test_f16x3_gpu.py tests/test_ops_gpu.py tests/test_model_gpu.py tests/test_unet_native_gpu.py tests/test_vqvae_native_gpu.py tests/test_c_host_gpu.py -m gpu -q -x > gpurun_out/r03_v_tests.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r03_v_tests.log )
+tail -15 gpurun_out/r03_v_tests.log
+for arm in "CS_NO_ATTN_IMG=1" "CS_NO_ATTN_IMG=" "CS_NO_ATTN_IMG=1" "CS_NO_ATTN_IMG="; do
+  echo "== $arm"
+  env $arm timeout 300 python tools/attn_bench.py 2>&1 | grep -v amdgpu.ids
+done | tee gpurun_out/r03_v_attn_bench.txt
+for arm in "CS_NO_ATTN_IMG=1" "CS_NO_ATTN_IMG=" "CS_NO_ATTN_IMG=1" "CS_NO_ATTN_IMG="; do
+  echo "== $arm"
+  env $arm timeout 300 python tools/decode_bench.py 2>&1 | grep -v amdgpu.ids | head -1
+  env $arm timeout 300 python bench.py --no-cpu-baseline --no-fp32-leg --steps 10 --warmup 2 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bench ms/step', round(d['ms_per_step'],2), 'c2', round(d['c2']['ms_per_step'],2), 'c7', round(d['c7']['ms_per_step'],2), 'decode', round(d['decode']['ms'],2))"
+done | tee gpurun_out/r03_v_bench_ab.txt
