@@ -248,7 +248,9 @@ __global__ void relayout_weight_kernel(const float* __restrict__ w, float* __res
 
 }  // namespace
 
-int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p, int M, int tile, int splits, hipStream_t s);  // cs_gemm_f16x3.hip
+int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p, int M, int tile, int splits, hipStream_t s, int omap_f = 0,
+                                int omap_p = 0);                                        // cs_gemm_f16x3.hip
+bool cs_f16x3_slab4_ok(const CsConvGemm& p, int tile, int splits);                      // cs_gemm_f16x3.hip
 bool cs_pw_gemm_f16x3_applicable(const CsConvGemm& p, int64_t M);                                   // cs_gemm_pw.hip
 bool cs_pw_gemm_f16x3_preferred(const CsConvGemm& p, int64_t M);
 int cs_pw_gemm_f16x3_launch(const CsConvGemm& p, int M, hipStream_t s);
@@ -339,32 +341,10 @@ extern "C" int cs_conv_gemm_plan(const CsConvGemm* d, int32_t* splitk, int64_t* 
   return CS_OK;
 }
 
-extern "C" int cs_conv_gemm(const CsConvGemm* d, cs_stream_t stream) {
-  if (!d || !d->x || !d->w || !d->out) return CS_EINVAL;
-  const CsConvGemm& p = *d;
-  if (p.nb <= 0 || p.cin <= 0 || p.cout <= 0 || p.dout <= 0 || p.hout <= 0 || p.wout <= 0)
-    return CS_EINVAL;
-  const bool f16x3 = p.math == CS_MATH_F16X3;
-  if ((p.cin & 3) || (p.lda & 3) || p.lda < p.cin) return CS_EINVAL;
-  if (!f16x3 && ((p.ldw & 3) || p.ldw < p.cout))
-    return CS_EINVAL;
-  if (((uintptr_t)p.x & 15) || ((uintptr_t)p.w & 15)) return CS_EINVAL;
-  if (p.kd <= 0 || p.kh <= 0 || p.kw <= 0 || p.sd <= 0 || p.sh <= 0 || p.sw <= 0) return CS_EINVAL;
-  if (p.ud < 0 || p.uh < 0 || p.uw < 0 || p.ud > 4 || p.uh > 4 || p.uw > 4) return CS_EINVAL;
-  if (p.scale && !p.shift) return CS_EINVAL;
-  if (p.rowvec && p.rv_rows <= 0) return CS_EINVAL;
-  const int out_cols = (p.act == CS_ACT_GEGLU) ? p.cout / 2 : p.cout;
-  if (p.act == CS_ACT_GEGLU && (!f16x3 || (p.cout & 1))) return CS_EINVAL;
-  if (p.ldo < out_cols || (p.res && p.ldr < p.cout)) return CS_EINVAL;
-  if (p.math != CS_MATH_FP32 && !f16x3) return CS_EINVAL;
-  const int64_t M64 = (int64_t)p.nb * p.dout * p.hout * p.wout;
-  if (M64 > 0x7fffffffLL) return CS_EINVAL;
-  const int M = (int)M64;
-  int tile = p.tile;
-  if (tile == 5 && !(f16x3 && cs_pw_gemm_f16x3_applicable(p, M))) return CS_EINVAL;
-  if (tile == 0 && f16x3 && cs_pw_gemm_f16x3_applicable(p, M) && cs_pw_gemm_f16x3_preferred(p, M))
-    tile = 5;                                        // short-K token GEMMs: persistent ping-pong kernel
-  if (tile == 0) {
+// tile of an automatic (desc->tile == 0) launch that is not the ping-pong kernel's
+static int auto_tile(const CsConvGemm& p, int M, bool f16x3) {
+  int tile = 0;
+  {
     // largest tile that still gives every one of the 256 CUs a workgroup; small problems take the 64x64 tile
     // (measured at CFG batch 2: 64x64 is ~2x the 128x224 tile, which leaves 3/4 of the chip idle)
     const int64_t mt = (M + 127) / 128;
@@ -403,7 +383,39 @@ extern "C" int cs_conv_gemm(const CsConvGemm* d, cs_stream_t stream) {
     // epilogue with the other's K loop: 805 vs 867 us at 65536 x 448 -> 3584 (the 672-channel one prefers 256 rows)
     if (p.act == CS_ACT_GEGLU && tile == 4 && (p.cin + 15) / 16 <= 32) tile = 2;
   }
+  return tile;
+}
+
+// omap_f / omap_p != 0 (cs_conv_gemm_up2 only): this GEMM is one output parity class of a folded Upsample conv and
+// stores straight into the doubled grid (cs_gemm_f16x3.hip, slab4 kernel); d->out / d->ldo are then the final tensor's
+static int conv_gemm_impl(const CsConvGemm* d, cs_stream_t stream, int omap_f, int omap_p) {
+  if (!d || !d->x || !d->w || !d->out) return CS_EINVAL;
+  const CsConvGemm& p = *d;
+  if (p.nb <= 0 || p.cin <= 0 || p.cout <= 0 || p.dout <= 0 || p.hout <= 0 || p.wout <= 0)
+    return CS_EINVAL;
+  const bool f16x3 = p.math == CS_MATH_F16X3;
+  if ((p.cin & 3) || (p.lda & 3) || p.lda < p.cin) return CS_EINVAL;
+  if (!f16x3 && ((p.ldw & 3) || p.ldw < p.cout))
+    return CS_EINVAL;
+  if (((uintptr_t)p.x & 15) || ((uintptr_t)p.w & 15)) return CS_EINVAL;
+  if (p.kd <= 0 || p.kh <= 0 || p.kw <= 0 || p.sd <= 0 || p.sh <= 0 || p.sw <= 0) return CS_EINVAL;
+  if (p.ud < 0 || p.uh < 0 || p.uw < 0 || p.ud > 4 || p.uh > 4 || p.uw > 4) return CS_EINVAL;
+  if (p.scale && !p.shift) return CS_EINVAL;
+  if (p.rowvec && p.rv_rows <= 0) return CS_EINVAL;
+  const int out_cols = (p.act == CS_ACT_GEGLU) ? p.cout / 2 : p.cout;
+  if (p.act == CS_ACT_GEGLU && (!f16x3 || (p.cout & 1))) return CS_EINVAL;
+  if (p.ldo < out_cols || (p.res && p.ldr < p.cout)) return CS_EINVAL;
+  if (p.math != CS_MATH_FP32 && !f16x3) return CS_EINVAL;
+  const int64_t M64 = (int64_t)p.nb * p.dout * p.hout * p.wout;
+  if (M64 > 0x7fffffffLL) return CS_EINVAL;
+  const int M = (int)M64;
+  int tile = p.tile;
+  if (tile == 5 && !(f16x3 && cs_pw_gemm_f16x3_applicable(p, M))) return CS_EINVAL;
+  if (tile == 0 && f16x3 && cs_pw_gemm_f16x3_applicable(p, M) && cs_pw_gemm_f16x3_preferred(p, M))
+    tile = 5;                                        // short-K token GEMMs: persistent ping-pong kernel
+  if (tile == 0) tile = auto_tile(p, M, f16x3);
   hipStream_t s = (hipStream_t)stream;
+  if (p.splitk > 1 && omap_f) return CS_EINVAL;
   if (p.splitk > 1) {
     // caller-requested split-K (cs_conv_gemm_plan): partial tiles to the workspace, then reduce + epilogue
     auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
@@ -427,8 +439,9 @@ extern "C" int cs_conv_gemm(const CsConvGemm* d, cs_stream_t stream) {
     CS_CHECK_LAUNCH();
     return CS_OK;
   }
+  if (omap_f && (!f16x3 || tile == 5)) return CS_EINVAL;
   if (tile == 5) return cs_pw_gemm_f16x3_launch(p, M, s);
-  if (f16x3) return cs_conv_gemm_f16x3_dispatch(p, M, tile, 1, s);
+  if (f16x3) return cs_conv_gemm_f16x3_dispatch(p, M, tile, 1, s, omap_f, omap_p);
   switch (tile) {
     case 1: return launch<2, 2, 2, 2>(p, M, s);
     case 2: return launch<1, 7, 4, 1>(p, M, s);
@@ -441,6 +454,8 @@ extern "C" int cs_conv_gemm(const CsConvGemm* d, cs_stream_t stream) {
     default: return CS_EINVAL;
   }
 }
+
+extern "C" int cs_conv_gemm(const CsConvGemm* d, cs_stream_t stream) { return conv_gemm_impl(d, stream, 0, 0); }
 
 // ---------------------------------------------------------------------------------------------------------
 // Nearest x2 upsampling followed by a 3x3x3 stride-1 conv (Upsample: openai_model_3d.py:150-153, vqvae_modules.py:
@@ -561,7 +576,7 @@ extern "C" int cs_conv_gemm_up2(const CsConvGemm* d, const void* const* w_cls, c
   const int nh = d->uh ? 2 : 1, nw = d->uw ? 2 : 1;
   const int ncls = (d->ud ? 2 : 1) * nh * nw;
   float* tmp = reinterpret_cast<float*>(ws);
-  for (int cls = 0; cls < ncls; ++cls) {
+  auto class_desc = [&](int cls) {
     const int pw = cls % nw, ph = (cls / nw) % nh, pd = cls / (nw * nh);
     CsConvGemm q = *d;
     q.kd = d->ud ? 2 : 3; q.kh = d->uh ? 2 : 3; q.kw = d->uw ? 2 : 3;
@@ -574,6 +589,31 @@ extern "C" int cs_conv_gemm_up2(const CsConvGemm* d, const void* const* w_cls, c
     q.out = tmp + (int64_t)cls * m1 * d->cout;
     q.ldo = d->cout;
     q.tile = 0;
+    return q;
+  };
+  // r3: where every class runs the four-tap slab kernel unsplit, the classes store straight into the doubled grid (the
+  // kernel's scattered-store epilogue) -- no scratch tensor, no interleave pass (2.06 of 57.8 ms per 32-object decode,
+  // 0.23 ms of a UNet step).  CS_NO_UP2_DIRECT=1: scratch + interleave everywhere (A/B runs, the equality test).
+  static const char* e_dir = getenv("CS_NO_UP2_DIRECT");
+  bool direct = f16x3 && !(e_dir && *e_dir == '1') && m1 * (int64_t)ncls <= 0x7fffffffLL;
+  for (int cls = 0; cls < ncls && direct; ++cls) {
+    const CsConvGemm q = class_desc(cls);
+    direct = plan_splitk(q, m1) <= 1 && cs_f16x3_slab4_ok(q, auto_tile(q, (int)m1, true), 1);
+  }
+  if (direct) {
+    const int omap_f = (d->ud ? 4 : 0) | (d->uh ? 2 : 0) | (d->uw ? 1 : 0);
+    for (int cls = 0; cls < ncls; ++cls) {
+      const int pw = cls % nw, ph = (cls / nw) % nh, pd = cls / (nw * nh);
+      CsConvGemm q = class_desc(cls);
+      q.out = d->out;
+      q.ldo = d->ldo;
+      const int rc = conv_gemm_impl(&q, stream, omap_f, (pd << 2) | (ph << 1) | pw);
+      if (rc != CS_OK) return rc;
+    }
+    return CS_OK;
+  }
+  for (int cls = 0; cls < ncls; ++cls) {
+    CsConvGemm q = class_desc(cls);
     const int s = plan_splitk(q, m1);
     q.splitk = s > 1 ? s : 0;
     q.splitk_ws = s > 1 ? (void*)(tmp + (int64_t)ncls * m1 * d->cout) : nullptr;

@@ -75,7 +75,7 @@ template <int WMB, int WNB, int WAVES_M, int WAVES_N, bool PRE, int SLAB = 0, bo
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_kernel(const CsConvGemm p, int M, int tiles_n,
                                                               int taps_hw, int kw_, int kg_per_tap,
                                                               long long x_bytes, unsigned w_bytes, int vec_epilogue,
-                                                              int splits) {
+                                                              int splits, int omap_f, int omap_p) {
   constexpr int BM = 32 * WMB * WAVES_M;
   constexpr int BN = 32 * WNB * WAVES_N;
   constexpr int NW = WAVES_M * WAVES_N;            // waves per workgroup (4, or 8 for the 256-row tile)
@@ -119,7 +119,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   // the pipelined epilogue re-uses the LDS from offset 0 (staging + two residual slabs per wave + the vector rows)
   constexpr int EP_KU = (4 * (32 * WNB / 4) + 63) / 64;
   constexpr int EPI_NEED = NW * (16 * 32 * WNB) + NW * 2 * EP_KU * 1024 + 2048;
-  constexpr int LDS_BYTES = (ROWMIN + 16 > EPI_NEED) ? ROWMIN + 16 : EPI_NEED;
+  // (TPK == 4, the folded Upsample convs: int32 [BM] output-row table of the scattered store, see the epilogue)
+  constexpr int OTAB = ((ROWMIN + 16 > EPI_NEED) ? ROWMIN + 16 : EPI_NEED);
+  constexpr int LDS_BYTES = OTAB + (TPK == 4 ? BM * 4 : 0);
   constexpr short INVALID = (short)0x8000;
   // ---- DMA schedule: wave-instructions of 64 x 16 B ----
   constexpr int A_WI = BM / 16;                    // A wave-instructions per chunk
@@ -676,6 +678,37 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   // residual loads) per lane -- issue-bound, and for the short-K token GEMMs as long as the main loop.  Stage
   // 16 rows x (32*WNB) columns per wave through the (now idle) LDS ring and write whole rows as float4.
   float* const outp = p.out + (int64_t)split * M * p.ldo;      // split-K: slice s owns rows [s*M, (s+1)*M) of the ws
+  // r3: scattered store of one output parity class of a folded Upsample conv (cs_conv_gemm_up2) -- GEMM row m = source
+  // voxel (n, d, h, w) lands on row ((n*Do + d*fd + pd)*Ho + h*fh + ph)*Wo + w*fw + pw of the DOUBLED grid, so the
+  // classes write the final tensor themselves and the scratch tensor + interleave pass are gone.  omap_f / omap_p: bit
+  // 2 / 1 / 0 = D / H / W doubled / parity.  The row map of the tile goes to LDS once (otab, relative to the tile's
+  // first output row `ob`); every store path below takes its row from it.
+  const bool omap = (TPK == 4) && omap_f != 0;
+  int* const otab = reinterpret_cast<int*>(smem + OTAB);
+  long long ob = m0, Mo = M;
+  int ospan = BM;                                              // rows the tile's stores span (32-bit offset window)
+  if constexpr (TPK == 4) {
+    if (omap) {
+      const int fd = 1 + ((omap_f >> 2) & 1), fh = 1 + ((omap_f >> 1) & 1), fw = 1 + (omap_f & 1);
+      const int qd = (omap_p >> 2) & 1, qh = (omap_p >> 1) & 1, qw = omap_p & 1;
+      auto orow = [&](int m) -> long long {
+        const int w = m % p.win;
+        int t = m / p.win;
+        const int h = t % p.hin;
+        t /= p.hin;
+        const int d = t % p.din;
+        const int n = t / p.din;
+        return (((long long)n * (p.din * fd) + d * fd + qd) * (p.hin * fh) + h * fh + qh) * (p.win * fw) + w * fw + qw;
+      };
+      ob = orow(m0);
+      Mo = (long long)M * (fd * fh * fw);
+      const int mlast = min(m0 + BM, M) - 1;
+      ospan = (int)(orow(mlast) - ob) + 1;
+      for (int r = tid; r < BM; r += NT) otab[r] = (m0 + r < M) ? (int)(orow(m0 + r) - ob) : 0;
+      __syncthreads();
+    }
+  }
+  auto orel = [&](int row) -> int { return omap ? otab[row] : row; };     // row of the tile -> row offset from `ob`
   constexpr int WCOLS = 32 * WNB;
   constexpr int PASS_R = (NW * 16 * WCOLS * 4 <= DUMP) ? 8 : 4;             // accumulator registers per pass
   constexpr int EPI_ROWS = 2 * PASS_R;                                       // rows staged per wave per pass
@@ -707,7 +740,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
     const bool has_res = p.res != nullptr;
     const bool piped = !(CS_ABLATE & 32) && vec_epilogue && (p.res || p.bias || p.rowvec) && !p.scale && splits == 1 &&
                        n0 + BN <= p.cout && (!p.rowvec || (m0 / p.rv_rows == m_last / p.rv_rows)) &&
-                       (long long)BM * p.ldo * 4 < 0x7FF00000LL && (!p.res || (long long)BM * p.ldr * 4 < 0x7FF00000LL);
+                       (long long)ospan * p.ldo * 4 < 0x7FF00000LL && (!p.res || (long long)BM * p.ldr * 4 < 0x7FF00000LL);
     if (piped) {
       __syncthreads();                                       // every wave has left the ring
       float* const ep = reinterpret_cast<float*>(smem + wave * EPB);
@@ -715,11 +748,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
       float* const vb = reinterpret_cast<float*>(smem + VEC0);
       float* const vr = vb + 256;
       // per-tile descriptor windows (32-bit offsets inside BM rows)
-      const long long o_skip = (long long)m0 * p.ldo * 4, r_skip = (long long)m0 * p.ldr * 4;
-      const long long o_left = ((long long)(M - 1) * p.ldo + p.cout) * 4 - o_skip;
+      const long long o_skip = ob * p.ldo * 4, r_skip = (long long)m0 * p.ldr * 4;
+      const long long o_left = ((Mo - 1) * p.ldo + p.cout) * 4 - o_skip;
       const long long r_left = has_res ? ((long long)(M - 1) * p.ldr + p.cout) * 4 - r_skip : 0;
       const long long o_cols = geglu ? p.cout / 2 : p.cout;
-      const long long o_left2 = ((long long)(M - 1) * p.ldo + o_cols) * 4 - o_skip;
+      const long long o_left2 = ((Mo - 1) * p.ldo + o_cols) * 4 - o_skip;
       (void)o_left;
       const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(
           (void*)((char*)p.out + o_skip), 0, o_left2 > 0x7FF00000LL ? 0x7FF00000u : (unsigned)o_left2, 0x00020000);
@@ -792,7 +825,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
               }
 #pragma unroll
               for (int e = 0; e < 4; ++e) xv[e] = xv[e] * cs_gelu(gv[e]);
-              off = (unsigned)(row * p.ldo + (n0 + wn0) / 2 + 4 * c4) * 4u;
+              off = (unsigned)(orel(row) * p.ldo + (n0 + wn0) / 2 + 4 * c4) * 4u;
             }
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xv), ors, off, 0, 0);
           }
@@ -814,7 +847,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
               for (int e = 0; e < 4; ++e) v[e] = cs_act(v[e], p.act);
             }
             if (has_res) v += *reinterpret_cast<const f32x4*>(rs + (pass & 1) * (RSLAB / 4) + 4 * u);
-            off = (unsigned)(row * p.ldo + n0 + wn0 + 4 * c4) * 4u;
+            off = (unsigned)(orel(row) * p.ldo + n0 + wn0 + 4 * c4) * 4u;
           }
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, off, 0, 0);   // OOB lanes: dropped
         }
@@ -874,7 +907,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) xv[e] = xv[e] * cs_gelu(gv[e]);
-                *reinterpret_cast<f32x4*>(outp + (int64_t)m * p.ldo + (n0 + wn0) / 2 + 4 * c4) = xv;
+                *reinterpret_cast<f32x4*>(outp + (ob + orel(m - m0)) * p.ldo + (n0 + wn0) / 2 + 4 * c4) = xv;
               }
             }
           }
@@ -900,7 +933,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
                 for (int e = 0; e < 4; ++e) v[e] = cs_act(v[e], p.act);
               }
               if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (int64_t)m * p.ldr + n);
-              *reinterpret_cast<f32x4*>(outp + (int64_t)m * p.ldo + n) = v;
+              *reinterpret_cast<f32x4*>(outp + (ob + orel(m - m0)) * p.ldo + n) = v;
             }
           }
         }
@@ -926,7 +959,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
           if (p.rowvec) v += p.rowvec[(int64_t)(m / p.rv_rows) * p.ldrv + n];
           v = cs_act(v, p.act);
           if (p.res) v += p.res[(int64_t)m * p.ldr + n];
-          outp[(int64_t)m * p.ldo + n] = v;
+          outp[(ob + orel(row)) * p.ldo + n] = v;
         }
       }
     }
@@ -934,7 +967,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
 }
 
 template <int WMB, int WNB, int WAVES_M, int WAVES_N, bool PRE, int SLAB = 0, bool PAIR = false, int TPK = 9, bool PW = false>
-int launch16(const CsConvGemm& p, int M, int splits, hipStream_t stream) {
+int launch16(const CsConvGemm& p, int M, int splits, hipStream_t stream, int omap_f = 0, int omap_p = 0) {
   constexpr int BM = 32 * WMB * WAVES_M;
   constexpr int BN = 32 * WNB * WAVES_N;
   const int tiles_m = (M + BM - 1) / BM;
@@ -958,7 +991,8 @@ int launch16(const CsConvGemm& p, int M, int splits, hipStream_t stream) {
     if (!vec || (WCOLS / 2) % 4 || p.cout % WCOLS || p.scale || p.rowvec || p.res) return CS_EINVAL;
   }
   CS_LAUNCH((conv_gemm_f16x3_kernel<WMB, WNB, WAVES_M, WAVES_N, PRE, SLAB, PAIR, TPK, PW>), dim3((unsigned)nblk), dim3(64 * WAVES_M * WAVES_N), 0,
-            stream, p, M, tiles_n, p.kh * p.kw, p.kw, kg_per_tap, (long long)x_bytes, (unsigned)w_bytes, vec, splits);
+            stream, p, M, tiles_n, p.kh * p.kw, p.kw, kg_per_tap, (long long)x_bytes, (unsigned)w_bytes, vec, splits,
+            TPK == 4 ? omap_f : 0, TPK == 4 ? omap_p : 0);
   CS_CHECK_LAUNCH();
   return CS_OK;
 }
@@ -986,10 +1020,29 @@ __global__ __launch_bounds__(256) void pack_f16x3_kernel(const float* __restrict
 
 }  // namespace
 
-// called from cs_conv_gemm (cs_gemm.hip) when desc->math == CS_MATH_F16X3; arguments already validated
-int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p_in, int M, int tile, int splits, hipStream_t s) {
+// Will this descriptor run the four-taps-per-kd slab kernel (the 3x2x2 / 2x2x2 kernels of the Upsample convs folded onto
+// the source grid)?  One rule for the dispatch below and for cs_conv_gemm_up2, which lets the classes store straight
+// into the doubled grid only on that kernel.  CS_NO_SLAB4=1 keeps them on the per-tap gather (A/B runs, and the
+// reference of the equality test).
+bool cs_f16x3_slab4_ok(const CsConvGemm& p, int tile, int splits) {
+#ifdef CS_NO_SLAB
+  return false;
+#else
+  static const char* e4 = getenv("CS_NO_SLAB4");
+  return !(e4 && *e4 == '1') && p.a_format == 0 && (tile == 4 || tile == 6) && splits <= 1 && p.kh == 2 && p.kw == 2 &&
+         (p.kd == 2 || p.kd == 3) && p.sd == 1 && p.sh == 1 && p.sw == 1 && p.ud == 0 && p.uh == 0 && p.uw == 0 &&
+         (unsigned)p.pd <= 1u && (unsigned)p.ph <= 1u && (unsigned)p.pw <= 1u && (p.kd == 2 || p.pd == 1) &&
+         p.din == p.dout && p.hin == p.hout && p.win == p.wout && p.win <= 32 &&
+         (256 + 2LL * p.hin * p.win + 2 * p.win + 32) * p.lda * 4 < 0x7FF00000LL;
+#endif
+}
+
+// called from cs_conv_gemm (cs_gemm.hip) when desc->math == CS_MATH_F16X3; arguments already validated.
+// omap_f / omap_p != 0: scattered store of one parity class of a folded Upsample conv (slab4 kernel only, see its epilogue)
+int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p_in, int M, int tile, int splits, hipStream_t s, int omap_f, int omap_p) {
   CsConvGemm p = p_in;
   if (splits < 1) splits = 1;
+  if (omap_f && !cs_f16x3_slab4_ok(p, tile, splits)) return CS_EINVAL;
   if (p.a_scale == 0.f) p.a_scale = A_SCALE_DEFAULT;
   if (!p.w_lo || !(p.acc_scale > 0.f) || !(p.a_scale > 0.f)) return CS_EINVAL;
   if (p.kd * p.kh * p.kw > MAX_TAPS) return CS_EINVAL;                             // LDS row table extent
@@ -1069,20 +1122,12 @@ int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p_in, int M, int tile, int spl
     }
   }
   if (p.a_format != 0) return CS_EINVAL;
-#ifndef CS_NO_SLAB
-  {
-    // r3: the 3x2x2 / 2x2x2 kernels of the Upsample convs folded onto the source grid (cs_conv_gemm_up2): slab path with
-    // four taps per kd.  CS_NO_SLAB4=1 keeps them on the per-tap gather (A/B runs, and the reference of the equality test).
-    static const char* e4 = getenv("CS_NO_SLAB4");
-    const bool slab4 = !(e4 && *e4 == '1') && splits == 1 && p.kh == 2 && p.kw == 2 && (p.kd == 2 || p.kd == 3) &&
-                       p.sd == 1 && p.sh == 1 && p.sw == 1 && p.ud == 0 && p.uh == 0 && p.uw == 0 &&
-                       (unsigned)p.pd <= 1u && (unsigned)p.ph <= 1u && (unsigned)p.pw <= 1u && (p.kd == 2 || p.pd == 1) &&
-                       p.din == p.dout && p.hin == p.hout && p.win == p.wout && p.win <= 32 &&
-                       (256 + 2LL * p.hin * p.win + 2 * p.win + 32) * p.lda * 4 < 0x7FF00000LL;
-    if (slab4 && tile == 4) return launch16<1, 7, 8, 1, false, 32, false, 4>(p, M, splits, s);
-    if (slab4 && tile == 6) return launch16<1, 4, 8, 1, false, 32, false, 4>(p, M, splits, s);
+  // r3: the 3x2x2 / 2x2x2 kernels of the Upsample convs folded onto the source grid (cs_conv_gemm_up2): slab path with
+  // four taps per kd
+  if (cs_f16x3_slab4_ok(p, tile, splits)) {
+    if (tile == 4) return launch16<1, 7, 8, 1, false, 32, false, 4>(p, M, splits, s, omap_f, omap_p);
+    return launch16<1, 4, 8, 1, false, 32, false, 4>(p, M, splits, s, omap_f, omap_p);
   }
-#endif
 #ifndef CS_NO_SLAB      // (A/B timing builds: -DCS_NO_SLAB keeps the per-tap gather everywhere)
   // 3x3x3, stride 1, "same" padding, no upsampling, one K slice, 256-row tiles: the A operand comes from a slab
   // shared by the nine (kh, kw) taps of each kd (see the kernel's header)

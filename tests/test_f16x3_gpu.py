@@ -665,29 +665,37 @@ def test_folded_upsample_convs_on_the_four_tap_slab_path(tmp_path):
     """r3: the 3x2x2 / 2x2x2 kernels of the folded Upsample convs run the slab path with four taps per kd (TPK = 4: slab of
     BM + W + 1 rows starting at -pad, four-stage weight ring) instead of the per-tap gather.  Same chunk order => bit for
     bit equal to the gather path (CS_NO_SLAB4=1, separate process: the switch is read once per process), incl. the
-    W = 4 level where a tile spans samples (a NaN sample stays confined), and fp32-grade against the direct 27-tap form."""
+    W = 4 level where a tile spans samples (a NaN sample stays confined), and fp32-grade against the direct 27-tap form.
+    The slab kernel's classes also store straight into the doubled grid (scattered-store epilogue; no scratch tensor, no
+    interleave pass): equal to the interleave route (CS_NO_UP2_DIRECT=1) bit for bit, incl. a ragged last tile and an
+    output that is a channel slice of a wider buffer."""
     import os, subprocess, sys
     from pathlib import Path
     from commonscenes_amd import lib as L, ops, synth
     root = Path(__file__).resolve().parent
     outs = []
-    for arm in ("", "1"):
-        f = tmp_path / f"slab4_{arm or 0}.pt"
-        env = dict(os.environ, CS_NO_SLAB4=arm)
+    # arms: (slab kernel, classes store straight into the doubled grid) | per-tap gather + interleave | slab + interleave
+    for i, arm in enumerate(({}, {"CS_NO_SLAB4": "1"}, {"CS_NO_UP2_DIRECT": "1"})):
+        f = tmp_path / f"slab4_{i}.pt"
+        env = dict(os.environ, **arm)
         r = subprocess.run([sys.executable, str(root / "_slab4_worker.py"), str(f)], capture_output=True, text=True,
                            timeout=600, env=env)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         outs.append(torch.load(f))
-    a, b = outs
-    for k in a:
-        if k.endswith(":tile"):
-            assert int(a[k]) in (4, 6), (k, int(a[k]))          # the 256-row tiles: the ones with a four-tap slab variant
-            continue
-        if k == "unet_hw_w4":
-            assert torch.isnan(a[k][1]).all() and torch.isfinite(a[k][0]).all() and torch.isfinite(a[k][2:]).all()
-            assert torch.equal(a[k][0], b[k][0]) and torch.equal(a[k][2:], b[k][2:])
-        else:
-            assert torch.isfinite(a[k]).all() and torch.equal(a[k], b[k]), k
+    a = outs[0]
+    for b in outs[1:]:
+        for k in a:
+            if k.endswith(":tile"):
+                assert int(a[k]) in (4, 6), (k, int(a[k]))      # the 256-row tiles: the ones with a four-tap slab variant
+                continue
+            if k.endswith(":pad"):
+                assert torch.equal(a[k], torch.full((4,), 7.0)), a[k]   # the scattered store stays inside its columns
+                continue
+            if k == "unet_hw_w4":
+                assert torch.isnan(a[k][1]).all() and torch.isfinite(a[k][0]).all() and torch.isfinite(a[k][2:]).all()
+                assert torch.equal(a[k][0], b[k][0]) and torch.equal(a[k][2:], b[k][2:])
+            else:
+                assert torch.isfinite(a[k]).all() and torch.equal(a[k], b[k]), k
     # against the direct form (27 taps on the doubled grid) in this process
     x = synth.tensor_device("s4:x:unet_hw", (48, 16, 8, 8, 48), 1.0)
     w = synth.tensor_device("s4:w:unet_hw", (224, 48, 3, 3, 3), (48 * 27) ** -0.5)
