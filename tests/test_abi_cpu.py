@@ -152,7 +152,7 @@ def test_every_entry_rejects_null_arguments_without_touching_the_device():
     import ctypes as C
     from commonscenes_amd import lib
     dll = lib.load()
-    skip = {"cs_abi_version", "cs_groupnorm_ws_bytes", "cs_conv_gemm_up2_ws_bytes", "cs_mc_blocks_per_object", "cs_gcn_csr_ints", "cs_unet_destroy", "cs_unet_param_count", "cs_unet_raw_bytes",
+    skip = {"cs_abi_version", "cs_groupnorm_ws_bytes", "cs_attn_f16x3_ws_bytes", "cs_conv_gemm_up2_ws_bytes", "cs_mc_blocks_per_object", "cs_gcn_csr_ints", "cs_unet_destroy", "cs_unet_param_count", "cs_unet_raw_bytes",
             "cs_unet_arena_bytes", "cs_unet_context_floats", "cs_vqvae_destroy", "cs_vqvae_param_count",
             "cs_vqvae_raw_bytes", "cs_vqvae_arena_bytes"}
     checked = 0
