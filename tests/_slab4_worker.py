@@ -17,7 +17,8 @@ CASES = [("unet_hw", (48, 16, 8, 8), 48, 224, (0, 1, 1)),      # H, W doubled (3
          ("unet_hw_w4", (200, 16, 4, 4), 32, 224, (0, 1, 1)),  # W = 4: a 256-row tile spans samples
          ("dec_dhw", (12, 16, 16, 16), 32, 128, (1, 1, 1)),    # all three doubled (2x2x2 taps), 256x128 tile
          ("dec_dhw_256", (13, 16, 16, 16), 16, 256, (1, 1, 1)),
-         ("ragged_strided", (77, 16, 5, 8), 32, 224, (0, 1, 1))]   # M = 49280 = 192.5 tiles; out = a slice of a wider buffer
+         ("ragged_strided", (77, 16, 5, 8), 32, 224, (0, 1, 1)),
+         ("unet_dhw", (96, 8, 8, 8), 32, 224, (1, 1, 1))]      # dims = 4 UNet (concat conditioning): all three doubled, 256x224 tile   # M = 49280 = 192.5 tiles; out = a slice of a wider buffer
 for name, shp, cin, cout, up in CASES:
     x = synth.tensor_device(f"s4:x:{name}", (*shp, cin), 1.0)
     x[1] = float("nan") if name == "unet_hw_w4" else x[1]      # a NaN sample must stay confined to itself
