@@ -16,6 +16,12 @@
 
 namespace {
 
+// image kernel: fragment-read ring depth (A/B builds: -DCS_ATTN_RING=0 leaves the schedule to the compiler)
+#ifndef CS_ATTN_RING
+#define CS_ATTN_RING 3
+#endif
+constexpr int RING = CS_ATTN_RING > 0 ? CS_ATTN_RING : 1;
+
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
@@ -402,24 +408,42 @@ __global__ __launch_bounds__(64 * NW) void attn_f16x3_img_kernel(const float* __
                                                                  const _Float16* __restrict__ img,
                                                                  float* __restrict__ out, int nq, int nk, int heads,
                                                                  int dh, int ldq, int ldo, float scale, int qtiles,
-                                                                 int ntiles, int32_t* __restrict__ status) {
+                                                                 int ntiles, int nbh, int32_t* __restrict__ status) {
   using I = AttnImg<DB, KT>;
   constexpr int DP = I::DP, LDK = I::LDK, LDV = I::LDV;
   constexpr int JB = KT / 32;
   constexpr int KS = DP / 16;
-  constexpr int NCH = I::TILE_BYTES / 1024;            // 1 KB (one wave-wide 16-byte DMA) chunks per tile image
+  // LDS: two K slots [Kh | Kl] then two V slots [Vh | Vl].  The K images run ONE TILE AHEAD of the V images: iteration t
+  // computes S(t + 1) = K(t + 1) Q^T next to the softmax of S(t) (independent work for the one wave a SIMD holds: MFMA
+  // under VALU) and then O += V(t) P(t); K(t + 2) and V(t + 1) are in flight meanwhile.  Same per-tile operations in the
+  // same order as attn_f16x3_kernel: bit-identical output.
+  constexpr int KBYTES = 4 * KT * LDK, VBYTES = 4 * DP * LDV;
+  static_assert(KBYTES + VBYTES == I::TILE_BYTES && KBYTES % 1024 == 0 && VBYTES % 1024 == 0, "image layout");
+  constexpr int KCH = KBYTES / 1024, VCH = VBYTES / 1024;      // 1 KB (one wave-wide 16-byte DMA) chunks
   extern __shared__ __attribute__((aligned(16))) unsigned char smb[];
   float amax = 0.f;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: the DMA chunk loop branches on it
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: the DMA chunk loops branch on it
   const int l31 = lane & 31;
   const int half = lane >> 5;
 
+  // XCD-aware placement (speed only): block w runs on XCD w % 8, each XCD has its own 4 MB L2, and the query tiles of
+  // one (sample, head) all stream the SAME tile images -- so the j-th block of XCD x takes query tile j % qtiles of group
+  // x + 8 * (j / qtiles): a group's workgroups share one L2 and run side by side (the decoder: 32 query tiles = the 32 CUs
+  // of an XCD).  In launch order every XCD would hold tiles of eight groups at once (77 MB of images against 4 MB of
+  // L2: each workgroup then pulls its 9.6 MB through the fabric, ~5 TB/s chip-wide -- that was the kernel's bound).
+#ifdef CS_ATTN_NO_XCD
   int bid = blockIdx.x;
   const int qt = bid % qtiles;
   bid /= qtiles;
+#else
+  const int xw = blockIdx.x & 7, xj = blockIdx.x >> 3;
+  const int qt = xj % qtiles;
+  const int bid = xw + 8 * (xj / qtiles);
+  if (bid >= nbh) return;                              // grid padded to a multiple of 8 groups (whole workgroup exits)
+#endif
   const int h = bid % heads;
   const int b = bid / heads;
 
@@ -431,16 +455,26 @@ __global__ __launch_bounds__(64 * NW) void attn_f16x3_img_kernel(const float* __
   const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(img + ((int64_t)b * heads + h) * ntiles * I::TILE_HALVES), 0, (unsigned)ntiles * (unsigned)I::TILE_BYTES,
       0x00020000);
-  auto dma_tile = [&](int t) {                         // image t -> ring slot t & 1; chunk c by wave c % NW
-    unsigned char* dst = smb + (t & 1) * I::TILE_BYTES;
+  auto dma_k = [&](int t) {                            // K image of tile t -> K slot t & 1; chunk c by wave c % NW
+    unsigned char* dst = smb + (t & 1) * KBYTES;
     const unsigned base = (unsigned)t * (unsigned)I::TILE_BYTES + (unsigned)lane * 16u;
 #pragma unroll
-    for (int i = 0; i < (NCH + NW - 1) / NW; ++i) {
+    for (int i = 0; i < (KCH + NW - 1) / NW; ++i) {
       const int c = wave + NW * i;                     // wave-uniform
-      if (c < NCH) __builtin_amdgcn_raw_ptr_buffer_load_lds(irs, dst + c * 1024, 16, base + (unsigned)c * 1024u, 0, 0, 0);
+      if (c < KCH) __builtin_amdgcn_raw_ptr_buffer_load_lds(irs, dst + c * 1024, 16, base + (unsigned)c * 1024u, 0, 0, 0);
     }
   };
-  dma_tile(0);
+  auto dma_v = [&](int t) {                            // V image of tile t -> V slot t & 1
+    unsigned char* dst = smb + 2 * KBYTES + (t & 1) * VBYTES;
+    const unsigned base = (unsigned)t * (unsigned)I::TILE_BYTES + (unsigned)KBYTES + (unsigned)lane * 16u;
+#pragma unroll
+    for (int i = 0; i < (VCH + NW - 1) / NW; ++i) {
+      const int c = wave + NW * i;
+      if (c < VCH) __builtin_amdgcn_raw_ptr_buffer_load_lds(irs, dst + c * 1024, 16, base + (unsigned)c * 1024u, 0, 0, 0);
+    }
+  };
+  dma_k(0);
+  dma_v(0);
 
   h8 qh[KS], ql[KS];
 #pragma unroll
@@ -465,22 +499,43 @@ __global__ __launch_bounds__(64 * NW) void attn_f16x3_img_kernel(const float* __
   const float cexp = 1.44269504088896340736f / (QK_SCALE * QK_SCALE);
   const float lp = 10.0f;             // log2(P_SCALE)
 
-  for (int t = 0; t < ntiles; ++t) {
-    const int kt0 = t * KT;
-    cs16::wait_vmcnt<0>();            // this wave's chunks of image t have landed ...
-    __syncthreads();                  // ... everyone's have, and everyone is done reading slot (t + 1) & 1
-    if (t + 1 < ntiles) dma_tile(t + 1);
-    const _Float16* Kh = reinterpret_cast<const _Float16*>(smb + (t & 1) * I::TILE_BYTES);
+  // S^T = K Q^T of tile t (its K image sits in K slot t & 1)
+  auto qk = [&](int t, f32x16 (&sacc)[JB]) {
+    const _Float16* Kh = reinterpret_cast<const _Float16*>(smb + (t & 1) * KBYTES);
     const _Float16* Kl = Kh + KT * LDK;
-    const _Float16* Vh = Kl + KT * LDK;
-    const _Float16* Vl = Vh + DP * LDV;
-
-    // ---- S^T = K Q^T ----
-    f32x16 sacc[JB];
 #pragma unroll
     for (int jb = 0; jb < JB; ++jb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) sacc[jb][r] = 0.f;
+#if CS_ATTN_RING
+    // fragment reads RING steps ahead of their MFMAs; the scheduling fences keep the compiler from sinking every read
+    // next to its use (at 512 live registers it minimises live ranges: read -> wait -> MFMA, the whole LDS latency exposed)
+    constexpr int NS = KS * JB;
+    h8 ah[RING], al[RING];
+    auto ld = [&](int st, int slot) {
+      const int tt = st / JB, jb = st - tt * JB;
+      const int off = (jb * 32 + l31) * LDK + 16 * tt + 8 * half;
+#ifdef CS_ATTN_WHATIF_NO_LDSREAD
+      ah[slot] = qh[tt]; al[slot] = ql[tt]; (void)off;
+#else
+      ah[slot] = *reinterpret_cast<const h8*>(Kh + off);
+      al[slot] = *reinterpret_cast<const h8*>(Kl + off);
+#endif
+    };
+#pragma unroll
+    for (int st = 0; st < RING && st < NS; ++st) ld(st, st);
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+      const int tt = st / JB, jb = st - tt * JB, slot = st % RING;
+      __builtin_amdgcn_sched_barrier(0);
+      const h8 kh = ah[slot], kl = al[slot];
+      sacc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[tt], sacc[jb], 0, 0, 0);
+      sacc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[tt], sacc[jb], 0, 0, 0);
+      sacc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[tt], sacc[jb], 0, 0, 0);
+      if (st + RING < NS) ld(st + RING, slot);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#else
 #pragma unroll
     for (int tt = 0; tt < KS; ++tt)
 #pragma unroll
@@ -492,23 +547,42 @@ __global__ __launch_bounds__(64 * NW) void attn_f16x3_img_kernel(const float* __
         sacc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[tt], sacc[jb], 0, 0, 0);
         sacc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[tt], sacc[jb], 0, 0, 0);
       }
+#endif
+  };
 
-    __builtin_amdgcn_sched_barrier(0);      // (keeps the V^T fragment reads from being hoisted over the K phase: spills)
-    // ---- online softmax (per query i = lane&31) ----
+  f32x16 scur[JB], snext[JB];
+  cs16::wait_vmcnt<0>();
+  __syncthreads();                    // K(0), V(0) have landed for every wave
+  if (ntiles > 1) dma_k(1);
+  qk(0, scur);
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int kt0 = t * KT;
+    cs16::wait_vmcnt<0>();            // this wave's chunks of K(t + 1) (and V(t), t > 0) have landed ...
+#ifndef CS_ATTN_WHATIF_NO_BARRIER
+    __syncthreads();                  // ... everyone's have, and everyone is done with K(t) and V(t - 1)
+#endif
+#ifndef CS_ATTN_WHATIF_NO_DMA          // (timing-only what-if builds below: wrong results)
+    if (t + 2 < ntiles) dma_k(t + 2);
+    if (t + 1 < ntiles) dma_v(t + 1);
+#endif
+    if (t + 1 < ntiles) qk(t + 1, snext);
+
+    // ---- online softmax of tile t (per query i = lane&31) ----
     if (kt0 + KT > nk) {               // ragged last tile only (wave-uniform): keys past nk take no weight
 #pragma unroll
       for (int jb = 0; jb < JB; ++jb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int j = kt0 + jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (j >= nk) sacc[jb][r] = -INFINITY;
+          if (j >= nk) scur[jb][r] = -INFINITY;
         }
     }
     float mloc = -INFINITY;
 #pragma unroll
     for (int jb = 0; jb < JB; ++jb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, sacc[jb][r]);
+      for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, scur[jb][r]);
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
     const float mnew = fmaxf(mrun, mloc);
     const float alpha = (mrun == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((mrun - mnew) * cexp);
@@ -517,19 +591,65 @@ __global__ __launch_bounds__(64 * NW) void attn_f16x3_img_kernel(const float* __
     for (int jb = 0; jb < JB; ++jb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[jb][r] - mnew, cexp, lp));   // = p * P_SCALE
-        sacc[jb][r] = pv;
+#ifdef CS_ATTN_WHATIF_NO_EXP           // (timing-only what-if build: wrong results)
+        const float pv = fmaf(scur[jb][r] - mnew, cexp, lp);
+#else
+        const float pv = __builtin_amdgcn_exp2f(fmaf(scur[jb][r] - mnew, cexp, lp));   // = p * P_SCALE
+#endif
+        scur[jb][r] = pv;
         psum += pv;
       }
     lrun = lrun * alpha + psum;
     mrun = mnew;
+#ifndef CS_ATTN_WHATIF_NO_RESCALE      // (timing-only what-if build: wrong results)
 #pragma unroll
     for (int d = 0; d < DB; ++d)
 #pragma unroll
       for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+#endif
 
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- O^T += V^T P^T ----
+    // ---- O^T += V(t)^T P^T ----
+    const _Float16* Vh = reinterpret_cast<const _Float16*>(smb + 2 * KBYTES + (t & 1) * VBYTES);
+    const _Float16* Vl = Vh + DP * LDV;
+#if CS_ATTN_RING
+    {
+      constexpr int NS = JB * 2 * DB;                    // step = ((jb, qq), d)
+      h8 ph[JB * 2], pl[JB * 2];
+#pragma unroll
+      for (int g = 0; g < JB * 2; ++g)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          _Float16 a, c;
+          split1(scur[g >> 1][8 * (g & 1) + e], a, c);
+          ph[g][e] = a;
+          pl[g][e] = c;
+        }
+      h8 ah[RING], al[RING];
+      auto ld = [&](int st, int slot) {
+        const int g = st / DB, d = st - g * DB;
+        const int off = (32 * d + l31) * LDV + 32 * (g >> 1) + 16 * (g & 1) + 8 * half;
+#ifdef CS_ATTN_WHATIF_NO_LDSREAD
+        ah[slot] = qh[d]; al[slot] = ql[d]; (void)off;
+#else
+        ah[slot] = *reinterpret_cast<const h8*>(Vh + off);
+        al[slot] = *reinterpret_cast<const h8*>(Vl + off);
+#endif
+      };
+#pragma unroll
+      for (int st = 0; st < RING && st < NS; ++st) ld(st, st);
+#pragma unroll
+      for (int st = 0; st < NS; ++st) {
+        const int g = st / DB, d = st - g * DB, slot = st % RING;
+        __builtin_amdgcn_sched_barrier(0);
+        const h8 vh = ah[slot], vl = al[slot];
+        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[g], oacc[d], 0, 0, 0);
+        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[g], oacc[d], 0, 0, 0);
+        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[g], oacc[d], 0, 0, 0);
+        if (st + RING < NS) ld(st + RING, slot);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#else
 #pragma unroll
     for (int jb = 0; jb < JB; ++jb)
 #pragma unroll
@@ -538,7 +658,7 @@ __global__ __launch_bounds__(64 * NW) void attn_f16x3_img_kernel(const float* __
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           _Float16 a, c;
-          split1(sacc[jb][8 * qq + e], a, c);
+          split1(scur[jb][8 * qq + e], a, c);
           ph[e] = a;
           pl[e] = c;
         }
@@ -552,6 +672,9 @@ __global__ __launch_bounds__(64 * NW) void attn_f16x3_img_kernel(const float* __
           oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, oacc[d], 0, 0, 0);
         }
       }
+#endif
+#pragma unroll
+    for (int jb = 0; jb < JB; ++jb) scur[jb] = snext[jb];
   }
 
   if (status && amax >= 65504.f) atomicOr(status, CS_STATUS_F16X3_OVERFLOW);
@@ -584,7 +707,11 @@ int launch_attn16_img(const float* q, const float* k, const float* v, float* out
   if ((int64_t)ntiles * I::TILE_BYTES >= 0x7FF00000LL) return CS_EINVAL;
   const int64_t pgrid = (int64_t)nb * heads * ntiles;
   const int qtiles = (nq + 32 * NW - 1) / (32 * NW);
+#ifdef CS_ATTN_NO_XCD
   const int64_t grid = (int64_t)qtiles * heads * nb;
+#else
+  const int64_t grid = (int64_t)qtiles * (((int64_t)heads * nb + 7) / 8 * 8);      // whole groups of eight (sample, head)s
+#endif
   if (pgrid > 0x7fffffffLL || grid > 0x7fffffffLL) return CS_EINVAL;
   auto pk = attn_presplit_kernel<DB, KT>;
   auto kern = attn_f16x3_img_kernel<DB, KT, NW>;
@@ -600,7 +727,7 @@ int launch_attn16_img(const float* q, const float* k, const float* v, float* out
             ntiles, status);
   CS_CHECK_LAUNCH();
   CS_LAUNCH(kern, dim3((unsigned)grid), dim3(64 * NW), (size_t)2 * I::TILE_BYTES, s, q, (const _Float16*)ws, out, nq, nk,
-            heads, dh, ldq, ldo, scale, qtiles, ntiles, status);
+            heads, dh, ldq, ldo, scale, qtiles, ntiles, nb * heads, status);
   CS_CHECK_LAUNCH();
   return CS_OK;
 }
