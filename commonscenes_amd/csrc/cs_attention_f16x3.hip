@@ -49,7 +49,7 @@ template <int DB, int KT, bool X1, int NW>
 __global__ __launch_bounds__(64 * NW) void attn_f16x3_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                          const float* __restrict__ v, float* __restrict__ out,
                                                          int nq, int nk, int heads, int dh, int ldq, int ldk,
-                                                         int ldv, int ldo, float scale, int qtiles,
+                                                         int ldv, int ldo, float scale, int qtiles, int nbh,
                                                          int32_t* __restrict__ status) {
   constexpr int DP = 32 * DB;
   float amax = 0.f;                    // largest |scaled Q / K / V operand| this lane converted to fp16
@@ -69,9 +69,18 @@ __global__ __launch_bounds__(64 * NW) void attn_f16x3_kernel(const float* __rest
   const int l31 = lane & 31;
   const int half = lane >> 5;
 
+  // XCD-aware placement (speed only; see attn_f16x3_img_kernel): the query tiles of one (sample, head) read the same K / V
+  // rows, so they go to ONE XCD (block w runs on XCD w % 8) and fetch them through the fabric once, not once per tile
+#ifdef CS_ATTN_NO_XCD
   int bid = blockIdx.x;
   const int qt = bid % qtiles;
   bid /= qtiles;
+#else
+  const int xw = blockIdx.x & 7, xj = blockIdx.x >> 3;
+  const int qt = xj % qtiles;
+  const int bid = xw + 8 * (xj / qtiles);
+  if (bid >= nbh) return;                              // grid padded to a multiple of 8 groups (whole workgroup exits)
+#endif
   const int h = bid % heads;
   const int b = bid / heads;
 
@@ -750,7 +759,11 @@ int launch_attn16(const float* q, const float* k, const float* v, float* out, in
   constexpr int DP = 32 * DB;
   const size_t smem = (size_t)(2 * KT * (DP + 8) + 2 * DP * (KT + 8)) * sizeof(_Float16);
   const int qtiles = (nq + 32 * NW - 1) / (32 * NW);
+#ifdef CS_ATTN_NO_XCD
   const int64_t grid = (int64_t)qtiles * heads * nb;
+#else
+  const int64_t grid = (int64_t)qtiles * (((int64_t)heads * nb + 7) / 8 * 8);      // whole groups of eight (sample, head)s
+#endif
   if (grid > 0x7fffffffLL) return CS_EINVAL;
   auto kern = attn_f16x3_kernel<DB, KT, X1, NW>;
   if (smem > 64 * 1024) {
@@ -758,7 +771,7 @@ int launch_attn16(const float* q, const float* k, const float* v, float* out, in
     if (e != hipSuccess) return (int)e;
   }
   CS_LAUNCH(kern, dim3((unsigned)grid), dim3(64 * NW), smem, s, q, k, v, out, nq, nk, heads, dh, ldq, ldk, ldv, ldo,
-            scale, qtiles, status);
+            scale, qtiles, nb * heads, status);
   CS_CHECK_LAUNCH();
   return CS_OK;
 }
