@@ -198,6 +198,9 @@ __global__ __launch_bounds__(64 * NW) void attn_f16x3_kernel(const float* __rest
   for (int kt0 = 0; kt0 < nk; kt0 += KT) {
     __syncthreads();  // previous tile fully consumed
     if constexpr (PIPE) {
+#ifdef CS_ATTN_WHATIF_NO_STAGE         // (timing-only what-if builds, tools/attn_unet_whatif.sh: wrong results)
+      if (kt0 == 0)
+#endif
       store_tile();
     } else {
       for (int u = tid; u < KT * dh4; u += NT) {          // K: unit = (key j, 4 channels)
@@ -231,7 +234,11 @@ __global__ __launch_bounds__(64 * NW) void attn_f16x3_kernel(const float* __rest
       }
     }
     __syncthreads();
+#ifdef CS_ATTN_WHATIF_NO_STAGE
+    if (PIPE && kt0 == 0) load_tile(KT);
+#else
     if (PIPE && kt0 + KT < nk) load_tile(kt0 + KT);
+#endif
 
     // ---- S^T = K Q^T ----
     f32x16 sacc[JB];
@@ -276,16 +283,22 @@ __global__ __launch_bounds__(64 * NW) void attn_f16x3_kernel(const float* __rest
     for (int jb = 0; jb < JB; ++jb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
+#ifdef CS_ATTN_WHATIF_NO_EXP
+        const float pv = fmaf(sacc[jb][r] - mnew, cexp, lp);
+#else
         const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[jb][r] - mnew, cexp, lp));   // = p * P_SCALE
+#endif
         sacc[jb][r] = pv;
         psum += pv;
       }
     lrun = lrun * alpha + psum;
     mrun = mnew;
+#ifndef CS_ATTN_WHATIF_NO_RESCALE
 #pragma unroll
     for (int d = 0; d < DB; ++d)
 #pragma unroll
       for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+#endif
 
     // ---- O^T += V^T P^T ----
 #pragma unroll
