@@ -297,13 +297,38 @@ int plan_splitk(const CsConvGemm& p, int64_t M) {
   return s1 < 2 ? 1 : (int)s1;
 #endif
   if (nk < 64) return 1;
-  // r3: long K loops (>= 1024 chunks: the 4^3-level 3x3x3 convs) take one more doubling, up to 704 workgroups -- at 7
-  // objects (84 tiles) eight slices ran 268 / 491 us against 287 / 541 for four (profiles/r03_d_smallm_sweep.txt)
-  static const char* e_lim = getenv("CS_PLAN_LONGK_LIMIT");      // A/B runs: 512 = the round-2 rule
-  const int64_t limit = nk >= 1024 ? (e_lim ? atoll(e_lim) : 704) : 512;
-  int64_t s = 1;
-  while (2 * s * wgs <= limit && 2 * s <= 32 && 2 * s <= nk / 8) s *= 2;
-  return (int)s;
+  // r3: ANY slice count -- the largest s with tiles x s <= 512, i.e. exactly one round of the chip's 2-per-CU workgroup
+  // slots (at most 32 slices, at least 8 K chunks each).  The power-of-two rule left slots empty (48 tiles x 8 = 384) or
+  // spilled into a second, mostly empty round (84 tiles x 8 = 672 under the long-K exception): at 7 objects the 4^3-level
+  // convs take 6 slices (244 / 452 us against 274 / 500 for 8), at 4 objects 10 (155 / 277 against 163 / 299), at 14
+  // objects 3 (455 / 867 against 499 / 936 for 4) -- tools/gemm_smallm.py with SM_SPLITS, profiles/r03_ai_splitk_any.txt.
+  // (r2's "odd counts fight the tile map" was 48 x 11 = 528 > 512: a second round, not the oddness.)
+  // CS_PLAN_POW2=1: the previous rule (largest power of two, up to 704 workgroups for K loops of >= 1024 chunks), A/B runs.
+  // Short K loops (the 1x1x1 / token GEMMs: <= 168 chunks) keep the power-of-two rule: more, shorter slices only add
+  // partial-tile traffic there (1792 -> 448 at 2048 rows: 8 slices 40.6 us, 16 slices 43.1).
+  static const char* e_p2 = getenv("CS_PLAN_POW2");
+  if ((e_p2 && *e_p2 == '1') || !(p.kd == 3 && p.kh == 3 && p.kw == 3)) {
+    const int64_t limit = nk >= 1024 ? 704 : 512;
+    int64_t s = 1;
+    while (2 * s * wgs <= limit && 2 * s <= 32 && 2 * s <= nk / 8) s *= 2;
+    return (int)s;
+  }
+  int64_t s = 512 / wgs;
+  if (s > 32) s = 32;
+  if (s > nk / 8) s = nk / 8;
+  if (s < 1) s = 1;
+  {
+    // the slab kernel cuts K in whole super-chunks (nine taps) and is taken only where that pads the slices by at most a
+    // tenth (cs_conv_gemm_f16x3_dispatch: slab_slices_ok): the fewest slices of the same length (no empty last slice:
+    // 84 super-chunks over 15 slices of 6 is 14 slices), stepping down to the next count that qualifies
+    const int64_t nsc = 3LL * ((p.cin + 15) / 16);
+    s = (nsc + (nsc + s - 1) / s - 1) / ((nsc + s - 1) / s);
+    while (s > 1 && ((nsc + s - 1) / s) * s * 10 > nsc * 11) {
+      --s;
+      s = (nsc + (nsc + s - 1) / s - 1) / ((nsc + s - 1) / s);
+    }
+  }
+  return s < 1 ? 1 : (int)s;
 }
 
 // sums the split-K partial tiles in slice order and applies the epilogue of conv_gemm_* (bias, BN scale/shift,

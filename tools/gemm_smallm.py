@@ -6,6 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from commonscenes_amd import lib as L, ops, synth
 NB = int(os.environ.get("SM_BATCH", "2"))
+SPLITS = tuple(int(v) for v in os.environ.get("SM_SPLITS", "1,2,4,8,16,32").split(","))   # e.g. 1,2,3,4,5,6,7,8,10,12,16
+ONLY3 = bool(os.environ.get("SM_ONLY3"))                                                   # 3x3x3 shapes only
 SHAPES = [  # (d,h,w), cin, cout, k
     ((16, 4, 4), 672, 672, 3), ((16, 4, 4), 1344, 672, 3), ((16, 8, 8), 448, 448, 3), ((16, 8, 8), 1120, 448, 3),
     ((16, 16, 16), 224, 224, 3), ((16, 16, 16), 672, 224, 3), ((16, 16, 16), 448, 448, 3),
@@ -26,6 +28,8 @@ def timeit(fn, iters=20):
 
 
 for sp, cin, cout, k in SHAPES:
+    if ONLY3 and k != 3:
+        continue
     x = synth.tensor_device(f"x{sp}{cin}", (NB, *sp, cin), 1.0)
     w = synth.tensor_device(f"w{cin}{cout}{k}", (cout, cin, k, k, k) if k > 1 else (cout, cin), (3.0 / (cin * k ** 3)) ** 0.5)
     b = synth.tensor_device(f"b{cout}", (cout,), 0.1)
@@ -33,7 +37,7 @@ for sp, cin, cout, k in SHAPES:
     M = NB * sp[0] * sp[1] * sp[2]
     nk = k ** 3 * ((cin + 15) // 16)
     res = {"auto": timeit(lambda: ops.conv_gemm(x, pw))}
-    for s in (1, 2, 4, 8, 16, 32):
+    for s in SPLITS:
         if s <= nk // 2 and cout % 224 == 0:
             res[f"t2/s{s}"] = timeit(lambda: ops.conv_gemm(x, pw, tile=2, splitk=s if s > 1 else None) if s > 1 else ops.conv_gemm(x, pw, tile=2, splitk=0))
     res["t3"] = timeit(lambda: ops.conv_gemm(x, pw, tile=3, splitk=0))
