@@ -249,7 +249,8 @@ __global__ void relayout_weight_kernel(const float* __restrict__ w, float* __res
 }  // namespace
 
 int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p, int M, int tile, int splits, hipStream_t s, int omap_f = 0,
-                                int omap_p = 0);                                        // cs_gemm_f16x3.hip
+                                int omap_p = 0, const void* const* cls_w = nullptr, const void* const* cls_w_lo = nullptr,
+                                const float* cls_acc = nullptr, int ncls = 0);          // cs_gemm_f16x3.hip
 bool cs_f16x3_slab4_ok(const CsConvGemm& p, int tile, int splits);                      // cs_gemm_f16x3.hip
 bool cs_pw_gemm_f16x3_applicable(const CsConvGemm& p, int64_t M);                                   // cs_gemm_pw.hip
 bool cs_pw_gemm_f16x3_preferred(const CsConvGemm& p, int64_t M);
@@ -413,7 +414,9 @@ static int auto_tile(const CsConvGemm& p, int M, bool f16x3) {
 
 // omap_f / omap_p != 0 (cs_conv_gemm_up2 only): this GEMM is one output parity class of a folded Upsample conv and
 // stores straight into the doubled grid (cs_gemm_f16x3.hip, slab4 kernel); d->out / d->ldo are then the final tensor's
-static int conv_gemm_impl(const CsConvGemm* d, cs_stream_t stream, int omap_f, int omap_p) {
+static int conv_gemm_impl(const CsConvGemm* d, cs_stream_t stream, int omap_f, int omap_p,
+                          const void* const* cls_w = nullptr, const void* const* cls_w_lo = nullptr,
+                          const float* cls_acc = nullptr, int ncls = 0) {
   if (!d || !d->x || !d->w || !d->out) return CS_EINVAL;
   const CsConvGemm& p = *d;
   if (p.nb <= 0 || p.cin <= 0 || p.cout <= 0 || p.dout <= 0 || p.hout <= 0 || p.wout <= 0)
@@ -466,7 +469,7 @@ static int conv_gemm_impl(const CsConvGemm* d, cs_stream_t stream, int omap_f, i
   }
   if (omap_f && (!f16x3 || tile == 5)) return CS_EINVAL;
   if (tile == 5) return cs_pw_gemm_f16x3_launch(p, M, s);
-  if (f16x3) return cs_conv_gemm_f16x3_dispatch(p, M, tile, 1, s, omap_f, omap_p);
+  if (f16x3) return cs_conv_gemm_f16x3_dispatch(p, M, tile, 1, s, omap_f, omap_p, cls_w, cls_w_lo, cls_acc, ncls);
   switch (tile) {
     case 1: return launch<2, 2, 2, 2>(p, M, s);
     case 2: return launch<1, 7, 4, 1>(p, M, s);
@@ -624,6 +627,16 @@ extern "C" int cs_conv_gemm_up2(const CsConvGemm* d, const void* const* w_cls, c
   for (int cls = 0; cls < ncls && direct; ++cls) {
     const CsConvGemm q = class_desc(cls);
     direct = plan_splitk(q, m1) <= 1 && cs_f16x3_slab4_ok(q, auto_tile(q, (int)m1, true), 1);
+  }
+  // ... and as ONE launch over all classes (virtual tile range [class][tile]): 192-workgroup class GEMMs (the UNet's 4^3
+  // level at 32 objects) fill the chip together, and seven launch ramps go.  CS_NO_UP2_BATCH=1: one launch per class.
+  static const char* e_bat = getenv("CS_NO_UP2_BATCH");
+  if (direct && !(e_bat && *e_bat == '1') && (int64_t)ncls * ((m1 + 255) / 256) * ((d->cout + 63) / 64) < 0x7fffffffLL) {
+    const int omap_f = (d->ud ? 4 : 0) | (d->uh ? 2 : 0) | (d->uw ? 1 : 0);
+    CsConvGemm q = class_desc(0);
+    q.out = d->out;
+    q.ldo = d->ldo;
+    return conv_gemm_impl(&q, stream, omap_f, 0, w_cls, w_lo_cls, acc_scale_cls, ncls);
   }
   if (direct) {
     const int omap_f = (d->ud ? 4 : 0) | (d->uh ? 2 : 0) | (d->uw ? 1 : 0);

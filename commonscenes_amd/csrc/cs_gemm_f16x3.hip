@@ -23,6 +23,7 @@
 // + halo, so they hit L1/L2 instead of re-streaming the activation tensor per tap).
 // fp16 32x32x16 operand map: lane l holds row/col l&31 and k = 8*(l>>5) .. 8*(l>>5)+7; C/D as for fp32.
 #include <cstdlib>
+#include <cstring>
 #include "cs_f16x3.h"
 #include <type_traits>
 
@@ -71,11 +72,19 @@ constexpr int MAX_TAPS = 27;
 // PW (r3) = pointwise: 1x1x1, stride 1, no upsampling -- every token / Linear GEMM and skip convolution.  Output row m reads
 // source row m, so the per-workgroup source-row tables (three integer divisions per row, an atomicMin, two barriers in the
 // prologue) and the per-DMA-instruction table look-up in the K loop are replaced by one validity bit per lane.
+// per-class operands of a batched folded-Upsample launch (TPK == 4 kernels; n <= 1: unused)
+struct CsClsBatch {
+  const void* w[8];
+  const void* w_lo[8];
+  float acc_scale[8];
+  int n;
+};
+
 template <int WMB, int WNB, int WAVES_M, int WAVES_N, bool PRE, int SLAB = 0, bool PAIR = false, int TPK = 9, bool PW = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_kernel(const CsConvGemm p, int M, int tiles_n,
                                                               int taps_hw, int kw_, int kg_per_tap,
                                                               long long x_bytes, unsigned w_bytes, int vec_epilogue,
-                                                              int splits, int omap_f, int omap_p) {
+                                                              int splits, int omap_f, int omap_p_in, const CsClsBatch cb) {
   constexpr int BM = 32 * WMB * WAVES_M;
   constexpr int BN = 32 * WNB * WAVES_N;
   constexpr int NW = WAVES_M * WAVES_N;            // waves per workgroup (4, or 8 for the 256-row tile)
@@ -148,6 +157,30 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
     const int q = nblk >> 3, r = nblk & 7, xcd = b & 7, within = b >> 3;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
   }
+  // Class-dependent operands.  TPK == 4 only: ONE launch may cover all output parity classes of a folded Upsample conv
+  // (cs_conv_gemm_up2, cb.n = 4 or 8) -- the virtual tile range is then [class][tile], each class with its own packed
+  // weights / accumulator scale, its pads = 1 - parity in the doubled dims and its scatter parity; at 32 objects the 4^3
+  // level's classes are 192 workgroups each (a quarter of the CUs idle per launch), together 768 = three even rounds.
+  const void* w_hi_ = p.w;
+  const void* w_lo_ = p.w_lo;
+  float acc_scale_ = p.acc_scale;
+  int pad_d = p.pd, pad_h = p.ph, pad_w = p.pw, omap_p = omap_p_in;
+  if constexpr (TPK == 4) {
+    if (cb.n > 1) {
+      const int per_cls = ((M + BM - 1) / BM) * tiles_n;          // (splits == 1 on this route)
+      const int cls = tile / per_cls;
+      tile -= cls * per_cls;
+      w_hi_ = cb.w[cls];
+      w_lo_ = cb.w_lo[cls];
+      acc_scale_ = cb.acc_scale[cls];
+      const int nw = 1 + (omap_f & 1), nh = 1 + ((omap_f >> 1) & 1);
+      const int qw = cls % nw, qh = (cls / nw) % nh, qd = cls / (nw * nh);
+      pad_d = (omap_f & 4) ? 1 - qd : 1;
+      pad_h = (omap_f & 2) ? 1 - qh : 1;
+      pad_w = (omap_f & 1) ? 1 - qw : 1;
+      omap_p = (qd << 2) | (qh << 1) | qw;
+    }
+  }
   // split-K: consecutive virtual tiles are the K slices of one output tile (same XCD: they share the A rows).
   // Slab kernel with K slices (the large-batch four-way cut of the 4^3-level convs: 49 MB of weights per conv, far
   // beyond an XCD's L2): row tiles fastest instead, so the workgroups an XCD runs together stream the SAME weight
@@ -168,8 +201,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   const int m0 = tm * BM;
   const int n0 = tn * BN;
 
-  const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, w_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_lo, 0, w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc((void*)w_hi_, 0, w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc((void*)w_lo_, 0, w_bytes, 0x00020000);
 
   // ---- source-row tables, built once per workgroup ----
   const int ntaps = p.kd * taps_hw;
@@ -195,15 +228,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
       const int od = mm % p.dout;
       const int n = mm / p.dout;
       // reference position: the (clamped) source voxel of the window origin
-      const int cd = min(max(od * p.sd - p.pd, 0), vdin - 1) >> p.ud;
-      const int ch = min(max(oh * p.sh - p.ph, 0), vhin - 1) >> p.uh;
-      const int cw = min(max(ow * p.sw - p.pw, 0), vwin - 1) >> p.uw;
+      const int cd = min(max(od * p.sd - pad_d, 0), vdin - 1) >> p.ud;
+      const int ch = min(max(oh * p.sh - pad_h, 0), vhin - 1) >> p.uh;
+      const int cw = min(max(ow * p.sw - pad_w, 0), vwin - 1) >> p.uw;
       const int base = ((n * p.din + cd) * p.hin + ch) * p.win + cw;
       if (sub == 0) {
         rowbase[row] = base;
         if (m < M) atomicMin(rowmin, base);      // not simply row 0: with upsampling / clamped borders a later row of
       }                                          // a tile that starts mid-line can sit at a smaller source row
-      const int vd0 = od * p.sd - p.pd, vh0 = oh * p.sh - p.ph, vw0 = ow * p.sw - p.pw;
+      const int vd0 = od * p.sd - pad_d, vh0 = oh * p.sh - pad_h, vw0 = ow * p.sw - pad_w;
       int t = 0;
       for (int kd_ = 0; kd_ < p.kd; ++kd_)
         for (int kh_ = 0; kh_ < p.kh; ++kh_)
@@ -228,7 +261,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   // rows), with 32-bit offsets inside a window of a few MB.  The tensor itself may therefore be larger than
   // the 4 GiB a single descriptor spans (288 GB of HBM: 200+ objects per batch at the 16^3 x 672-channel level).
   // (slab: the lowest row any of the three kd slabs can start at)
-  const int row_lo = SLAB ? max(0, m0 - p.pd * p.hin * p.win - p.ph * p.win - p.pw)
+  const int row_lo = SLAB ? max(0, m0 - pad_d * p.hin * p.win - pad_h * p.win - pad_w)
                      : PW ? m0 : __builtin_amdgcn_readfirstlane(*rowmin);
   const long long x_skip = (long long)row_lo * p.lda * (PRE ? 2 : 4);
   const long long x_left = x_bytes - x_skip;
@@ -437,8 +470,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
 #pragma unroll
         for (int t = 0; t < 3 * TPK; ++t) {               // (kd >= p.kd: never used)
           const int kd_ = t / TPK, kh_ = (t / KW_) % KW_, kwi = t % KW_;
-          if ((unsigned)(od + kd_ - p.pd) < (unsigned)p.din && (unsigned)(oh + kh_ - p.ph) < (unsigned)p.hin &&
-              (unsigned)(ow + kwi - p.pw) < (unsigned)p.win)
+          if ((unsigned)(od + kd_ - pad_d) < (unsigned)p.din && (unsigned)(oh + kh_ - pad_h) < (unsigned)p.hin &&
+              (unsigned)(ow + kwi - pad_w) < (unsigned)p.win)
             vmask[i] |= 1u << t;
         }
       }
@@ -464,7 +497,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   const int KD = p.kd;                                     // 3, or 2 for a folded depth dimension
   auto issue_slab = [&](int sc) {
     const int cc = sc / KD, kd_ = sc - KD * cc;
-    const int src0 = m0 + (kd_ - p.pd) * s_hw - p.ph * s_w - p.pw;
+    const int src0 = m0 + (kd_ - pad_d) * s_hw - pad_h * s_w - pad_w;
     unsigned char* dst = smem + (sc & 1) * SLAB_BYTES;
 #pragma unroll
     for (int i = 0; i < SLAB_PW; ++i) {
@@ -804,7 +837,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
 #pragma unroll
         for (int j = 0; j < WNB; ++j)
 #pragma unroll
-          for (int rr = 0; rr < QR; ++rr) ep[(rr + QR * half) * WCOLS + 32 * j + l31] = acc[i][j][QR * q + rr] * p.acc_scale;
+          for (int rr = 0; rr < QR; ++rr) ep[(rr + QR * half) * WCOLS + 32 * j + l31] = acc[i][j][QR * q + rr] * acc_scale_;
         if (geglu) {
           // columns of this wave = [x (WCOLS/2) | gate (WCOLS/2)] (weights packed that way by the host):
           // out[m][n/2 ..] = (x + bias_x) * gelu(gate + bias_g)   -- attention.py:44-46 fused into ff.net.0.proj
@@ -882,7 +915,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
           for (int rr = 0; rr < PASS_R; ++rr) {
             const int r = PASS_R * ph + rr;
             const int lrow = (r & 3) + 8 * ((r >> 2) % (PASS_R / 4)) + 4 * half;
-            ep[lrow * WCOLS + 32 * j + l31] = acc[i][j][r] * p.acc_scale;
+            ep[lrow * WCOLS + 32 * j + l31] = acc[i][j][r] * acc_scale_;
           }
         // same-wave LDS ops are ordered; the compiler waits on lgkmcnt before the reads below
         if (p.act == CS_ACT_GEGLU) {
@@ -954,7 +987,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
         const int row = wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
         const int m = m0 + row;
         if (nok && m < M) {
-          float v = acc[i][j][r] * p.acc_scale + bias;
+          float v = acc[i][j][r] * acc_scale_ + bias;
           if (p.scale) v = v * sc + sh;
           if (p.rowvec) v += p.rowvec[(int64_t)(m / p.rv_rows) * p.ldrv + n];
           v = cs_act(v, p.act);
@@ -967,12 +1000,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
 }
 
 template <int WMB, int WNB, int WAVES_M, int WAVES_N, bool PRE, int SLAB = 0, bool PAIR = false, int TPK = 9, bool PW = false>
-int launch16(const CsConvGemm& p, int M, int splits, hipStream_t stream, int omap_f = 0, int omap_p = 0) {
+int launch16(const CsConvGemm& p, int M, int splits, hipStream_t stream, int omap_f = 0, int omap_p = 0,
+             const CsClsBatch* cls = nullptr) {
   constexpr int BM = 32 * WMB * WAVES_M;
   constexpr int BN = 32 * WNB * WAVES_N;
   const int tiles_m = (M + BM - 1) / BM;
   const int tiles_n = (p.cout + BN - 1) / BN;
-  const int64_t nblk = (int64_t)tiles_m * tiles_n * splits;
+  CsClsBatch cb;
+  memset(&cb, 0, sizeof(cb));
+  if (cls && TPK == 4 && cls->n > 1 && splits == 1 && omap_f) cb = *cls;
+  const int64_t nblk = (int64_t)tiles_m * tiles_n * splits * (cb.n > 1 ? cb.n : 1);
   if (nblk > 0x7fffffffLL) return CS_EINVAL;
   const int kg_per_tap = ((p.cin + 15) / 16) * 2;
   // buffer-descriptor extents: everything the loader may touch, and < 0xFFE00000 so OOB stays out of range
@@ -992,7 +1029,7 @@ int launch16(const CsConvGemm& p, int M, int splits, hipStream_t stream, int oma
   }
   CS_LAUNCH((conv_gemm_f16x3_kernel<WMB, WNB, WAVES_M, WAVES_N, PRE, SLAB, PAIR, TPK, PW>), dim3((unsigned)nblk), dim3(64 * WAVES_M * WAVES_N), 0,
             stream, p, M, tiles_n, p.kh * p.kw, p.kw, kg_per_tap, (long long)x_bytes, (unsigned)w_bytes, vec, splits,
-            TPK == 4 ? omap_f : 0, TPK == 4 ? omap_p : 0);
+            TPK == 4 ? omap_f : 0, TPK == 4 ? omap_p : 0, cb);
   CS_CHECK_LAUNCH();
   return CS_OK;
 }
@@ -1039,10 +1076,25 @@ bool cs_f16x3_slab4_ok(const CsConvGemm& p, int tile, int splits) {
 
 // called from cs_conv_gemm (cs_gemm.hip) when desc->math == CS_MATH_F16X3; arguments already validated.
 // omap_f / omap_p != 0: scattered store of one parity class of a folded Upsample conv (slab4 kernel only, see its epilogue)
-int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p_in, int M, int tile, int splits, hipStream_t s, int omap_f, int omap_p) {
+// ncls > 1 (with omap_f): ONE launch covers all ncls parity classes -- class c has the packed weights cls_w[c] / cls_w_lo[c]
+// and accumulator scale cls_acc[c]; its pads and scatter parity follow from c and omap_f (see the kernel)
+int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p_in, int M, int tile, int splits, hipStream_t s, int omap_f, int omap_p,
+                                const void* const* cls_w, const void* const* cls_w_lo, const float* cls_acc, int ncls) {
   CsConvGemm p = p_in;
   if (splits < 1) splits = 1;
   if (omap_f && !cs_f16x3_slab4_ok(p, tile, splits)) return CS_EINVAL;
+  CsClsBatch cb;
+  memset(&cb, 0, sizeof(cb));
+  if (ncls > 1) {
+    if (!omap_f || ncls > 8 || !cls_w || !cls_w_lo || !cls_acc) return CS_EINVAL;
+    for (int c = 0; c < ncls; ++c) {
+      if (!cls_w[c] || !cls_w_lo[c] || !(cls_acc[c] > 0.f)) return CS_EINVAL;
+      cb.w[c] = cls_w[c];
+      cb.w_lo[c] = cls_w_lo[c];
+      cb.acc_scale[c] = cls_acc[c];
+    }
+    cb.n = ncls;
+  }
   if (p.a_scale == 0.f) p.a_scale = A_SCALE_DEFAULT;
   if (!p.w_lo || !(p.acc_scale > 0.f) || !(p.a_scale > 0.f)) return CS_EINVAL;
   if (p.kd * p.kh * p.kw > MAX_TAPS) return CS_EINVAL;                             // LDS row table extent
@@ -1125,8 +1177,8 @@ int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p_in, int M, int tile, int spl
   // r3: the 3x2x2 / 2x2x2 kernels of the Upsample convs folded onto the source grid (cs_conv_gemm_up2): slab path with
   // four taps per kd
   if (cs_f16x3_slab4_ok(p, tile, splits)) {
-    if (tile == 4) return launch16<1, 7, 8, 1, false, 32, false, 4>(p, M, splits, s, omap_f, omap_p);
-    return launch16<1, 4, 8, 1, false, 32, false, 4>(p, M, splits, s, omap_f, omap_p);
+    if (tile == 4) return launch16<1, 7, 8, 1, false, 32, false, 4>(p, M, splits, s, omap_f, omap_p, &cb);
+    return launch16<1, 4, 8, 1, false, 32, false, 4>(p, M, splits, s, omap_f, omap_p, &cb);
   }
 #ifndef CS_NO_SLAB      // (A/B timing builds: -DCS_NO_SLAB keeps the per-tap gather everywhere)
   // 3x3x3, stride 1, "same" padding, no upsampling, one K slice, 256-row tiles: the A operand comes from a slab

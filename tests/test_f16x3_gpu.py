@@ -667,15 +667,17 @@ def test_folded_upsample_convs_on_the_four_tap_slab_path(tmp_path):
     bit equal to the gather path (CS_NO_SLAB4=1, separate process: the switch is read once per process), incl. the
     W = 4 level where a tile spans samples (a NaN sample stays confined), and fp32-grade against the direct 27-tap form.
     The slab kernel's classes also store straight into the doubled grid (scattered-store epilogue; no scratch tensor, no
-    interleave pass): equal to the interleave route (CS_NO_UP2_DIRECT=1) bit for bit, incl. a ragged last tile and an
-    output that is a channel slice of a wider buffer."""
+    interleave pass) and run as ONE launch over all parity classes: equal to the interleave route (CS_NO_UP2_DIRECT=1) and
+    to one launch per class (CS_NO_UP2_BATCH=1) bit for bit, incl. a ragged last tile, an output that is a channel slice of a
+    wider buffer and a 4.4 GiB output."""
     import os, subprocess, sys
     from pathlib import Path
     from commonscenes_amd import lib as L, ops, synth
     root = Path(__file__).resolve().parent
     outs = []
-    # arms: (slab kernel, classes store straight into the doubled grid) | per-tap gather + interleave | slab + interleave
-    for i, arm in enumerate(({}, {"CS_NO_SLAB4": "1"}, {"CS_NO_UP2_DIRECT": "1"})):
+    # arms: (slab kernel, ONE launch over all classes, each storing straight into the doubled grid) | per-tap gather +
+    # interleave | slab + interleave | slab, scattered store, one launch per class
+    for i, arm in enumerate(({}, {"CS_NO_SLAB4": "1"}, {"CS_NO_UP2_DIRECT": "1"}, {"CS_NO_UP2_BATCH": "1"})):
         f = tmp_path / f"slab4_{i}.pt"
         env = dict(os.environ, **arm)
         r = subprocess.run([sys.executable, str(root / "_slab4_worker.py"), str(f)], capture_output=True, text=True,
