@@ -87,8 +87,10 @@ def parse():
                          "batch; ~1-2 min of host time); quick = one mini-batch of 7, one step, scaled")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the fp32-input-MFMA comparison steps")
     ap.add_argument("--traffic", action="store_true",
-                    help="measure the dominant kernel's HBM bytes per launch now: two rocprofv3 --pmc passes "
-                         "(FETCH_SIZE, WRITE_SIZE) of a short run of this script (tools/pmc_traffic.sh)")
+                    help="(default at one GPU unless --no-extras / --no-traffic) measure the dominant kernel's HBM bytes per "
+                         "launch now: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of a short run of this script "
+                         "(tools/pmc_traffic.sh); each pass is bounded by a timeout and a failure leaves the field null")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc passes: roofline.traffic = null")
     ap.add_argument("--math", choices=["fp32", "f16x3"], default=os.environ.get("CS_MATH", "f16x3"),
                     help="GEMM numerics: fp32-input MFMA, or fp32 carried as fp16 hi/lo pairs on the fp16 MFMA")
     ap.add_argument("--driver", choices=["python", "native"], default="python",
@@ -186,7 +188,11 @@ def measure_traffic(ksub: str, a):
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", c, "--output-format", "csv", "-d", f"{td}/{c}", "-o", "p", "--",
                    sys.executable, str(Path(__file__).resolve()), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
                    "--no-extras", "--no-fp32-leg", "--objects", str(a.objects), "--math", a.math]
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True)
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True,
+                                   timeout=240)
+            except (subprocess.TimeoutExpired, OSError):
+                return None
             files = glob.glob(f"{td}/{c}/**/*counter_collection.csv", recursive=True)
             if r.returncode != 0 or not files:
                 return None
@@ -540,8 +546,19 @@ def main():
         roof["traffic_note"] = ("null: not measured in this run (PMC counters need rocprofv3 around the process; "
                                 "`bench.py --traffic` measures it in the run that prints it: profiles/r03_traffic.json is "
                                 "that measurement for this round's kernels, 562 MB per launch)")
-        if a.traffic and world == 1 and roof.get("rocprof_kernel"):
-            tr = measure_traffic(roof["rocprof_kernel"], a)
+        want_traffic = a.traffic or not (a.no_traffic or a.no_extras or a.small)
+        # never from inside a profiler session (the child passes would inherit the outer tool's injection)
+        traced = [k for k in os.environ if k.startswith(("ROCPROF", "ROCP_TOOL", "ROCTRACER")) or k == "HSA_TOOLS_LIB"]
+        if traced and not a.traffic:
+            want_traffic = False
+            roof["traffic_note"] = ("null: this run is itself being profiled (" + traced[0] + " is set), the --pmc passes were "
+                                    "skipped; profiles/r03_traffic.json is the measurement for this round's kernels")
+        if want_traffic and world == 1 and roof.get("rocprof_kernel"):
+            try:
+                tr = measure_traffic(roof["rocprof_kernel"], a)
+            except Exception as e:                       # a profiler hiccup must not cost the bench line
+                tr = None
+                roof["traffic_note"] = f"null: the rocprofv3 --pmc passes failed ({type(e).__name__}: {e})"
             if tr:
                 roof["traffic"] = tr["hbm_bytes_per_launch"]
                 roof["traffic_note"] = tr["note"]

@@ -8,7 +8,7 @@ timeout 900 python bench.py --traffic > gpurun_out/r03_z_bench.json 2> gpurun_ou
 python -c "import json; d=json.load(open('gpurun_out/r03_z_bench.json')); r=d['roofline']; print(d['value'], d['ms_per_step'], r['frac'], r['avg_launch_ms'], r['launches'], r['traffic'], d['c2']['ms_per_step'], d['c7']['ms_per_step'], d['decode']['ms_per_object'], d['cpu_baseline']['value'], d['fp32_mfma']['value'])"
 REPO=$(pwd)
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/prof_r03z -o bench -- python $REPO/bench.py --no-cpu-baseline --gemm-table > $REPO/gpurun_out/r03_z_bench_under_rocprof.json 2> $REPO/gpurun_out/r03_z_gemm_table.txt
+timeout 600 rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/prof_r03z -o bench -- python $REPO/bench.py --no-cpu-baseline --no-traffic --gemm-table > $REPO/gpurun_out/r03_z_bench_under_rocprof.json 2> $REPO/gpurun_out/r03_z_gemm_table.txt
 timeout 600 rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/prof_r03z2 -o bench -- python $REPO/bench.py --no-cpu-baseline --no-extras > $REPO/gpurun_out/r03_z_bench_steploop_under_rocprof.json 2> /dev/null
 cd $REPO
 DB=$(find gpurun_out/prof_r03z -name "*.db" | head -1)
