@@ -460,7 +460,15 @@ static int conv_gemm_impl(const CsConvGemm* d, cs_stream_t stream, int omap_f, i
     part.bias = part.scale = part.shift = part.rowvec = part.res = nullptr;
     part.act = CS_ACT_NONE;
     // small batches: 128x224 tiles; the large-batch four-way cut (plan_splitk) keeps the 256x224 slab kernel
-    const int rc = cs_conv_gemm_f16x3_dispatch(part, M, split4_large(p, M) ? 4 : 2, p.splitk, s);
+    // r3: K-sliced 3x3x3 slab convs run the 256x224 tile at EVERY batch size (one 8-wave workgroup per CU: 256 slots,
+    // the same slice count as 512 slots of the 128-row tile) -- 4-7 % faster than the 128x224 tile on every shape from
+    // 1 to 14 objects (tools/gemm_smallm_t4.py, profiles/r03_an_tile4_slices*.txt); convs the slab kernel does not take
+    // (strided, W > 32) keep the 128-row tile.  CS_SLICE_TILE2=1: the previous rule, A/B runs.
+    static const char* e_t2 = getenv("CS_SLICE_TILE2");
+    const bool slab3 = !(e_t2 && *e_t2 == '1') && p.kd == 3 && p.kh == 3 && p.kw == 3 && p.sd == 1 && p.sh == 1 &&
+                       p.sw == 1 && p.pd == 1 && p.ph == 1 && p.pw == 1 && !(p.ud | p.uh | p.uw) && p.din == p.dout &&
+                       p.hin == p.hout && p.win == p.wout && p.win <= 32;
+    const int rc = cs_conv_gemm_f16x3_dispatch(part, M, (split4_large(p, M) || p.tile == 4 || slab3) ? 4 : 2, p.splitk, s);
     if (rc != CS_OK) return rc;
     CS_LAUNCH(splitk_reduce_kernel, dim3(cs_grid_for((int64_t)M * (p.cout >> 2), 256)), dim3(256), 0, s, p,
               reinterpret_cast<const float*>(p.splitk_ws), M, p.splitk);

@@ -481,6 +481,9 @@ def conv_gemm(x: Tensor, w: PackedWeight, *, spatial: Optional[Tuple[int, int, i
                       rv_rows=rv_rows if rowvec is not None else 0, conv3_win=wd if c3 else 0, presplit=xs is not None)
         if p.splitk > 1 and tl in (8, 9):
             tl -= 1 if tl == 8 else 3
+        if p.splitk > 1 and math == L.MATH_F16X3:
+            # K-sliced launches: the 256x224 tile for slab convs (r3), the 128x224 tile otherwise (cs_conv_gemm)
+            tl = 4 if (c3 and wd <= 32 and not os.environ.get("CS_SLICE_TILE2")) or tl == 4 else 2
         prof.append(dict(e0=e0, e1=e1, flops=2.0 * mo * w.cout * w.cin * kd * kh * kw, taps=kd * kh * kw,
                          m=mo, n=w.cout, k=w.cin * kd * kh * kw, tile=tl,
                          slab=slab_width(tl, (kd, kh, kw), stride, up, wd, math, xs is not None, p.splitk),
