@@ -801,13 +801,22 @@ static int attn16_dispatch(const float* q, const float* k, const float* v, float
     return CS_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   if (dh <= 32) return launch_attn16<1, 64, X1>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, s);
+  // eight waves per staged tile amortise the K / V conversion over 256 queries -- but only once such workgroups fill the
+  // chip: at small batches (1 object: 16 (sample, head) groups, 64 workgroups at 1024 tokens, 16 at 256) four-wave
+  // workgroups double the count on a mostly idle GPU (1 object: 71.4 -> 60.0 us and 34.5 -> 31.7; from 128 eight-wave
+  // workgroups up they lose: 224 -> 448 workgroups at 14 objects' 256-token level 48.7 -> 55.2 us;
+  // profiles/r03_ar_attn_nw.txt).  Same per-query arithmetic either way: bit-identical.
+  // CS_ATTN_NW8=1: the previous rule (eight waves from 512 / 256 queries), A/B runs.
+  static const char* e_nw = getenv("CS_ATTN_NW8");
+  const bool fill8 = (e_nw && *e_nw == '1') || (int64_t)nb * heads * ((nq + 255) / 256) >= 128;
   if (dh <= 64) {
-    if (nq >= 512)      // eight waves per staged tile: the K / V conversion is amortised over 256 queries
+    if (nq >= 512 && fill8)
       return launch_attn16<2, 64, X1, 8>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, s);
     return launch_attn16<2, 64, X1>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, s);
   }
   if (dh <= 96) {
-    if (nq >= 256) return launch_attn16<3, 64, X1, 8>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, s);
+    if (nq >= 256 && fill8)
+      return launch_attn16<3, 64, X1, 8>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, s);
     return launch_attn16<3, 64, X1>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, s);
   }
   if (dh <= 128) return launch_attn16<4, 64, X1>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, s);
