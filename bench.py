@@ -21,6 +21,9 @@ Prints ONE JSON line (rank 0):
   decode                VQ-VAE decode of the rank's 32 latents (quantise + Decoder3D, 723 GFLOP/object), own roofline block;
   end_to_end            steps/s with decode + all-gather amortised over the S-step run (what a whole sample() costs);
   c2                    BASELINE configs[1]: ONE object (N=1 only): ms/step and steps/s;
+  c7 / c7x5             the reference's sampler mini-batch of 7 (ms per object-step), and the DEFAULT product call
+                        SDFusionText2ShapeModel.rel2shape on 32 objects (mini_B = 7 slices coalesced into one launch
+                        batch, r4) next to the reference's own five sequential mini-batches (launch_B = 0);
   mesh                  sdf_to_mesh (HIP marching cubes) of 32 analytic 64^3 SDFs (N=1 only);
   cpu_baseline          the CPU oracle (oracle/ref_torch.py -- a port; the reference cannot travel) on a bounded sample.
 """
@@ -132,7 +135,12 @@ def cpu_baseline(df, cfg, objects_per_step: int, quick: bool = False):
 
     torch.set_num_threads(cores)
     out = dict(unit="DDIM steps/s (32 objects)", kind="port", cores=cores, host_cores=host_cores,
-               torch=torch.__version__, oracle="oracle/ref_torch.py (CPU fp32, pinned on the reference's goldens)")
+               torch=torch.__version__, oracle="oracle/ref_torch.py (CPU fp32, pinned on the reference's goldens)",
+               cores_note=(f"BASELINE.md section 4 says 'all host cores'; {cores} of {host_cores} are used because that is "
+                           "the FASTEST setting on this host, i.e. the strongest CPU baseline: oneDNN's conv3d regresses "
+                           "beyond it at these batch sizes (profiles/r01_cpu_threads.txt, CFG batch 4: 16 threads 0.42 "
+                           "s/sample, 32: 0.43, 64: 0.75, 128: 1.77); the one-batch leg also tries 64 threads and keeps "
+                           "the faster; CS_CPU_THREADS overrides"))
     if quick:
         steps(7, 1, "w")
         dt = steps(7, 1, "q")
@@ -216,6 +224,68 @@ def measure_traffic(ksub: str, a):
                 fetch_correction=corr, raw=res,
                 note=f"measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE, separate passes around "
                      f"`bench.py --steps 2 --warmup 1`; FETCH_SIZE x{corr:.3f} (calibrated on ln_kernel<2>'s 112 MiB read)")
+
+
+def measure_mfma_busy(ksubs, a):
+    """Matrix-pipe occupancy and effective clock of the kernels whose names contain one of `ksubs`, from ONE more
+    rocprofv3 pass (--kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE, nothing else) around a
+    short child run of this script (the power-ceiling argument must rest on this round's binaries).
+      effective clock = GRBM_GUI_ACTIVE / 8 XCDs / the dispatch's own duration in the same pass
+      mfma_busy_frac  = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)   (MI355X_MICROARCH.md: the counter
+                        counts cycles, 32 per 32x32x16 MFMA)"""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None
+    ctrs = ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_MFMA", "GRBM_GUI_ACTIVE")
+    with tempfile.TemporaryDirectory(dir="/tmp") as td:
+        cmd = ["rocprofv3", "--kernel-trace", "--pmc", *ctrs, "--output-format", "csv", "-d", f"{td}/m", "-o", "p", "--",
+               sys.executable, str(Path(__file__).resolve()), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+               "--no-extras", "--no-fp32-leg", "--objects", str(a.objects), "--math", a.math]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True,
+                               timeout=300)
+        except (subprocess.TimeoutExpired, OSError):
+            return None
+        files = glob.glob(f"{td}/m/**/*counter_collection.csv", recursive=True)
+        if r.returncode != 0 or not files:
+            return None
+        dur = {}
+        for f in glob.glob(f"{td}/m/**/*kernel_trace.csv", recursive=True):
+            for row in csv.DictReader(open(f)):
+                try:
+                    dur[row["Dispatch_Id"]] = float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+                except (KeyError, ValueError):
+                    pass
+        per = {}                                         # (ksub, dispatch) -> counters
+        for row in csv.DictReader(open(files[0])):
+            ks = next((k for k in ksubs if k in row["Kernel_Name"]), None)
+            if ks is None or row["Counter_Name"] not in ctrs:
+                continue
+            d = per.setdefault((ks, row["Dispatch_Id"]), {})
+            d[row["Counter_Name"]] = d.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+            if "Start_Timestamp" in row and row.get("End_Timestamp"):
+                try:
+                    d["ns"] = float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+                except ValueError:
+                    pass
+    out = {}
+    for ks in ksubs:
+        rows = [dict(v, ns=v.get("ns", dur.get(did))) for (k, did), v in per.items() if k == ks]
+        rows = [v for v in rows if all(c in v for c in ctrs) and v["GRBM_GUI_ACTIVE"] > 0]
+        if not rows:
+            continue
+        gui = sum(v["GRBM_GUI_ACTIVE"] for v in rows) / 8.0
+        busy = sum(v["SQ_VALU_MFMA_BUSY_CYCLES"] for v in rows)
+        ns = sum(v["ns"] for v in rows if v.get("ns"))
+        out[ks] = dict(launches=len(rows), mfma_busy_frac=busy / (1024.0 * gui),
+                       effective_clock_ghz=(gui / ns) if ns else None,
+                       mfma_insts_per_launch=sum(v["SQ_INSTS_MFMA"] for v in rows) / len(rows),
+                       avg_launch_us_under_pmc=(ns / len(rows) / 1e3) if ns else None)
+    return out or None
 
 
 def gemm_summary(prof, wall_ms, math):
@@ -409,7 +479,7 @@ def main():
     overflow = ops.read_status(dev) != 0
 
     # ---- extras, outside the timed region: decode of this rank's latents, the all-gather, one object (C2) ----
-    decode = e2e = c2 = c7 = mesh = fp32_leg = None
+    decode = e2e = c2 = c7 = c7x5 = mesh = fp32_leg = None
     if not a.no_extras and not a.small:
         vq = VQVAE(K.VQVAE_DDCONFIG, K.VQVAE_N_EMBED, K.VQVAE_EMBED_DIM, device=dev).set_math(a.math)
         vq.load_state_dict(synth.synth_state_dict(vqvae_param_shapes(K.VQVAE_DDCONFIG, K.VQVAE_N_EMBED,
@@ -504,6 +574,30 @@ def main():
                   "ms_per_step": d7 * 1e3, "ms_per_object_step": d7 * 1e3 / nb7,
                   "whole_step_tflops": 2 * nb7 * K.UNET_GFLOP_PER_SAMPLE / d7 / 1e3}
             df.reset_run_cache() if hasattr(df, "reset_run_cache") else None
+            # c7x5 (VERDICT r3 next #1a): what the DEFAULT product API delivers for the metric's 32 objects --
+            # SDFusionText2ShapeModel.rel2shape(data, ddim_steps=S, uc_scale=3.0): mini-batches of 7 as the reference
+            # slices them (sdfusion_txt2shape_model.py:493-511), coalesced into one launch batch (r4), decode included --
+            # next to the reference's own schedule of five sequential sampler runs (launch_B=0)
+            import tempfile
+            from commonscenes_amd.sdfusion import SDFusionText2ShapeModel
+            with tempfile.TemporaryDirectory(dir="/tmp") as tdir:
+                pm = SDFusionText2ShapeModel(K.write_yaml_configs(tdir, unet=cfg))
+            pm.df = pm.df_module = df                     # the weights already resident (same classes the model builds)
+            pm.vqvae = pm.vqvae_module = vq
+            data = {"sdf": torch.zeros(B, 1), "rel": c, "uc": uc}
+            pm.rel2shape(data, ddim_steps=S, uc_scale=3.0, x_T=x_T, max_steps=2)            # warm the allocator
+            c7x5 = {"workload": f"{B} objects through the default product call rel2shape(ddim_steps={S}, uc_scale=3.0): "
+                                f"mini_B={pm.mini_B} slices, launch_B={pm.launch_B}; decode to 64^3 included"}
+            for key, kw in (("default_api", {}), ("reference_minibatching", {"launch_B": 0})):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                g_sdf = pm.rel2shape(data, ddim_steps=S, uc_scale=3.0, x_T=x_T, **kw)
+                torch.cuda.synchronize()
+                dtp = time.perf_counter() - t0
+                c7x5[key] = {"seconds": dtp, "launch_sizes": list(pm.last_launch_sizes), "steps_per_s": S / dtp,
+                             "ms_per_object_step": dtp * 1e3 / (S * B), "finite": bool(torch.isfinite(g_sdf).all().item())}
+            c7x5["speedup"] = c7x5["reference_minibatching"]["seconds"] / c7x5["default_api"]["seconds"]
+            del g_sdf, pm
         if world == 1 and a.math == "f16x3" and not a.no_fp32_leg:
             # the same workload on the fp32-input MFMA kernels (the reference's dtype on the matrix pipe it maps to), so
             # that what CS_MATH_F16X3 buys is on the record next to the metric; 1 warm-up + 2 timed steps
@@ -563,6 +657,25 @@ def main():
                 roof["traffic"] = tr["hbm_bytes_per_launch"]
                 roof["traffic_note"] = tr["note"]
                 roof["traffic_detail"] = tr
+            # r4: matrix-pipe occupancy + effective clock of the dominant kernel, the pointwise token kernel and the UNet's
+            # 1024-token attention kernel, measured on THIS run's binaries (one more --pmc pass)
+            tok = "conv_gemm_f16x3_kernel<1, 7, 8, 1, false, 0, true, 9, true>"
+            att = "attn_f16x3_kernel<2, 64"
+            try:
+                mb = measure_mfma_busy([roof["rocprof_kernel"], tok, att], a)
+            except Exception as e:
+                mb = None
+                roof["mfma_busy_note"] = f"null: the rocprofv3 --pmc pass failed ({type(e).__name__}: {e})"
+            if mb:
+                dk = mb.get(roof["rocprof_kernel"])
+                if dk:
+                    roof["mfma_busy_frac"] = dk["mfma_busy_frac"]
+                    roof["effective_clock_ghz"] = dk["effective_clock_ghz"]
+                roof["mfma_busy_detail"] = {"dominant": dk, "token_gemm_pointwise_pair": mb.get(tok),
+                                            "attention_1024_tokens": mb.get(att)}
+                roof["mfma_busy_note"] = ("measured in this run: rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES "
+                                          "SQ_INSTS_MFMA GRBM_GUI_ACTIVE around `bench.py --steps 2 --warmup 1`; busy = "
+                                          "MFMA_BUSY / (1024 SIMDs x GUI_ACTIVE / 8 XCDs), clock = GUI_ACTIVE / 8 / duration")
         roof["whole_step_tflops"] = (2 * B * K.UNET_GFLOP_PER_SAMPLE * 1e9 * a.steps / dt / 1e12) if not a.small else None
         # executed work = what the launches of the timed region actually issued (HIP-event records of every GEMM) + the
         # self-attention and norm terms of SURVEY App. A; it is below the reference's direct form because (a) the two
@@ -594,7 +707,7 @@ def main():
                        "objects_per_gpu": B, "unet_batch": 2 * B, "ddim_steps": S,
                        "parallelism": f"object-sharded x{world} (replicated weights, no per-step collective; "
                                       "1 broadcast in, 1 all-gather out)"},
-            "roofline": roof, "decode": decode, "end_to_end": e2e, "c2": c2, "c7": c7, "fp32_mfma": fp32_leg,
+            "roofline": roof, "decode": decode, "end_to_end": e2e, "c2": c2, "c7": c7, "c7x5": c7x5, "fp32_mfma": fp32_leg,
             "mesh": mesh,
             "conditioning_ms": cond_ms["warm"], "conditioning_cold_ms": cond_ms["cold"],
             "conditioning_note": "rank 0: graph synthesis + embeddings + 5 GCN layers + rel_mlp for all objects; cold = the "

@@ -46,13 +46,21 @@ def build_native(force: bool = False, verbose: bool = True) -> Path:
     objdir.mkdir(exist_ok=True)
     procs = []
     objs = []
+    # incremental: an object is rebuilt when its source, any header, this file or the flag set is newer / different
+    stamp = objdir / "flags.txt"
+    flagstr = " ".join([*FLAGS, *extra])
+    same_flags = stamp.exists() and stamp.read_text() == flagstr
+    newest_hdr = max(d.stat().st_mtime for d in HEADERS + [Path(__file__)])
     for s in SOURCES:
         obj = objdir / (s.replace(".hip", ".o"))
+        objs.append(str(obj))
+        if (not force and same_flags and obj.exists() and obj.stat().st_mtime > (CSRC / s).stat().st_mtime
+                and obj.stat().st_mtime > newest_hdr):
+            continue
         cmd = [hipcc, *FLAGS, *extra, "-c", str(CSRC / s), "-o", str(obj)]
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-        objs.append(str(obj))
     for s, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
@@ -60,6 +68,7 @@ def build_native(force: bool = False, verbose: bool = True) -> Path:
             raise RuntimeError(f"hipcc failed on {s}")
         if verbose and out.strip():
             print(out.decode())
+    stamp.write_text(flagstr)
     tmp = LIB_PATH.with_suffix(".so.tmp")
     cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", str(tmp)]
     if verbose:

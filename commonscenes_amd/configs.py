@@ -29,6 +29,25 @@ UNET_GFLOP_EXECUTED_PER_SAMPLE = 557.9 - 38.5        # 519.4
 VQ_DECODE_GFLOP_EXECUTED_PER_OBJECT = 723.4 - 244.8  # 478.6
 
 
+def write_yaml_configs(dirpath, unet: dict = None, conditioning_key: str = "crossattn") -> dict:
+    """The `opt` mapping SDFusionText2ShapeModel / Sg2ScVAEModel take (config/v2_full.yaml's hyper / network / misc
+    sections), with df_cfg / vq_cfg written under `dirpath` from the dicts above -- for callers without a reference
+    checkout (bench.py's product-API block, the C host demo)."""
+    from pathlib import Path
+    import yaml
+    d = Path(dirpath)
+    d.mkdir(parents=True, exist_ok=True)
+    ucfg = dict(unet if unet is not None else (UNET_CONCAT if conditioning_key == "concat" else UNET_CROSSATTN))
+    (d / "df.yaml").write_text(yaml.safe_dump(dict(
+        model=dict(params=dict(conditioning_key=conditioning_key, **DIFFUSION)),
+        unet=dict(params={k: (list(v) if isinstance(v, tuple) else v) for k, v in ucfg.items()}))))
+    (d / "vq.yaml").write_text(yaml.safe_dump(dict(model=dict(params=dict(
+        embed_dim=VQVAE_EMBED_DIM, n_embed=VQVAE_N_EMBED,
+        ddconfig={k: (list(v) if isinstance(v, tuple) else v) for k, v in VQVAE_DDCONFIG.items()})))))
+    return dict(hyper=dict(device="cuda", batch_size=4),
+                network=dict(df_cfg=str(d / "df.yaml"), vq_cfg=str(d / "vq.yaml"), vq_ckpt=None), misc=dict(seed=111))
+
+
 def reduced(cfg: dict, model_channels: int = 32) -> dict:
     """the same topology at a smaller width (tests / debugging; never the benchmarked configuration)."""
     return dict(cfg, model_channels=model_channels)

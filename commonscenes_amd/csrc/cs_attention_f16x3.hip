@@ -737,13 +737,14 @@ int launch_attn16_img(const float* q, const float* k, const float* v, float* out
   if (pgrid > 0x7fffffffLL || grid > 0x7fffffffLL) return CS_EINVAL;
   auto pk = attn_presplit_kernel<DB, KT>;
   auto kern = attn_f16x3_img_kernel<DB, KT, NW>;
-  static bool once = false;      // (per instantiation) raise the dynamic-LDS limits
-  if (!once) {
+  {
+    // raise the dynamic-LDS limits on every call, as launch_attn16 does: the attribute is per device, a process may drive
+    // several (the status word is keyed per device), and a `static bool once` guard is a data race under concurrent
+    // callers.  The call is a host-side table update (~1 us), nothing next to the two launches below.
     hipError_t e = hipFuncSetAttribute((const void*)pk, hipFuncAttributeMaxDynamicSharedMemorySize, I::TILE_BYTES);
     if (e == hipSuccess)
       e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * I::TILE_BYTES);
     if (e != hipSuccess) return (int)e;
-    once = true;
   }
   CS_LAUNCH(pk, dim3((unsigned)pgrid), dim3(256), (size_t)I::TILE_BYTES, s, k, v, (_Float16*)ws, nk, heads, dh, ldk, ldv,
             ntiles, status);

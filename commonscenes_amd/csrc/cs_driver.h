@@ -39,7 +39,6 @@ struct Gemm {        // one packed GEMM weight (possibly several reference tenso
   // input-channel range [c0, c0 + cin) of source tensors that have src_cin input channels (0 = all of them): the two
   // halves of a channel-split conv (cs_unet.hip: res_block_split); the operand scale is the WHOLE tensor's either way
   int c0 = 0, src_cin = 0;
-  bool unused = false;   // registered (its parameters are part of the state_dict) but never launched: not packed
   // > 0: a thin-output 3x3x3 conv (tap_cout <= 4 output channels) run as "taps as columns": the packed weight is the
   // POINTWISE one with cout = 27 * tap_cout (+ pad) columns (cs_pack_weight_f16x3_tapcol; k = 1 here), and cs_tapsum27
   // adds the 27 shifted columns of every output channel and the bias (ops.py::pack_weight_tapcol)
@@ -148,13 +147,17 @@ int add_gemm(Plan& u, std::vector<Piece> w, std::vector<Piece> b, int cout, int 
 }
 
 // conv (k = 3 or 1) or Linear (k = 0) as a single-tensor GEMM
+// tapcol: the caller names this layer as a thin-output conv to run as "taps as columns" -- exactly the layers the Python
+// hosts name (unet.py: `out.2`, vqvae.py: `decoder.conv_out`); whether it is then taken is ops.py::tapcol_ok's rule.  (r3
+// applied the rule to ANY thin 3x3x3 conv here: a config with another one would have made the two hosts sum in a
+// different order -- ADVICE r3.)
 int add_layer_gemm(Plan& u, const std::string& p, int o, int i, int k, bool bias = true, int cin_pad = 0,
-                   int up_mask = 0) {
+                   int up_mask = 0, bool tapcol = false) {
   int wp, bp;
   add_wb(u, p, o, i, k, bias, wp, bp);
   std::vector<Piece> b;
   if (bp >= 0) b.push_back({bp, 0, o});
-  {
+  if (tapcol) {
     // ops.py::tapcol_ok -- the same rule on both hosts (CS_NO_TAPCOL=1: A/B runs)
     const char* e = getenv("CS_NO_TAPCOL");
     if (k == 3 && !up_mask && o <= 4 && (i & 3) == 0 && cin_pad == 0 && u.math == CS_MATH_F16X3 && !(e && *e)) {
@@ -196,7 +199,6 @@ void layout_arena(Plan& u) {
   int64_t off = 0;
   int slots = (int)u.params.size();
   for (Gemm& g : u.gemms) {
-    if (g.unused) continue;
     if (g.up_mask) {
       const int ftaps = g.fkd * g.fkh * g.fkw;
       g.ldw = f16 ? g.cout : (g.cout + 3) / 4 * 4;
@@ -352,8 +354,7 @@ int pack_plan(Plan* u, const void* raw_dev, void* arena_dev, cs_stream_t stream)
     float* d_amax = reinterpret_cast<float*>(arena + u->amax_off);
     if (hipMemsetAsync(d_amax, 0, (size_t)u->amax_slots * 4, st) != hipSuccess) return CS_EINVAL;
     for (const Gemm& g : u->gemms) {
-      if (g.unused) continue;
-      if (g.up_mask) {
+        if (g.up_mask) {
         const int64_t n = (int64_t)g.cout * g.cin * g.fkd * g.fkh * g.fkw;
         for (int c = 0; c < g.ncls; ++c) {
           CS_LAUNCH(absmax_kernel, dim3(cs_grid_for(n, 256, 256)), dim3(256), 0, st,
@@ -398,7 +399,6 @@ int pack_plan(Plan* u, const void* raw_dev, void* arena_dev, cs_stream_t stream)
     return CS_OK;
   };
   for (Gemm& g : u->gemms) {
-    if (g.unused) continue;
     if (g.up_mask) {      // one packed image (pair) per parity class, each with its own power-of-two scale
       const int ftaps = g.fkd * g.fkh * g.fkw;
       const int64_t n = (int64_t)g.cout * g.cin * ftaps;

@@ -273,7 +273,7 @@ int build(cs_unet& u) {
   if (const char* e = getenv("CS_CFG_SPLIT_MIN_ROWS")) u.split_min_rows = atoll(e);
   u.ch_final = ch;
   u.n_out = add_norm(u, P + "out.0", ch);
-  u.g_out = add_layer_gemm(u, P + "out.2", c.out_channels, mc, 3);
+  u.g_out = add_layer_gemm(u, P + "out.2", c.out_channels, mc, 3, true, 0, 0, /*tapcol=*/true);
   // all ResBlock emb_layers Linears read the same SiLU(emb): one GEMM [nb, 4mc] x [4mc, sum(cout)]
   u.g_emb_all = add_gemm(u, emb.w, emb.b, emb.total, ted, 0);
   u.emb_total = emb.total;

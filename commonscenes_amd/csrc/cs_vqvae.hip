@@ -87,7 +87,7 @@ int build(cs_vqvae& u) {
   }
   u.c_final = block_in;
   u.n_out = add_norm(u, D + "norm_out", block_in);
-  u.g_conv_out = add_layer_gemm(u, D + "conv_out", c.out_ch, block_in, 3);
+  u.g_conv_out = add_layer_gemm(u, D + "conv_out", c.out_ch, block_in, 3, true, 0, 0, /*tapcol=*/true);
   const int book = add_param(u, "quantize.embedding.weight", {c.n_embed, c.embed_dim});
   u.c_book = add_copy(u, book);
   // post_quant_conv (network.py:92): emits a zero 4th channel so conv_in reads float4-aligned rows

@@ -19,6 +19,15 @@ import torch.distributed as dist
 Tensor = torch.Tensor
 
 
+def _force() -> bool:
+    """TEST-ONLY switch (CS_DIST_FORCE_COLLECTIVES=1): issue the collectives even in a one-rank group.  Every function
+    below returns early at world size 1, and every multi-rank test on a one-GPU box pairs device tensors with gloo (RCCL
+    needs one GPU per rank) -- so without this the device-to-device `backend="nccl"` lines would first execute on the
+    8-GPU node.  tests/test_rccl_single_rank_gpu.py drives them through a one-rank RCCL group."""
+    import os
+    return os.environ.get("CS_DIST_FORCE_COLLECTIVES", "") == "1" and dist.is_available() and dist.is_initialized()
+
+
 def world() -> Tuple[int, int]:
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
@@ -68,7 +77,7 @@ def broadcast_conditioning(x_T: Optional[Tensor], uc: Optional[Tensor], c: Optio
             raise ValueError("broadcast_conditioning: tensor sizes do not match (n_obj, latent_shape, ctx_dim)")
     else:
         buf = torch.empty(n_lat + 2 * n_obj * ctx_dim, dtype=torch.float32, device=device)
-    if ws > 1:
+    if ws > 1 or _force():
         dist.broadcast(buf, src=src)
     return unpack_conditioning(buf, n_obj, latent_shape, ctx_dim, cond_shape)
 
@@ -77,7 +86,7 @@ def all_gather_objects(local: Tensor, total: int) -> Tensor:
     """Concatenate per-rank object slabs (contiguous shard_range order).  Shards may differ by one object:
     pad to the largest shard so a single fixed-size all-gather moves everything."""
     rank, ws = world()
-    if ws == 1 or total == 0:
+    if (ws == 1 and not _force()) or total == 0:
         return local
     sizes = [shard_range(total, ws, r)[1] - shard_range(total, ws, r)[0] for r in range(ws)]
     mx = max(sizes)               # >= 1; a rank whose shard is empty (more ranks than objects) sends only padding
@@ -98,7 +107,7 @@ def all_gather_objects(local: Tensor, total: int) -> Tensor:
 def all_reduce_max(t: Tensor) -> Tensor:
     """Element-wise max over the ranks (identity without a process group); gloo reduces on the host."""
     rank, ws = world()
-    if ws == 1:
+    if ws == 1 and not _force():
         return t
     if t.is_cuda and dist.get_backend() == "gloo":
         h = t.cpu()
@@ -112,7 +121,7 @@ def any_rank_failed(failed: bool, device) -> bool:
     """One 4-byte all-reduce that every rank reaches whether or not its shard raised: lets a failing rank tell its peers
     BEFORE the data collective, so nobody blocks in an all-gather that will never complete."""
     rank, ws = world()
-    if ws == 1:
+    if ws == 1 and not _force():
         return bool(failed)
     return bool(all_reduce_max(torch.tensor([1.0 if failed else 0.0], device=device))[0] > 0)
 

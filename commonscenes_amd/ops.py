@@ -53,11 +53,19 @@ def read_status(device=None, reset: bool = True) -> int:
     return v
 
 
+def clear_status(device=None) -> None:
+    """Stream-ordered clear of the device's status word (no read-back, no host synchronisation)."""
+    status_word(device).zero_()
+
+
 def check_overflow(device=None, what: str = "F16X3 kernels") -> None:
-    """Raise CsOverflowError if any F16X3 kernel since the last check met an activation beyond the fp16 range
-    (|a| >= 65504 / 16 ~ 4094): that launch's output is garbage; the caller re-runs with set_math('fp32')."""
+    """Raise CsOverflowError if any F16X3 kernel since the last check met an operand beyond the fp16 range: a value a
+    is carried as fp16 halves of a * a_scale, where a_scale is the layer's operand scale -- derived from the producing
+    normalisation's bound (norm_a_scale: cannot overflow) or 16 for raw activations (|a| >= 65504 / 16 ~ 4094
+    overflows).  That launch's output is garbage; the caller re-runs with set_math('fp32')."""
     if read_status(device) & L.STATUS_F16X3_OVERFLOW:
-        raise L.CsOverflowError(f"{what}: an activation left the fp16 range of CS_MATH_F16X3 (|a| * 16 >= 65504); "
+        raise L.CsOverflowError(f"{what}: an activation left the fp16 range of CS_MATH_F16X3 (|a| * a_scale >= 65504, "
+                                "a_scale = the layer's operand scale: 16 for raw activations); "
                                 "results of this run are invalid -- use set_math('fp32')")
 
 

@@ -7,11 +7,16 @@ Like the reference's BaseModel (model/base_model.py:31) this is a plain class, n
 (SURVEY F11): `.df` / `.vqvae` carry their own state and are saved under 'df' / 'vqvae' keys.
 
 Extensions over the reference (SURVEY 8b "Extension the build adds"):
-  * rel2shape(..., x_T=None, mini_B=None): inject the shared initial noise (the reference seeds it from
-    time.time(), F7) and choose the sampler mini-batch.  The DEFAULT is the reference's hard-coded 7
-    (sdfusion_txt2shape_model.py:493), so a drop-in run reproduces its batching; objects are independent, so a
-    larger mini-batch (`mini_B=32`, `model.mini_B = 32` or CS_MINI_B=32: 2.7 instead of 3.6 ms per object-step on
-    an MI355X) gives the same per-object result to ~1e-5 (different GEMM tilings add in a different order).
+  * rel2shape(..., x_T=None, mini_B=None, launch_B=None): inject the shared initial noise (the reference seeds it
+    from time.time(), F7) and choose the sampler mini-batch.  `mini_B` defaults to the reference's hard-coded 7
+    (sdfusion_txt2shape_model.py:493): the objects are SLICED exactly as the reference slices them.  Since r4 the
+    slices are then COALESCED: with the deterministic sampler (eta = 0: no per-mini-batch noise draw) consecutive
+    mini-batches are launched as one sampler run of up to `launch_B` objects (default 32 -> ceil(32 / 7) = 5
+    mini-batches per launch; `model.launch_B`, CS_LAUNCH_B; 0 = one sampler run per mini-batch, the r3 behaviour).
+    Objects are independent -- batch dimensions never mix -- so a coalesced launch gives every object the result of
+    its own mini-batch to ~1e-5 (different GEMM tilings add in a different order; gated by
+    tests/test_parity_depth_gpu.py), and the default API delivers the benchmarked 32-object throughput
+    (2.6 instead of 3.3 ms per object-step on an MI355X) instead of five sequential 7-object runs.
 """
 from __future__ import annotations
 
@@ -124,6 +129,9 @@ class SDFusionText2ShapeModel:
         self.vqvae_module = self.vqvae
         self.ddim_steps = 100                                           # :128 (hard-coded in the reference)
         self.mini_B = int(os.environ.get("CS_MINI_B", "7"))               # :493 (hard-coded 7 in the reference)
+        # objects per sampler LAUNCH: consecutive mini-batches of the deterministic sampler run as one batch (see the
+        # module docstring); 0 = never coalesce
+        self.launch_B = int(os.environ.get("CS_LAUNCH_B", "32"))
 
     def name(self):
         return "SDFusion-Text2Shape-Model"
@@ -196,8 +204,9 @@ class SDFusionText2ShapeModel:
             if hasattr(self.df, "reset_run_cache"):
                 self.df.reset_run_cache()           # per-run caches (one-token context vectors) never outlive a run
             # the status word is sticky per device: clear what earlier, unchecked F16X3 launches (a direct decode, a
-            # bench loop, a call that raised before its own check) may have left, so only THIS run is attributed
-            ops.read_status(self.device)
+            # bench loop, a call that raised before its own check) may have left, so only THIS run is attributed.
+            # Stream-ordered clear, no read-back: the one host sync per run is check_overflow's below.
+            ops.clear_status(self.device)
             out, _ = sampler.sample(S=ddim_steps, batch_size=c.shape[0], shape=shape, conditioning=c, x_T=noise,
                                     verbose=False, unconditional_guidance_scale=uc_scale,
                                     unconditional_conditioning=uc, eta=ddim_eta, max_steps=max_steps)
@@ -212,10 +221,11 @@ class SDFusionText2ShapeModel:
             warnings.warn("F16X3 activation overflow in the UNet: re-running this mini-batch (and continuing) on the "
                           "fp32-input MFMA kernels (set_math('fp32'))")
             self.df.set_math("fp32")
+            self._df_fell_back = True
             return run()
 
     def _decode_checked(self, samples):
-        ops.read_status(self.device)                # see _sample_minibatch: attribute only this decode's kernels
+        ops.clear_status(self.device)               # see _sample_minibatch: attribute only this decode's kernels
         out = self.vqvae_module.decode_no_quant(samples)
         try:
             ops.check_overflow(self.device, "VQ-VAE decode")
@@ -226,6 +236,7 @@ class SDFusionText2ShapeModel:
             import warnings
             warnings.warn("F16X3 activation overflow in the VQ-VAE decoder: re-running on the fp32-input MFMA kernels")
             self.vqvae.set_math("fp32")
+            self._vq_fell_back = True
             out = self.vqvae_module.decode_no_quant(samples)
         return out
 
@@ -233,21 +244,27 @@ class SDFusionText2ShapeModel:
         """Sharded runs: the fp32 fall-back is decided per rank (only the rank whose shard overflowed switches), which
         would leave the ranks on different numerics for every later call -- shards then stop matching the single-rank
         run bit for bit.  One tiny all-reduce after the shard is done: if ANY rank fell back, all do."""
-        flags = torch.tensor([float(getattr(self.df, "math", 0) == L.MATH_FP32),
-                              float(getattr(self.vqvae, "math", 0) == L.MATH_FP32)], device=self.device)
+        # (explicit fell-back flags, set where the fall-back is taken: a module without a `math` attribute, or one that
+        # was STARTED in fp32 (CS_MATH=fp32), must not read as "fell back" and drag its peers to fp32 -- ADVICE r3)
+        flags = torch.tensor([float(bool(getattr(self, "_df_fell_back", False))),
+                              float(bool(getattr(self, "_vq_fell_back", False)))], device=self.device)
         flags = dist.all_reduce_max(flags)
         if flags[0] > 0 and getattr(self.df, "math", None) == L.MATH_F16X3:
             self.df.set_math("fp32")
+            self._df_fell_back = True
         if flags[1] > 0 and getattr(self.vqvae, "math", None) == L.MATH_F16X3 and hasattr(self.vqvae, "set_math"):
             self.vqvae.set_math("fp32")
+            self._vq_fell_back = True
 
     @torch.no_grad()
     def rel2shape(self, data, ddim_steps=100, ddim_eta=0.0, uc_scale=None, x_T: Optional[Tensor] = None,
                   mini_B: Optional[int] = None, return_latents: bool = False, max_steps: Optional[int] = None,
-                  sharded: Optional[bool] = None, sampler: str = "ddim"):
+                  sharded: Optional[bool] = None, sampler: str = "ddim", launch_B: Optional[int] = None):
         """:459-516.  data = {'sdf': (B,...) only its batch size is used, 'rel': (B,1,1280), 'uc': (B,1,1280)}.
 
         Extensions: `x_T` injection (the reference seeds from the clock), `mini_B` (reference: 7),
+        `launch_B` (objects per sampler launch: consecutive mini-batches of the deterministic sampler are coalesced, see
+        the module docstring; None = self.launch_B, 0 = one launch per mini-batch as in the reference),
         `sampler` ('ddim' | 'plms', samplers/plms.py), and `sharded`: with torch.distributed initialised (one process
         per GPU, RCCL) the objects are split contiguously over the ranks -- rank 0's (x_T, uc, c) is broadcast once,
         every rank samples + decodes its shard, one all-gather returns ALL objects on every rank.  No per-step
@@ -278,8 +295,9 @@ class SDFusionText2ShapeModel:
         rank, ws = dist.world()
         if sharded is None:
             sharded = ws > 1 and os.environ.get("CS_SHARD", "1") != "0"
+        multi = ws > 1 or dist._force()     # (_force: test-only, drives the collectives through a one-rank RCCL group)
         lo, hi = 0, B
-        if sharded and ws > 1:
+        if sharded and multi:
             # one broadcast of the packed [x_T | uc | c] buffer: every rank then holds rank 0's bits (x_T is
             # time-seeded, and the GCN that produced uc / c ran on every rank or only on rank 0 -- either way)
             single_noise, uc, c_text = dist.broadcast_conditioning(
@@ -289,11 +307,22 @@ class SDFusionText2ShapeModel:
         r = self.vqvae.cfg["resolution"] if hasattr(self.vqvae, "cfg") else 64
         och = self.vqvae.cfg.get("out_ch", 1) if hasattr(self.vqvae, "cfg") else 1
         mb = int(mini_B or self.mini_B)
+        # :493-511 slices the objects into ceil(B / 7) mini-batches and runs the sampler once per slice.  Every object
+        # starts from the same x_T and the batch dimension never mixes, so with eta = 0 (no noise draw inside the loop)
+        # the slices are independent of how they are grouped: whole mini-batches are coalesced into launches of about
+        # launch_B objects (ceil(launch_B / mb) slices).  eta > 0 keeps one launch per slice: the sampler draws one
+        # noise tensor per slice and step (ddim.py:240), which grouping would re-order.
+        lb = int(self.launch_B if launch_B is None else launch_B)
+        step = mb
+        if lb > mb and float(ddim_eta) == 0.0:
+            step = -(-lb // mb) * mb
+        self.last_launch_sizes = []
         gen, lats = [], []
         failure: Optional[BaseException] = None
         try:
-            for i in range(lo, hi, mb):                                  # ceil((hi - lo) / mb) sampler runs (:493-511)
-                sl = slice(i, min(i + mb, hi))
+            for i in range(lo, hi, step):                                # ceil((hi - lo) / step) sampler launches
+                sl = slice(i, min(i + step, hi))
+                self.last_launch_sizes.append(sl.stop - sl.start)
                 num = sl.stop - sl.start
                 noise = single_noise.repeat(num, 1, 1, 1, 1)             # every object shares one x_T (:491)
                 samples = self._sample_minibatch(smp, ddim_steps, shape, c_text[sl], uc[sl], noise, uc_scale, ddim_eta,
@@ -301,10 +330,10 @@ class SDFusionText2ShapeModel:
                 lats.append(samples)
                 gen.append(self._decode_checked(samples))
         except Exception as e:              # noqa: BLE001 -- re-raised below, after the other ranks have been told
-            if not (sharded and ws > 1):
+            if not (sharded and multi):
                 raise
             failure = e
-        if sharded and ws > 1:
+        if sharded and multi:
             # a rank that raised must not leave its peers blocked in the all-gather: agree on failure first
             bad = dist.any_rank_failed(failure is not None, self.device)
             if failure is not None:
@@ -318,7 +347,7 @@ class SDFusionText2ShapeModel:
         else:       # an empty shard (more ranks than objects) or B == 0: nothing to sample, still join the gather
             local = torch.empty((0, och, r, r, r), dtype=torch.float32, device=self.device)
             llat = torch.empty((0, C_, D, H, W), dtype=torch.float32, device=self.device)
-        if sharded and ws > 1:
+        if sharded and multi:
             local = dist.all_gather_objects(local, B)
             if return_latents:
                 llat = dist.all_gather_objects(llat, B)

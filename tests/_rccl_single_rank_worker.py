@@ -1,0 +1,79 @@
+"""One-rank RCCL group on the GPU box (tests/test_rccl_single_rank_gpu.py): with CS_DIST_FORCE_COLLECTIVES=1 the
+early returns of commonscenes_amd/dist.py at world size 1 are skipped, so `backend="nccl"` (RCCL) runs the very calls
+an 8-GPU job makes -- device-to-device broadcast of the packed conditioning, all_gather_into_tensor of a padded slab
+(incl. an empty local shard), all_reduce MAX of the fp32 failure / math flags -- on device tensors, without a host hop."""
+import json
+import os
+import sys
+import tempfile
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ["CS_DIST_FORCE_COLLECTIVES"] = "1"
+
+import torch
+import torch.distributed as td
+
+
+def main():
+    port = int(os.environ.get("CS_RCCL_PORT", "29571"))
+    torch.cuda.set_device(0)
+    td.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    from commonscenes_amd import dist as D
+    res = dict(backend=td.get_backend(), world=td.get_world_size(), forced=D._force())
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(5)
+    # (1) broadcast of the packed [x_T | uc | c] buffer, device to device
+    B = 5
+    x_T = torch.randn(1, 3, 16, 16, 16, generator=g).to(dev)
+    uc = torch.randn(B, 1, 1280, generator=g).to(dev)
+    c = torch.randn(B, 1, 1280, generator=g).to(dev)
+    x2, uc2, c2 = D.broadcast_conditioning(x_T, uc, c, B, dev)
+    res["bcast_equal"] = bool(torch.equal(x2, x_T) and torch.equal(uc2, uc) and torch.equal(c2, c))
+    res["bcast_on_device"] = bool(x2.is_cuda and uc2.is_cuda and c2.is_cuda)
+    # the concat family's condition volume (cond_shape) and a non-contiguous source view
+    cv = torch.randn(B, 2, 16, 16, 16, generator=g).to(dev)[:, :1]
+    x3, u3, c3 = D.broadcast_conditioning(x_T, cv, cv, B, dev, ctx_dim=4096, cond_shape=(1, 16, 16, 16))
+    res["bcast_volume_equal"] = bool(torch.equal(c3, cv) and c3.shape == (B, 1, 16, 16, 16))
+    # (2) all-gather of the decoded slab: full shard, a non-contiguous slab, an EMPTY local shard, B = 0
+    sdf = torch.randn(B, 1, 64, 64, 64, generator=g).to(dev)
+    out = D.all_gather_objects(sdf, B)
+    res["gather_equal"] = bool(out.is_cuda and torch.equal(out, sdf))
+    nc = torch.randn(B, 2, 8, 8, 8, generator=g).to(dev)[:, 1:]
+    res["gather_noncontig_equal"] = bool(torch.equal(D.all_gather_objects(nc, B), nc))
+    lat = torch.randn(B, 3, 16, 16, 16, generator=g).to(dev)
+    res["gather_latents_equal"] = bool(torch.equal(D.all_gather_objects(lat, B), lat))
+    empty = torch.empty((0, 1, 64, 64, 64), dtype=torch.float32, device=dev)
+    res["gather_b0_shape"] = list(D.all_gather_objects(empty, 0).shape)
+    # (3) the fp32 flags
+    res["any_failed_false"] = D.any_rank_failed(False, dev)
+    res["any_failed_true"] = D.any_rank_failed(True, dev)
+    fl = D.all_reduce_max(torch.tensor([0.0, 1.0], device=dev))
+    res["flags"] = [float(v) for v in fl.cpu()]
+    # (4) the product call: rel2shape(sharded=True) through the same collectives == the unsharded run, bit for bit
+    from commonscenes_amd import synth
+    from test_model_gpu import _scene
+    with tempfile.TemporaryDirectory() as tdir:
+        m = _scene(Path(tdir))
+        n = 3
+        cc = synth.gaussian_like("r1:c", (n, 1, 1280)).cuda()
+        uu = synth.gaussian_like("r1:uc", (n, 1, 1280)).cuda()
+        xx = synth.gaussian_like("r1:xT", (1, 3, 16, 16, 16))
+        data = {"sdf": torch.zeros(n, 1), "rel": cc, "uc": uu}
+        kw = dict(ddim_steps=50, uc_scale=3.0, x_T=xx, return_latents=True, max_steps=2)
+        a, la = m.Diff.rel2shape(data, sharded=True, **kw)
+        os.environ["CS_DIST_FORCE_COLLECTIVES"] = "0"
+        b, lb = m.Diff.rel2shape(data, sharded=False, **kw)
+        torch.cuda.synchronize()
+        res["rel2shape_equal"] = bool(torch.equal(a, b) and torch.equal(la, lb))
+        res["rel2shape_shape"] = list(a.shape)
+    td.barrier()
+    td.destroy_process_group()
+    Path(os.environ["CS_RCCL_OUT"]).write_text(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

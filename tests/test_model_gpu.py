@@ -33,8 +33,20 @@ def _unet_cfg(small):
 _CACHE = {}
 
 
-def _unet(small, math=None):
-    """cached model; `math` None = whatever the class starts in (F16X3, the product default)."""
+# conftest forces the channel-split ResBlock route (CS_CFG_SPLIT_MIN_ROWS=0) so that the small test batches
+# run what large product batches run; the PRODUCT threshold (65536 rows: the unsplit route for these batches, i.e. what a
+# 1- to 7-object call takes) must stay under the same reference gates: goldens / trajectories are run on both.
+ROUTES = {"split": 0, "product": 65536}
+
+
+def _unet(small, math=None, route="split"):
+    """cached model; `math` None = whatever the class starts in (F16X3, the product default).  `route`: see ROUTES."""
+    df = _unet_cached(small, math)
+    df.split_min_rows = ROUTES[route]
+    return df
+
+
+def _unet_cached(small, math=None):
     key = ("unet", small)
     if key in _CACHE and math is not None:
         _CACHE[key].set_math(math)
@@ -95,10 +107,11 @@ def test_device_synth_fill_is_bit_identical_to_host():
 # ---------------------------------------------------------------------------------------------------
 # UNet
 # ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("route", ["split", "product"])
 @pytest.mark.parametrize("math", ["fp32", "f16x3"])
-def test_unet_small_vs_reference_golden(math):
+def test_unet_small_vs_reference_golden(math, route):
     g = _g("unet_small")
-    df = _unet(True, math)
+    df = _unet(True, math, route)
     df.trace = {}
     eps = df(_cu(g["x"]), _cu(g["t"]), c_crossattn=[_cu(g["ctx"])])
     torch.cuda.synchronize()
@@ -109,10 +122,11 @@ def test_unet_small_vs_reference_golden(math):
     assert rel_l2(eps, torch.from_numpy(g["eps"])) < 1e-5
 
 
+@pytest.mark.parametrize("route", ["split", "product"])
 @pytest.mark.parametrize("math", ["fp32", "f16x3"])
-def test_unet_full_vs_reference_golden(math):
+def test_unet_full_vs_reference_golden(math, route):
     g = _g("unet_full")
-    df = _unet(False, math)
+    df = _unet(False, math, route)
     eps = df(_cu(g["x"]), _cu(g["t"]), c_crossattn=[_cu(g["ctx"])])
     torch.cuda.synchronize()
     assert eps.shape == (2, 3, 16, 16, 16)

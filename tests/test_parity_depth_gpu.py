@@ -41,14 +41,14 @@ def _report(key, value):
         pass
 
 
-def _model(small, math):
+def _model(small, math, route="split"):
     from test_model_gpu import _SamplerModel, _unet
-    return _SamplerModel(_unet(small, math))
+    return _SamplerModel(_unet(small, math, route))
 
 
-def _run_traj(name, sampler_cls, small, math):
+def _run_traj(name, sampler_cls, small, math, route="split"):
     g = _g(name)
-    m = _model(small, math)
+    m = _model(small, math, route)
     B = g["c"].shape[0]
     x_T = torch.from_numpy(g["x_T"]).cuda()
     if x_T.shape[0] != B:
@@ -68,17 +68,20 @@ def _run_traj(name, sampler_cls, small, math):
     return dev, p0
 
 
+@pytest.mark.parametrize("route", ["split", "product"])
 @pytest.mark.parametrize("math", ["f16x3", "fp32"])
 @pytest.mark.parametrize("small", [True, False])
-def test_ddim_whole_trajectory_vs_reference_golden(small, math):
+def test_ddim_whole_trajectory_vs_reference_golden(small, math, route):
     """C2: one object, all 50 classifier-free-guided DDIM steps through DDIMSampler.sample (ddim.py:60-179) vs the
     reference's own loop.  Gate: rel-L2 <= 1e-4 at EVERY kept step (SURVEY 8d "k-step DDIM latent 1e-4"), final
     latent and final pred_x0 included; the per-step growth is reported."""
     from commonscenes_amd.ddim import DDIMSampler
     name = "traj_small" if small else "traj_full"
-    dev, p0 = _run_traj(name, DDIMSampler, small, math)
-    print(f"[{name} {math}] rel-L2 by step: " + ", ".join(f"{k}:{e:.2e}" for k, e in dev.items()) + f"; pred_x0 {p0:.2e}")
-    _report(f"{name}:{math}", dict(per_step=dev, pred_x0_final=p0))
+    if route == "product" and math != "f16x3":
+        pytest.skip("the product-threshold route is run in the product's math mode")
+    dev, p0 = _run_traj(name, DDIMSampler, small, math, route)
+    print(f"[{name} {math} {route}] rel-L2 by step: " + ", ".join(f"{k}:{e:.2e}" for k, e in dev.items()) + f"; pred_x0 {p0:.2e}")
+    _report(f"{name}:{math}" + ("" if route == "split" else ":product_route"), dict(per_step=dev, pred_x0_final=p0))
     assert max(dev.values()) < 1e-4, dev
     assert dev[50] < 1e-4 and p0 < 1e-4
 
@@ -372,10 +375,31 @@ def test_c4_full_width_256_objects_on_one_gpu(tmp_path):
         torch.cuda.synchronize()
         assert torch.equal(l2, lat[sl]) and torch.equal(s2, sdf[sl]), r
     # the reference's own mini-batching (7) of the same objects: same shapes to fp32 summation-order noise
-    s7, l7 = m.Diff.rel2shape({"sdf": torch.zeros(9, 1), "rel": c[:9], "uc": uc[:9]}, **dict(kw, mini_B=7))
+    # (launch_B=0: one sampler run per mini-batch, exactly the reference's loop)
+    s7, l7 = m.Diff.rel2shape({"sdf": torch.zeros(9, 1), "rel": c[:9], "uc": uc[:9]}, **dict(kw, mini_B=7, launch_B=0))
     torch.cuda.synchronize()
     from conftest import rel_l2
+    assert m.Diff.last_launch_sizes == [7, 2]
     assert rel_l2(l7, lat[:9]) < 1e-4
+    # r4: the DEFAULT call (mini_B = 7, launch_B = 32) coalesces the reference's mini-batches into launches of
+    # ceil(32 / 7) * 7 = 35 objects; every object must come out as its own 7-object mini-batch would have produced it
+    # (<= 1e-5: only the GEMM tilings, i.e. fp32 summation orders, differ), and equal conditioning -> equal result
+    kd = dict(ddim_steps=100, uc_scale=3.0, x_T=x_T, return_latents=True, max_steps=2)
+    sl40 = {"sdf": torch.zeros(40, 1), "rel": c[:40], "uc": uc[:40]}
+    assert m.Diff.mini_B == 7 and m.Diff.launch_B == 32
+    sc, lc = m.Diff.rel2shape(sl40, **kd)
+    assert m.Diff.last_launch_sizes == [35, 5]
+    sr, lr = m.Diff.rel2shape(sl40, **dict(kd, launch_B=0))
+    torch.cuda.synchronize()
+    assert m.Diff.last_launch_sizes == [7, 7, 7, 7, 7, 5]
+    worst = max(rel_l2(lc[i], lr[i]) for i in range(40))
+    print(f"[coalesced mini-batches] worst per-object latent rel-L2 vs the reference's own mini-batching: {worst:.2e}")
+    assert worst < 1e-5, worst
+    assert rel_l2(lc, lat[:40]) < 1e-5
+    # eta > 0 draws one noise tensor per mini-batch and step (ddim.py:240): those calls are never coalesced
+    m.Diff.rel2shape({"sdf": torch.zeros(9, 1), "rel": c[:9], "uc": uc[:9]}, ddim_steps=100, uc_scale=3.0, x_T=x_T,
+                     ddim_eta=0.5, max_steps=1)
+    assert m.Diff.last_launch_sizes == [7, 2]
 
 
 def test_full_size_conv_paths_agree_at_the_benchmark_shapes():
