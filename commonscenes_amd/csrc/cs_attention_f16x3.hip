@@ -757,8 +757,7 @@ int launch_attn16_img(const float* q, const float* k, const float* v, float* out
 
 // which (DB, KT, NW) the image path runs for a head width / query count, 0 = none (the in-kernel split above)
 inline int img_variant(int nq, int nk, int dh) {
-  static const char* e = getenv("CS_NO_ATTN_IMG");
-  if (e && *e == '1') return 0;
+  if (cs_debug()->no_attn_img) return 0;
   // Only where the pre-pass is amortised over many query tiles AND the in-kernel split dominates: the 256-wide variant
   // (one wave per SIMD, nothing overlaps its staging) from 8 query tiles up -- the VQ decoder's mid attention, 4096 tokens:
   // 2385 -> 1005 us per 16 objects (115 -> 270 TF/s).  Measured and left on the in-kernel split: dh 56 at 1024 tokens
@@ -808,8 +807,7 @@ static int attn16_dispatch(const float* q, const float* k, const float* v, float
   // workgroups up they lose: 224 -> 448 workgroups at 14 objects' 256-token level 48.7 -> 55.2 us;
   // profiles/r03_ar_attn_nw.txt).  Same per-query arithmetic either way: bit-identical.
   // CS_ATTN_NW8=1: the previous rule (eight waves from 512 / 256 queries), A/B runs.
-  static const char* e_nw = getenv("CS_ATTN_NW8");
-  const bool fill8 = (e_nw && *e_nw == '1') || (int64_t)nb * heads * ((nq + 255) / 256) >= 128;
+  const bool fill8 = cs_debug()->attn_nw8 || (int64_t)nb * heads * ((nq + 255) / 256) >= 128;
   if (dh <= 64) {
     if (nq >= 512 && fill8)
       return launch_attn16<2, 64, X1, 8>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, s);

@@ -58,19 +58,9 @@ struct Norm {
   float gmax = 1.f, bmax = 0.f;   // max |gamma|, max |beta| (filled by pack_plan in F16X3 mode): norm_a_scale
 };
 
-// F16X3 operand scale of a GEMM fed by a normalisation over n elements per statistic: |y| <= gmax * sqrt(n - 1) + bmax,
-// so the largest power of two that keeps that bound below the fp16 range can never overflow (ops.py::norm_a_scale --
-// the same IEEE double operations in the same order, so both hosts derive the same scale)
-inline float norm_a_scale(float gmax, float bmax, int64_t n) {
-  const double bound = (double)gmax * std::sqrt((double)(n > 1 ? n - 1 : 1)) + (double)bmax;
-  if (!(bound > 0.0) || !std::isfinite(bound)) return (float)std::ldexp(1.0, 40);
-  int ex = 0;
-  (void)std::frexp(65000.0 / bound, &ex);
-  int k = ex - 1;
-  if (k < -8) k = -8;
-  if (k > 40) k = 40;
-  return (float)std::ldexp(1.0, k);
-}
+// F16X3 operand scale of a GEMM fed by a normalisation over n elements per statistic: cs_norm_a_scale (csrc/cs_plan.hip),
+// the one rule both hosts call
+inline float norm_a_scale(float gmax, float bmax, int64_t n) { return cs_norm_a_scale(gmax, bmax, n); }
 
 struct RawCopy {     // a parameter copied verbatim into the arena (e.g. the VQ codebook)
   int param;
@@ -158,9 +148,8 @@ int add_layer_gemm(Plan& u, const std::string& p, int o, int i, int k, bool bias
   std::vector<Piece> b;
   if (bp >= 0) b.push_back({bp, 0, o});
   if (tapcol) {
-    // ops.py::tapcol_ok -- the same rule on both hosts (CS_NO_TAPCOL=1: A/B runs)
-    const char* e = getenv("CS_NO_TAPCOL");
-    if (k == 3 && !up_mask && o <= 4 && (i & 3) == 0 && cin_pad == 0 && u.math == CS_MATH_F16X3 && !(e && *e)) {
+    // cs_tapcol_ok: the one rule (csrc/cs_plan.hip) both hosts ask
+    if (!up_mask && cin_pad == 0 && cs_tapcol_ok(o, i, k, u.math)) {
       const int gi = add_gemm(u, {{wp, 0, o}}, b, (27 * o + 3) / 4 * 4, i, 1);
       u.gemms[gi].tap_cout = o;
       return gi;
@@ -513,10 +502,21 @@ int pack_plan(Plan* u, const void* raw_dev, void* arena_dev, cs_stream_t stream)
 // ---------------------------------------------------------------------------------------------------------
 // execution
 // ---------------------------------------------------------------------------------------------------------
+// per-(row tile, column) GroupNorm partial sums a producing GEMM left in the workspace (CsConvGemm.gn_part; ops.ColStats)
+struct Stat {
+  int64_t off = -1, bytes = 0;
+  int nch = 0, nb = 0, tps = 0, ncls = 1;      // columns, samples the producer ran, tiles per sample (per class), classes
+  bool valid() const { return off >= 0; }
+};
+
 struct Buf {
   int64_t off = -1, bytes = 0;
   int64_t rows = 0;
   int c = 0;
+  // r4: the producers' partials covering this tensor's channels in order -- one segment (a GEMM output) or two (a channel
+  // concatenation [h | skip]: seg[1] starts at channel seg[0].nch); released with the buffer
+  Stat seg[2];
+  int nseg = 0;
   bool half = false;   // fp16 hi image [rows][c] followed by the lo image (the F16X3 GEMMs' pre-split A operand);
                        // same footprint as fp32 [rows][c]
   bool pair = false;   // the INTERLEAVED operand pair (CsConvGemm.a_format = 2): bytes / row stride of fp32 [rows][c],
@@ -572,7 +572,39 @@ struct ExecBase {
     b.off = 0;
     return b;
   }
+  void release_region(int64_t off, int64_t bytes) {
+    Buf t;
+    t.off = off;
+    t.bytes = bytes;
+    release_data(t);
+  }
+  Stat alloc_stat(int64_t tiles, int nch, int nb, int tps, int ncls) {
+    Buf t = alloc(tiles * nch * 4, 1);          // [tiles][nch][2] doubles = 16 bytes per (tile, column)
+    Stat st;
+    st.off = t.off;
+    st.bytes = t.bytes;
+    st.nch = nch; st.nb = nb; st.tps = tps; st.ncls = ncls;
+    return st;
+  }
+  // a private copy of a producer's partials (the guidance split: the shared tensor lives on as a skip, its duplicate feeds
+  // the next GroupNorm; each copy is released with its buffer)
+  Stat dup_stat(const Stat& a) {
+    if (!a.valid()) return Stat();
+    Stat st = alloc_stat(a.bytes / ((int64_t)a.nch * 16), a.nch, a.nb, a.tps, a.ncls);
+    if (ok() && !dry && hipMemcpyAsync(ws + st.off, ws + a.off, (size_t)a.bytes, hipMemcpyDeviceToDevice, this->st) != hipSuccess)
+      chk(CS_EINVAL);
+    return st;
+  }
   void release(Buf& b) {
+    for (int i = 0; i < 2; ++i)
+      if (b.seg[i].valid()) {
+        release_region(b.seg[i].off, b.seg[i].bytes);
+        b.seg[i] = Stat();
+      }
+    b.nseg = 0;
+    release_data(b);
+  }
+  void release_data(Buf& b) {
     if (b.off < 0 || b.bytes == 0) return;
     size_t i = 0;
     while (i < fl.size() && fl[i].off < b.off) ++i;
@@ -590,9 +622,11 @@ struct ExecBase {
   }
 
   // conv (k^3 taps, stride (1,s,s), nearest upsample (0,up,up)) or pointwise/linear GEMM with the fused epilogue
+  // want_stats: the result feeds a GroupNorm -- where the launch can (cs_conv_gemm_epilogue_caps: the one rule both hosts
+  // ask), its epilogue leaves the per-(row tile, column) partial sums and the returned buffer carries them (seg[0])
   Buf gemm(const Buf& x, int gi, int nb, int d, int h, int w, int s_hw = 1, int up_hw = 0, int act = CS_ACT_NONE,
            const float* rowvec = nullptr, int ldrv = 0, int rv_rows = 1, const float* res = nullptr, int ldr = 0,
-           int tile = 0, int s_d = 1, int up_d = 0) {
+           int tile = 0, int s_d = 1, int up_d = 0, bool want_stats = false, float out_pair = 0.f) {
     const Gemm& g = pl.gemms[gi];
     const bool tc = g.tap_cout > 0;      // taps as columns: the pointwise GEMM below, then cs_tapsum27
     if (tc) {
@@ -600,8 +634,7 @@ struct ExecBase {
         chk(CS_EINVAL);
         return Buf();
       }
-      const int64_t t256 = ((int64_t)nb * d * h * w + 255) / 256;
-      tile = t256 < 192 ? 0 : (g.cout <= 64 ? 7 : 6);      // ops.py::tapcol_tile
+      tile = cs_tapcol_tile((int64_t)nb * d * h * w, g.cout);
     }
     const int k = g.k, pad = k / 2;
     const int vh = h << up_hw, vw = w << up_hw;
@@ -661,6 +694,7 @@ struct ExecBase {
       }
       Buf uws = alloc(ub / 4, 1);
       if (!ok()) return out;
+      if (want_stats) stats_for(q, out, nb, (int64_t)d * h * w, (int64_t)nb * d * h * w, g.ncls, g.b_off >= 0, 0, 0);
       if (!dry) {
         const void* wc[8];
         const void* wl[8];
@@ -682,6 +716,18 @@ struct ExecBase {
       if (!ok()) return out;
       q.splitk = sk;
       q.splitk_ws = dry ? nullptr : p(skws);
+    }
+    if (want_stats && !tc) stats_for(q, out, nb, (int64_t)dout * hout * wout, mo, 1, g.b_off >= 0, ldr, ldrv);
+    if (out_pair > 0.f && !tc && pl.math == CS_MATH_F16X3) {
+      // the result's only reader is the next F16X3 GEMM: written as the interleaved operand pair where the launch can
+      // (ops.py::conv_gemm out_pair=; the sizing pass needs no answer: same bytes either way)
+      int32_t pair = 0;
+      if (!cs_debug()->no_pair_epilogue && !dry && cs_conv_gemm_epilogue_caps(&q, nullptr, &pair) == CS_OK && pair) {
+        q.out_format = 2;
+        q.out_scale = out_pair;
+        out.pair = true;
+        out.a_scale = out_pair;
+      }
     }
     if (!dry) chk(cs_conv_gemm(&q, st));
     release(skws);      // stream-ordered: later kernels that reuse the region run after the reduce
@@ -744,7 +790,75 @@ struct ExecBase {
     release(skws);
   }
 
+  // ops.py::_epilogue_extras: ask the library what the launch's epilogue can emit and point the descriptor at a fresh
+  // partials region (rps = rows per sample the statistics tiles run over, m_rows = the rows they cover in all)
+  void stats_for(CsConvGemm& q, Buf& out, int nb, int64_t rps, int64_t m_rows, int ncls, bool dry_bias, int dry_ldr,
+                 int dry_ldrv) {
+    if (cs_debug()->no_gn_parts || pl.math != CS_MATH_F16X3) return;
+    CsConvGemm probe = q;
+    if (dry) {
+      // the sizing pass carries no pointers, but the rule looks at which epilogue terms exist (and at their alignment):
+      // aligned stand-ins for exactly the operands the real pass will set, so both passes get the same answer
+      const float* some = reinterpret_cast<const float*>((uintptr_t)256);
+      probe.out = const_cast<float*>(some);
+      probe.bias = dry_bias ? some : nullptr;
+      probe.res = dry_ldr > 0 ? some : nullptr;
+      probe.ldr = dry_ldr;
+      probe.rowvec = dry_ldrv > 0 ? some : nullptr;
+      probe.ldrv = dry_ldrv;
+    }
+    int32_t rows = 0;
+    if (cs_conv_gemm_epilogue_caps(&probe, &rows, nullptr) != CS_OK || rows <= 0) return;
+    const int64_t tiles = (m_rows + rows - 1) / rows;
+    Stat sx = alloc_stat((int64_t)ncls * tiles, q.cout, nb, (int)(rps / rows), ncls);
+    if (!ok()) return;
+    out.seg[0] = sx;
+    out.nseg = 1;
+    q.gn_part = dry ? nullptr : reinterpret_cast<double*>(ws + sx.off);
+    q.gn_ld = q.cout;
+    q.gn_rows = rows;
+  }
+  // do x's segments cover its channels?  (ops.py::stats_segments)
+  bool has_parts(const Buf& x) const {
+    if (cs_debug()->no_gn_parts || x.nseg < 1) return false;
+    int n = 0;
+    for (int i = 0; i < x.nseg; ++i) {
+      if (!x.seg[i].valid()) return false;
+      n += x.seg[i].nch;
+    }
+    return n == x.c;
+  }
+  // (mean, rstd) from the producers' partials: ops.py::groupnorm_stats_from_parts
+  void seg_array(const Buf& x, CsGnSeg* sg) const {
+    int ch0 = 0;
+    for (int i = 0; i < x.nseg; ++i) {
+      const Stat& a = x.seg[i];
+      sg[i].part = reinterpret_cast<const double*>(ws + a.off);
+      sg[i].ld = a.nch; sg[i].col0 = 0; sg[i].ch0 = ch0; sg[i].nch = a.nch;
+      sg[i].tiles_per_sample = a.tps; sg[i].ncls = a.ncls; sg[i].nb_src = a.nb; sg[i].reserved = 0;
+      ch0 += a.nch;
+    }
+  }
+  void finalize_parts(const Buf& x, int nb, float eps, int groups, const Buf& stats) {
+    if (!ok() || dry) return;
+    CsGnSeg sg[2];
+    int ch0 = 0;
+    for (int i = 0; i < x.nseg; ++i) {
+      const Stat& a = x.seg[i];
+      sg[i].part = reinterpret_cast<const double*>(ws + a.off);
+      sg[i].ld = a.nch; sg[i].col0 = 0; sg[i].ch0 = ch0; sg[i].nch = a.nch;
+      sg[i].tiles_per_sample = a.tps; sg[i].ncls = a.ncls; sg[i].nb_src = a.nb; sg[i].reserved = 0;
+      ch0 += a.nch;
+    }
+    chk(cs_groupnorm_finalize_parts(sg, x.nseg, nb, (int)(x.rows / nb), x.c, groups, eps, p(stats), st));
+  }
+
   Buf gn_stats(const Buf& x, int nb, float eps, int groups = 32) {
+    if (has_parts(x)) {
+      Buf stats = alloc((int64_t)nb * groups * 2, 1);
+      finalize_parts(x, nb, eps, groups, stats);
+      return stats;
+    }
     Buf wsb = alloc((cs_groupnorm_ws_bytes(nb, groups) + 3) / 4, 1);
     Buf stats = alloc((int64_t)nb * groups * 2, 1);
     if (ok() && !dry) chk(cs_groupnorm_stats(p(x), nb, (int)(x.rows / nb), x.c, x.c, groups, eps, p(wsb), p(stats), st));
@@ -776,23 +890,16 @@ struct ExecBase {
   }
 
   Buf linear(const Buf& x, int gi, int act = CS_ACT_NONE, const float* rowvec = nullptr, int ldrv = 0,
-             int rv_rows = 1, const float* res = nullptr, int ldr = 0, int tile = 0) {
-    return gemm(x, gi, (int)x.rows, 1, 1, 1, 1, 0, act, rowvec, ldrv, rv_rows, res, ldr, tile);
+             int rv_rows = 1, const float* res = nullptr, int ldr = 0, int tile = 0, float out_pair = 0.f) {
+    return gemm(x, gi, (int)x.rows, 1, 1, 1, 1, 0, act, rowvec, ldrv, rv_rows, res, ldr, tile, 1, 0, false, out_pair);
   }
 
-  // mirror of ops.wants_split16: the GroupNorm feeding conv `gi` emits the fp16 hi / lo operand pair where that conv
-  // runs the slab kernel (3x3x3 on a 256-row tile); bit-identical to the fp32 route either way
+  // does the GroupNorm feeding conv `gi` over m output rows emit the pre-split operand pair?  (cs_conv_wants_split16: the
+  // one rule, csrc/cs_plan.hip; bit-identical to the fp32 route either way)
   bool wants_split16(int64_t m, int gi) const {
-    static const bool off = getenv("CS_NO_SPLIT16") != nullptr;
-    if (off || gi < 0 || pl.math != CS_MATH_F16X3) return false;
+    if (gi < 0) return false;
     const Gemm& g = pl.gemms[gi];
-    if (g.up_mask || g.k != 3 || (g.cin & 7) || g.cin_pad != g.cin) return false;
-    const int64_t t256 = (m + 255) / 256;
-    // (r3: ... and the 128-row slab tile of medium batches, from CS_SPLIT16_MIN_ROWS rows; ops.py::wants_split16)
-    static const int64_t min_rows = getenv("CS_SPLIT16_MIN_ROWS") ? atoll(getenv("CS_SPLIT16_MIN_ROWS")) : 8192;
-    if (g.cout % 224 == 0) return t256 * (g.cout / 224) >= 192 || (min_rows > 0 && m >= min_rows);
-    if (g.cout % 128 == 0) return t256 * (g.cout / 128) >= 192;
-    return (g.cout == 64 || g.cout <= 4) && t256 >= 192;
+    return cs_conv_wants_split16(m, g.cin, g.cout, g.k, !g.up_mask && !g.tap_cout && g.cin_pad == g.cin, pl.math) != 0;
   }
 
   // self-attention over a fused [rows][3c] q | k | v buffer -> a [rows][c]; F16X3: K / V tile images in a scratch buffer
@@ -815,6 +922,28 @@ struct ExecBase {
   Buf groupnorm(const Buf& x, int ni, int nb, float eps, int act, int groups = 32, int conv_gi = -1) {
     const Norm& n = pl.norms[ni];
     Buf y = alloc(x.rows, x.c);
+    if (has_parts(x)) {      // r4: statistics from the producers' partials, the tensor is read once (ops.py::groupnorm)
+      Buf stats = alloc((int64_t)nb * groups * 2, 1);
+      if (pl.math == CS_MATH_F16X3) y.a_scale = norm_a_scale(n.gmax, n.bmax, (x.rows / nb) * (int64_t)(x.c / groups));
+      const int rows = (int)(x.rows / nb);
+      if (wants_split16(x.rows, conv_gi)) {
+        y.half = true;
+        finalize_parts(x, nb, eps, groups, stats);
+        if (ok() && !dry) {
+          char* yh = reinterpret_cast<char*>(p(y));
+          chk(cs_groupnorm_apply_split16(p(x), p(stats), wf(n.g_off), wf(n.b_off), yh, yh + x.rows * x.c * 2, nb, rows, x.c,
+                                         x.c, x.c, groups, act, y.a_scale, status, st));
+        }
+      } else if (ok() && !dry) {
+        // one call: a single launch for small tensors, finalize + apply otherwise (cs_groupnorm_parts decides)
+        CsGnSeg sg[2];
+        seg_array(x, sg);
+        chk(cs_groupnorm_parts(p(x), sg, x.nseg, wf(n.g_off), wf(n.b_off), p(y), nb, rows, x.c, x.c, x.c, groups, eps, act,
+                               p(stats), st));
+      }
+      release(stats);
+      return y;
+    }
     Buf wsb = alloc((cs_groupnorm_ws_bytes(nb, groups) + 3) / 4, 1);
     Buf stats = alloc((int64_t)nb * groups * 2, 1);
     if (pl.math == CS_MATH_F16X3) y.a_scale = norm_a_scale(n.gmax, n.bmax, (x.rows / nb) * (int64_t)(x.c / groups));
@@ -845,8 +974,7 @@ struct ExecBase {
     if (pl.math == CS_MATH_F16X3) y.a_scale = norm_a_scale(n.gmax, n.bmax, x.c);
     // LayerNorm outputs only ever feed GEMMs: in F16X3 mode they are written as the interleaved operand pair
     // (ops.py::layernorm pair_scale; CS_NO_PAIR16=1 keeps fp32 for A/B runs)
-    static const bool no_pair = getenv("CS_NO_PAIR16") != nullptr && *getenv("CS_NO_PAIR16");
-    if (pl.math == CS_MATH_F16X3 && !no_pair && x.c % 16 == 0) {
+    if (pl.math == CS_MATH_F16X3 && !cs_debug()->no_pair16 && x.c % 16 == 0) {
       y.pair = true;
       if (ok() && !dry)
         chk(cs_layernorm_pair16(p(x), wf(n.g_off), wf(n.b_off), p(y), (int)x.rows, x.c, x.c, x.c, 1e-5f, y.a_scale,

@@ -307,8 +307,7 @@ int plan_splitk(const CsConvGemm& p, int64_t M) {
   // CS_PLAN_POW2=1: the previous rule (largest power of two, up to 704 workgroups for K loops of >= 1024 chunks), A/B runs.
   // Short K loops (the 1x1x1 / token GEMMs: <= 168 chunks) keep the power-of-two rule: more, shorter slices only add
   // partial-tile traffic there (1792 -> 448 at 2048 rows: 8 slices 40.6 us, 16 slices 43.1).
-  static const char* e_p2 = getenv("CS_PLAN_POW2");
-  if ((e_p2 && *e_p2 == '1') || !(p.kd == 3 && p.kh == 3 && p.kw == 3)) {
+  if (cs_debug()->plan_pow2 || !(p.kd == 3 && p.kh == 3 && p.kw == 3)) {
     const int64_t limit = nk >= 1024 ? 704 : 512;
     int64_t s = 1;
     while (2 * s * wgs <= limit && 2 * s <= 32 && 2 * s <= nk / 8) s *= 2;
@@ -355,7 +354,182 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const CsConvGemm p, 
   }
 }
 
+// splitk_reduce_kernel with the r4 epilogue outputs (CsConvGemm.gn_part / out_format): a workgroup owns SKR rows x 64
+// columns -- 16 float4 column lanes x 16 row lanes, one row per thread (a first version gave a thread two rows: half the
+// workgroups, 16 instead of 9.5 us per call at one object) -- so that it can (a) leave the fp64 (sum, sum of
+// squares) of its rows per column for the GroupNorm that follows (statistics tile = SKR rows; at small batches nearly
+// every GroupNorm input comes out of this kernel) and (b) write the interleaved operand pair, lanes 2t / 2t + 1 swapping a
+// half as in the GEMM's own epilogue.  Same sums, same order per element as splitk_reduce_kernel.
+constexpr int SKR = 16;
+__global__ __launch_bounds__(256) void splitk_reduce_epi_kernel(const CsConvGemm p, const float* __restrict__ ws, int M,
+                                                                int splits) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  __shared__ double sc[16][64];
+  const int cbn = (p.cout + 63) / 64;
+  const int rb = blockIdx.x / cbn, cbi = blockIdx.x - rb * cbn;
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int n = cbi * 64 + cl * 4;
+  const bool nok = n < p.cout;
+  const bool gstat = p.gn_part != nullptr, opair = p.out_format == 2;
+  double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+  float oamax = 0.f;
+#pragma unroll
+  for (int rr = 0; rr < SKR / 16; ++rr) {
+    const int m = rb * SKR + rl + 16 * rr;
+    const bool ok = nok && m < M;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (ok) {
+      v = *reinterpret_cast<const f32x4*>(ws + (int64_t)m * p.cout + n);
+      for (int sl = 1; sl < splits; ++sl) v += *reinterpret_cast<const f32x4*>(ws + ((int64_t)sl * M + m) * p.cout + n);
+      if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+      if (p.scale) v = v * *reinterpret_cast<const f32x4*>(p.scale + n) + *reinterpret_cast<const f32x4*>(p.shift + n);
+      if (p.rowvec) v += *reinterpret_cast<const f32x4*>(p.rowvec + (int64_t)(m / p.rv_rows) * p.ldrv + n);
+      if (p.act != CS_ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = cs_act(v[e], p.act);
+      }
+      if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (int64_t)m * p.ldr + n);
+      if (gstat) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const double d = (double)v[e];
+          s[e] += d;
+          q[e] += d * d;
+        }
+      }
+    }
+    if (opair) {      // uniform branch: every lane takes part in the half swap
+      h4 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float o = v[e] * p.out_scale;
+        oamax = fmaxf(oamax, fabsf(o));
+        hi[e] = (_Float16)o;
+        lo[e] = (_Float16)(o - (float)hi[e]);
+      }
+      const u32x2 H = __builtin_bit_cast(u32x2, hi), L = __builtin_bit_cast(u32x2, lo);
+      const bool odd = cl & 1;
+      const u32x2 send = odd ? H : L;
+      u32x2 recv;
+      recv[0] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send[0], 0xB1, 0xF, 0xF, true);
+      recv[1] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send[1], 0xB1, 0xF, 0xF, true);
+      u32x4 r;
+      r[0] = odd ? recv[0] : H[0];
+      r[1] = odd ? recv[1] : H[1];
+      r[2] = odd ? L[0] : recv[0];
+      r[3] = odd ? L[1] : recv[1];
+      if (ok) {
+        char* row = reinterpret_cast<char*>(p.out + (int64_t)m * p.ldo);
+        *reinterpret_cast<u32x4*>(row + (n >> 4) * 64 + ((n & 8) ? 32 : 0) + ((n & 4) ? 16 : 0)) = r;
+      }
+    } else if (ok) {
+      *reinterpret_cast<f32x4*>(p.out + (int64_t)m * p.ldo + n) = v;
+    }
+  }
+  if (opair && p.status && oamax >= 65504.f) atomicOr(p.status, CS_STATUS_F16X3_OVERFLOW);
+  if (gstat) {
+    double tot[2][4];
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sc[rl][cl * 4 + e] = which ? q[e] : s[e];
+      __syncthreads();
+      if (rl == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          double t = 0.0;
+          for (int r2 = 0; r2 < 16; ++r2) t += sc[r2][cl * 4 + e];
+          tot[which][e] = t;
+        }
+      }
+    }
+    if (rl == 0 && nok) {
+      double* o = p.gn_part + ((int64_t)rb * p.gn_ld + n) * 2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[2 * e] = tot[0][e];
+        o[2 * e + 1] = tot[1][e];
+      }
+    }
+  }
+}
+
+// rows x columns of a tile code's output tile (0: no fixed tile -- the ping-pong kernel, the 512-row codes that may fall back)
+void tile_dims(int tile, int& bm, int& bn) {
+  switch (tile) {
+    case 1: bm = 128; bn = 128; break;
+    case 2: bm = 128; bn = 224; break;
+    case 3: bm = 64; bn = 64; break;
+    case 4: bm = 256; bn = 224; break;
+    case 6: bm = 256; bn = 128; break;
+    case 7: bm = 256; bn = 64; break;
+    default: bm = 0; bn = 0; break;
+  }
+}
+
 }  // namespace
+
+static int auto_tile(const CsConvGemm& p, int M, bool f16x3);
+static bool up2_direct_batched(const CsConvGemm& d, int64_t m1, int ncls);
+
+// ONE rule for what a launch's epilogue can emit (CsConvGemm.gn_part / out_format): only the pipelined epilogue of the
+// F16X3 tile kernels and the split-K reduce can, so every condition under which the kernel takes another path is
+// checked here, on the host, for ALL tiles of the launch -- the hosts ask before they allocate, cs_conv_gemm re-checks.
+extern "C" int cs_conv_gemm_epilogue_caps(const CsConvGemm* d, int32_t* gn_rows, int32_t* pair_ok) {
+  if (!d) return CS_EINVAL;
+  if (gn_rows) *gn_rows = 0;
+  if (pair_ok) *pair_ok = 0;
+  const CsConvGemm& p = *d;
+  if (p.math != CS_MATH_F16X3 || p.nb <= 0 || p.cout <= 0 || p.dout <= 0 || p.hout <= 0 || p.wout <= 0) return CS_OK;
+  const int64_t M64 = (int64_t)p.nb * p.dout * p.hout * p.wout;
+  if (M64 > 0x7fffffffLL) return CS_OK;
+  const int M = (int)M64;
+  auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+  const int ocols = p.act == CS_ACT_GEGLU ? p.cout / 2 : p.cout;
+  const bool vec = (p.cout % 4 == 0) && (p.ldo % 4 == 0) && al16(p.out) && (!p.bias || al16(p.bias)) &&
+                   (!p.scale || (al16(p.scale) && al16(p.shift))) && (!p.rowvec || (p.ldrv % 4 == 0 && al16(p.rowvec))) &&
+                   (!p.res || (p.ldr % 4 == 0 && al16(p.res)));
+  if (!vec) return CS_OK;
+  const bool pair_geom = (ocols % 8 == 0) && (p.ldo % 16 == 0) && (((uintptr_t)p.out & 63) == 0);
+  int64_t rps = (int64_t)p.dout * p.hout * p.wout;           // output rows per sample
+  int bm = 0, bn = 0;
+  if (p.ud | p.uh | p.uw) {
+    // folded Upsample conv (cs_conv_gemm_up2): only the one-launch direct-store route, tiles over the SOURCE rows
+    const int64_t m1 = (int64_t)p.nb * p.din * p.hin * p.win;
+    const int ncls = (p.ud ? 2 : 1) * (p.uh ? 2 : 1) * (p.uw ? 2 : 1);
+    if (p.splitk > 1 || !up2_direct_batched(p, m1, ncls)) return CS_OK;
+    CsConvGemm q = p;
+    q.kd = p.ud ? 2 : 3; q.kh = p.uh ? 2 : 3; q.kw = p.uw ? 2 : 3;
+    q.ud = q.uh = q.uw = 0;
+    q.dout = p.din; q.hout = p.hin; q.wout = p.win;
+    q.tile = 0;
+    tile_dims(auto_tile(q, (int)m1, true), bm, bn);
+    rps = (int64_t)p.din * p.hin * p.win;
+    if (!bm || !p.bias) return CS_OK;                         // (piped epilogue needs bias / residual / row vector)
+    if (gn_rows && rps % bm == 0 && p.act != CS_ACT_GEGLU) *gn_rows = bm;
+    return CS_OK;                                            // (no pair output from the scattered store)
+  }
+  if (p.splitk > 1) {
+    if (gn_rows && rps % SKR == 0 && p.act != CS_ACT_GEGLU) *gn_rows = SKR;
+    if (pair_ok && pair_geom && p.act != CS_ACT_GEGLU) *pair_ok = 1;
+    return CS_OK;
+  }
+  int tile = p.tile ? p.tile : auto_tile(p, M, true);
+  if (tile == 5 || (p.tile == 0 && cs_pw_gemm_f16x3_applicable(p, M) && cs_pw_gemm_f16x3_preferred(p, M))) return CS_OK;
+  tile_dims(tile, bm, bn);
+  if (!bm) return CS_OK;
+  // the kernel's `piped` condition, for every tile of the launch
+  const bool piped = (p.res || p.bias || p.rowvec) && !p.scale && (p.act != CS_ACT_GEGLU || p.cout % bn == 0) &&
+                     (!p.rowvec || p.rv_rows % bm == 0) &&
+                     (int64_t)bm * p.ldo * 4 < 0x7FF00000LL && (!p.res || (int64_t)bm * p.ldr * 4 < 0x7FF00000LL);
+  if (!piped) return CS_OK;
+  if (gn_rows && rps % bm == 0 && p.act != CS_ACT_GEGLU) *gn_rows = bm;
+  if (pair_ok && pair_geom) *pair_ok = 1;
+  return CS_OK;
+}
 
 extern "C" int cs_conv_gemm_plan(const CsConvGemm* d, int32_t* splitk, int64_t* ws_bytes) {
   if (!d || !splitk) return CS_EINVAL;
@@ -397,12 +571,12 @@ static int auto_tile(const CsConvGemm& p, int M, bool f16x3) {
     // are NOT auto-selected: on the VQ-VAE decoder's 64^3 / 32^3 convs they measured 334-360 / 405-443 TF/s against
     // 366-377 / 434-451 for the 256-row tiles, profiles/r03_g_decode_tables.txt.  CS_TILE512=1 selects them for A/B runs.)
     {
-      static const char* e512 = getenv("CS_TILE512");
+      const bool t512on = cs_debug()->tile512 != 0;
       const bool conv3 = p.kd == 3 && p.kh == 3 && p.kw == 3 && p.sd == 1 && p.sh == 1 && p.sw == 1 &&
                          !(p.ud | p.uh | p.uw) && p.pd == 1 && p.ph == 1 && p.pw == 1;
       const int64_t t512 = (M + 511) / 512;
-      if (e512 && *e512 == '1' && conv3 && tile == 7 && p.cout == 64 && p.win <= 64 && t512 >= 512) tile = 8;
-      if (e512 && *e512 == '1' && conv3 && tile == 6 && p.win <= 32 && t512 * (p.cout / 128) >= 512) tile = 9;
+      if (t512on && conv3 && tile == 7 && p.cout == 64 && p.win <= 64 && t512 >= 512) tile = 8;
+      if (t512on && conv3 && tile == 6 && p.win <= 32 && t512 * (p.cout / 128) >= 512) tile = 9;
     }
     if (p.act == CS_ACT_GEGLU && tile != 4) tile = 2;   // the fused gate needs whole [x | gate] 224-column tiles
     // ... and with a short K loop (the 448-channel level: 28 chunks) two 128-row workgroups per CU overlap one's gate
@@ -410,6 +584,16 @@ static int auto_tile(const CsConvGemm& p, int M, bool f16x3) {
     if (p.act == CS_ACT_GEGLU && tile == 4 && (p.cin + 15) / 16 <= 32) tile = 2;
   }
   return tile;
+}
+
+// tile of a K-sliced launch (desc->splitk > 1): explicit narrow tiles (6 / 7) as given; the 256x224 tile for the large-batch
+// four-way cut, an explicit tile 4 and -- r3 -- every 3x3x3 slab conv (CS_SLICE_TILE2=1: those on the 128-row tile); else 128x224
+static int sliced_tile(const CsConvGemm& p, int M) {
+  if (p.tile == 6 || p.tile == 7) return p.tile;
+  const bool slab3 = !cs_debug()->slice_tile2 && p.kd == 3 && p.kh == 3 && p.kw == 3 && p.sd == 1 && p.sh == 1 &&
+                     p.sw == 1 && p.pd == 1 && p.ph == 1 && p.pw == 1 && !(p.ud | p.uh | p.uw) && p.din == p.dout &&
+                     p.hin == p.hout && p.win == p.wout && p.win <= 32;
+  return (split4_large(p, M) || p.tile == 4 || slab3) ? 4 : 2;
 }
 
 // omap_f / omap_p != 0 (cs_conv_gemm_up2 only): this GEMM is one output parity class of a folded Upsample conv and
@@ -444,10 +628,21 @@ static int conv_gemm_impl(const CsConvGemm* d, cs_stream_t stream, int omap_f, i
   if (tile == 0) tile = auto_tile(p, M, f16x3);
   hipStream_t s = (hipStream_t)stream;
   if (p.splitk > 1 && omap_f) return CS_EINVAL;
+  if ((p.gn_part || p.out_format) && !omap_f) {
+    // epilogue outputs beside the fp32 tile: only where cs_conv_gemm_epilogue_caps says the launch can produce them
+    int32_t rows = 0, pair = 0;
+    if (!f16x3 || (p.out_format != 0 && p.out_format != 2) || cs_conv_gemm_epilogue_caps(d, &rows, &pair) != CS_OK)
+      return CS_EINVAL;
+    if (p.gn_part && (rows == 0 || rows != p.gn_rows || p.gn_ld < p.cout || ((uintptr_t)p.gn_part & 15))) return CS_EINVAL;
+    if (p.out_format == 2 && (!pair || !(p.out_scale > 0.f))) return CS_EINVAL;
+  }
   if (p.splitk > 1) {
     // caller-requested split-K (cs_conv_gemm_plan): partial tiles to the workspace, then reduce + epilogue
     auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
-    if (!f16x3 || p.act == CS_ACT_GEGLU || p.cout % 224 || !p.splitk_ws || !al16(p.splitk_ws) || p.splitk > 64)
+    // (explicit tiles 6 / 7 -- 256x128 / 256x64, any cout % 4 == 0 -- are accepted for K-sliced launches too: tuning sweeps)
+    const bool narrow = p.tile == 6 || p.tile == 7;
+    if (!f16x3 || p.act == CS_ACT_GEGLU || (narrow ? (p.cout & 3) : p.cout % 224) || !p.splitk_ws || !al16(p.splitk_ws) ||
+        p.splitk > 64)
       return CS_EINVAL;
     if ((p.ldo & 3) || !al16(p.out) || (p.bias && !al16(p.bias)) || (p.scale && (!al16(p.scale) || !al16(p.shift))) ||
         (p.rowvec && ((p.ldrv & 3) || !al16(p.rowvec))) || (p.res && ((p.ldr & 3) || !al16(p.res))))
@@ -459,23 +654,29 @@ static int conv_gemm_impl(const CsConvGemm* d, cs_stream_t stream, int omap_f, i
     part.ldo = p.cout;
     part.bias = part.scale = part.shift = part.rowvec = part.res = nullptr;
     part.act = CS_ACT_NONE;
+    part.gn_part = nullptr;              // the slices write plain partial tiles; the reduce kernel emits the extras
+    part.out_format = 0;
     // small batches: 128x224 tiles; the large-batch four-way cut (plan_splitk) keeps the 256x224 slab kernel
     // r3: K-sliced 3x3x3 slab convs run the 256x224 tile at EVERY batch size (one 8-wave workgroup per CU: 256 slots,
     // the same slice count as 512 slots of the 128-row tile) -- 4-7 % faster than the 128x224 tile on every shape from
     // 1 to 14 objects (tools/gemm_smallm_t4.py, profiles/r03_an_tile4_slices*.txt); convs the slab kernel does not take
     // (strided, W > 32) keep the 128-row tile.  CS_SLICE_TILE2=1: the previous rule, A/B runs.
-    static const char* e_t2 = getenv("CS_SLICE_TILE2");
-    const bool slab3 = !(e_t2 && *e_t2 == '1') && p.kd == 3 && p.kh == 3 && p.kw == 3 && p.sd == 1 && p.sh == 1 &&
-                       p.sw == 1 && p.pd == 1 && p.ph == 1 && p.pw == 1 && !(p.ud | p.uh | p.uw) && p.din == p.dout &&
-                       p.hin == p.hout && p.win == p.wout && p.win <= 32;
-    const int rc = cs_conv_gemm_f16x3_dispatch(part, M, (split4_large(p, M) || p.tile == 4 || slab3) ? 4 : 2, p.splitk, s);
+    const int rc = cs_conv_gemm_f16x3_dispatch(part, M, sliced_tile(p, M), p.splitk, s);
     if (rc != CS_OK) return rc;
-    CS_LAUNCH(splitk_reduce_kernel, dim3(cs_grid_for((int64_t)M * (p.cout >> 2), 256)), dim3(256), 0, s, p,
-              reinterpret_cast<const float*>(p.splitk_ws), M, p.splitk);
+    if (p.gn_part || p.out_format) {
+      const int64_t nblk = (int64_t)((M + SKR - 1) / SKR) * ((p.cout + 63) / 64);
+      if (nblk > 0x7fffffffLL) return CS_EINVAL;
+      CS_LAUNCH(splitk_reduce_epi_kernel, dim3((unsigned)nblk), dim3(256), 0, s, p,
+                reinterpret_cast<const float*>(p.splitk_ws), M, p.splitk);
+    } else {
+      CS_LAUNCH(splitk_reduce_kernel, dim3(cs_grid_for((int64_t)M * (p.cout >> 2), 256)), dim3(256), 0, s, p,
+                reinterpret_cast<const float*>(p.splitk_ws), M, p.splitk);
+    }
     CS_CHECK_LAUNCH();
     return CS_OK;
   }
   if (omap_f && (!f16x3 || tile == 5)) return CS_EINVAL;
+  if ((p.gn_part || p.out_format) && (!f16x3 || tile == 5)) return CS_EINVAL;
   if (tile == 5) return cs_pw_gemm_f16x3_launch(p, M, s);
   if (f16x3) return cs_conv_gemm_f16x3_dispatch(p, M, tile, 1, s, omap_f, omap_p, cls_w, cls_w_lo, cls_acc, ncls);
   switch (tile) {
@@ -492,6 +693,29 @@ static int conv_gemm_impl(const CsConvGemm* d, cs_stream_t stream, int omap_f, i
 }
 
 extern "C" int cs_conv_gemm(const CsConvGemm* d, cs_stream_t stream) { return conv_gemm_impl(d, stream, 0, 0); }
+
+int cs_f16x3_slab_width(const CsConvGemm& p, int tile, int splits);      // cs_gemm_f16x3.hip
+
+// the tile / slab choice conv_gemm_impl + cs_conv_gemm_f16x3_dispatch make for this descriptor, for hosts that account
+// per kernel variant (bench.py) -- computed by the same functions the launch path calls
+extern "C" int cs_conv_gemm_launch_info(const CsConvGemm* d, int32_t* tile_out, int32_t* slab_out) {
+  if (!d || d->nb <= 0 || d->cout <= 0 || d->dout <= 0 || d->hout <= 0 || d->wout <= 0) return CS_EINVAL;
+  const CsConvGemm& p = *d;
+  const int64_t M64 = (int64_t)p.nb * p.dout * p.hout * p.wout;
+  if (M64 > 0x7fffffffLL) return CS_EINVAL;
+  const int M = (int)M64;
+  const bool f16x3 = p.math == CS_MATH_F16X3;
+  int tile = p.tile;
+  if (p.splitk > 1) {
+    tile = sliced_tile(p, M);
+  } else {
+    if (tile == 0 && f16x3 && cs_pw_gemm_f16x3_applicable(p, M) && cs_pw_gemm_f16x3_preferred(p, M)) tile = 5;
+    if (tile == 0) tile = auto_tile(p, M, f16x3);
+  }
+  if (tile_out) *tile_out = tile;
+  if (slab_out) *slab_out = (f16x3 && tile != 5) ? cs_f16x3_slab_width(p, tile, p.splitk > 1 ? p.splitk : 1) : 0;
+  return CS_OK;
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // Nearest x2 upsampling followed by a 3x3x3 stride-1 conv (Upsample: openai_model_3d.py:150-153, vqvae_modules.py:
@@ -568,6 +792,27 @@ bool up2_ok(const CsConvGemm& p) {
 
 }  // namespace
 
+// Will cs_conv_gemm_up2 run this folded Upsample conv as ONE launch whose parity classes store straight into the doubled
+// grid?  (Every class on the four-tap slab kernel, unsplit; CS_NO_UP2_DIRECT / CS_NO_UP2_BATCH switch the route off.)
+static bool up2_direct_batched(const CsConvGemm& d, int64_t m1, int ncls) {
+  if (d.math != CS_MATH_F16X3 || !up2_ok(d) || m1 > 0x7fffffffLL) return false;
+  if (cs_debug()->no_up2_direct || cs_debug()->no_up2_batch || m1 * (int64_t)ncls > 0x7fffffffLL) return false;
+  const int nh = d.uh ? 2 : 1, nw = d.uw ? 2 : 1;
+  for (int cls = 0; cls < ncls; ++cls) {
+    const int pw = cls % nw, ph = (cls / nw) % nh, pd = cls / (nw * nh);
+    CsConvGemm q = d;
+    q.kd = d.ud ? 2 : 3; q.kh = d.uh ? 2 : 3; q.kw = d.uw ? 2 : 3;
+    q.pd = d.ud ? 1 - pd : 1; q.ph = d.uh ? 1 - ph : 1; q.pw = d.uw ? 1 - pw : 1;
+    q.ud = q.uh = q.uw = 0;
+    q.dout = d.din; q.hout = d.hin; q.wout = d.win;
+    q.ldo = d.cout;
+    q.tile = 0;
+    q.splitk = 0;
+    if (plan_splitk(q, m1) > 1 || !cs_f16x3_slab4_ok(q, auto_tile(q, (int)m1, true), 1)) return false;
+  }
+  return (int64_t)ncls * ((m1 + 255) / 256) * ((d.cout + 63) / 64) < 0x7fffffffLL;
+}
+
 extern "C" int cs_conv_up2_info(int ud, int uh, int uw, int32_t* ncls, int32_t* kd, int32_t* kh, int32_t* kw) {
   if (ud < 0 || ud > 1 || uh < 0 || uh > 1 || uw < 0 || uw > 1 || !(ud | uh | uw)) return CS_EINVAL;
   if (ncls) *ncls = (ud ? 2 : 1) * (uh ? 2 : 1) * (uw ? 2 : 1);
@@ -630,16 +875,22 @@ extern "C" int cs_conv_gemm_up2(const CsConvGemm* d, const void* const* w_cls, c
   // r3: where every class runs the four-tap slab kernel unsplit, the classes store straight into the doubled grid (the
   // kernel's scattered-store epilogue) -- no scratch tensor, no interleave pass (2.06 of 57.8 ms per 32-object decode,
   // 0.23 ms of a UNet step).  CS_NO_UP2_DIRECT=1: scratch + interleave everywhere (A/B runs, the equality test).
-  static const char* e_dir = getenv("CS_NO_UP2_DIRECT");
-  bool direct = f16x3 && !(e_dir && *e_dir == '1') && m1 * (int64_t)ncls <= 0x7fffffffLL;
+  bool direct = f16x3 && !cs_debug()->no_up2_direct && m1 * (int64_t)ncls <= 0x7fffffffLL;
   for (int cls = 0; cls < ncls && direct; ++cls) {
     const CsConvGemm q = class_desc(cls);
     direct = plan_splitk(q, m1) <= 1 && cs_f16x3_slab4_ok(q, auto_tile(q, (int)m1, true), 1);
   }
   // ... and as ONE launch over all classes (virtual tile range [class][tile]): 192-workgroup class GEMMs (the UNet's 4^3
   // level at 32 objects) fill the chip together, and seven launch ramps go.  CS_NO_UP2_BATCH=1: one launch per class.
-  static const char* e_bat = getenv("CS_NO_UP2_BATCH");
-  if (direct && !(e_bat && *e_bat == '1') && (int64_t)ncls * ((m1 + 255) / 256) * ((d->cout + 63) / 64) < 0x7fffffffLL) {
+  const bool batched = up2_direct_batched(*d, m1, ncls);
+  if (d->gn_part) {      // GroupNorm partials: the one-launch route only (tiles ordered [class][source-row tile])
+    int32_t rows = 0;
+    if (!batched || cs_conv_gemm_epilogue_caps(d, &rows, nullptr) != CS_OK || rows == 0 || rows != d->gn_rows ||
+        d->gn_ld < d->cout || ((uintptr_t)d->gn_part & 15))
+      return CS_EINVAL;
+  }
+  if (d->out_format) return CS_EINVAL;
+  if (batched) {
     const int omap_f = (d->ud ? 4 : 0) | (d->uh ? 2 : 0) | (d->uw ? 1 : 0);
     CsConvGemm q = class_desc(0);
     q.out = d->out;
@@ -725,4 +976,4 @@ extern "C" int cs_relayout_weight(const float* w_torch, float* w_out, int cout, 
   return CS_OK;
 }
 
-extern "C" int cs_abi_version(void) { return 13; }
+extern "C" int cs_abi_version(void) { return 14; }

@@ -165,10 +165,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   const void* w_lo_ = p.w_lo;
   float acc_scale_ = p.acc_scale;
   int pad_d = p.pd, pad_h = p.ph, pad_w = p.pw, omap_p = omap_p_in;
+  int cls_id = 0;                                                 // parity class of a batched folded-Upsample launch
   if constexpr (TPK == 4) {
     if (cb.n > 1) {
       const int per_cls = ((M + BM - 1) / BM) * tiles_n;          // (splits == 1 on this route)
       const int cls = tile / per_cls;
+      cls_id = cls;
       tile -= cls * per_cls;
       w_hi_ = cb.w[cls];
       w_lo_ = cb.w_lo[cls];
@@ -771,12 +773,60 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
     const int m_last = min(m0 + BM, M) - 1;
     const bool geglu = p.act == CS_ACT_GEGLU;
     const bool has_res = p.res != nullptr;
+    // (r4: an edge column tile -- cout not a multiple of BN -- takes this path too, its lanes past cout masked like the rows
+    // past M; only the fused gate needs whole [x | gate] column groups)
     const bool piped = !(CS_ABLATE & 32) && vec_epilogue && (p.res || p.bias || p.rowvec) && !p.scale && splits == 1 &&
-                       n0 + BN <= p.cout && (!p.rowvec || (m0 / p.rv_rows == m_last / p.rv_rows)) &&
+                       (!geglu || n0 + BN <= p.cout) && (!p.rowvec || (m0 / p.rv_rows == m_last / p.rv_rows)) &&
                        (long long)ospan * p.ldo * 4 < 0x7FF00000LL && (!p.res || (long long)BM * p.ldr * 4 < 0x7FF00000LL);
+    // r4 (ABI 14): what the epilogue emits beside / instead of the fp32 tile -- only this (piped) path can; the host asks
+    // cs_conv_gemm_epilogue_caps first, so reaching another path with either set is a planning bug, reported loudly
+    const bool gstat = p.gn_part != nullptr;                 // per-(tile, column) GroupNorm partial sums
+    const bool opair = p.out_format == 2;                    // `out` as the interleaved operand pair of out * out_scale
+    if ((gstat || opair) && !piped && tid == 0 && p.status) atomicOr(p.status, CS_STATUS_INTERNAL);
     if (piped) {
       __syncthreads();                                       // every wave has left the ring
       float* const ep = reinterpret_cast<float*>(smem + wave * EPB);
+      // sum / sum of squares of the FINAL values of this lane's columns over the rows it stores: lane u = lane + 64 k keeps
+      // float4 column (u % UPR) of staged row (u / UPR) in every pass, so 4 KU accumulator pairs cover the tile.  A lane
+      // adds its 16 WMB values per column in fp32 (packed v_pk_add / v_pk_fma: a first version kept fp64 accumulators here
+      // -- 768 double-rate VALU instructions per wave per tile, ~0.9 ms per step on an epilogue nothing overlaps); everything
+      // above the lane -- rows of a wave, waves of a tile, tiles of a sample -- is summed in fp64.  Relative error of a
+      // 16-term fp32 sum ~2e-7, averaged down by the thousands of lane sums in a group: statistics stay at fp64 grade.
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      f32x2 gs[KU][2], gq[KU][2];
+#pragma unroll
+      for (int k = 0; k < KU; ++k)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) gs[k][e] = gq[k][e] = f32x2{0.f, 0.f};
+      float oamax = 0.f;                                     // largest |out * out_scale| this lane converted (opair)
+      // interleaved pair: lanes 2t / 2t + 1 hold columns 8g .. 8g+3 / 8g+4 .. 8g+7 of one row (UPR is even); the even lane
+      // stores [hi 8g .. 8g+7], the odd one [lo 8g .. 8g+7] -- one 16-byte store each after swapping a half (quad_perm 1,0,3,2)
+      auto pair16 = [&](const f32x4& v) -> u32x4 {
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        h4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float o = v[e] * p.out_scale;
+          oamax = fmaxf(oamax, fabsf(o));
+          hi[e] = (_Float16)o;
+          lo[e] = (_Float16)(o - (float)hi[e]);
+        }
+        const u32x2 H = __builtin_bit_cast(u32x2, hi), L = __builtin_bit_cast(u32x2, lo);
+        const bool odd = lane & 1;
+        const u32x2 send = odd ? H : L;
+        u32x2 recv;
+        recv[0] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send[0], 0xB1, 0xF, 0xF, true);
+        recv[1] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send[1], 0xB1, 0xF, 0xF, true);
+        u32x4 r;
+        r[0] = odd ? recv[0] : H[0];
+        r[1] = odd ? recv[1] : H[1];
+        r[2] = odd ? L[0] : recv[0];
+        r[3] = odd ? L[1] : recv[1];
+        return r;
+      };
+      // byte offset of that store inside the row: 64-byte chunks of 16 columns = [hi 0-7 | lo 0-7 | hi 8-15 | lo 8-15]
+      auto pair_off = [](int col) -> unsigned { return (unsigned)((col >> 4) * 64 + ((col & 8) ? 32 : 0) + ((col & 4) ? 16 : 0)); };
       float* const rs = reinterpret_cast<float*>(smem + RES0 + wave * 2 * RSLAB);
       float* const vb = reinterpret_cast<float*>(smem + VEC0);
       float* const vr = vb + 256;
@@ -849,7 +899,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
             const int row = pass_row(i, q, lrow & 3);
             f32x4 xv = {0.f, 0.f, 0.f, 0.f};
             unsigned off = OOB;
-            if (u < UNG && m0 + row < M) {
+            const bool ok = u < UNG && m0 + row < M;
+            if (ok) {
               xv = *reinterpret_cast<const f32x4*>(ep + lrow * WCOLS + 4 * c4);
               f32x4 gv = *reinterpret_cast<const f32x4*>(ep + lrow * WCOLS + HC + 4 * c4);
               if (p.bias) {
@@ -860,7 +911,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
               for (int e = 0; e < 4; ++e) xv[e] = xv[e] * cs_gelu(gv[e]);
               off = (unsigned)(orel(row) * p.ldo + (n0 + wn0) / 2 + 4 * c4) * 4u;
             }
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xv), ors, off, 0, 0);
+            if (opair) {                                     // (uniform branch: every lane takes part in the half swap)
+              const u32x4 pk = pair16(xv);
+              if (ok) off = (unsigned)(orel(row) * p.ldo) * 4u + pair_off((n0 + wn0) / 2 + 4 * c4);
+              __builtin_amdgcn_raw_buffer_store_b128(pk, ors, off, 0, 0);
+            } else {
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xv), ors, off, 0, 0);
+            }
           }
           return;
         }
@@ -871,7 +928,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
           const int row = pass_row(i, q, lrow & 3);
           f32x4 v = {0.f, 0.f, 0.f, 0.f};
           unsigned off = OOB;
-          if (u < UN && m0 + row < M) {
+          const bool ok = u < UN && m0 + row < M && n0 + wn0 + 4 * c4 < p.cout;
+          if (ok) {
             v = *reinterpret_cast<const f32x4*>(ep + lrow * WCOLS + 4 * c4);
             if (p.bias) v += *reinterpret_cast<const f32x4*>(vb + wn0 + 4 * c4);
             if (p.rowvec) v += *reinterpret_cast<const f32x4*>(vr + wn0 + 4 * c4);
@@ -881,8 +939,21 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
             }
             if (has_res) v += *reinterpret_cast<const f32x4*>(rs + (pass & 1) * (RSLAB / 4) + 4 * u);
             off = (unsigned)(orel(row) * p.ldo + n0 + wn0 + 4 * c4) * 4u;
+            if (gstat) {
+              const f32x2 lo2 = {v[0], v[1]}, hi2 = {v[2], v[3]};
+              gs[k][0] += lo2;
+              gs[k][1] += hi2;
+              gq[k][0] = __builtin_elementwise_fma(lo2, lo2, gq[k][0]);
+              gq[k][1] = __builtin_elementwise_fma(hi2, hi2, gq[k][1]);
+            }
           }
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, off, 0, 0);   // OOB lanes: dropped
+          if (opair) {
+            const u32x4 pk = pair16(v);
+            if (ok) off = (unsigned)(orel(row) * p.ldo) * 4u + pair_off(n0 + wn0 + 4 * c4);
+            __builtin_amdgcn_raw_buffer_store_b128(pk, ors, off, 0, 0);
+          } else {
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, off, 0, 0);   // OOB lanes: dropped
+          }
         }
       };
       auto all_q = [&](auto i_c) {
@@ -898,6 +969,46 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
       all_q(std::integral_constant<int, 0>{});
       if constexpr (WMB > 1) all_q(std::integral_constant<int, 1>{});
       static_assert(WMB <= 2 && NQ == 8, "pass enumeration");
+      if (opair && p.status && oamax >= 65504.f) atomicOr(p.status, CS_STATUS_F16X3_OVERFLOW);
+      if (gstat) {
+        // lanes -> [wave][staged row][column] in LDS, then thread t < BN adds column t over the waves that own it and
+        // the four staged rows, always in the same order; the tile's (sum, sum of squares) row goes out as 16-byte pairs
+        static_assert(NW * 4 * WCOLS * 8 <= LDS_BYTES && BN <= NT, "statistics scratch must fit the kernel's LDS");
+        double* const sc = reinterpret_cast<double*>(smem);
+        double tot[2] = {0.0, 0.0};
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+          __syncthreads();
+#pragma unroll
+          for (int k = 0; k < KU; ++k) {
+            const int u = lane + 64 * k;
+            if (u < UN) {
+              const int lrow = u / UPR, c4 = u - lrow * UPR;
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                sc[(wave * 4 + lrow) * WCOLS + 4 * c4 + e] = (double)(which ? gq[k][e >> 1][e & 1] : gs[k][e >> 1][e & 1]);
+            }
+          }
+          __syncthreads();
+          if (tid < BN) {
+            const int wn = tid / WCOLS, cc = tid - wn * WCOLS;
+            double t = 0.0;
+            for (int wm = 0; wm < WAVES_M; ++wm)
+#pragma unroll
+              for (int lr = 0; lr < 4; ++lr) t += sc[((wm * WAVES_N + wn) * 4 + lr) * WCOLS + cc];
+            tot[which] = t;
+          }
+        }
+        if (tid < BN && n0 + tid < p.cout) {
+          typedef double d2 __attribute__((ext_vector_type(2)));
+          const int tiles_m = (M + BM - 1) / BM;
+          const int64_t trow = (int64_t)cls_id * tiles_m + tm;
+          d2 o;
+          o[0] = tot[0];
+          o[1] = tot[1];
+          *reinterpret_cast<d2*>(p.gn_part + (trow * p.gn_ld + n0 + tid) * 2) = o;
+        }
+      }
       return;
     }
   }
@@ -1065,12 +1176,45 @@ bool cs_f16x3_slab4_ok(const CsConvGemm& p, int tile, int splits) {
 #ifdef CS_NO_SLAB
   return false;
 #else
-  static const char* e4 = getenv("CS_NO_SLAB4");
-  return !(e4 && *e4 == '1') && p.a_format == 0 && (tile == 4 || tile == 6) && splits <= 1 && p.kh == 2 && p.kw == 2 &&
+  return !cs_debug()->no_slab4 && p.a_format == 0 && (tile == 4 || tile == 6) && splits <= 1 && p.kh == 2 && p.kw == 2 &&
          (p.kd == 2 || p.kd == 3) && p.sd == 1 && p.sh == 1 && p.sw == 1 && p.ud == 0 && p.uh == 0 && p.uw == 0 &&
          (unsigned)p.pd <= 1u && (unsigned)p.ph <= 1u && (unsigned)p.pw <= 1u && (p.kd == 2 || p.pd == 1) &&
          p.din == p.dout && p.hin == p.hout && p.win == p.wout && p.win <= 32 &&
          (256 + 2LL * p.hin * p.win + 2 * p.win + 32) * p.lda * 4 < 0x7FF00000LL;
+#endif
+}
+
+// Line width of the A slab (32 / 64) the dispatch below stages for this descriptor on `tile` with `splits` K slices, 0 = the
+// per-tap gather.  ONE rule: the dispatch asks it, and so does cs_conv_gemm_launch_info (what the hosts' per-kernel
+// accounting reads instead of mirroring this file).
+int cs_f16x3_slab_width(const CsConvGemm& p, int tile, int splits) {
+#ifdef CS_NO_SLAB
+  return 0;
+#else
+  if (splits < 1) splits = 1;
+  if (p.a_format == 2) return 0;                                   // interleaved pairs: gather path only
+  if (p.a_format == 0 && cs_f16x3_slab4_ok(p, tile, splits)) return 32;      // folded Upsample classes: four taps per kd
+  const bool geom0 = p.kd == 3 && p.kh == 3 && p.kw == 3 && p.sd == 1 && p.sh == 1 && p.sw == 1 && p.pd == 1 && p.ph == 1 &&
+                     p.pw == 1 && p.ud == 0 && p.uh == 0 && p.uw == 0 && p.din == p.dout && p.hin == p.hout &&
+                     p.win == p.wout && p.win <= 64 && (512 + 2LL * p.hin * p.win + 2 * p.win + 32) * p.lda * 4 < 0x7FF00000LL;
+  // tiles 8 / 9 (512 x 64 / 512 x 128: two row blocks per wave) exist for the slab path on pre-split operands only (with the
+  // in-loop fp32 -> hi/lo conversion two row blocks x nine unrolled taps spill); elsewhere they run as 7 / 6
+  if (tile == 8 && !(geom0 && splits == 1 && p.a_format == 1)) tile = 7;
+  if (tile == 9 && !(geom0 && splits == 1 && p.win <= 32 && p.a_format == 1)) tile = 6;
+  const bool geom = (splits == 1 || tile == 4 || tile == 2 || tile == 6 || tile == 7) && geom0 &&
+                    (p.win <= 32 || tile == 7 || tile == 8);
+  // K slices of the slab kernel are whole super-chunks (nine taps): take it only where that granularity pads the slices
+  // by at most a tenth (42 super-chunks over 32 slices would leave a third of the workgroups idle)
+  const int64_t nsc_all = 3LL * ((p.cin + 15) / 16);
+  const bool slices_ok = splits == 1 || ((nsc_all + splits - 1) / splits) * splits * 10 <= nsc_all * 11;
+  if (!(geom && slices_ok)) return 0;
+  switch (tile) {
+    case 2: case 4: case 6: return 32;
+    case 7: return p.win <= 32 ? 32 : 64;
+    case 8: return p.a_format == 1 ? (p.win <= 32 ? 32 : 64) : 0;
+    case 9: return p.a_format == 1 ? 32 : 0;
+    default: return 0;
+  }
 #endif
 }
 
@@ -1110,11 +1254,8 @@ int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p_in, int M, int tile, int spl
   // (pre-split operands only: with the in-loop fp32 -> hi/lo conversion two row blocks x nine unrolled taps spill)
   if (tile == 8 && !(slab_geom0 && splits == 1 && p.a_format == 1)) tile = 7;
   if (tile == 9 && !(slab_geom0 && splits == 1 && p.win <= 32 && p.a_format == 1)) tile = 6;
-  const bool slab_geom = (splits == 1 || tile == 4 || tile == 2) && slab_geom0 && (p.win <= 32 || tile == 7 || tile == 8);
-  // K slices of the slab kernel are whole super-chunks (nine taps): take it only where that granularity pads the slices
-  // by at most a tenth (42 super-chunks over 32 slices would leave a third of the workgroups idle)
-  const int64_t nsc_all = 3LL * ((p.cin + 15) / 16);
-  const bool slab_slices_ok = splits == 1 || ((nsc_all + splits - 1) / splits) * splits * 10 <= nsc_all * 11;
+  const bool slab_geom = cs_f16x3_slab_width(p, tile, splits) != 0 && !cs_f16x3_slab4_ok(p, tile, splits);   // (the one rule, above)
+  const bool slab_slices_ok = true;
   if (p.a_format == 1) {
     if (!p.x_lo || ((uintptr_t)p.x_lo & 15) || (p.cin & 7) || (p.lda & 7)) return CS_EINVAL;
 #ifndef CS_NO_SLAB
@@ -1145,8 +1286,7 @@ int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p_in, int M, int tile, int spl
     }
   }
   // pointwise (1x1x1, stride 1, no upsampling): no source-row tables (template argument PW); CS_NO_PW=1 for A/B runs
-  static const char* e_pw = getenv("CS_NO_PW");
-  const bool pw = !(e_pw && *e_pw == '1') && p.kd == 1 && p.kh == 1 && p.kw == 1 && p.sd == 1 && p.sh == 1 && p.sw == 1 &&
+  const bool pw = !cs_debug()->no_pw && p.kd == 1 && p.kh == 1 && p.kw == 1 && p.sd == 1 && p.sh == 1 && p.sw == 1 &&
                   p.ud == 0 && p.uh == 0 && p.uw == 0 && p.pd == 0 && p.ph == 0 && p.pw == 0 &&
                   (int64_t)p.dout * p.hout * p.wout == (int64_t)p.din * p.hin * p.win &&
                   256LL * p.lda * 4 < 0x7FF00000LL;

@@ -30,18 +30,19 @@ __device__ __forceinline__ int mc_case(const float* __restrict__ s, int n, int i
 }
 
 // crossing flags of voxel (i,j,k)'s own +x/+y/+z edges (bits 0..2) and its cube's triangle count
-__device__ __forceinline__ void mc_voxel(const float* __restrict__ s, int n, int v, float level, int& flags, int& ntri) {
+__device__ __forceinline__ void mc_voxel(const float* __restrict__ s, int n, int v, float level, int table, int& flags,
+                                         int& ntri) {
   const int k = v % n, j = (v / n) % n, i = v / (n * n);
   const bool in0 = s[v] < level;
   flags = 0;
   if (i + 1 < n) flags |= (in0 != (s[v + n * n] < level)) << 0;
   if (j + 1 < n) flags |= (in0 != (s[v + n] < level)) << 1;
   if (k + 1 < n) flags |= (in0 != (s[v + 1] < level)) << 2;
-  ntri = (i + 1 < n && j + 1 < n && k + 1 < n) ? cs_mc_n_tris[mc_case(s, n, i, j, k, level)] : 0;
+  ntri = (i + 1 < n && j + 1 < n && k + 1 < n) ? cs_mc_n_tris[table][mc_case(s, n, i, j, k, level)] : 0;
 }
 
 __global__ __launch_bounds__(MC_THREADS) void mc_count_kernel(const float* __restrict__ sdf, int n, int nvox,
-                                                              int blocks_per_obj, float level,
+                                                              int blocks_per_obj, float level, int table,
                                                               int32_t* __restrict__ block_sums) {
   const int obj = blockIdx.y, blk = blockIdx.x;
   const float* s = sdf + (int64_t)obj * nvox;
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(MC_THREADS) void mc_count_kernel(const float* __res
     const int v = blk * MC_BLOCK + threadIdx.x * MC_PER + q;
     if (v < nvox) {
       int f, t;
-      mc_voxel(s, n, v, level, f, t);
+      mc_voxel(s, n, v, level, table, f, t);
       nv += __popc(f);
       nt += t;
     }
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(MC_THREADS) void mc_vertices_kernel(const float* __
     const int v = blk * MC_BLOCK + threadIdx.x * MC_PER + q;
     int t = 0;
     flags[q] = 0;
-    if (v < nvox) mc_voxel(s, n, v, level, flags[q], t);
+    if (v < nvox) mc_voxel(s, n, v, level, 0, flags[q], t);      // (the flags do not depend on the table)
     cnt += __popc(flags[q]);
   }
   int off = block_exclusive(cnt, nullptr);
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(MC_THREADS) void mc_vertices_kernel(const float* __
 }
 
 __global__ __launch_bounds__(MC_THREADS) void mc_faces_kernel(const float* __restrict__ sdf, int n, int nvox,
-                                                              int blocks_per_obj, float level,
+                                                              int blocks_per_obj, float level, int table,
                                                               const int32_t* __restrict__ block_sums,
                                                               const int64_t* __restrict__ face_base,
                                                               const int32_t* __restrict__ voff,
@@ -158,19 +159,19 @@ __global__ __launch_bounds__(MC_THREADS) void mc_faces_kernel(const float* __res
       const int k = v % n, j = (v / n) % n, i = v / (n * n);
       if (i + 1 < n && j + 1 < n && k + 1 < n) cases[q] = mc_case(s, n, i, j, k, level);
     }
-    cnt += cs_mc_n_tris[cases[q]];
+    cnt += cs_mc_n_tris[table][cases[q]];
   }
   int off = block_exclusive(cnt, nullptr);
   for (int b = 0; b < blk; ++b) off += block_sums[((int64_t)obj * blocks_per_obj + b) * 2 + 1];
   int64_t* fo = faces + face_base[obj] * 3;
   for (int q = 0; q < MC_PER; ++q) {
-    const int nt = cs_mc_n_tris[cases[q]];
+    const int nt = cs_mc_n_tris[table][cases[q]];
     if (!nt) continue;
     const int v = blk * MC_BLOCK + threadIdx.x * MC_PER + q;
     for (int t = 0; t < nt; ++t) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const int e = cs_mc_tri_table[cases[q]][3 * t + c];
+        const int e = cs_mc_tri_table[table][cases[q]][3 * t + c];
         const int owner = v + (cs_mc_edge_owner[e][0] * n + cs_mc_edge_owner[e][1]) * n + cs_mc_edge_owner[e][2];
         const int axis = cs_mc_edge_owner[e][3];
         const int packed = vf[owner];
@@ -189,26 +190,28 @@ extern "C" int cs_mc_blocks_per_object(int n) {
   return (n * n * n + MC_BLOCK - 1) / MC_BLOCK;
 }
 
-extern "C" int cs_mc_count(const float* sdf, int nb, int n, float level, int32_t* block_sums, cs_stream_t stream) {
-  if (!sdf || !block_sums || nb <= 0 || n < 2 || n > 160) return CS_EINVAL;
+extern "C" int cs_mc_count(const float* sdf, int nb, int n, float level, int table, int32_t* block_sums,
+                           cs_stream_t stream) {
+  if (!sdf || !block_sums || nb <= 0 || n < 2 || n > 160 || table < 0 || table >= CS_MC_NTABLES) return CS_EINVAL;
   const int nvox = n * n * n, bpo = cs_mc_blocks_per_object(n);
-  CS_LAUNCH(mc_count_kernel, dim3(bpo, nb), dim3(MC_THREADS), 0, (hipStream_t)stream, sdf, n, nvox, bpo, level, block_sums);
+  CS_LAUNCH(mc_count_kernel, dim3(bpo, nb), dim3(MC_THREADS), 0, (hipStream_t)stream, sdf, n, nvox, bpo, level, table,
+            block_sums);
   CS_CHECK_LAUNCH();
   return CS_OK;
 }
 
-extern "C" int cs_mc_emit(const float* sdf, int nb, int n, float level, const int32_t* block_sums,
+extern "C" int cs_mc_emit(const float* sdf, int nb, int n, float level, int table, const int32_t* block_sums,
                           const int64_t* vert_base, const int64_t* face_base, float* verts, int64_t* faces,
                           int32_t* voxel_ws, float vert_div, float vert_shift, cs_stream_t stream) {
   if (!sdf || !block_sums || !vert_base || !face_base || !verts || !faces || !voxel_ws || nb <= 0 || n < 2 || n > 160 ||
-      !(vert_div > 0.f))
+      !(vert_div > 0.f) || table < 0 || table >= CS_MC_NTABLES)
     return CS_EINVAL;
   const int nvox = n * n * n, bpo = cs_mc_blocks_per_object(n);
   hipStream_t s = (hipStream_t)stream;
   CS_LAUNCH(mc_vertices_kernel, dim3(bpo, nb), dim3(MC_THREADS), 0, s, sdf, n, nvox, bpo, level, block_sums, vert_base,
             verts, voxel_ws, vert_div, vert_shift);
   CS_CHECK_LAUNCH();
-  CS_LAUNCH(mc_faces_kernel, dim3(bpo, nb), dim3(MC_THREADS), 0, s, sdf, n, nvox, bpo, level, block_sums, face_base,
+  CS_LAUNCH(mc_faces_kernel, dim3(bpo, nb), dim3(MC_THREADS), 0, s, sdf, n, nvox, bpo, level, table, block_sums, face_base,
             voxel_ws, faces);
   CS_CHECK_LAUNCH();
   return CS_OK;

@@ -104,6 +104,62 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
   }
 }
 
+// Statistics from the producers' per-(row tile, column) partials (CsConvGemm.gn_part) instead of a pass over the tensor.
+// One wave per (sample, group): for each channel of the group in turn the lanes stride over that channel's tiles, then a
+// fixed butterfly -- the result does not depend on scheduling or on how many samples share the launch.
+struct GnSegs {
+  CsGnSeg s[4];
+  int n;
+};
+// the (sum, sum of squares) of group g of sample n from the segments' partials: the lanes of one wave stride over the
+// (channel, tile) pairs of each segment's share of the group -- independent loads, all in flight together (a first version
+// walked the channels one after the other: up to 42 dependent load latencies per group) -- in a fixed order
+__device__ __forceinline__ void gn_group_parts(const GnSegs& sg, int n, int g, int cpg, int lane, int nlanes, double& s,
+                                               double& q) {
+  s = 0;
+  q = 0;
+  const int c_lo = g * cpg, c_hi = c_lo + cpg;
+#pragma unroll
+  for (int si = 0; si < 4; ++si) {
+    if (si >= sg.n) break;
+    const CsGnSeg& sp = sg.s[si];
+    const int lo = max(c_lo, sp.ch0), hi = min(c_hi, sp.ch0 + sp.nch);
+    if (hi <= lo) continue;
+    const int tps = sp.tiles_per_sample, nt = sp.ncls * tps, items = (hi - lo) * nt;
+    const int64_t cls_stride = (int64_t)sp.nb_src * tps;
+    const int64_t t0 = (int64_t)(n % sp.nb_src) * tps;
+    for (int j = lane; j < items; j += nlanes) {
+      const int k = j / nt, r = j - k * nt;               // channel lo + k, tile r = cls * tps + t
+      const int cls = r / tps, t = r - cls * tps;
+      const double* d = sp.part + ((cls * cls_stride + t0 + t) * sp.ld + sp.col0 + (lo + k - sp.ch0)) * 2;
+      s += d[0];
+      q += d[1];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_finalize_parts_kernel(const GnSegs sg, int groups, int cpg, double count,
+                                                                float eps, float* __restrict__ stats, int total) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);  // n * groups + g
+  if (i >= total) return;
+  const int n = i / groups, g = i - n * groups;
+  double s, q;
+  gn_group_parts(sg, n, g, cpg, lane, 64, s, q);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o, 64);
+    q += __shfl_xor(q, o, 64);
+  }
+  if (lane == 0) {
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0) var = 0;
+    stats[2 * i] = (float)mean;
+    stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
 // One workgroup = a run of rows of ONE sample; a thread keeps its float4 column for the whole run, so the group
 // statistics and the affine parameters of its four channels are loaded once and the row loop has no index
 // arithmetic beyond a pointer bump (the previous flat element loop spent its time in 64-bit divisions: 45 % of the
@@ -434,6 +490,70 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const float* __restrict__
   }
 }
 
+// gn_small_kernel with the statistics taken from the producers' partials (r4): one workgroup per (sample, group) adds the
+// group's partial sums (256 threads over the (channel, tile) pairs, fixed LDS tree) and makes ONE sweep over the group.
+// Small tensors only (the gn_small rule): one launch per GroupNorm where the two-launch form would sit at its launch floors.
+__global__ __launch_bounds__(256) void gn_small_parts_kernel(const float* __restrict__ x, const GnSegs sg,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float* __restrict__ y,
+                                                             float* __restrict__ stats, int rows, int c, int ldx, int ldy,
+                                                             int groups, float eps, int act) {
+  __shared__ double red[2][256];
+  const int n = blockIdx.x / groups, g = blockIdx.x - n * groups;
+  const int cpg = c / groups;
+  const int tid = threadIdx.x;
+  double s, q;
+  gn_group_parts(sg, n, g, cpg, tid, 256, s, q);
+  red[0][tid] = s;
+  red[1][tid] = q;
+  __syncthreads();
+#pragma unroll
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) {
+      red[0][tid] += red[0][tid + o];
+      red[1][tid] += red[1][tid + o];
+    }
+    __syncthreads();
+  }
+  const double count = (double)rows * cpg;
+  const double mean_d = red[0][0] / count;
+  double var = red[1][0] / count - mean_d * mean_d;
+  if (var < 0) var = 0;
+  const float mean = (float)mean_d;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  if (tid == 0 && stats) {
+    stats[2 * blockIdx.x] = mean;
+    stats[2 * blockIdx.x + 1] = rstd;
+  }
+  const float* xb = x + (int64_t)n * rows * ldx + g * cpg;
+  float* yb = y + (int64_t)n * rows * ldy + g * cpg;
+  const int dr = 256 / cpg, dk = 256 - dr * cpg;
+  int r = tid / cpg, k = tid - r * cpg;
+  while (r < rows) {
+    float v[4], ga[4], be[4];
+    int rr[4], kk[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      rr[u] = r;
+      kk[u] = k;
+      if (r < rows) {
+        v[u] = xb[(int64_t)r * ldx + k];
+        ga[u] = gamma[g * cpg + k];
+        be[u] = beta[g * cpg + k];
+      }
+      r += dr;
+      k += dk;
+      if (k >= cpg) {
+        k -= cpg;
+        ++r;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (rr[u] < rows) yb[(int64_t)rr[u] * ldy + kk[u]] = cs_act((v[u] - mean) * rstd * ga[u] + be[u], act);
+  }
+}
+
 // row slices per sample: enough workgroups to fill the chip (~2048 in total) but no slice shorter than
 // GN_MIN_SPLIT_ROWS rows (each workgroup ends in a serial LDS reduction that longer slices amortise)
 int gn_nsplit(int rows, int nb) {
@@ -448,6 +568,63 @@ int gn_nsplit(int rows, int nb) {
 
 extern "C" int64_t cs_groupnorm_ws_bytes(int nb, int groups) {
   return (int64_t)nb * GN_MAX_SPLITS * groups * 2 * (int64_t)sizeof(double);
+}
+
+static int gn_pack_segs(const CsGnSeg* segs, int nseg, int nb, int c, GnSegs& sg) {
+  if (!segs || nseg < 1 || nseg > 4) return CS_EINVAL;
+  sg.n = nseg;
+  int next = 0;
+  for (int i = 0; i < nseg; ++i) {
+    const CsGnSeg& s = segs[i];
+    // contiguous cover of [0, c) in channel order; every tile index the kernel forms must exist
+    if (!s.part || ((uintptr_t)s.part & 15) || s.ch0 != next || s.nch <= 0 || s.col0 < 0 || s.col0 + s.nch > s.ld ||
+        s.tiles_per_sample <= 0 || s.ncls <= 0 || s.nb_src <= 0 || (nb % s.nb_src) != 0)
+      return CS_EINVAL;
+    next += s.nch;
+    sg.s[i] = s;
+  }
+  if (next != c) return CS_EINVAL;
+  for (int i = nseg; i < 4; ++i) sg.s[i] = segs[0];
+  return CS_OK;
+}
+
+extern "C" int cs_groupnorm_finalize_parts(const CsGnSeg* segs, int nseg, int nb, int rows, int c, int groups, float eps,
+                                           float* stats, cs_stream_t stream) {
+  if (!stats || nb <= 0 || rows <= 0 || c <= 0 || groups <= 0 || c % groups) return CS_EINVAL;
+  GnSegs sg;
+  const int rc = gn_pack_segs(segs, nseg, nb, c, sg);
+  if (rc != CS_OK) return rc;
+  const int total = nb * groups;
+  CS_LAUNCH(gn_finalize_parts_kernel, dim3((total + 3) / 4), dim3(256), 0, (hipStream_t)stream, sg, groups, c / groups,
+            (double)rows * (c / groups), eps, stats, total);
+  CS_CHECK_LAUNCH();
+  return CS_OK;
+}
+
+// GroupNorm of a tensor whose statistics come from its producers' partials, in ONE call: a single launch for small
+// tensors (the cs_groupnorm rule: <= 16 MB, <= 11264 elements per (sample, group)), cs_groupnorm_finalize_parts +
+// cs_groupnorm_apply otherwise.  `stats` [nb][groups][2] is written either way.
+extern "C" int cs_groupnorm_parts(const float* x, const CsGnSeg* segs, int nseg, const float* gamma, const float* beta,
+                                  float* y, int nb, int rows, int c, int ldx, int ldy, int groups, float eps, int act,
+                                  float* stats, cs_stream_t stream) {
+  if (!x || !gamma || !beta || !y || !stats || nb <= 0 || rows <= 0 || c <= 0 || groups <= 0 || c % groups || ldx < c ||
+      ldy < c)
+    return CS_EINVAL;
+  GnSegs sg;
+  const int rc0 = gn_pack_segs(segs, nseg, nb, c, sg);
+  if (rc0 != CS_OK) return rc0;
+  const int cpg = c / groups;
+  const int64_t small_group = cs_debug()->gn_small_group;
+  if ((int64_t)nb * rows * c * 4 <= GN_SMALL_BYTES && cpg <= 256 && (int64_t)rows * cpg <= small_group &&
+      (int64_t)nb * groups <= 65535) {
+    CS_LAUNCH(gn_small_parts_kernel, dim3((unsigned)(nb * groups)), dim3(256), 0, (hipStream_t)stream, x, sg, gamma, beta, y,
+              stats, rows, c, ldx, ldy, groups, eps, act);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+  }
+  const int rc = cs_groupnorm_finalize_parts(segs, nseg, nb, rows, c, groups, eps, stats, stream);
+  if (rc) return rc;
+  return cs_groupnorm_apply(x, stats, gamma, beta, y, nb, rows, c, ldx, ldy, groups, act, stream);
 }
 
 extern "C" int cs_groupnorm_stats(const float* x, int nb, int rows, int c, int ldx, int groups,
@@ -552,10 +729,7 @@ extern "C" int cs_groupnorm(const float* x, const float* gamma, const float* bet
   if (!x || !gamma || !beta || !y || !stats || nb <= 0 || rows <= 0 || c <= 0 || groups <= 0) return CS_EINVAL;
   if (c % groups || ldx < c || ldy < c) return CS_EINVAL;
   const int cpg = c / groups;
-  static const int64_t small_group = [] {                 // CS_GN_SMALL_GROUP: tuning override (tools/gn_bench.py)
-    const char* e = getenv("CS_GN_SMALL_GROUP");
-    return e ? (int64_t)atoll(e) : GN_SMALL_GROUP;
-  }();
+  const int64_t small_group = cs_debug()->gn_small_group;      // (CS_GN_SMALL_GROUP: tuning override, tools/gn_bench.py)
   // one launch while the tensor is a few MB (it stays in L2 between the two sweeps) and a group is a handful of
   // elements per thread; otherwise statistics (two launches) + apply
   if ((int64_t)nb * rows * c * 4 <= GN_SMALL_BYTES && cpg <= 256 && (int64_t)rows * cpg <= small_group &&

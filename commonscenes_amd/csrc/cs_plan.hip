@@ -1,0 +1,116 @@
+// Host-side decisions that every host of the library shares (r4, VERDICT r3 next #5: "one plan, one place").
+//
+// Until r3 the Python host (ops.py) and the native drivers (cs_driver.h) each carried their own copy of the rules that
+// decide HOW an operator is run -- the F16X3 operand scale of a normalisation-fed GEMM, whether a GroupNorm emits the
+// pre-split operand pair for the conv that follows, the tile of a taps-as-columns GEMM, the row threshold of the
+// channel-split ResBlocks -- and ~40 CS_* environment switches were parsed wherever they were used, in both languages.
+// The rules live here now, once, behind the C ABI: both hosts call them (and cs_conv_gemm_plan / cs_conv_gemm_epilogue_caps /
+// cs_conv_gemm_launch_info in cs_gemm.hip), and the switches are ONE struct, CsDebug, parsed ONCE from the environment.
+// Nothing in this file touches the device.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+#include "cs_common.h"
+
+namespace {
+
+CsDebug g_dbg;
+std::once_flag g_once;
+
+bool flag(const char* name) {       // set, non-empty and not "0"
+  const char* e = getenv(name);
+  return e && *e && !(e[0] == '0' && e[1] == 0);
+}
+long long num(const char* name, long long dflt) {
+  const char* e = getenv(name);
+  return (e && *e) ? atoll(e) : dflt;
+}
+
+void parse_env(CsDebug& d) {
+  memset(&d, 0, sizeof(d));
+  d.no_split16 = flag("CS_NO_SPLIT16");
+  d.split16_min_rows = num("CS_SPLIT16_MIN_ROWS", 8192);
+  d.no_pair16 = flag("CS_NO_PAIR16");
+  d.no_upfold = flag("CS_NO_UPFOLD");
+  d.no_splitk = flag("CS_NO_SPLITK");
+  d.no_fused_geglu = flag("CS_NO_FUSED_GEGLU");
+  d.no_tapcol = flag("CS_NO_TAPCOL");
+  d.tapcol_tile = (int32_t)num("CS_TAPCOL_TILE", 0);
+  d.no_cfg_split = flag("CS_NO_CFG_SPLIT");
+  d.cfg_split_min_rows = num("CS_CFG_SPLIT_MIN_ROWS", 65536);
+  d.concat_copy = flag("CS_CONCAT_COPY");
+  d.gn_small_group = num("CS_GN_SMALL_GROUP", 11264);
+  d.tile512 = flag("CS_TILE512");
+  d.no_pw = flag("CS_NO_PW");
+  d.no_slab4 = flag("CS_NO_SLAB4");
+  d.no_attn_img = flag("CS_NO_ATTN_IMG");
+  d.attn_nw8 = flag("CS_ATTN_NW8");
+  d.no_up2_direct = flag("CS_NO_UP2_DIRECT");
+  d.no_up2_batch = flag("CS_NO_UP2_BATCH");
+  d.plan_pow2 = flag("CS_PLAN_POW2");
+  d.slice_tile2 = flag("CS_SLICE_TILE2");
+  d.no_gn_parts = flag("CS_NO_GN_PARTS");
+  d.no_pair_epilogue = flag("CS_NO_PAIR_EPILOGUE");
+}
+
+}  // namespace
+
+extern "C" const CsDebug* cs_debug(void) {
+  std::call_once(g_once, [] { parse_env(g_dbg); });
+  return &g_dbg;
+}
+
+extern "C" void cs_debug_set(const CsDebug* d) {
+  (void)cs_debug();
+  if (d)
+    g_dbg = *d;
+  else
+    parse_env(g_dbg);
+}
+
+// F16X3 operand scale of a GEMM fed by a GroupNorm / LayerNorm (+ SiLU / GELU / identity) taking its statistics over n
+// elements.  A normalised value obeys |x^| <= sqrt(n - 1), so |y| <= gmax * sqrt(n - 1) + bmax =: bound (|silu(y)|,
+// |gelu(y)| <= |y|): the largest power of two 2^k with bound * 2^k <= 65000 < 65504 cannot leave the fp16 range WHATEVER the
+// input -- the producer's bound replaces a fixed guess (r3) -- and is 16-128x larger than the raw-activation default 16 for
+// the shipped layers, so the absolute floor 2^-25 / a_scale of tiny operands drops accordingly.  k is clamped to [-8, 40].
+extern "C" float cs_norm_a_scale(float gmax, float bmax, int64_t n) {
+  const double bound = (double)gmax * std::sqrt((double)(n > 1 ? n - 1 : 1)) + (double)bmax;
+  if (!(bound > 0.0) || !std::isfinite(bound)) return (float)std::ldexp(1.0, 40);
+  int ex = 0;
+  (void)std::frexp(65000.0 / bound, &ex);
+  int k = ex - 1;
+  if (k < -8) k = -8;
+  if (k > 40) k = 40;
+  return (float)std::ldexp(1.0, k);
+}
+
+// Should the GroupNorm feeding a conv (cout x cin x k^3, `plain`: neither a folded Upsample conv nor taps-as-columns) over m
+// output rows emit the fp16 hi / lo operand pair (CsConvGemm.a_format = 1)?  Yes where that conv runs the slab kernel on a
+// 256-row tile -- there the in-loop conversion is what is left to remove -- and, for the 224-column convs of
+// medium batches, on the 128-row slab tile from split16_min_rows rows (r3: 7 objects 27.34 -> 26.94 ms/step; below it
+// slower).  Bit-identical to the fp32 route either way.
+extern "C" int cs_conv_wants_split16(int64_t m, int cin, int cout, int k, int plain, int math) {
+  const CsDebug* d = cs_debug();
+  if (d->no_split16 || math != CS_MATH_F16X3 || !plain || k != 3 || (cin & 7)) return 0;
+  const int64_t t256 = (m + 255) / 256;
+  if (cout % 224 == 0) return t256 * (cout / 224) >= 192 || (d->split16_min_rows > 0 && m >= d->split16_min_rows);
+  if (cout % 128 == 0) return t256 * (cout / 128) >= 192;
+  return (cout == 64 || cout <= 4) && t256 >= 192;
+}
+
+// Tile of the pointwise GEMM of a taps-as-columns conv (cs_pack_weight_f16x3_tapcol: ncolp = 27 * cout + pad columns):
+// 256-row tiles once they fill the chip, the library's automatic choice (0) below.
+extern "C" int cs_tapcol_tile(int64_t m, int ncolp) {
+  const CsDebug* d = cs_debug();
+  if (d->tapcol_tile) return d->tapcol_tile;
+  if ((m + 255) / 256 < 192) return 0;
+  return ncolp <= 64 ? 7 : 6;
+}
+
+// Is a 3x3x3 conv with this few output channels run as "taps as columns" ?  The callers name the layers
+// (UNet `out.2`, VQ decoder `conv_out`); this is the rule they are then held to.
+extern "C" int cs_tapcol_ok(int cout, int cin, int k, int math) {
+  return !cs_debug()->no_tapcol && math == CS_MATH_F16X3 && k == 3 && cout <= 4 && (cin & 3) == 0;
+}

@@ -237,8 +237,7 @@ int build(cs_unet& u) {
   // channel-split ResBlocks: output block j reads the skip of input block (n_in - 1 - j); the ones from the context-free
   // prefix of the input path (before the first attention block) are shared by the guidance halves.  Same rule and same
   // split point as unet.py::_pack.
-  const char* no_split = getenv("CS_NO_CFG_SPLIT");
-  if (c.use_spatial_transformer && !(no_split && *no_split)) {
+  if (c.use_spatial_transformer && !cs_debug()->no_cfg_split) {
     size_t n_prefix = 0;
     while (n_prefix < u.inp.size()) {
       bool attn = false;
@@ -270,7 +269,7 @@ int build(cs_unet& u) {
       l.ch_h = ch_h;
     }
   }
-  if (const char* e = getenv("CS_CFG_SPLIT_MIN_ROWS")) u.split_min_rows = atoll(e);
+  u.split_min_rows = cs_debug()->cfg_split_min_rows;
   u.ch_final = ch;
   u.n_out = add_norm(u, P + "out.0", ch);
   u.g_out = add_layer_gemm(u, P + "out.2", c.out_channels, mc, 3, true, 0, 0, /*tapcol=*/true);
@@ -290,16 +289,21 @@ struct Exec : ExecBase {
   Act res_block(const Layer& l, const Act& x, const Buf& semb) {
     const int rows = x.d * x.h * x.w;
     Buf hn = groupnorm(x.b, l.n[0], x.nb, 1e-5f, CS_ACT_SILU, 32, l.g[0]);
-    Buf h1 = gemm(hn, l.g[0], x.nb, x.d, x.h, x.w, 1, 0, CS_ACT_NONE, dry ? nullptr : p(semb) + l.emb_lo, semb.c, rows);
+    // (want_stats: the conv's epilogue leaves the partial sums the next GroupNorm takes its statistics from -- unet.py::_res)
+    Buf h1 = gemm(hn, l.g[0], x.nb, x.d, x.h, x.w, 1, 0, CS_ACT_NONE, dry ? nullptr : p(semb) + l.emb_lo, semb.c, rows,
+                  nullptr, 0, 0, 1, 0, /*want_stats=*/true);
     release(hn);
     Buf hn2 = groupnorm(h1, l.n[1], x.nb, 1e-5f, CS_ACT_SILU, 32, l.g[1]);
     release(h1);
-    Buf skip = x.b;
-    if (l.g[2] >= 0) skip = gemm(x.b, l.g[2], x.nb, x.d, x.h, x.w);
+    Buf skip;
+    const bool own_skip = l.g[2] >= 0;
+    if (own_skip) skip = gemm(x.b, l.g[2], x.nb, x.d, x.h, x.w);
     Act o = x;
-    o.b = gemm(hn2, l.g[1], x.nb, x.d, x.h, x.w, 1, 0, CS_ACT_NONE, nullptr, 0, 1, dry ? nullptr : p(skip), skip.c);
+    const Buf& sk = own_skip ? skip : x.b;
+    o.b = gemm(hn2, l.g[1], x.nb, x.d, x.h, x.w, 1, 0, CS_ACT_NONE, nullptr, 0, 1, dry ? nullptr : p(sk), sk.c, 0, 1, 0,
+               /*want_stats=*/true);
     release(hn2);
-    if (l.g[2] >= 0) release(skip);
+    if (own_skip) release(skip);
     return o;
   }
 
@@ -349,7 +353,8 @@ struct Exec : ExecBase {
     Buf skc = gemm(x.b, l.g[2], nb, x.d, x.h, x.w);
     Buf hn2 = groupnorm(h1, l.n[1], nb, 1e-5f, CS_ACT_SILU, 32, l.g[1]);
     release(h1);
-    o.b = gemm(hn2, l.g[1], nb, x.d, x.h, x.w, 1, 0, CS_ACT_NONE, nullptr, 0, 1, dry ? nullptr : p(skc), cout);
+    o.b = gemm(hn2, l.g[1], nb, x.d, x.h, x.w, 1, 0, CS_ACT_NONE, nullptr, 0, 1, dry ? nullptr : p(skc), cout, 0, 1, 0,
+               /*want_stats=*/true);
     release(hn2);
     release(skc);
     return o;
@@ -375,8 +380,11 @@ struct Exec : ExecBase {
     release(t0);
     Buf n3 = layernorm(t1, l.n[3]);
     Buf gg;
+    // gg's only reader is ff.net.2, t2's only reader proj_out: both producers write the operand pair where they can
+    // (unet.py::_attn, out_pair=)
+    const float pairs = u.cfg.math == CS_MATH_F16X3 ? 16.f : 0.f;
     if (l.fused_geglu) {
-      gg = linear(n3, l.g[5], CS_ACT_GEGLU);           // tile 0: cs_conv_gemm picks a 224-column tile for the gate
+      gg = linear(n3, l.g[5], CS_ACT_GEGLU, nullptr, 0, 1, nullptr, 0, 0, pairs);   // tile 0: a 224-column tile for the gate
     } else {
       Buf ff = linear(n3, l.g[5]);
       gg = alloc(rows, 4 * c);
@@ -384,11 +392,13 @@ struct Exec : ExecBase {
       release(ff);
     }
     release(n3);
-    Buf t2 = linear(gg, l.g[6], CS_ACT_NONE, nullptr, 0, 1, dry ? nullptr : p(t1), c);
+    Buf t2 = linear(gg, l.g[6], CS_ACT_NONE, nullptr, 0, 1, dry ? nullptr : p(t1), c, 0, pairs);
     release(gg);
     release(t1);
     Act o = x;
-    o.b = linear(t2, l.g[7], CS_ACT_NONE, nullptr, 0, 1, dry ? nullptr : p(x.b), c);
+    // (x.nb samples of n tokens: what the epilogue's GroupNorm partial sums are tiled by -- unet.py::_attn, spatial=)
+    o.b = gemm(t2, l.g[7], x.nb, n, 1, 1, 1, 0, CS_ACT_NONE, nullptr, 0, 1, dry ? nullptr : p(x.b), c, 0, 1, 0,
+               /*want_stats=*/true);
     release(t2);
     return o;
   }
@@ -404,7 +414,8 @@ struct Exec : ExecBase {
     self_attention(qkv, a, x.nb, n, heads, dh, c, (float)std::pow((double)dh, -0.5));
     release(qkv);
     Act o = x;
-    o.b = linear(a, l.g[1], CS_ACT_NONE, nullptr, 0, 1, dry ? nullptr : p(x.b), c);
+    o.b = gemm(a, l.g[1], x.nb, n, 1, 1, 1, 0, CS_ACT_NONE, nullptr, 0, 1, dry ? nullptr : p(x.b), c, 0, 1, 0,
+               /*want_stats=*/true);
     release(a);
     return o;
   }
@@ -425,7 +436,7 @@ struct Exec : ExecBase {
       switch (l.kind) {
         case CONV_IN:
           o = h;
-          o.b = gemm(h.b, l.g[0], h.nb, h.d, h.h, h.w);
+          o.b = gemm(h.b, l.g[0], h.nb, h.d, h.h, h.w, 1, 0, CS_ACT_NONE, nullptr, 0, 1, nullptr, 0, 0, 1, 0, true);
           break;
         case RES:
           o = res_block(l, h, semb);
@@ -439,7 +450,7 @@ struct Exec : ExecBase {
         case DOWN: {   // dims == 3: inner two dims only (openai_model_3d.py:188); dims == 4: all three
           const int sd = u.cfg.dims == 3 ? 1 : 2;
           o = h;
-          o.b = gemm(h.b, l.g[0], h.nb, h.d, h.h, h.w, 2, 0, CS_ACT_NONE, nullptr, 0, 1, nullptr, 0, 0, sd, 0);
+          o.b = gemm(h.b, l.g[0], h.nb, h.d, h.h, h.w, 2, 0, CS_ACT_NONE, nullptr, 0, 1, nullptr, 0, 0, sd, 0, true);
           o.d = h.d / sd;
           o.h = h.h / 2;
           o.w = h.w / 2;
@@ -448,7 +459,7 @@ struct Exec : ExecBase {
         case UP: {     // nearest x2 folded into the conv's addressing (openai_model_3d.py:148-157)
           const int ud = u.cfg.dims == 3 ? 0 : 1;
           o = h;
-          o.b = gemm(h.b, l.g[0], h.nb, h.d, h.h, h.w, 1, 1, CS_ACT_NONE, nullptr, 0, 1, nullptr, 0, 0, 1, ud);
+          o.b = gemm(h.b, l.g[0], h.nb, h.d, h.h, h.w, 1, 1, CS_ACT_NONE, nullptr, 0, 1, nullptr, 0, 0, 1, ud, true);
           o.d = h.d << ud;
           o.h = h.h * 2;
           o.w = h.w * 2;
@@ -462,8 +473,12 @@ struct Exec : ExecBase {
     return h;
   }
 
-  Buf duplicate(const Buf& a) {   // torch.cat([a, a], dim=0)
+  Buf duplicate(const Buf& a) {   // torch.cat([a, a], dim=0); the copy gets its own copy of the producer's partials
     Buf o = alloc(2 * a.rows, a.c);
+    if (a.nseg == 1 && a.seg[0].valid()) {
+      o.seg[0] = dup_stat(a.seg[0]);
+      o.nseg = o.seg[0].valid() ? 1 : 0;
+    }
     if (ok() && !dry) {
       const size_t bytes = (size_t)a.rows * a.c * 4;
       if (hipMemcpyAsync(p(o), p(a), bytes, hipMemcpyDeviceToDevice, st) != hipSuccess ||
@@ -541,6 +556,17 @@ int forward(Exec& e, const float* x_ncdhw, const int64_t* t, const float* ctxvec
       for (int g = 0; g < groups && e.ok(); ++g)
         e.chk(cs_copy_rows(e.p(sk.b), e.p(cat.b) + (int64_t)g * sk.b.rows * cat.b.c + h.b.c, sk.b.rows, sk.b.c,
                            sk.b.c, cat.b.c, e.st));
+    }
+    // the concatenation's GroupNorm takes its statistics from both halves' producers (unet.py: cs_segs): their partials
+    // move to the concatenation buffer and are released with it
+    cat.b.nseg = 0;
+    if (h.b.nseg == 1 && sk.b.nseg == 1 && h.b.seg[0].valid() && sk.b.seg[0].valid()) {
+      cat.b.seg[0] = h.b.seg[0];
+      cat.b.seg[1] = sk.b.seg[0];
+      cat.b.nseg = 2;
+      h.b.seg[0] = Stat();
+      sk.b.seg[0] = Stat();
+      h.b.nseg = sk.b.nseg = 0;
     }
     e.release(h.b);
     if (layers[0].kind == RES && layers[0].ks > 0 && cat.b.rows >= u.split_min_rows) {

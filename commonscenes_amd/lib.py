@@ -17,7 +17,7 @@ import torch  # noqa: F401
 
 from .build import LIB_PATH
 
-ABI_VERSION = 13     # cs_abi_version() of the library this module's SIGNATURES table describes
+ABI_VERSION = 14     # cs_abi_version() of the library this module's SIGNATURES table describes
 CS_OK = 0
 CS_EINVAL = -22
 CS_ENOMEM = -12
@@ -52,7 +52,23 @@ class CsConvGemm(C.Structure):
         ("w_lo", C.c_void_p), ("acc_scale", C.c_float), ("a_scale", C.c_float),
         ("x_lo", C.c_void_p), ("a_format", C.c_int32), ("splitk", C.c_int32),
         ("splitk_ws", C.c_void_p), ("status", C.c_void_p),
+        ("gn_part", C.c_void_p), ("gn_ld", C.c_int32), ("gn_rows", C.c_int32), ("out_format", C.c_int32),
+        ("out_scale", C.c_float),
     ]
+
+
+class CsGnSeg(C.Structure):
+    _fields_ = [("part", C.c_void_p), ("ld", C.c_int32), ("col0", C.c_int32), ("ch0", C.c_int32), ("nch", C.c_int32),
+                ("tiles_per_sample", C.c_int32), ("ncls", C.c_int32), ("nb_src", C.c_int32), ("reserved", C.c_int32)]
+
+
+class CsDebug(C.Structure):
+    """include/commonscenes_hip.h: the debug / A-B switches, parsed ONCE from the CS_* environment by the library"""
+    _fields_ = [(n, C.c_int32) for n in (
+        "no_split16", "no_pair16", "no_upfold", "no_splitk", "no_fused_geglu", "no_tapcol", "tapcol_tile", "no_cfg_split",
+        "concat_copy", "tile512", "no_pw", "no_slab4", "no_attn_img", "attn_nw8", "no_up2_direct", "no_up2_batch",
+        "plan_pow2", "slice_tile2", "no_gn_parts", "no_pair_epilogue")] + [
+        ("split16_min_rows", C.c_int64), ("cfg_split_min_rows", C.c_int64), ("gn_small_group", C.c_int64)]
 
 
 class CsUnetConfig(C.Structure):
@@ -80,6 +96,16 @@ _pp = C.POINTER(C.c_void_p)
 SIGNATURES = {
     "cs_conv_gemm": (_i, [C.POINTER(CsConvGemm), _s]),
     "cs_conv_gemm_plan": (_i, [C.POINTER(CsConvGemm), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    "cs_conv_gemm_epilogue_caps": (_i, [C.POINTER(CsConvGemm), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "cs_conv_gemm_launch_info": (_i, [C.POINTER(CsConvGemm), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "cs_debug": (C.POINTER(CsDebug), []),
+    "cs_debug_set": (None, [C.POINTER(CsDebug)]),
+    "cs_norm_a_scale": (_fl, [_fl, _fl, _l]),
+    "cs_conv_wants_split16": (_i, [_l, _i, _i, _i, _i, _i]),
+    "cs_tapcol_ok": (_i, [_i, _i, _i, _i]),
+    "cs_tapcol_tile": (_i, [_l, _i]),
+    "cs_groupnorm_finalize_parts": (_i, [C.POINTER(CsGnSeg), _i, _i, _i, _i, _i, _fl, _f, _s]),
+    "cs_groupnorm_parts": (_i, [_f, C.POINTER(CsGnSeg), _i, _f, _f, _f, _i, _i, _i, _i, _i, _i, _fl, _i, _f, _s]),
     "cs_conv_up2_info": (_i, [_i, _i, _i, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                               C.POINTER(C.c_int32)]),
     "cs_fold_upsample_weight": (_i, [_f, _f, _i, _i, _i, _i, _i, _s]),
@@ -122,8 +148,8 @@ SIGNATURES = {
     "cs_emd_matchcost": (_i, [_f, _f, _f, _f, _i, _i, _i, _s]),
     "cs_emd_matchcost_grad": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _s]),
     "cs_mc_blocks_per_object": (_i, [_i]),
-    "cs_mc_count": (_i, [_f, _i, _i, _fl, _f, _s]),
-    "cs_mc_emit": (_i, [_f, _i, _i, _fl, _f, _f, _f, _f, _f, _f, _fl, _fl, _s]),
+    "cs_mc_count": (_i, [_f, _i, _i, _fl, _i, _f, _s]),
+    "cs_mc_emit": (_i, [_f, _i, _i, _fl, _i, _f, _f, _f, _f, _f, _f, _fl, _fl, _s]),
     "cs_chamfer_nm_distance": (_i, [_f, _f, _f, _f, _i, _i, _i, _s]),
     "cs_unet_create": (_i, [C.POINTER(CsUnetConfig), _pp]),
     "cs_unet_destroy": (None, [C.c_void_p]),
@@ -202,9 +228,38 @@ class CsOverflowError(CsError):
 
 
 STATUS_F16X3_OVERFLOW = 1
+STATUS_INTERNAL = 2
 
 
 def check(rc: int, what: str) -> None:
     if rc != CS_OK:
         kind = {CS_EINVAL: "invalid argument", CS_ENOMEM: "workspace too small"}.get(rc, f"hipError_t {rc}")
         raise CsError(f"{what} failed: {kind}")
+
+
+def debug() -> CsDebug:
+    """The library's CsDebug struct (live view): the ONE parse of the CS_* A/B switches, shared by every host."""
+    return load().cs_debug().contents
+
+
+class debug_override:
+    """`with lib.debug_override(no_gn_parts=1): ...` -- flip switches inside one process (tests, A/B tools); restores the
+    previous state on exit.  cs_debug_set copies the struct, so the library and every host see the change at once."""
+
+    def __init__(self, **fields):
+        self.fields = fields
+
+    def __enter__(self):
+        cur = debug()
+        self.prev = CsDebug.from_buffer_copy(cur)
+        new = CsDebug.from_buffer_copy(cur)
+        for k, v in self.fields.items():
+            if not hasattr(new, k):
+                raise AttributeError(f"CsDebug has no field {k!r}")
+            setattr(new, k, int(v))
+        load().cs_debug_set(C.byref(new))
+        return self
+
+    def __exit__(self, *exc):
+        load().cs_debug_set(C.byref(self.prev))
+        return False

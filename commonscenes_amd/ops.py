@@ -151,7 +151,7 @@ def pack_weight(w: Tensor, bias: Optional[Tensor] = None, cin_pad: Optional[int]
     """torch Conv3d (cout,cin,kd,kh,kw) or Linear (out,in) weight -> PackedWeight (device op).
     fold_up=(ud,uh,uw): the conv follows a nearest x2 upsampling of the flagged dims; its taps are pre-summed per output
     parity class (cs_fold_upsample_weight) and conv_gemm(..., up=fold_up) runs on the source grid."""
-    if fold_up is not None and any(fold_up) and FOLD_UPSAMPLE:
+    if fold_up is not None and any(fold_up) and _sw("FOLD_UPSAMPLE"):
         return _pack_weight_folded(w, bias, cin_pad, math, tuple(int(u) for u in fold_up))
     if math == L.MATH_F16X3:
         return _pack_weight_f16x3(w, bias, cin_pad, amax)
@@ -182,24 +182,38 @@ A_SCALE = 16.0      # activation pre-scale of the f16x3 mode (CsConvGemm.a_scale
 
 def norm_a_scale(gmax: float, bmax: float, n: int) -> float:
     """Operand scale of an F16X3 GEMM fed by a GroupNorm / LayerNorm (+ SiLU / GELU / identity) over n elements per
-    statistic.  A normalised value obeys |x^| <= sqrt(n - 1), so |y| <= gmax * sqrt(n - 1) + bmax =: bound (|silu(y)|,
-    |gelu(y)| <= |y|): the largest power of two 2^k with bound * 2^k <= 65000 < 65504 cannot overflow the fp16 range
-    WHATEVER the input -- the producer's bound replaces the fixed guess of 16 (r3; VERDICT r2 next #7c) -- and is 16-128x
-    larger for the shipped layers, so the absolute floor 2^-25 / a_scale of tiny operands (the lo half leaves fp16's
-    normal range below a_scale * |a| = 2^-3) drops accordingly; a layer whose affine parameters are uniformly tiny gets a
-    correspondingly huge scale and keeps full relative precision.  k is clamped to [-8, 40] (products stay below
-    2^16 * 2^14 by construction, acc_scale = 2^-(k + weight exponent) stays a normal fp32).  Every step is an IEEE double operation, mirrored in csrc/cs_driver.h::norm_a_scale: both
-    hosts derive the same scale."""
-    import math as _m
-    bound = float(gmax) * _m.sqrt(float(max(n - 1, 1))) + float(bmax)
-    if not (bound > 0.0) or not _m.isfinite(bound):
-        return 2.0 ** 40
-    k = _m.frexp(65000.0 / bound)[1] - 1
-    return 2.0 ** max(-8, min(40, k))
+    statistic: the largest power of two that keeps the producer's bound |y| <= gmax * sqrt(n - 1) + bmax inside the fp16
+    range -- it cannot overflow WHATEVER the input (r3).  The rule itself is cs_norm_a_scale (csrc/cs_plan.hip): ONE
+    implementation, called by this host and by the native drivers (r4; r3 kept a Python copy here)."""
+    return float(L.load().cs_norm_a_scale(float(gmax), float(bmax), int(n)))
 
 
-# CS_NO_UPFOLD=1: upsample convs take the direct form (27 taps on the doubled grid) -- A/B runs
-FOLD_UPSAMPLE = not os.environ.get("CS_NO_UPFOLD")
+# ---- switches ---------------------------------------------------------------------------------------------------------
+# r4: the CS_* A/B switches are ONE struct parsed once by the library (include/commonscenes_hip.h CsDebug, lib.debug());
+# the module attributes below are views of it, kept under their r1-r3 names.  A test may still assign one
+# (monkeypatch.setattr(ops, "SPLITK", False)): the assignment shadows the view for this module's own reads too.
+_SWITCHES = {
+    "FOLD_UPSAMPLE": lambda d: not d.no_upfold,          # CS_NO_UPFOLD=1: Upsample convs in direct form (27 taps, doubled grid)
+    "TAPCOL": lambda d: not d.no_tapcol,                 # CS_NO_TAPCOL=1: thin-output convs stay on the implicit GEMM
+    "SPLITK": lambda d: not d.no_splitk,                 # CS_NO_SPLITK=1: never ask cs_conv_gemm_plan for K slices
+    "PAIR16_PRODUCERS": lambda d: not d.no_pair16,       # CS_NO_PAIR16=1: LayerNorm keeps emitting fp32
+    "SPLIT16_PRODUCERS": lambda d: not d.no_split16,     # CS_NO_SPLIT16=1: GroupNorm emits fp32, not the operand pair
+    "PAIR_EPILOGUES": lambda d: not d.no_pair_epilogue,  # CS_NO_PAIR_EPILOGUE=1: GEMM epilogues always write fp32
+    "GN_PARTS": lambda d: not d.no_gn_parts,             # CS_NO_GN_PARTS=1: GroupNorm statistics from a pass over the tensor
+}
+
+
+def _sw(name: str):
+    g = globals()
+    return g[name] if name in g else _SWITCHES[name](L.debug())
+
+
+def __getattr__(name: str):          # PEP 562: ops.SPLITK etc. for outside readers
+    if name in _SWITCHES:
+        return _sw(name)
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
+
+
 
 
 def _pack_weight_folded(w: Tensor, bias: Optional[Tensor], cin_pad: Optional[int], math: int,
@@ -252,14 +266,11 @@ def _pack_weight_f16x3(w: Tensor, bias: Optional[Tensor], cin_pad: Optional[int]
     return PackedWeight(None, b, cout, cin, cp, cout, (kd, kh, kw), L.MATH_F16X3, wh, wl, 1.0 / (scale * A_SCALE))
 
 
-# CS_NO_TAPCOL=1: thin-output convs stay on the implicit GEMM (A/B runs)
-TAPCOL = not os.environ.get("CS_NO_TAPCOL")
-
-
 def tapcol_ok(w: Tensor, math: int) -> bool:
-    """the rule both hosts apply (csrc/cs_driver.h::add_layer_gemm): F16X3, 3x3x3, at most 4 output channels"""
-    return (TAPCOL and math == L.MATH_F16X3 and w.dim() == 5 and tuple(w.shape[2:]) == (3, 3, 3) and w.shape[0] <= 4
-            and w.shape[1] % 4 == 0)
+    """is this (named) thin-output 3x3x3 conv run as taps-as-columns?  cs_tapcol_ok: the rule both hosts ask"""
+    if not _sw("TAPCOL") or w.dim() != 5 or tuple(w.shape[2:]) != (3, 3, 3):
+        return False
+    return bool(L.load().cs_tapcol_ok(int(w.shape[0]), int(w.shape[1]), 3, int(math)))
 
 
 def pack_weight_tapcol(w: Tensor, bias: Optional[Tensor] = None) -> PackedWeight:
@@ -292,12 +303,8 @@ def pack_weight_tapcol(w: Tensor, bias: Optional[Tensor] = None) -> PackedWeight
 
 
 def tapcol_tile(m: int, ncolp: int) -> int:
-    """tile of the taps-as-columns GEMM (mirrored in cs_driver.h): 256-row tiles once they fill the chip"""
-    if os.environ.get("CS_TAPCOL_TILE"):               # tuning runs (Python host only)
-        return int(os.environ["CS_TAPCOL_TILE"])
-    if (m + 255) // 256 < 192:
-        return 0
-    return 7 if ncolp <= 64 else 6
+    """tile of the taps-as-columns GEMM: cs_tapcol_tile (csrc/cs_plan.hip), the rule both hosts ask"""
+    return int(L.load().cs_tapcol_tile(int(m), int(ncolp)))
 
 
 def _conv_tapcol(x, w: PackedWeight, spatial, a_scale, out, out_fn) -> Tensor:
@@ -339,15 +346,92 @@ def pack_geglu_weight(w: Tensor, bias: Tensor, group: int = 112) -> PackedWeight
     return pack_weight(w[perm].contiguous(), bias[perm].contiguous(), math=L.MATH_F16X3)
 
 
+@dataclass
+class ColStats:
+    """Per-(row tile, column) fp64 (sum, sum of squares) of a GEMM's output, written by its epilogue
+    (CsConvGemm.gn_part): what the GroupNorm that follows needs instead of a pass over the tensor."""
+    part: Tensor          # [tiles, ld, 2] float64
+    nch: int              # columns (= the producer's cout)
+    nb: int               # samples the producer ran
+    tps: int              # statistics tiles per sample (and per class)
+    ncls: int = 1         # parity classes of a folded Upsample launch (tiles ordered [class][sample][tile])
+
+
+def attach_stats(t: Tensor, st) -> Tensor:
+    """remember the producer's partials on the tensor object (a plain attribute: views made later do not inherit it)"""
+    if st is not None:
+        t.cs_stats = st
+    return t
+
+
+def stats_segments(x: Tensor):
+    """[(first channel, ColStats)] covering x's channels in order, or None: `cs_segs` (a concatenation whose halves came
+    from two producers) or `cs_stats` (one producer)."""
+    if not _sw("GN_PARTS"):
+        return None
+    segs = getattr(x, "cs_segs", None)
+    if segs is None:
+        st = getattr(x, "cs_stats", None)
+        segs = [(0, st)] if st is not None else None
+    if segs is None or any(s is None for _, s in segs) or sum(s.nch for _, s in segs) != x.shape[-1]:
+        return None
+    return segs
+
+
+def _seg_array(segs):
+    arr = (L.CsGnSeg * len(segs))()
+    for i, (ch0, st) in enumerate(segs):
+        arr[i].part, arr[i].ld, arr[i].col0 = st.part.data_ptr(), int(st.part.shape[1]), 0
+        arr[i].ch0, arr[i].nch = int(ch0), int(st.nch)
+        arr[i].tiles_per_sample, arr[i].ncls, arr[i].nb_src = int(st.tps), int(st.ncls), int(st.nb)
+    return arr
+
+
+def groupnorm_stats_from_parts(segs, nb: int, rows: int, c: int, groups: int, eps: float, device) -> Tensor:
+    """(mean, rstd) [nb, groups, 2] from the producers' partials (cs_groupnorm_finalize_parts): no pass over the tensor."""
+    arr = _seg_array(segs)
+    stats = torch.empty((nb, groups, 2), dtype=torch.float32, device=device)
+    L.check(L.load().cs_groupnorm_finalize_parts(arr, len(segs), nb, rows, c, groups, eps, stats.data_ptr(), _stream()),
+            "cs_groupnorm_finalize_parts")
+    return stats
+
+
+def _epilogue_extras(lib, p, x_dev, nb: int, rps: int, m_tiles_rows: int, cout: int, want_stats: bool,
+                     out_pair: Optional[float], ncls: int = 1):
+    """Ask the library what this launch's epilogue can emit (cs_conv_gemm_epilogue_caps -- the one rule) and set the
+    descriptor up for it.  Returns (ColStats | None, pair_taken: bool).  rps = rows per sample the statistics tiles run
+    over (the source rows for a folded Upsample conv), m_tiles_rows = the rows those tiles cover in all."""
+    if not (want_stats and _sw("GN_PARTS")) and out_pair is None:
+        return None, False
+    rows, pair = C.c_int32(0), C.c_int32(0)
+    L.check(lib.cs_conv_gemm_epilogue_caps(C.byref(p), C.byref(rows), C.byref(pair)), "cs_conv_gemm_epilogue_caps")
+    st = None
+    if want_stats and _sw("GN_PARTS") and rows.value > 0:
+        tiles = (m_tiles_rows + rows.value - 1) // rows.value
+        part = torch.empty((ncls * tiles, cout, 2), dtype=torch.float64, device=x_dev)
+        p.gn_part, p.gn_ld, p.gn_rows = part.data_ptr(), cout, rows.value
+        st = ColStats(part, cout, nb, rps // rows.value, ncls)
+    took = False
+    if out_pair is not None and pair.value:
+        p.out_format, p.out_scale = 2, float(out_pair)
+        took = True
+    return st, took
+
+
 def conv_gemm(x: Tensor, w: PackedWeight, *, spatial: Optional[Tuple[int, int, int, int]] = None,
               stride: Sequence[int] = (1, 1, 1), up: Sequence[int] = (0, 0, 0), act: int = L.ACT_NONE,
               rowvec: Optional[Tensor] = None, rv_rows: int = 1, res: Optional[Tensor] = None,
               scale: Optional[Tensor] = None, shift: Optional[Tensor] = None,
               out: Optional[Tensor] = None, tile: int = 0, math: int = L.MATH_FP32,
-              splitk: Optional[int] = None, out_fn=None, a_scale: Optional[float] = None) -> Tensor:
+              splitk: Optional[int] = None, out_fn=None, a_scale: Optional[float] = None,
+              stats: bool = False, out_pair: Optional[float] = None):
     """Conv3d (k in {1,3}, pad k//2) / Linear.  x: [nb,d,h,w,c] (conv) or [..., c] rows (linear).
 
     `spatial=(nb,d,h,w)` lets a row matrix be interpreted as a volume without reshaping.
+    r4: `stats=True` -- the result feeds a GroupNorm: where the launch can (cs_conv_gemm_epilogue_caps), its epilogue
+    leaves per-(row tile, column) partial sums and the returned tensor carries them as `.cs_stats` (ColStats).
+    `out_pair=s` -- the result's only reader is the next F16X3 GEMM: where the launch can, it is written as the
+    interleaved operand pair of out * s and a Pair16 is returned instead of a tensor.
     """
     if w.tapcol is not None:
         if (tuple(stride) != (1, 1, 1) or tuple(up) != (0, 0, 0) or act != L.ACT_NONE or rowvec is not None
@@ -458,17 +542,15 @@ def conv_gemm(x: Tensor, w: PackedWeight, *, spatial: Optional[Tuple[int, int, i
     p.sd, p.sh, p.sw = stride
     p.pd, p.ph, p.pw = pd, ph, pw
     p.ud, p.uh, p.uw = up
-    if PINGPONG_OFF and tile == 0 and _pingpong_ok(mo, w.cin, w.cout, math, pointwise, scale is not None,
-                                                   rv_rows if rowvec is not None else 0):
-        tile = tile_for(mo, w.cout, 0, math, act=act)          # what the library picks without tile 5
     p.act, p.rv_rows, p.math, p.tile = act, rv_rows, math, tile
     lib = L.load()
     if folded:
-        return _conv_gemm_up2(lib, p, w, x, out, mo)
+        st, _ = _epilogue_extras(lib, p, x.device, nb, d * h * wd, m, w.cout, stats, None, ncls=len(w.classes))
+        return attach_stats(_conv_gemm_up2(lib, p, w, x, out, mo), st)
     if splitk is not None and splitk > 1:            # explicit split-K factor (tuning / tests); the plan is bypassed
         ws = torch.empty((splitk * mo * w.cout,), dtype=torch.float32, device=x.device)
         p.splitk, p.splitk_ws = int(splitk), ws.data_ptr()
-    elif math == L.MATH_F16X3 and tile == 0 and SPLITK and splitk is None:
+    elif math == L.MATH_F16X3 and tile == 0 and _sw("SPLITK") and splitk is None:
         # few output tiles (small batches): let the library cut the K loop into slices; the partial tiles live in a
         # scratch tensor that the stream-ordered allocator may reuse as soon as this call's kernels are queued
         sk, wsb = C.c_int32(1), C.c_int64(0)
@@ -476,6 +558,9 @@ def conv_gemm(x: Tensor, w: PackedWeight, *, spatial: Optional[Tuple[int, int, i
         if sk.value > 1:
             ws = torch.empty((wsb.value // 4,), dtype=torch.float32, device=x.device)
             p.splitk, p.splitk_ws = sk.value, ws.data_ptr()
+    st, paired = (None, False)
+    if math == L.MATH_F16X3:
+        st, paired = _epilogue_extras(lib, p, x.device, nb, do * ho * wo, mo, w.cout, stats, out_pair)
     prof = GEMM_PROFILE
     if prof is not None:
         e0 = torch.cuda.Event(enable_timing=True)
@@ -484,19 +569,16 @@ def conv_gemm(x: Tensor, w: PackedWeight, *, spatial: Optional[Tuple[int, int, i
     L.check(lib.cs_conv_gemm(C.byref(p), _stream()), "cs_conv_gemm")
     if prof is not None:
         e1.record()
-        c3 = (kd, kh, kw) == (3, 3, 3) and tuple(stride) == (1, 1, 1) and tuple(up) == (0, 0, 0)
-        tl = tile_for(mo, w.cout, tile, w.math, cin=w.cin, pointwise=pointwise, bn=scale is not None, act=act,
-                      rv_rows=rv_rows if rowvec is not None else 0, conv3_win=wd if c3 else 0, presplit=xs is not None)
-        if p.splitk > 1 and tl in (8, 9):
-            tl -= 1 if tl == 8 else 3
-        if p.splitk > 1 and math == L.MATH_F16X3:
-            # K-sliced launches: the 256x224 tile for slab convs (r3), the 128x224 tile otherwise (cs_conv_gemm)
-            tl = 4 if (c3 and wd <= 32 and not os.environ.get("CS_SLICE_TILE2")) or tl == 4 else 2
+        # which kernel variant ran: asked from the library (cs_conv_gemm_launch_info), not mirrored here
+        tl_, sl_ = C.c_int32(0), C.c_int32(0)
+        L.check(lib.cs_conv_gemm_launch_info(C.byref(p), C.byref(tl_), C.byref(sl_)), "cs_conv_gemm_launch_info")
+        tl = tl_.value
         prof.append(dict(e0=e0, e1=e1, flops=2.0 * mo * w.cout * w.cin * kd * kh * kw, taps=kd * kh * kw,
                          m=mo, n=w.cout, k=w.cin * kd * kh * kw, tile=tl,
-                         slab=slab_width(tl, (kd, kh, kw), stride, up, wd, math, xs is not None, p.splitk),
-                         pre=xs is not None, pair=xp is not None))
-    return out
+                         slab=sl_.value, pre=xs is not None, pair=xp is not None))
+    if paired:
+        return Pair16(out, float(out_pair))
+    return attach_stats(out, st)
 
 
 def _conv_gemm_up2(lib, p, w: PackedWeight, x: Tensor, out: Tensor, mo: int) -> Tensor:
@@ -523,91 +605,24 @@ def _conv_gemm_up2(lib, p, w: PackedWeight, x: Tensor, out: Tensor, mo: int) -> 
         m1 = mo // n
         # executed multiply-adds (all classes); the direct form's 27-tap count is 27 / (kd * kh * kw) times this
         prof.append(dict(e0=e0, e1=e1, flops=2.0 * mo * w.cout * w.cin * kd * kh * kw, taps=kd * kh * kw, m=m1,
-                         n=w.cout, k=w.cin * kd * kh * kw, tile=tile_for(m1, w.cout, 0, w.math, cin=w.cin)))
+                         n=w.cout, k=w.cin * kd * kh * kw, tile=4 if w.cout % 224 == 0 else 6, slab=32))
     return out
 
-
-# Split-K for GEMMs with few output tiles (cs_conv_gemm_plan decides); CS_NO_SPLITK=1 turns it off (A/B runs).
-SPLITK = not os.environ.get("CS_NO_SPLITK")
 
 # Set to a list to collect one record per GEMM launch (HIP events on the launch stream): bench.py uses this
 # to measure the dominant kernel's achieved TFLOP/s inside the timed region.
 GEMM_PROFILE = None
 
 
-# CS_NO_PINGPONG=1: token GEMMs on the one-tile-per-workgroup kernels (A/B runs; same bits either way)
-PINGPONG_OFF = bool(os.environ.get("CS_NO_PINGPONG"))
-
-
-def _pingpong_ok(m: int, cin: int, cout: int, math: int, pointwise: bool, bn: bool = False, rv_rows: int = 0) -> bool:
-    """cs_pw_gemm_f16x3_applicable (csrc/cs_gemm_pw.hip), alignment conditions aside.  rv_rows: rows per row-vector
-    entry when the GEMM has one (0: none)."""
-    return (math == L.MATH_F16X3 and pointwise and not bn and cout % 224 == 0 and (cin + 15) // 16 >= 28
-            and ((m + 127) // 128) * (cout // 224) >= 384 and rv_rows % 128 == 0)
-
-
-TILE512 = os.environ.get("CS_TILE512", "") == "1"      # auto-select the 512-row slab tiles (A/B runs; off: they lost)
-
-
-def tile_for(m: int, cout: int, tile: int = 0, math: int = L.MATH_FP32, cin: int = 0, pointwise: bool = False,
-             bn: bool = False, act: int = L.ACT_NONE, rv_rows: int = 0, conv3_win: int = 0, presplit: bool = False) -> int:
-    """mirror of the tile auto-selection in cs_conv_gemm (csrc/cs_gemm.hip).  conv3_win: the line width W of a 3x3x3
-    stride-1 "same" conv (0 = any other geometry); presplit: the activations arrive as the fp16 hi / lo pair."""
-    if tile:
-        return tile
-    t = _tile_for(m, cout, math, cin, act)
-    # the 512-row slab tiles (two row blocks per wave): only with CS_TILE512=1 (cs_gemm.hip), pre-split operands only
-    if conv3_win and presplit and TILE512 and math == L.MATH_F16X3:
-        t512 = (m + 511) // 512
-        if t == 7 and cout == 64 and conv3_win <= 64 and t512 >= 512:
-            return 8
-        if t == 6 and conv3_win <= 32 and t512 * (cout // 128) >= 512:
-            return 9
-    return t
-
-
-def _tile_for(m: int, cout: int, math: int, cin: int, act: int) -> int:
-    # tile 5 (the persistent ping-pong kernel) is never auto-selected: cs_pw_gemm_f16x3_preferred() is false
-    mt = (m + 127) // 128
-    if math == L.MATH_F16X3 and cout % 224 == 0 and ((m + 255) // 256) * (cout // 224) >= 192:
-        return 2 if (act == L.ACT_GEGLU and 0 < (cin + 15) // 16 <= 32) else 4
-    if math == L.MATH_F16X3 and cout % 128 == 0 and ((m + 255) // 256) * (cout // 128) >= 192:
-        return 6 if act != L.ACT_GEGLU else 2
-    if math == L.MATH_F16X3 and (cout == 64 or cout <= 4) and (m + 255) // 256 >= 192:
-        return 7 if act != L.ACT_GEGLU else 2
-    if cout % 224 == 0 and mt * (cout // 224) >= 256:
-        t = 2
-    elif cout > 64 and mt * ((cout + 127) // 128) >= 256:
-        t = 1
-    else:
-        t = 3
-    return 2 if act == L.ACT_GEGLU else t
-
-
 def wants_split16(m: int, w: "PackedWeight") -> bool:
-    """Should the GroupNorm feeding the conv `w` over m output rows emit the fp16 hi / lo operand pair?  Yes where the conv
-    will run the slab kernel (3x3x3 on a 256-row tile: large batches) -- there the in-loop conversion is what is left
-    to remove.  Small batches (128-row / 64-row tiles, split-K) measured slightly slower with it (7.85 vs 7.58 ms per
-    one-object step), 1-tap GEMMs neutral: both keep fp32 activations."""
-    if not (SPLIT16_PRODUCERS and w.math == L.MATH_F16X3 and w.classes is None and w.tapcol is None
-            and tuple(w.k) == (3, 3, 3) and w.cin % 8 == 0):
+    """Should the GroupNorm feeding the conv `w` over m output rows emit the fp16 hi / lo operand pair?  The rule is
+    cs_conv_wants_split16 (csrc/cs_plan.hip: where the conv will run the slab kernel on a 256-row tile, and on the 128-row
+    slab tile of medium batches) -- ONE implementation for this host and the native drivers (r4)."""
+    if not _sw("SPLIT16_PRODUCERS"):
         return False
-    if _tile_for(m, w.cout, w.math, w.cin, L.ACT_NONE) in (4, 6, 7):
-        return True
-    # r3: also where the conv runs the 128-row slab tile (224-column convs of medium batches, with or without K slices)
-    return SPLIT16_MIN_ROWS > 0 and w.cout % 224 == 0 and m >= SPLIT16_MIN_ROWS
-
-
-def slab_width(tile: int, k, stride, up, win: int, math: int, presplit: bool, splitk: int) -> int:
-    """mirror of the slab dispatch in cs_conv_gemm_f16x3_dispatch (csrc/cs_gemm_f16x3.hip): 0 = per-tap gather."""
-    if splitk > 1 and tile != 4:
-        tile = 2                                     # the K-sliced path runs 128x224 tiles (cs_conv_gemm)
-    if (math != L.MATH_F16X3 or tuple(k) != (3, 3, 3) or tuple(stride) != (1, 1, 1)
-            or tuple(up) != (0, 0, 0) or tile not in (2, 4, 6, 7, 8, 9) or win > 64):
-        return 0
-    if win <= 32:
-        return 32
-    return 64 if tile in (7, 8) else 0
+    k = w.k[0] if tuple(w.k) == (w.k[0],) * 3 else 0
+    return bool(L.load().cs_conv_wants_split16(int(m), int(w.cin), int(w.cout), int(k),
+                                               int(w.classes is None and w.tapcol is None), int(w.math)))
 
 
 def linear(x: Tensor, w: PackedWeight, **kw) -> Tensor:
@@ -656,35 +671,59 @@ class Pair16:
         return Pair16(self.t.view(*shape), self.a_scale)
 
 
-# CS_NO_PAIR16=1: LayerNorm keeps emitting fp32 (A/B runs; bit-identical either way)
-PAIR16_PRODUCERS = not os.environ.get("CS_NO_PAIR16", "")
 
 
-# Producer-side operand split: GroupNorm writes the fp16 hi/lo pair of y * A_SCALE (same bytes as fp32 y) and the GEMM
-# DMA-loads it with a_format=1, so its K loop carries no conversion VALU.  With the per-tap gather kernels this was
-# neutral (108.0 vs 107.5 ms/step in round 1: the conversion hid under the DMA-bound loop); on the slab kernel the
-# conversion is what is left -- a timing-only build without it ran the conv shapes at 472-475 instead of 402-405 TF/s
-# (tools/slab_whatif2.sh) -- so it is the default.  Results are bit-identical either way (y * 16 is exact).
-# CS_NO_SPLIT16=1 turns it off (A/B runs).
-SPLIT16_PRODUCERS = not os.environ.get("CS_NO_SPLIT16")
-# ... and (r3) where it runs the 128-row slab tile, from this many rows (4 objects at 16x8x8): 7 objects 27.34 -> 26.94
-# ms/step, 4 objects 17.61 -> 17.41, 16 objects 49.11 -> 48.75; below it slower (1 object 8.58 -> 8.73): the three-launch
-# GroupNorm replaces the single-launch one there (profiles/r03_j_split16_small_ab.txt).  0 = never.
-SPLIT16_MIN_ROWS = int(os.environ.get("CS_SPLIT16_MIN_ROWS", "8192"))
+# Producer-side operand split: GroupNorm writes the fp16 hi/lo pair of y * a_scale (same bytes as fp32 y) and the GEMM
+# DMA-loads it with a_format=1, so its K loop carries no conversion VALU.  Bit-identical either way.
+# Switches: CsDebug.no_split16 / split16_min_rows (CS_NO_SPLIT16, CS_SPLIT16_MIN_ROWS).
 
 
 def groupnorm(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float, act: int = L.ACT_NONE,
               out: Optional[Tensor] = None, split16: bool = False, a_scale: Optional[float] = None):
     """GroupNorm over [nb, ..., c] (stats per sample & group), fused activation.
-    split16=True returns a Split16 (fp16 hi/lo pair, pre-scaled) for an F16X3 GEMM to consume."""
+    split16=True returns a Split16 (fp16 hi/lo pair, pre-scaled) for an F16X3 GEMM to consume.
+    r4: when x carries its producers' partial sums (stats_segments) the statistics come from them -- one tiny launch
+    instead of a pass over the tensor -- and the tensor is read once, by the apply kernel."""
     _chk(x, "x")
     nb = x.shape[0]
     m, c, ldx = rows_ld(x, "x")
     rows = m // nb
     lib = L.load()
+    segs = stats_segments(x)
+    if segs is not None and not (split16 and _sw("SPLIT16_PRODUCERS")):
+        # one call: a single launch for small tensors, finalize + apply otherwise (cs_groupnorm_parts decides)
+        if out is None:
+            out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        om, oc, ldy = rows_ld(out, "out")
+        if om != m or oc != c:
+            raise L.CsError("groupnorm out shape mismatch")
+        stats = torch.empty((nb, groups, 2), dtype=torch.float32, device=x.device)
+        L.check(lib.cs_groupnorm_parts(x.data_ptr(), _seg_array(segs), len(segs), gamma.data_ptr(), beta.data_ptr(),
+                                       out.data_ptr(), nb, rows, c, ldx, ldy, groups, eps, act, stats.data_ptr(), _stream()),
+                "cs_groupnorm_parts")
+        return out
+    if segs is not None:
+        stats = groupnorm_stats_from_parts(segs, nb, rows, c, groups, eps, x.device)
+        if split16 and _sw("SPLIT16_PRODUCERS"):
+            yh = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+            yl = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+            a_sc = float(a_scale or A_SCALE)
+            L.check(lib.cs_groupnorm_apply_split16(x.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                                   yh.data_ptr(), yl.data_ptr(), nb, rows, c, ldx, c, groups, act,
+                                                   a_sc, status_word(x.device).data_ptr(), _stream()),
+                    "cs_groupnorm_apply_split16")
+            return Split16(yh, yl, a_sc)
+        if out is None:
+            out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        om, oc, ldy = rows_ld(out, "out")
+        if om != m or oc != c:
+            raise L.CsError("groupnorm out shape mismatch")
+        L.check(lib.cs_groupnorm_apply(x.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(),
+                                       nb, rows, c, ldx, ldy, groups, act, _stream()), "cs_groupnorm_apply")
+        return out
     ws = torch.empty(lib.cs_groupnorm_ws_bytes(nb, groups) // 8, dtype=torch.float64, device=x.device)
     stats = torch.empty((nb, groups, 2), dtype=torch.float32, device=x.device)
-    if split16 and SPLIT16_PRODUCERS:
+    if split16 and _sw("SPLIT16_PRODUCERS"):
         L.check(lib.cs_groupnorm_stats(x.data_ptr(), nb, rows, c, ldx, groups, eps, ws.data_ptr(),
                                        stats.data_ptr(), _stream()), "cs_groupnorm_stats")
         yh = torch.empty(x.shape, dtype=torch.float16, device=x.device)
@@ -712,6 +751,9 @@ def groupnorm_stats(x: Tensor, groups: int, eps: float) -> Tensor:
     nb = x.shape[0]
     m, c, ldx = rows_ld(x, "x")
     lib = L.load()
+    segs = stats_segments(x)
+    if segs is not None:
+        return groupnorm_stats_from_parts(segs, nb, m // nb, c, groups, eps, x.device)
     ws = torch.empty(lib.cs_groupnorm_ws_bytes(nb, groups) // 8, dtype=torch.float64, device=x.device)
     stats = torch.empty((nb, groups, 2), dtype=torch.float32, device=x.device)
     L.check(lib.cs_groupnorm_stats(x.data_ptr(), nb, m // nb, c, ldx, groups, eps, ws.data_ptr(), stats.data_ptr(),
@@ -731,7 +773,7 @@ def groupnorm_apply_range(x: Tensor, stats: Tensor, gamma: Tensor, beta: Tensor,
     if stats.shape[0] < nb or not stats.is_contiguous() or gamma.numel() != c or beta.numel() != c:
         raise L.CsError("groupnorm_apply_range: stats / gamma / beta do not match x")
     lib = L.load()
-    if split16 and SPLIT16_PRODUCERS:
+    if split16 and _sw("SPLIT16_PRODUCERS"):
         yh = torch.empty(x.shape, dtype=torch.float16, device=x.device)
         yl = torch.empty(x.shape, dtype=torch.float16, device=x.device)
         a_sc = float(a_scale or A_SCALE)
@@ -753,7 +795,7 @@ def layernorm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5, out: Op
     GEMM; c % 16 == 0) instead of an fp32 tensor."""
     _chk(x, "x")
     m, c, ldx = rows_ld(x, "x")
-    if pair_scale is not None and PAIR16_PRODUCERS and c % 16 == 0:
+    if pair_scale is not None and _sw("PAIR16_PRODUCERS") and c % 16 == 0:
         y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
         L.check(L.load().cs_layernorm_pair16(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), m, c, ldx, c,
                                              eps, float(pair_scale), status_word(x.device).data_ptr(), _stream()),

@@ -14,7 +14,6 @@ cross-attention collapses to a per-sample row vector folded into the attn1 outpu
 """
 from __future__ import annotations
 
-import os
 from collections import OrderedDict
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -196,7 +195,8 @@ class DiffusionUNet:
         self.math = L.DEFAULT_MATH      # F16X3 unless CS_MATH=fp32
         self.attn_math: Optional[int] = None        # None: follow self.math; L.MATH_F16: plain-fp16 attention (opt-in)
         self.trace: Optional[Dict[str, Tensor]] = None   # set to {} to capture per-block outputs (tests)
-        self.split_min_rows = int(os.environ.get("CS_CFG_SPLIT_MIN_ROWS", "65536"))     # see _pack: channel-split ResBlocks
+        self.split_min_rows: Optional[int] = None      # see _pack: channel-split ResBlocks; None = the library's threshold
+        # (CsDebug.cfg_split_min_rows, CS_CFG_SPLIT_MIN_ROWS, default 65536 -- the same number the native driver reads)
         self._split_info: Dict[str, Tuple[int, int]] = {}
         self._ngb: Dict[str, Tuple[float, float]] = {}
 
@@ -333,7 +333,7 @@ class DiffusionUNet:
                     pw(t + ".attn2.to_v")
                     pw(t + ".attn2.to_out.0")
                     if (self.math == L.MATH_F16X3 and (4 * l["cin"]) % 112 == 0
-                            and not os.environ.get("CS_NO_FUSED_GEGLU")):
+                            and not L.debug().no_fused_geglu):
                         pk[t + ".ff.geglu"] = ops.pack_geglu_weight(sd[t + ".ff.net.0.proj.weight"],
                                                                     sd[t + ".ff.net.0.proj.bias"])
                     else:
@@ -369,7 +369,7 @@ class DiffusionUNet:
         # the unsplit weights stay packed for the small-batch route.
         self._split_info = {}
         n_prefix = next((i for i, layers in enumerate(inp) if any(l["kind"] == "attn" for l in layers)), len(inp))
-        if self.cfg["use_spatial_transformer"] and not os.environ.get("CS_NO_CFG_SPLIT"):
+        if self.cfg["use_spatial_transformer"] and not L.debug().no_cfg_split:
             for j, layers in enumerate(out):
                 src = len(inp) - 1 - j
                 l = layers[0]
@@ -433,12 +433,14 @@ class DiffusionUNet:
                            split16=ops.wants_split16(nb * rows, pk[p + ".in_layers.2"]), a_scale=s1)
         lo, hi = self._emb_slices[p]
         embo = semb[:, lo:hi]                         # slice of the batched emb projection (row stride = total)
-        h = ops.conv_gemm(hn, pk[p + ".in_layers.2"], rowvec=embo, rv_rows=rows, math=self.math, a_scale=s1)
+        # (stats=True: the conv's epilogue leaves the partial sums the next GroupNorm takes its statistics from, r4)
+        h = ops.conv_gemm(hn, pk[p + ".in_layers.2"], rowvec=embo, rv_rows=rows, math=self.math, a_scale=s1, stats=True)
         s2 = self._nas(p + ".out_layers.0", rows * (l["cout"] // 32))
         hn2 = ops.groupnorm(h, sd[p + ".out_layers.0.weight"], sd[p + ".out_layers.0.bias"], 32, 1e-5, L.ACT_SILU,
                             split16=ops.wants_split16(nb * rows, pk[p + ".out_layers.3"]), a_scale=s2)
         skip = x if l["cin"] == l["cout"] else ops.conv_gemm(x, pk[p + ".skip_connection"], math=self.math)
-        return ops.conv_gemm(hn2, pk[p + ".out_layers.3"], res=skip, math=self.math, out_fn=out_fn, a_scale=s2)
+        return ops.conv_gemm(hn2, pk[p + ".out_layers.3"], res=skip, math=self.math, out_fn=out_fn, a_scale=s2,
+                             stats=True)
 
     def _res_split(self, p: str, l: dict, x: Tensor, skip: Tensor, semb: Tensor, out_fn=None) -> Tensor:
         """ResBlock of an output block whose skip half is shared by the guidance halves (see _pack): x = the
@@ -471,11 +473,12 @@ class DiffusionUNet:
             sl = slice(g * nbs, (g + 1) * nbs)
             ops.conv_gemm(a_h[sl], wh, rowvec=semb[sl, lo:hi], rv_rows=rows, res=y_s, out=h1[sl], math=self.math,
                           a_scale=s1)
+        # (the two launches write sample ranges of h1: its GroupNorm takes its statistics from a pass over the tensor)
         sk = ops.conv_gemm(x, pk[p + ".skip_connection"], math=self.math)
         s2 = self._nas(p + ".out_layers.0", rows * (cout // 32))
         hn2 = ops.groupnorm(h1, sd[p + ".out_layers.0.weight"], sd[p + ".out_layers.0.bias"], 32, 1e-5, L.ACT_SILU,
                             split16=ops.wants_split16(nb * rows, pk[p + ".out_layers.3"]), a_scale=s2)
-        return ops.conv_gemm(hn2, pk[p + ".out_layers.3"], res=sk, math=self.math, out_fn=out_fn, a_scale=s2)
+        return ops.conv_gemm(hn2, pk[p + ".out_layers.3"], res=sk, math=self.math, out_fn=out_fn, a_scale=s2, stats=True)
 
     def _context_vectors(self, ctx: Tensor):
         """One-token context: every transformer block's cross-attention output is the per-sample
@@ -515,8 +518,10 @@ class DiffusionUNet:
         a = ops.attention(qkv[..., 0:c], qkv[..., c:2 * c], qkv[..., 2 * c:3 * c], heads, (c // heads) ** -0.5,
                           math=self.attn_math if self.attn_math is not None else self.math)
         dst = out_fn((nb, d, h, w, c)).view(nb, n, c) if out_fn is not None else None
-        out = ops.linear(a, pk[p + ".proj_out"], res=x.view(nb, n, c), math=self.math, out=dst)
-        return out.view(nb, d, h, w, c)
+        # (spatial=: the rows are nb samples of n tokens -- what the epilogue's GroupNorm partial sums are tiled by)
+        out = ops.linear(a, pk[p + ".proj_out"], res=x.view(nb, n, c), math=self.math, out=dst, stats=True,
+                         spatial=(nb, n, 1, 1))
+        return ops.attach_stats(out.view(nb, d, h, w, c), getattr(out, "cs_stats", None))
 
     def _attn(self, p: str, l: dict, x: Tensor, ctx, out_fn=None) -> Tensor:
         sd, pk = self._sd, self._packed
@@ -546,15 +551,21 @@ class DiffusionUNet:
             t1 = ops.linear(a2, pk[t + ".attn2.to_out.0"], res=t1a, math=self.math)
         s3 = self._nas(t + ".norm3", c)
         n3 = ops.layernorm(t1, sd[t + ".norm3.weight"], sd[t + ".norm3.bias"], pair_scale=s3)
+        # r4: gg's only reader is ff.net.2 and t2's only reader is proj_out (attention.py:241-245, 349), so both producers
+        # write the interleaved F16X3 operand pair where their launch can (out_pair: scale 16, the raw-activation default;
+        # a value beyond the fp16 range is now flagged by the producer) -- the consumers' K loops carry no conversion.
+        # Bit-identical to the fp32 hand-over (tests/test_epilogue_outputs_gpu.py).
+        pair = ops.A_SCALE if (self.math == L.MATH_F16X3 and ops._sw("PAIR_EPILOGUES")) else None
         if (t + ".ff.geglu") in pk:      # GEGLU gate fused into the projection GEMM's epilogue
-            gg = ops.linear(n3, pk[t + ".ff.geglu"], act=L.ACT_GEGLU, a_scale=s3)    # the library picks a 224-column tile
+            gg = ops.linear(n3, pk[t + ".ff.geglu"], act=L.ACT_GEGLU, a_scale=s3, out_pair=pair)   # the library picks a 224-column tile
         else:
             ff = ops.linear(n3, pk[t + ".ff.net.0.proj"], math=self.math, a_scale=s3)
             gg = ops.geglu(ff)
-        t2 = ops.linear(gg, pk[t + ".ff.net.2"], res=t1, math=self.math)
+        t2 = ops.linear(gg, pk[t + ".ff.net.2"], res=t1, math=self.math, out_pair=pair)
         dst = out_fn((nb, d, h, w, c)).view(nb, n, c) if out_fn is not None else None
-        out = ops.linear(t2, pk[p + ".proj_out"], res=x.view(nb, n, c), math=self.math, out=dst)
-        return out.view(nb, d, h, w, c)
+        out = ops.linear(t2, pk[p + ".proj_out"], res=x.view(nb, n, c), math=self.math, out=dst, stats=True,
+                         spatial=(nb, n, 1, 1))
+        return ops.attach_stats(out.view(nb, d, h, w, c), getattr(out, "cs_stats", None))
 
     def _run(self, bp: str, layers, h: Tensor, semb: Tensor, ctx: Tensor, out_fn=None, split_skip=None) -> Tensor:
         """`out_fn(shape) -> tensor`: where the block's LAST layer writes its result (a channel slice of the
@@ -565,7 +576,7 @@ class DiffusionUNet:
             k = l["kind"]
             of = out_fn if li == len(layers) - 1 else None
             if k == "conv_in":
-                h = ops.conv_gemm(h, pk[p], math=self.math, out_fn=of)
+                h = ops.conv_gemm(h, pk[p], math=self.math, out_fn=of, stats=True)
             elif k == "res":
                 if li == 0 and split_skip is not None and p in self._split_info:
                     h = self._res_split(p, l, h, split_skip, semb, of)
@@ -576,9 +587,9 @@ class DiffusionUNet:
                      else self._attnblock(p, l, h, of))
             elif k == "down":      # dims == 3: inner two dims only (openai_model_3d.py:188); dims == 4: all three
                 h = ops.conv_gemm(h, pk[p + ".op"], stride=(1, 2, 2) if self.cfg["dims"] == 3 else (2, 2, 2),
-                                  math=self.math, out_fn=of)
+                                  math=self.math, out_fn=of, stats=True)
             elif k == "up":        # nearest x2 folded into the conv's addressing (openai_model_3d.py:148-157)
-                h = ops.conv_gemm(h, pk[p + ".conv"], up=self._up, math=self.math, out_fn=of)
+                h = ops.conv_gemm(h, pk[p + ".conv"], up=self._up, math=self.math, out_fn=of, stats=True)
         return h
 
     @torch.no_grad()
@@ -610,7 +621,11 @@ class DiffusionUNet:
         ch_skip = [layers[-1]["cout"] for layers in inp][::-1]               # skip channels of output block j
         ch_h = [out[j][0]["cin"] - ch_skip[j] for j in range(nout)]
         cats: List[Optional[Tensor]] = [None] * nout
-        nocopy = not os.environ.get("CS_CONCAT_COPY")                        # A/B switch: the copying form
+        nocopy = not L.debug().concat_copy                                   # A/B switch: the copying form
+        # r4: the partial sums each half's producer left for the GroupNorm of output block j (ops.ColStats or None)
+        split_min_rows = self.split_min_rows if self.split_min_rows is not None else int(L.debug().cfg_split_min_rows)
+        seg_l: List[Optional[object]] = [None] * nout
+        seg_r: List[Optional[object]] = [None] * nout
 
         def slot(j: int, left: bool):
             def fn(shape):
@@ -625,18 +640,23 @@ class DiffusionUNet:
         shared = cfg_pairs          # True while h still holds one copy per (x, t) pair
         for i, layers in enumerate(inp):
             if shared and any(l["kind"] == "attn" for l in layers):
+                st = getattr(h, "cs_stats", None)
                 h = torch.cat([h, h], dim=0)          # first context-dependent block: split into [uc; c]
+                ops.attach_stats(h, st)               # (sample n reads the partials of sample n % B)
                 semb = torch.cat([semb, semb], dim=0)
                 shared = False
             direct = nocopy and not shared            # a skip at the full batch goes straight into its slice
             h = self._run(f"{P}input_blocks.{i}", layers, h, semb, ctx, slot(nout - 1 - i, False) if direct else None)
             hs.append(None if direct else h)
+            seg_r[nout - 1 - i] = getattr(h, "cs_stats", None)
             if tr is not None:
                 tr[f"input_blocks.{i}"] = h
         if shared:
-            h = torch.cat([h, h], dim=0)
+            st = getattr(h, "cs_stats", None)
+            h = ops.attach_stats(torch.cat([h, h], dim=0), st)
             semb = torch.cat([semb, semb], dim=0)
         h = self._run(P + "middle_block", mid, h, semb, ctx, slot(0, True) if nocopy else None)
+        seg_l[0] = getattr(h, "cs_stats", None)
         if tr is not None:
             tr["middle_block"] = h
         for i, layers in enumerate(out):
@@ -651,14 +671,17 @@ class DiffusionUNet:
                         ops.copy_rows(skip, right[g * nbs:(g + 1) * nbs])
                 h = cats[i]
                 cats[i] = None
+                h.cs_segs = [(0, seg_l[i]), (ch_h[i], seg_r[i])]     # both halves' producers' partials (None: unavailable)
             # channel-split blocks take the skip tensor itself: the shared (B-sized) one under guidance pairs, else the
             # right half of the concatenation
             split_skip = None
             if (f"{P}output_blocks.{i}.0" in self._split_info
-                    and h.shape[0] * h.shape[1] * h.shape[2] * h.shape[3] >= self.split_min_rows):
+                    and h.shape[0] * h.shape[1] * h.shape[2] * h.shape[3] >= split_min_rows):
                 split_skip = skip if skip is not None else h[..., ch_h[i]:]
             h = self._run(f"{P}output_blocks.{i}", layers, h, semb, ctx,
                           slot(i + 1, True) if nocopy and i + 1 < nout else None, split_skip=split_skip)
+            if i + 1 < nout:
+                seg_l[i + 1] = getattr(h, "cs_stats", None)
             if tr is not None:
                 tr[f"output_blocks.{i}"] = h
         so = self._nas(P + "out.0", h.shape[1] * h.shape[2] * h.shape[3] * (h.shape[4] // 32))

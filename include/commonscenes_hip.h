@@ -53,6 +53,61 @@ typedef struct ihipStream_t* cs_stream_t; /* == hipStream_t */
  *   CS_STATUS_F16X3_OVERFLOW: a CS_MATH_F16X3 kernel met an operand with |a| * a_scale >= 65504 (fp16 range): its hi
  *   half is +-inf and the result of that launch is garbage -- re-run on CS_MATH_FP32 (the host classes do). */
 #define CS_STATUS_F16X3_OVERFLOW 1
+/*   CS_STATUS_INTERNAL: a kernel was asked for an epilogue output (gn_part / out_format) on a path that cannot produce it
+ *   -- a host-side planning bug, never data dependent; the launch's extra outputs are missing. */
+#define CS_STATUS_INTERNAL 2
+
+/*
+ * Debug / A-B switches (r4: ONE struct instead of ~40 getenv() calls spread over two host languages).  All zero = the
+ * product path -- the measured-best route everywhere.  cs_debug() parses the environment ONCE (field `x` <- CS_X in
+ * capitals, e.g. CS_NO_SLAB4=1; "set, non-empty, not 0" for the flags) and every host reads this struct and nothing else:
+ * the library itself, commonscenes_amd/ops.py (lib.debug()), csrc/cs_driver.h.  cs_debug_set overrides it at run time
+ * (tests flip a switch inside one process; NULL re-reads the environment).  Not part of the data path's contract:
+ * switches exist for same-box A/B timing and for the equality tests between two routes (every pair gives the same bits
+ * unless a field says otherwise).
+ */
+typedef struct CsDebug {
+  int32_t no_split16;         /* GroupNorm emits fp32, never the pre-split operand pair (a_format = 1) */
+  int32_t no_pair16;          /* LayerNorm emits fp32, never the interleaved pair (a_format = 2) */
+  int32_t no_upfold;          /* Upsample convs in direct form (27 taps on the doubled grid); different fp32 sum order */
+  int32_t no_splitk;          /* hosts do not ask cs_conv_gemm_plan for K slices */
+  int32_t no_fused_geglu;     /* GEGLU projection and gate as two kernels */
+  int32_t no_tapcol;          /* thin-output convs on the implicit GEMM; different fp32 sum order */
+  int32_t tapcol_tile;        /* tile of the taps-as-columns GEMM (0 = cs_tapcol_tile's rule) */
+  int32_t no_cfg_split;       /* no channel-split ResBlocks; different fp32 sum order */
+  int32_t concat_copy;        /* channel concatenation by copy (Python host) */
+  int32_t tile512;            /* auto-select the 512-row slab tiles (they lost: DESIGN 4.5) */
+  int32_t no_pw;              /* pointwise GEMMs on the generic gather kernel */
+  int32_t no_slab4;           /* folded Upsample convs on the per-tap gather */
+  int32_t no_attn_img;        /* attention without K / V tile images */
+  int32_t attn_nw8;           /* eight-wave attention workgroups at every batch size */
+  int32_t no_up2_direct;      /* folded Upsample classes through scratch + interleave */
+  int32_t no_up2_batch;       /* one launch per Upsample parity class */
+  int32_t plan_pow2;          /* power-of-two split-K plan (r2) */
+  int32_t slice_tile2;        /* K-sliced slab convs on the 128-row tile */
+  int32_t no_gn_parts;        /* GroupNorm statistics always from a pass over the tensor (r4) */
+  int32_t no_pair_epilogue;   /* GEMM epilogues always write fp32 (r4) */
+  int64_t split16_min_rows;   /* pre-split operands on the 128-row slab tile from this many rows (8192; 0 = never) */
+  int64_t cfg_split_min_rows; /* channel-split ResBlocks from this many rows (65536) */
+  int64_t gn_small_group;     /* single-launch GroupNorm up to this many elements per (sample, group) (11264) */
+} CsDebug;
+const CsDebug* cs_debug(void);
+void cs_debug_set(const CsDebug* d);
+
+/*
+ * Host-side rules every host shares (csrc/cs_plan.hip; no device work).  r3 kept a copy of each in ops.py and in
+ * cs_driver.h ("mirror of ops....") -- there is one now.
+ *   cs_norm_a_scale        F16X3 operand scale of a GEMM fed by a GroupNorm / LayerNorm with max |gamma| = gmax, max |beta| =
+ *                          bmax over n elements per statistic: the largest power of two that keeps |y| <= gmax sqrt(n - 1) +
+ *                          bmax inside the fp16 range (cannot overflow whatever the input).
+ *   cs_conv_wants_split16  should the GroupNorm feeding a (cout x cin x k^3) conv over m output rows emit the pre-split pair?
+ *                          (plain = neither folded Upsample nor taps-as-columns)
+ *   cs_tapcol_ok / cs_tapcol_tile   is a thin-output 3x3x3 conv run as taps-as-columns, and on which tile
+ */
+float cs_norm_a_scale(float gmax, float bmax, int64_t n);
+int cs_conv_wants_split16(int64_t m, int cin, int cout, int k, int plain, int math);
+int cs_tapcol_ok(int cout, int cin, int k, int math);
+int cs_tapcol_tile(int64_t m, int ncolp);
 
 /* GEMM numerics mode */
 #define CS_MATH_FP32 0     /* v_mfma_f32_32x32x2_f32, bit-equal to an fp32 fma chain  */
@@ -119,9 +174,37 @@ typedef struct CsConvGemm {
   int32_t splitk;
   void* splitk_ws;
   int32_t* status;   /* sticky CS_STATUS_* word (device), or NULL */
+  /* ABI 14 (r4), CS_MATH_F16X3 only -- what the epilogue can emit BESIDE / INSTEAD OF the fp32 result, so that the next
+   * operator does not have to read the tensor again for it (cs_conv_gemm_epilogue_caps says what a descriptor supports):
+   *   gn_part != NULL: per (row tile, output column) the fp64 sum and sum of squares of the FINAL output values (after
+   *     bias / row vector / activation / residual): gn_part[tile][gn_ld][2], tile = rows [tile * gn_rows, +gn_rows) of the
+   *     output (folded Upsample classes: tile = class * tiles + source-row tile).  A GroupNorm that follows
+   *     (ldm_diffusion_util.py:222-239, openai_model_3d.py:294-314) takes its statistics from these partials
+   *     (cs_groupnorm_finalize_parts) instead of a pass over the tensor.  gn_rows must be the value
+   *     cs_conv_gemm_epilogue_caps reports for this descriptor; gn_ld >= cout lets several producers fill column ranges of
+   *     one buffer.  Sums run in a fixed order: bit-reproducible, independent of how many samples share the launch.
+   *   out_format = 2: `out` receives the INTERLEAVED OPERAND PAIR of out * out_scale (the a_format = 2 layout above: same
+   *     bytes and ldo as the fp32 tensor) -- for a result whose only reader is the next F16X3 GEMM (attention.py:241-244:
+   *     GEGLU -> ff.net.2 -> proj_out).  |out| * out_scale >= 65504 raises CS_STATUS_F16X3_OVERFLOW.  0 = fp32. */
+  double* gn_part;
+  int32_t gn_ld;
+  int32_t gn_rows;
+  int32_t out_format;
+  float out_scale;
 } CsConvGemm;
 
 int cs_conv_gemm(const CsConvGemm* desc, cs_stream_t stream);
+
+/* What cs_conv_gemm's epilogue can emit for this descriptor (fill in everything that will be passed to cs_conv_gemm,
+ * including splitk; gn_part / out_format themselves are ignored): *gn_rows = rows per statistics tile (0: not available
+ * -- e.g. a tile would straddle two samples, or the launch takes the unfused epilogue), *pair_ok = 1 if out_format = 2 is
+ * available.  Host-only.  ONE rule for every host (ops.py, cs_driver.h). */
+int cs_conv_gemm_epilogue_caps(const CsConvGemm* desc, int32_t* gn_rows, int32_t* pair_ok);
+
+/* Which kernel variant cs_conv_gemm will launch for this descriptor (fill in everything, including splitk): *tile = the
+ * tile code (CsConvGemm.tile's numbering; 5 = the ping-pong kernel), *slab = the line width of the A slab (32 / 64) or 0
+ * for the per-tap gather.  Host-only; what bench.py's per-kernel accounting asks instead of mirroring the dispatch. */
+int cs_conv_gemm_launch_info(const CsConvGemm* desc, int32_t* tile, int32_t* slab);
 
 /* The split-K factor cs_conv_gemm's heuristic would pick for this descriptor (1 = none) and the workspace it then
  * needs; host-only, no device work.  A caller that wants it sets desc->splitk / desc->splitk_ws accordingly. */
@@ -227,6 +310,33 @@ int cs_groupnorm_apply_split16_range(const float* x, const float* stats, const f
  * cs_groupnorm_apply.  `stats` is written either way; `ws` as for cs_groupnorm_stats. */
 int cs_groupnorm(const float* x, const float* gamma, const float* beta, float* y, int nb, int rows, int c, int ldx,
                  int ldy, int groups, float eps, int act, void* ws, float* stats, cs_stream_t stream);
+/* (ABI 14, r4) GroupNorm statistics WITHOUT a pass over the tensor: from the per-(row tile, column) fp64 partial sums the
+ * producing GEMMs' epilogues wrote (CsConvGemm.gn_part).  The c channels of the normalised tensor are covered by 1-4
+ * column segments, one per producer -- a channel concatenation [h | skip] (openai_model_3d.py:781) has two; a skip tensor
+ * that one copy serves for both classifier-free-guidance halves is described by nb_src < nb (sample n reads the
+ * partials of sample n % nb_src).  One wave per (sample, group) adds the group's partials in a fixed order (lanes
+ * stride over the tiles of one channel after the other, then a butterfly): bit-reproducible, fp64 throughout, the same
+ * mean / rstd expressions as cs_groupnorm_stats.  `stats`: [nb][groups][2] as for cs_groupnorm_apply*. */
+typedef struct CsGnSeg {
+  const double* part;        /* [tiles][ld][2] (sum, sum of squares) */
+  int32_t ld;                /* columns per tile of `part` */
+  int32_t col0;              /* column of `part` holding the segment's first channel */
+  int32_t ch0;               /* first channel of the normalised tensor this segment covers */
+  int32_t nch;               /* channels covered */
+  int32_t tiles_per_sample;  /* statistics tiles per sample (and per class): rows per sample / CsConvGemm.gn_rows */
+  int32_t ncls;              /* 1; or the parity-class count of a folded Upsample launch (cs_conv_gemm_up2), whose tiles are
+                                ordered [class][sample][tile] over the SOURCE rows */
+  int32_t nb_src;            /* samples the producer ran */
+  int32_t reserved;
+} CsGnSeg;
+int cs_groupnorm_finalize_parts(const CsGnSeg* segs, int nseg, int nb, int rows, int c, int groups, float eps,
+                                float* stats, cs_stream_t stream);
+/* ... and the whole GroupNorm (+ activation) from them in one call, the counterpart of cs_groupnorm: ONE launch for small
+ * tensors (the same size rule: one workgroup per (sample, group) adds the group's partials and makes a single sweep over
+ * it), cs_groupnorm_finalize_parts + cs_groupnorm_apply otherwise.  `stats` is written either way. */
+int cs_groupnorm_parts(const float* x, const CsGnSeg* segs, int nseg, const float* gamma, const float* beta, float* y,
+                       int nb, int rows, int c, int ldx, int ldy, int groups, float eps, int act, float* stats,
+                       cs_stream_t stream);
 /* SURVEY name: cs_groupnorm with a SiLU epilogue. */
 int cs_groupnorm_silu_ndhwc(const float* x, const float* gamma, const float* beta, float* y,
                             int nb, int rows, int c, int groups, float eps, void* ws, float* stats,
@@ -439,9 +549,14 @@ int cs_emd_matchcost_grad(const float* xyz1, const float* xyz2, const float* mat
  * PyMCubes' mcubes.marching_cubes(sdf_i, level) on the CPU per object).  sdf: [nb][n][n][n] fp32 (the decoder's
  * (B,1,64,64,64) output as is), n <= 160.  A vertex per grid edge whose endpoints straddle `level` ((v < level) differs),
  * linearly interpolated in fp64 like PyMCubes; vertices unique per edge, voxel-raster order (+x, +y, +z edge of each
- * voxel); triangles from a 256-case table derived from the cube geometry (commonscenes_amd/mc_tables.py: ambiguous
- * faces cut off the inside corners, so neighbouring cubes always agree -- watertight), normals towards increasing
- * value, cube-raster order.  Deterministic, no atomics.
+ * voxel); triangles from a 256-case table (commonscenes_amd/mc_tables.py), cube-raster order:
+ *   table = CS_MC_TABLE_CLASSIC (0, ABI 14): the classic Lorensen-Cline table in its universally replicated 256-row form
+ *     (Bourke's triTable, 820 triangles) -- the triangle SET a user of mcubes.marching_cubes gets; normals towards
+ *     decreasing value, as published;
+ *   table = CS_MC_TABLE_WATERTIGHT (1): derived from the cube geometry (ambiguous faces cut off the inside corners);
+ *     normals towards increasing value.
+ * Both mesh the same watertight surface -- same patch boundaries on all 256 cases (tests/test_mesh.py) -- and differ in
+ * how polygons are fanned and in winding.  Deterministic, no atomics.
  *   cs_mc_blocks_per_object(n)  B = ceil(n^3 / 4096)
  *   cs_mc_count   -> block_sums [nb][B][2] int32: vertices and triangles per 4096-voxel block.  The caller reads them
  *                  back (the library never synchronises), sizes the outputs and passes per-object bases:
@@ -451,8 +566,10 @@ int cs_emd_matchcost_grad(const float* xyz1, const float* xyz2, const float* mat
  *                  (n, -0.5 reproduce util_3d.py:218; 1, 0 give PyMCubes' raw index coordinates).
  */
 int cs_mc_blocks_per_object(int n);
-int cs_mc_count(const float* sdf, int nb, int n, float level, int32_t* block_sums, cs_stream_t stream);
-int cs_mc_emit(const float* sdf, int nb, int n, float level, const int32_t* block_sums, const int64_t* vert_base,
+#define CS_MC_TABLE_CLASSIC 0
+#define CS_MC_TABLE_WATERTIGHT 1
+int cs_mc_count(const float* sdf, int nb, int n, float level, int table, int32_t* block_sums, cs_stream_t stream);
+int cs_mc_emit(const float* sdf, int nb, int n, float level, int table, const int32_t* block_sums, const int64_t* vert_base,
                const int64_t* face_base, float* verts, int64_t* faces, int32_t* voxel_ws, float vert_div,
                float vert_shift, cs_stream_t stream);
 

@@ -96,9 +96,11 @@ def table():
     return _TABLE
 
 
-def marching_cubes(vol: np.ndarray, level: float):
+def marching_cubes(vol: np.ndarray, level: float, tab=None):
     """vol: (n,n,n) float32 -> (verts float64 [V,3] in index coordinates, faces int64 [F,3]); vertex order: voxel raster,
-    +x, +y, +z edge of each voxel; face order: cube raster, table order."""
+    +x, +y, +z edge of each voxel; face order: cube raster, table order.  tab: 256 lists of (edge, edge, edge) triangles;
+    None = the table derived above (the product's 'watertight' table).  The classic Lorensen-Cline table is published
+    DATA -- it cannot be re-derived, only validated (mc_tables.validate_table) -- so tests hand the product's copy in."""
     n = vol.shape[0]
     v64 = vol.astype(np.float64)
     ins = vol < np.float32(level)
@@ -116,7 +118,7 @@ def marching_cubes(vol: np.ndarray, level: float):
                         p[a] += t
                         vid[i, j, k, a] = len(verts)
                         verts.append(p)
-    tab = table()
+    tab = table() if tab is None else tab
     faces = []
     for i in range(n - 1):
         for j in range(n - 1):

@@ -27,7 +27,7 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(dll, s), f"{s} declared in the header but not exported"
         assert s in lib.SIGNATURES, f"{s} has no ctypes signature"
     assert set(lib.SIGNATURES) == set(syms)
-    assert dll.cs_abi_version() == lib.ABI_VERSION == 13
+    assert dll.cs_abi_version() == lib.ABI_VERSION == 14
 
 
 def test_struct_layout_matches_header():
@@ -45,7 +45,7 @@ def test_struct_layout_matches_header():
         for n in decl[-1].split(","):
             names.append(n.strip().lstrip("*").strip())
     assert names == [f[0] for f in lib.CsConvGemm._fields_]
-    assert ctypes.sizeof(lib.CsConvGemm) == 12 * 8 + 32 * 4 + 2 * 4
+    assert ctypes.sizeof(lib.CsConvGemm) == 13 * 8 + 35 * 4 + 3 * 4
 
 
 def test_missing_library_fails_loudly(tmp_path):
@@ -154,7 +154,9 @@ def test_every_entry_rejects_null_arguments_without_touching_the_device():
     dll = lib.load()
     skip = {"cs_abi_version", "cs_groupnorm_ws_bytes", "cs_attn_f16x3_ws_bytes", "cs_conv_gemm_up2_ws_bytes", "cs_mc_blocks_per_object", "cs_gcn_csr_ints", "cs_unet_destroy", "cs_unet_param_count", "cs_unet_raw_bytes",
             "cs_unet_arena_bytes", "cs_unet_context_floats", "cs_vqvae_destroy", "cs_vqvae_param_count",
-            "cs_vqvae_raw_bytes", "cs_vqvae_arena_bytes"}
+            "cs_vqvae_raw_bytes", "cs_vqvae_arena_bytes",
+            # r4: host-side rule / switch queries (csrc/cs_plan.hip): plain functions of their arguments, no status code
+            "cs_debug", "cs_debug_set", "cs_norm_a_scale", "cs_conv_wants_split16", "cs_tapcol_ok", "cs_tapcol_tile"}
     checked = 0
     for name, (res, args) in lib.SIGNATURES.items():
         if name in skip:
@@ -220,3 +222,102 @@ def test_vqvae_plan_is_host_only_and_lists_the_decode_side_state_dict():
     assert lib.cs_vqvae_arena_bytes(n._h) > 0
     w1, w8 = lib.cs_vqvae_workspace_bytes(n._h, 1), lib.cs_vqvae_workspace_bytes(n._h, 8)
     assert 0 < w1 < w8 < 64 * 2 ** 30
+
+
+def test_epilogue_caps_is_one_host_side_rule():
+    """cs_conv_gemm_epilogue_caps (r4, ABI 14): what a launch's epilogue can emit -- GroupNorm partial sums per tile of
+    gn_rows rows, the interleaved operand pair -- decided on the host for all tiles of the launch; both hosts (ops.py,
+    cs_driver.h) ask it, cs_conv_gemm re-checks.  No device work: runs without a GPU."""
+    import ctypes as C
+    from commonscenes_amd import lib
+    dll = lib.load()
+    buf = (C.c_float * 256)()
+    base = C.addressof(buf)
+    base += (-base) % 64
+
+    def desc(**kw):
+        p = lib.CsConvGemm()
+        p.x = p.w = p.out = p.bias = base
+        p.kd = p.kh = p.kw = p.sd = p.sh = p.sw = 1
+        p.rv_rows = 1
+        p.math = lib.MATH_F16X3
+        for k, v in kw.items():
+            setattr(p, k, v)
+        p.lda = p.lda or p.cin
+        p.ldo = p.ldo or p.cout
+        p.ldw = p.cout
+        return p
+
+    def caps(p):
+        rows, pair = C.c_int32(-1), C.c_int32(-1)
+        assert dll.cs_conv_gemm_epilogue_caps(C.byref(p), C.byref(rows), C.byref(pair)) == 0
+        return rows.value, pair.value
+
+    conv = dict(kd=3, kh=3, kw=3, pd=1, ph=1, pw=1)
+    # 32 objects' level-0 conv: 256x224 tiles, 16 of them per sample
+    assert caps(desc(nb=64, din=16, hin=16, win=16, dout=16, hout=16, wout=16, cin=224, cout=224, **conv)) == (256, 1)
+    # one object (CFG batch 2), 4^3 level: the plan cuts K, the reduce kernel emits per 16 rows
+    p = desc(nb=2, din=16, hin=4, win=4, dout=16, hout=4, wout=4, cin=672, cout=672, **conv)
+    sk, ws = C.c_int32(0), C.c_int64(0)
+    assert dll.cs_conv_gemm_plan(C.byref(p), C.byref(sk), C.byref(ws)) == 0 and sk.value > 1
+    p.splitk = sk.value
+    assert caps(p) == (16, 1)
+    # no bias / residual / row vector: the kernel takes the unfused epilogue -> nothing
+    q = desc(nb=64, din=1024, hin=1, win=1, dout=1024, hout=1, wout=1, cin=448, cout=1344)
+    q.bias = None
+    assert caps(q) == (0, 0)
+    # token GEMM seen as nb samples of n tokens: tiles of 256 rows divide the 1024-token samples, not 100-token ones
+    assert caps(desc(nb=64, din=1024, hin=1, win=1, dout=1024, hout=1, wout=1, cin=448, cout=448)) == (256, 1)
+    assert caps(desc(nb=64, din=100, hin=1, win=1, dout=100, hout=1, wout=1, cin=448, cout=448)) == (0, 1)
+    # rows described as M one-row samples (how a plain Linear is described): no sample structure to tile
+    assert caps(desc(nb=65536, din=1, hin=1, win=1, dout=1, hout=1, wout=1, cin=448, cout=448))[0] == 0
+    # a column count the tile does not divide (236 columns run 128x128 tiles): the edge tile's lanes past cout are masked;
+    # 236 % 8 != 0 -> no pair layout
+    assert caps(desc(nb=64, din=16, hin=16, win=16, dout=16, hout=16, wout=16, cin=224, cout=236, **conv)) == (128, 0)
+    # fp32-input MFMA mode: never
+    assert caps(desc(nb=64, din=16, hin=16, win=16, dout=16, hout=16, wout=16, cin=224, cout=224, math=lib.MATH_FP32, **conv)) == (0, 0)
+    # cs_conv_gemm refuses what the rule does not allow, before any launch
+    bad = desc(nb=64, din=100, hin=1, win=1, dout=100, hout=1, wout=1, cin=448, cout=448)
+    bad.w_lo, bad.acc_scale, bad.gn_part, bad.gn_ld, bad.gn_rows = base, 1.0, base, 448, 256
+    assert dll.cs_conv_gemm(C.byref(bad), None) == lib.CS_EINVAL
+
+
+def test_shared_host_rules_and_debug_struct():
+    """r4 "one plan, one place": the rules both hosts used to carry a copy of live in the library (csrc/cs_plan.hip) and the
+    CS_* switches are ONE struct.  Host-only entries: checked without a GPU."""
+    from commonscenes_amd import lib as L, ops
+    dll = L.load()
+    # cs_norm_a_scale: the values the GPU suite pins for the shipped layers
+    assert ops.norm_a_scale(1.2, 0.1, 28672) == 256.0 and ops.norm_a_scale(1.2, 0.1, 448) == 2048.0
+    assert ops.norm_a_scale(0.0, 0.0, 100) == 2.0 ** 40 and ops.norm_a_scale(1e9, 0.0, 100) == 2.0 ** -8
+    # cs_conv_wants_split16: large batches (slab kernel on a 256-row tile) yes, 1 object no, medium batches from 8192 rows
+    assert dll.cs_conv_wants_split16(64 * 4096, 224, 224, 3, 1, L.MATH_F16X3) == 1
+    assert dll.cs_conv_wants_split16(2 * 4096, 224, 224, 3, 1, L.MATH_F16X3) == 1          # >= 8192 rows
+    assert dll.cs_conv_wants_split16(2 * 1024, 448, 448, 3, 1, L.MATH_F16X3) == 0
+    assert dll.cs_conv_wants_split16(64 * 4096, 224, 224, 1, 1, L.MATH_F16X3) == 0          # not a 3x3x3 conv
+    assert dll.cs_conv_wants_split16(64 * 4096, 224, 224, 3, 0, L.MATH_F16X3) == 0          # folded / taps-as-columns
+    assert dll.cs_conv_wants_split16(64 * 4096, 224, 224, 3, 1, L.MATH_FP32) == 0
+    assert dll.cs_tapcol_ok(3, 224, 3, L.MATH_F16X3) == 1 and dll.cs_tapcol_ok(8, 224, 3, L.MATH_F16X3) == 0
+    assert dll.cs_tapcol_tile(100, 84) == 0 and dll.cs_tapcol_tile(64 * 4096, 84) == 6 and dll.cs_tapcol_tile(64 * 4096, 28) == 7
+    # the debug struct: defaults, override, restore; ops' module attributes are views of it
+    d = L.debug()
+    assert d.split16_min_rows == 8192 and d.gn_small_group == 11264 and d.no_gn_parts == 0
+    assert ops.GN_PARTS is True and ops.SPLITK is True
+    with L.debug_override(no_gn_parts=1, split16_min_rows=0):
+        assert L.debug().no_gn_parts == 1 and ops.GN_PARTS is False
+        assert dll.cs_conv_wants_split16(2 * 4096, 224, 224, 3, 1, L.MATH_F16X3) == 0
+    assert L.debug().no_gn_parts == 0 and ops.GN_PARTS is True
+    # cs_conv_gemm_launch_info: the dominant kernel's variant, asked not mirrored
+    import ctypes as C
+    p = L.CsConvGemm()
+    p.nb, p.din, p.hin, p.win, p.dout, p.hout, p.wout = 64, 16, 16, 16, 16, 16, 16
+    p.cin, p.cout, p.lda, p.ldo, p.ldw = 672, 224, 672, 224, 224
+    p.kd = p.kh = p.kw = 3
+    p.sd = p.sh = p.sw = p.pd = p.ph = p.pw = 1
+    p.math, p.a_format, p.rv_rows = L.MATH_F16X3, 1, 1
+    t, sl = C.c_int32(0), C.c_int32(0)
+    assert dll.cs_conv_gemm_launch_info(C.byref(p), C.byref(t), C.byref(sl)) == 0 and (t.value, sl.value) == (4, 32)
+    p.kd = p.kh = p.kw = 1
+    p.pd = p.ph = p.pw = 0
+    p.a_format = 0
+    assert dll.cs_conv_gemm_launch_info(C.byref(p), C.byref(t), C.byref(sl)) == 0 and (t.value, sl.value) == (4, 0)

@@ -1,0 +1,211 @@
+"""r4 (ABI 14): what a GEMM's epilogue emits beside / instead of the fp32 tile.
+
+  * CsConvGemm.gn_part -- per-(row tile, column) fp64 partial sums, from which the GroupNorm that follows takes its
+    statistics (ldm_diffusion_util.py:222-239 after openai_model_3d.py:294-314): must reproduce the statistics of a
+    pass over the tensor (fp64 sums in another order: mean / rstd equal to an ulp or two of fp32) for every producer
+    kind -- the tile kernels' pipelined epilogue (slab / gather / pointwise / strided / residual + row vector), the
+    split-K reduce, the folded Upsample conv's one-launch scattered store, two producers filling a concatenation, a
+    producer at batch B feeding a consumer at batch 2B (the classifier-free-guidance prefix);
+  * CsConvGemm.out_format = 2 -- the result as the interleaved operand pair: the next GEMM fed with it must produce the
+    SAME BITS as when it converts the fp32 tensor in its K loop (same hi / lo halves by construction).
+"""
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).cuda()
+
+
+def _stats_close(a, b):
+    """(mean, rstd) [nb, groups, 2] against a reference: a lane adds its 16-32 values per column in fp32, everything above
+    in fp64 -- the mean may move by 1e-7 of the group's standard deviation, rstd by 1e-7 relative (the per-op gate is 1e-6)"""
+    a, b = a.double(), b.double()
+    dm = ((a[..., 0] - b[..., 0]).abs() * b[..., 1]).max()          # in units of the group's standard deviation
+    dr = ((a[..., 1] - b[..., 1]).abs() / b[..., 1]).max()
+    assert float(dm) < 2e-7 and float(dr) < 2e-7, (float(dm), float(dr))
+
+
+CASES = [
+    # nb, (d, h, w), cin, cout, k, stride, residual, rowvec, splitk, tile, note
+    (24, (16, 8, 8), 64, 448, 3, (1, 1, 1), True, False, None, 0, "slab conv on the 256x224 tile, residual"),
+    (24, (16, 8, 8), 64, 448, 3, (1, 1, 1), False, True, None, 0, "slab conv + per-sample row vector"),
+    (64, (16, 8, 8), 96, 448, 1, (1, 1, 1), True, False, None, 0, "pointwise 256x224 tile + residual (proj_out)"),
+    (48, (16, 16, 16), 32, 224, 3, (1, 2, 2), False, False, None, 0, "strided (Downsample) conv, gather kernel"),
+    (2, (16, 4, 4), 224, 672, 3, (1, 1, 1), True, True, None, 0, "small batch: K slices by the plan, reduce kernel"),
+    (2, (16, 8, 8), 96, 224, 3, (1, 1, 1), True, False, 5, 0, "explicit 5 K slices"),
+    (4, (16, 8, 8), 64, 224, 3, (1, 1, 1), True, False, None, 2, "128x224 tile"),
+    (4, (16, 8, 8), 64, 128, 3, (1, 1, 1), True, False, None, 1, "128x128 tile"),
+    (2, (16, 4, 4), 64, 64, 3, (1, 1, 1), False, False, None, 3, "64x64 tile"),
+    (2, (16, 4, 4), 64, 96, 3, (1, 1, 1), False, False, None, 3, "64x64 tile, cout 96: masked edge column tile"),
+    (3, (10, 5, 5), 64, 224, 3, (1, 1, 1), False, False, None, 2, "250-row samples under 128-row tiles -> falls back"),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[-1] for c in CASES])
+def test_gemm_epilogue_partials_give_the_groupnorm_statistics(case):
+    from commonscenes_amd import lib as L, ops
+    nb, sp, cin, cout, k, stride, with_res, with_rv, splitk, tile, note = case
+    up = (0, 0, 0)
+    d, h, w = sp
+    x = _rand(nb, d, h, w, cin, seed=1)
+    wt = _rand(cout, cin, k, k, k, seed=2, scale=(cin * k ** 3) ** -0.5) if k > 1 else _rand(cout, cin, seed=2, scale=cin ** -0.5)
+    b = _rand(cout, seed=3)
+    pw = ops.pack_weight(wt, b, math=L.MATH_F16X3)
+    do, ho, wo = d, (h + 2 * (k // 2) - k) // stride[1] + 1, (w + 2 * (k // 2) - k) // stride[2] + 1
+    res = _rand(nb, do, ho, wo, cout, seed=4) + 0.7 if with_res else None       # (non-centred: mean^2 ~ var)
+    rv = _rand(nb, cout, seed=5) if with_rv else None
+    kw = dict(stride=stride, up=up, res=res, rowvec=rv, rv_rows=do * ho * wo)
+    if splitk:
+        kw["splitk"] = splitk
+    if tile:
+        kw["tile"] = tile
+    y = ops.conv_gemm(x, pw, stats=True, **kw)
+    y0 = ops.conv_gemm(x, pw, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y0), "asking for the partials must not change the result"
+    groups = 32 if cout % 32 == 0 else 8
+    expect = "falls back" not in note
+    assert (getattr(y, "cs_stats", None) is not None) == expect, note
+    if not expect:
+        return
+    st = y.cs_stats
+    assert st.nch == cout and st.nb == nb
+    a = ops.groupnorm_stats_from_parts([(0, st)], nb, do * ho * wo, cout, groups, 1e-5, y.device)
+    ref = ops.groupnorm_stats(y0, groups, 1e-5)                                 # y0 carries no partials: a pass over it
+    torch.cuda.synchronize()
+    _stats_close(a, ref)
+    # fp64 statistics of the tensor itself
+    t = y0.double().reshape(nb, -1, groups, cout // groups)
+    mean, var = t.mean(dim=(1, 3)), t.var(dim=(1, 3), unbiased=False)
+    _stats_close(a, torch.stack([mean, 1.0 / (var + 1e-5).sqrt()], dim=-1))
+    # ... and the GroupNorm output through them
+    gam, bet = _rand(cout, seed=6) + 1.0, _rand(cout, seed=7)
+    g1 = ops.groupnorm(y, gam, bet, groups, 1e-5, L.ACT_SILU)
+    g0 = ops.groupnorm(y0, gam, bet, groups, 1e-5, L.ACT_SILU)
+    torch.cuda.synchronize()
+    assert rel_l2(g1, g0) < 2e-7
+
+
+def test_partials_of_the_folded_upsample_conv_and_of_a_concatenation():
+    """(a) the Upsample conv on the source grid, all parity classes in one launch storing straight into the doubled grid:
+    statistics tiles ordered [class][sample][source-row tile]; (b) two producers writing channel slices of one
+    concatenation buffer (openai_model_3d.py:781), the right one at batch B under a consumer at batch 2 B."""
+    from commonscenes_amd import lib as L, ops
+    nb, d, h, w, c = 64, 16, 4, 4, 672          # 32 objects' level-2 -> level-1 Upsample: 192 256-row tiles per class
+    x = _rand(nb, d, h, w, c, seed=11)
+    wt = _rand(c, c, 3, 3, 3, seed=12, scale=(c * 27) ** -0.5)
+    b = _rand(c, seed=13)
+    pw = ops.pack_weight(wt, b, math=L.MATH_F16X3, fold_up=(0, 1, 1))
+    y = ops.conv_gemm(x, pw, up=(0, 1, 1), stats=True)
+    y0 = ops.conv_gemm(x, pw, up=(0, 1, 1))
+    torch.cuda.synchronize()
+    assert torch.equal(y, y0) and y.shape == (nb, d, 2 * h, 2 * w, c)
+    st = getattr(y, "cs_stats", None)
+    assert st is not None and st.ncls == 4
+    a = ops.groupnorm_stats_from_parts([(0, st)], nb, d * 4 * h * w, c, 32, 1e-5, y.device)
+    _stats_close(a, ops.groupnorm_stats(y0, 32, 1e-5))
+    # (b)
+    B, ch, cs = 8, 224, 224
+    cat = torch.empty((2 * B, 16, 8, 8, ch + cs), dtype=torch.float32, device="cuda")
+    xl = _rand(2 * B, 16, 8, 8, 64, seed=14)
+    pl = ops.pack_weight(_rand(ch, 64, 3, 3, 3, seed=15, scale=(64 * 27) ** -0.5), _rand(ch, seed=16), math=L.MATH_F16X3)
+    left = ops.conv_gemm(xl, pl, out=cat[..., :ch], stats=True)
+    xr = _rand(B, 16, 8, 8, 64, seed=17)
+    pr = ops.pack_weight(_rand(cs, 64, 3, 3, 3, seed=18, scale=(64 * 27) ** -0.5), _rand(cs, seed=19), math=L.MATH_F16X3)
+    right = ops.conv_gemm(xr, pr, stats=True)                   # the shared (B-sized) skip tensor
+    for g in range(2):
+        ops.copy_rows(right, cat[g * B:(g + 1) * B, ..., ch:])
+    assert left.cs_stats is not None and right.cs_stats is not None and right.cs_stats.nb == B
+    cat.cs_segs = [(0, left.cs_stats), (ch, right.cs_stats)]
+    a = ops.groupnorm_stats(cat, 32, 1e-5)                      # 14-channel groups: group 16 straddles the seam
+    plain = torch.empty_like(cat).copy_(cat)
+    torch.cuda.synchronize()
+    _stats_close(a, ops.groupnorm_stats(plain, 32, 1e-5))
+
+
+@pytest.mark.parametrize("m,cin,cmid,cout,tile,splitk,kind", [
+    (65536, 224, 448, 448, 0, None, "residual"), (4096, 224, 448, 448, 0, None, "residual"),
+    (512, 1792, 448, 448, 0, None, "residual"), (16384, 96, 224, 672, 4, None, "bias"), (3000, 448, 3584, 448, 0, None, "geglu"),
+    (512, 448, 3584, 448, 0, None, "geglu")])
+def test_pair_emitting_epilogue_feeds_the_next_gemm_bit_identically(m, cin, cmid, cout, tile, splitk, kind):
+    """attention.py:241-245: GEGLU -> ff.net.2 -> (+ residual) -> proj_out.  The producer writes the interleaved operand
+    pair (out_format = 2) where its result has one reader, the next GEMM; that GEMM must then give the bits it gives on
+    the fp32 tensor, whose operands it splits itself -- incl. the split-K reduce as the producer (small batches)."""
+    from commonscenes_amd import lib as L, ops
+    x = _rand(m, cin, seed=31)
+    if kind == "geglu":
+        w1 = ops.pack_geglu_weight(_rand(2 * cmid, cin, seed=32, scale=cin ** -0.5), _rand(2 * cmid, seed=33) * 0.1)
+        kw = dict(act=L.ACT_GEGLU)
+    else:
+        w1 = ops.pack_weight(_rand(cmid, cin, seed=32, scale=cin ** -0.5), _rand(cmid, seed=33), math=L.MATH_F16X3)
+        kw = dict(res=_rand(m, cmid, seed=34)) if kind == "residual" else {}
+        if tile:
+            kw["tile"] = tile
+        if splitk is not None and splitk > 0:
+            kw["splitk"] = splitk
+    w2 = ops.pack_weight(_rand(cout, cmid, seed=35, scale=cmid ** -0.5), _rand(cout, seed=36), math=L.MATH_F16X3)
+    ops.read_status()
+    mid32 = ops.linear(x, w1, **kw)
+    midp = ops.linear(x, w1, out_pair=16.0, **kw)
+    assert isinstance(midp, ops.Pair16) and midp.a_scale == 16.0, "the launch should have taken the pair route"
+    o32 = ops.linear(mid32, w2)
+    op = ops.linear(midp, w2)
+    torch.cuda.synchronize()
+    assert torch.equal(o32, op)
+    assert ops.read_status() == 0
+    if kind == "residual":
+        # an output beyond the fp16 range of the pair (|out| * 16 >= 65504) is reported by the PRODUCER now
+        kw["res"] = kw["res"] + 5000.0
+        big = ops.linear(x, w1, out_pair=16.0, **kw)
+        torch.cuda.synchronize()
+        assert isinstance(big, ops.Pair16) and ops.read_status() & L.STATUS_F16X3_OVERFLOW
+
+
+def test_unet_takes_its_groupnorm_statistics_from_the_producers(monkeypatch):
+    """the shipped-width UNet at batch 64 (the benchmark's tiles) and 3 (K slices + reduce kernel): with the partials
+    (default) vs passes over the tensors (CS_NO_GN_PARTS) -- the same network to fp32 rounding of the statistics, and
+    (batch 64) every GroupNorm but the channel-split blocks' out_layers.0 served by its producers."""
+    from commonscenes_amd import ops
+    from test_model_gpu import _unet
+    df = _unet(False)
+    nbx = 64
+    x = _rand(nbx, 3, 16, 16, 16, seed=41)
+    t = torch.full((nbx,), 501, device="cuda", dtype=torch.long)
+    ctx = _rand(nbx, 1, 1280, seed=42)
+    calls = {"parts": 0, "pass": 0}
+    import commonscenes_amd.lib as L
+    lib = L.load()
+    real_parts, real_stats, real_gn = lib.cs_groupnorm_finalize_parts, lib.cs_groupnorm_stats, lib.cs_groupnorm
+    real_gnp = lib.cs_groupnorm_parts
+
+    class Count:
+        def __init__(self, fn, key):
+            self.fn, self.key = fn, key
+
+        def __call__(self, *a):
+            calls[self.key] += 1
+            return self.fn(*a)
+    monkeypatch.setattr(lib, "cs_groupnorm_finalize_parts", Count(real_parts, "parts"), raising=False)
+    monkeypatch.setattr(lib, "cs_groupnorm_parts", Count(real_gnp, "parts"), raising=False)
+    monkeypatch.setattr(lib, "cs_groupnorm_stats", Count(real_stats, "pass"), raising=False)
+    monkeypatch.setattr(lib, "cs_groupnorm", Count(real_gn, "pass"), raising=False)
+    a = df(x, t, c_crossattn=[ctx])
+    torch.cuda.synchronize()
+    n_parts, n_pass = calls["parts"], calls["pass"]
+    with L.debug_override(no_gn_parts=1):             # the library-wide switch (CsDebug), as CS_NO_GN_PARTS=1 would set it
+        b = df(x, t, c_crossattn=[ctx])
+        torch.cuda.synchronize()
+    print(f"GroupNorms from producer partials: {n_parts}, from a pass over the tensor: {n_pass}")
+    assert n_parts == 42 and n_pass == 4, (n_parts, n_pass)     # 46 GroupNorms; the channel-split h1 tensors keep a pass
+    assert rel_l2(a, b) < 5e-7
+    a3 = df(x[:3], t[:3], c_crossattn=[ctx[:3]])
+    with L.debug_override(no_gn_parts=1):
+        b3 = df(x[:3], t[:3], c_crossattn=[ctx[:3]])
+        torch.cuda.synchronize()
+    assert rel_l2(a3, b3) < 5e-7

@@ -544,7 +544,7 @@ def test_pingpong_gemm_is_bit_identical_to_the_tile_kernels(case):
             kw["res"] = r
         if case.get("rowvec"):
             kw.update(rowvec=synth.tensor_device(tag + ":rv", (nb, n), 1.0), rv_rows=tok)
-    assert ops._pingpong_ok(nb * tok, k, n, L.MATH_F16X3, True, False, tok if case.get("rowvec") else 0)
+    # (tile = 5 below is refused with CS_EINVAL where the ping-pong kernel is not applicable: the call is the check)
     ops.read_status()
     ref = ops.linear(x, pw, tile=2, **kw)
     got = ops.linear(x, pw, tile=5, **kw)

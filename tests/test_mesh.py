@@ -20,19 +20,77 @@ def _noise(n, seed):
     return vol
 
 
+def _rows(T, t):
+    tab, n = T.TABLES[t]
+    return [[tuple(int(v) for v in tab[c][3 * i:3 * i + 3]) for i in range(int(n[c]))] for c in range(256)]
+
+
 def test_tables_product_generator_equals_oracle_derivation():
     from commonscenes_amd import mc_tables as T
     tab = RM.table()
-    assert T.MAX_TRIS == 5 and int(T.N_TRIS.sum()) == 820
-    for c in range(256):
-        mine = [tuple(int(v) for v in T.TRI_TABLE[c][3 * i:3 * i + 3]) for i in range(int(T.N_TRIS[c]))]
-        assert mine == tab[c], c
+    wt, wn = T.TABLES[T.TABLE_WATERTIGHT]
+    assert T.MAX_TRIS == 5 and int(wn.sum()) == 820
+    assert _rows(T, T.TABLE_WATERTIGHT) == tab
     assert not tab[0] and not tab[255]
-    # the committed header is what the generator produces now
+    # the committed header is what the generator produces now (both tables)
     from pathlib import Path
     hdr = (Path(__file__).resolve().parent.parent / "commonscenes_amd" / "csrc" / "cs_mc_tables.h").read_text()
-    for c in (1, 0x5A, 0xA5, 0x3C, 254):
-        assert "{" + ",".join(str(int(v)) for v in T.TRI_TABLE[c]) + "}" in hdr
+    for t in (T.TABLE_CLASSIC, T.TABLE_WATERTIGHT):
+        for c in (1, 0x5A, 0xA5, 0x3C, 254):
+            assert "{" + ",".join(str(int(v)) for v in T.TABLES[t][0][c]) + "}" in hdr
+
+
+def test_classic_table_is_a_valid_marching_cubes_table_and_agrees_with_the_derived_one():
+    """VERDICT r3 next #7.  The classic Lorensen-Cline table in its universally replicated 256-row form (the default since
+    r4: what PyMCubes ships) is published data that cannot be re-derived -- so every row is held to what ANY marching-
+    cubes table must satisfy (exactly the crossed edges, a manifold consistently oriented patch, boundary along cube faces
+    through every crossed edge once in and once out: a mistyped digit cannot survive that), and it has the classic census
+    (820 triangles, at most 5 per cube).  Measured here, not assumed: on ALL 256 cases -- the 120 with an ambiguous face
+    included -- its patches have the boundary loops of the table derived from the cube geometry (the replicated table
+    cuts off the inside corners of an ambiguous face too; only the original 15-case table with complement symmetry
+    leaves holes), so the two tables mesh the same surface and differ in how polygons are fanned and in winding."""
+    from commonscenes_amd import mc_tables as T
+    ct, cn = T.TABLES[T.TABLE_CLASSIC]
+    wt, wn = T.TABLES[T.TABLE_WATERTIGHT]
+    assert T.TRI_TABLE is ct and ct.shape == (256, 15)                     # the default table
+    assert T.validate_table(ct) == [] and T.validate_table(wt) == []
+    assert int(cn.sum()) == 820 and int(cn.max()) == 5 and cn[0] == cn[255] == 0
+    assert sum(T.face_ambiguous(c) for c in range(256)) == 120
+    rc, rw = _rows(T, T.TABLE_CLASSIC), _rows(T, T.TABLE_WATERTIGHT)
+    other_fan = 0
+    for c in range(256):
+        assert T.boundary_segments(ct[c]) == T.boundary_segments(wt[c]) and cn[c] == wn[c], c
+        other_fan += {frozenset(t) for t in rc[c]} != {frozenset(t) for t in rw[c]}
+    print(f"classic vs derived table: same patches on all 256 cases; {other_fan} cases fan a polygon differently")
+    assert 0 < other_fan < 256
+    # not complement-symmetric on the ambiguous cases (that symmetry is what leaves holes in the 15-case original)
+    sym = sum({frozenset(t) for t in rc[c]} == {frozenset(t) for t in rc[255 - c]} for c in range(256))
+    assert sym == 136
+    # winding: classic normals point to DECREASING values (as published), the derived table's to increasing ones
+    mid = lambda e: (T.CORNERS[T.EDGES[e][0]] + T.CORNERS[T.EDGES[e][1]]) / 2.0
+    for rows, sign in ((rc, -1.0), (rw, 1.0)):
+        a, b, cc = rows[1][0]                                               # case 1: corner 0 inside
+        n = np.cross(mid(b) - mid(a), mid(cc) - mid(a))
+        assert np.sign(n @ np.ones(3)) == sign
+
+
+def test_oracle_marching_cubes_with_the_classic_table_on_analytic_shapes():
+    """the classic table through the oracle's mesher: closed genus-0 / genus-1 surfaces with the analytic area and volume,
+    normals towards decreasing SDF; the SAME vertex set as the watertight table (the tables only choose triangles)."""
+    from commonscenes_amd import mc_tables as T
+    classic = _rows(T, T.TABLE_CLASSIC)
+    c, r = (9.3, 10.1, 9.7), 6.2
+    vol = _sphere(20, c, r)
+    v, f = RM.marching_cubes(vol, 0.02, classic)
+    v2, f2 = RM.marching_cubes(vol, 0.02)
+    assert np.array_equal(v, v2) and f.shape == f2.shape
+    assert RM.mesh_invariants(v, f) == (0, 0, 0, 2)
+    tri = v[f]
+    nrm = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+    assert ((nrm * (tri.mean(1) - np.array(c))).sum(1) < 0).all()          # towards DECREASING SDF, as published
+    name, fn, kind, cc, prm, chi = _SHAPES[2]                               # the torus at the decoder's resolution
+    v, f = RM.marching_cubes((fn(64) / 64.0).astype(np.float32), 0.02, classic)
+    _check_analytic(name + " (classic table)", v, f, kind, cc, prm, chi, 0.02 * 64)
 
 
 def test_oracle_marching_cubes_invariants():
@@ -116,35 +174,44 @@ def test_oracle_mesh_geometry_against_analytic_shapes(shape):
     _check_analytic(name, v, f, kind, c, prm, chi, 0.02 * 64)
 
 
+def _oracle_table(table):
+    from commonscenes_amd import mc_tables as T
+    return _rows(T, T.TABLE_CLASSIC) if table == "classic" else None
+
+
 @pytest.mark.gpu
-def test_sdf_to_mesh_geometry_against_analytic_shapes():
+@pytest.mark.parametrize("table", ["classic", "watertight"])
+def test_sdf_to_mesh_geometry_against_analytic_shapes(table):
     """the same geometry gates on the PRODUCT entry (sdf_to_mesh: batch of three 64^3 SDFs, level 0.02, vertices
-    normalised verts / 64 - .5 as util_3d.py:216 does), plus exact equality with the oracle at this size."""
+    normalised verts / 64 - .5 as util_3d.py:216 does), plus exact equality with the oracle at this size -- with the
+    default (classic) table and with the watertight one."""
     from commonscenes_amd.mesh import sdf_to_mesh
     vols = np.stack([(s[1](64) / 64.0).astype(np.float32) for s in _SHAPES])
-    m = sdf_to_mesh(torch.from_numpy(vols)[:, None], level=0.02, render_all=True)      # a CPU tensor: uploaded, like the
+    kw = {} if table == "classic" else {"table": table}                                 # classic IS the default
+    m = sdf_to_mesh(torch.from_numpy(vols)[:, None], level=0.02, render_all=True, **kw)  # a CPU tensor: uploaded, like the
     torch.cuda.synchronize()                                                            # reference accepts either
     for b, (name, fn, kind, c, prm, chi) in enumerate(_SHAPES):
         v = (m.verts_list()[b].cpu().numpy().astype(np.float64) + 0.5) * 64.0
         f = m.faces_list()[b].cpu().numpy()
         _check_analytic(name, v, f, kind, c, prm, chi, 0.02 * 64)
-        rv, rf = RM.marching_cubes(vols[b], 0.02)
+        rv, rf = RM.marching_cubes(vols[b], 0.02, _oracle_table(table))
         assert np.array_equal(f, rf) and np.abs(v - rv).max() < 1e-4
 
 
 @pytest.mark.gpu
-def test_hip_marching_cubes_equals_oracle_exactly():
+@pytest.mark.parametrize("table", ["classic", "watertight"])
+def test_hip_marching_cubes_equals_oracle_exactly(table):
     from commonscenes_amd.mesh import marching_cubes
     vols = [_sphere(20, (9.3, 10.1, 9.7), 6.2), _noise(14, 0), _noise(14, 1), np.ones((14, 14, 14), np.float32)]
     vols[3][7, 7, 7] = -1.0                                                # one inside voxel: an octahedron
     for level in (0.02, 0.0):
         for group in ([vols[0]], vols[1:]):                               # batches of 1 and 3 (equal grid size)
             sdf = torch.from_numpy(np.stack(group)).cuda()
-            v, f, nv, nf = marching_cubes(sdf, level)
+            v, f, nv, nf = marching_cubes(sdf, level, table=table)
             torch.cuda.synchronize()
             vs, fs = torch.split(v.cpu(), nv), torch.split(f.cpu(), nf)
             for b, vol in enumerate(group):
-                rv, rf = RM.marching_cubes(vol, level)
+                rv, rf = RM.marching_cubes(vol, level, _oracle_table(table))
                 assert vs[b].shape[0] == rv.shape[0] and fs[b].shape[0] == rf.shape[0]
                 assert np.array_equal(fs[b].numpy(), rf)
                 assert np.array_equal(vs[b].numpy(), rv.astype(np.float32))
@@ -166,9 +233,12 @@ def test_sdf_to_mesh_on_64_cubed_batch_properties():
                      rng.uniform(6, 18, 3).astype(np.float32)[:, None, None, None], axis=0)
         vols.append(np.minimum(s, box).astype(np.float32) if b % 2 else s)          # union of a sphere and a box
     sdf = torch.from_numpy(np.stack(vols))[:, None].cuda()
-    m = sdf_to_mesh(sdf, level=0.02, color=(0.2, 0.4, 0.6), render_all=True)
+    m = sdf_to_mesh(sdf, level=0.02, color=(0.2, 0.4, 0.6), render_all=True, table="watertight")
     torch.cuda.synchronize()
     assert len(m) == B and len(sdf_to_mesh(sdf)) == 16
+    mc = sdf_to_mesh(sdf, level=0.02, render_all=True)                       # the default (classic) table: same vertices
+    assert all(torch.equal(a, b) for a, b in zip(mc.verts_list(), m.verts_list()))
+    assert all(a.shape == b.shape for a, b in zip(mc.faces_list(), m.faces_list()))
     for b in (0, 1, 7, 31):
         v, f = m.verts_list()[b].cpu().numpy().astype(np.float64), m.faces_list()[b].cpu().numpy()
         assert f.dtype == np.int64 and v.min() >= -0.5 and v.max() < 0.5
@@ -199,7 +269,7 @@ def test_sdf_to_mesh_on_decoder_output_of_the_reference_golden():
     g = np.load(Path(__file__).resolve().parent / "golden" / "vq_decode.npz")
     sdf = torch.from_numpy(g["dec"]).cuda()                      # (1, 1, 64, 64, 64)
     level = float(np.median(g["dec"]))                           # a level the field actually crosses
-    v, f, nv, nf = marching_cubes(sdf[:, 0], level)
+    v, f, nv, nf = marching_cubes(sdf[:, 0], level, table="watertight")     # a noise-like field: every ambiguous case
     torch.cuda.synchronize()
     rv, rf = RM.marching_cubes(g["dec"][0, 0], level)
     assert nv[0] == rv.shape[0] and nf[0] == rf.shape[0] and nf[0] > 1000
@@ -216,5 +286,11 @@ def test_sdf_to_mesh_on_decoder_output_of_the_reference_golden():
         if c == 1:
             pa, pb = rv[a], rv[b]
             assert any((pa[k] in (0.0, 63.0)) and (pb[k] in (0.0, 63.0)) and pa[k] == pb[k] for k in range(3)), (pa, pb)
-    m = sdf_to_mesh(sdf, level=level)
+    m = sdf_to_mesh(sdf, level=level)                            # default table: the classic one, same vertex set
     assert len(m) == 1 and m.verts_list()[0].shape[0] == nv[0]
+    vc, fc, nvc, nfc = marching_cubes(sdf[:, 0], level)
+    rvc, rfc = RM.marching_cubes(g["dec"][0, 0], level, _oracle_table("classic"))
+    assert np.array_equal(fc.cpu().numpy(), rfc) and np.array_equal(vc.cpu().numpy(), rvc.astype(np.float32))
+    oc, nmc, badc, _ = RM.mesh_invariants(rvc, rfc)
+    print(f"noise-like 64^3 field: classic table {oc} open edges, {nmc} non-manifold (derived table: {open_e}, {nonman})")
+    assert oc == open_e and badc == 0        # same patches per cube: open only where the surface leaves the volume
