@@ -21,6 +21,7 @@ Prints ONE JSON line (rank 0):
   decode                VQ-VAE decode of the rank's 32 latents (quantise + Decoder3D, 723 GFLOP/object), own roofline block;
   end_to_end            steps/s with decode + all-gather amortised over the S-step run (what a whole sample() costs);
   c2                    BASELINE configs[1]: ONE object (N=1 only): ms/step and steps/s;
+  native_driver         the same 32-object and 1-object steps through the native whole-forward driver cs_unet_step;
   c7 / c7x5             the reference's sampler mini-batch of 7 (ms per object-step), and the DEFAULT product call
                         SDFusionText2ShapeModel.rel2shape on 32 objects (mini_B = 7 slices coalesced into one launch
                         batch, r4) next to the reference's own five sequential mini-batches (launch_B = 0);
@@ -479,7 +480,7 @@ def main():
     overflow = ops.read_status(dev) != 0
 
     # ---- extras, outside the timed region: decode of this rank's latents, the all-gather, one object (C2) ----
-    decode = e2e = c2 = c7 = c7x5 = mesh = fp32_leg = None
+    decode = e2e = c2 = c7 = c7x5 = mesh = fp32_leg = native = None
     if not a.no_extras and not a.small:
         vq = VQVAE(K.VQVAE_DDCONFIG, K.VQVAE_N_EMBED, K.VQVAE_EMBED_DIM, device=dev).set_math(a.math)
         vq.load_state_dict(synth.synth_state_dict(vqvae_param_shapes(K.VQVAE_DDCONFIG, K.VQVAE_N_EMBED,
@@ -598,6 +599,35 @@ def main():
                              "ms_per_object_step": dtp * 1e3 / (S * B), "finite": bool(torch.isfinite(g_sdf).all().item())}
             c7x5["speedup"] = c7x5["reference_minibatching"]["seconds"] / c7x5["default_api"]["seconds"]
             del g_sdf, pm
+        if world == 1 and a.driver == "python":
+            # r4: the NATIVE whole-forward driver (csrc/cs_unet.hip: cs_unet_step -- what a C / C++ /
+            # any-FFI host of the library calls) on the same two workloads, beside the Python sequencer the metric above
+            # ran on; same kernels, same bits (tests/test_unet_native_gpu.py), so the difference is host overhead only --
+            # which matters at one object (~400 launches in ~7 ms), not at 32
+            from commonscenes_amd.unet_native import NativeDiffusionUNet
+            ndf = NativeDiffusionUNet(cfg, conditioning_key="crossattn", device=dev, math=a.math)
+            ndf.load_state_dict(df.state_dict())
+            nmodel = K.ScheduleModel(ndf, dev)
+            nsamp = DDIMSampler(nmodel)
+            nsamp.make_schedule(a.ddim_steps, ddim_eta=0.0, verbose=False)
+
+            def nsteps(xx, cc, n_warm, n_timed):
+                for j in range(n_warm):
+                    xx, _ = nsamp._step(xx, cc, int(ts[j]), S - j - 1, True, 3.0, want_pred_x0=False)
+                torch.cuda.synchronize()
+                t0_ = time.perf_counter()
+                for j in range(n_warm, n_warm + n_timed):
+                    xx, _ = nsamp._step(xx, cc, int(ts[j]), S - j - 1, True, 3.0, want_pred_x0=False)
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0_) / n_timed
+            dn32 = nsteps(x_T.repeat(B, 1, 1, 1, 1).contiguous(), c_in, 2, a.steps)
+            ndf.reset_run_cache()
+            dn1 = nsteps(x_T.clone(), torch.cat([uc[:1], c[:1]]), 3, 20)
+            native = {"driver": "cs_unet_step (csrc/cs_unet.hip), workspace and arena owned by the caller",
+                      "ms_per_step": dn32 * 1e3, "steps_per_s": 1.0 / dn32, "steps": a.steps,
+                      "c2_ms_per_step": dn1 * 1e3, "python_driver_ms_per_step": dt / a.steps * 1e3,
+                      "python_driver_c2_ms_per_step": c2["ms_per_step"] if c2 else None}
+            del ndf, nmodel, nsamp
         if world == 1 and a.math == "f16x3" and not a.no_fp32_leg:
             # the same workload on the fp32-input MFMA kernels (the reference's dtype on the matrix pipe it maps to), so
             # that what CS_MATH_F16X3 buys is on the record next to the metric; 1 warm-up + 2 timed steps
@@ -707,7 +737,7 @@ def main():
                        "objects_per_gpu": B, "unet_batch": 2 * B, "ddim_steps": S,
                        "parallelism": f"object-sharded x{world} (replicated weights, no per-step collective; "
                                       "1 broadcast in, 1 all-gather out)"},
-            "roofline": roof, "decode": decode, "end_to_end": e2e, "c2": c2, "c7": c7, "c7x5": c7x5, "fp32_mfma": fp32_leg,
+            "roofline": roof, "decode": decode, "end_to_end": e2e, "c2": c2, "c7": c7, "c7x5": c7x5, "native_driver": native, "fp32_mfma": fp32_leg,
             "mesh": mesh,
             "conditioning_ms": cond_ms["warm"], "conditioning_cold_ms": cond_ms["cold"],
             "conditioning_note": "rank 0: graph synthesis + embeddings + 5 GCN layers + rel_mlp for all objects; cold = the "

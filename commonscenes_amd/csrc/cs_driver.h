@@ -540,6 +540,9 @@ struct ExecBase {
   int rc = CS_OK;
   int64_t peak = 0;
   int32_t* status = nullptr;     // caller's sticky CS_STATUS_* word (device) handed to every F16X3 kernel
+  // magnitude-bound slots of this forward (CsConvGemm.a_bound; unet.py::_slot / ops.range_bound): one small zeroed region
+  Buf amax_arena;
+  int amax_next = 0, amax_cap = 0;
   std::vector<FreeBlock> fl;
 
   ExecBase(const Plan& pl_, const void* arena_, void* ws_, int64_t ws_bytes_, bool dry_, hipStream_t st_)
@@ -577,6 +580,17 @@ struct ExecBase {
     t.off = off;
     t.bytes = bytes;
     release_data(t);
+  }
+  void amax_begin(int slots) {
+    if (pl.math != CS_MATH_F16X3 || cs_debug()->no_dyn_scale || cs_debug()->no_gn_parts) return;
+    amax_arena = alloc(slots, 1);
+    amax_cap = ok() ? slots : 0;
+    amax_next = 0;
+    if (ok() && !dry && hipMemsetAsync(ws + amax_arena.off, 0, (size_t)slots * 4, st) != hipSuccess) chk(CS_EINVAL);
+  }
+  int64_t amax_slot() {       // a fresh slot's workspace offset, or -1 (feature off / arena exhausted)
+    if (amax_next >= amax_cap) return -1;
+    return amax_arena.off + 4 * (int64_t)amax_next++;
   }
   Stat alloc_stat(int64_t tiles, int nch, int nb, int tps, int ncls) {
     Buf t = alloc(tiles * nch * 4, 1);          // [tiles][nch][2] doubles = 16 bytes per (tile, column)
@@ -626,7 +640,8 @@ struct ExecBase {
   // ask), its epilogue leaves the per-(row tile, column) partial sums and the returned buffer carries them (seg[0])
   Buf gemm(const Buf& x, int gi, int nb, int d, int h, int w, int s_hw = 1, int up_hw = 0, int act = CS_ACT_NONE,
            const float* rowvec = nullptr, int ldrv = 0, int rv_rows = 1, const float* res = nullptr, int ldr = 0,
-           int tile = 0, int s_d = 1, int up_d = 0, bool want_stats = false, float out_pair = 0.f) {
+           int tile = 0, int s_d = 1, int up_d = 0, bool want_stats = false, float out_pair = 0.f,
+           int64_t a_bound_off = -1) {
     const Gemm& g = pl.gemms[gi];
     const bool tc = g.tap_cout > 0;      // taps as columns: the pointwise GEMM below, then cs_tapsum27
     if (tc) {
@@ -680,6 +695,10 @@ struct ExecBase {
     q.pd = q.ph = q.pw = pad;
     q.ud = up_d; q.uh = q.uw = up_hw;
     q.act = act; q.rv_rows = rv_rows; q.math = pl.math; q.tile = tile;
+    // a_bound_off >= 0: x is a RAW activation whose magnitude bound sits in that workspace slot (range_bound / the
+    // GroupNorm over x): the kernel derives the operand scale from it instead of the fixed 16 (ops.py: x_bound=)
+    if (a_bound_off >= 0 && pl.math == CS_MATH_F16X3 && !x.half && !x.pair && !dry)
+      q.a_bound = reinterpret_cast<const float*>(ws + a_bound_off);
     if (g.up_mask) {
       // Upsample's conv on the source grid: one GEMM per output parity class + interleave (cs_conv_gemm_up2)
       if (g.up_mask != ((up_d << 2) | (up_hw << 1) | up_hw) || s_hw != 1 || s_d != 1 || res || rowvec || tile ||
@@ -839,24 +858,35 @@ struct ExecBase {
       ch0 += a.nch;
     }
   }
-  void finalize_parts(const Buf& x, int nb, float eps, int groups, const Buf& stats) {
+  float* bound_ptr(int64_t off) const { return off >= 0 ? reinterpret_cast<float*>(ws + off) : nullptr; }
+  void finalize_parts(const Buf& x, int nb, float eps, int groups, const Buf& stats, int64_t bound_off = -1) {
     if (!ok() || dry) return;
     CsGnSeg sg[2];
-    int ch0 = 0;
-    for (int i = 0; i < x.nseg; ++i) {
-      const Stat& a = x.seg[i];
-      sg[i].part = reinterpret_cast<const double*>(ws + a.off);
-      sg[i].ld = a.nch; sg[i].col0 = 0; sg[i].ch0 = ch0; sg[i].nch = a.nch;
-      sg[i].tiles_per_sample = a.tps; sg[i].ncls = a.ncls; sg[i].nb_src = a.nb; sg[i].reserved = 0;
-      ch0 += a.nch;
+    seg_array(x, sg);
+    chk(cs_groupnorm_finalize_parts(sg, x.nseg, nb, (int)(x.rows / nb), x.c, groups, eps, p(stats), bound_ptr(bound_off), st));
+  }
+  // ops.py::range_bound: the magnitude bound of a RAW tensor that no GroupNorm follows, from its producers' partials, into
+  // a fresh slot; -1 when x carries none (the consumer then keeps the fixed scale)
+  int64_t range_bound(const Buf& x, int nb, int groups = 32) {
+    if (!has_parts(x) || x.c % groups) return -1;
+    const int64_t off = amax_slot();
+    if (off < 0) return -1;
+    if (ok() && !dry) {
+      CsGnSeg sg[2];
+      seg_array(x, sg);
+      chk(cs_groupnorm_finalize_parts(sg, x.nseg, nb, (int)(x.rows / nb), x.c, groups, 1e-5f, nullptr, bound_ptr(off), st));
     }
-    chk(cs_groupnorm_finalize_parts(sg, x.nseg, nb, (int)(x.rows / nb), x.c, groups, eps, p(stats), st));
+    return off;
   }
 
-  Buf gn_stats(const Buf& x, int nb, float eps, int groups = 32) {
+  // bound_off (out): the slot x's magnitude bound went to (-1: none -- x carries no partials or the feature is off)
+  Buf gn_stats(const Buf& x, int nb, float eps, int groups = 32, int64_t* bound_off = nullptr) {
+    if (bound_off) *bound_off = -1;
     if (has_parts(x)) {
       Buf stats = alloc((int64_t)nb * groups * 2, 1);
-      finalize_parts(x, nb, eps, groups, stats);
+      const int64_t off = bound_off ? amax_slot() : -1;
+      finalize_parts(x, nb, eps, groups, stats, off);
+      if (bound_off) *bound_off = off;
       return stats;
     }
     Buf wsb = alloc((cs_groupnorm_ws_bytes(nb, groups) + 3) / 4, 1);
@@ -919,16 +949,22 @@ struct ExecBase {
   }
 
   // conv_gi: the 3x3x3 conv that consumes the result (decides the output format), or -1
-  Buf groupnorm(const Buf& x, int ni, int nb, float eps, int act, int groups = 32, int conv_gi = -1) {
+  // bound_off (out, optional): wanted when a consumer will read x RAW (the ResBlock's skip conv): the slot x's magnitude
+  // bound went to, -1 if none (ops.py::groupnorm bound=)
+  Buf groupnorm(const Buf& x, int ni, int nb, float eps, int act, int groups = 32, int conv_gi = -1,
+                int64_t* bound_off = nullptr) {
     const Norm& n = pl.norms[ni];
     Buf y = alloc(x.rows, x.c);
+    if (bound_off) *bound_off = -1;
     if (has_parts(x)) {      // r4: statistics from the producers' partials, the tensor is read once (ops.py::groupnorm)
+      const int64_t boff = bound_off ? amax_slot() : -1;
+      if (bound_off) *bound_off = boff;
       Buf stats = alloc((int64_t)nb * groups * 2, 1);
       if (pl.math == CS_MATH_F16X3) y.a_scale = norm_a_scale(n.gmax, n.bmax, (x.rows / nb) * (int64_t)(x.c / groups));
       const int rows = (int)(x.rows / nb);
       if (wants_split16(x.rows, conv_gi)) {
         y.half = true;
-        finalize_parts(x, nb, eps, groups, stats);
+        finalize_parts(x, nb, eps, groups, stats, boff);
         if (ok() && !dry) {
           char* yh = reinterpret_cast<char*>(p(y));
           chk(cs_groupnorm_apply_split16(p(x), p(stats), wf(n.g_off), wf(n.b_off), yh, yh + x.rows * x.c * 2, nb, rows, x.c,
@@ -939,7 +975,7 @@ struct ExecBase {
         CsGnSeg sg[2];
         seg_array(x, sg);
         chk(cs_groupnorm_parts(p(x), sg, x.nseg, wf(n.g_off), wf(n.b_off), p(y), nb, rows, x.c, x.c, x.c, groups, eps, act,
-                               p(stats), st));
+                               p(stats), bound_ptr(boff), st));
       }
       release(stats);
       return y;

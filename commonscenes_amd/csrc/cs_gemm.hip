@@ -628,6 +628,7 @@ static int conv_gemm_impl(const CsConvGemm* d, cs_stream_t stream, int omap_f, i
   if (tile == 0) tile = auto_tile(p, M, f16x3);
   hipStream_t s = (hipStream_t)stream;
   if (p.splitk > 1 && omap_f) return CS_EINVAL;
+  if (p.a_bound && (!f16x3 || p.a_format != 0 || ((uintptr_t)p.a_bound & 3))) return CS_EINVAL;
   if ((p.gn_part || p.out_format) && !omap_f) {
     // epilogue outputs beside the fp32 tile: only where cs_conv_gemm_epilogue_caps says the launch can produce them
     int32_t rows = 0, pair = 0;

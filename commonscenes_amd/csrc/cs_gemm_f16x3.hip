@@ -273,7 +273,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   const __amdgpu_buffer_rsrc_t xlrs = __builtin_amdgcn_make_buffer_rsrc(
       (void*)((const char*)(PRE ? p.x_lo : (const void*)p.x) + x_skip), 0, x_win, 0x00020000);
 
-  const float a_scale = p.a_scale;
+  // r4: operand scale from a bound on the tensor's magnitude (CsConvGemm.a_bound, left by the GroupNorm finalize kernels):
+  // the largest power of two that keeps the bound inside the fp16 range; acc_scale_ follows by the exact ratio.  Uniform.
+  float a_scale = p.a_scale;
+  if constexpr (!PRE && !PAIR) {
+    if (p.a_bound) {
+      const float m = *p.a_bound;
+      int ex = 0;
+      float s2 = 1.0995116e12f;                              // 2^40: an all-zero (or empty) tensor
+      if (m > 0.f && m < 3.0e38f) {
+        (void)frexpf(65000.0f / m, &ex);
+        s2 = ldexpf(1.0f, min(max(ex - 1, -8), 40));
+      }
+      acc_scale_ *= a_scale / s2;
+      a_scale = s2;
+    }
+  }
   const int chunks_per_tap = kg_per_tap >> 1;   // cin16 / 16
   const int nk_all = ntaps * chunks_per_tap;
   // this workgroup's slice of the chunk sequence (slab path: whole super-chunks of nine taps)
@@ -974,30 +989,30 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
         // lanes -> [wave][staged row][column] in LDS, then thread t < BN adds column t over the waves that own it and
         // the four staged rows, always in the same order; the tile's (sum, sum of squares) row goes out as 16-byte pairs
         static_assert(NW * 4 * WCOLS * 8 <= LDS_BYTES && BN <= NT, "statistics scratch must fit the kernel's LDS");
-        double* const sc = reinterpret_cast<double*>(smem);
+        // ONE round: every lane leaves its (sum, sum of squares) fp32 pairs, then 32 WAVES_M adds per column in fp64
+        f32x2* const sc = reinterpret_cast<f32x2*>(smem);
         double tot[2] = {0.0, 0.0};
+        __syncthreads();
 #pragma unroll
-        for (int which = 0; which < 2; ++which) {
-          __syncthreads();
+        for (int k = 0; k < KU; ++k) {
+          const int u = lane + 64 * k;
+          if (u < UN) {
+            const int lrow = u / UPR, c4 = u - lrow * UPR;
 #pragma unroll
-          for (int k = 0; k < KU; ++k) {
-            const int u = lane + 64 * k;
-            if (u < UN) {
-              const int lrow = u / UPR, c4 = u - lrow * UPR;
+            for (int e = 0; e < 4; ++e)
+              sc[(wave * 4 + lrow) * WCOLS + 4 * c4 + e] = f32x2{gs[k][e >> 1][e & 1], gq[k][e >> 1][e & 1]};
+          }
+        }
+        __syncthreads();
+        if (tid < BN) {
+          const int wn = tid / WCOLS, cc = tid - wn * WCOLS;
+          for (int wm = 0; wm < WAVES_M; ++wm)
 #pragma unroll
-              for (int e = 0; e < 4; ++e)
-                sc[(wave * 4 + lrow) * WCOLS + 4 * c4 + e] = (double)(which ? gq[k][e >> 1][e & 1] : gs[k][e >> 1][e & 1]);
+            for (int lr = 0; lr < 4; ++lr) {
+              const f32x2 v2 = sc[((wm * WAVES_N + wn) * 4 + lr) * WCOLS + cc];
+              tot[0] += (double)v2[0];
+              tot[1] += (double)v2[1];
             }
-          }
-          __syncthreads();
-          if (tid < BN) {
-            const int wn = tid / WCOLS, cc = tid - wn * WCOLS;
-            double t = 0.0;
-            for (int wm = 0; wm < WAVES_M; ++wm)
-#pragma unroll
-              for (int lr = 0; lr < 4; ++lr) t += sc[((wm * WAVES_N + wn) * 4 + lr) * WCOLS + cc];
-            tot[which] = t;
-          }
         }
         if (tid < BN && n0 + tid < p.cout) {
           typedef double d2 __attribute__((ext_vector_type(2)));

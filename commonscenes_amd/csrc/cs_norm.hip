@@ -138,8 +138,18 @@ __device__ __forceinline__ void gn_group_parts(const GnSegs& sg, int n, int g, i
   }
 }
 
+// |mean| + std * sqrt(n - 1) >= max |x| over the group (Samuelson's inequality), rounded UP to fp32; the maximum over all
+// (sample, group)s bounds the tensor: what CsConvGemm.a_bound reads.  atomicMax of the bits: order-independent.
+__device__ __forceinline__ void gn_bound_max(float* bound, double mean, double var, double count) {
+  const double b = fabs(mean) + sqrt(var * (count > 1.0 ? count - 1.0 : 1.0));
+  float bf = (float)b;
+  if ((double)bf < b) bf = __uint_as_float(__float_as_uint(bf) + 1u);
+  if (bf == bf && bf > 0.f) atomicMax(reinterpret_cast<unsigned int*>(bound), __float_as_uint(bf));
+}
+
 __global__ __launch_bounds__(256) void gn_finalize_parts_kernel(const GnSegs sg, int groups, int cpg, double count,
-                                                                float eps, float* __restrict__ stats, int total) {
+                                                                float eps, float* __restrict__ stats,
+                                                                float* __restrict__ bound, int total) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);  // n * groups + g
   if (i >= total) return;
@@ -155,8 +165,11 @@ __global__ __launch_bounds__(256) void gn_finalize_parts_kernel(const GnSegs sg,
     const double mean = s / count;
     double var = q / count - mean * mean;
     if (var < 0) var = 0;
-    stats[2 * i] = (float)mean;
-    stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    if (stats) {
+      stats[2 * i] = (float)mean;
+      stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    if (bound) gn_bound_max(bound, mean, var, count);
   }
 }
 
@@ -496,8 +509,8 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void gn_small_parts_kernel(const float* __restrict__ x, const GnSegs sg,
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float* __restrict__ y,
-                                                             float* __restrict__ stats, int rows, int c, int ldx, int ldy,
-                                                             int groups, float eps, int act) {
+                                                             float* __restrict__ stats, float* __restrict__ bound, int rows,
+                                                             int c, int ldx, int ldy, int groups, float eps, int act) {
   __shared__ double red[2][256];
   const int n = blockIdx.x / groups, g = blockIdx.x - n * groups;
   const int cpg = c / groups;
@@ -525,6 +538,7 @@ __global__ __launch_bounds__(256) void gn_small_parts_kernel(const float* __rest
     stats[2 * blockIdx.x] = mean;
     stats[2 * blockIdx.x + 1] = rstd;
   }
+  if (tid == 0 && bound) gn_bound_max(bound, mean_d, var, count);
   const float* xb = x + (int64_t)n * rows * ldx + g * cpg;
   float* yb = y + (int64_t)n * rows * ldy + g * cpg;
   const int dr = 256 / cpg, dk = 256 - dr * cpg;
@@ -589,14 +603,14 @@ static int gn_pack_segs(const CsGnSeg* segs, int nseg, int nb, int c, GnSegs& sg
 }
 
 extern "C" int cs_groupnorm_finalize_parts(const CsGnSeg* segs, int nseg, int nb, int rows, int c, int groups, float eps,
-                                           float* stats, cs_stream_t stream) {
-  if (!stats || nb <= 0 || rows <= 0 || c <= 0 || groups <= 0 || c % groups) return CS_EINVAL;
+                                           float* stats, float* bound, cs_stream_t stream) {
+  if ((!stats && !bound) || ((uintptr_t)bound & 3) || nb <= 0 || rows <= 0 || c <= 0 || groups <= 0 || c % groups) return CS_EINVAL;
   GnSegs sg;
   const int rc = gn_pack_segs(segs, nseg, nb, c, sg);
   if (rc != CS_OK) return rc;
   const int total = nb * groups;
   CS_LAUNCH(gn_finalize_parts_kernel, dim3((total + 3) / 4), dim3(256), 0, (hipStream_t)stream, sg, groups, c / groups,
-            (double)rows * (c / groups), eps, stats, total);
+            (double)rows * (c / groups), eps, stats, bound, total);
   CS_CHECK_LAUNCH();
   return CS_OK;
 }
@@ -606,8 +620,8 @@ extern "C" int cs_groupnorm_finalize_parts(const CsGnSeg* segs, int nseg, int nb
 // cs_groupnorm_apply otherwise.  `stats` [nb][groups][2] is written either way.
 extern "C" int cs_groupnorm_parts(const float* x, const CsGnSeg* segs, int nseg, const float* gamma, const float* beta,
                                   float* y, int nb, int rows, int c, int ldx, int ldy, int groups, float eps, int act,
-                                  float* stats, cs_stream_t stream) {
-  if (!x || !gamma || !beta || !y || !stats || nb <= 0 || rows <= 0 || c <= 0 || groups <= 0 || c % groups || ldx < c ||
+                                  float* stats, float* bound, cs_stream_t stream) {
+  if (!x || !gamma || !beta || !y || !stats || ((uintptr_t)bound & 3) || nb <= 0 || rows <= 0 || c <= 0 || groups <= 0 || c % groups || ldx < c ||
       ldy < c)
     return CS_EINVAL;
   GnSegs sg;
@@ -618,11 +632,11 @@ extern "C" int cs_groupnorm_parts(const float* x, const CsGnSeg* segs, int nseg,
   if ((int64_t)nb * rows * c * 4 <= GN_SMALL_BYTES && cpg <= 256 && (int64_t)rows * cpg <= small_group &&
       (int64_t)nb * groups <= 65535) {
     CS_LAUNCH(gn_small_parts_kernel, dim3((unsigned)(nb * groups)), dim3(256), 0, (hipStream_t)stream, x, sg, gamma, beta, y,
-              stats, rows, c, ldx, ldy, groups, eps, act);
+              stats, bound, rows, c, ldx, ldy, groups, eps, act);
     CS_CHECK_LAUNCH();
     return CS_OK;
   }
-  const int rc = cs_groupnorm_finalize_parts(segs, nseg, nb, rows, c, groups, eps, stats, stream);
+  const int rc = cs_groupnorm_finalize_parts(segs, nseg, nb, rows, c, groups, eps, stats, bound, stream);
   if (rc) return rc;
   return cs_groupnorm_apply(x, stats, gamma, beta, y, nb, rows, c, ldx, ldy, groups, act, stream);
 }

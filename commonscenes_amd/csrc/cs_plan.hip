@@ -53,6 +53,7 @@ void parse_env(CsDebug& d) {
   d.slice_tile2 = flag("CS_SLICE_TILE2");
   d.no_gn_parts = flag("CS_NO_GN_PARTS");
   d.no_pair_epilogue = flag("CS_NO_PAIR_EPILOGUE");
+  d.no_dyn_scale = flag("CS_NO_DYN_SCALE");
 }
 
 }  // namespace

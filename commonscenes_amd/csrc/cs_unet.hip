@@ -288,7 +288,9 @@ struct Exec : ExecBase {
 
   Act res_block(const Layer& l, const Act& x, const Buf& semb) {
     const int rows = x.d * x.h * x.w;
-    Buf hn = groupnorm(x.b, l.n[0], x.nb, 1e-5f, CS_ACT_SILU, 32, l.g[0]);
+    // (xb: the skip conv below reads x RAW -- the GroupNorm's finalize kernel leaves x's magnitude bound on the way)
+    int64_t xb = -1;
+    Buf hn = groupnorm(x.b, l.n[0], x.nb, 1e-5f, CS_ACT_SILU, 32, l.g[0], l.g[2] >= 0 ? &xb : nullptr);
     // (want_stats: the conv's epilogue leaves the partial sums the next GroupNorm takes its statistics from -- unet.py::_res)
     Buf h1 = gemm(hn, l.g[0], x.nb, x.d, x.h, x.w, 1, 0, CS_ACT_NONE, dry ? nullptr : p(semb) + l.emb_lo, semb.c, rows,
                   nullptr, 0, 0, 1, 0, /*want_stats=*/true);
@@ -297,7 +299,9 @@ struct Exec : ExecBase {
     release(h1);
     Buf skip;
     const bool own_skip = l.g[2] >= 0;
-    if (own_skip) skip = gemm(x.b, l.g[2], x.nb, x.d, x.h, x.w);
+    // (the skip conv reads the RAW residual stream: operand scale from the tensor's actual range, unet.py::_res x_bound=)
+    if (own_skip)
+      skip = gemm(x.b, l.g[2], x.nb, x.d, x.h, x.w, 1, 0, CS_ACT_NONE, nullptr, 0, 1, nullptr, 0, 0, 1, 0, false, 0.f, xb);
     Act o = x;
     const Buf& sk = own_skip ? skip : x.b;
     o.b = gemm(hn2, l.g[1], x.nb, x.d, x.h, x.w, 1, 0, CS_ACT_NONE, nullptr, 0, 1, dry ? nullptr : p(sk), sk.c, 0, 1, 0,
@@ -321,7 +325,8 @@ struct Exec : ExecBase {
       return o;
     }
     const int64_t m_launch = (int64_t)nbs * rows;
-    Buf stats = gn_stats(x.b, nb, 1e-5f);
+    int64_t xb = -1;
+    Buf stats = gn_stats(x.b, nb, 1e-5f, 32, &xb);
     const float* xs = dry ? nullptr : p(sk.b) + off;           // the shared channels of the skip tensor
     Buf a_h = gn_apply_range(dry ? nullptr : p(x.b), C, x.b.rows, nb, stats, l.n[0], 32, cpg, 0, ks, CS_ACT_SILU, l.gsp[0],
                              m_launch);
@@ -350,7 +355,7 @@ struct Exec : ExecBase {
     }
     release(a_h);
     release(y_s);
-    Buf skc = gemm(x.b, l.g[2], nb, x.d, x.h, x.w);
+    Buf skc = gemm(x.b, l.g[2], nb, x.d, x.h, x.w, 1, 0, CS_ACT_NONE, nullptr, 0, 1, nullptr, 0, 0, 1, 0, false, 0.f, xb);
     Buf hn2 = groupnorm(h1, l.n[1], nb, 1e-5f, CS_ACT_SILU, 32, l.g[1]);
     release(h1);
     o.b = gemm(hn2, l.g[1], nb, x.d, x.h, x.w, 1, 0, CS_ACT_NONE, nullptr, 0, 1, dry ? nullptr : p(skc), cout, 0, 1, 0,
@@ -450,7 +455,9 @@ struct Exec : ExecBase {
         case DOWN: {   // dims == 3: inner two dims only (openai_model_3d.py:188); dims == 4: all three
           const int sd = u.cfg.dims == 3 ? 1 : 2;
           o = h;
-          o.b = gemm(h.b, l.g[0], h.nb, h.d, h.h, h.w, 2, 0, CS_ACT_NONE, nullptr, 0, 1, nullptr, 0, 0, sd, 0, true);
+          // (Down / Upsample read the RAW stream with no GroupNorm in front: its bound from the producers' partials)
+          o.b = gemm(h.b, l.g[0], h.nb, h.d, h.h, h.w, 2, 0, CS_ACT_NONE, nullptr, 0, 1, nullptr, 0, 0, sd, 0, true, 0.f,
+                     range_bound(h.b, h.nb));
           o.d = h.d / sd;
           o.h = h.h / 2;
           o.w = h.w / 2;
@@ -459,7 +466,8 @@ struct Exec : ExecBase {
         case UP: {     // nearest x2 folded into the conv's addressing (openai_model_3d.py:148-157)
           const int ud = u.cfg.dims == 3 ? 0 : 1;
           o = h;
-          o.b = gemm(h.b, l.g[0], h.nb, h.d, h.h, h.w, 1, 1, CS_ACT_NONE, nullptr, 0, 1, nullptr, 0, 0, 1, ud, true);
+          o.b = gemm(h.b, l.g[0], h.nb, h.d, h.h, h.w, 1, 1, CS_ACT_NONE, nullptr, 0, 1, nullptr, 0, 0, 1, ud, true, 0.f,
+                     range_bound(h.b, h.nb));
           o.d = h.d << ud;
           o.h = h.h * 2;
           o.w = h.w * 2;
@@ -500,6 +508,7 @@ int forward(Exec& e, const float* x_ncdhw, const int64_t* t, const float* ctxvec
   const cs_unet& u = e.u;
   const CsUnetConfig& c = u.cfg;
   const int S = c.d * c.h * c.w;
+  e.amax_begin(64);       // magnitude-bound slots of this forward (unet.py::forward_ndhwc: self._amax)
   Buf temb = e.alloc(nbx, c.model_channels);
   if (e.ok() && !e.dry) e.chk(cs_timestep_embedding(t, e.p(temb), nbx, c.model_channels, 10000.0f, e.st));
   Buf e1 = e.linear(temb, u.g_te0, CS_ACT_SILU);
@@ -585,6 +594,7 @@ int forward(Exec& e, const float* x_ncdhw, const int64_t* t, const float* ctxvec
   if (e.ok() && !e.dry) e.chk(cs_ndhwc_to_nchw(e.p(eps), eps_ncdhw, h.nb, c.out_channels, S, eps.c, e.st));
   e.release(eps);
   e.release(semb);
+  e.release(e.amax_arena);
   return e.rc;
 }
 

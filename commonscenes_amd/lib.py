@@ -53,7 +53,7 @@ class CsConvGemm(C.Structure):
         ("x_lo", C.c_void_p), ("a_format", C.c_int32), ("splitk", C.c_int32),
         ("splitk_ws", C.c_void_p), ("status", C.c_void_p),
         ("gn_part", C.c_void_p), ("gn_ld", C.c_int32), ("gn_rows", C.c_int32), ("out_format", C.c_int32),
-        ("out_scale", C.c_float),
+        ("out_scale", C.c_float), ("a_bound", C.c_void_p),
     ]
 
 
@@ -67,7 +67,7 @@ class CsDebug(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "no_split16", "no_pair16", "no_upfold", "no_splitk", "no_fused_geglu", "no_tapcol", "tapcol_tile", "no_cfg_split",
         "concat_copy", "tile512", "no_pw", "no_slab4", "no_attn_img", "attn_nw8", "no_up2_direct", "no_up2_batch",
-        "plan_pow2", "slice_tile2", "no_gn_parts", "no_pair_epilogue")] + [
+        "plan_pow2", "slice_tile2", "no_gn_parts", "no_pair_epilogue", "no_dyn_scale", "reserved0")] + [
         ("split16_min_rows", C.c_int64), ("cfg_split_min_rows", C.c_int64), ("gn_small_group", C.c_int64)]
 
 
@@ -104,8 +104,8 @@ SIGNATURES = {
     "cs_conv_wants_split16": (_i, [_l, _i, _i, _i, _i, _i]),
     "cs_tapcol_ok": (_i, [_i, _i, _i, _i]),
     "cs_tapcol_tile": (_i, [_l, _i]),
-    "cs_groupnorm_finalize_parts": (_i, [C.POINTER(CsGnSeg), _i, _i, _i, _i, _i, _fl, _f, _s]),
-    "cs_groupnorm_parts": (_i, [_f, C.POINTER(CsGnSeg), _i, _f, _f, _f, _i, _i, _i, _i, _i, _i, _fl, _i, _f, _s]),
+    "cs_groupnorm_finalize_parts": (_i, [C.POINTER(CsGnSeg), _i, _i, _i, _i, _i, _fl, _f, _f, _s]),
+    "cs_groupnorm_parts": (_i, [_f, C.POINTER(CsGnSeg), _i, _f, _f, _f, _i, _i, _i, _i, _i, _i, _fl, _i, _f, _f, _s]),
     "cs_conv_up2_info": (_i, [_i, _i, _i, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                               C.POINTER(C.c_int32)]),
     "cs_fold_upsample_weight": (_i, [_f, _f, _i, _i, _i, _i, _i, _s]),

@@ -200,6 +200,7 @@ _SWITCHES = {
     "SPLIT16_PRODUCERS": lambda d: not d.no_split16,     # CS_NO_SPLIT16=1: GroupNorm emits fp32, not the operand pair
     "PAIR_EPILOGUES": lambda d: not d.no_pair_epilogue,  # CS_NO_PAIR_EPILOGUE=1: GEMM epilogues always write fp32
     "GN_PARTS": lambda d: not d.no_gn_parts,             # CS_NO_GN_PARTS=1: GroupNorm statistics from a pass over the tensor
+    "DYN_SCALE": lambda d: not d.no_dyn_scale,           # CS_NO_DYN_SCALE=1: raw-activation consumers keep the fixed scale 16
 }
 
 
@@ -387,26 +388,47 @@ def _seg_array(segs):
     return arr
 
 
-def groupnorm_stats_from_parts(segs, nb: int, rows: int, c: int, groups: int, eps: float, device) -> Tensor:
-    """(mean, rstd) [nb, groups, 2] from the producers' partials (cs_groupnorm_finalize_parts): no pass over the tensor."""
+def range_bound(x: Tensor, slot: Optional[Tensor], groups: int = 32) -> Optional[Tensor]:
+    """Leave an upper bound of max |x| in `slot` (a zeroed 1-element fp32 device tensor) -- the maximum over x's (sample,
+    group) statistics of |mean| + std * sqrt(n - 1) (Samuelson), computed from the producers' partial sums by the tiny
+    finalize kernel -- and remember it on x (`x.cs_bound`).  A consumer of the RAW tensor hands it to
+    conv_gemm(x_bound=): its F16X3 operand scale then follows the tensor's actual range (CsConvGemm.a_bound) instead of
+    the fixed guess 16.  For tensors that are NOT followed by a GroupNorm (the inputs of Downsample / Upsample); a
+    GroupNorm over x leaves the bound as a by-product (groupnorm(..., bound=slot)).  None when x carries no partials."""
+    segs = stats_segments(x)
+    if slot is None or segs is None or not _sw("DYN_SCALE") or x.shape[-1] % groups:
+        return None
+    nb = x.shape[0]
+    m, c, _ = rows_ld(x, "x")
+    L.check(L.load().cs_groupnorm_finalize_parts(_seg_array(segs), len(segs), nb, m // nb, c, groups, 1e-5, None,
+                                                 slot.data_ptr(), _stream()), "cs_groupnorm_finalize_parts")
+    x.cs_bound = slot
+    return slot
+
+
+def groupnorm_stats_from_parts(segs, nb: int, rows: int, c: int, groups: int, eps: float, device,
+                               bound: Optional[Tensor] = None) -> Tensor:
+    """(mean, rstd) [nb, groups, 2] from the producers' partials (cs_groupnorm_finalize_parts): no pass over the tensor.
+    bound: a zeroed 1-element slot that receives the tensor's magnitude bound (see range_bound)."""
     arr = _seg_array(segs)
     stats = torch.empty((nb, groups, 2), dtype=torch.float32, device=device)
-    L.check(L.load().cs_groupnorm_finalize_parts(arr, len(segs), nb, rows, c, groups, eps, stats.data_ptr(), _stream()),
-            "cs_groupnorm_finalize_parts")
+    L.check(L.load().cs_groupnorm_finalize_parts(arr, len(segs), nb, rows, c, groups, eps, stats.data_ptr(), _ptr(bound),
+                                                 _stream()), "cs_groupnorm_finalize_parts")
     return stats
 
 
-def _epilogue_extras(lib, p, x_dev, nb: int, rps: int, m_tiles_rows: int, cout: int, want_stats: bool,
+def _epilogue_extras(lib, p, x_dev, nb: int, rps: int, m_tiles_rows: int, cout: int, want_stats,
                      out_pair: Optional[float], ncls: int = 1):
     """Ask the library what this launch's epilogue can emit (cs_conv_gemm_epilogue_caps -- the one rule) and set the
     descriptor up for it.  Returns (ColStats | None, pair_taken: bool).  rps = rows per sample the statistics tiles run
     over (the source rows for a folded Upsample conv), m_tiles_rows = the rows those tiles cover in all."""
-    if not (want_stats and _sw("GN_PARTS")) and out_pair is None:
+    want = bool(want_stats)
+    if not (want and _sw("GN_PARTS")) and out_pair is None:
         return None, False
     rows, pair = C.c_int32(0), C.c_int32(0)
     L.check(lib.cs_conv_gemm_epilogue_caps(C.byref(p), C.byref(rows), C.byref(pair)), "cs_conv_gemm_epilogue_caps")
     st = None
-    if want_stats and _sw("GN_PARTS") and rows.value > 0:
+    if want and _sw("GN_PARTS") and rows.value > 0:
         tiles = (m_tiles_rows + rows.value - 1) // rows.value
         part = torch.empty((ncls * tiles, cout, 2), dtype=torch.float64, device=x_dev)
         p.gn_part, p.gn_ld, p.gn_rows = part.data_ptr(), cout, rows.value
@@ -424,7 +446,7 @@ def conv_gemm(x: Tensor, w: PackedWeight, *, spatial: Optional[Tuple[int, int, i
               scale: Optional[Tensor] = None, shift: Optional[Tensor] = None,
               out: Optional[Tensor] = None, tile: int = 0, math: int = L.MATH_FP32,
               splitk: Optional[int] = None, out_fn=None, a_scale: Optional[float] = None,
-              stats: bool = False, out_pair: Optional[float] = None):
+              stats: bool = False, out_pair: Optional[float] = None, x_bound: Optional[Tensor] = None):
     """Conv3d (k in {1,3}, pad k//2) / Linear.  x: [nb,d,h,w,c] (conv) or [..., c] rows (linear).
 
     `spatial=(nb,d,h,w)` lets a row matrix be interpreted as a volume without reshaping.
@@ -432,6 +454,8 @@ def conv_gemm(x: Tensor, w: PackedWeight, *, spatial: Optional[Tuple[int, int, i
     leaves per-(row tile, column) partial sums and the returned tensor carries them as `.cs_stats` (ColStats).
     `out_pair=s` -- the result's only reader is the next F16X3 GEMM: where the launch can, it is written as the
     interleaved operand pair of out * s and a Pair16 is returned instead of a tensor.
+    `x_bound=slot` (x.cs_bound, see range_bound) -- x is a RAW activation with a known magnitude bound: the kernel derives
+    the operand scale from it (no fixed guess, no overflow possible).
     """
     if w.tapcol is not None:
         if (tuple(stride) != (1, 1, 1) or tuple(up) != (0, 0, 0) or act != L.ACT_NONE or rowvec is not None
@@ -543,6 +567,8 @@ def conv_gemm(x: Tensor, w: PackedWeight, *, spatial: Optional[Tuple[int, int, i
     p.pd, p.ph, p.pw = pd, ph, pw
     p.ud, p.uh, p.uw = up
     p.act, p.rv_rows, p.math, p.tile = act, rv_rows, math, tile
+    if x_bound is not None and math == L.MATH_F16X3 and xs is None and xp is None and _sw("DYN_SCALE"):
+        p.a_bound = x_bound.data_ptr()
     lib = L.load()
     if folded:
         st, _ = _epilogue_extras(lib, p, x.device, nb, d * h * wd, m, w.cout, stats, None, ncls=len(w.classes))
@@ -679,11 +705,13 @@ class Pair16:
 
 
 def groupnorm(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float, act: int = L.ACT_NONE,
-              out: Optional[Tensor] = None, split16: bool = False, a_scale: Optional[float] = None):
+              out: Optional[Tensor] = None, split16: bool = False, a_scale: Optional[float] = None,
+              bound: Optional[Tensor] = None):
     """GroupNorm over [nb, ..., c] (stats per sample & group), fused activation.
     split16=True returns a Split16 (fp16 hi/lo pair, pre-scaled) for an F16X3 GEMM to consume.
     r4: when x carries its producers' partial sums (stats_segments) the statistics come from them -- one tiny launch
-    instead of a pass over the tensor -- and the tensor is read once, by the apply kernel."""
+    instead of a pass over the tensor -- and the tensor is read once, by the apply kernel.  bound: a zeroed 1-element slot;
+    on that route the finalize kernel also leaves x's magnitude bound there and x remembers it (`x.cs_bound`, range_bound)."""
     _chk(x, "x")
     nb = x.shape[0]
     m, c, ldx = rows_ld(x, "x")
@@ -698,12 +726,20 @@ def groupnorm(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float, a
         if om != m or oc != c:
             raise L.CsError("groupnorm out shape mismatch")
         stats = torch.empty((nb, groups, 2), dtype=torch.float32, device=x.device)
+        if not _sw("DYN_SCALE"):
+            bound = None
         L.check(lib.cs_groupnorm_parts(x.data_ptr(), _seg_array(segs), len(segs), gamma.data_ptr(), beta.data_ptr(),
-                                       out.data_ptr(), nb, rows, c, ldx, ldy, groups, eps, act, stats.data_ptr(), _stream()),
-                "cs_groupnorm_parts")
+                                       out.data_ptr(), nb, rows, c, ldx, ldy, groups, eps, act, stats.data_ptr(),
+                                       _ptr(bound), _stream()), "cs_groupnorm_parts")
+        if bound is not None:
+            x.cs_bound = bound
         return out
     if segs is not None:
-        stats = groupnorm_stats_from_parts(segs, nb, rows, c, groups, eps, x.device)
+        if not _sw("DYN_SCALE"):
+            bound = None
+        stats = groupnorm_stats_from_parts(segs, nb, rows, c, groups, eps, x.device, bound)
+        if bound is not None:
+            x.cs_bound = bound
         if split16 and _sw("SPLIT16_PRODUCERS"):
             yh = torch.empty(x.shape, dtype=torch.float16, device=x.device)
             yl = torch.empty(x.shape, dtype=torch.float16, device=x.device)
@@ -745,7 +781,7 @@ def groupnorm(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float, a
     return out
 
 
-def groupnorm_stats(x: Tensor, groups: int, eps: float) -> Tensor:
+def groupnorm_stats(x: Tensor, groups: int, eps: float, bound: Optional[Tensor] = None) -> Tensor:
     """(mean, rstd) per (sample, group) of a channels-last tensor: [nb, groups, 2] fp32 (fp64 accumulation)."""
     _chk(x, "x")
     nb = x.shape[0]
@@ -753,7 +789,11 @@ def groupnorm_stats(x: Tensor, groups: int, eps: float) -> Tensor:
     lib = L.load()
     segs = stats_segments(x)
     if segs is not None:
-        return groupnorm_stats_from_parts(segs, nb, m // nb, c, groups, eps, x.device)
+        if bound is not None and _sw("DYN_SCALE"):
+            x.cs_bound = bound
+        else:
+            bound = None
+        return groupnorm_stats_from_parts(segs, nb, m // nb, c, groups, eps, x.device, bound)
     ws = torch.empty(lib.cs_groupnorm_ws_bytes(nb, groups) // 8, dtype=torch.float64, device=x.device)
     stats = torch.empty((nb, groups, 2), dtype=torch.float32, device=x.device)
     L.check(lib.cs_groupnorm_stats(x.data_ptr(), nb, m // nb, c, ldx, groups, eps, ws.data_ptr(), stats.data_ptr(),

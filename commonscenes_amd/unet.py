@@ -195,10 +195,20 @@ class DiffusionUNet:
         self.math = L.DEFAULT_MATH      # F16X3 unless CS_MATH=fp32
         self.attn_math: Optional[int] = None        # None: follow self.math; L.MATH_F16: plain-fp16 attention (opt-in)
         self.trace: Optional[Dict[str, Tensor]] = None   # set to {} to capture per-block outputs (tests)
-        self.split_min_rows: Optional[int] = None      # see _pack: channel-split ResBlocks; None = the library's threshold
-        # (CsDebug.cfg_split_min_rows, CS_CFG_SPLIT_MIN_ROWS, default 65536 -- the same number the native driver reads)
+        self._split_min_rows: Optional[int] = None     # see the split_min_rows property
         self._split_info: Dict[str, Tuple[int, int]] = {}
         self._ngb: Dict[str, Tuple[float, float]] = {}
+
+    @property
+    def split_min_rows(self) -> int:
+        """Channel-split ResBlocks (see _pack) are taken from this many rows of the concatenation.  Unless assigned, the
+        library's threshold: CsDebug.cfg_split_min_rows (CS_CFG_SPLIT_MIN_ROWS, default 65536) -- the number the native
+        driver reads too."""
+        return self._split_min_rows if self._split_min_rows is not None else int(L.debug().cfg_split_min_rows)
+
+    @split_min_rows.setter
+    def split_min_rows(self, v) -> None:
+        self._split_min_rows = None if v is None else int(v)
 
     # ---- nn.Module-like surface -----------------------------------------------------------
     def state_dict(self) -> "OrderedDict[str, Tensor]":
@@ -423,14 +433,25 @@ class DiffusionUNet:
         gb = self._ngb.get(norm)
         return ops.norm_a_scale(gb[0], gb[1], n) if gb is not None else None
 
+    def _slot(self):
+        """a fresh 1-element slot of this forward's arena (zeroed once in forward_ndhwc) for the magnitude bound of a RAW
+        residual-stream tensor (ops.range_bound / groupnorm(bound=)); None when the feature is off"""
+        a = getattr(self, "_amax", None)
+        if a is None or self._amax_i >= a.numel():
+            return None
+        self._amax_i += 1
+        return a[self._amax_i - 1:self._amax_i]
+
     def _res(self, p: str, l: dict, x: Tensor, semb: Tensor, out_fn=None) -> Tensor:
         sd, pk = self._sd, self._packed
         nb = x.shape[0]
         rows = x.shape[1] * x.shape[2] * x.shape[3]
         # GN output goes straight to a conv: emit its fp16 hi/lo operand form where that conv runs the slab kernel
         s1 = self._nas(p + ".in_layers.0", rows * (l["cin"] // 32))
+        # (bound=: the skip conv below reads x RAW -- the GroupNorm's finalize kernel leaves x's magnitude bound on the way)
         hn = ops.groupnorm(x, sd[p + ".in_layers.0.weight"], sd[p + ".in_layers.0.bias"], 32, 1e-5, L.ACT_SILU,
-                           split16=ops.wants_split16(nb * rows, pk[p + ".in_layers.2"]), a_scale=s1)
+                           split16=ops.wants_split16(nb * rows, pk[p + ".in_layers.2"]), a_scale=s1,
+                           bound=self._slot() if l["cin"] != l["cout"] else None)
         lo, hi = self._emb_slices[p]
         embo = semb[:, lo:hi]                         # slice of the batched emb projection (row stride = total)
         # (stats=True: the conv's epilogue leaves the partial sums the next GroupNorm takes its statistics from, r4)
@@ -438,7 +459,9 @@ class DiffusionUNet:
         s2 = self._nas(p + ".out_layers.0", rows * (l["cout"] // 32))
         hn2 = ops.groupnorm(h, sd[p + ".out_layers.0.weight"], sd[p + ".out_layers.0.bias"], 32, 1e-5, L.ACT_SILU,
                             split16=ops.wants_split16(nb * rows, pk[p + ".out_layers.3"]), a_scale=s2)
-        skip = x if l["cin"] == l["cout"] else ops.conv_gemm(x, pk[p + ".skip_connection"], math=self.math)
+        # (x_bound: the skip conv reads the RAW residual stream -- its operand scale follows the tensor's actual range)
+        skip = x if l["cin"] == l["cout"] else ops.conv_gemm(x, pk[p + ".skip_connection"], math=self.math,
+                                                             x_bound=getattr(x, "cs_bound", None))
         return ops.conv_gemm(hn2, pk[p + ".out_layers.3"], res=skip, math=self.math, out_fn=out_fn, a_scale=s2,
                              stats=True)
 
@@ -459,7 +482,7 @@ class DiffusionUNet:
             raise L.CsError("channel-split ResBlock: skip tensor does not match the concatenation")
         gam, bet = sd[p + ".in_layers.0.weight"], sd[p + ".in_layers.0.bias"]
         wh, ws = pk[p + ".in_layers.2:h"], pk[p + ".in_layers.2:s"]
-        stats = ops.groupnorm_stats(x, 32, 1e-5)
+        stats = ops.groupnorm_stats(x, 32, 1e-5, bound=self._slot())
         s1 = self._nas(p + ".in_layers.0", rows * cpg)
         a_h = ops.groupnorm_apply_range(x[..., :ks], stats, gam[:ks], bet[:ks], cpg, 0, L.ACT_SILU,
                                         split16=ops.wants_split16(nbs * rows, wh), a_scale=s1)
@@ -474,11 +497,12 @@ class DiffusionUNet:
             ops.conv_gemm(a_h[sl], wh, rowvec=semb[sl, lo:hi], rv_rows=rows, res=y_s, out=h1[sl], math=self.math,
                           a_scale=s1)
         # (the two launches write sample ranges of h1: its GroupNorm takes its statistics from a pass over the tensor)
-        sk = ops.conv_gemm(x, pk[p + ".skip_connection"], math=self.math)
+        sk = ops.conv_gemm(x, pk[p + ".skip_connection"], math=self.math, x_bound=getattr(x, "cs_bound", None))
         s2 = self._nas(p + ".out_layers.0", rows * (cout // 32))
         hn2 = ops.groupnorm(h1, sd[p + ".out_layers.0.weight"], sd[p + ".out_layers.0.bias"], 32, 1e-5, L.ACT_SILU,
                             split16=ops.wants_split16(nb * rows, pk[p + ".out_layers.3"]), a_scale=s2)
-        return ops.conv_gemm(hn2, pk[p + ".out_layers.3"], res=sk, math=self.math, out_fn=out_fn, a_scale=s2, stats=True)
+        return ops.conv_gemm(hn2, pk[p + ".out_layers.3"], res=sk, math=self.math, out_fn=out_fn, a_scale=s2,
+                             stats=True)
 
     def _context_vectors(self, ctx: Tensor):
         """One-token context: every transformer block's cross-attention output is the per-sample
@@ -586,10 +610,12 @@ class DiffusionUNet:
                 h = (self._attn(p, l, h, ctx, of) if self.cfg["use_spatial_transformer"]
                      else self._attnblock(p, l, h, of))
             elif k == "down":      # dims == 3: inner two dims only (openai_model_3d.py:188); dims == 4: all three
+                # (Down / Upsample read the RAW stream with no GroupNorm in front: its bound from the producers' partials)
                 h = ops.conv_gemm(h, pk[p + ".op"], stride=(1, 2, 2) if self.cfg["dims"] == 3 else (2, 2, 2),
-                                  math=self.math, out_fn=of, stats=True)
+                                  math=self.math, out_fn=of, stats=True, x_bound=ops.range_bound(h, self._slot()))
             elif k == "up":        # nearest x2 folded into the conv's addressing (openai_model_3d.py:148-157)
-                h = ops.conv_gemm(h, pk[p + ".conv"], up=self._up, math=self.math, out_fn=of, stats=True)
+                h = ops.conv_gemm(h, pk[p + ".conv"], up=self._up, math=self.math, out_fn=of, stats=True,
+                                  x_bound=ops.range_bound(h, self._slot()))
         return h
 
     @torch.no_grad()
@@ -605,6 +631,10 @@ class DiffusionUNet:
             self._pack()
         sd, pk, P = self._sd, self._packed, self.prefix
         inp, mid, out = self._blocks
+        # magnitude-bound slots of this forward (one per raw-stream consumer; one memset): see _slot / ops.range_bound
+        self._amax = (torch.zeros(64, dtype=torch.float32, device=h.device)
+                      if self.math == L.MATH_F16X3 and ops._sw("DYN_SCALE") and ops._sw("GN_PARTS") else None)
+        self._amax_i = 0
         temb = ops.timestep_embedding(t, self.cfg["model_channels"])
         e1 = ops.linear(temb, pk[P + "time_embed.0"], act=L.ACT_SILU, math=self.math)
         # every consumer of `emb` is emb_layers = SiLU -> Linear (openai_model_3d.py:257-263): keep SiLU(emb)
@@ -623,7 +653,7 @@ class DiffusionUNet:
         cats: List[Optional[Tensor]] = [None] * nout
         nocopy = not L.debug().concat_copy                                   # A/B switch: the copying form
         # r4: the partial sums each half's producer left for the GroupNorm of output block j (ops.ColStats or None)
-        split_min_rows = self.split_min_rows if self.split_min_rows is not None else int(L.debug().cfg_split_min_rows)
+        split_min_rows = self.split_min_rows
         seg_l: List[Optional[object]] = [None] * nout
         seg_r: List[Optional[object]] = [None] * nout
 

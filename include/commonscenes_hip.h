@@ -87,6 +87,8 @@ typedef struct CsDebug {
   int32_t slice_tile2;        /* K-sliced slab convs on the 128-row tile */
   int32_t no_gn_parts;        /* GroupNorm statistics always from a pass over the tensor (r4) */
   int32_t no_pair_epilogue;   /* GEMM epilogues always write fp32 (r4) */
+  int32_t no_dyn_scale;       /* raw-activation consumers keep the fixed operand scale 16 + overflow flag (r4) */
+  int32_t reserved0;
   int64_t split16_min_rows;   /* pre-split operands on the 128-row slab tile from this many rows (8192; 0 = never) */
   int64_t cfg_split_min_rows; /* channel-split ResBlocks from this many rows (65536) */
   int64_t gn_small_group;     /* single-launch GroupNorm up to this many elements per (sample, group) (11264) */
@@ -191,6 +193,16 @@ typedef struct CsConvGemm {
   int32_t gn_rows;
   int32_t out_format;
   float out_scale;
+  /*   a_bound != NULL (a_format = 0 only): the operand scale is taken from a BOUND on the tensor's magnitude instead of
+   *     a_scale -- the kernel reads *a_bound (device float: max over the tensor's (sample, group) statistics of
+   *     |mean| + std * sqrt(n - 1) >= max |x| by Samuelson's inequality, left by cs_groupnorm_finalize_parts /
+   *     cs_groupnorm_parts, which have every group's mean and variance in hand anyway) and uses the largest power of two s
+   *     with bound * s <= 65000 (clamped to [2^-8, 2^40]); acc_scale must be given for a_scale as usual, the kernel
+   *     rescales it by the exact power of two.  For the consumers of RAW activations -- the residual stream read by
+   *     skip_connection / Downsample / Upsample (openai_model_3d.py:146-199, 307-313) has no producer-side bound -- this
+   *     replaces the fixed guess 16 and the CS_STATUS_F16X3_OVERFLOW detect-and-rerun cliff: no activation magnitude can
+   *     leave the fp16 range, and a tensor of any scale keeps the same relative precision. */
+  const float* a_bound;
 } CsConvGemm;
 
 int cs_conv_gemm(const CsConvGemm* desc, cs_stream_t stream);
@@ -316,7 +328,10 @@ int cs_groupnorm(const float* x, const float* gamma, const float* beta, float* y
  * that one copy serves for both classifier-free-guidance halves is described by nb_src < nb (sample n reads the
  * partials of sample n % nb_src).  One wave per (sample, group) adds the group's partials in a fixed order (lanes
  * stride over the tiles of one channel after the other, then a butterfly): bit-reproducible, fp64 throughout, the same
- * mean / rstd expressions as cs_groupnorm_stats.  `stats`: [nb][groups][2] as for cs_groupnorm_apply*. */
+ * mean / rstd expressions as cs_groupnorm_stats.  `stats`: [nb][groups][2] as for cs_groupnorm_apply* (NULL: not wanted).
+ * `bound` (NULL or a device float the caller zeroed): receives max over (sample, group) of |mean| + std * sqrt(n - 1), an
+ * upper bound of max |x| over the whole tensor (Samuelson) -- what CsConvGemm.a_bound reads; an atomic max of the value's
+ * bits, order-independent. */
 typedef struct CsGnSeg {
   const double* part;        /* [tiles][ld][2] (sum, sum of squares) */
   int32_t ld;                /* columns per tile of `part` */
@@ -330,13 +345,13 @@ typedef struct CsGnSeg {
   int32_t reserved;
 } CsGnSeg;
 int cs_groupnorm_finalize_parts(const CsGnSeg* segs, int nseg, int nb, int rows, int c, int groups, float eps,
-                                float* stats, cs_stream_t stream);
+                                float* stats, float* bound, cs_stream_t stream);
 /* ... and the whole GroupNorm (+ activation) from them in one call, the counterpart of cs_groupnorm: ONE launch for small
  * tensors (the same size rule: one workgroup per (sample, group) adds the group's partials and makes a single sweep over
  * it), cs_groupnorm_finalize_parts + cs_groupnorm_apply otherwise.  `stats` is written either way. */
 int cs_groupnorm_parts(const float* x, const CsGnSeg* segs, int nseg, const float* gamma, const float* beta, float* y,
                        int nb, int rows, int c, int ldx, int ldy, int groups, float eps, int act, float* stats,
-                       cs_stream_t stream);
+                       float* bound, cs_stream_t stream);
 /* SURVEY name: cs_groupnorm with a SiLU epilogue. */
 int cs_groupnorm_silu_ndhwc(const float* x, const float* gamma, const float* beta, float* y,
                             int nb, int rows, int c, int groups, float eps, void* ws, float* stats,

@@ -43,9 +43,9 @@ def test_struct_layout_matches_header():
             continue
         decl = line.split(None, 2) if line.startswith("const") else line.split(None, 1)
         for n in decl[-1].split(","):
-            names.append(n.strip().lstrip("*").strip())
+            names.append(n.strip().lstrip("*").strip().split("[")[0])      # (array fields: `a_amax[2]` -> a_amax)
     assert names == [f[0] for f in lib.CsConvGemm._fields_]
-    assert ctypes.sizeof(lib.CsConvGemm) == 13 * 8 + 35 * 4 + 3 * 4
+    assert ctypes.sizeof(lib.CsConvGemm) == 14 * 8 + 35 * 4 + 3 * 4
 
 
 def test_missing_library_fails_loudly(tmp_path):
