@@ -868,15 +868,32 @@ struct ExecBase {
   // ops.py::range_bound: the magnitude bound of a RAW tensor that no GroupNorm follows, from its producers' partials, into
   // a fresh slot; -1 when x carries none (the consumer then keeps the fixed scale)
   int64_t range_bound(const Buf& x, int nb, int groups = 32) {
-    if (!has_parts(x) || x.c % groups) return -1;
+    if (x.c % groups) return -1;
     const int64_t off = amax_slot();
     if (off < 0) return -1;
-    if (ok() && !dry) {
-      CsGnSeg sg[2];
-      seg_array(x, sg);
-      chk(cs_groupnorm_finalize_parts(sg, x.nseg, nb, (int)(x.rows / nb), x.c, groups, 1e-5f, nullptr, bound_ptr(off), st));
+    if (has_parts(x)) {
+      if (ok() && !dry) {
+        CsGnSeg sg[2];
+        seg_array(x, sg);
+        chk(cs_groupnorm_finalize_parts(sg, x.nseg, nb, (int)(x.rows / nb), x.c, groups, 1e-5f, nullptr, bound_ptr(off), st));
+      }
+      return off;
     }
+    // no partials (e.g. a folded Upsample conv at a small batch): one statistics pass over the (small) tensor
+    Buf wsb = alloc((cs_groupnorm_ws_bytes(nb, groups) + 3) / 4, 1);
+    Buf stats = alloc((int64_t)nb * groups * 2, 1);
+    if (ok() && !dry)
+      chk(cs_groupnorm_stats_bound(p(x), nb, (int)(x.rows / nb), x.c, x.c, groups, 1e-5f, p(wsb), p(stats), bound_ptr(off), st));
+    release(wsb);
+    release(stats);
     return off;
+  }
+  // the statistics pass of a tensor without partials; leaves the magnitude bound too when a slot is given
+  void stats_pass(const Buf& x, int nb, float eps, int groups, const Buf& wsb, const Buf& stats, int64_t boff) {
+    if (!ok() || dry) return;
+    const int rows = (int)(x.rows / nb);
+    chk(boff >= 0 ? cs_groupnorm_stats_bound(p(x), nb, rows, x.c, x.c, groups, eps, p(wsb), p(stats), bound_ptr(boff), st)
+                  : cs_groupnorm_stats(p(x), nb, rows, x.c, x.c, groups, eps, p(wsb), p(stats), st));
   }
 
   // bound_off (out): the slot x's magnitude bound went to (-1: none -- x carries no partials or the feature is off)
@@ -891,7 +908,9 @@ struct ExecBase {
     }
     Buf wsb = alloc((cs_groupnorm_ws_bytes(nb, groups) + 3) / 4, 1);
     Buf stats = alloc((int64_t)nb * groups * 2, 1);
-    if (ok() && !dry) chk(cs_groupnorm_stats(p(x), nb, (int)(x.rows / nb), x.c, x.c, groups, eps, p(wsb), p(stats), st));
+    const int64_t off = bound_off ? amax_slot() : -1;
+    if (bound_off) *bound_off = off;
+    stats_pass(x, nb, eps, groups, wsb, stats, off);
     release(wsb);
     return stats;
   }
@@ -982,12 +1001,14 @@ struct ExecBase {
     }
     Buf wsb = alloc((cs_groupnorm_ws_bytes(nb, groups) + 3) / 4, 1);
     Buf stats = alloc((int64_t)nb * groups * 2, 1);
+    const int64_t boff = bound_off ? amax_slot() : -1;
+    if (bound_off) *bound_off = boff;
     if (pl.math == CS_MATH_F16X3) y.a_scale = norm_a_scale(n.gmax, n.bmax, (x.rows / nb) * (int64_t)(x.c / groups));
     if (wants_split16(x.rows, conv_gi)) {
       y.half = true;
+      stats_pass(x, nb, eps, groups, wsb, stats, boff);
       if (ok() && !dry) {
         const int rows = (int)(x.rows / nb);
-        chk(cs_groupnorm_stats(p(x), nb, rows, x.c, x.c, groups, eps, p(wsb), p(stats), st));
         char* yh = reinterpret_cast<char*>(p(y));
         chk(cs_groupnorm_apply_split16(p(x), p(stats), wf(n.g_off), wf(n.b_off), yh, yh + x.rows * x.c * 2, nb, rows, x.c,
                                        x.c, x.c, groups, act, y.a_scale, status, st));
@@ -996,7 +1017,12 @@ struct ExecBase {
       release(stats);
       return y;
     }
-    if (ok() && !dry) {
+    if (boff >= 0) {       // bound wanted: statistics (+ bound) and apply as two launches (ops.py::groupnorm)
+      stats_pass(x, nb, eps, groups, wsb, stats, boff);
+      if (ok() && !dry)
+        chk(cs_groupnorm_apply(p(x), p(stats), wf(n.g_off), wf(n.b_off), p(y), nb, (int)(x.rows / nb), x.c, x.c, x.c, groups,
+                               act, st));
+    } else if (ok() && !dry) {
       const int rows = (int)(x.rows / nb);
       chk(cs_groupnorm(p(x), wf(n.g_off), wf(n.b_off), p(y), nb, rows, x.c, x.c, x.c, groups, eps, act, p(wsb), p(stats), st));
     }

@@ -77,9 +77,11 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
 // One wave per (sample, group): lanes take the row-slice partials in a strided fashion and a fixed butterfly
 // combines them, so the result does not depend on scheduling (the serial version walked up to 256 dependent
 // loads per thread: 17-27 us for what is a few KB of data).
+__device__ __forceinline__ void gn_bound_max(float* bound, double mean, double var, double count);
+
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ partial, int nsplit, int groups,
                                                           double count, float eps, float* __restrict__ stats,
-                                                          int total) {
+                                                          int total, float* __restrict__ bound = nullptr) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);  // n*groups + g
   if (i >= total) return;
@@ -101,6 +103,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
     if (var < 0) var = 0;
     stats[2 * i] = (float)mean;
     stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    if (bound) gn_bound_max(bound, mean, var, count);
   }
 }
 
@@ -641,8 +644,24 @@ extern "C" int cs_groupnorm_parts(const float* x, const CsGnSeg* segs, int nseg,
   return cs_groupnorm_apply(x, stats, gamma, beta, y, nb, rows, c, ldx, ldy, groups, act, stream);
 }
 
+static int gn_stats_impl(const float* x, int nb, int rows, int c, int ldx, int groups, float eps, void* ws, float* stats,
+                         float* bound, cs_stream_t stream);
+
 extern "C" int cs_groupnorm_stats(const float* x, int nb, int rows, int c, int ldx, int groups,
                                   float eps, void* ws, float* stats, cs_stream_t stream) {
+  return gn_stats_impl(x, nb, rows, c, ldx, groups, eps, ws, stats, nullptr, stream);
+}
+
+// cs_groupnorm_stats that also leaves the tensor's magnitude bound (max over (sample, group) of |mean| + std sqrt(n - 1),
+// see cs_groupnorm_finalize_parts) in `bound`: for a tensor whose producers left no partial sums (r4)
+extern "C" int cs_groupnorm_stats_bound(const float* x, int nb, int rows, int c, int ldx, int groups, float eps, void* ws,
+                                        float* stats, float* bound, cs_stream_t stream) {
+  if (!bound || ((uintptr_t)bound & 3)) return CS_EINVAL;
+  return gn_stats_impl(x, nb, rows, c, ldx, groups, eps, ws, stats, bound, stream);
+}
+
+static int gn_stats_impl(const float* x, int nb, int rows, int c, int ldx, int groups, float eps, void* ws, float* stats,
+                         float* bound, cs_stream_t stream) {
   if (!x || !ws || !stats || nb <= 0 || rows <= 0 || c <= 0 || groups <= 0) return CS_EINVAL;
   if ((c & 3) || (ldx & 3) || ldx < c || c % groups || groups > 256) return CS_EINVAL;
   if (((uintptr_t)x & 15) || ((uintptr_t)ws & 7)) return CS_EINVAL;
@@ -660,7 +679,7 @@ extern "C" int cs_groupnorm_stats(const float* x, int nb, int rows, int c, int l
   const int total = nb * groups;
   CS_LAUNCH(gn_finalize_kernel, dim3((total + 3) / 4), dim3(256), 0, s,
                      (const double*)ws, nsplit, groups, (double)rows * (c / groups), eps, stats,
-                     total);
+                     total, bound);
   CS_CHECK_LAUNCH();
   return CS_OK;
 }

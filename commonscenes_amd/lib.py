@@ -120,6 +120,7 @@ SIGNATURES = {
     "cs_tapsum27": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),
     "cs_groupnorm_ws_bytes": (_l, [_i, _i]),
     "cs_groupnorm_stats": (_i, [_f, _i, _i, _i, _i, _i, _fl, _f, _f, _s]),
+    "cs_groupnorm_stats_bound": (_i, [_f, _i, _i, _i, _i, _i, _fl, _f, _f, _f, _s]),
     "cs_groupnorm_apply": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),
     "cs_groupnorm_apply_split16": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _fl, _f, _s]),
     "cs_layernorm_pair16": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _fl, _fl, _f, _s]),

@@ -395,13 +395,20 @@ def range_bound(x: Tensor, slot: Optional[Tensor], groups: int = 32) -> Optional
     conv_gemm(x_bound=): its F16X3 operand scale then follows the tensor's actual range (CsConvGemm.a_bound) instead of
     the fixed guess 16.  For tensors that are NOT followed by a GroupNorm (the inputs of Downsample / Upsample); a
     GroupNorm over x leaves the bound as a by-product (groupnorm(..., bound=slot)).  None when x carries no partials."""
-    segs = stats_segments(x)
-    if slot is None or segs is None or not _sw("DYN_SCALE") or x.shape[-1] % groups:
+    if slot is None or not _sw("DYN_SCALE") or x.shape[-1] % groups:
         return None
+    segs = stats_segments(x)
     nb = x.shape[0]
-    m, c, _ = rows_ld(x, "x")
-    L.check(L.load().cs_groupnorm_finalize_parts(_seg_array(segs), len(segs), nb, m // nb, c, groups, 1e-5, None,
-                                                 slot.data_ptr(), _stream()), "cs_groupnorm_finalize_parts")
+    m, c, ldx = rows_ld(x, "x")
+    lib = L.load()
+    if segs is not None:
+        L.check(lib.cs_groupnorm_finalize_parts(_seg_array(segs), len(segs), nb, m // nb, c, groups, 1e-5, None,
+                                                slot.data_ptr(), _stream()), "cs_groupnorm_finalize_parts")
+    else:       # no partials (e.g. a folded Upsample conv at a small batch): one statistics pass over the (small) tensor
+        ws = torch.empty(lib.cs_groupnorm_ws_bytes(nb, groups) // 8, dtype=torch.float64, device=x.device)
+        st = torch.empty((nb, groups, 2), dtype=torch.float32, device=x.device)
+        L.check(lib.cs_groupnorm_stats_bound(x.data_ptr(), nb, m // nb, c, ldx, groups, 1e-5, ws.data_ptr(), st.data_ptr(),
+                                             slot.data_ptr(), _stream()), "cs_groupnorm_stats_bound")
     x.cs_bound = slot
     return slot
 
@@ -759,9 +766,18 @@ def groupnorm(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float, a
         return out
     ws = torch.empty(lib.cs_groupnorm_ws_bytes(nb, groups) // 8, dtype=torch.float64, device=x.device)
     stats = torch.empty((nb, groups, 2), dtype=torch.float32, device=x.device)
+    want_bound = bound is not None and _sw("DYN_SCALE")
+
+    def _stats():
+        if want_bound:      # no partials on x: the statistics pass leaves the magnitude bound beside (mean, rstd)
+            L.check(lib.cs_groupnorm_stats_bound(x.data_ptr(), nb, rows, c, ldx, groups, eps, ws.data_ptr(), stats.data_ptr(),
+                                                 bound.data_ptr(), _stream()), "cs_groupnorm_stats_bound")
+            x.cs_bound = bound
+        else:
+            L.check(lib.cs_groupnorm_stats(x.data_ptr(), nb, rows, c, ldx, groups, eps, ws.data_ptr(),
+                                           stats.data_ptr(), _stream()), "cs_groupnorm_stats")
     if split16 and _sw("SPLIT16_PRODUCERS"):
-        L.check(lib.cs_groupnorm_stats(x.data_ptr(), nb, rows, c, ldx, groups, eps, ws.data_ptr(),
-                                       stats.data_ptr(), _stream()), "cs_groupnorm_stats")
+        _stats()
         yh = torch.empty(x.shape, dtype=torch.float16, device=x.device)
         yl = torch.empty(x.shape, dtype=torch.float16, device=x.device)
         a_sc = float(a_scale or A_SCALE)
@@ -775,6 +791,11 @@ def groupnorm(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float, a
     om, oc, ldy = rows_ld(out, "out")
     if om != m or oc != c:
         raise L.CsError("groupnorm out shape mismatch")
+    if want_bound:
+        _stats()
+        L.check(lib.cs_groupnorm_apply(x.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(),
+                                       nb, rows, c, ldx, ldy, groups, act, _stream()), "cs_groupnorm_apply")
+        return out
     # one launch for small tensors (one or two objects), statistics + apply otherwise: cs_groupnorm decides
     L.check(lib.cs_groupnorm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), nb, rows, c, ldx, ldy,
                              groups, eps, act, ws.data_ptr(), stats.data_ptr(), _stream()), "cs_groupnorm")
@@ -796,6 +817,11 @@ def groupnorm_stats(x: Tensor, groups: int, eps: float, bound: Optional[Tensor] 
         return groupnorm_stats_from_parts(segs, nb, m // nb, c, groups, eps, x.device, bound)
     ws = torch.empty(lib.cs_groupnorm_ws_bytes(nb, groups) // 8, dtype=torch.float64, device=x.device)
     stats = torch.empty((nb, groups, 2), dtype=torch.float32, device=x.device)
+    if bound is not None and _sw("DYN_SCALE"):
+        L.check(lib.cs_groupnorm_stats_bound(x.data_ptr(), nb, m // nb, c, ldx, groups, eps, ws.data_ptr(), stats.data_ptr(),
+                                             bound.data_ptr(), _stream()), "cs_groupnorm_stats_bound")
+        x.cs_bound = bound
+        return stats
     L.check(lib.cs_groupnorm_stats(x.data_ptr(), nb, m // nb, c, ldx, groups, eps, ws.data_ptr(), stats.data_ptr(),
                                    _stream()), "cs_groupnorm_stats")
     return stats

@@ -296,6 +296,9 @@ int cs_tapsum27(const float* y, const float* bias, float* out, int nb, int d, in
 int64_t cs_groupnorm_ws_bytes(int nb, int groups);
 int cs_groupnorm_stats(const float* x, int nb, int rows, int c, int ldx, int groups, float eps,
                        void* ws, float* stats, cs_stream_t stream);
+/* (ABI 14) ... and the tensor's magnitude bound beside the statistics: see cs_groupnorm_finalize_parts / CsConvGemm.a_bound */
+int cs_groupnorm_stats_bound(const float* x, int nb, int rows, int c, int ldx, int groups, float eps, void* ws,
+                             float* stats, float* bound, cs_stream_t stream);
 int cs_groupnorm_apply(const float* x, const float* stats, const float* gamma, const float* beta,
                        float* y, int nb, int rows, int c, int ldx, int ldy, int groups, int act,
                        cs_stream_t stream);

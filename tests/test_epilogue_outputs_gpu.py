@@ -191,10 +191,16 @@ def test_unet_takes_its_groupnorm_statistics_from_the_producers(monkeypatch):
         def __call__(self, *a):
             calls[self.key] += 1
             return self.fn(*a)
-    monkeypatch.setattr(lib, "cs_groupnorm_finalize_parts", Count(real_parts, "parts"), raising=False)
+
+    class CountFinalize(Count):        # stats = NULL is ops.range_bound (bound only, no GroupNorm): not counted
+        def __call__(self, *a):
+            calls[self.key] += a[7] is not None
+            return self.fn(*a)
+    monkeypatch.setattr(lib, "cs_groupnorm_finalize_parts", CountFinalize(real_parts, "parts"), raising=False)
     monkeypatch.setattr(lib, "cs_groupnorm_parts", Count(real_gnp, "parts"), raising=False)
     monkeypatch.setattr(lib, "cs_groupnorm_stats", Count(real_stats, "pass"), raising=False)
     monkeypatch.setattr(lib, "cs_groupnorm", Count(real_gn, "pass"), raising=False)
+    monkeypatch.setattr(lib, "cs_groupnorm_stats_bound", Count(lib.cs_groupnorm_stats_bound, "pass"), raising=False)
     a = df(x, t, c_crossattn=[ctx])
     torch.cuda.synchronize()
     n_parts, n_pass = calls["parts"], calls["pass"]

@@ -185,19 +185,21 @@ def test_f16x3_attention_raises_the_overflow_flag():
 
 
 def test_rel2shape_reruns_an_overflowing_minibatch_in_fp32(tmp_path):
-    """A checkpoint whose activations leave the fp16 range: conv_in's bias is set to 1e4, so the FIRST ResBlock's
-    1x1x1-free path sees |h| ~ 1e4 in its GroupNorm input (harmless) and the skip/concat consumers see it raw.  The
-    F16X3 run raises the flag; rel2shape re-runs the mini-batch on the fp32 kernels (policy 'fp32') and matches a
-    pure-fp32 model bit for bit; policy 'raise' propagates CsOverflowError."""
+    """A checkpoint whose activations leave the fp16 range where the operand scale is still the constant 16: the first
+    transformer block's to_v weights are scaled by 1e5, so its V (and the attention output feeding to_out) sit at ~1e5.
+    (Until r4 this test put one residual-stream channel at 1e4 through conv_in's bias; the raw-stream consumers now take
+    their scale from the tensor's magnitude bound and that checkpoint runs on F16X3 without a flag --
+    test_unet_residual_stream_scaled_up_and_down_needs_no_fallback.)  The F16X3 run raises the flag; rel2shape re-runs
+    the mini-batch on the fp32 kernels (policy 'fp32') and matches a pure-fp32 model bit for bit; policy 'raise'
+    propagates CsOverflowError."""
     import warnings
     from commonscenes_amd import lib as L
     from commonscenes_amd import ops, synth
     from test_model_gpu import _scene
     m = _scene(tmp_path)
     sd = dict(m.Diff.df.state_dict())
-    b = sd["diffusion_net.input_blocks.0.0.bias"].clone()
-    b[3] = 1.0e4                                 # one channel of the level-0 activations sits at 1e4 for every voxel
-    sd["diffusion_net.input_blocks.0.0.bias"] = b
+    kv = next(k for k in sorted(sd) if k.endswith("attn1.to_v.weight"))
+    sd[kv] = sd[kv] * 1.0e5                      # V of the first transformer block at ~1e5: outside 16 x fp16
     m.Diff.df.load_state_dict(sd)
     B = 3
     data = {"sdf": torch.zeros(B, 1), "rel": synth.gaussian_like("ovr:c", (B, 1, 1280)).cuda(),
