@@ -666,14 +666,12 @@ struct ExecBase {
     }
     CsConvGemm q;
     memset(&q, 0, sizeof(q));
+    // (the operand format is part of what the tile rule looks at: set in the sizing pass too, so that both passes ask
+    // cs_conv_gemm_epilogue_caps about the same launch)
+    q.a_format = x.half ? 1 : x.pair ? 2 : 0;
     if (!dry) {
       q.x = p(x);
-      if (x.half) {
-        q.x_lo = reinterpret_cast<const char*>(p(x)) + x.rows * x.c * 2;
-        q.a_format = 1;
-      } else if (x.pair) {
-        q.a_format = 2;
-      }
+      if (x.half) q.x_lo = reinterpret_cast<const char*>(p(x)) + x.rows * x.c * 2;
       q.out = p(out);
       q.w = reinterpret_cast<const float*>(arena + g.w_off);
       if (pl.math == CS_MATH_F16X3) {
@@ -740,8 +738,11 @@ struct ExecBase {
     if (out_pair > 0.f && !tc && pl.math == CS_MATH_F16X3) {
       // the result's only reader is the next F16X3 GEMM: written as the interleaved operand pair where the launch can
       // (ops.py::conv_gemm out_pair=; the sizing pass needs no answer: same bytes either way)
+      // (asked in the sizing pass too -- same bytes either way, but the consumer's tile rule looks at its operand format)
       int32_t pair = 0;
-      if (!cs_debug()->no_pair_epilogue && !dry && cs_conv_gemm_epilogue_caps(&q, nullptr, &pair) == CS_OK && pair) {
+      CsConvGemm probe = q;
+      if (dry) dry_operands(probe, g.b_off >= 0, ldr, ldrv);
+      if (!cs_debug()->no_pair_epilogue && cs_conv_gemm_epilogue_caps(&probe, nullptr, &pair) == CS_OK && pair) {
         q.out_format = 2;
         q.out_scale = out_pair;
         out.pair = true;
@@ -811,21 +812,22 @@ struct ExecBase {
 
   // ops.py::_epilogue_extras: ask the library what the launch's epilogue can emit and point the descriptor at a fresh
   // partials region (rps = rows per sample the statistics tiles run over, m_rows = the rows they cover in all)
+  // the sizing pass carries no pointers, but cs_conv_gemm_epilogue_caps looks at which epilogue terms exist (and at their
+  // alignment): aligned stand-ins for exactly the operands the real pass will set, so both passes get the same answer
+  static void dry_operands(CsConvGemm& probe, bool bias, int ldr, int ldrv) {
+    const float* some = reinterpret_cast<const float*>((uintptr_t)256);
+    probe.out = const_cast<float*>(some);
+    probe.bias = bias ? some : nullptr;
+    probe.res = ldr > 0 ? some : nullptr;
+    probe.ldr = ldr;
+    probe.rowvec = ldrv > 0 ? some : nullptr;
+    probe.ldrv = ldrv;
+  }
   void stats_for(CsConvGemm& q, Buf& out, int nb, int64_t rps, int64_t m_rows, int ncls, bool dry_bias, int dry_ldr,
                  int dry_ldrv) {
     if (cs_debug()->no_gn_parts || pl.math != CS_MATH_F16X3) return;
     CsConvGemm probe = q;
-    if (dry) {
-      // the sizing pass carries no pointers, but the rule looks at which epilogue terms exist (and at their alignment):
-      // aligned stand-ins for exactly the operands the real pass will set, so both passes get the same answer
-      const float* some = reinterpret_cast<const float*>((uintptr_t)256);
-      probe.out = const_cast<float*>(some);
-      probe.bias = dry_bias ? some : nullptr;
-      probe.res = dry_ldr > 0 ? some : nullptr;
-      probe.ldr = dry_ldr;
-      probe.rowvec = dry_ldrv > 0 ? some : nullptr;
-      probe.ldrv = dry_ldrv;
-    }
+    if (dry) dry_operands(probe, dry_bias, dry_ldr, dry_ldrv);
     int32_t rows = 0;
     if (cs_conv_gemm_epilogue_caps(&probe, &rows, nullptr) != CS_OK || rows <= 0) return;
     const int64_t tiles = (m_rows + rows - 1) / rows;

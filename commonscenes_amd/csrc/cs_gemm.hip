@@ -307,6 +307,12 @@ int plan_splitk(const CsConvGemm& p, int64_t M) {
   // CS_PLAN_POW2=1: the previous rule (largest power of two, up to 704 workgroups for K loops of >= 1024 chunks), A/B runs.
   // Short K loops (the 1x1x1 / token GEMMs: <= 168 chunks) keep the power-of-two rule: more, shorter slices only add
   // partial-tile traffic there (1792 -> 448 at 2048 rows: 8 slices 40.6 us, 16 slices 43.1).
+  // r4 (tools/gemm_tok_smallm.py, profiles/r04_tok_smallm_b{2,14,64}.txt): 1-tap GEMMs with K < 2048 are better off
+  // UNSPLIT on the 128x128 / 64x64 tiles at every batch measured -- 1792 -> 448 at 14336 rows: 82.0 us on 128x128 against
+  // 95.6 for two slices of 128x224, at 2048 rows 25.2 (64x64) against 35.6 (eight slices); 1120 -> 448: 65.3 vs 70.8 and
+  // 25.2 vs 37.5 -- their K loop (<= 112 chunks) is too short to pay for partial tiles + the reduce launch.  Only the
+  // 2688 -> 672 ff.net.2 (168 chunks) keeps its slices (66.2 vs 76.9 at 3584 rows, 28.8 vs 33.3 at 512).
+  if (p.kd * p.kh * p.kw == 1 && nk < 128 && !cs_debug()->plan_pow2 && !cs_debug()->no_tok_rules) return 1;
   if (cs_debug()->plan_pow2 || !(p.kd == 3 && p.kh == 3 && p.kw == 3)) {
     const int64_t limit = nk >= 1024 ? 704 : 512;
     int64_t s = 1;
@@ -577,6 +583,19 @@ static int auto_tile(const CsConvGemm& p, int M, bool f16x3) {
       const int64_t t512 = (M + 511) / 512;
       if (t512on && conv3 && tile == 7 && p.cout == 64 && p.win <= 64 && t512 >= 512) tile = 8;
       if (t512on && conv3 && tile == 6 && p.win <= 32 && t512 * (p.cout / 128) >= 512) tile = 9;
+    }
+    // r4, 1-tap GEMMs (tools/gemm_tok_smallm.py): (i) the 256x224 tile runs one workgroup per CU, so a launch of r = tiles /
+    // 256 rounds pays ceil(r): where the last round is mostly empty (ceil(r) / r >= 1.25: 672 -> 2016 at 16384 rows is 576
+    // tiles = 2.25 rounds, 448 -> 1344 at 14336 rows 1.31) the 128x128 tile's finer grain wins -- 145 vs 179 us, 74 vs 94;
+    // (ii) with a SHORT K loop (<= 32 chunks) and the operand pair already split, two 128-row workgroups per CU overlap
+    // one's epilogue with the other's K loop, as in the fused-gate rule below: 448 -> 1344 at 65536 rows 281 vs 300 us.
+    if (f16x3 && tile == 4 && p.kd * p.kh * p.kw == 1 && p.act != CS_ACT_GEGLU && !cs_debug()->no_tok_rules) {
+      const int64_t t4 = ((M + 255) / 256) * (int64_t)(p.cout / 224);
+      const int64_t rounds = (t4 + 255) / 256;
+      if (t4 > 256 && rounds * 256 * 4 >= t4 * 5)
+        tile = 1;
+      else if (p.a_format == 2 && (p.cin + 15) / 16 <= 32)
+        tile = 2;
     }
     if (p.act == CS_ACT_GEGLU && tile != 4) tile = 2;   // the fused gate needs whole [x | gate] 224-column tiles
     // ... and with a short K loop (the 448-channel level: 28 chunks) two 128-row workgroups per CU overlap one's gate

@@ -54,6 +54,7 @@ void parse_env(CsDebug& d) {
   d.no_gn_parts = flag("CS_NO_GN_PARTS");
   d.no_pair_epilogue = flag("CS_NO_PAIR_EPILOGUE");
   d.no_dyn_scale = flag("CS_NO_DYN_SCALE");
+  d.no_tok_rules = flag("CS_NO_TOK_RULES");
 }
 
 }  // namespace

@@ -88,7 +88,7 @@ typedef struct CsDebug {
   int32_t no_gn_parts;        /* GroupNorm statistics always from a pass over the tensor (r4) */
   int32_t no_pair_epilogue;   /* GEMM epilogues always write fp32 (r4) */
   int32_t no_dyn_scale;       /* raw-activation consumers keep the fixed operand scale 16 + overflow flag (r4) */
-  int32_t reserved0;
+  int32_t no_tok_rules;       /* 1-tap GEMMs keep r3's tile / K-slice choices (r4: quantisation-aware tile, no slices under 128 chunks) */
   int64_t split16_min_rows;   /* pre-split operands on the 128-row slab tile from this many rows (8192; 0 = never) */
   int64_t cfg_split_min_rows; /* channel-split ResBlocks from this many rows (65536) */
   int64_t gn_small_group;     /* single-launch GroupNorm up to this many elements per (sample, group) (11264) */

@@ -1,6 +1,7 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 REPO=$(pwd)
+timeout 600 python -m pytest tests/test_parity_depth_gpu.py -m gpu -q -k "overflow or rerun" 2>&1 | tail -3
 cd /tmp && export TMPDIR=/tmp
 for ob in 7 1; do
 timeout 600 rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/prof_h$ob -o bench -- python $REPO/bench.py --no-cpu-baseline --no-traffic --no-extras --objects $ob --steps 10 --warmup 3 --gemm-table > $REPO/gpurun_out/r04_h_bench_c$ob.json 2> $REPO/gpurun_out/r04_h_gemm_table_c$ob.txt
