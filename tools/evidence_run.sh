@@ -29,17 +29,23 @@ cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/prof_${TAG} -o bench -- python $REPO/bench.py --no-cpu-baseline --no-traffic --gemm-table > $REPO/gpurun_out/${TAG}_bench_under_rocprof.json 2> $REPO/gpurun_out/${TAG}_gemm_table.txt
 timeout 600 rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/prof_${TAG}2 -o bench -- python $REPO/bench.py --no-cpu-baseline --no-extras > $REPO/gpurun_out/${TAG}_bench_steploop_under_rocprof.json 2> /dev/null
 timeout 600 rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/prof_${TAG}3 -o bench -- python $REPO/bench.py --no-cpu-baseline --no-extras --objects 1 --steps 20 --warmup 3 > $REPO/gpurun_out/${TAG}_bench_c2_under_rocprof.json 2> /dev/null
+timeout 600 rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/prof_${TAG}4 -o bench -- python $REPO/bench.py --no-cpu-baseline --no-traffic --no-extras --objects 7 --steps 10 --warmup 3 --gemm-table > $REPO/gpurun_out/${TAG}_bench_c7_under_rocprof.json 2> $REPO/gpurun_out/${TAG}_gemm_table_c7.txt
 cd $REPO
+DB=$(find gpurun_out/prof_${TAG}4 -name "*.db" | head -1)
+[ -n "$DB" ] && python tools/rocpd_summary.py $DB > gpurun_out/${TAG}_c7_kernel_stats.txt
+grep -v "^[WEI]2026" gpurun_out/${TAG}_gemm_table_c7.txt | head -45 > gpurun_out/${TAG}_gemm_table_c7_clean.txt
 DB=$(find gpurun_out/prof_${TAG} -name "*.db" | head -1)
 [ -n "$DB" ] && python tools/rocpd_summary.py $DB > gpurun_out/${TAG}_kernel_stats.txt
 DB=$(find gpurun_out/prof_${TAG}2 -name "*.db" | head -1)
 [ -n "$DB" ] && python tools/rocpd_summary.py $DB > gpurun_out/${TAG}_kernel_stats_steploop.txt && python tools/rocpd_by_grid.py $DB "conv_gemm_f16x3_kernel<1, 7, 8, 1, true, 32," > gpurun_out/${TAG}_dominant_kernel_by_grid.txt && head -8 gpurun_out/${TAG}_kernel_stats_steploop.txt | cut -c1-170
 DB=$(find gpurun_out/prof_${TAG}3 -name "*.db" | head -1)
 [ -n "$DB" ] && python tools/rocpd_summary.py $DB > gpurun_out/${TAG}_c2_kernel_stats.txt
-rm -rf gpurun_out/prof_${TAG} gpurun_out/prof_${TAG}2 gpurun_out/prof_${TAG}3
+rm -rf gpurun_out/prof_${TAG} gpurun_out/prof_${TAG}2 gpurun_out/prof_${TAG}3 gpurun_out/prof_${TAG}4
 grep -v "^[WEI]2026" gpurun_out/${TAG}_gemm_table.txt | head -45 > gpurun_out/${TAG}_gemm_table_clean.txt
 if [ "$MODE" != "quick" ]; then
   python tools/hbm_bench.py > gpurun_out/${TAG}_hbm_bound_kernels.txt 2>&1
   python tools/decode_bench.py > gpurun_out/${TAG}_decode_table.txt 2>&1
+  for nb in 2 14 64; do SM_BATCH=$nb timeout 600 python tools/gemm_tok_smallm.py > gpurun_out/${TAG}_tok_smallm_b$nb.txt 2>&1; done
+  SM_BATCH=2 timeout 600 python tools/gemm_smallm_tiles.py > gpurun_out/${TAG}_smallm_tiles_b2.txt 2>&1
   head -3 gpurun_out/${TAG}_decode_table.txt
 fi
