@@ -411,7 +411,7 @@ def test_f16x3_presplit_slab_path_is_bit_identical(shape, cin, cout, tile, monke
     (2, (16, 4, 4), 672, 672, 3, True),      # one object's 256-voxel level: 12 output tiles -> 32 K slices
     (2, (16, 8, 8), 448, 448, 3, False),
     (1, (4, 8, 8), 224, 224, 3, True),
-    (3, (1, 1, 170), 1792, 224, 1, True),    # linear, ragged M (K loops under 64 chunks are not split)
+    (3, (1, 1, 170), 2688, 672, 1, True),    # linear, ragged M (r4: 1-tap K loops under 128 chunks are not split)
 ])
 def test_f16x3_splitk_matches_fp64_and_unsplit(nb, shape, cin, cout, k, extras):
     """cs_conv_gemm_plan proposes K slices for GEMMs with few output tiles; the sliced result (partials summed in

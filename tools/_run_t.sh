@@ -1,0 +1,2 @@
+cd $GRAFT_REPO_ROOT
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -v Warning | tail -8
