@@ -29,9 +29,16 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: cannot build libcommonscenes_hip.so")
 
 
+def _flagstr() -> str:
+    return " ".join([*FLAGS, *os.environ.get("CS_EXTRA_HIPCC_FLAGS", "").split()])
+
+
 def needs_build() -> bool:
     if not LIB_PATH.exists():
         return True
+    stamp = PKG_DIR / "build" / "flags.txt"
+    if stamp.exists() and stamp.read_text() != _flagstr():
+        return True             # the library on disk came from another flag set (a what-if build): never keep it silently
     t = LIB_PATH.stat().st_mtime
     deps = [CSRC / s for s in SOURCES] + HEADERS + [Path(__file__)]
     return any(d.stat().st_mtime > t for d in deps)
@@ -48,7 +55,7 @@ def build_native(force: bool = False, verbose: bool = True) -> Path:
     objs = []
     # incremental: an object is rebuilt when its source, any header, this file or the flag set is newer / different
     stamp = objdir / "flags.txt"
-    flagstr = " ".join([*FLAGS, *extra])
+    flagstr = _flagstr()
     same_flags = stamp.exists() and stamp.read_text() == flagstr
     newest_hdr = max(d.stat().st_mtime for d in HEADERS + [Path(__file__)])
     for s in SOURCES:

@@ -26,6 +26,7 @@
 #include <cstring>
 #include "cs_f16x3.h"
 #include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -80,6 +81,12 @@ struct CsClsBatch {
   int n;
 };
 
+// f(integral_constant<int, I>) for I = 0 .. N-1, unrolled at compile time (the ring positions of the K loop)
+template <class F, int... I>
+__device__ __forceinline__ void static_steps(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+
 template <int WMB, int WNB, int WAVES_M, int WAVES_N, bool PRE, int SLAB = 0, bool PAIR = false, int TPK = 9, bool PW = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_kernel(const CsConvGemm p, int M, int tiles_n,
                                                               int taps_hw, int kw_, int kg_per_tap,
@@ -117,7 +124,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
 #ifdef CS_PW_RING3
   constexpr int NSTAGE = (BM == 64 && BN == 64) ? 6 : (TPK == 4 ? 4 : 3);
 #else
-  constexpr int NSTAGE = (BM == 64 && BN == 64) ? 6 : ((TPK == 4 || (PW && BM == 256 && BN == 224)) ? 4 : 3);
+#ifndef CS_RING64
+#define CS_RING64 6
+#endif
+  constexpr int NSTAGE = (BM == 64 && BN == 64) ? CS_RING64 : ((TPK == 4 || (PW && BM == 256 && BN == 224)) ? 4 : 3);
 #endif
 #endif
   constexpr int PF = NSTAGE - 1;
@@ -693,16 +703,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   } else
   for (int kc = 0; kc < nk; kc += NSTAGE) {
     step(std::integral_constant<int, 0>{});
-    if (kc + 1 < nk) step(std::integral_constant<int, 1>{});
-    if (kc + 2 < nk) step(std::integral_constant<int, 2>{});
-    if constexpr (NSTAGE == 4) {
-      if (kc + 3 < nk) step(std::integral_constant<int, 3>{});
-    }
-    if constexpr (NSTAGE == 6) {
-      if (kc + 3 < nk) step(std::integral_constant<int, 3>{});
-      if (kc + 4 < nk) step(std::integral_constant<int, 4>{});
-      if (kc + 5 < nk) step(std::integral_constant<int, 5>{});
-    }
+    static_steps(std::make_integer_sequence<int, NSTAGE - 1>{}, [&](auto s1) {
+      constexpr int st = decltype(s1)::value + 1;
+      if (kc + st < nk) step(std::integral_constant<int, st>{});
+    });
   }
   wait_vmcnt<0>();   // drain the prefetches issued past the end before LDS is released
   if constexpr (!PRE && !PAIR) {

@@ -131,12 +131,27 @@ __device__ __forceinline__ void gn_group_parts(const GnSegs& sg, int n, int g, i
     const int tps = sp.tiles_per_sample, nt = sp.ncls * tps, items = (hi - lo) * nt;
     const int64_t cls_stride = (int64_t)sp.nb_src * tps;
     const int64_t t0 = (int64_t)(n % sp.nb_src) * tps;
-    for (int j = lane; j < items; j += nlanes) {
-      const int k = j / nt, r = j - k * nt;               // channel lo + k, tile r = cls * tps + t
-      const int cls = r / tps, t = r - cls * tps;
-      const double* d = sp.part + ((cls * cls_stride + t0 + t) * sp.ld + sp.col0 + (lo + k - sp.ch0)) * 2;
-      s += d[0];
-      q += d[1];
+    // four items' loads in flight per lane (the plain loop waited out one load latency per item: 28 items a lane at the
+    // 16-row partials of the split-K reduce = 9.6 us for a kernel that moves 30 KB); added in the same order as before
+    for (int j = lane; j < items; j += 4 * nlanes) {
+      double2 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int ju = j + u * nlanes;
+        v[u] = make_double2(0.0, 0.0);
+        if (ju < items) {
+          const int k = ju / nt, r = ju - k * nt;           // channel lo + k, tile r = cls * tps + t
+          const int cls = r / tps, t = r - cls * tps;
+          v[u] = *reinterpret_cast<const double2*>(sp.part +
+                                                   ((cls * cls_stride + t0 + t) * sp.ld + sp.col0 + (lo + k - sp.ch0)) * 2);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (j + u * nlanes < items) {
+          s += v[u].x;
+          q += v[u].y;
+        }
     }
   }
 }
