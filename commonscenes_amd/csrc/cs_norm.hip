@@ -158,36 +158,57 @@ __device__ __forceinline__ void gn_group_parts(const GnSegs& sg, int n, int g, i
 
 // |mean| + std * sqrt(n - 1) >= max |x| over the group (Samuelson's inequality), rounded UP to fp32; the maximum over all
 // (sample, group)s bounds the tensor: what CsConvGemm.a_bound reads.  atomicMax of the bits: order-independent.
-__device__ __forceinline__ void gn_bound_max(float* bound, double mean, double var, double count) {
+__device__ __forceinline__ float gn_bound_value(double mean, double var, double count) {
   const double b = fabs(mean) + sqrt(var * (count > 1.0 ? count - 1.0 : 1.0));
   float bf = (float)b;
   if ((double)bf < b) bf = __uint_as_float(__float_as_uint(bf) + 1u);
-  if (bf == bf && bf > 0.f) atomicMax(reinterpret_cast<unsigned int*>(bound), __float_as_uint(bf));
+  return (bf == bf && bf > 0.f) ? bf : 0.f;
+}
+__device__ __forceinline__ void gn_bound_commit(float* bound, float bf) {
+  if (bf > 0.f) atomicMax(reinterpret_cast<unsigned int*>(bound), __float_as_uint(bf));
+}
+__device__ __forceinline__ void gn_bound_max(float* bound, double mean, double var, double count) {
+  gn_bound_commit(bound, gn_bound_value(mean, var, count));
 }
 
-__global__ __launch_bounds__(256) void gn_finalize_parts_kernel(const GnSegs sg, int groups, int cpg, double count,
-                                                                float eps, float* __restrict__ stats,
-                                                                float* __restrict__ bound, int total) {
-  const int lane = threadIdx.x & 63;
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);  // n * groups + g
-  if (i >= total) return;
-  const int n = i / groups, g = i - n * groups;
-  double s, q;
-  gn_group_parts(sg, n, g, cpg, lane, 64, s, q);
+// One word per tensor: the 2048 (sample, group)s of a 32-object launch each hitting it with an atomic serialise in L2
+// (measured: 30 us for a kernel that otherwise takes 5), so a workgroup is SIXTEEN waves = sixteen (sample, group)s and
+// commits one maximum.
+constexpr int GN_FIN_WAVES = 16;
+__global__ __launch_bounds__(64 * GN_FIN_WAVES) void gn_finalize_parts_kernel(const GnSegs sg, int groups, int cpg,
+                                                                              double count, float eps,
+                                                                              float* __restrict__ stats,
+                                                                              float* __restrict__ bound, int total) {
+  __shared__ float bmax[GN_FIN_WAVES];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * GN_FIN_WAVES + wave;  // n * groups + g
+  float bf = 0.f;
+  if (i < total) {
+    const int n = i / groups, g = i - n * groups;
+    double s, q;
+    gn_group_parts(sg, n, g, cpg, lane, 64, s, q);
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    s += __shfl_xor(s, o, 64);
-    q += __shfl_xor(q, o, 64);
-  }
-  if (lane == 0) {
+    for (int o = 32; o > 0; o >>= 1) {
+      s += __shfl_xor(s, o, 64);
+      q += __shfl_xor(q, o, 64);
+    }
     const double mean = s / count;
     double var = q / count - mean * mean;
     if (var < 0) var = 0;
-    if (stats) {
+    if (lane == 0 && stats) {
       stats[2 * i] = (float)mean;
       stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
     }
-    if (bound) gn_bound_max(bound, mean, var, count);
+    if (bound) bf = gn_bound_value(mean, var, count);
+  }
+  if (!bound) return;                  // (kernel-uniform)
+  if (lane == 0) bmax[wave] = bf;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float m = bmax[0];
+#pragma unroll
+    for (int w = 1; w < GN_FIN_WAVES; ++w) m = fmaxf(m, bmax[w]);
+    gn_bound_commit(bound, m);
   }
 }
 
@@ -627,7 +648,7 @@ extern "C" int cs_groupnorm_finalize_parts(const CsGnSeg* segs, int nseg, int nb
   const int rc = gn_pack_segs(segs, nseg, nb, c, sg);
   if (rc != CS_OK) return rc;
   const int total = nb * groups;
-  CS_LAUNCH(gn_finalize_parts_kernel, dim3((total + 3) / 4), dim3(256), 0, (hipStream_t)stream, sg, groups, c / groups,
+  CS_LAUNCH(gn_finalize_parts_kernel, dim3((total + GN_FIN_WAVES - 1) / GN_FIN_WAVES), dim3(64 * GN_FIN_WAVES), 0, (hipStream_t)stream, sg, groups, c / groups,
             (double)rows * (c / groups), eps, stats, bound, total);
   CS_CHECK_LAUNCH();
   return CS_OK;
