@@ -394,7 +394,8 @@ def range_bound(x: Tensor, slot: Optional[Tensor], groups: int = 32) -> Optional
     finalize kernel -- and remember it on x (`x.cs_bound`).  A consumer of the RAW tensor hands it to
     conv_gemm(x_bound=): its F16X3 operand scale then follows the tensor's actual range (CsConvGemm.a_bound) instead of
     the fixed guess 16.  For tensors that are NOT followed by a GroupNorm (the inputs of Downsample / Upsample); a
-    GroupNorm over x leaves the bound as a by-product (groupnorm(..., bound=slot)).  None when x carries no partials."""
+    GroupNorm over x leaves the bound as a by-product (groupnorm(..., bound=slot)).  A tensor without partials gets it from
+    one statistics pass (cs_groupnorm_stats_bound).  None when the feature is off or the channels do not divide."""
     if slot is None or not _sw("DYN_SCALE") or x.shape[-1] % groups:
         return None
     segs = stats_segments(x)

@@ -310,3 +310,40 @@ def test_unet_residual_stream_scaled_up_and_down_needs_no_fallback(mag):
     assert flagged == 0 and e16 < 2e-5
     if mag >= 1e3:
         assert amax > 4094 and fold & L.STATUS_F16X3_OVERFLOW   # the r3 behaviour on the same input: detect and re-run
+
+
+@pytest.mark.parametrize("shape", [(3, 16, 4, 4, 224), (2, 8, 8, 8, 64), (1, 4, 4, 4, 672)])
+def test_statistics_pass_leaves_the_same_magnitude_bound(shape):
+    """A tensor whose producer left no partial sums (a folded Upsample conv at a small batch, the channel-split blocks'
+    h1) takes its GroupNorm statistics from a pass over the tensor; cs_groupnorm_stats_bound makes that pass leave the
+    magnitude bound too: (mean, rstd) bit-identical to cs_groupnorm_stats, bound >= max |x| (Samuelson) and within the
+    sqrt(n) slack of it, NaN / zero tensors leave the slot untouched."""
+    from commonscenes_amd import lib as L, ops
+    lib = L.load()
+    nb, d, h, w, c = shape
+    groups = 32
+    x = (_rand(*shape, seed=91) * 3.0 + 0.5).cuda()
+    rows = d * h * w
+    ws = torch.empty(lib.cs_groupnorm_ws_bytes(nb, groups) // 8, dtype=torch.float64, device="cuda")
+    st_a = torch.empty((nb, groups, 2), dtype=torch.float32, device="cuda")
+    st_b = torch.empty_like(st_a)
+    bound = torch.zeros(1, dtype=torch.float32, device="cuda")
+    s = ops._stream()
+    L.check(lib.cs_groupnorm_stats(x.data_ptr(), nb, rows, c, c, groups, 1e-5, ws.data_ptr(), st_a.data_ptr(), s), "stats")
+    L.check(lib.cs_groupnorm_stats_bound(x.data_ptr(), nb, rows, c, c, groups, 1e-5, ws.data_ptr(), st_b.data_ptr(),
+                                         bound.data_ptr(), s), "stats_bound")
+    torch.cuda.synchronize()
+    assert torch.equal(st_a, st_b)
+    amax = float(x.abs().max())
+    n = rows * (c // groups)
+    assert amax <= float(bound) <= amax * (n ** 0.5 + 1.0), (amax, float(bound), n)
+    # through the host wrapper: the slot a consumer would read (ops.range_bound without partials on x)
+    slot = torch.zeros(1, dtype=torch.float32, device="cuda")
+    assert ops.range_bound(x, slot) is slot and float(slot) == float(bound)
+    zero = torch.zeros(1, dtype=torch.float32, device="cuda")
+    L.check(lib.cs_groupnorm_stats_bound(torch.zeros_like(x).data_ptr(), nb, rows, c, c, groups, 1e-5, ws.data_ptr(),
+                                         st_b.data_ptr(), zero.data_ptr(), s), "stats_bound")
+    torch.cuda.synchronize()
+    assert float(zero) == 0.0
+    assert lib.cs_groupnorm_stats_bound(x.data_ptr(), nb, rows, c, c, groups, 1e-5, ws.data_ptr(), st_b.data_ptr(), None,
+                                        s) == L.CS_EINVAL
