@@ -214,3 +214,60 @@ def test_self_attention_at_full_size_against_fp64():
         got.append(out[b_, i_, sl].double().cpu().numpy())
     err, worst = _report("self-attention 1024 tokens x dh 56", np.concatenate(got), np.concatenate(ref))
     assert err < 1e-6 and worst < 1e-5
+
+
+def test_skip_connection_conv_at_full_size_against_fp64():
+    """ResBlock.skip_connection (openai_model_3d.py:283-292: Conv3d(1) on the RAW concatenation) of the first output block at
+    level 0, batch 64: 448 -> 224 over M = 262 144 rows, the operand scale derived from the tensor's magnitude bound (the
+    by-product of the block's own in_layers GroupNorm).  1024 whole rows against fp64."""
+    from commonscenes_amd import lib as L, ops, synth
+    D, C, N = 16, 448, 224
+    x = synth.tensor_device("fss:x", (NB, D, D, D, C), 1.0)
+    x[..., :16] *= 25.0                                            # a few hot channels: the bound, not the guess 16, sets the scale
+    g, bt = synth.tensor_device("fss:g", (C,), 0.3) + 1.0, synth.tensor_device("fss:bt", (C,), 0.1)
+    w = synth.tensor_device("fss:w", (N, C, 1, 1, 1), C ** -0.5)
+    b = synth.tensor_device("fss:b", (N,), 0.1)
+    slot = torch.zeros(1, device="cuda")
+    ops.groupnorm(x, g, bt, 32, 1e-5, L.ACT_SILU, bound=slot)     # what unet.py::_res does before the skip conv
+    assert getattr(x, "cs_bound", None) is slot and float(slot) >= float(x.abs().max())
+    out = ops.conv_gemm(x, ops.pack_weight(w, b, math=L.MATH_F16X3), math=L.MATH_F16X3, x_bound=slot)
+    torch.cuda.synchronize()
+    assert ops.read_status() == 0
+    rs = np.random.RandomState(16)
+    idx = tuple(torch.from_numpy(rs.randint(0, d_, 1024)).cuda() for d_ in (NB, D, D, D))
+    ref = (x[idx].double() @ w.double().reshape(N, C).t() + b.double()).cpu().numpy()
+    err, worst = _report("skip_connection 448 -> 224 (1x1x1, bound-derived scale)", out[idx].double().cpu().numpy().ravel(),
+                         ref.ravel())
+    assert err < 1e-6 and worst < 1e-5
+
+
+def test_groupnorm_statistics_from_the_dominant_kernels_epilogue_at_full_size():
+    """The benchmarked instantiation's pipelined epilogue (256x224 tile, bias + row vector + residual) leaves the per-(row
+    tile, column) partial sums of what it writes; the GroupNorm statistics derived from them (42 of the step's 46 GroupNorms
+    take this route) against fp64 statistics of the written tensor, at the benchmark's own size: 224 -> 224 at 16^3, batch
+    64, 16 partial tiles per sample."""
+    from commonscenes_amd import lib as L, ops, synth
+    D, C = 16, 224
+    x = synth.tensor_device("fsg:x", (NB, D, D, D, C), 1.0)
+    g, bt = synth.tensor_device("fsg:g", (C,), 0.3) + 1.0, synth.tensor_device("fsg:bt", (C,), 0.1)
+    pk = ops.pack_weight(synth.tensor_device("fsg:w", (C, C, 3, 3, 3), (C * 27) ** -0.5),
+                         synth.tensor_device("fsg:b", (C,), 0.1), math=L.MATH_F16X3)
+    rv = synth.tensor_device("fsg:rv", (NB, C), 0.5)
+    prof = ops.GEMM_PROFILE = []
+    try:
+        out = ops.conv_gemm(ops.groupnorm(x, g, bt, 32, 1e-5, L.ACT_SILU, split16=True), pk, rowvec=rv, rv_rows=D ** 3, res=x,
+                            stats=True)
+    finally:
+        ops.GEMM_PROFILE = None
+    torch.cuda.synchronize()
+    assert (prof[0]["tile"], prof[0]["slab"], prof[0]["pre"]) == (4, 32, True)      # the benchmarked instantiation
+    cs = getattr(out, "cs_stats", None)
+    assert cs is not None and cs.tps == D ** 3 // 256
+    st = ops.groupnorm_stats(out, 32, 1e-5).double()
+    o64 = out.double().reshape(NB, D ** 3, 32, C // 32)
+    mu = o64.mean(dim=(1, 3))
+    rstd = 1.0 / torch.sqrt(((o64 - mu[:, None, :, None]) ** 2).mean(dim=(1, 3)) + 1e-5)
+    dm = float(((st[..., 0] - mu).abs() * rstd).max())
+    dr = float(((st[..., 1] - rstd).abs() / rstd).max())
+    print(f"GroupNorm statistics from the 256x224 tile's partials at full size: |d mean| / sigma {dm:.2e}, |d rstd| / rstd {dr:.2e}")
+    assert dm < 1e-6 and dr < 1e-6
