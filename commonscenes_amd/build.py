@@ -33,6 +33,19 @@ def _flagstr() -> str:
     return " ".join([*FLAGS, *os.environ.get("CS_EXTRA_HIPCC_FLAGS", "").split()])
 
 
+def _deps(src: Path, seen=None) -> set:
+    """src and every file it includes with quotes, recursively (paths relative to the including file)"""
+    import re
+    seen = set() if seen is None else seen
+    src = src.resolve()
+    if src in seen or not src.exists():
+        return seen
+    seen.add(src)
+    for m in re.finditer(r'^\s*#\s*include\s+"([^"]+)"', src.read_text(), re.M):
+        _deps(src.parent / m.group(1), seen)
+    return seen
+
+
 def needs_build() -> bool:
     if not LIB_PATH.exists():
         return True
@@ -40,7 +53,7 @@ def needs_build() -> bool:
     if stamp.exists() and stamp.read_text() != _flagstr():
         return True             # the library on disk came from another flag set (a what-if build): never keep it silently
     t = LIB_PATH.stat().st_mtime
-    deps = [CSRC / s for s in SOURCES] + HEADERS + [Path(__file__)]
+    deps = [CSRC / s for s in SOURCES] + HEADERS      # (the flag set is tracked by build/flags.txt)
     return any(d.stat().st_mtime > t for d in deps)
 
 
@@ -57,12 +70,13 @@ def build_native(force: bool = False, verbose: bool = True) -> Path:
     stamp = objdir / "flags.txt"
     flagstr = _flagstr()
     same_flags = stamp.exists() and stamp.read_text() == flagstr
-    newest_hdr = max(d.stat().st_mtime for d in HEADERS + [Path(__file__)])
     for s in SOURCES:
         obj = objdir / (s.replace(".hip", ".o"))
         objs.append(str(obj))
-        if (not force and same_flags and obj.exists() and obj.stat().st_mtime > (CSRC / s).stat().st_mtime
-                and obj.stat().st_mtime > newest_hdr):
+        # (per-source dependencies: the quoted includes, followed recursively -- cs_gemm_f16x3.hip takes five minutes and
+        # does not include cs_driver.h)
+        newest_dep = max(d.stat().st_mtime for d in _deps(CSRC / s))
+        if not force and same_flags and obj.exists() and obj.stat().st_mtime > newest_dep:
             continue
         cmd = [hipcc, *FLAGS, *extra, "-c", str(CSRC / s), "-o", str(obj)]
         if verbose:

@@ -588,6 +588,21 @@ struct ExecBase {
     amax_next = 0;
     if (ok() && !dry && hipMemsetAsync(ws + amax_arena.off, 0, (size_t)slots * 4, st) != hipSuccess) chk(CS_EINVAL);
   }
+  // split-K arrival counters of this forward (CsConvGemm.splitk_sync, ops.py::sync_words): zeroed with the bound slots'
+  // region (one memset), returned to zero by the kernels that use them
+  Buf sync_arena;
+  static constexpr int SYNC_WORDS = 8192;
+  void sync_begin() {
+    if (pl.math != CS_MATH_F16X3) return;
+    sync_arena = alloc(SYNC_WORDS, 1);
+    if (ok() && !dry && hipMemsetAsync(ws + sync_arena.off, 0, (size_t)SYNC_WORDS * 4, st) != hipSuccess) chk(CS_EINVAL);
+  }
+  void set_sync(CsConvGemm& q) const {
+    if (q.splitk > 1 && sync_arena.off >= 0 && !dry) {
+      q.splitk_sync = reinterpret_cast<int32_t*>(ws + sync_arena.off);
+      q.splitk_sync_words = SYNC_WORDS;
+    }
+  }
   int64_t amax_slot() {       // a fresh slot's workspace offset, or -1 (feature off / arena exhausted)
     if (amax_next >= amax_cap) return -1;
     return amax_arena.off + 4 * (int64_t)amax_next++;
@@ -733,6 +748,7 @@ struct ExecBase {
       if (!ok()) return out;
       q.splitk = sk;
       q.splitk_ws = dry ? nullptr : p(skws);
+      set_sync(q);
     }
     if (want_stats && !tc) stats_for(q, out, nb, (int64_t)dout * hout * wout, mo, 1, g.b_off >= 0, ldr, ldrv);
     if (out_pair > 0.f && !tc && pl.math == CS_MATH_F16X3) {
@@ -805,6 +821,7 @@ struct ExecBase {
       if (!ok()) return;
       q.splitk = sk;
       q.splitk_ws = dry ? nullptr : p(skws);
+      set_sync(q);
     }
     if (!dry) chk(cs_conv_gemm(&q, st));
     release(skws);

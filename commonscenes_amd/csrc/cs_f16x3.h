@@ -2,6 +2,24 @@
 #pragma once
 #include "cs_common.h"
 
+// r5: the split-K reduce + epilogue folded into the slice kernel (CsConvGemm.splitk_sync; cs_gemm.hip decides).  n = 0: off.
+// The final descriptor's epilogue terms travel here; the kernel's own descriptor `p` stays the plain partial-tile one.
+struct CsFuseK {
+  float* out;
+  const float* bias;
+  const float* scale;
+  const float* shift;
+  const float* rowvec;
+  const float* res;
+  double* gn_part;
+  int32_t* sync;          // two zeroed words per output tile: arrivals, departures (returned to zero by the last reducer)
+  int32_t* status;
+  int32_t ldo, ldr, ldrv, rv_rows, act, gn_ld, out_format;
+  int32_t reducers;       // slices 0 .. reducers - 1 of a tile each reduce BM / reducers rows (a multiple of 16)
+  float out_scale;
+};
+
+
 namespace cs16 {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));

@@ -13,7 +13,9 @@
 //   A[i = lane&31][k = lane>>5], B[k = lane>>5][j = lane&31],
 //   D: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5), r in [0,16).
 #include <cstdlib>
-#include "cs_common.h"
+#include <atomic>
+#include <cstring>
+#include "cs_f16x3.h"
 
 namespace {
 
@@ -250,7 +252,8 @@ __global__ void relayout_weight_kernel(const float* __restrict__ w, float* __res
 
 int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p, int M, int tile, int splits, hipStream_t s, int omap_f = 0,
                                 int omap_p = 0, const void* const* cls_w = nullptr, const void* const* cls_w_lo = nullptr,
-                                const float* cls_acc = nullptr, int ncls = 0);          // cs_gemm_f16x3.hip
+                                const float* cls_acc = nullptr, int ncls = 0,
+                                const CsFuseK* fuse = nullptr);                         // cs_gemm_f16x3.hip
 bool cs_f16x3_slab4_ok(const CsConvGemm& p, int tile, int splits);                      // cs_gemm_f16x3.hip
 bool cs_pw_gemm_f16x3_applicable(const CsConvGemm& p, int64_t M);                                   // cs_gemm_pw.hip
 bool cs_pw_gemm_f16x3_preferred(const CsConvGemm& p, int64_t M);
@@ -515,6 +518,12 @@ extern "C" int cs_conv_gemm_epilogue_caps(const CsConvGemm* d, int32_t* gn_rows,
     tile_dims(auto_tile(q, (int)m1, true), bm, bn);
     rps = (int64_t)p.din * p.hin * p.win;
     if (!bm || !p.bias) return CS_OK;                         // (piped epilogue needs bias / residual / row vector)
+    // ... the rest of the kernel's `piped` condition: no BN scale / shift, and the rows one tile's scattered
+    // stores span on the doubled grid -- at most the tile's rows plus a plane, a line and a voxel of halo, times the
+    // doubling factor -- inside a 32-bit offset window
+    if (p.scale) return CS_OK;
+    const int64_t ospan = ((int64_t)bm + 2LL * p.hin * p.win + 2LL * p.win + 2) * ncls;
+    if (ospan * p.ldo * 4 >= 0x7FF00000LL) return CS_OK;
     if (gn_rows && rps % bm == 0 && p.act != CS_ACT_GEGLU) *gn_rows = bm;
     return CS_OK;                                            // (no pair output from the scattered store)
   }
@@ -615,6 +624,37 @@ static int sliced_tile(const CsConvGemm& p, int M) {
   return (split4_large(p, M) || p.tile == 4 || slab3) ? 4 : 2;
 }
 
+// CUs of the current device (cached per process; 0 if the query fails -- then nothing is assumed resident)
+static int device_cus() {
+  static std::atomic<int> cached{-1};
+  int v = cached.load(std::memory_order_relaxed);
+  if (v >= 0) return v;
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+    n = 0;
+  (void)hipGetLastError();
+  cached.store(n, std::memory_order_relaxed);
+  return n;
+}
+
+// Reducers per output tile of a K-sliced launch whose reduce + epilogue run inside the slice kernel (fused_splitk_reduce,
+// cs_gemm_f16x3.hip), or 0: the two-kernel form.  The reducers WAIT for their tile's other slices, so every workgroup of
+// the launch must be resident at once: one 8-wave workgroup per CU on the 256-row tiles, two 4-wave ones on the 128-row
+// tile (launch bounds and LDS footprints of cs_gemm_f16x3.hip) -- the small-batch plan's launches are sized to exactly
+// that; the large-batch four-way cut (768 workgroups) keeps the second launch.  Each reducer takes BM / R rows in whole
+// 16-row statistics blocks: R = the largest power of two <= min(slices, BM / 16).
+static int fused_reduce_plan(const CsConvGemm& p, int M, int stile) {
+  if (!p.splitk_sync || cs_debug()->no_fused_reduce || p.splitk < 2 || (stile != 2 && stile != 4)) return 0;
+  if (p.cout % 224 || ((uintptr_t)p.splitk_sync & 3)) return 0;
+  const int bm = stile == 4 ? 256 : 128;
+  const int64_t tiles = (int64_t)((M + bm - 1) / bm) * (p.cout / 224);
+  const int64_t slots = (int64_t)device_cus() * (stile == 4 ? 1 : 2);
+  if (tiles * p.splitk > slots || 2 * tiles > p.splitk_sync_words) return 0;
+  int r = 1;
+  while (2 * r <= p.splitk && 2 * r <= bm / 16) r *= 2;
+  return r;
+}
+
 // omap_f / omap_p != 0 (cs_conv_gemm_up2 only): this GEMM is one output parity class of a folded Upsample conv and
 // stores straight into the doubled grid (cs_gemm_f16x3.hip, slab4 kernel); d->out / d->ldo are then the final tensor's
 static int conv_gemm_impl(const CsConvGemm* d, cs_stream_t stream, int omap_f, int omap_p,
@@ -681,7 +721,20 @@ static int conv_gemm_impl(const CsConvGemm* d, cs_stream_t stream, int omap_f, i
     // the same slice count as 512 slots of the 128-row tile) -- 4-7 % faster than the 128x224 tile on every shape from
     // 1 to 14 objects (tools/gemm_smallm_t4.py, profiles/r03_an_tile4_slices*.txt); convs the slab kernel does not take
     // (strided, W > 32) keep the 128-row tile.  CS_SLICE_TILE2=1: the previous rule, A/B runs.
-    const int rc = cs_conv_gemm_f16x3_dispatch(part, M, sliced_tile(p, M), p.splitk, s);
+    const int stile = sliced_tile(p, M);
+    // r5: reduce + epilogue inside the slice kernel (CsConvGemm.splitk_sync) -- when every workgroup of the launch is resident
+    // at once (the reducers wait for their tile's other slices), for whole 224-column tiles with the float4 epilogue
+    CsFuseK fz;
+    memset(&fz, 0, sizeof(fz));
+    const int reducers = fused_reduce_plan(p, M, stile);
+    if (reducers > 0) {
+      fz.out = p.out; fz.bias = p.bias; fz.scale = p.scale; fz.shift = p.shift; fz.rowvec = p.rowvec; fz.res = p.res;
+      fz.gn_part = p.gn_part; fz.sync = p.splitk_sync; fz.status = p.status;
+      fz.ldo = p.ldo; fz.ldr = p.ldr; fz.ldrv = p.ldrv; fz.rv_rows = p.rv_rows; fz.act = p.act; fz.gn_ld = p.gn_ld;
+      fz.out_format = p.out_format; fz.reducers = reducers; fz.out_scale = p.out_scale;
+      return cs_conv_gemm_f16x3_dispatch(part, M, stile, p.splitk, s, 0, 0, nullptr, nullptr, nullptr, 0, &fz);
+    }
+    const int rc = cs_conv_gemm_f16x3_dispatch(part, M, stile, p.splitk, s);
     if (rc != CS_OK) return rc;
     if (p.gn_part || p.out_format) {
       const int64_t nblk = (int64_t)((M + SKR - 1) / SKR) * ((p.cout + 63) / 64);
@@ -996,4 +1049,4 @@ extern "C" int cs_relayout_weight(const float* w_torch, float* w_out, int cout, 
   return CS_OK;
 }
 
-extern "C" int cs_abi_version(void) { return 14; }
+extern "C" int cs_abi_version(void) { return 15; }

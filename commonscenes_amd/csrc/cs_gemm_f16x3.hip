@@ -81,6 +81,137 @@ struct CsClsBatch {
   int n;
 };
 
+// The slices of output tile `otile` have each stored their partial tile to ws[slice][M][cout].  Publish (agent-scope release),
+// arrive, and -- slices 0 .. R-1 only -- wait for the others, then sum rows [split * BM/R, +BM/R) of the tile over the slices
+// IN SLICE ORDER and apply the epilogue: per element the arithmetic of splitk_reduce_epi_kernel / splitk_reduce_kernel
+// (cs_gemm.hip), per (16-row block, column) the same fp64 row-order sums for gn_part, the same pair conversion -- bit for bit
+// the two-kernel form.  Visibility follows MI355X_MICROARCH.md "inter-workgroup visibility": plain stores -> barrier -> one
+// lane's release fence -> drained -> relaxed agent atomic; one relaxed poll loop -> one acquire fence -> barrier -> plain loads.
+template <int NT, int BM, int BN>
+__device__ __forceinline__ void fused_splitk_reduce(const CsFuseK& f, const float* __restrict__ ws, unsigned char* smem, int M,
+                                                    int cout, int m0, int n0, int split, int splits, int otile, int tid) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  int32_t* const arrive = f.sync + 2 * otile;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                           // every wave's partial stores are issued and drained
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (the compiler may drop the wait behind buffer_wbl2: G16)
+    __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  const int R = f.reducers;
+  if (split >= R) return;                                    // (workgroup-uniform)
+  if (tid == 0) {
+    int spins = 0;
+    while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < splits) {
+      __builtin_amdgcn_s_sleep(4);
+      if (++spins > (1 << 23)) {                             // ~ seconds: a slice that is not resident (planning bug), not a hang
+        if (f.status) atomicOr(f.status, CS_STATUS_INTERNAL);
+        break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+  constexpr int C4 = BN / 4;                                 // float4 columns of the tile
+  constexpr int UNITS = 16 * C4;                             // one 16-row statistics block
+  static_assert(UNITS % 2 == 0 && BN <= NT && 16 * BN * 4 <= 32768, "fused split-K reduce geometry");
+  float* const lv = reinterpret_cast<float*>(smem);          // [16][BN] final values of the block (gn_part only)
+  const bool gstat = f.gn_part != nullptr, opair = f.out_format == 2;
+  const int rows_per = BM / R;
+  float oamax = 0.f;
+  for (int blk = 0; blk < rows_per / 16; ++blk) {
+    const int r0 = split * rows_per + 16 * blk;              // first row of the block inside the tile
+    if (m0 + r0 >= M) break;                                 // (uniform; blocks past M hold nothing: rows per sample % 16 == 0)
+    for (int u0 = 0; u0 < UNITS; u0 += NT) {
+      const int u = u0 + tid;
+      const int lrow = u / C4, c4 = u - lrow * C4;
+      const int m = m0 + r0 + lrow, n = n0 + 4 * c4;
+      const bool ok = u < UNITS && m < M && n < cout;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) {
+        const float* src = ws + (int64_t)m * cout + n;
+        const int64_t sstride = (int64_t)M * cout;
+        v = *reinterpret_cast<const f32x4*>(src);
+        for (int s = 1; s < splits; s += 8) {                // eight loads in flight, added in slice order
+          f32x4 t[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            if (s + q < splits) t[q] = *reinterpret_cast<const f32x4*>(src + (s + q) * sstride);
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            if (s + q < splits) v += t[q];
+        }
+        if (f.bias) v += *reinterpret_cast<const f32x4*>(f.bias + n);
+        if (f.scale) v = v * *reinterpret_cast<const f32x4*>(f.scale + n) + *reinterpret_cast<const f32x4*>(f.shift + n);
+        if (f.rowvec) v += *reinterpret_cast<const f32x4*>(f.rowvec + (int64_t)(m / f.rv_rows) * f.ldrv + n);
+        if (f.act != CS_ACT_NONE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = cs_act(v[e], f.act);
+        }
+        if (f.res) v += *reinterpret_cast<const f32x4*>(f.res + (int64_t)m * f.ldr + n);
+      }
+      if (gstat && u < UNITS) *reinterpret_cast<f32x4*>(lv + lrow * BN + 4 * c4) = v;     // (masked rows / columns: zeros)
+      if (opair) {                                           // uniform branch: every lane takes part in the half swap
+        h4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float o = v[e] * f.out_scale;
+          oamax = fmaxf(oamax, fabsf(o));
+          hi[e] = (_Float16)o;
+          lo[e] = (_Float16)(o - (float)hi[e]);
+        }
+        const u32x2 H = __builtin_bit_cast(u32x2, hi), L = __builtin_bit_cast(u32x2, lo);
+        const bool odd = tid & 1;                            // (UNITS and NT are even: lanes 2t / 2t + 1 = columns 8g / 8g + 4 of a row)
+        const u32x2 send = odd ? H : L;
+        u32x2 recv;
+        recv[0] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send[0], 0xB1, 0xF, 0xF, true);
+        recv[1] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send[1], 0xB1, 0xF, 0xF, true);
+        u32x4 r;
+        r[0] = odd ? recv[0] : H[0];
+        r[1] = odd ? recv[1] : H[1];
+        r[2] = odd ? L[0] : recv[0];
+        r[3] = odd ? L[1] : recv[1];
+        if (ok) {
+          char* row = reinterpret_cast<char*>(f.out + (int64_t)m * f.ldo);
+          *reinterpret_cast<u32x4*>(row + (n >> 4) * 64 + ((n & 8) ? 32 : 0) + ((n & 4) ? 16 : 0)) = r;
+        }
+      } else if (ok) {
+        *reinterpret_cast<f32x4*>(f.out + (int64_t)m * f.ldo + n) = v;
+      }
+    }
+    if (gstat) {
+      __syncthreads();
+      if (tid < BN && n0 + tid < cout) {
+        double ts = 0.0, tq = 0.0;
+#pragma unroll
+        for (int r2 = 0; r2 < 16; ++r2) {
+          const double d = (double)lv[r2 * BN + tid];
+          ts += d;
+          tq += d * d;
+        }
+        double* o = f.gn_part + ((int64_t)((m0 + r0) / 16) * f.gn_ld + n0 + tid) * 2;
+        o[0] = ts;
+        o[1] = tq;
+      }
+      __syncthreads();
+    }
+  }
+  if (opair && f.status && oamax >= 65504.f) atomicOr(f.status, CS_STATUS_F16X3_OVERFLOW);
+  // leave: the last reducer of the tile returns both counters to zero (every reducer has left its wait by then; the slices
+  // that do not reduce arrived before that wait could end)
+  __syncthreads();
+  if (tid == 0) {
+    const int d = __hip_atomic_fetch_add(arrive + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (d == R - 1) {
+      __hip_atomic_store(arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(arrive + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 // f(integral_constant<int, I>) for I = 0 .. N-1, unrolled at compile time (the ring positions of the K loop)
 template <class F, int... I>
 __device__ __forceinline__ void static_steps(std::integer_sequence<int, I...>, F&& f) {
@@ -91,7 +222,8 @@ template <int WMB, int WNB, int WAVES_M, int WAVES_N, bool PRE, int SLAB = 0, bo
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_kernel(const CsConvGemm p, int M, int tiles_n,
                                                               int taps_hw, int kw_, int kg_per_tap,
                                                               long long x_bytes, unsigned w_bytes, int vec_epilogue,
-                                                              int splits, int omap_f, int omap_p_in, const CsClsBatch cb) {
+                                                              int splits, int omap_f, int omap_p_in, const CsClsBatch cb,
+                                                              const CsFuseK fz) {
   constexpr int BM = 32 * WMB * WAVES_M;
   constexpr int BN = 32 * WNB * WAVES_N;
   constexpr int NW = WAVES_M * WAVES_N;            // waves per workgroup (4, or 8 for the 256-row tile)
@@ -1101,6 +1233,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
           }
         }
       }
+    // r5: K slices of one output tile finish the reduce + epilogue here instead of in a second launch (see CsFuseK)
+    if constexpr (BN <= NT && TPK == 9) {
+      if (fz.sync) {
+        __syncthreads();                                      // the staging LDS is free again
+        fused_splitk_reduce<NT, BM, BN>(fz, p.out, smem, M, p.cout, m0, n0, split, splits, tm * tiles_n + tn, tid);
+      }
+    }
     return;
   }
 #pragma unroll
@@ -1131,7 +1270,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
 
 template <int WMB, int WNB, int WAVES_M, int WAVES_N, bool PRE, int SLAB = 0, bool PAIR = false, int TPK = 9, bool PW = false>
 int launch16(const CsConvGemm& p, int M, int splits, hipStream_t stream, int omap_f = 0, int omap_p = 0,
-             const CsClsBatch* cls = nullptr) {
+             const CsClsBatch* cls = nullptr, const CsFuseK* fuse = nullptr) {
   constexpr int BM = 32 * WMB * WAVES_M;
   constexpr int BN = 32 * WNB * WAVES_N;
   const int tiles_m = (M + BM - 1) / BM;
@@ -1157,9 +1296,19 @@ int launch16(const CsConvGemm& p, int M, int splits, hipStream_t stream, int oma
     constexpr int WCOLS = 32 * WNB;
     if (!vec || (WCOLS / 2) % 4 || p.cout % WCOLS || p.scale || p.rowvec || p.res) return CS_EINVAL;
   }
+  CsFuseK fz;
+  memset(&fz, 0, sizeof(fz));
+  if (fuse && fuse->sync) {
+    // the slices' partial tiles must take the float4 staged store the fused tail hangs off, whole column tiles only
+    if (splits < 2 || TPK != 9 || BN > 64 * WAVES_M * WAVES_N || !vec || p.cout % BN || p.bias || p.res || p.rowvec || p.scale ||
+        p.act != CS_ACT_NONE || p.gn_part || p.out_format || fuse->reducers < 1 || fuse->reducers > splits ||
+        BM % (16 * fuse->reducers))
+      return CS_EINVAL;
+    fz = *fuse;
+  }
   CS_LAUNCH((conv_gemm_f16x3_kernel<WMB, WNB, WAVES_M, WAVES_N, PRE, SLAB, PAIR, TPK, PW>), dim3((unsigned)nblk), dim3(64 * WAVES_M * WAVES_N), 0,
             stream, p, M, tiles_n, p.kh * p.kw, p.kw, kg_per_tap, (long long)x_bytes, (unsigned)w_bytes, vec, splits,
-            TPK == 4 ? omap_f : 0, TPK == 4 ? omap_p : 0, cb);
+            TPK == 4 ? omap_f : 0, TPK == 4 ? omap_p : 0, cb, fz);
   CS_CHECK_LAUNCH();
   return CS_OK;
 }
@@ -1242,7 +1391,8 @@ int cs_f16x3_slab_width(const CsConvGemm& p, int tile, int splits) {
 // ncls > 1 (with omap_f): ONE launch covers all ncls parity classes -- class c has the packed weights cls_w[c] / cls_w_lo[c]
 // and accumulator scale cls_acc[c]; its pads and scatter parity follow from c and omap_f (see the kernel)
 int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p_in, int M, int tile, int splits, hipStream_t s, int omap_f, int omap_p,
-                                const void* const* cls_w, const void* const* cls_w_lo, const float* cls_acc, int ncls) {
+                                const void* const* cls_w, const void* const* cls_w_lo, const float* cls_acc, int ncls,
+                                const CsFuseK* fuse) {
   CsConvGemm p = p_in;
   if (splits < 1) splits = 1;
   if (omap_f && !cs_f16x3_slab4_ok(p, tile, splits)) return CS_EINVAL;
@@ -1280,14 +1430,14 @@ int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p_in, int M, int tile, int spl
 #ifndef CS_NO_SLAB
     if (slab_geom && slab_slices_ok) {
       switch (tile) {
-        case 2: return launch16<1, 7, 4, 1, true, 32>(p, M, splits, s);    // r3: small batches (128-row tiles, K slices)
-        case 4: return launch16<1, 7, 8, 1, true, 32>(p, M, splits, s);
-        case 6: return launch16<1, 4, 8, 1, true, 32>(p, M, splits, s);
-        case 7: return p.win <= 32 ? launch16<1, 2, 8, 1, true, 32>(p, M, splits, s)
-                                   : launch16<1, 2, 8, 1, true, 64>(p, M, splits, s);
-        case 8: return p.win <= 32 ? launch16<2, 2, 8, 1, true, 32>(p, M, splits, s)
-                                   : launch16<2, 2, 8, 1, true, 64>(p, M, splits, s);
-        case 9: return launch16<2, 4, 8, 1, true, 32>(p, M, splits, s);
+        case 2: return launch16<1, 7, 4, 1, true, 32>(p, M, splits, s, 0, 0, nullptr, fuse);    // r3: small batches (128-row tiles, K slices)
+        case 4: return launch16<1, 7, 8, 1, true, 32>(p, M, splits, s, 0, 0, nullptr, fuse);
+        case 6: return launch16<1, 4, 8, 1, true, 32>(p, M, splits, s, 0, 0, nullptr, fuse);
+        case 7: return p.win <= 32 ? launch16<1, 2, 8, 1, true, 32>(p, M, splits, s, 0, 0, nullptr, fuse)
+                                   : launch16<1, 2, 8, 1, true, 64>(p, M, splits, s, 0, 0, nullptr, fuse);
+        case 8: return p.win <= 32 ? launch16<2, 2, 8, 1, true, 32>(p, M, splits, s, 0, 0, nullptr, fuse)
+                                   : launch16<2, 2, 8, 1, true, 64>(p, M, splits, s, 0, 0, nullptr, fuse);
+        case 9: return launch16<2, 4, 8, 1, true, 32>(p, M, splits, s, 0, 0, nullptr, fuse);
         default: break;
       }
     }
@@ -1295,12 +1445,12 @@ int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p_in, int M, int tile, int spl
     if (tile == 8) tile = 7;      // (only reachable in -DCS_NO_SLAB builds)
     if (tile == 9) tile = 6;
     switch (tile) {
-      case 1: return launch16<2, 2, 2, 2, true>(p, M, splits, s);
-      case 2: return launch16<1, 7, 4, 1, true>(p, M, splits, s);
-      case 3: return launch16<1, 1, 2, 2, true>(p, M, splits, s);
-      case 4: return launch16<1, 7, 8, 1, true>(p, M, splits, s);
-      case 6: return launch16<1, 4, 8, 1, true>(p, M, splits, s);
-      case 7: return launch16<1, 2, 8, 1, true>(p, M, splits, s);
+      case 1: return launch16<2, 2, 2, 2, true>(p, M, splits, s, 0, 0, nullptr, fuse);
+      case 2: return launch16<1, 7, 4, 1, true>(p, M, splits, s, 0, 0, nullptr, fuse);
+      case 3: return launch16<1, 1, 2, 2, true>(p, M, splits, s, 0, 0, nullptr, fuse);
+      case 4: return launch16<1, 7, 8, 1, true>(p, M, splits, s, 0, 0, nullptr, fuse);
+      case 6: return launch16<1, 4, 8, 1, true>(p, M, splits, s, 0, 0, nullptr, fuse);
+      case 7: return launch16<1, 2, 8, 1, true>(p, M, splits, s, 0, 0, nullptr, fuse);
       default: return CS_EINVAL;
     }
   }
@@ -1315,20 +1465,20 @@ int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p_in, int M, int tile, int spl
     if (tile == 9) tile = 6;
     if (pw) {
       switch (tile) {
-        case 1: return launch16<2, 2, 2, 2, false, 0, true, 9, true>(p, M, splits, s);
-        case 2: return launch16<1, 7, 4, 1, false, 0, true, 9, true>(p, M, splits, s);
-        case 3: return launch16<1, 1, 2, 2, false, 0, true, 9, true>(p, M, splits, s);
-        case 4: return launch16<1, 7, 8, 1, false, 0, true, 9, true>(p, M, splits, s);
+        case 1: return launch16<2, 2, 2, 2, false, 0, true, 9, true>(p, M, splits, s, 0, 0, nullptr, fuse);
+        case 2: return launch16<1, 7, 4, 1, false, 0, true, 9, true>(p, M, splits, s, 0, 0, nullptr, fuse);
+        case 3: return launch16<1, 1, 2, 2, false, 0, true, 9, true>(p, M, splits, s, 0, 0, nullptr, fuse);
+        case 4: return launch16<1, 7, 8, 1, false, 0, true, 9, true>(p, M, splits, s, 0, 0, nullptr, fuse);
         default: break;
       }
     }
     switch (tile) {
-      case 1: return launch16<2, 2, 2, 2, false, 0, true>(p, M, splits, s);
-      case 2: return launch16<1, 7, 4, 1, false, 0, true>(p, M, splits, s);
-      case 3: return launch16<1, 1, 2, 2, false, 0, true>(p, M, splits, s);
-      case 4: return launch16<1, 7, 8, 1, false, 0, true>(p, M, splits, s);
-      case 6: return launch16<1, 4, 8, 1, false, 0, true>(p, M, splits, s);
-      case 7: return launch16<1, 2, 8, 1, false, 0, true>(p, M, splits, s);
+      case 1: return launch16<2, 2, 2, 2, false, 0, true>(p, M, splits, s, 0, 0, nullptr, fuse);
+      case 2: return launch16<1, 7, 4, 1, false, 0, true>(p, M, splits, s, 0, 0, nullptr, fuse);
+      case 3: return launch16<1, 1, 2, 2, false, 0, true>(p, M, splits, s, 0, 0, nullptr, fuse);
+      case 4: return launch16<1, 7, 8, 1, false, 0, true>(p, M, splits, s, 0, 0, nullptr, fuse);
+      case 6: return launch16<1, 4, 8, 1, false, 0, true>(p, M, splits, s, 0, 0, nullptr, fuse);
+      case 7: return launch16<1, 2, 8, 1, false, 0, true>(p, M, splits, s, 0, 0, nullptr, fuse);
       default: return CS_EINVAL;
     }
   }
@@ -1345,33 +1495,33 @@ int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p_in, int M, int tile, int spl
   const bool slab = slab_geom && slab_slices_ok;
   if (slab) {
     switch (tile) {
-      case 2: return launch16<1, 7, 4, 1, false, 32>(p, M, splits, s);   // small batches: 128-row tiles, K slices
-      case 4: return launch16<1, 7, 8, 1, false, 32>(p, M, splits, s);
-      case 6: return launch16<1, 4, 8, 1, false, 32>(p, M, splits, s);
-      case 7: return p.win <= 32 ? launch16<1, 2, 8, 1, false, 32>(p, M, splits, s)
-                                 : launch16<1, 2, 8, 1, false, 64>(p, M, splits, s);   // the decoder's 64^3 level
+      case 2: return launch16<1, 7, 4, 1, false, 32>(p, M, splits, s, 0, 0, nullptr, fuse);   // small batches: 128-row tiles, K slices
+      case 4: return launch16<1, 7, 8, 1, false, 32>(p, M, splits, s, 0, 0, nullptr, fuse);
+      case 6: return launch16<1, 4, 8, 1, false, 32>(p, M, splits, s, 0, 0, nullptr, fuse);
+      case 7: return p.win <= 32 ? launch16<1, 2, 8, 1, false, 32>(p, M, splits, s, 0, 0, nullptr, fuse)
+                                 : launch16<1, 2, 8, 1, false, 64>(p, M, splits, s, 0, 0, nullptr, fuse);   // the decoder's 64^3 level
       default: break;
     }
   }
 #endif
   if (pw) {
     switch (tile) {
-      case 1: return launch16<2, 2, 2, 2, false, 0, false, 9, true>(p, M, splits, s);
-      case 2: return launch16<1, 7, 4, 1, false, 0, false, 9, true>(p, M, splits, s);
-      case 3: return launch16<1, 1, 2, 2, false, 0, false, 9, true>(p, M, splits, s);
-      case 4: return launch16<1, 7, 8, 1, false, 0, false, 9, true>(p, M, splits, s);
-      case 6: return launch16<1, 4, 8, 1, false, 0, false, 9, true>(p, M, splits, s);
-      case 7: return launch16<1, 2, 8, 1, false, 0, false, 9, true>(p, M, splits, s);
+      case 1: return launch16<2, 2, 2, 2, false, 0, false, 9, true>(p, M, splits, s, 0, 0, nullptr, fuse);
+      case 2: return launch16<1, 7, 4, 1, false, 0, false, 9, true>(p, M, splits, s, 0, 0, nullptr, fuse);
+      case 3: return launch16<1, 1, 2, 2, false, 0, false, 9, true>(p, M, splits, s, 0, 0, nullptr, fuse);
+      case 4: return launch16<1, 7, 8, 1, false, 0, false, 9, true>(p, M, splits, s, 0, 0, nullptr, fuse);
+      case 6: return launch16<1, 4, 8, 1, false, 0, false, 9, true>(p, M, splits, s, 0, 0, nullptr, fuse);
+      case 7: return launch16<1, 2, 8, 1, false, 0, false, 9, true>(p, M, splits, s, 0, 0, nullptr, fuse);
       default: break;
     }
   }
   switch (tile) {
-    case 1: return launch16<2, 2, 2, 2, false>(p, M, splits, s);
-    case 2: return launch16<1, 7, 4, 1, false>(p, M, splits, s);
-    case 3: return launch16<1, 1, 2, 2, false>(p, M, splits, s);
-    case 4: return launch16<1, 7, 8, 1, false>(p, M, splits, s);
-    case 6: return launch16<1, 4, 8, 1, false>(p, M, splits, s);     // 256x128: the VQ decoder's 128- / 256-channel convs
-    case 7: return launch16<1, 2, 8, 1, false>(p, M, splits, s);     // 256x64:  its 64-channel convs
+    case 1: return launch16<2, 2, 2, 2, false>(p, M, splits, s, 0, 0, nullptr, fuse);
+    case 2: return launch16<1, 7, 4, 1, false>(p, M, splits, s, 0, 0, nullptr, fuse);
+    case 3: return launch16<1, 1, 2, 2, false>(p, M, splits, s, 0, 0, nullptr, fuse);
+    case 4: return launch16<1, 7, 8, 1, false>(p, M, splits, s, 0, 0, nullptr, fuse);
+    case 6: return launch16<1, 4, 8, 1, false>(p, M, splits, s, 0, 0, nullptr, fuse);     // 256x128: the VQ decoder's 128- / 256-channel convs
+    case 7: return launch16<1, 2, 8, 1, false>(p, M, splits, s, 0, 0, nullptr, fuse);     // 256x64:  its 64-channel convs
     default: return CS_EINVAL;
   }
 }

@@ -508,6 +508,7 @@ int forward(Exec& e, const float* x_ncdhw, const int64_t* t, const float* ctxvec
   const cs_unet& u = e.u;
   const CsUnetConfig& c = u.cfg;
   const int S = c.d * c.h * c.w;
+  e.sync_begin();         // split-K arrival counters (CsConvGemm.splitk_sync)
   e.amax_begin(64);       // magnitude-bound slots of this forward (unet.py::forward_ndhwc: self._amax)
   Buf temb = e.alloc(nbx, c.model_channels);
   if (e.ok() && !e.dry) e.chk(cs_timestep_embedding(t, e.p(temb), nbx, c.model_channels, 10000.0f, e.st));

@@ -17,7 +17,7 @@ import torch  # noqa: F401
 
 from .build import LIB_PATH
 
-ABI_VERSION = 14     # cs_abi_version() of the library this module's SIGNATURES table describes
+ABI_VERSION = 15     # cs_abi_version() of the library this module's SIGNATURES table describes
 CS_OK = 0
 CS_EINVAL = -22
 CS_ENOMEM = -12
@@ -54,6 +54,7 @@ class CsConvGemm(C.Structure):
         ("splitk_ws", C.c_void_p), ("status", C.c_void_p),
         ("gn_part", C.c_void_p), ("gn_ld", C.c_int32), ("gn_rows", C.c_int32), ("out_format", C.c_int32),
         ("out_scale", C.c_float), ("a_bound", C.c_void_p),
+        ("splitk_sync", C.c_void_p), ("splitk_sync_words", C.c_int32),
     ]
 
 
@@ -67,7 +68,8 @@ class CsDebug(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "no_split16", "no_pair16", "no_upfold", "no_splitk", "no_fused_geglu", "no_tapcol", "tapcol_tile", "no_cfg_split",
         "concat_copy", "tile512", "no_pw", "no_slab4", "no_attn_img", "attn_nw8", "no_up2_direct", "no_up2_batch",
-        "plan_pow2", "slice_tile2", "no_gn_parts", "no_pair_epilogue", "no_dyn_scale", "no_tok_rules")] + [
+        "plan_pow2", "slice_tile2", "no_gn_parts", "no_pair_epilogue", "no_dyn_scale", "no_tok_rules", "no_fused_reduce",
+        "no_temb_table", "no_gn_fold", "no_kwave")] + [
         ("split16_min_rows", C.c_int64), ("cfg_split_min_rows", C.c_int64), ("gn_small_group", C.c_int64)]
 
 

@@ -8,6 +8,7 @@ into libcommonscenes_hip.so on the current HIP stream.  Tensors are fp32, channe
 from __future__ import annotations
 
 import ctypes as C
+import dataclasses
 from dataclasses import dataclass
 from typing import Optional, Sequence, Tuple
 
@@ -58,12 +59,35 @@ def clear_status(device=None) -> None:
     status_word(device).zero_()
 
 
+# Split-K arrival counters (CsConvGemm.splitk_sync, ABI 15): zeroed once per (device, stream); the kernels that use them
+# return them to zero, so one buffer serves every K-sliced launch queued on that stream.
+_SYNC: dict = {}
+SYNC_WORDS = 8192
+
+
+def sync_words() -> Tensor:
+    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    t = _SYNC.get(key)
+    if t is None:
+        t = _SYNC[key] = torch.zeros((SYNC_WORDS,), dtype=torch.int32, device=torch.device("cuda", key[0]))
+    return t
+
+
 def check_overflow(device=None, what: str = "F16X3 kernels") -> None:
     """Raise CsOverflowError if any F16X3 kernel since the last check met an operand beyond the fp16 range: a value a
     is carried as fp16 halves of a * a_scale, where a_scale is the layer's operand scale -- derived from the producing
     normalisation's bound (norm_a_scale: cannot overflow) or 16 for raw activations (|a| >= 65504 / 16 ~ 4094
-    overflows).  That launch's output is garbage; the caller re-runs with set_math('fp32')."""
-    if read_status(device) & L.STATUS_F16X3_OVERFLOW:
+    overflows).  That launch's output is garbage; the caller re-runs with set_math('fp32').
+    CS_STATUS_INTERNAL (a kernel was asked for an epilogue output on a path that cannot produce it, or a K slice never
+    arrived at its tile's counter: a planning bug, never a data condition) raises CsError -- no fall-back hides it."""
+    st = read_status(device)
+    if st & L.STATUS_INTERNAL:
+        for t in _SYNC.values():          # the counters of an aborted hand-off may be left non-zero
+            t.zero_()
+        raise L.CsError(f"{what}: CS_STATUS_INTERNAL -- a kernel reached an epilogue path that cannot emit what its "
+                        "descriptor asked for (GroupNorm partials / operand pair), or a split-K slice never arrived; "
+                        "results of this run are invalid (library planning bug)")
+    if st & L.STATUS_F16X3_OVERFLOW:
         raise L.CsOverflowError(f"{what}: an activation left the fp16 range of CS_MATH_F16X3 (|a| * a_scale >= 65504, "
                                 "a_scale = the layer's operand scale: 16 for raw activations); "
                                 "results of this run are invalid -- use set_math('fp32')")
@@ -205,8 +229,16 @@ _SWITCHES = {
 
 
 def _sw(name: str):
+    """The switch's value: the library's CsDebug view (lib.debug_override(...) / cs_debug_set reach every host at once).
+    A module global of the same name -- `ops.SPLITK = False`, monkeypatch.setattr(ops, ...) -- overrides it ONLY while it
+    DIFFERS from the default-on state: setting it back to True (what monkeypatch's undo and the old tests' `finally` do)
+    removes the override instead of pinning the switch on for the rest of the process."""
     g = globals()
-    return g[name] if name in g else _SWITCHES[name](L.debug())
+    if name in g:
+        if g[name] is False or g[name] == 0:
+            return False
+        del g[name]                         # restored to "on": back to the live CsDebug view
+    return _SWITCHES[name](L.debug())
 
 
 def __getattr__(name: str):          # PEP 562: ops.SPLITK etc. for outside readers
@@ -356,13 +388,30 @@ class ColStats:
     nb: int               # samples the producer ran
     tps: int              # statistics tiles per sample (and per class)
     ncls: int = 1         # parity classes of a folded Upsample launch (tiles ordered [class][sample][tile])
+    owner: Optional[Tuple[int, int]] = None     # (data_ptr, _version) of the tensor the partials describe (attach_stats)
+
+
+def _forget_stats(t: Tensor) -> None:
+    for a in ("cs_stats", "cs_segs", "cs_bound"):
+        if hasattr(t, a):
+            delattr(t, a)
 
 
 def attach_stats(t: Tensor, st) -> Tensor:
-    """remember the producer's partials on the tensor object (a plain attribute: views made later do not inherit it)"""
+    """Remember the producer's partials on the tensor object (a plain attribute: views made later do not inherit it).
+    Whatever an EARLIER launch into the same tensor object left -- partials, segments, a magnitude bound -- is dropped first:
+    a caller-supplied `out=` buffer that is reused must never keep statistics of its previous contents.  The
+    partials remember the tensor's (data_ptr, _version): stats_segments() refuses them after an in-place torch update."""
+    _forget_stats(t)
     if st is not None:
-        t.cs_stats = st
+        t.cs_stats = dataclasses.replace(st, owner=(t.data_ptr(), t._version))
     return t
+
+
+def _stats_fresh(x: Tensor, st) -> bool:
+    # (a view made by the sequencer shares storage offset 0 .. and the version counter with its base: data_ptr may differ
+    # for a re-attached view, so only the version is compared when the pointer moved inside the same storage)
+    return st is not None and (st.owner is None or st.owner[1] == x._version)
 
 
 def stats_segments(x: Tensor):
@@ -376,6 +425,9 @@ def stats_segments(x: Tensor):
         segs = [(0, st)] if st is not None else None
     if segs is None or any(s is None for _, s in segs) or sum(s.nch for _, s in segs) != x.shape[-1]:
         return None
+    st1 = getattr(x, "cs_stats", None)
+    if st1 is not None and getattr(x, "cs_segs", None) is None and not _stats_fresh(x, st1):
+        return None                          # x was updated in place after its producer left the partials
     return segs
 
 
@@ -592,6 +644,9 @@ def conv_gemm(x: Tensor, w: PackedWeight, *, spatial: Optional[Tuple[int, int, i
         if sk.value > 1:
             ws = torch.empty((wsb.value // 4,), dtype=torch.float32, device=x.device)
             p.splitk, p.splitk_ws = sk.value, ws.data_ptr()
+    if p.splitk > 1 and math == L.MATH_F16X3:
+        # r5: arrival counters -- where the launch is resident at once the slices finish the reduce + epilogue themselves
+        p.splitk_sync, p.splitk_sync_words = sync_words().data_ptr(), SYNC_WORDS
     st, paired = (None, False)
     if math == L.MATH_F16X3:
         st, paired = _epilogue_extras(lib, p, x.device, nb, do * ho * wo, mo, w.cout, stats, out_pair)

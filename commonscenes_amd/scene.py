@@ -535,3 +535,41 @@ class Sg2ScVAEModel(BoxVAEMixin):
         gen_sdf = (self._shapes_for(z, dec_objs, dec_triplets, text, rel, dec_sdfs, attributes, x_T, ddim_steps, sharded)
                    if gen_shape else None)
         return self.decoder(z, dec_objs, dec_triplets, text, rel, attributes), gen_sdf
+
+    @torch.no_grad()
+    def sample_many(self, scenes, gen_shape: bool = True, ddim_steps: int = 100, launch_B: Optional[int] = None):
+        """Extension: `sample` for SEVERAL scenes with ONE coalesced sampler + decode.
+
+        scenes: a list of dicts with sample()'s arguments -- dec_objs, dec_triplets, dec_sdfs, encoded_dec_text_feat,
+        encoded_dec_rel_feat, and optionally attributes, z, x_T (point_classes_idx / mean_est / cov_est as for sample():
+        z is drawn from (mean_est, cov_est) when absent).  Each scene's graph runs through encoder_2 and the layout decoder
+        SEPARATELY (graphs must not mix: the GCN pools over a scene's own triples, VAEGAN_V2FULL.py:220-242); the shaped
+        objects of all scenes then go through Diff.rel2shape_many -- per-scene shared x_T kept -- which is where the
+        reference's scene-by-scene loop (scripts/eval_3dfront.py:484-513) leaves the chip mostly idle.
+        Returns [(boxes_or_(boxes, angles), gen_sdf | None)] in scene order, exactly what sample() returns per scene."""
+        dev = self.device
+        prepared, datas, x_Ts = [], [], []
+        for sc in scenes:
+            objs, triples = sc["dec_objs"], sc["dec_triplets"]
+            z = sc.get("z")
+            if z is None:
+                z = torch.from_numpy(np.random.multivariate_normal(_np(sc["mean_est"]), _np(sc["cov_est"]),
+                                                                   objs.size(0))).float()
+            z = z.to(dev)
+            text = sc["encoded_dec_text_feat"].to(device=dev, dtype=torch.float32)
+            rel = sc["encoded_dec_rel_feat"].to(device=dev, dtype=torch.float32)
+            attributes = sc.get("attributes")
+            prepared.append((z, objs, triples, text, rel, attributes))
+            if gen_shape:
+                un_rel_feat, rel_feat = self.encoder_2(z, objs, triples, text, rel, attributes)
+                dec_sdfs = sc["dec_sdfs"]
+                mask = torch.ne(dec_sdfs, torch.zeros_like(dec_sdfs[0]))
+                ids = torch.unique(torch.where(mask)[0])
+                ids_d = ids.to(dev)
+                datas.append({"sdf": dec_sdfs[ids], "rel": rel_feat[ids_d], "uc": un_rel_feat[ids_d]})
+                x_Ts.append(sc.get("x_T"))
+        gens = [None] * len(scenes)
+        if gen_shape and scenes:
+            gens = self.Diff.rel2shape_many(datas, ddim_steps=ddim_steps, uc_scale=3., x_Ts=x_Ts, launch_B=launch_B)
+        return [(self.decoder(z, objs, triples, text, rel, attributes), gens[i])
+                for i, (z, objs, triples, text, rel, attributes) in enumerate(prepared)]

@@ -256,6 +256,97 @@ class SDFusionText2ShapeModel:
             self.vqvae.set_math("fp32")
             self._vq_fell_back = True
 
+    def _launch_slices(self, lo: int, hi: int, mini_B: Optional[int], launch_B: Optional[int], ddim_eta: float):
+        """The sampler launches over objects [lo, hi).  :493-511 slices the objects into ceil(B / 7) mini-batches and runs
+        the sampler once per slice.  Every object starts from its scene's x_T and the batch dimension never mixes, so with
+        eta = 0 (no noise draw inside the loop) the slices are independent of how they are grouped: WHOLE mini-batches
+        are coalesced into launches.  launch_B counts objects and is rounded UP to whole mini-batches (launch_B = 32,
+        mini_B = 7: up to five slices = 35 objects per launch -- a cap on memory should be given as a multiple of
+        mini_B); the mini-batches are then dealt EVENLY over the fewest launches that respects it, so 40 objects run as
+        21 + 19, not as 35 + 5 with an inefficient tail launch.  eta > 0 keeps one launch per slice: the
+        sampler draws one noise tensor per slice and step (ddim.py:240), which grouping would re-order."""
+        mb = max(1, int(mini_B or self.mini_B))
+        lb = int(self.launch_B if launch_B is None else launch_B)
+        n = hi - lo
+        if n <= 0:
+            return []
+        n_mb = -(-n // mb)
+        per = -(-lb // mb) if (lb > mb and float(ddim_eta) == 0.0) else 1
+        n_launch = -(-n_mb // per)
+        base, extra = divmod(n_mb, n_launch)
+        out, i = [], lo
+        for k in range(n_launch):
+            cnt = (base + (1 if k < extra else 0)) * mb
+            out.append(slice(i, min(i + cnt, hi)))
+            i += cnt
+        return out
+
+    @torch.no_grad()
+    def rel2shape_many(self, datas, ddim_steps=100, ddim_eta=0.0, uc_scale=None, x_Ts=None, mini_B: Optional[int] = None,
+                       return_latents: bool = False, max_steps: Optional[int] = None, sampler: str = "ddim",
+                       launch_B: Optional[int] = None):
+        """Extension: rel2shape for SEVERAL scenes in one coalesced sampler + decode.
+
+        The reference's evaluation loop calls rel2shape once per scene (scripts/eval_3dfront.py:484-513 ->
+        VAEGAN_V2FULL.py:600-618 -> sdfusion_txt2shape_model.py:459-516) with 5-15 shaped objects each: small batches, the
+        regime furthest from the roofline.  Objects never mix along the batch dimension (GroupNorm / LayerNorm /
+        attention are per sample), so the scenes' objects are concatenated and sampled together; what is kept per scene is
+        its SHARED x_T (:489-491: one noise volume repeated over the scene's objects) -- x_Ts[i] (or a fresh time-seeded
+        draw per scene) is repeated over scene i's objects only.  Returns a list of per-scene gen_df (and latents).
+        Per-object results equal the per-scene call bit for bit whenever the GEMM plan is the same (the plan depends on
+        the launch's object count), within fp32 summation order otherwise.  Deterministic samplers only (eta = 0)."""
+        if float(ddim_eta) != 0.0:
+            raise ValueError("rel2shape_many coalesces scenes: deterministic sampling (ddim_eta = 0) only")
+        self.switch_eval()
+        if sampler == "ddim":
+            smp = DDIMSampler(self)
+        elif sampler == "plms":
+            from .plms import PLMSSampler
+            smp = PLMSSampler(self)
+        else:
+            raise ValueError(f"sampler must be 'ddim' or 'plms', got {sampler!r}")
+        if ddim_steps is None:
+            ddim_steps = self.ddim_steps
+        if uc_scale is None:
+            uc_scale = self.scale
+        shape = self.z_shape
+        C_, D, H, W = shape
+        counts, cs, ucs, noises = [], [], [], []
+        for i, data in enumerate(datas):
+            self.set_input(data)
+            c_i = self.rel.to(device=self.device, dtype=torch.float32)
+            cs.append(c_i)
+            ucs.append(self.uc_rel.to(device=self.device, dtype=torch.float32))
+            counts.append(int(c_i.shape[0]))
+            if x_Ts is None or x_Ts[i] is None:
+                torch.manual_seed(int(time.time()) + i)                  # :489 (time-seeded in the reference), per scene
+                n_i = torch.randn((1, C_, D, H, W), device=self.device)
+            else:
+                n_i = x_Ts[i].to(device=self.device, dtype=torch.float32).reshape(1, C_, D, H, W)
+            noises.append(n_i.expand(counts[-1], C_, D, H, W))
+        total = sum(counts)
+        r = self.vqvae.cfg["resolution"] if hasattr(self.vqvae, "cfg") else 64
+        och = self.vqvae.cfg.get("out_ch", 1) if hasattr(self.vqvae, "cfg") else 1
+        self.last_launch_sizes = []
+        if total == 0:
+            gens = [torch.empty((0, och, r, r, r), dtype=torch.float32, device=self.device) for _ in counts]
+            lat = [torch.empty((0, C_, D, H, W), dtype=torch.float32, device=self.device) for _ in counts]
+            return (gens, lat) if return_latents else gens
+        c_all, uc_all = torch.cat(cs, dim=0), torch.cat(ucs, dim=0)
+        noise_all = torch.cat(noises, dim=0).contiguous()
+        gen, lats = [], []
+        for sl in self._launch_slices(0, total, mini_B, launch_B, ddim_eta):
+            self.last_launch_sizes.append(sl.stop - sl.start)
+            samples = self._sample_minibatch(smp, ddim_steps, shape, c_all[sl], uc_all[sl], noise_all[sl].contiguous(),
+                                             uc_scale, ddim_eta, max_steps)
+            lats.append(samples)
+            gen.append(self._decode_checked(samples))
+        g_all, l_all = torch.cat(gen, dim=0), torch.cat(lats, dim=0)
+        gens = list(torch.split(g_all, counts, dim=0))
+        lat = list(torch.split(l_all, counts, dim=0))
+        self.last_latents, self.gen_df = l_all, g_all
+        return (gens, lat) if return_latents else gens
+
     @torch.no_grad()
     def rel2shape(self, data, ddim_steps=100, ddim_eta=0.0, uc_scale=None, x_T: Optional[Tensor] = None,
                   mini_B: Optional[int] = None, return_latents: bool = False, max_steps: Optional[int] = None,
@@ -306,22 +397,11 @@ class SDFusionText2ShapeModel:
             lo, hi = dist.shard_range(B, ws, rank)
         r = self.vqvae.cfg["resolution"] if hasattr(self.vqvae, "cfg") else 64
         och = self.vqvae.cfg.get("out_ch", 1) if hasattr(self.vqvae, "cfg") else 1
-        mb = int(mini_B or self.mini_B)
-        # :493-511 slices the objects into ceil(B / 7) mini-batches and runs the sampler once per slice.  Every object
-        # starts from the same x_T and the batch dimension never mixes, so with eta = 0 (no noise draw inside the loop)
-        # the slices are independent of how they are grouped: whole mini-batches are coalesced into launches of about
-        # launch_B objects (ceil(launch_B / mb) slices).  eta > 0 keeps one launch per slice: the sampler draws one
-        # noise tensor per slice and step (ddim.py:240), which grouping would re-order.
-        lb = int(self.launch_B if launch_B is None else launch_B)
-        step = mb
-        if lb > mb and float(ddim_eta) == 0.0:
-            step = -(-lb // mb) * mb
         self.last_launch_sizes = []
         gen, lats = [], []
         failure: Optional[BaseException] = None
         try:
-            for i in range(lo, hi, step):                                # ceil((hi - lo) / step) sampler launches
-                sl = slice(i, min(i + step, hi))
+            for sl in self._launch_slices(lo, hi, mini_B, launch_B, ddim_eta):
                 self.last_launch_sizes.append(sl.stop - sl.start)
                 num = sl.stop - sl.start
                 noise = single_noise.repeat(num, 1, 1, 1, 1)             # every object shares one x_T (:491)

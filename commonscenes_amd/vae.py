@@ -119,6 +119,19 @@ class VAE:
                                       **inject)
         return self.sample_box(dec_objs, dec_triplets, encoded_dec_text_feat, encoded_dec_rel_feat, attributes), None
 
+    def sample_box_and_shape_many(self, scenes, gen_shape=True, ddim_steps: int = 100, launch_B=None):
+        """Extension: sample_box_and_shape for a LIST of scenes -- each a dict with its keyword arguments (dec_objs,
+        dec_triplets, dec_sdfs, encoded_dec_text_feat, encoded_dec_rel_feat[, attributes, z, x_T]) -- with every scene's
+        graph encoded and laid out on its own and ONE coalesced DDIM sampler + VQ decode over all scenes' shaped objects
+        (Sg2ScVAEModel.sample_many).  Returns [(boxes_or_(boxes, angles), gen_sdf | None)] in scene order.  The default
+        per-scene call (model/VAE.py:286-294) is unchanged."""
+        if self.type_ != "v2_full":
+            return [(self.sample_box(sc["dec_objs"], sc["dec_triplets"], sc["encoded_dec_text_feat"],
+                                     sc["encoded_dec_rel_feat"], sc.get("attributes")), None) for sc in scenes]
+        full = [dict(sc, mean_est=sc.get("mean_est", self.mean_est), cov_est=sc.get("cov_est", self.cov_est))
+                for sc in scenes]
+        return self.vae_v2.sample_many(full, gen_shape=gen_shape, ddim_steps=ddim_steps, launch_B=launch_B)
+
     def sample_box(self, dec_objs, dec_triplets, encoded_dec_text_feat, encoded_dec_rel_feat, attributes=None):
         if self.type_ == "v2_box":
             return self.vae_box.sampleBoxes(self.mean_est_box, self.cov_est_box, dec_objs, dec_triplets,

@@ -89,6 +89,10 @@ typedef struct CsDebug {
   int32_t no_pair_epilogue;   /* GEMM epilogues always write fp32 (r4) */
   int32_t no_dyn_scale;       /* raw-activation consumers keep the fixed operand scale 16 + overflow flag (r4) */
   int32_t no_tok_rules;       /* 1-tap GEMMs keep r3's tile / K-slice choices (r4: quantisation-aware tile, no slices under 128 chunks) */
+  int32_t no_fused_reduce;    /* split-K always as two kernels (slices, then reduce + epilogue); same bits (r5) */
+  int32_t no_temb_table;      /* timestep-embedding chain evaluated per step instead of looked up in the per-model table (r5) */
+  int32_t no_gn_fold;         /* GroupNorm (mean, rstd) always by the separate finalize launch, never in the apply kernel's prologue (r5) */
+  int32_t no_kwave;           /* small 1-tap GEMMs stay on the 64x64 one-accumulator-chain tile (r5: K cut across the four waves) */
   int64_t split16_min_rows;   /* pre-split operands on the 128-row slab tile from this many rows (8192; 0 = never) */
   int64_t cfg_split_min_rows; /* channel-split ResBlocks from this many rows (65536) */
   int64_t gn_small_group;     /* single-launch GroupNorm up to this many elements per (sample, group) (11264) */
@@ -203,6 +207,17 @@ typedef struct CsConvGemm {
    *     replaces the fixed guess 16 and the CS_STATUS_F16X3_OVERFLOW detect-and-rerun cliff: no activation magnitude can
    *     leave the fp16 range, and a tensor of any scale keeps the same relative precision. */
   const float* a_bound;
+  /* ABI 15 (r5), split-K only: splitk_sync != NULL lets cs_conv_gemm fold the reduce + epilogue INTO the slice kernel (no
+   * second launch, no flush of the partial tiles between two kernels): every slice workgroup publishes its partial tile,
+   * arrives on its output tile's counter, and the first `reducers` slices of the tile then each sum a 16-row-aligned share of
+   * the tile over all slices IN SLICE ORDER and apply the epilogue -- the same sums, the same order, the same bits as the
+   * two-kernel form (which remains the path when splitk_sync is NULL, when the launch has more workgroups than the device
+   * can hold resident at once, or under CS_NO_FUSED_REDUCE=1).  splitk_sync points at splitk_sync_words int32 words
+   * (>= 2 per output tile) that are ZERO on entry; the kernel returns them to zero, so one buffer zeroed once serves every
+   * launch on a stream (launches on different streams need different buffers).  A slice that never arrives (a resident-
+   * workgroup miscount) raises CS_STATUS_INTERNAL after a bounded wait instead of hanging. */
+  int32_t* splitk_sync;
+  int32_t splitk_sync_words;
 } CsConvGemm;
 
 int cs_conv_gemm(const CsConvGemm* desc, cs_stream_t stream);

@@ -27,7 +27,7 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(dll, s), f"{s} declared in the header but not exported"
         assert s in lib.SIGNATURES, f"{s} has no ctypes signature"
     assert set(lib.SIGNATURES) == set(syms)
-    assert dll.cs_abi_version() == lib.ABI_VERSION == 14
+    assert dll.cs_abi_version() == lib.ABI_VERSION == 15
 
 
 def test_struct_layout_matches_header():
@@ -45,7 +45,7 @@ def test_struct_layout_matches_header():
         for n in decl[-1].split(","):
             names.append(n.strip().lstrip("*").strip().split("[")[0])      # (array fields: `a_amax[2]` -> a_amax)
     assert names == [f[0] for f in lib.CsConvGemm._fields_]
-    assert ctypes.sizeof(lib.CsConvGemm) == 14 * 8 + 35 * 4 + 3 * 4
+    assert ctypes.sizeof(lib.CsConvGemm) == 15 * 8 + 35 * 4 + 3 * 4 + 2 * 4
 
 
 def test_missing_library_fails_loudly(tmp_path):

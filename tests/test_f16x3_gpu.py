@@ -127,8 +127,8 @@ def test_f16x3_four_way_k_split_of_the_three_column_tile_convs(monkeypatch):
     kw = dict(rv_rows=256, act=L.ACT_SILU)
     half = ops.conv_gemm(x[:nb], pk, rowvec=rv[:nb], **kw)
     whole = ops.conv_gemm(x, pk, rowvec=rv, **kw)
-    monkeypatch.setattr(ops, "SPLITK", False)
-    unsplit = ops.conv_gemm(x[:nb], pk, rowvec=rv[:nb], **kw)
+    with L.debug_override(no_splitk=1):
+        unsplit = ops.conv_gemm(x[:nb], pk, rowvec=rv[:nb], **kw)
     torch.cuda.synchronize()
     assert torch.equal(whole[:nb], half)
     assert not torch.equal(half, unsplit) and rel_l2(half, unsplit) < 1e-6      # another summation partition, same grade
@@ -434,11 +434,9 @@ def test_f16x3_splitk_matches_fp64_and_unsplit(nb, shape, cin, cout, k, extras):
     xd = x.cuda()
     assert ops.SPLITK
     split = ops.conv_gemm(xd, pw, **kw)
-    ops.SPLITK = False
-    try:
+    with L.debug_override(no_splitk=1):          # (the CsDebug view: reaches both hosts, restored on exit -- ADVICE r4)
         whole = ops.conv_gemm(xd, pw, **kw)
-    finally:
-        ops.SPLITK = True
+    assert ops.SPLITK
     torch.cuda.synchronize()
     # the plan really split this shape
     p = L.CsConvGemm()

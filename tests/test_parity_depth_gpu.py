@@ -390,7 +390,7 @@ def test_c4_full_width_256_objects_on_one_gpu(tmp_path):
     sl40 = {"sdf": torch.zeros(40, 1), "rel": c[:40], "uc": uc[:40]}
     assert m.Diff.mini_B == 7 and m.Diff.launch_B == 32
     sc, lc = m.Diff.rel2shape(sl40, **kd)
-    assert m.Diff.last_launch_sizes == [35, 5]
+    assert m.Diff.last_launch_sizes == [21, 19]     # whole mini-batches dealt evenly over two launches (r5)
     sr, lr = m.Diff.rel2shape(sl40, **dict(kd, launch_B=0))
     torch.cuda.synchronize()
     assert m.Diff.last_launch_sizes == [7, 7, 7, 7, 7, 5]
@@ -446,11 +446,8 @@ def test_full_size_conv_paths_agree_at_the_benchmark_shapes():
                           synth.tensor_device("fs:c2", (672,), 0.1), math=L.MATH_F16X3)
     whole = ops.conv_gemm(x2, pk2)
     half = ops.conv_gemm(x2[:nb], pk2)
-    ops.SPLITK = False
-    try:
+    with L.debug_override(no_splitk=1):          # (the CsDebug view: reaches both hosts, restored on exit -- ADVICE r4)
         unsplit = ops.conv_gemm(x2[:nb], pk2)
-    finally:
-        ops.SPLITK = True
     torch.cuda.synchronize()
     assert torch.equal(whole[:nb], half)
     assert rel_l2(half, unsplit) < 3e-6          # K = 18144 summed in four slices vs one chain

@@ -115,3 +115,91 @@ def test_v2_full_facade_checkpoint_and_sample(tmp_path):
     assert int(back2["gconv_net_ec_rel.gconvs.0.net1.1.num_batches_tracked"]) == 7
     k = "gconv_net_ec_rel.gconvs.0.net1.0.weight"
     assert rel_l2(back[k], ck[k]) == 0.0
+
+
+def _small_full_vae(tmp_path):
+    """a v2_full VAE on the reduced UNet + full VQ decoder, synthetic checkpoint in the reference's layout"""
+    import yaml
+    from commonscenes_amd import synth
+    from commonscenes_amd.scene import scene_param_shapes
+    from commonscenes_amd.unet import unet_param_shapes
+    from commonscenes_amd.vae import VAE
+    from commonscenes_amd.vqvae import vqvae_param_shapes
+    from oracle.ref_torch import UNET_SMALL, VQ_FULL
+    ucfg = dict(UNET_SMALL, dims=3, use_spatial_transformer=True)
+    df_yaml = dict(model=dict(params=dict(linear_start=0.00085, linear_end=0.012, conditioning_key="crossattn",
+                                          timesteps=1000)),
+                   unet=dict(params={k: (list(v) if isinstance(v, tuple) else v) for k, v in ucfg.items()}))
+    vq_yaml = dict(model=dict(params=dict(embed_dim=3, n_embed=8192, ddconfig=dict(
+        double_z=False, z_channels=3, resolution=64, in_channels=1, out_ch=1, ch=64, ch_mult=[1, 2, 4],
+        num_res_blocks=1, attn_resolutions=[], dropout=0.0))))
+    (tmp_path / "df.yaml").write_text(yaml.safe_dump(df_yaml))
+    (tmp_path / "vq.yaml").write_text(yaml.safe_dump(vq_yaml))
+    opt = dict(hyper=dict(device="cuda", batch_size=4), network=dict(df_cfg=str(tmp_path / "df.yaml"),
+                                                                      vq_cfg=str(tmp_path / "vq.yaml"), vq_ckpt=None),
+               misc=dict(seed=111))
+    ck = dict(synth.synth_state_dict(scene_param_shapes(35, 16)))
+    ck["vqvae"] = synth.synth_state_dict(vqvae_param_shapes(VQ_FULL, 8192, 3))
+    ck["df"] = synth.synth_state_dict(unet_param_shapes(ucfg))
+    ck.update(opt={}, epoch=1, counter=1)
+    (tmp_path / "checkpoint").mkdir(exist_ok=True)
+    torch.save(ck, tmp_path / "checkpoint" / "model1.pth")
+    m = VAE(type="v2_full", diff_opt=opt, vocab=VOCAB, replace_latent=True, with_changes=True, residual=True,
+            with_angles=True, clip=True, with_E2=True)
+    m.load_networks(str(tmp_path), 1)
+    m.compute_statistics(str(tmp_path), 1, _loader())
+    return m
+
+
+def test_several_scenes_through_one_coalesced_sampler(tmp_path):
+    """sample_box_and_shape_many -- eight synthetic scenes of 4-9 shaped objects.  Each scene's graph is
+    encoded and laid out on its own, ONE sampler + decode runs over all scenes' objects with each scene's own shared x_T
+    (sdfusion_txt2shape_model.py:489-491).  Per scene the boxes are bit-equal to the per-scene call (same GCN launches)
+    and every object's SDF agrees with the per-scene call: bit for bit where the launch has the same GEMM plan, within
+    fp32 summation order (1e-5 on the latents) otherwise.  The default per-scene API is untouched."""
+    from commonscenes_amd import synth
+    m = _small_full_vae(tmp_path)
+    sizes = [4, 9, 5, 7, 6, 8, 4, 9]
+    scenes, per_scene = [], []
+    for i, n in enumerate(sizes):
+        g = synth.random_scene_graph(n, seed=40 + i)
+        O = g["objs"].shape[0]
+        dec_sdfs = torch.zeros(O, 1, 4, 4, 4)
+        dec_sdfs[:n] = 1.0                                                  # the n objects are shaped; floor / _scene_ are not
+        x_T = synth.gaussian_like(f"many:x{i}", (1, 3, 16, 16, 16))
+        z = synth.gaussian_like(f"many:z{i}", (O, 64))
+        scenes.append(dict(dec_objs=g["objs"], dec_triplets=g["triples"], dec_sdfs=dec_sdfs,
+                           encoded_dec_text_feat=g["text_feats"], encoded_dec_rel_feat=g["rel_feats"], z=z, x_T=x_T))
+        per_scene.append(m.sample_box_and_shape(None, g["objs"], g["triples"], dec_sdfs, g["text_feats"], g["rel_feats"],
+                                                gen_shape=True, z=z, x_T=x_T, ddim_steps=3))
+        lat_ref = m.vae_v2.Diff.last_latents.clone()
+        per_scene[-1] = per_scene[-1] + (lat_ref,)
+    outs = m.sample_box_and_shape_many(scenes, gen_shape=True, ddim_steps=3)
+    lat_all = m.vae_v2.Diff.last_latents
+    torch.cuda.synchronize()
+    assert len(outs) == len(sizes)
+    assert sum(m.vae_v2.Diff.last_launch_sizes) == sum(sizes) and len(m.vae_v2.Diff.last_launch_sizes) == 2   # 52 objects: 28 + 24
+    off = 0
+    for n, (boxes, sdf), (rboxes, rsdf, rlat) in zip(sizes, outs, per_scene):
+        assert sdf.shape == (n, 1, 64, 64, 64) and torch.isfinite(sdf).all()
+        assert torch.equal(boxes[0], rboxes[0]) and torch.equal(boxes[1], rboxes[1])
+        assert rel_l2(lat_all[off:off + n], rlat) < 1e-5
+        off += n
+    # two scenes given the SAME x_T and graph come out identical object for object; different x_T does not
+    g = synth.random_scene_graph(5, seed=77)
+    O = g["objs"].shape[0]
+    dec_sdfs = torch.zeros(O, 1, 4, 4, 4)
+    dec_sdfs[:5] = 1.0
+    z = synth.gaussian_like("many:zz", (O, 64))
+    xa, xb = synth.gaussian_like("many:xa", (1, 3, 16, 16, 16)), synth.gaussian_like("many:xb", (1, 3, 16, 16, 16))
+    mk = lambda x: dict(dec_objs=g["objs"], dec_triplets=g["triples"], dec_sdfs=dec_sdfs, encoded_dec_text_feat=g["text_feats"],
+                        encoded_dec_rel_feat=g["rel_feats"], z=z, x_T=x)
+    (_, s1), (_, s2), (_, s3) = m.sample_box_and_shape_many([mk(xa), mk(xa), mk(xb)], ddim_steps=2)
+    torch.cuda.synchronize()
+    assert torch.equal(s1, s2) and not torch.equal(s1, s3)
+    # an empty list and a scene without shaped objects
+    assert m.sample_box_and_shape_many([], ddim_steps=2) == []
+    none = dict(mk(xa), dec_sdfs=torch.zeros(O, 1, 4, 4, 4))
+    (b0, s0), (b1, s1b) = m.sample_box_and_shape_many([none, mk(xa)], ddim_steps=2)
+    torch.cuda.synchronize()
+    assert s0.shape[0] == 0 and torch.equal(s1b, s1)
