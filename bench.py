@@ -305,6 +305,16 @@ def gemm_summary(prof, wall_ms, math):
     all_ms = sum(r["e0"].elapsed_time(r["e1"]) for r in prof)
     all_fl = sum(r["flops"] for r in prof)
     achieved = fl / (ms * 1e-3) / 1e12
+    # ALGORITHMIC HBM bytes of the dominant kernel's launches (what `traffic`, the counted bytes, is to be ratioed against):
+    # the A operand once (m x cin x 4 B: fp32, or the fp16 hi + lo pair), the packed weights once (k x n x 4 B: fp16 hi +
+    # lo), the fp32 result once (m x n x 4 B) and the residual where the launch adds one -- per launch, averaged over the
+    # kernel's launches.  The counters come out ~2.4x above this at 32 objects: a slab conv re-reads its A rows once per
+    # 224-column tile of the output and per kd (the halo planes), both of which hit L2 / MALL rather than HBM only partly.
+    ab = 0.0
+    for r in sel:
+        cin = r["k"] / max(1, r["taps"])
+        ab += r["m"] * cin * 4.0 + r["k"] * r["n"] * 4.0 + r["m"] * r["n"] * 4.0 * (2.0 if r.get("res") else 1.0)
+    alg_bytes = ab / len(sel)
     if math == "f16x3":
         peak = F16_MFMA_PEAK_TFLOPS / 3.0
         kname = f"{kernel_label(dom)}; implicit GEMM, 3x v_mfma_f32_32x32x16_f16 per K=16 on hi/lo splits)"
@@ -323,7 +333,8 @@ def gemm_summary(prof, wall_ms, math):
             "issued_mfma_tflops": 3.0 * achieved if math == "f16x3" else achieved,
             "kernel": kname, "rocprof_kernel": rocprof_name(dom) if math == "f16x3" else "conv_gemm_f32_kernel<1, 7, 4, 1>",
             "math": math, "launches": len(sel), "avg_launch_ms": ms / len(sel),
-            "algorithmic_gflop_per_launch": fl / len(sel) / 1e9, "share_of_wall_time": ms / wall_ms,
+            "algorithmic_gflop_per_launch": fl / len(sel) / 1e9, "algorithmic_bytes_per_launch": alg_bytes,
+            "share_of_wall_time": ms / wall_ms,
             "all_gemm_tflops": all_fl / (all_ms * 1e-3) / 1e12, "all_gemm_share_of_wall_time": all_ms / wall_ms}
 
 
@@ -685,6 +696,8 @@ def main():
                 roof["traffic_note"] = f"null: the rocprofv3 --pmc passes failed ({type(e).__name__}: {e})"
             if tr:
                 roof["traffic"] = tr["hbm_bytes_per_launch"]
+                if roof.get("algorithmic_bytes_per_launch"):
+                    roof["traffic_over_algorithmic"] = roof["traffic"] / roof["algorithmic_bytes_per_launch"]
                 roof["traffic_note"] = tr["note"]
                 roof["traffic_detail"] = tr
             # r4: matrix-pipe occupancy + effective clock of the dominant kernel, the pointwise token kernel and the UNet's

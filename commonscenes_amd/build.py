@@ -64,6 +64,8 @@ def build_native(force: bool = False, verbose: bool = True) -> Path:
     extra = os.environ.get("CS_EXTRA_HIPCC_FLAGS", "").split()      # debug builds only (e.g. -DCS_ABLATE=1)
     objdir = PKG_DIR / "build"
     objdir.mkdir(exist_ok=True)
+    import time
+    t0 = time.time()          # outputs are stamped with the build's START: a source edited while hipcc runs stays newer
     procs = []
     objs = []
     # incremental: an object is rebuilt when its source, any header, this file or the flag set is newer / different
@@ -89,6 +91,7 @@ def build_native(force: bool = False, verbose: bool = True) -> Path:
             raise RuntimeError(f"hipcc failed on {s}")
         if verbose and out.strip():
             print(out.decode())
+        os.utime(objdir / (s.replace(".hip", ".o")), (t0, t0))
     stamp.write_text(flagstr)
     tmp = LIB_PATH.with_suffix(".so.tmp")
     cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", str(tmp)]
@@ -96,6 +99,7 @@ def build_native(force: bool = False, verbose: bool = True) -> Path:
         print("[build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     os.replace(tmp, LIB_PATH)
+    os.utime(LIB_PATH, (t0, t0))
     return LIB_PATH
 
 

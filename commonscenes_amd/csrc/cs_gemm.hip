@@ -650,6 +650,7 @@ static int fused_reduce_plan(const CsConvGemm& p, int M, int stile) {
   const int64_t tiles = (int64_t)((M + bm - 1) / bm) * (p.cout / 224);
   const int64_t slots = (int64_t)device_cus() * (stile == 4 ? 1 : 2);
   if (tiles * p.splitk > slots || 2 * tiles > p.splitk_sync_words) return 0;
+  if ((int64_t)p.splitk * M * p.cout * 4 >= 0xFFE00000LL) return 0;      // the reducers address the partials through one descriptor
   int r = 1;
   while (2 * r <= p.splitk && 2 * r <= bm / 16) r *= 2;
   return r;
@@ -855,6 +856,50 @@ __global__ __launch_bounds__(256) void up2_interleave_kernel(const float* __rest
   }
 }
 
+// r5: the K-sliced class batch of small launches (cs_conv_gemm_up2): ws [cls][slice][M1][cout] partial tiles -> the sum over
+// the slices IN SLICE ORDER + bias + activation, stored to the class's rows of the doubled grid.  One launch instead of a
+// reduce per class and the interleave pass; per element the arithmetic of splitk_reduce_kernel.
+__global__ __launch_bounds__(256) void up2_reduce_scatter_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
+                                                                 float* __restrict__ out, int64_t m1, int cout, int ldo,
+                                                                 int D, int H, int W, int ud, int uh, int uw, int splits,
+                                                                 int act) {
+  const int nh = uh ? 2 : 1, nw = uw ? 2 : 1;
+  const int cls = blockIdx.y;
+  const int pw = cls % nw, ph = (cls / nw) % nh, pd = cls / (nw * nh);
+  const int c4n = cout >> 2;
+  const int64_t total = m1 * c4n;
+  const int64_t sstride = m1 * cout;
+  const float* src = ws + (int64_t)cls * splits * sstride;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % c4n);
+    int64_t m = i / c4n;
+    const float* sp = src + m * cout + c4 * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(sp);
+    for (int s0 = 1; s0 < splits; s0 += 8) {
+      f32x4 t[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (s0 + q < splits) t[q] = *reinterpret_cast<const f32x4*>(sp + (s0 + q) * sstride);
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (s0 + q < splits) v += t[q];
+    }
+    if (bias) v += *reinterpret_cast<const f32x4*>(bias + c4 * 4);
+    if (act != CS_ACT_NONE) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = cs_act(v[e], act);
+    }
+    const int w_ = (int)(m % W);
+    m /= W;
+    const int h_ = (int)(m % H);
+    m /= H;
+    const int d_ = (int)(m % D);
+    const int64_t n = m / D;
+    const int64_t orow = ((n * (D << ud) + ((d_ << ud) + pd)) * (H << uh) + ((h_ << uh) + ph)) * (W << uw) + ((w_ << uw) + pw);
+    *reinterpret_cast<f32x4*>(out + orow * ldo + c4 * 4) = v;
+  }
+}
+
 bool up2_ok(const CsConvGemm& p) {
   return p.kd == 3 && p.kh == 3 && p.kw == 3 && p.sd == 1 && p.sh == 1 && p.sw == 1 && p.pd == 1 && p.ph == 1 &&
          p.pw == 1 && (p.ud | p.uh | p.uw) != 0 && p.ud >= 0 && p.ud <= 1 && p.uh >= 0 && p.uh <= 1 && p.uw >= 0 &&
@@ -884,6 +929,36 @@ static bool up2_direct_batched(const CsConvGemm& d, int64_t m1, int ncls) {
     if (plan_splitk(q, m1) > 1 || !cs_f16x3_slab4_ok(q, auto_tile(q, (int)m1, true), 1)) return false;
   }
   return (int64_t)ncls * ((m1 + 255) / 256) * ((d.cout + 63) / 64) < 0x7fffffffLL;
+}
+
+// r5: K slices of the ONE-launch class batch for small folded-Upsample launches, or 0.  One object's 4^3 -> 8x8 Upsample
+// conv is four 512-row GEMMs (672 -> 672, twelve taps): run per class they are 12 output tiles each -- 16 K slices and a
+// reduce per class plus the interleave pass, nine launches, ~260 us for 22 GFLOP.  All classes' tiles x S slices fill
+// the chip once instead, on the four-tap slab kernel (256-row tiles), and ONE reduce-scatter writes the doubled grid.
+static int up2_sliced_plan(const CsConvGemm& d, int64_t m1, int ncls) {
+  if (d.math != CS_MATH_F16X3 || !up2_ok(d) || d.a_format != 0 || d.gn_part || d.out_format || m1 > 0x7fffffffLL) return 0;
+  if (cs_debug()->no_up2_direct || cs_debug()->no_up2_batch || cs_debug()->no_slab4) return 0;
+  const int tile = d.cout % 224 == 0 ? 4 : d.cout % 128 == 0 ? 6 : 0;
+  if (!tile) return 0;
+  const int bn = tile == 4 ? 224 : 128;
+  CsConvGemm q = d;
+  q.kd = d.ud ? 2 : 3; q.kh = d.uh ? 2 : 3; q.kw = d.uw ? 2 : 3;
+  q.pd = q.ph = q.pw = 1;
+  q.ud = q.uh = q.uw = 0;
+  q.dout = d.din; q.hout = d.hin; q.wout = d.win;
+  q.tile = 0; q.splitk = 0;
+  if (!cs_f16x3_slab4_ok(q, tile, -1)) return 0;
+  const int64_t tiles = (int64_t)ncls * ((m1 + 255) / 256) * (d.cout / bn);
+  const int64_t slots = device_cus();
+  if (tiles * 2 > slots) return 0;                          // at least two slices: larger launches keep their routes
+  const int64_t nsc = (int64_t)q.kd * ((d.cin + 15) / 16);  // super-chunks (one kd x 16 channels = four taps)
+  int64_t sl = slots / tiles;
+  if (sl > 32) sl = 32;
+  if (sl > nsc / 2) sl = nsc / 2;
+  if (sl < 2) return 0;
+  sl = (nsc + (nsc + sl - 1) / sl - 1) / ((nsc + sl - 1) / sl);      // the fewest slices of that length
+  if ((int64_t)ncls * sl * m1 * d.cout * 4 >= 0x7FF00000LL * 4) return 0;
+  return sl < 2 ? 0 : (int)sl;
 }
 
 extern "C" int cs_conv_up2_info(int ud, int uh, int uw, int32_t* ncls, int32_t* kd, int32_t* kh, int32_t* kw) {
@@ -916,7 +991,10 @@ extern "C" int64_t cs_conv_gemm_up2_ws_bytes(const CsConvGemm* d) {
   q.dout = d->din; q.hout = d->hin; q.wout = d->win;
   q.tile = 0;
   const int s = plan_splitk(q, m1);
-  return ((int64_t)ncls + (s > 1 ? s : 0)) * m1 * d->cout * 4;
+  const int64_t per_class = ((int64_t)ncls + (s > 1 ? s : 0)) * m1 * d->cout * 4;
+  const int sb = up2_sliced_plan(*d, m1, ncls);            // r5: [class][slice] partial tiles of the one-launch class batch
+  const int64_t batched = (int64_t)ncls * sb * m1 * d->cout * 4;
+  return per_class > batched ? per_class : batched;
 }
 
 extern "C" int cs_conv_gemm_up2(const CsConvGemm* d, const void* const* w_cls, const void* const* w_lo_cls,
@@ -963,6 +1041,25 @@ extern "C" int cs_conv_gemm_up2(const CsConvGemm* d, const void* const* w_cls, c
       return CS_EINVAL;
   }
   if (d->out_format) return CS_EINVAL;
+  const int sliced = batched ? 0 : up2_sliced_plan(*d, m1, ncls);
+  if (sliced > 1) {
+    const int omap_f = (d->ud ? 4 : 0) | (d->uh ? 2 : 0) | (d->uw ? 1 : 0) | 8;
+    CsConvGemm q = class_desc(0);
+    q.out = tmp;
+    q.ldo = d->cout;
+    q.bias = nullptr;
+    q.act = CS_ACT_NONE;
+    q.gn_part = nullptr;
+    const int tile = d->cout % 224 == 0 ? 4 : 6;
+    const int rc = cs_conv_gemm_f16x3_dispatch(q, (int)m1, tile, sliced, (hipStream_t)stream, omap_f, 0, w_cls, w_lo_cls,
+                                               acc_scale_cls, ncls);
+    if (rc != CS_OK) return rc;
+    const int64_t units = m1 * (d->cout >> 2);
+    CS_LAUNCH(up2_reduce_scatter_kernel, dim3(cs_grid_for(units, 256, 256 * 8), ncls), dim3(256), 0, (hipStream_t)stream, tmp,
+              d->bias, d->out, m1, d->cout, d->ldo, d->din, d->hin, d->win, d->ud, d->uh, d->uw, sliced, d->act);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+  }
   if (batched) {
     const int omap_f = (d->ud ? 4 : 0) | (d->uh ? 2 : 0) | (d->uw ? 1 : 0);
     CsConvGemm q = class_desc(0);

@@ -94,13 +94,12 @@ __device__ __forceinline__ void fused_splitk_reduce(const CsFuseK& f, const floa
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   typedef _Float16 h4 __attribute__((ext_vector_type(4)));
   int32_t* const arrive = f.sync + 2 * otile;
+  // (the partial tile went out as 16-byte WRITE-THROUGH stores -- `sc1` -- so publishing is "drain, then arrive": no
+  // buffer_wbl2 over the 229 KB this workgroup just dirtied; v1 of this seam used plain stores + a release fence and cost
+  // ~23 us per conv against ~15 for the second launch, profiles/r05_a_fused_ab.txt)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();                                           // every wave's partial stores are issued and drained
-  if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (the compiler may drop the wait behind buffer_wbl2: G16)
-    __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  __syncthreads();                                           // every wave's partial stores are drained
+  if (tid == 0) __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int R = f.reducers;
   if (split >= R) return;                                    // (workgroup-uniform)
   if (tid == 0) {
@@ -112,13 +111,14 @@ __device__ __forceinline__ void fused_splitk_reduce(const CsFuseK& f, const floa
         break;
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
-  __syncthreads();
+  __syncthreads();                                           // (the partials are read with `sc1` loads: no acquire fence needed)
   constexpr int C4 = BN / 4;                                 // float4 columns of the tile
   constexpr int UNITS = 16 * C4;                             // one 16-row statistics block
   static_assert(UNITS % 2 == 0 && BN <= NT && 16 * BN * 4 <= 32768, "fused split-K reduce geometry");
   float* const lv = reinterpret_cast<float*>(smem);          // [16][BN] final values of the block (gn_part only)
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)ws, 0, (unsigned)((int64_t)splits * M * cout * 4), 0x00020000);
   const bool gstat = f.gn_part != nullptr, opair = f.out_format == 2;
   const int rows_per = BM / R;
   float oamax = 0.f;
@@ -132,14 +132,17 @@ __device__ __forceinline__ void fused_splitk_reduce(const CsFuseK& f, const floa
       const bool ok = u < UNITS && m < M && n < cout;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (ok) {
-        const float* src = ws + (int64_t)m * cout + n;
-        const int64_t sstride = (int64_t)M * cout;
-        v = *reinterpret_cast<const f32x4*>(src);
+        // `sc1` loads (served by L2 / memory, never by this CU's L1) of what the slices stored `sc1`; the slice stride
+        // M * cout * 4 bytes stays far below the descriptor's 4 GiB at every size the resident-launch rule admits
+        const unsigned off0 = (unsigned)(((int64_t)m * cout + n) * 4);
+        const unsigned sstride = (unsigned)((int64_t)M * cout * 4);
+        v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, off0, 0, 16));
         for (int s = 1; s < splits; s += 8) {                // eight loads in flight, added in slice order
           f32x4 t[8];
 #pragma unroll
           for (int q = 0; q < 8; ++q)
-            if (s + q < splits) t[q] = *reinterpret_cast<const f32x4*>(src + (s + q) * sstride);
+            if (s + q < splits)
+              t[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, off0 + (unsigned)(s + q) * sstride, 0, 16));
 #pragma unroll
           for (int q = 0; q < 8; ++q)
             if (s + q < splits) v += t[q];
@@ -310,7 +313,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   int cls_id = 0;                                                 // parity class of a batched folded-Upsample launch
   if constexpr (TPK == 4) {
     if (cb.n > 1) {
-      const int per_cls = ((M + BM - 1) / BM) * tiles_n;          // (splits == 1 on this route)
+      // (r5: omap_f bit 3 = the K-SLICED class batch of small launches -- plain partial tiles [class][slice][M][cout] to the
+      // workspace, summed and scattered by up2_reduce_scatter_kernel, cs_gemm.hip -- instead of the direct scattered store)
+      const int per_cls = ((M + BM - 1) / BM) * tiles_n * splits;
       const int cls = tile / per_cls;
       cls_id = cls;
       tile -= cls * per_cls;
@@ -863,13 +868,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   // Fast path: the C/D layout gives a lane one column and 16 scattered rows, i.e. 112 dword stores (+112 dword
   // residual loads) per lane -- issue-bound, and for the short-K token GEMMs as long as the main loop.  Stage
   // 16 rows x (32*WNB) columns per wave through the (now idle) LDS ring and write whole rows as float4.
-  float* const outp = p.out + (int64_t)split * M * p.ldo;      // split-K: slice s owns rows [s*M, (s+1)*M) of the ws
+  // split-K: slice s owns rows [s*M, (s+1)*M) of the ws (class-batched: [class][slice])
+  float* const outp = p.out + ((int64_t)cls_id * splits + split) * M * p.ldo;
   // r3: scattered store of one output parity class of a folded Upsample conv (cs_conv_gemm_up2) -- GEMM row m = source
   // voxel (n, d, h, w) lands on row ((n*Do + d*fd + pd)*Ho + h*fh + ph)*Wo + w*fw + pw of the DOUBLED grid, so the
   // classes write the final tensor themselves and the scratch tensor + interleave pass are gone.  omap_f / omap_p: bit
   // 2 / 1 / 0 = D / H / W doubled / parity.  The row map of the tile goes to LDS once (otab, relative to the tile's
   // first output row `ob`); every store path below takes its row from it.
-  const bool omap = (TPK == 4) && omap_f != 0;
+  const bool omap = (TPK == 4) && (omap_f & 7) != 0 && !(omap_f & 8);
   int* const otab = reinterpret_cast<int*>(smem + OTAB);
   long long ob = m0, Mo = M;
   int ospan = BM;                                              // rows the tile's stores span (32-bit offset window)
@@ -1167,6 +1173,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   if (vec_ok) {
     __syncthreads();                                        // every wave has left the ring
     float* ep = reinterpret_cast<float*>(smem + wave * EPI_BYTES);
+    typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+    // (fused-reduce slices only: this tile's rows of the slice's partial tensor, 32-bit offsets)
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(outp + (int64_t)m0 * p.ldo), 0, (unsigned)((int64_t)BM * p.ldo * 4), 0x00020000);
 #pragma unroll
     for (int i = 0; i < WMB; ++i)
 #pragma unroll
@@ -1228,7 +1238,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
                 for (int e = 0; e < 4; ++e) v[e] = cs_act(v[e], p.act);
               }
               if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (int64_t)m * p.ldr + n);
-              *reinterpret_cast<f32x4*>(outp + (ob + orel(m - m0)) * p.ldo + n) = v;
+              if (fz.sync)        // (uniform) a K slice of a fused-reduce launch: write-through, see fused_splitk_reduce
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, v), prs,
+                                                       (unsigned)(((m - m0) * p.ldo + n) * 4), 0, 16);
+              else
+                *reinterpret_cast<f32x4*>(outp + (ob + orel(m - m0)) * p.ldo + n) = v;
             }
           }
         }
@@ -1277,7 +1291,7 @@ int launch16(const CsConvGemm& p, int M, int splits, hipStream_t stream, int oma
   const int tiles_n = (p.cout + BN - 1) / BN;
   CsClsBatch cb;
   memset(&cb, 0, sizeof(cb));
-  if (cls && TPK == 4 && cls->n > 1 && splits == 1 && omap_f) cb = *cls;
+  if (cls && TPK == 4 && cls->n > 1 && (omap_f & 7) && ((omap_f & 8) ? splits > 1 : splits == 1)) cb = *cls;
   const int64_t nblk = (int64_t)tiles_m * tiles_n * splits * (cb.n > 1 ? cb.n : 1);
   if (nblk > 0x7fffffffLL) return CS_EINVAL;
   const int kg_per_tap = ((p.cin + 15) / 16) * 2;
@@ -1344,6 +1358,7 @@ bool cs_f16x3_slab4_ok(const CsConvGemm& p, int tile, int splits) {
 #ifdef CS_NO_SLAB
   return false;
 #else
+  // (splits < 0: the geometry alone -- the K-sliced class batch of small launches, cs_conv_gemm_up2, r5)
   return !cs_debug()->no_slab4 && p.a_format == 0 && (tile == 4 || tile == 6) && splits <= 1 && p.kh == 2 && p.kw == 2 &&
          (p.kd == 2 || p.kd == 3) && p.sd == 1 && p.sh == 1 && p.sw == 1 && p.ud == 0 && p.uh == 0 && p.uw == 0 &&
          (unsigned)p.pd <= 1u && (unsigned)p.ph <= 1u && (unsigned)p.pw <= 1u && (p.kd == 2 || p.pd == 1) &&
@@ -1395,7 +1410,11 @@ int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p_in, int M, int tile, int spl
                                 const CsFuseK* fuse) {
   CsConvGemm p = p_in;
   if (splits < 1) splits = 1;
-  if (omap_f && !cs_f16x3_slab4_ok(p, tile, splits)) return CS_EINVAL;
+  const bool cls_sliced = (omap_f & 8) != 0;           // r5: all parity classes x K slices in one launch, partial tiles out
+  if (cls_sliced && (splits < 2 || ncls < 2 || p.a_format != 0 || (tile != 4 && tile != 6) || !cs_f16x3_slab4_ok(p, tile, -1) ||
+                     p.bias || p.res || p.rowvec || p.scale || p.act != CS_ACT_NONE || p.gn_part || p.out_format))
+    return CS_EINVAL;
+  if (omap_f && !cls_sliced && !cs_f16x3_slab4_ok(p, tile, splits)) return CS_EINVAL;
   CsClsBatch cb;
   memset(&cb, 0, sizeof(cb));
   if (ncls > 1) {
@@ -1485,7 +1504,7 @@ int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p_in, int M, int tile, int spl
   if (p.a_format != 0) return CS_EINVAL;
   // r3: the 3x2x2 / 2x2x2 kernels of the Upsample convs folded onto the source grid (cs_conv_gemm_up2): slab path with
   // four taps per kd
-  if (cs_f16x3_slab4_ok(p, tile, splits)) {
+  if (cs_f16x3_slab4_ok(p, tile, cls_sliced ? -1 : splits)) {
     if (tile == 4) return launch16<1, 7, 8, 1, false, 32, false, 4>(p, M, splits, s, omap_f, omap_p, &cb);
     return launch16<1, 4, 8, 1, false, 32, false, 4>(p, M, splits, s, omap_f, omap_p, &cb);
   }

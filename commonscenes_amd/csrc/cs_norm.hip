@@ -175,23 +175,48 @@ __device__ __forceinline__ void gn_bound_max(float* bound, double mean, double v
 // (measured: 30 us for a kernel that otherwise takes 5), so a workgroup is SIXTEEN waves = sixteen (sample, group)s and
 // commits one maximum.
 constexpr int GN_FIN_WAVES = 16;
+// WPG = waves per (sample, group).  r5: at one or two objects a group of the 16^3 level is 1792 (channel, tile) pairs of
+// 16-row partials -- 28 dependent-latency rounds for ONE wave (15.9 us per launch, 27 launches per one-object step); with
+// four waves per group the same kernel takes a third of that.  WPG is chosen from the pairs per group alone (a property of
+// the sample's own partials, cs_groupnorm_finalize_parts), never from the batch: the summation tree of a sample does not
+// depend on what else shares the launch.
+template <int WPG>
 __global__ __launch_bounds__(64 * GN_FIN_WAVES) void gn_finalize_parts_kernel(const GnSegs sg, int groups, int cpg,
                                                                               double count, float eps,
                                                                               float* __restrict__ stats,
                                                                               float* __restrict__ bound, int total) {
+  constexpr int GPB = GN_FIN_WAVES / WPG;           // (sample, group)s per workgroup
   __shared__ float bmax[GN_FIN_WAVES];
+  __shared__ double wsum[GN_FIN_WAVES][2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i = blockIdx.x * GN_FIN_WAVES + wave;  // n * groups + g
+  const int slot = wave / WPG, sub = wave - slot * WPG;
+  const int i = blockIdx.x * GPB + slot;  // n * groups + g
   float bf = 0.f;
+  double s = 0, q = 0;
   if (i < total) {
     const int n = i / groups, g = i - n * groups;
-    double s, q;
-    gn_group_parts(sg, n, g, cpg, lane, 64, s, q);
+    gn_group_parts(sg, n, g, cpg, sub * 64 + lane, 64 * WPG, s, q);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       s += __shfl_xor(s, o, 64);
       q += __shfl_xor(q, o, 64);
     }
+  }
+  if constexpr (WPG > 1) {
+    if (lane == 0) {
+      wsum[wave][0] = s;
+      wsum[wave][1] = q;
+    }
+    __syncthreads();
+    s = 0;
+    q = 0;
+#pragma unroll
+    for (int w = 0; w < WPG; ++w) {               // fixed order over the group's waves
+      s += wsum[slot * WPG + w][0];
+      q += wsum[slot * WPG + w][1];
+    }
+  }
+  if (i < total && sub == 0) {
     const double mean = s / count;
     double var = q / count - mean * mean;
     if (var < 0) var = 0;
@@ -549,9 +574,13 @@ __global__ __launch_bounds__(256) void gn_small_parts_kernel(const float* __rest
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float* __restrict__ y,
                                                              float* __restrict__ stats, float* __restrict__ bound, int rows,
-                                                             int c, int ldx, int ldy, int groups, float eps, int act) {
+                                                             int c, int ldx, int ldy, int groups, float eps, int act,
+                                                             int rsplit) {
+  // r5: `rsplit` workgroups per (sample, group), each deriving the SAME statistics from the partials (a few hundred pairs)
+  // and sweeping its share of the rows -- one or two objects are 64 (sample, group)s, a quarter of the CUs
   __shared__ double red[2][256];
-  const int n = blockIdx.x / groups, g = blockIdx.x - n * groups;
+  const int sgi = blockIdx.x / rsplit, rs = blockIdx.x - sgi * rsplit;
+  const int n = sgi / groups, g = sgi - n * groups;
   const int cpg = c / groups;
   const int tid = threadIdx.x;
   double s, q;
@@ -573,15 +602,18 @@ __global__ __launch_bounds__(256) void gn_small_parts_kernel(const float* __rest
   if (var < 0) var = 0;
   const float mean = (float)mean_d;
   const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-  if (tid == 0 && stats) {
-    stats[2 * blockIdx.x] = mean;
-    stats[2 * blockIdx.x + 1] = rstd;
+  if (tid == 0 && stats && rs == 0) {
+    stats[2 * sgi] = mean;
+    stats[2 * sgi + 1] = rstd;
   }
-  if (tid == 0 && bound) gn_bound_max(bound, mean_d, var, count);
+  if (tid == 0 && bound && rs == 0) gn_bound_max(bound, mean_d, var, count);
+  const int rper = (rows + rsplit - 1) / rsplit;
+  const int rbeg = rs * rper, rend = min(rows, rbeg + rper);
   const float* xb = x + (int64_t)n * rows * ldx + g * cpg;
   float* yb = y + (int64_t)n * rows * ldy + g * cpg;
   const int dr = 256 / cpg, dk = 256 - dr * cpg;
-  int r = tid / cpg, k = tid - r * cpg;
+  int r = rbeg + tid / cpg, k = tid - (tid / cpg) * cpg;
+  rows = rend;                                    // (this workgroup's share ends here; xb / yb were formed above)
   while (r < rows) {
     float v[4], ga[4], be[4];
     int rr[4], kk[4];
@@ -648,8 +680,20 @@ extern "C" int cs_groupnorm_finalize_parts(const CsGnSeg* segs, int nseg, int nb
   const int rc = gn_pack_segs(segs, nseg, nb, c, sg);
   if (rc != CS_OK) return rc;
   const int total = nb * groups;
-  CS_LAUNCH(gn_finalize_parts_kernel, dim3((total + GN_FIN_WAVES - 1) / GN_FIN_WAVES), dim3(64 * GN_FIN_WAVES), 0, (hipStream_t)stream, sg, groups, c / groups,
-            (double)rows * (c / groups), eps, stats, bound, total);
+  // (channel, tile) pairs of the largest group share: four waves per group from 512 pairs (see the kernel)
+  int64_t pairs = 0;
+  for (int i = 0; i < nseg; ++i) {
+    const int64_t nt = (int64_t)segs[i].ncls * segs[i].tiles_per_sample;
+    const int64_t chs = segs[i].nch < c / groups ? segs[i].nch : c / groups;
+    if (nt * chs > pairs) pairs = nt * chs;
+  }
+  if (pairs >= 512 && !cs_debug()->no_gn_fold) {
+    CS_LAUNCH(gn_finalize_parts_kernel<4>, dim3((total + 3) / 4), dim3(64 * GN_FIN_WAVES), 0, (hipStream_t)stream, sg, groups,
+              c / groups, (double)rows * (c / groups), eps, stats, bound, total);
+  } else {
+    CS_LAUNCH(gn_finalize_parts_kernel<1>, dim3((total + GN_FIN_WAVES - 1) / GN_FIN_WAVES), dim3(64 * GN_FIN_WAVES), 0,
+              (hipStream_t)stream, sg, groups, c / groups, (double)rows * (c / groups), eps, stats, bound, total);
+  }
   CS_CHECK_LAUNCH();
   return CS_OK;
 }
@@ -670,8 +714,14 @@ extern "C" int cs_groupnorm_parts(const float* x, const CsGnSeg* segs, int nseg,
   const int64_t small_group = cs_debug()->gn_small_group;
   if ((int64_t)nb * rows * c * 4 <= GN_SMALL_BYTES && cpg <= 256 && (int64_t)rows * cpg <= small_group &&
       (int64_t)nb * groups <= 65535) {
-    CS_LAUNCH(gn_small_parts_kernel, dim3((unsigned)(nb * groups)), dim3(256), 0, (hipStream_t)stream, x, sg, gamma, beta, y,
-              stats, bound, rows, c, ldx, ldy, groups, eps, act);
+    // (row shares per (sample, group): up to four while the launch stays under ~512 workgroups and a share keeps >= 4
+    // elements per thread; depends on the sample's own shape and on nb only through the workgroup budget -- the
+    // arithmetic per element does not depend on it)
+    int rsplit = 1;
+    while (rsplit < 4 && (int64_t)nb * groups * rsplit * 2 <= 512 && (int64_t)rows * cpg >= 2048LL * rsplit) rsplit *= 2;
+    if (cs_debug()->no_gn_fold) rsplit = 1;
+    CS_LAUNCH(gn_small_parts_kernel, dim3((unsigned)(nb * groups * rsplit)), dim3(256), 0, (hipStream_t)stream, x, sg, gamma,
+              beta, y, stats, bound, rows, c, ldx, ldy, groups, eps, act, rsplit);
     CS_CHECK_LAUNCH();
     return CS_OK;
   }
@@ -738,7 +788,10 @@ extern "C" int cs_groupnorm_apply_range(const float* x, const float* stats, cons
   const int ch4 = c >> 2;
   const int rowlanes = 256 / (ch4 < 256 ? ch4 : 256);
   int blocks_per_sample = (2048 + nb - 1) / nb;
-  const int max_blocks = (rows + 16 * rowlanes - 1) / (16 * rowlanes);
+  // (r5: down to four rows per row-lane -- one round of the kernel's four loads in flight -- where sixteen would leave
+  // most of the chip idle: 8192 x 224 at one object ran 128 workgroups x 4 dependent rounds, 12 us for 14 MB)
+  const int min_rows = (int64_t)nb * ((rows + 16 * rowlanes - 1) / (16 * rowlanes)) >= 1024 ? 16 : 4;
+  const int max_blocks = (rows + min_rows * rowlanes - 1) / (min_rows * rowlanes);
   if (blocks_per_sample > max_blocks) blocks_per_sample = max_blocks;
   if (blocks_per_sample < 1) blocks_per_sample = 1;
   const int rpb = (rows + blocks_per_sample - 1) / blocks_per_sample;
@@ -772,7 +825,10 @@ extern "C" int cs_groupnorm_apply_split16_range(const float* x, const float* sta
   const int ch4 = c >> 2;
   const int rowlanes = 256 / (ch4 < 256 ? ch4 : 256);
   int blocks_per_sample = (2048 + nb - 1) / nb;
-  const int max_blocks = (rows + 16 * rowlanes - 1) / (16 * rowlanes);
+  // (r5: down to four rows per row-lane -- one round of the kernel's four loads in flight -- where sixteen would leave
+  // most of the chip idle: 8192 x 224 at one object ran 128 workgroups x 4 dependent rounds, 12 us for 14 MB)
+  const int min_rows = (int64_t)nb * ((rows + 16 * rowlanes - 1) / (16 * rowlanes)) >= 1024 ? 16 : 4;
+  const int max_blocks = (rows + min_rows * rowlanes - 1) / (min_rows * rowlanes);
   if (blocks_per_sample > max_blocks) blocks_per_sample = max_blocks;
   if (blocks_per_sample < 1) blocks_per_sample = 1;
   const int rpb = (rows + blocks_per_sample - 1) / blocks_per_sample;

@@ -664,7 +664,7 @@ def conv_gemm(x: Tensor, w: PackedWeight, *, spatial: Optional[Tuple[int, int, i
         tl = tl_.value
         prof.append(dict(e0=e0, e1=e1, flops=2.0 * mo * w.cout * w.cin * kd * kh * kw, taps=kd * kh * kw,
                          m=mo, n=w.cout, k=w.cin * kd * kh * kw, tile=tl,
-                         slab=sl_.value, pre=xs is not None, pair=xp is not None))
+                         slab=sl_.value, pre=xs is not None, pair=xp is not None, res=res is not None))
     if paired:
         return Pair16(out, float(out_pair))
     return attach_stats(out, st)

@@ -55,6 +55,11 @@ def main():
             res["equal_single_call"] = bool(torch.equal(sdf, one_sdf))
             res["rel_l2_single_call"] = float((sdf.double() - one_sdf.double()).norm() / one_sdf.double().norm())
             res["lat_rel_l2_single_call"] = float((lat.double() - one_lat.double()).norm() / one_lat.double().norm())
+        if os.environ.get("CS_SHARD_LIGHT") == "1":       # the 8-rank pre-flight: the sharded call and its equivalence only
+            td.barrier()
+            Path(os.environ["CS_SHARD_OUT"], f"rank{rank}.json").write_text(json.dumps(res))
+            td.destroy_process_group()
+            return
         # the outer API: every rank calls sample() with the same scene; sharding is automatic under a process group
         g = synth.random_scene_graph(6, seed=11)
         O = g["objs"].shape[0]

@@ -50,6 +50,29 @@ def test_bench_gpus_2_without_a_launcher_spawns_two_ranks():
     assert abs(d["ms_per_step"] - d["ranks"]["ms_per_step_max"]) < 0.5 * d["ms_per_step"]
 
 
+@pytest.mark.gpu
+def test_bench_eight_ranks_on_one_device():
+    """`bench.py --gpus 8` end to end -- eight ranks spawned by bench.py itself, the packed-conditioning
+    broadcast, barrier + max-over-ranks timing, ONE JSON line whose value is the eight-rank aggregate it claims (reduced
+    UNet, one device + gloo: what is exercised is the control flow the driver's 8-GPU run takes over RCCL)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(CS_BENCH_ONE_DEVICE="1", CS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--small", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--objects", "2"],
+                       capture_output=True, text=True, timeout=1500, env=env, cwd=str(ROOT))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["steps"] == 2 and d["finite"] is True
+    assert d["ranks"]["world_size"] == 8 and len(d["ranks"]["ms_per_step_by_rank"]) == 8
+    assert all(t > 0 for t in d["ranks"]["ms_per_step_by_rank"])
+    assert abs(d["ms_per_step"] - max(d["ranks"]["ms_per_step_by_rank"])) < 0.5 * d["ms_per_step"]
+    # whole-job aggregate: eight ranks each advance their objects one step per ms_per_step
+    assert abs(d["value"] - 8 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert d["config"]["objects_per_gpu"] == 2 and "x8" in d["config"]["parallelism"]
+
+
 def test_bench_refuses_to_run_fewer_ranks_than_asked():
     """No silent one-rank fallback: with fewer visible devices than --gpus (here: none) the launcher exits non-zero and
     prints no metric line."""

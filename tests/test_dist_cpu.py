@@ -31,6 +31,9 @@ def _fake_sampler(x_T, uc, c):
     return feat.reshape(B, 1, 4, 4, 4).contiguous()
 
 
+_fake_sampler.out_shape = (1, 4, 4, 4)      # what an EMPTY shard contributes to the all-gather (dist.sharded_rel2shape)
+
+
 def _inputs(total):
     g = torch.Generator().manual_seed(5)
     return (torch.randn(1, 3, 16, 16, 16, generator=g), torch.randn(total, 1, 1280, generator=g),
@@ -56,7 +59,9 @@ def _worker(rank, ws, port, total, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("ws,total", [(2, 8), (2, 7), (3, 10)])
+# (8, 256): BASELINE configs[3]'s partition -- 256 objects, eight ranks of 32; (8, 5): more ranks than objects, three EMPTY
+# shards that must still join the broadcast and the padded all-gather (the 8-rank pre-flight)
+@pytest.mark.parametrize("ws,total", [(2, 8), (2, 7), (3, 10), (8, 256), (8, 5)])
 def test_sharded_equals_unsharded(ws, total):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -64,11 +69,14 @@ def test_sharded_equals_unsharded(ws, total):
     procs = [ctx.Process(target=_worker, args=(r, ws, port, total, q)) for r in range(ws)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=120) for _ in range(ws)]
+    got = [q.get(timeout=300) for _ in range(ws)]
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
     x_T, uc, c = _inputs(total)
+    if ws == 8:
+        sizes = sorted(hi - lo for _, _, (lo, hi) in got)
+        assert sizes == ([32] * 8 if total == 256 else [0, 0, 0, 1, 1, 1, 1, 1])
     ref = _fake_sampler(x_T, uc, c)
     ranges = sorted(r for _, _, r in got)
     assert ranges[0][0] == 0 and ranges[-1][1] == total

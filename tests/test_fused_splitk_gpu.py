@@ -144,3 +144,53 @@ def test_one_object_unet_step_is_unchanged_and_launches_no_reduce_kernel():
     assert torch.isfinite(e0).all()
     assert torch.equal(e0, e1)
     df.check_overflow()
+
+
+@pytest.mark.parametrize("case", [
+    (2, 16, 4, 4, 672, 672, (0, 1, 1)),      # one object's 4^3 -> 8x8 Upsample conv (openai_model_3d.py:150-153): 24 tiles x 10 slices
+    (2, 16, 8, 8, 448, 448, (0, 1, 1)),      # 8x8 -> 16^3: 64 tiles x 4 slices
+    (1, 16, 4, 4, 96, 224, (0, 1, 1)),       # prefix-sized, ragged K slices
+    (1, 8, 8, 8, 64, 128, (1, 1, 1)),        # eight classes, two depth taps, 128-column tiles (the decoder's geometry)
+], ids=["4x4-672", "8x8-448", "small-224", "3d-128"])
+def test_small_folded_upsample_conv_as_one_sliced_class_batch(case):
+    """r5: at one or two objects the folded Upsample conv's parity classes are tiny GEMMs; all classes x K slices run as ONE
+    launch of the four-tap slab kernel (partial tiles [class][slice]) + ONE reduce-scatter into the doubled grid, instead
+    of a K-sliced launch and a reduce per class and the interleave pass.  Same folded weights, another K partition:
+    against the fp64 direct form of nearest x2 + conv (vqvae_modules.py:35-39 / openai_model_3d.py:150-153) and against
+    the per-class route (CS_NO_UP2_BATCH=1)."""
+    from commonscenes_amd import lib as L, ops
+    from oracle import ref_ops as R
+    from conftest import rel_l2
+    nb, d, h, w, cin, cout, up = case
+    x = _rand(nb, d, h, w, cin, seed=61).cpu()
+    wt = _rand(cout, cin, 3, 3, 3, seed=62, scale=(cin * 27) ** -0.5).cpu()
+    b = _rand(cout, seed=63).cpu()
+    ref = R.conv_ndhwc(x.double(), wt.double(), b.double(), (1, 1, 1), up)
+    pk = ops.pack_weight(wt.cuda(), b.cuda(), math=L.MATH_F16X3, fold_up=up)
+    xd = x.cuda()
+    prof = ops.GEMM_PROFILE = []
+    try:
+        out = ops.conv_gemm(xd, pk, up=up)
+    finally:
+        ops.GEMM_PROFILE = None
+    out2 = ops.conv_gemm(xd, pk, up=up)
+    with L.debug_override(no_up2_batch=1):
+        per_class = ops.conv_gemm(xd, pk, up=up)
+    torch.cuda.synchronize()
+    assert out.shape == ref.shape and torch.equal(out, out2)
+    e, ep = rel_l2(out, ref), rel_l2(per_class, ref)
+    print(f"small folded Upsample conv {case}: sliced class batch {e:.2e}, per class {ep:.2e}")
+    assert e < 1e-6 and e < 3 * ep + 3e-7
+    assert rel_l2(out, per_class) < 1e-6
+    # placement into a channel slice of a wider buffer; NaNs of a neighbouring sample do not leak through masked taps
+    wide = torch.full((*out.shape[:-1], cout + 8), 7.0, device="cuda")
+    ops.conv_gemm(xd, pk, up=up, out=wide[..., 4:4 + cout])
+    torch.cuda.synchronize()
+    assert torch.equal(wide[..., 4:4 + cout], out) and bool((wide[..., :4] == 7).all()) and bool((wide[..., -4:] == 7).all())
+    if nb > 1:
+        xn = xd.clone()
+        xn[1] = float("nan")
+        on = ops.conv_gemm(xn, pk, up=up)
+        torch.cuda.synchronize()
+        assert torch.equal(on[0], out[0]) and bool(torch.isnan(on[1]).all())
+    ops.read_status()

@@ -12,13 +12,13 @@ import pytest
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def _launch(nproc, port, objects, tmp_path):
+def _launch(nproc, port, objects, tmp_path, light=False):
     env = dict(os.environ, CS_ONE_DEVICE="1", CS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0",
-               CS_SHARD_OBJECTS=str(objects), CS_SHARD_OUT=str(tmp_path))
+               CS_SHARD_OBJECTS=str(objects), CS_SHARD_OUT=str(tmp_path), CS_SHARD_LIGHT="1" if light else "0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
                         "--master-addr", "127.0.0.1", "--master-port", str(port),
                         str(ROOT / "tests" / "_sharded_worker.py")],
-                       capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))
+                       capture_output=True, text=True, timeout=1500, env=env, cwd=str(ROOT))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     out = [json.loads(p.read_text()) for p in sorted(tmp_path.glob("rank*.json"))]
     assert len(out) == nproc, r.stdout[-2000:] + r.stderr[-2000:]
@@ -49,3 +49,17 @@ def test_three_rank_sharded_rel2shape_uneven_shards(tmp_path):
     res = _launch(3, 29557, 7, tmp_path)                     # 7 objects -> 3 + 2 + 2
     assert all(res[r]["shape"] == [7, 1, 64, 64, 64] and res[r]["finite"] for r in range(3))
     assert res[0]["equal_same_minibatching"] and res[0]["rel_l2_single_call"] < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("objects", [5, 256])
+def test_eight_rank_sharded_rel2shape_preflight(objects, tmp_path):
+    """the partition BASELINE configs[3] runs on eight GPUs, executed for real with eight ranks (one
+    device + gloo here; RCCL, one device per rank, on the node): 256 objects = eight shards of 32, and 5 objects = three EMPTY
+    shards that still take part in the broadcast and the padded all-gather.  Every rank ends up with all objects; rank 0
+    checks gathered == per-shard single-rank runs bit for bit."""
+    res = _launch(8, 29561 + (objects % 7), objects, tmp_path, light=True)
+    assert sorted(res) == list(range(8))
+    assert all(res[r]["shape"] == [objects, 1, 64, 64, 64] and res[r]["finite"] for r in range(8)), res
+    assert res[0]["equal_same_minibatching"], res[0]
+    assert res[0]["rel_l2_single_call"] < 1e-5

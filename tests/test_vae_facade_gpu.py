@@ -171,10 +171,10 @@ def test_several_scenes_through_one_coalesced_sampler(tmp_path):
         scenes.append(dict(dec_objs=g["objs"], dec_triplets=g["triples"], dec_sdfs=dec_sdfs,
                            encoded_dec_text_feat=g["text_feats"], encoded_dec_rel_feat=g["rel_feats"], z=z, x_T=x_T))
         per_scene.append(m.sample_box_and_shape(None, g["objs"], g["triples"], dec_sdfs, g["text_feats"], g["rel_feats"],
-                                                gen_shape=True, z=z, x_T=x_T, ddim_steps=3))
+                                                gen_shape=True, z=z, x_T=x_T, ddim_steps=4))
         lat_ref = m.vae_v2.Diff.last_latents.clone()
         per_scene[-1] = per_scene[-1] + (lat_ref,)
-    outs = m.sample_box_and_shape_many(scenes, gen_shape=True, ddim_steps=3)
+    outs = m.sample_box_and_shape_many(scenes, gen_shape=True, ddim_steps=4)
     lat_all = m.vae_v2.Diff.last_latents
     torch.cuda.synchronize()
     assert len(outs) == len(sizes)
