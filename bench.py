@@ -117,10 +117,12 @@ def cpu_baseline(df, cfg, objects_per_step: int, quick: bool = False):
     from commonscenes_amd import synth
     from oracle import ref_torch as R
     host_cores = os.cpu_count() or 1
-    # oneDNN's conv3d stops scaling (and regresses) far below this box's core count at small CFG batches: 16 threads was
-    # the fastest setting measured on the 256-core host at CFG batch 4 (profiles/r01_cpu_threads.txt: 16 -> 0.42,
-    # 32 -> 0.43, 64 -> 0.75, 128 -> 1.77 s/sample); the one-batch leg (CFG batch 64) also tries 64 threads
-    cores = int(os.environ.get("CS_CPU_THREADS", min(host_cores, 16)))
+    # oneDNN's conv3d stops scaling (and regresses) far below this box's core count: r5 swept BOTH legs at the batch sizes
+    # they run (profiles/r05_cpu_threads.txt, one CFG step on the 256-core host: one batch of 32 objects 30.7 / 29.2 / 36.7 /
+    # 55.5 / 159.6 s at 16 / 32 / 64 / 128 / 256 threads, a mini-batch of 7 5.65 / 4.79 / 7.55 / 15.6 / 117.8 s) -- 32
+    # threads is the fastest setting for both, i.e. the strongest CPU baseline; "all host cores" 
+    # would be 5x (one batch) to 25x (mini-batches) slower.  The one-batch leg also tries 64 threads and keeps the faster.
+    cores = int(os.environ.get("CS_CPU_THREADS", min(host_cores, 32)))
     sd = {k: v.detach().cpu() for k, v in df.state_dict().items()}
     sch = R.register_schedule(**R.DIFFUSION)
     fn = lambda a, t, cc: R.unet_forward(sd, cfg, a, t, cc)
@@ -138,10 +140,10 @@ def cpu_baseline(df, cfg, objects_per_step: int, quick: bool = False):
     out = dict(unit="DDIM steps/s (32 objects)", kind="port", cores=cores, host_cores=host_cores,
                torch=torch.__version__, oracle="oracle/ref_torch.py (CPU fp32, pinned on the reference's goldens)",
                cores_note=(f"BASELINE.md section 4 says 'all host cores'; {cores} of {host_cores} are used because that is "
-                           "the FASTEST setting on this host, i.e. the strongest CPU baseline: oneDNN's conv3d regresses "
-                           "beyond it at these batch sizes (profiles/r01_cpu_threads.txt, CFG batch 4: 16 threads 0.42 "
-                           "s/sample, 32: 0.43, 64: 0.75, 128: 1.77); the one-batch leg also tries 64 threads and keeps "
-                           "the faster; CS_CPU_THREADS overrides"))
+                           "the FASTEST setting on this host for both legs, i.e. the strongest CPU baseline "
+                           "(profiles/r05_cpu_threads.txt, one CFG step: 32 objects as one batch 30.7 / 29.2 / 36.7 / 55.5 / "
+                           "159.6 s and a mini-batch of 7 5.65 / 4.79 / 7.55 / 15.6 / 117.8 s at 16 / 32 / 64 / 128 / 256 "
+                           "threads); the one-batch leg also tries 64 threads and keeps the faster; CS_CPU_THREADS overrides"))
     if quick:
         steps(7, 1, "w")
         dt = steps(7, 1, "q")

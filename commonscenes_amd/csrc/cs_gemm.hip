@@ -258,6 +258,9 @@ bool cs_f16x3_slab4_ok(const CsConvGemm& p, int tile, int splits);              
 bool cs_pw_gemm_f16x3_applicable(const CsConvGemm& p, int64_t M);                                   // cs_gemm_pw.hip
 bool cs_pw_gemm_f16x3_preferred(const CsConvGemm& p, int64_t M);
 int cs_pw_gemm_f16x3_launch(const CsConvGemm& p, int M, hipStream_t s);
+bool cs_kw_gemm_applicable(const CsConvGemm& p, int64_t M);                                          // cs_gemm_kw.hip
+int cs_kw_gemm_f16x3_launch(const CsConvGemm& p, int M, hipStream_t s);
+static int device_cus();
 
 namespace {
 
@@ -475,6 +478,7 @@ void tile_dims(int tile, int& bm, int& bn) {
     case 4: bm = 256; bn = 224; break;
     case 6: bm = 256; bn = 128; break;
     case 7: bm = 256; bn = 64; break;
+    case 10: bm = 64; bn = 64; break;      // r5: the K-wave kernel (cs_gemm_kw.hip): its statistics tiles are its 64 rows
     default: bm = 0; bn = 0; break;
   }
 }
@@ -536,6 +540,12 @@ extern "C" int cs_conv_gemm_epilogue_caps(const CsConvGemm* d, int32_t* gn_rows,
   if (tile == 5 || (p.tile == 0 && cs_pw_gemm_f16x3_applicable(p, M) && cs_pw_gemm_f16x3_preferred(p, M))) return CS_OK;
   tile_dims(tile, bm, bn);
   if (!bm) return CS_OK;
+  if (tile == 10) {                        // the K-wave kernel's single epilogue emits both, whatever the epilogue terms
+    if (!cs_kw_gemm_applicable(p, M)) return CS_OK;
+    if (gn_rows && rps % bm == 0) *gn_rows = bm;
+    if (pair_ok && pair_geom) *pair_ok = 1;
+    return CS_OK;
+  }
   // the kernel's `piped` condition, for every tile of the launch
   const bool piped = (p.res || p.bias || p.rowvec) && !p.scale && (p.act != CS_ACT_GEGLU || p.cout % bn == 0) &&
                      (!p.rowvec || p.rv_rows % bm == 0) &&
@@ -610,6 +620,13 @@ static int auto_tile(const CsConvGemm& p, int M, bool f16x3) {
     // ... and with a short K loop (the 448-channel level: 28 chunks) two 128-row workgroups per CU overlap one's gate
     // epilogue with the other's K loop: 805 vs 867 us at 65536 x 448 -> 3584 (the 672-channel one prefers 256 rows)
     if (p.act == CS_ACT_GEGLU && tile == 4 && (p.cin + 15) / 16 <= 32) tile = 2;
+    // r5 (VERDICT r4 next #1a): small one-tap GEMMs -- every 64x64 tile resident at once (one 128 KB workgroup per CU) and
+    // at least two K chunks per wave -- take the K-wave kernel: the four waves of a workgroup each run a quarter of the K
+    // loop over the whole 64x64 tile, four accumulator chains and no barrier in the loop (cs_gemm_kw.hip).
+    // CS_NO_KWAVE=1: the one-chain 64x64 tile (A/B runs).
+    if (f16x3 && tile == 3 && !cs_debug()->no_kwave && (p.cin + 15) / 16 >= 8 && cs_kw_gemm_applicable(p, M) &&
+        (int64_t)((M + 63) / 64) * ((p.cout + 63) / 64) <= device_cus())
+      tile = 10;
   }
   return tile;
 }
@@ -752,6 +769,7 @@ static int conv_gemm_impl(const CsConvGemm* d, cs_stream_t stream, int omap_f, i
   if (omap_f && (!f16x3 || tile == 5)) return CS_EINVAL;
   if ((p.gn_part || p.out_format) && (!f16x3 || tile == 5)) return CS_EINVAL;
   if (tile == 5) return cs_pw_gemm_f16x3_launch(p, M, s);
+  if (tile == 10) return (f16x3 && !omap_f) ? cs_kw_gemm_f16x3_launch(p, M, s) : CS_EINVAL;
   if (f16x3) return cs_conv_gemm_f16x3_dispatch(p, M, tile, 1, s, omap_f, omap_p, cls_w, cls_w_lo, cls_acc, ncls);
   switch (tile) {
     case 1: return launch<2, 2, 2, 2>(p, M, s);

@@ -1,0 +1,320 @@
+// Small pointwise (1x1x1 / Linear) GEMMs with the K loop cut across the four waves of a workgroup -- CS_MATH_F16X3, tile code 10.
+//
+// Why (r5; VERDICT r4 next #1a, DESIGN "small batches"): at one or two objects the token GEMMs of a transformer block
+// (attention.py:179-245: proj_in, q|k|v, to_out, ff.net.2, proj_out; openai_model_3d.py:307-313 skip_connection; the
+// time-embedding Linears) have 512 ... 2048 rows -- a few dozen 64x64 output tiles -- and the 64x64 tile of
+// cs_gemm_f16x3.hip gives each wave ONE 32x32 accumulator: every 16-wide K chunk is a serial chain "LDS read -> three
+// dependent MFMAs -> operand split -> workgroup barrier", 0.245 us per chunk whatever the DMA depth (7.6 us fixed +
+// 0.245 us x K/16: profiles/r04_tok_smallm_b2.txt).  Here every wave owns the WHOLE 64x64 tile (four independent
+// accumulator chains) over a QUARTER of the K chunks, with its own LDS ring and its own LDS-DMA stream: no barrier in the
+// loop, four times fewer chunks per wave, twelve MFMAs per chunk to hide the fragment reads.  The four partial tiles are
+// then added IN WAVE ORDER through LDS (fixed order: deterministic, independent of scheduling) and one epilogue runs over
+// the tile: bias / row vector / activation / residual, GroupNorm partial sums (CsConvGemm.gn_part, 64-row statistics
+// tiles) and the interleaved operand pair (out_format = 2) -- so every small one-tap launch of a step qualifies.
+//
+// Numerics: the same operand values and power-of-two scales as every other F16X3 tile; the K sum is partitioned into four
+// contiguous ranges (like a four-way split-K), so results differ from the one-chain tiles by fp32 summation order only.
+// Operands: A fp32 rows (split in the loop) or the interleaved pair (a_format = 2); B the packed fp16 hi / lo images.
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+#include "cs_f16x3.h"
+
+namespace {
+
+using cs16::h8;
+using cs16::split8;
+using cs16::wait_vmcnt;
+using cs16::OOB;
+
+constexpr int KW_BM = 64, KW_BN = 64, KW_NST = 4;            // tile, ring stages per wave
+constexpr int KW_STAGE = 4096 + 2 * 2048;                     // A fp32 [64][16] + B hi [2][64][8] + B lo
+constexpr int KW_WAVE = KW_NST * KW_STAGE;                     // 32 KB of ring per wave
+constexpr int KW_LDS = 4 * KW_WAVE;                            // 128 KB: one workgroup per CU
+constexpr int KW_D = 8;                                        // LDS-DMA instructions per wave per chunk (4 A + 2 + 2 B)
+
+template <bool PAIR>
+__global__ __launch_bounds__(256, 1) void kw_gemm_f16x3_kernel(const CsConvGemm p, int M, int tiles_n, int nk,
+                                                               long long x_bytes, unsigned w_bytes) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[KW_LDS];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  int tile;
+  {
+    const int nblk = gridDim.x, b = blockIdx.x;                // XCD-aware: block b runs on XCD b % 8, each XCD a run of tiles
+    const int q = nblk >> 3, r = nblk & 7, xcd = b & 7, within = b >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+  }
+  const int tn = tile % tiles_n, tm = tile / tiles_n;
+  const int m0 = tm * KW_BM, n0 = tn * KW_BN;
+
+  // operand scale from a bound on the tensor's magnitude (CsConvGemm.a_bound), as in cs_gemm_f16x3.hip
+  float a_scale = p.a_scale, acc_scale = p.acc_scale;
+  if constexpr (!PAIR) {
+    if (p.a_bound) {
+      const float mb = *p.a_bound;
+      int ex = 0;
+      float s2 = 1.0995116e12f;
+      if (mb > 0.f && mb < 3.0e38f) {
+        (void)frexpf(65000.0f / mb, &ex);
+        s2 = ldexpf(1.0f, min(max(ex - 1, -8), 40));
+      }
+      acc_scale *= a_scale / s2;
+      a_scale = s2;
+    }
+  }
+
+  const long long x_skip = (long long)m0 * p.lda * 4;
+  const long long x_left = x_bytes - x_skip;
+  const unsigned x_win = x_left > 0xFFE00000LL ? 0xFFE00000u : (x_left > 0 ? (unsigned)x_left : 0u);
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.x + x_skip), 0, x_win, 0x00020000);
+  const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_lo, 0, w_bytes, 0x00020000);
+
+  // this wave's K range: whole chunks, contiguous
+  const int per = (nk + 3) >> 2;
+  const int k0 = wave * per, k1 = min(nk, k0 + per);
+  unsigned char* const ring = smem + wave * KW_WAVE;
+
+  // per-lane DMA constants.  A instruction i covers rows 16 i + lane / 4; LDS slot q = lane & 3 holds global 16-byte piece
+  // q ^ ((row >> 2) & 3) of the row's 64-byte chunk (conflict-free fragment reads, as in cs_gemm_f16x3.hip)
+  unsigned a_off[4];
+  unsigned a_ch[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 16 * i + (lane >> 2);
+    a_ch[i] = (unsigned)(((lane & 3) ^ ((row >> 2) & 3)) * 4);
+    a_off[i] = (m0 + row < M) ? (unsigned)row * ((unsigned)p.lda * 4u) : OOB;
+  }
+  unsigned b_off[2];
+#pragma unroll
+  for (int v = 0; v < 2; ++v) {
+    const int u = 64 * v + lane;                               // kg = u / 64, n = u % 64
+    const int kg = u >> 6, n = u & 63;
+    b_off[v] = (n0 + n < p.cout) ? (unsigned)((kg * p.cout + n0 + n) * 16) : OOB;
+  }
+  auto issue = [&](int kc, int stage) {
+    unsigned char* st = ring + stage * KW_STAGE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = kc * 16 + (int)a_ch[i];
+      const unsigned off = (a_off[i] != OOB && c < p.cin && kc < k1) ? a_off[i] + (unsigned)c * 4u : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, st + i * 1024, 16, off, 0, 0, 0);
+    }
+    const unsigned kbase = (unsigned)(kc * 2 * p.cout) * 16u;
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const unsigned off = (b_off[v] != OOB && kc < k1) ? b_off[v] + kbase : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(hrs, st + 4096 + v * 1024, 16, off, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(lrs, st + 6144 + v * 1024, 16, off, 0, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment addresses inside a stage
+  int a_frag[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = 32 * i + l31;
+    const int s = (row >> 2) & 3;
+    a_frag[i][0] = row * 64 + (((2 * half) ^ s) * 16);
+    a_frag[i][1] = row * 64 + (((2 * half + 1) ^ s) * 16);
+  }
+  const int b_frag = 4096 + (half * 64 + l31) * 16;
+
+  constexpr int PF = KW_NST - 1;                                // chunks of DMA in flight ahead of the MFMAs
+#pragma unroll
+  for (int q = 0; q < PF; ++q) issue(k0 + q, q);
+  float amax = 0.f;
+  auto body = [&](auto stage_c, int kc) {
+    constexpr int stage = decltype(stage_c)::value;
+    // outstanding, oldest first: chunk kc, kc + 1, kc + 2 -- the oldest must have landed (this wave's own data: no barrier)
+    wait_vmcnt<(PF - 1) * KW_D>();
+    const unsigned char* s = ring + stage * KW_STAGE;
+    h8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(s + a_frag[i][0]);
+      const f32x4 x1 = *reinterpret_cast<const f32x4*>(s + a_frag[i][1]);
+      if constexpr (PAIR) {
+        ah[i] = __builtin_bit_cast(h8, x0);
+        al[i] = __builtin_bit_cast(h8, x1);
+      } else {
+        split8(x0, x1, a_scale, ah[i], al[i], amax);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bh[j] = *reinterpret_cast<const h8*>(s + b_frag + j * 512);
+      bl[j] = *reinterpret_cast<const h8*>(s + b_frag + 2048 + j * 512);
+    }
+    // the stage this chunk's predecessor used is free: its fragments were in registers before its MFMAs issued
+    issue(kc + PF, (stage + PF) % KW_NST);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+      }
+  };
+  for (int kc = k0; kc < k1; kc += KW_NST) {
+    body(std::integral_constant<int, 0>{}, kc);
+    if (kc + 1 < k1) body(std::integral_constant<int, 1>{}, kc + 1);
+    if (kc + 2 < k1) body(std::integral_constant<int, 2>{}, kc + 2);
+    if (kc + 3 < k1) body(std::integral_constant<int, 3>{}, kc + 3);
+  }
+  wait_vmcnt<0>();                                              // the zero-fill prefetches issued past the range
+  if constexpr (!PAIR) {
+    if (p.status && amax >= 65504.f) atomicOr(p.status, CS_STATUS_F16X3_OVERFLOW);
+  }
+
+  // ---- the four waves' partial tiles -> LDS (each into its own ring: no hazard before the barrier) ----
+  float* const mine = reinterpret_cast<float*>(ring);           // [64][64]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+        mine[row * 64 + 32 * j + l31] = acc[i][j][r];
+      }
+  __syncthreads();
+
+  // ---- one epilogue over the tile: thread = (row, float4 column), four units each ----
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  const bool gstat = p.gn_part != nullptr, opair = p.out_format == 2;
+  float* const fin = reinterpret_cast<float*>(smem + 16384);    // [64][64] final values (gn_part): wave 0's ring, upper half
+  float oamax = 0.f;
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    const int u = tid + 256 * jj;
+    const int row = u >> 4, c4 = u & 15;
+    const int m = m0 + row, n = n0 + 4 * c4;
+    const bool ok = m < M && n < p.cout;
+    f32x4 v = *reinterpret_cast<const f32x4*>(smem + 0 * KW_WAVE + (row * 64 + 4 * c4) * 4);
+    v += *reinterpret_cast<const f32x4*>(smem + 1 * KW_WAVE + (row * 64 + 4 * c4) * 4);
+    v += *reinterpret_cast<const f32x4*>(smem + 2 * KW_WAVE + (row * 64 + 4 * c4) * 4);
+    v += *reinterpret_cast<const f32x4*>(smem + 3 * KW_WAVE + (row * 64 + 4 * c4) * 4);
+    v = v * acc_scale;
+    if (ok) {
+      if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+      if (p.scale) v = v * *reinterpret_cast<const f32x4*>(p.scale + n) + *reinterpret_cast<const f32x4*>(p.shift + n);
+      if (p.rowvec) v += *reinterpret_cast<const f32x4*>(p.rowvec + (int64_t)(m / p.rv_rows) * p.ldrv + n);
+      if (p.act != CS_ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = cs_act(v[e], p.act);
+      }
+      if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (int64_t)m * p.ldr + n);
+    } else {
+      v = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (gstat) *reinterpret_cast<f32x4*>(fin + row * 64 + 4 * c4) = v;
+    if (opair) {                                                // uniform branch: every lane takes part in the half swap
+      h4 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float o = v[e] * p.out_scale;
+        oamax = fmaxf(oamax, fabsf(o));
+        hi[e] = (_Float16)o;
+        lo[e] = (_Float16)(o - (float)hi[e]);
+      }
+      const u32x2 H = __builtin_bit_cast(u32x2, hi), L = __builtin_bit_cast(u32x2, lo);
+      const bool odd = tid & 1;
+      const u32x2 send = odd ? H : L;
+      u32x2 recv;
+      recv[0] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send[0], 0xB1, 0xF, 0xF, true);
+      recv[1] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send[1], 0xB1, 0xF, 0xF, true);
+      u32x4 r;
+      r[0] = odd ? recv[0] : H[0];
+      r[1] = odd ? recv[1] : H[1];
+      r[2] = odd ? L[0] : recv[0];
+      r[3] = odd ? L[1] : recv[1];
+      if (ok) {
+        char* orow = reinterpret_cast<char*>(p.out + (int64_t)m * p.ldo);
+        *reinterpret_cast<u32x4*>(orow + (n >> 4) * 64 + ((n & 8) ? 32 : 0) + ((n & 4) ? 16 : 0)) = r;
+      }
+    } else if (ok) {
+      *reinterpret_cast<f32x4*>(p.out + (int64_t)m * p.ldo + n) = v;
+    }
+  }
+  if (opair && p.status && oamax >= 65504.f) atomicOr(p.status, CS_STATUS_F16X3_OVERFLOW);
+  if (gstat) {
+    // per (64-row statistics tile, column): the fp64 sum and sum of squares of the FINAL values, rows in order
+    __syncthreads();
+    if (tid < 64 && n0 + tid < p.cout) {
+      double ts = 0.0, tq = 0.0;
+      for (int r2 = 0; r2 < 64; ++r2) {
+        const double d = (double)fin[r2 * 64 + tid];
+        ts += d;
+        tq += d * d;
+      }
+      double* o = p.gn_part + ((int64_t)tm * p.gn_ld + n0 + tid) * 2;
+      o[0] = ts;
+      o[1] = tq;
+    }
+  }
+}
+
+}  // namespace
+
+// Is this descriptor a GEMM the K-wave kernel takes?  Pointwise, F16X3, fp32 or pair operands, float4-aligned epilogue
+// operands.  (The tile RULE -- when auto-selection prefers it -- lives in cs_gemm.hip::auto_tile.)
+bool cs_kw_gemm_applicable(const CsConvGemm& p, int64_t M) {
+  auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+  if (p.math != CS_MATH_F16X3 || M <= 0 || M > 0x7fffffffLL || p.act == CS_ACT_GEGLU) return false;
+  if (!(p.kd == 1 && p.kh == 1 && p.kw == 1 && p.sd == 1 && p.sh == 1 && p.sw == 1 && p.ud == 0 && p.uh == 0 && p.uw == 0 &&
+        p.pd == 0 && p.ph == 0 && p.pw == 0 && (int64_t)p.dout * p.hout * p.wout == (int64_t)p.din * p.hin * p.win))
+    return false;
+  if (p.a_format != 0 && p.a_format != 2) return false;
+  if (p.a_format == 2 && ((p.cin & 15) || (p.lda & 15))) return false;
+  if ((p.cin & 3) || (p.lda & 3) || (p.cout & 3) || (p.ldo & 3) || !al16(p.x) || !al16(p.out) || !al16(p.w) || !p.w_lo ||
+      !al16(p.w_lo))
+    return false;
+  if ((p.bias && !al16(p.bias)) || (p.scale && (!p.shift || !al16(p.scale) || !al16(p.shift))) ||
+      (p.rowvec && ((p.ldrv & 3) || !al16(p.rowvec) || p.rv_rows <= 0)) || (p.res && ((p.ldr & 3) || !al16(p.res))))
+    return false;
+  if (64LL * p.lda * 4 >= 0x7FF00000LL) return false;            // a tile's rows inside one 32-bit offset window
+  if (p.splitk > 1) return false;
+  return true;
+}
+
+int cs_kw_gemm_f16x3_launch(const CsConvGemm& p_in, int M, hipStream_t s) {
+  CsConvGemm p = p_in;
+  if (!cs_kw_gemm_applicable(p, M)) return CS_EINVAL;
+  if (p.a_scale == 0.f) p.a_scale = cs16::A_SCALE_DEFAULT;
+  if (!(p.acc_scale > 0.f) || !(p.a_scale > 0.f)) return CS_EINVAL;
+  if (p.out_format != 0 && (p.out_format != 2 || !(p.out_scale > 0.f) || ((p.act == CS_ACT_GEGLU ? p.cout / 2 : p.cout) & 7) ||
+                            (p.ldo & 15) || ((uintptr_t)p.out & 63)))
+    return CS_EINVAL;
+  if (p.gn_part && (p.gn_rows != KW_BM || p.gn_ld < p.cout || ((uintptr_t)p.gn_part & 15))) return CS_EINVAL;
+  const int tiles_m = (M + KW_BM - 1) / KW_BM, tiles_n = (p.cout + KW_BN - 1) / KW_BN;
+  const int64_t nblk = (int64_t)tiles_m * tiles_n;
+  if (nblk > 0x7fffffffLL) return CS_EINVAL;
+  const int nk = (p.cin + 15) / 16;
+  const int kg_per_tap = nk * 2;
+  const int64_t x_bytes = ((int64_t)(M - 1) * p.lda + p.cin) * 4;
+  const int64_t w_bytes = (int64_t)kg_per_tap * p.cout * 16;
+  if (w_bytes > 0xFFE00000LL) return CS_EINVAL;
+  if (p.a_format == 2)
+    CS_LAUNCH((kw_gemm_f16x3_kernel<true>), dim3((unsigned)nblk), dim3(256), 0, s, p, M, tiles_n, nk, (long long)x_bytes,
+              (unsigned)w_bytes);
+  else
+    CS_LAUNCH((kw_gemm_f16x3_kernel<false>), dim3((unsigned)nblk), dim3(256), 0, s, p, M, tiles_n, nk, (long long)x_bytes,
+              (unsigned)w_bytes);
+  CS_CHECK_LAUNCH();
+  return CS_OK;
+}

@@ -117,6 +117,11 @@ def main():
                     help="additionally sample the first scene once with the default (fp32-grade F16X3) attention and once "
                          "with the fp16 MFMA attention from the SAME z / x_T and report the latent / SDF deviation "
                          "(SURVEY 8d: fp16-attention mode is report-only)")
+    ap.add_argument("--batch-scenes", action="store_true",
+                    help="additionally time the shape sampling of ALL scenes scene by scene (the reference's loop, "
+                         "scripts/eval_3dfront.py:484-513) against ONE coalesced call (VAE.sample_box_and_shape_many: each "
+                         "scene's graph and shared x_T kept, one sampler + decode over all scenes' objects), same z / x_T, "
+                         "and report the wall times and the per-object latent deviation")
     a = ap.parse_args()
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -173,6 +178,42 @@ def main():
                 note="fp16 MFMA attention (one fp16 pass, fp32 softmax/accumulate) vs the default fp32-grade F16X3 "
                      "attention, same z / x_T / weights; report-only (SURVEY 8d)")
             model.vae_v2.Diff.df.set_attention_math("f16" if a.attention == "f16" else "same")
+        if a.batch_scenes:
+            from commonscenes_amd import synth
+            scs = []
+            for si, data in enumerate(loader):
+                d = data["decoder"]
+                O = d["objs"].shape[0]
+                scs.append(dict(dec_objs=d["objs"].cuda(), dec_triplets=d["tripltes"].cuda(), dec_sdfs=d["sdfs"],
+                                encoded_dec_text_feat=d["text_feats"].cuda(), encoded_dec_rel_feat=d["rel_feats"].cuda(),
+                                z=synth.gaussian_like(f"ev:bs:z{si}", (O, 64)),
+                                x_T=synth.gaussian_like(f"ev:bs:x{si}", (1, 3, 16, 16, 16))))
+
+            def per_scene():
+                outs, lats = [], []
+                for sc in scs:
+                    outs.append(model.sample_box_and_shape(None, sc["dec_objs"], sc["dec_triplets"], sc["dec_sdfs"],
+                                                           sc["encoded_dec_text_feat"], sc["encoded_dec_rel_feat"],
+                                                           gen_shape=True, ddim_steps=a.ddim_steps, z=sc["z"], x_T=sc["x_T"]))
+                    lats.append(model.vae_v2.Diff.last_latents)
+                return outs, torch.cat(lats)
+
+            def batched():
+                outs = model.sample_box_and_shape_many(scs, gen_shape=True, ddim_steps=a.ddim_steps)
+                return outs, model.vae_v2.Diff.last_latents
+
+            with torch.no_grad():
+                per_scene(); batched()                        # warm-up (weight packing, allocator)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter(); o1, l1 = per_scene(); torch.cuda.synchronize(); t_ps = time.perf_counter() - t0
+                t0 = time.perf_counter(); o2, l2 = batched(); torch.cuda.synchronize(); t_b = time.perf_counter() - t0
+            dev = float((l2.double() - l1.double()).norm() / l1.double().norm())
+            res["batch_scenes"] = dict(scenes=len(scs), objects=[int(o[1].shape[0]) for o in o1], ddim_steps=a.ddim_steps,
+                                       scene_by_scene_s=t_ps, coalesced_s=t_b, speedup=t_ps / t_b,
+                                       launch_sizes=list(model.vae_v2.Diff.last_launch_sizes), latent_rel_l2=dev,
+                                       boxes_equal=all(bool(torch.equal(x[0][0], y[0][0])) for x, y in zip(o1, o2)),
+                                       note="shape sampling + decode of all scenes: one sample_box_and_shape call per scene "
+                                            "(eval_3dfront.py:484-513) vs VAE.sample_box_and_shape_many")
         x_T = None                                            # like the reference: fresh noise per call
         all_div_boxes, all_div_angles, all_div_chamfer = [], [], []
         t_all = time.perf_counter()
