@@ -50,7 +50,10 @@ __global__ __launch_bounds__(64 * NW) void attn_f16x3_kernel(const float* __rest
                                                          const float* __restrict__ v, float* __restrict__ out,
                                                          int nq, int nk, int heads, int dh, int ldq, int ldk,
                                                          int ldv, int ldo, float scale, int qtiles, int nbh,
-                                                         int32_t* __restrict__ status) {
+                                                         int32_t* __restrict__ status, float qs, float ks, float vs) {
+  // qs / ks / vs (r5): the power-of-two operand pre-scales of Q * scale, K and V -- 16 each by default (QK_SCALE), or the
+  // static bounds' scales of cs_attn_selfattn_f16x3_scaled (a transformer block's q / k / v are Linear(LayerNorm(x)):
+  // bounded by the weights alone)
   constexpr int DP = 32 * DB;
   float amax = 0.f;                    // largest |scaled Q / K / V operand| this lane converted to fp16
   constexpr int LDK = DP + 8;          // halves; 16 consecutive rows hit 16 distinct 16-byte slots
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(64 * NW) void attn_f16x3_kernel(const float* __rest
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int d = 16 * t + 8 * half + e;
-      const float x = d < dh ? qp[d] * (scale * QK_SCALE) : 0.f;
+      const float x = d < dh ? qp[d] * (scale * qs) : 0.f;
       _Float16 a, c;
       split1m(x, a, c, amax);
       qh[t][e] = a;
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(64 * NW) void attn_f16x3_kernel(const float* __rest
   // PV operands need is folded into the exponent, and the running sum carries it until the final normalisation).
   float mrun = -INFINITY;
   float lrun = 0.f;
-  const float cexp = 1.44269504088896340736f / (QK_SCALE * QK_SCALE);
+  const float cexp = 1.44269504088896340736f / (qs * ks);
   const float lp = 10.0f;             // log2(P_SCALE)
   static_assert(P_SCALE == 1024.0f, "lp = log2(P_SCALE)");
 
@@ -172,10 +175,10 @@ __global__ __launch_bounds__(64 * NW) void attn_f16x3_kernel(const float* __rest
       if (k_l[i] >= 0) {
         h4 hi, lo;
         _Float16 a, c;
-        split1m(kr[i].x * QK_SCALE, a, c, amax); hi[0] = a; lo[0] = c;
-        split1m(kr[i].y * QK_SCALE, a, c, amax); hi[1] = a; lo[1] = c;
-        split1m(kr[i].z * QK_SCALE, a, c, amax); hi[2] = a; lo[2] = c;
-        split1m(kr[i].w * QK_SCALE, a, c, amax); hi[3] = a; lo[3] = c;
+        split1m(kr[i].x * ks, a, c, amax); hi[0] = a; lo[0] = c;
+        split1m(kr[i].y * ks, a, c, amax); hi[1] = a; lo[1] = c;
+        split1m(kr[i].z * ks, a, c, amax); hi[2] = a; lo[2] = c;
+        split1m(kr[i].w * ks, a, c, amax); hi[3] = a; lo[3] = c;
         *reinterpret_cast<h4*>(Kh + k_l[i]) = hi;
         if constexpr (!X1) *reinterpret_cast<h4*>(Kl + k_l[i]) = lo;
       }
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(64 * NW) void attn_f16x3_kernel(const float* __rest
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           _Float16 a, c;
-          split1m(x[e] * QK_SCALE, a, c, amax);
+          split1m(x[e] * vs, a, c, amax);
           Vh[v_l[i] + e * LDV] = a;
           if constexpr (!X1) Vl[v_l[i] + e * LDV] = c;
         }
@@ -210,10 +213,10 @@ __global__ __launch_bounds__(64 * NW) void attn_f16x3_kernel(const float* __rest
         if (kt0 + j < nk) kv = *reinterpret_cast<const float4*>(kb + (int64_t)(kt0 + j) * ldk + c4 * 4);
         h4 hi, lo;
         _Float16 a, c;
-        split1m(kv.x * QK_SCALE, a, c, amax); hi[0] = a; lo[0] = c;
-        split1m(kv.y * QK_SCALE, a, c, amax); hi[1] = a; lo[1] = c;
-        split1m(kv.z * QK_SCALE, a, c, amax); hi[2] = a; lo[2] = c;
-        split1m(kv.w * QK_SCALE, a, c, amax); hi[3] = a; lo[3] = c;
+        split1m(kv.x * ks, a, c, amax); hi[0] = a; lo[0] = c;
+        split1m(kv.y * ks, a, c, amax); hi[1] = a; lo[1] = c;
+        split1m(kv.z * ks, a, c, amax); hi[2] = a; lo[2] = c;
+        split1m(kv.w * ks, a, c, amax); hi[3] = a; lo[3] = c;
         *reinterpret_cast<h4*>(Kh + j * LDK + c4 * 4) = hi;
         if constexpr (!X1) *reinterpret_cast<h4*>(Kl + j * LDK + c4 * 4) = lo;
       }
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(64 * NW) void attn_f16x3_kernel(const float* __rest
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           _Float16 a, c;
-          split1m(x[i] * QK_SCALE, a, c, amax);
+          split1m(x[i] * vs, a, c, amax);
           Vh[(c4 * 4 + i) * LDV + pj] = a;
           if constexpr (!X1) Vl[(c4 * 4 + i) * LDV + pj] = c;
         }
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(64 * NW) void attn_f16x3_kernel(const float* __rest
 
   if (status && amax >= 65504.f) atomicOr(status, CS_STATUS_F16X3_OVERFLOW);
   const float ltot = lrun + __shfl_xor(lrun, 32, 64);
-  const float inv = 1.0f / (ltot * QK_SCALE);       // ltot already carries P_SCALE
+  const float inv = 1.0f / (ltot * vs);       // ltot already carries P_SCALE
   if (q0 + l31 < nq) {
     float* op = out + ((int64_t)b * nq + q0 + l31) * ldo + h * dh;
 #pragma unroll
@@ -768,7 +771,8 @@ inline int img_variant(int nq, int nk, int dh) {
 
 template <int DB, int KT, bool X1, int NW = 4>
 int launch_attn16(const float* q, const float* k, const float* v, float* out, int nb, int nq, int nk, int heads,
-                  int dh, int ldq, int ldk, int ldv, int ldo, float scale, int32_t* status, hipStream_t s) {
+                  int dh, int ldq, int ldk, int ldv, int ldo, float scale, int32_t* status, hipStream_t s,
+                  float qs = QK_SCALE, float ks = QK_SCALE, float vs = QK_SCALE) {
   constexpr int DP = 32 * DB;
   const size_t smem = (size_t)(2 * KT * (DP + 8) + 2 * DP * (KT + 8)) * sizeof(_Float16);
   const int qtiles = (nq + 32 * NW - 1) / (32 * NW);
@@ -784,7 +788,7 @@ int launch_attn16(const float* q, const float* k, const float* v, float* out, in
     if (e != hipSuccess) return (int)e;
   }
   CS_LAUNCH(kern, dim3((unsigned)grid), dim3(64 * NW), smem, s, q, k, v, out, nq, nk, heads, dh, ldq, ldk, ldv, ldo,
-            scale, qtiles, nb * heads, status);
+            scale, qtiles, nb * heads, status, qs, ks, vs);
   CS_CHECK_LAUNCH();
   return CS_OK;
 }
@@ -793,14 +797,15 @@ int launch_attn16(const float* q, const float* k, const float* v, float* out, in
 
 template <bool X1>
 static int attn16_dispatch(const float* q, const float* k, const float* v, float* out, int nb, int nq, int nk, int heads,
-                           int dh, int ldq, int ldk, int ldv, int ldo, float scale, int32_t* status, cs_stream_t stream) {
+                           int dh, int ldq, int ldk, int ldv, int ldo, float scale, int32_t* status, cs_stream_t stream,
+                           float qs = QK_SCALE, float ks = QK_SCALE, float vs = QK_SCALE) {
   if (!q || !k || !v || !out || nb <= 0 || nq <= 0 || nk <= 0 || heads <= 0 || dh <= 0) return CS_EINVAL;
   if ((dh & 3) || (ldq & 3) || (ldk & 3) || (ldv & 3) || (ldo & 3)) return CS_EINVAL;
   if (ldq < heads * dh || ldk < heads * dh || ldv < heads * dh || ldo < heads * dh) return CS_EINVAL;
   if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || ((uintptr_t)out & 15))
     return CS_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  if (dh <= 32) return launch_attn16<1, 64, X1>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, s);
+  if (dh <= 32) return launch_attn16<1, 64, X1>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, s, qs, ks, vs);
   // eight waves per staged tile amortise the K / V conversion over 256 queries -- but only once such workgroups fill the
   // chip: at small batches (1 object: 16 (sample, head) groups, 64 workgroups at 1024 tokens, 16 at 256) four-wave
   // workgroups double the count on a mostly idle GPU (1 object: 71.4 -> 60.0 us and 34.5 -> 31.7; from 128 eight-wave
@@ -810,16 +815,16 @@ static int attn16_dispatch(const float* q, const float* k, const float* v, float
   const bool fill8 = cs_debug()->attn_nw8 || (int64_t)nb * heads * ((nq + 255) / 256) >= 128;
   if (dh <= 64) {
     if (nq >= 512 && fill8)
-      return launch_attn16<2, 64, X1, 8>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, s);
-    return launch_attn16<2, 64, X1>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, s);
+      return launch_attn16<2, 64, X1, 8>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, s, qs, ks, vs);
+    return launch_attn16<2, 64, X1>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, s, qs, ks, vs);
   }
   if (dh <= 96) {
     if (nq >= 256 && fill8)
-      return launch_attn16<3, 64, X1, 8>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, s);
-    return launch_attn16<3, 64, X1>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, s);
+      return launch_attn16<3, 64, X1, 8>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, s, qs, ks, vs);
+    return launch_attn16<3, 64, X1>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, s, qs, ks, vs);
   }
-  if (dh <= 128) return launch_attn16<4, 64, X1>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, s);
-  if (dh <= 256) return launch_attn16<8, 32, X1>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, s);
+  if (dh <= 128) return launch_attn16<4, 64, X1>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, s, qs, ks, vs);
+  if (dh <= 256) return launch_attn16<8, 32, X1>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, s, qs, ks, vs);
   return CS_EINVAL;
 }
 
@@ -827,6 +832,20 @@ extern "C" int cs_attn_selfattn_f16x3(const float* q, const float* k, const floa
                                       int nk, int heads, int dh, int ldq, int ldk, int ldv, int ldo, float scale,
                                       int32_t* status, cs_stream_t stream) {
   return attn16_dispatch<false>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, stream);
+}
+
+// r5: the same kernel with the operands' power-of-two pre-scales given by the caller instead of the constant 16: a
+// transformer block's q / k / v are Linear(LayerNorm(x)) -- bounded by the weights alone (|q_j| <= ||W_j||_2 (max|gamma| sqrt(C)
+// + ||beta||_2)) -- so the host picks, once per checkpoint, the largest powers of two that keep q * scale * q_scale,
+// k * k_scale and v * v_scale inside the fp16 range: no activation can raise CS_STATUS_F16X3_OVERFLOW here whatever the
+// input, and operands keep the same relative precision at any weight scale (attention.py:179-218).
+extern "C" int cs_attn_selfattn_f16x3_scaled(const float* q, const float* k, const float* v, float* out, int nb, int nq,
+                                             int nk, int heads, int dh, int ldq, int ldk, int ldv, int ldo, float scale,
+                                             float q_scale, float k_scale, float v_scale, int32_t* status,
+                                             cs_stream_t stream) {
+  if (!(q_scale > 0.f) || !(k_scale > 0.f) || !(v_scale > 0.f)) return CS_EINVAL;
+  return attn16_dispatch<false>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, stream, q_scale,
+                                k_scale, v_scale);
 }
 
 extern "C" int cs_attn_selfattn_f16(const float* q, const float* k, const float* v, float* out, int nb, int nq,

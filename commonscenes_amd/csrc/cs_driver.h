@@ -79,6 +79,8 @@ struct Plan {
   std::vector<RawCopy> copies;
   int64_t raw_bytes = 0, arena_bytes = 0, amax_off = 0;
   int amax_slots = 0;      // per-parameter |w| maxima, then one per parity class of every folded upsample conv
+  int extra_slots = 0;     // ... then this many more floats reserved by the model (cs_unet: 34 per transformer block, r5)
+  int extra_slot0 = 0;     // index of the first of them (set by layout_arena)
   bool packed = false;
 };
 
@@ -241,6 +243,8 @@ void layout_arena(Plan& u) {
     rc.arena_off = off;
     off += align_up(u.params[rc.param].numel * 4);
   }
+  u.extra_slot0 = slots;
+  slots += u.extra_slots;
   u.amax_off = off;
   u.amax_slots = slots;
   off += align_up((int64_t)slots * 4);
@@ -972,8 +976,18 @@ struct ExecBase {
 
   // self-attention over a fused [rows][3c] q | k | v buffer -> a [rows][c]; F16X3: K / V tile images in a scratch buffer
   // where the library has that path (cs_attn_f16x3_ws_bytes > 0)
-  void self_attention(const Buf& qkv, const Buf& a, int nb, int n, int heads, int dh, int c, float scale) {
+  // qkv_scales (r5): the static-bound operand scales of q * scale, k, v (cs_transformer_static_scales), or nullptr = 16
+  void self_attention(const Buf& qkv, const Buf& a, int nb, int n, int heads, int dh, int c, float scale,
+                      const float* qkv_scales = nullptr) {
     Buf ws;
+    if (qkv_scales && pl.math == CS_MATH_F16X3) {
+      if (ok() && !dry) {
+        const float* q = p(qkv);
+        chk(cs_attn_selfattn_f16x3_scaled(q, q + c, q + 2 * c, p(a), nb, n, n, heads, dh, 3 * c, 3 * c, 3 * c, c, scale,
+                                          qkv_scales[0], qkv_scales[1], qkv_scales[2], status, st));
+      }
+      return;
+    }
     const int64_t wsb = pl.math == CS_MATH_F16X3 ? cs_attn_f16x3_ws_bytes(nb, n, n, heads, dh) : 0;
     if (wsb > 0) ws = alloc(wsb / 4, 1);
     if (ok() && !dry) {

@@ -723,6 +723,43 @@ extern "C" int cs_embedding(const float* table, const int64_t* idx, float* out, 
   return CS_OK;
 }
 
+// r5: max over the rows of ||row||_2 and max |entry| of a [rows][cols] fp32 matrix (a Linear / 1x1x1 conv weight, a bias or
+// a norm's beta as one row) -- what the static operand bounds of a transformer block are built from (cs_transformer_static_
+// scales).  One wave per row, fp64 sum of squares, fixed butterfly; out2 = {max row norm, max abs} is combined by atomicMax
+// of the (non-negative) bits, so it must be ZERO on entry and several calls may fold into one slot pair.
+__global__ __launch_bounds__(256) void weight_rowstats_kernel(const float* __restrict__ w, int rows, int cols,
+                                                              float* __restrict__ out2) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* r = w + (int64_t)row * cols;
+  double ss = 0.0;
+  float am = 0.f;
+  for (int c = lane; c < cols; c += 64) {
+    const float v = r[c];
+    ss += (double)v * v;
+    am = fmaxf(am, fabsf(v));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ss += __shfl_xor(ss, o, 64);
+    am = fmaxf(am, __shfl_xor(am, o, 64));
+  }
+  if (lane == 0) {
+    float nrm = (float)sqrt(ss);
+    if ((double)nrm * nrm < ss) nrm = __uint_as_float(__float_as_uint(nrm) + 1u);      // round UP: it is a bound
+    atomicMax(reinterpret_cast<unsigned int*>(out2), __float_as_uint(nrm));
+    atomicMax(reinterpret_cast<unsigned int*>(out2 + 1), __float_as_uint(am));
+  }
+}
+
+extern "C" int cs_weight_rowstats(const float* w, int rows, int cols, float* out2, cs_stream_t stream) {
+  if (!w || !out2 || rows <= 0 || cols <= 0 || ((uintptr_t)out2 & 3)) return CS_EINVAL;
+  CS_LAUNCH(weight_rowstats_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, w, rows, cols, out2);
+  CS_CHECK_LAUNCH();
+  return CS_OK;
+}
+
 extern "C" int cs_log_softmax(const float* x, float* y, int m, int c, int ldx, int ldy, cs_stream_t stream) {
   if (!x || !y || m <= 0 || c <= 0 || ldx < c || ldy < c) return CS_EINVAL;
   CS_LAUNCH(log_softmax_kernel, dim3((m + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, y, m, c,

@@ -59,6 +59,7 @@ void parse_env(CsDebug& d) {
   d.no_temb_table = flag("CS_NO_TEMB_TABLE");
   d.no_gn_fold = flag("CS_NO_GN_FOLD");
   d.no_kwave = flag("CS_NO_KWAVE");
+  d.no_static_scales = flag("CS_NO_STATIC_SCALES");
 }
 
 }  // namespace
@@ -90,6 +91,58 @@ extern "C" float cs_norm_a_scale(float gmax, float bmax, int64_t n) {
   if (k < -8) k = -8;
   if (k > 40) k = 40;
   return (float)std::ldexp(1.0, k);
+}
+
+extern "C" float cs_bound_a_scale(float bound) {
+  if (!(bound > 0.f) || !std::isfinite(bound)) return (float)std::ldexp(1.0, 40);
+  int ex = 0;
+  (void)std::frexp(65000.0 / (double)bound, &ex);
+  int k = ex - 1;
+  if (k < -24) k = -24;
+  if (k > 40) k = 40;
+  return (float)std::ldexp(1.0, k);
+}
+
+// r5: F16X3 operand scales of the operands BORN INSIDE a transformer block (attention.py:237-245,
+// 335-351) from bounds that hold for every input -- so they can never leave the fp16 range and CS_STATUS_F16X3_OVERFLOW is a
+// pure assertion there.  ONE rule for both hosts (unet.py::_static_scales, cs_unet.hip::attn_block).
+//   st (CsTransformerStats): max row 2-norms r* and max |bias| b* of the block's Linears (cs_weight_rowstats), max |gamma|
+//   and ||beta||_2 of LayerNorm 1 / 3;  gn_gmax / gn_bmax: max |gamma| / |beta| of the SpatialTransformer's GroupNorm;
+//   ctx_max: the largest |entry| of the block's one-token cross-attention row vector (data of the RUN, read once per run).
+//     Y1 = g1 sqrt(c) + ||b1||            >= ||LayerNorm1(x) token||_2   (a normalised token has 2-norm sqrt(c))
+//     |q| <= rq Y1, |k| <= rk Y1, |v| <= rv Y1 =: Bv  (no bias);   |attention output| <= Bv  (softmax rows: convex weights)
+//     |t0| <= rpi sqrt(c) (gn_gmax sqrt(n - 1) + gn_bmax) + bpi,   n = tokens * c / 32 elements per GroupNorm group
+//     |t1| <= ro sqrt(c) Bv + bo + |t0| + ctx_max
+//     |x|, |gate| of the GEGLU <= rx Y3 + bx, rg Y3 + bg;   |gg| <= their product  (|gelu(g)| <= |g|)
+//     |t2| <= r2 sqrt(4c) |gg| + b2 + |t1|
+//   out[0..2] = scales of q * dh^-1/2, k, v (cs_attn_selfattn_f16x3_scaled), out[3] = attention output -> to_out,
+//   out[4] = gg -> ff.net.2, out[5] = t2 -> proj_out;  out[6..11] = the bounds (q, k, v, t1, gg, t2), for reports.
+// The 2-norm chains overshoot by one to three orders of magnitude: with scale = 65000 / bound an operand's absolute floor
+// is 2^-25 bound / 65000 ~ 5e-13 bound, still fp32 grade for values five orders of magnitude below the bound.
+extern "C" int cs_transformer_static_scales(const CsTransformerStats* st, int c, int64_t n_tokens, int heads, float gn_gmax,
+                                            float gn_bmax, float ctx_max, float* out12) {
+  if (!st || !out12 || c <= 0 || heads <= 0 || c % heads || n_tokens <= 0) return CS_EINVAL;
+  const double rc = std::sqrt((double)c);
+  const double dh = (double)(c / heads);
+  const double y1 = (double)st->g1 * rc + (double)st->be1;
+  const double bq = (double)st->rq * y1, bk = (double)st->rk * y1, bv = (double)st->rv * y1;
+  const double ngrp = (double)n_tokens * (double)(c / 32 > 0 ? c / 32 : 1);
+  const double egn = (double)gn_gmax * std::sqrt(ngrp > 1.0 ? ngrp - 1.0 : 1.0) + (double)gn_bmax;
+  const double bt0 = (double)st->rpi * rc * egn + (double)st->bpi;
+  const double bt1 = (double)st->ro * rc * bv + (double)st->bo + bt0 + (double)(ctx_max > 0.f ? ctx_max : 0.f);
+  const double y3 = (double)st->g3 * rc + (double)st->be3;
+  const double bgg = ((double)st->rx * y3 + (double)st->bx) * ((double)st->rg * y3 + (double)st->bg);
+  const double bt2 = (double)st->r2 * std::sqrt(4.0 * c) * bgg + (double)st->b2 + bt1;
+  auto S = [](double b) { return cs_bound_a_scale(b < 3.0e38 ? (float)(b * (1.0 + 1e-6)) : 3.0e38f); };
+  out12[0] = S(bq / std::sqrt(dh));
+  out12[1] = S(bk);
+  out12[2] = S(bv);
+  out12[3] = S(bv);
+  out12[4] = S(bgg);
+  out12[5] = S(bt2);
+  out12[6] = (float)bq; out12[7] = (float)bk; out12[8] = (float)bv; out12[9] = (float)bt1; out12[10] = (float)bgg;
+  out12[11] = (float)bt2;
+  return CS_OK;
 }
 
 // Should the GroupNorm feeding a conv (cout x cin x k^3, `plain`: neither a folded Upsample conv nor taps-as-columns) over m

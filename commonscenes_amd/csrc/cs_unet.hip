@@ -31,6 +31,13 @@ struct Layer {
   int gsp[4] = {-1, -1, -1, -1};
   int ctx_off = 0;     // ATTN: column offset into the context-vector block
   bool fused_geglu = false;
+  // ATTN, F16X3 (r5): what bounds the operands born inside the transformer block (cs_transformer_static_scales): filled by
+  // cs_unet_pack from the raw weights; ctx_max = the largest |entry| of the block's cross-attention row vector of the
+  // current run (cs_unet_set_context_bounds), 0 until the host sets it
+  CsTransformerStats ts;
+  bool has_ts = false;
+  float ctx_max = 0.f;
+  int ts_slot = -1;    // first of this block's 34 float slots behind the plan's |w| maxima
 };
 
 }  // namespace
@@ -277,7 +284,29 @@ int build(cs_unet& u) {
   u.g_emb_all = add_gemm(u, emb.w, emb.b, emb.total, ted, 0);
   u.emb_total = emb.total;
 
+  {
+    // r5: 34 float slots per transformer block for the static-bound statistics (cs_unet_pack)
+    int nblk = 0;
+    auto count = [&](std::vector<Layer>& layers) {
+      for (Layer& l : layers)
+        if (l.kind == ATTN) ++nblk;
+    };
+    for (auto& layers : u.inp) count(layers);
+    count(u.mid);
+    for (auto& layers : u.out) count(layers);
+    u.extra_slots = (c.math == CS_MATH_F16X3) ? 34 * nblk : 0;
+  }
   layout_arena(u);
+  if (u.extra_slots) {
+    int k = 0;
+    auto assign = [&](std::vector<Layer>& layers) {
+      for (Layer& l : layers)
+        if (l.kind == ATTN) l.ts_slot = u.extra_slot0 + 34 * k++;
+    };
+    for (auto& layers : u.inp) assign(layers);
+    assign(u.mid);
+    for (auto& layers : u.out) assign(layers);
+  }
   return CS_OK;
 }
 
@@ -376,7 +405,13 @@ struct Exec : ExecBase {
     Buf qkv = linear(n1, l.g[1]);
     release(n1);
     Buf a = alloc(rows, c);
-    self_attention(qkv, a, x.nb, n, heads, dh, c, (float)std::pow((double)dh, -0.5));
+    // r5: static bounds of the operands born inside the block (unet.py::_static_scales; the ONE rule in cs_plan.hip)
+    float ss[12];
+    const Norm& gnn = pl.norms[l.n[0]];
+    const bool stat = l.has_ts && u.cfg.math == CS_MATH_F16X3 && !cs_debug()->no_static_scales && ctxvec &&
+                      cs_transformer_static_scales(&l.ts, c, n, heads, gnn.gmax, gnn.bmax, l.ctx_max, ss) == CS_OK;
+    self_attention(qkv, a, x.nb, n, heads, dh, c, (float)std::pow((double)dh, -0.5), stat ? ss : nullptr);
+    if (stat) a.a_scale = ss[3];
     release(qkv);
     // one context token: attn2(x) == to_out(to_v(ctx)) for every query row -> a row vector in this epilogue
     Buf t1 = linear(a, l.g[2], CS_ACT_NONE, ctxvec ? ctxvec + l.ctx_off : nullptr, u.ctx_total, n,
@@ -388,16 +423,19 @@ struct Exec : ExecBase {
     // gg's only reader is ff.net.2, t2's only reader proj_out: both producers write the operand pair where they can
     // (unet.py::_attn, out_pair=)
     const float pairs = u.cfg.math == CS_MATH_F16X3 ? 16.f : 0.f;
+    const float pair_gg = (pairs > 0.f && stat) ? ss[4] : pairs, pair_t2 = (pairs > 0.f && stat) ? ss[5] : pairs;
     if (l.fused_geglu) {
-      gg = linear(n3, l.g[5], CS_ACT_GEGLU, nullptr, 0, 1, nullptr, 0, 0, pairs);   // tile 0: a 224-column tile for the gate
+      gg = linear(n3, l.g[5], CS_ACT_GEGLU, nullptr, 0, 1, nullptr, 0, 0, pair_gg);   // tile 0: a 224-column tile for the gate
     } else {
       Buf ff = linear(n3, l.g[5]);
       gg = alloc(rows, 4 * c);
       if (ok() && !dry) chk(cs_geglu(p(ff), p(gg), (int)rows, 4 * c, 8 * c, 4 * c, st));
       release(ff);
     }
+    if (stat && !gg.pair) gg.a_scale = ss[4];      // (a producer that could not emit the pair hands over fp32)
     release(n3);
-    Buf t2 = linear(gg, l.g[6], CS_ACT_NONE, nullptr, 0, 1, dry ? nullptr : p(t1), c, 0, pairs);
+    Buf t2 = linear(gg, l.g[6], CS_ACT_NONE, nullptr, 0, 1, dry ? nullptr : p(t1), c, 0, pair_t2);
+    if (stat && !t2.pair) t2.a_scale = ss[5];
     release(gg);
     release(t1);
     Act o = x;
@@ -633,7 +671,88 @@ extern "C" int64_t cs_unet_arena_bytes(const cs_unet* u) { return u ? u->arena_b
 extern "C" int64_t cs_unet_context_floats(const cs_unet* u) { return u ? u->ctx_total : 0; }
 
 extern "C" int cs_unet_pack(cs_unet* u, const void* raw_dev, void* arena_dev, cs_stream_t stream) {
-  return pack_plan(u, raw_dev, arena_dev, stream);
+  const int rc = pack_plan(u, raw_dev, arena_dev, stream);
+  if (rc != CS_OK || !u || u->math != CS_MATH_F16X3 || !u->cfg.use_spatial_transformer) return rc;
+  // r5: the static-bound statistics of every transformer block (unet.py::_pack: the same kernel, the same values) -- row
+  // 2-norm maxima and |.| maxima of the block's Linears and LayerNorm parameters; 34 float slots per block behind the
+  // plan's |w| maxima (zeroed by pack_plan), ONE more read-back at load time
+  hipStream_t st = (hipStream_t)stream;
+  const char* raw = reinterpret_cast<const char*>(raw_dev);
+  float* d_amax = reinterpret_cast<float*>(reinterpret_cast<char*>(arena_dev) + u->amax_off);
+  auto src = [&](int param) { return reinterpret_cast<const float*>(raw + u->params[param].raw_off); };
+  std::vector<Layer*> blocks;
+  auto collect = [&](std::vector<Layer>& layers) {
+    for (Layer& l : layers)
+      if (l.kind == ATTN && l.ts_slot >= 0) blocks.push_back(&l);
+  };
+  for (auto& layers : u->inp) collect(layers);
+  collect(u->mid);
+  for (auto& layers : u->out) collect(layers);
+  if (blocks.empty()) return rc;
+  for (Layer* lp : blocks) {
+    const Layer& l = *lp;
+    const int c = l.cin;
+    float* o = d_amax + l.ts_slot;
+    const Gemm& qkv = u->gemms[l.g[1]];
+    const Gemm& to = u->gemms[l.g[2]];
+    const Gemm& ff = u->gemms[l.g[5]];
+    const Gemm& f2 = u->gemms[l.g[6]];
+    const Gemm& pi = u->gemms[l.g[0]];
+    const Norm& n1 = u->norms[l.n[1]];
+    const Norm& n3 = u->norms[l.n[3]];
+    if (qkv.w.size() != 3 || to.w.empty() || to.b.empty() || ff.w.empty() || ff.b.empty() || f2.w.empty() || f2.b.empty() ||
+        pi.w.empty() || pi.b.empty())
+      return CS_EINVAL;
+    const float* wff = src(ff.w[0].param);
+    const float* bff = src(ff.b[0].param);
+    struct Job { const float* w; int rows, cols; };
+    const Job jobs[17] = {
+        {src(qkv.w[0].param), c, c}, {src(qkv.w[1].param), c, c}, {src(qkv.w[2].param), c, c},        // rq rk rv
+        {src(to.w[0].param), c, c}, {src(to.b[0].param), 1, c},                                          // ro bo
+        {wff, 4 * c, c}, {bff, 1, 4 * c}, {wff + (int64_t)4 * c * c, 4 * c, c}, {bff + 4 * c, 1, 4 * c},  // rx bx rg bg
+        {src(f2.w[0].param), c, 4 * c}, {src(f2.b[0].param), 1, c},                                      // r2 b2
+        {src(pi.w[0].param), c, c}, {src(pi.b[0].param), 1, c},                                          // rpi bpi
+        {src(n1.gp), 1, c}, {src(n1.bp), 1, c}, {src(n3.gp), 1, c}, {src(n3.bp), 1, c}};                 // g1 be1 g3 be3
+    for (int j = 0; j < 17; ++j) {
+      const int r2 = cs_weight_rowstats(jobs[j].w, jobs[j].rows, jobs[j].cols, o + 2 * j, stream);
+      if (r2 != CS_OK) return r2;
+    }
+  }
+  std::vector<float> host((size_t)34 * blocks.size());
+  // (the blocks' slots are contiguous: they were reserved one after the other)
+  if (hipMemcpyAsync(host.data(), d_amax + blocks[0]->ts_slot, host.size() * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess)
+    return CS_EINVAL;
+  for (size_t b = 0; b < blocks.size(); ++b) {
+    const float* h = host.data() + 34 * b;
+    // which of {row norm, abs max} each field takes (unet.py::_pack)
+    static const int which[17] = {0, 0, 0, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 1, 0, 1, 0};
+    float v[17];
+    for (int j = 0; j < 17; ++j) v[j] = h[2 * j + which[j]];
+    CsTransformerStats& t = blocks[b]->ts;
+    t.rq = v[0]; t.rk = v[1]; t.rv = v[2]; t.ro = v[3]; t.bo = v[4]; t.rx = v[5]; t.bx = v[6]; t.rg = v[7]; t.bg = v[8];
+    t.r2 = v[9]; t.b2 = v[10]; t.rpi = v[11]; t.bpi = v[12]; t.g1 = v[13]; t.be1 = v[14]; t.g3 = v[15]; t.be3 = v[16];
+    blocks[b]->has_ts = true;
+  }
+  return CS_OK;
+}
+
+// r5: the largest |entry| of every transformer block's cross-attention row vector of the CURRENT run, in block order (input
+// blocks, middle, output blocks) -- host data the caller reads back once per run after cs_unet_context (it enters t1's
+// static bound, cs_transformer_static_scales).  n must equal the number of transformer blocks; never called: 0 is assumed.
+extern "C" int cs_unet_set_context_bounds(cs_unet* u, const float* ctx_max, int n) {
+  if (!u || !ctx_max || n < 0) return CS_EINVAL;
+  std::vector<Layer*> blocks;
+  auto collect = [&](std::vector<Layer>& layers) {
+    for (Layer& l : layers)
+      if (l.kind == ATTN) blocks.push_back(&l);
+  };
+  for (auto& layers : u->inp) collect(layers);
+  collect(u->mid);
+  for (auto& layers : u->out) collect(layers);
+  if ((int)blocks.size() != n) return CS_EINVAL;
+  for (int i = 0; i < n; ++i) blocks[i]->ctx_max = ctx_max[i] > 0.f ? ctx_max[i] : 0.f;
+  return CS_OK;
 }
 
 extern "C" int64_t cs_unet_workspace_bytes(const cs_unet* u, int nb_x, int cfg_pairs) {

@@ -58,6 +58,11 @@ class CsConvGemm(C.Structure):
     ]
 
 
+class CsTransformerStats(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("rq", "rk", "rv", "ro", "bo", "rx", "bx", "rg", "bg", "r2", "b2", "rpi", "bpi", "g1",
+                                        "be1", "g3", "be3")]
+
+
 class CsGnSeg(C.Structure):
     _fields_ = [("part", C.c_void_p), ("ld", C.c_int32), ("col0", C.c_int32), ("ch0", C.c_int32), ("nch", C.c_int32),
                 ("tiles_per_sample", C.c_int32), ("ncls", C.c_int32), ("nb_src", C.c_int32), ("reserved", C.c_int32)]
@@ -69,7 +74,7 @@ class CsDebug(C.Structure):
         "no_split16", "no_pair16", "no_upfold", "no_splitk", "no_fused_geglu", "no_tapcol", "tapcol_tile", "no_cfg_split",
         "concat_copy", "tile512", "no_pw", "no_slab4", "no_attn_img", "attn_nw8", "no_up2_direct", "no_up2_batch",
         "plan_pow2", "slice_tile2", "no_gn_parts", "no_pair_epilogue", "no_dyn_scale", "no_tok_rules", "no_fused_reduce",
-        "no_temb_table", "no_gn_fold", "no_kwave")] + [
+        "no_temb_table", "no_gn_fold", "no_kwave", "no_static_scales")] + [
         ("split16_min_rows", C.c_int64), ("cfg_split_min_rows", C.c_int64), ("gn_small_group", C.c_int64)]
 
 
@@ -103,6 +108,9 @@ SIGNATURES = {
     "cs_debug": (C.POINTER(CsDebug), []),
     "cs_debug_set": (None, [C.POINTER(CsDebug)]),
     "cs_norm_a_scale": (_fl, [_fl, _fl, _l]),
+    "cs_bound_a_scale": (_fl, [_fl]),
+    "cs_weight_rowstats": (_i, [_f, _i, _i, _f, _s]),
+    "cs_transformer_static_scales": (_i, [C.POINTER(CsTransformerStats), _i, _l, _i, _fl, _fl, _fl, _f]),
     "cs_conv_wants_split16": (_i, [_l, _i, _i, _i, _i, _i]),
     "cs_tapcol_ok": (_i, [_i, _i, _i, _i]),
     "cs_tapcol_tile": (_i, [_l, _i]),
@@ -133,6 +141,7 @@ SIGNATURES = {
     "cs_layernorm": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _fl, _s]),
     "cs_attn_selfattn": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _s]),
     "cs_attn_selfattn_f16x3": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _f, _s]),
+    "cs_attn_selfattn_f16x3_scaled": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _fl, _fl, _fl, _f, _s]),
     "cs_attn_f16x3_ws_bytes": (_l, [_i, _i, _i, _i, _i]),
     "cs_attn_selfattn_f16x3_ws": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _f, _f, _s]),
     "cs_attn_selfattn_f16": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _f, _s]),
@@ -162,6 +171,7 @@ SIGNATURES = {
     "cs_unet_raw_bytes": (_l, [C.c_void_p]),
     "cs_unet_arena_bytes": (_l, [C.c_void_p]),
     "cs_unet_context_floats": (_l, [C.c_void_p]),
+    "cs_unet_set_context_bounds": (_i, [C.c_void_p, C.POINTER(C.c_float), _i]),
     "cs_unet_pack": (_i, [C.c_void_p, _f, _f, _s]),
     "cs_unet_workspace_bytes": (_l, [C.c_void_p, _i, _i]),
     "cs_unet_context": (_i, [C.c_void_p, _f, _f, _i, _f, _f, _f, _l, _s]),

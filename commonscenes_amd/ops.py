@@ -225,6 +225,7 @@ _SWITCHES = {
     "PAIR_EPILOGUES": lambda d: not d.no_pair_epilogue,  # CS_NO_PAIR_EPILOGUE=1: GEMM epilogues always write fp32
     "GN_PARTS": lambda d: not d.no_gn_parts,             # CS_NO_GN_PARTS=1: GroupNorm statistics from a pass over the tensor
     "DYN_SCALE": lambda d: not d.no_dyn_scale,           # CS_NO_DYN_SCALE=1: raw-activation consumers keep the fixed scale 16
+    "STATIC_SCALES": lambda d: not d.no_static_scales,   # CS_NO_STATIC_SCALES=1: transformer-internal operands keep 16 + flag
 }
 
 
@@ -931,9 +932,17 @@ def layernorm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5, out: Op
     return out
 
 
+def bound_a_scale(bound: float) -> float:
+    """cs_bound_a_scale: the largest power of two s with bound * s <= 65000 -- the F16X3 operand scale of a tensor whose
+    magnitude is bounded by `bound` (ONE rule for every host)."""
+    return float(L.load().cs_bound_a_scale(float(bound)))
+
+
 def attention(q: Tensor, k: Tensor, v: Tensor, heads: int, scale: float, out: Optional[Tensor] = None,
-              math: int = L.MATH_FP32) -> Tensor:
-    """q: [nb, nq, heads*dh] (views with wider row stride allowed), k/v: [nb, nk, heads*dh]."""
+              math: int = L.MATH_FP32, scales: Optional[Tuple[float, float, float]] = None) -> Tensor:
+    """q: [nb, nq, heads*dh] (views with wider row stride allowed), k/v: [nb, nk, heads*dh].
+    scales (F16X3 only, r5): the power-of-two operand pre-scales (q * scale, k, v) from the static bounds of a transformer
+    block's q / k / v instead of the constant 16 (cs_attn_selfattn_f16x3_scaled)."""
     for t, n in ((q, "q"), (k, "k"), (v, "v")):
         _chk(t, n)
         if t.dim() != 3:
@@ -948,7 +957,12 @@ def attention(q: Tensor, k: Tensor, v: Tensor, heads: int, scale: float, out: Op
         out = torch.empty((nb, nq, cq), dtype=torch.float32, device=q.device)
     _, _, ldo = rows_ld(out, "out")
     lib = L.load()
-    if math == L.MATH_F16X3:
+    if math == L.MATH_F16X3 and scales is not None:
+        L.check(lib.cs_attn_selfattn_f16x3_scaled(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), nb, nq, nk, heads,
+                                                  dh, ldq, ldk, ldv, ldo, scale, float(scales[0]), float(scales[1]),
+                                                  float(scales[2]), status_word(q.device).data_ptr(), _stream()),
+                "cs_attn_selfattn_f16x3_scaled")
+    elif math == L.MATH_F16X3:
         # K / V split once per call into their LDS tile images where the library has that path (ws_bytes > 0)
         wsb = lib.cs_attn_f16x3_ws_bytes(nb, nq, nk, heads, dh)
         ws = torch.empty((wsb // 4,), dtype=torch.float32, device=q.device) if wsb > 0 else None

@@ -17,6 +17,8 @@ from __future__ import annotations
 from collections import OrderedDict
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import ctypes as C
+
 import torch
 
 from . import lib as L
@@ -422,6 +424,45 @@ class DiffusionUNet:
             self._ngb = {n: (float(mx[i, 0]), float(mx[i, 1])) for i, n in enumerate(norms)}
         else:
             self._ngb = {}
+        # r5: what bounds the operands BORN INSIDE a transformer block (attention.py:237-245) -- q / k /
+        # v, the attention output, the GEGLU product, t2 -- from the weights alone.  Per block: max row 2-norms of the
+        # Linear weights (a row's output is <= ||row||_2 ||input||_2), max |bias|, and the LayerNorms' max |gamma| and
+        # ||beta||_2 (||LN(x)||_2 <= max|gamma| sqrt(C) + ||beta||_2: a normalised token has 2-norm sqrt(C)).  One stacked
+        # reduction + one read-back at load time; _static_scales() turns them into operand scales.
+        self._tstat: Dict[str, object] = {}
+        if self.math == L.MATH_F16X3 and self.cfg["use_spatial_transformer"]:
+            lib = L.load()
+            jobs = []                          # (block, field, tensor as [rows, cols], which of {row norm, abs max})
+            for bp, layers in ([(f"{P}input_blocks.{i}", l) for i, l in enumerate(inp)] + [(P + "middle_block", mid)]
+                               + [(f"{P}output_blocks.{i}", l) for i, l in enumerate(out)]):
+                for l in layers:
+                    if l["kind"] != "attn":
+                        continue
+                    p = f"{bp}.{l['idx']}"
+                    t = p + ".transformer_blocks.0"
+                    wff, bff = sd[t + ".ff.net.0.proj.weight"], sd[t + ".ff.net.0.proj.bias"]
+                    h = wff.shape[0] // 2
+                    row = lambda v: v.reshape(1, -1)
+                    mat = lambda v: v.reshape(v.shape[0], -1)
+                    for fld, ten, which in (
+                            ("rq", mat(sd[t + ".attn1.to_q.weight"]), 0), ("rk", mat(sd[t + ".attn1.to_k.weight"]), 0),
+                            ("rv", mat(sd[t + ".attn1.to_v.weight"]), 0), ("ro", mat(sd[t + ".attn1.to_out.0.weight"]), 0),
+                            ("bo", row(sd[t + ".attn1.to_out.0.bias"]), 1), ("rx", mat(wff[:h]), 0), ("bx", row(bff[:h]), 1),
+                            ("rg", mat(wff[h:]), 0), ("bg", row(bff[h:]), 1), ("r2", mat(sd[t + ".ff.net.2.weight"]), 0),
+                            ("b2", row(sd[t + ".ff.net.2.bias"]), 1), ("rpi", mat(sd[p + ".proj_in.weight"]), 0),
+                            ("bpi", row(sd[p + ".proj_in.bias"]), 1), ("g1", row(sd[t + ".norm1.weight"]), 1),
+                            ("be1", row(sd[t + ".norm1.bias"]), 0), ("g3", row(sd[t + ".norm3.weight"]), 1),
+                            ("be3", row(sd[t + ".norm3.bias"]), 0)):
+                        jobs.append((t, fld, ten.contiguous(), which))
+            if jobs:
+                slots = torch.zeros((len(jobs), 2), dtype=torch.float32, device=self.device)
+                for k_, (_, _, ten, _) in enumerate(jobs):        # the SAME kernel the native driver's pack uses: same values
+                    L.check(lib.cs_weight_rowstats(ten.data_ptr(), int(ten.shape[0]), int(ten.shape[1]), slots[k_].data_ptr(),
+                                                   ops._stream()), "cs_weight_rowstats")
+                host = slots.cpu().tolist()
+                for (t, fld, _, which), v_ in zip(jobs, host):
+                    st = self._tstat.setdefault(t, L.CsTransformerStats())
+                    setattr(st, fld, float(v_[which]))
         self._packed = pk
         self._blocks = (inp, mid, out)
         self._ctx_cache = None
@@ -432,6 +473,39 @@ class DiffusionUNet:
         (None in fp32 mode: the default is used and ignored)."""
         gb = self._ngb.get(norm)
         return ops.norm_a_scale(gb[0], gb[1], n) if gb is not None else None
+
+    def _static_scales(self, p: str, t: str, c: int, n_tokens: int, ctx) -> Optional[Dict[str, object]]:
+        """F16X3 operand scales of the operands born inside transformer block `t` of SpatialTransformer3D `p` (c channels,
+        n_tokens tokens per sample), from static bounds -- so that no input can push them out of the fp16 range and the
+        CS_STATUS_F16X3_OVERFLOW detect-and-re-run cliff is gone for them (attention.py:179-245, 335-351):
+            Y1 = max|g1| sqrt(c) + ||b1||_2                      >= ||LayerNorm1(x) token||_2
+            |q| <= rq Y1, |k| <= rk Y1, |v| <= rv Y1 =: Bv         (to_q / to_k / to_v have no bias)
+            |a| <= Bv                                             (softmax rows are convex weights)
+            |t0| <= rpi sqrt(c) Egn + |b_pi|,  Egn = max|g| sqrt(n - 1) + max|b| of the block's GroupNorm (n = n_tokens c/32)
+            |t1| <= ro sqrt(c) Bv + |b_o| + |t0| + max|ctx vector|  (t1 = to_out(a) + t0 + attn2's row vector)
+            |x part|, |gate| of the GEGLU <= rx Y3 + |b|;  |gg| <= Bx Bg   (|gelu(g)| <= |g|)
+            |t2| <= r2 sqrt(4c) Bgg + |b_2| + |t1|
+        The 2-norm chains overshoot by one to three orders of magnitude; with a power-of-two scale 65000 / bound an operand's
+        absolute floor is 2^-25 bound / 65000 ~ 5e-13 bound -- fp32 grade for values down to 1e-5 of the bound.  Returns None
+        when the feature is off, the model is not in F16X3 mode or the context is not the one-token form."""
+        st = self._tstat.get(t)
+        if st is None or self.math != L.MATH_F16X3 or not ops._sw("STATIC_SCALES") or not isinstance(ctx, tuple):
+            return None
+        key = (t, n_tokens, id(ctx))
+        cache = self.__dict__.setdefault("_sscache", {})
+        hit = cache.get(key)
+        if hit is not None:
+            return hit
+        gb = self._ngb.get(p + ".norm", (1.0, 0.0))
+        cmax = float(ctx[3].get(t, 0.0)) if len(ctx) > 3 else 0.0
+        o = (C.c_float * 12)()
+        L.check(L.load().cs_transformer_static_scales(C.byref(st), int(c), int(n_tokens), int(self.cfg["num_heads"]),
+                                                      float(gb[0]), float(gb[1]), cmax, o), "cs_transformer_static_scales")
+        out = dict(attn=(float(o[0]), float(o[1]), float(o[2])), a=float(o[3]), gg=float(o[4]), t2=float(o[5]),
+                   bounds=dict(q=float(o[6]), k=float(o[7]), v=float(o[8]), t1=float(o[9]), gg=float(o[10]), t2=float(o[11]),
+                               ctx=cmax))
+        cache[key] = out
+        return out
 
     def _slot(self):
         """a fresh 1-element slot of this forward's arena (zeroed once in forward_ndhwc) for the magnitude bound of a RAW
@@ -526,8 +600,16 @@ class DiffusionUNet:
                     t = f"{bp}.{l['idx']}.transformer_blocks.0"
                     v2 = ops.linear(flat, pk[t + ".attn2.to_v"], math=self.math)
                     vecs[t] = ops.linear(v2, pk[t + ".attn2.to_out.0"], math=self.math)
-        cached = ("ctxvec", vecs, ctx)          # keeps ctx alive so its data_ptr cannot be recycled
+        # (r5: the largest |row-vector entry| per block -- it enters t1's static bound, _static_scales -- ONE read-back per
+        # sampling run, beside the run's one status read-back; never inside the step loop)
+        cmax = {}
+        if self.math == L.MATH_F16X3 and ops._sw("STATIC_SCALES") and vecs:
+            ks = list(vecs)
+            host = torch.stack([vecs[k_].abs().max() for k_ in ks]).cpu().tolist()
+            cmax = {k_: float(v_) for k_, v_ in zip(ks, host)}
+        cached = ("ctxvec", vecs, ctx, cmax)    # keeps ctx alive so its data_ptr cannot be recycled
         self._ctx_cache = (key, cached)
+        self.__dict__.pop("_sscache", None)
         return cached
 
     def _attnblock(self, p: str, l: dict, x: Tensor, out_fn=None) -> Tensor:
@@ -560,11 +642,16 @@ class DiffusionUNet:
         s1 = self._nas(t + ".norm1", c)
         n1 = ops.layernorm(t0, sd[t + ".norm1.weight"], sd[t + ".norm1.bias"], pair_scale=s1)
         qkv = ops.linear(n1, pk[t + ".attn1.qkv"], math=self.math, a_scale=s1)
-        a = ops.attention(qkv[..., 0:c], qkv[..., c:2 * c], qkv[..., 2 * c:3 * c], heads, dh ** -0.5, math=self.attn_math if self.attn_math is not None else self.math)
+        # r5: static bounds of the operands born inside the block (q / k / v, the attention output, gg, t2): _static_scales
+        ss = self._static_scales(p, t, c, n, ctx)
+        amath = self.attn_math if self.attn_math is not None else self.math
+        a = ops.attention(qkv[..., 0:c], qkv[..., c:2 * c], qkv[..., 2 * c:3 * c], heads, dh ** -0.5, math=amath,
+                          scales=ss["attn"] if (ss is not None and amath == L.MATH_F16X3) else None)
         if isinstance(ctx, tuple):
             # one context token: softmax over one key == 1, attn2(x) = to_out(to_v(ctx)) for every
             # query row -> a per-sample row vector folded into the attn1 output GEMM.
-            t1 = ops.linear(a, pk[t + ".attn1.to_out.0"], res=t0, rowvec=ctx[1][t], rv_rows=n, math=self.math)
+            t1 = ops.linear(a, pk[t + ".attn1.to_out.0"], res=t0, rowvec=ctx[1][t], rv_rows=n, math=self.math,
+                            a_scale=ss["a"] if ss is not None else None)
         else:
             t1a = ops.linear(a, pk[t + ".attn1.to_out.0"], res=t0, math=self.math)
             n2 = ops.layernorm(t1a, sd[t + ".norm2.weight"], sd[t + ".norm2.bias"])
@@ -579,16 +666,20 @@ class DiffusionUNet:
         # write the interleaved F16X3 operand pair where their launch can (out_pair: scale 16, the raw-activation default;
         # a value beyond the fp16 range is now flagged by the producer) -- the consumers' K loops carry no conversion.
         # Bit-identical to the fp32 hand-over (tests/test_epilogue_outputs_gpu.py).
-        pair = ops.A_SCALE if (self.math == L.MATH_F16X3 and ops._sw("PAIR_EPILOGUES")) else None
+        on = self.math == L.MATH_F16X3 and ops._sw("PAIR_EPILOGUES")
+        pair_gg = (ss["gg"] if ss is not None else ops.A_SCALE) if on else None
+        pair_t2 = (ss["t2"] if ss is not None else ops.A_SCALE) if on else None
         if (t + ".ff.geglu") in pk:      # GEGLU gate fused into the projection GEMM's epilogue
-            gg = ops.linear(n3, pk[t + ".ff.geglu"], act=L.ACT_GEGLU, a_scale=s3, out_pair=pair)   # the library picks a 224-column tile
+            gg = ops.linear(n3, pk[t + ".ff.geglu"], act=L.ACT_GEGLU, a_scale=s3, out_pair=pair_gg)   # the library picks a 224-column tile
         else:
             ff = ops.linear(n3, pk[t + ".ff.net.0.proj"], math=self.math, a_scale=s3)
             gg = ops.geglu(ff)
-        t2 = ops.linear(gg, pk[t + ".ff.net.2"], res=t1, math=self.math, out_pair=pair)
+        # (a producer that could not emit the pair hands over fp32: the consumer then takes the same static scale itself)
+        t2 = ops.linear(gg, pk[t + ".ff.net.2"], res=t1, math=self.math, out_pair=pair_t2,
+                        a_scale=None if isinstance(gg, ops.Pair16) or ss is None else ss["gg"])
         dst = out_fn((nb, d, h, w, c)).view(nb, n, c) if out_fn is not None else None
         out = ops.linear(t2, pk[p + ".proj_out"], res=x.view(nb, n, c), math=self.math, out=dst, stats=True,
-                         spatial=(nb, n, 1, 1))
+                         spatial=(nb, n, 1, 1), a_scale=None if isinstance(t2, ops.Pair16) or ss is None else ss["t2"])
         return ops.attach_stats(out.view(nb, d, h, w, c), getattr(out, "cs_stats", None))
 
     def _run(self, bp: str, layers, h: Tensor, semb: Tensor, ctx: Tensor, out_fn=None, split_skip=None) -> Tensor:

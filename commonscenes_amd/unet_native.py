@@ -173,6 +173,16 @@ class NativeDiffusionUNet:
         L.check(L.load().cs_unet_context(self._h, self._arena.data_ptr(), ctx.data_ptr(), ctx.shape[0], vec.data_ptr(),
                                          ops.status_word(self.device).data_ptr(), ws.data_ptr(), ws.numel(),
                                          _stream()), "cs_unet_context")
+        # r5: per transformer block the largest |entry| of its row vector -> the static bound of the block's t1 / t2
+        # operands (cs_unet_set_context_bounds; unet.py::_context_vectors does the same): ONE read-back per run
+        if self.math == L.MATH_F16X3 and self.cfg["use_spatial_transformer"] and not L.debug().no_static_scales:
+            from .unet import unet_blocks
+            inp, mid, out = unet_blocks(self.cfg)[:3]
+            widths = [l["cin"] for layers in (list(inp) + [mid] + list(out)) for l in layers if l["kind"] == "attn"]
+            if sum(widths) == self.ctx_floats and widths:
+                mx = torch.stack([seg.abs().max() for seg in torch.split(vec, widths, dim=1)]).cpu().tolist()
+                arr = (C.c_float * len(widths))(*[float(v) for v in mx])
+                L.check(L.load().cs_unet_set_context_bounds(self._h, arr, len(widths)), "cs_unet_set_context_bounds")
         self._ctx_cache = (key, vec, ctx)
         return vec
 

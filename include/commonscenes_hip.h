@@ -93,6 +93,7 @@ typedef struct CsDebug {
   int32_t no_temb_table;      /* timestep-embedding chain evaluated per step instead of looked up in the per-model table (r5) */
   int32_t no_gn_fold;         /* GroupNorm (mean, rstd) always by the separate finalize launch, never in the apply kernel's prologue (r5) */
   int32_t no_kwave;           /* small 1-tap GEMMs stay on the 64x64 one-accumulator-chain tile (r5: K cut across the four waves) */
+  int32_t no_static_scales;   /* operands born inside a transformer block keep the constant scale 16 + overflow flag (r5: static bounds) */
   int64_t split16_min_rows;   /* pre-split operands on the 128-row slab tile from this many rows (8192; 0 = never) */
   int64_t cfg_split_min_rows; /* channel-split ResBlocks from this many rows (65536) */
   int64_t gn_small_group;     /* single-launch GroupNorm up to this many elements per (sample, group) (11264) */
@@ -111,6 +112,26 @@ void cs_debug_set(const CsDebug* d);
  *   cs_tapcol_ok / cs_tapcol_tile   is a thin-output 3x3x3 conv run as taps-as-columns, and on which tile
  */
 float cs_norm_a_scale(float gmax, float bmax, int64_t n);
+/*   cs_bound_a_scale       (r5) the largest power of two s with bound * s <= 65000, clamped to [2^-24, 2^40]: the F16X3 operand
+ *                          scale of a tensor whose magnitude is bounded by `bound` (static bounds of the operands born
+ *                          inside a transformer block). */
+float cs_bound_a_scale(float bound);
+/*   cs_weight_rowstats     (r5; device work) out2 = {max over rows of ||row||_2 (rounded up), max |entry|} of a [rows][cols]
+ *                          fp32 matrix, folded into out2 by atomicMax of the bits: zero it first.
+ *   cs_transformer_static_scales  (r5) the F16X3 scales of the operands born inside a transformer block -- q / k / v of the
+ *                          self-attention, its output (-> to_out), the GEGLU product (-> ff.net.2), t2 (-> proj_out) -- from
+ *                          bounds that hold for EVERY input (attention.py:237-245, 335-351): see csrc/cs_plan.hip. */
+typedef struct CsTransformerStats {
+  float rq, rk, rv;       /* max row 2-norm of attn1.to_q / to_k / to_v */
+  float ro, bo;           /* attn1.to_out.0: max row 2-norm, max |bias| */
+  float rx, bx, rg, bg;   /* ff.net.0.proj value / gate halves: max row 2-norm, max |bias| */
+  float r2, b2;           /* ff.net.2 */
+  float rpi, bpi;         /* proj_in */
+  float g1, be1, g3, be3; /* norm1 / norm3: max |gamma|, ||beta||_2 */
+} CsTransformerStats;
+int cs_weight_rowstats(const float* w, int rows, int cols, float* out2, cs_stream_t stream);
+int cs_transformer_static_scales(const CsTransformerStats* st, int c, int64_t n_tokens, int heads, float gn_gmax,
+                                 float gn_bmax, float ctx_max, float* out12);
 int cs_conv_wants_split16(int64_t m, int cin, int cout, int k, int plain, int math);
 int cs_tapcol_ok(int cout, int cin, int k, int math);
 int cs_tapcol_tile(int64_t m, int ncolp);
@@ -404,6 +425,11 @@ int cs_attn_selfattn_f16x3(const float* q, const float* k, const float* v, float
                            int nk, int heads, int dh, int ldq, int ldk, int ldv, int ldo, float scale,
                            int32_t* status, cs_stream_t stream);
 
+/* (ABI 15, r5) cs_attn_selfattn_f16x3 with caller-chosen power-of-two operand pre-scales for Q * scale, K and V (the plain
+ * entry uses 16 for all three): see csrc/cs_attention_f16x3.hip. */
+int cs_attn_selfattn_f16x3_scaled(const float* q, const float* k, const float* v, float* out, int nb, int nq, int nk,
+                                  int heads, int dh, int ldq, int ldk, int ldv, int ldo, float scale, float q_scale,
+                                  float k_scale, float v_scale, int32_t* status, cs_stream_t stream);
 /* Workspace form (r3, ABI 13): with `ws` (cs_attn_f16x3_ws_bytes(...) bytes, 16-byte aligned) K and V are split into
  * their fp16 hi / lo tile images ONCE per call by a pre-pass and the attention kernel streams whole images into LDS with
  * buffer_load ... lds -- the plain entry converts every K / V tile inside every workgroup.  Covers 128 < dh <= 256 from
@@ -654,6 +680,12 @@ int cs_unet_param_info(const cs_unet* u, int i, const char** name, int64_t shape
 int64_t cs_unet_raw_bytes(const cs_unet* u);
 int64_t cs_unet_arena_bytes(const cs_unet* u);
 int64_t cs_unet_context_floats(const cs_unet* u);
+/* (ABI 15, r5) the largest |entry| of every transformer block's cross-attention row vector of the CURRENT run -- block order:
+ * input blocks, middle block, output blocks; block b's columns of cs_unet_context's output are the next c_b floats -- read
+ * back by the host once per sampling run and handed over here: it enters the static bound of the block's t1 / t2 operands
+ * (cs_transformer_static_scales).  Never called: 0 is assumed (a run whose context vectors are large may then raise
+ * CS_STATUS_F16X3_OVERFLOW on proj_out's operand, as before r5).  Host-only. */
+int cs_unet_set_context_bounds(cs_unet* u, const float* ctx_max, int n_blocks);
 int cs_unet_pack(cs_unet* u, const void* raw_dev, void* arena_dev, cs_stream_t stream);
 int64_t cs_unet_workspace_bytes(const cs_unet* u, int nb_x, int cfg_pairs);
 int cs_unet_context(const cs_unet* u, const void* arena, const float* ctx, int nb_ctx, float* ctxvec,

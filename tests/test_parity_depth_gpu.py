@@ -208,20 +208,91 @@ def test_rel2shape_reruns_an_overflowing_minibatch_in_fp32(tmp_path):
     kw = dict(ddim_steps=50, uc_scale=3.0, x_T=x_T, return_latents=True, max_steps=2)
     ops.read_status()
     m.Diff.df.set_math("f16x3")
-    m.Diff.overflow_policy = "raise"
-    with pytest.raises(L.CsOverflowError):
-        m.Diff.rel2shape(data, **kw)
-    assert m.Diff.df.math == L.MATH_F16X3
-    m.Diff.overflow_policy = "fp32"
-    with warnings.catch_warnings(record=True) as wlist:
-        warnings.simplefilter("always")
-        sdf_a, lat_a = m.Diff.rel2shape(data, **kw)
-    assert any("overflow" in str(w.message) for w in wlist)
-    assert m.Diff.df.math == L.MATH_FP32                                 # stays on the fp32 kernels afterwards
-    sdf_b, lat_b = m.Diff.rel2shape(data, **kw)                          # a pure fp32 run
+    # r5: with the static bounds of the transformer-internal operands (the default) THIS checkpoint runs on F16X3 without a
+    # flag -- test_transformer_operands_take_static_scales_and_need_no_fallback; the detect-and-re-run machinery is
+    # exercised here with the feature off (CS_NO_STATIC_SCALES: the r4 behaviour)
+    with L.debug_override(no_static_scales=1):
+        m.Diff.overflow_policy = "raise"
+        with pytest.raises(L.CsOverflowError):
+            m.Diff.rel2shape(data, **kw)
+        assert m.Diff.df.math == L.MATH_F16X3
+        m.Diff.overflow_policy = "fp32"
+        with warnings.catch_warnings(record=True) as wlist:
+            warnings.simplefilter("always")
+            sdf_a, lat_a = m.Diff.rel2shape(data, **kw)
+        assert any("overflow" in str(w.message) for w in wlist)
+        assert m.Diff.df.math == L.MATH_FP32                                 # stays on the fp32 kernels afterwards
+        sdf_b, lat_b = m.Diff.rel2shape(data, **kw)                          # a pure fp32 run
+        torch.cuda.synchronize()
+        assert torch.isfinite(lat_a).all() and torch.equal(lat_a, lat_b) and torch.equal(sdf_a, sdf_b)
+        assert ops.read_status() == 0
+
+
+@pytest.mark.parametrize("scaled", ["to_v x1e5", "to_q,to_k x30", "ff.net.0 x300", "context x1e4", "none"])
+def test_transformer_operands_take_static_scales_and_need_no_fallback(scaled):
+    """the operands BORN INSIDE a transformer block (attention.py:237-245: q / k / v, the attention
+    output, the GEGLU product, t2) used to ride the constant scale 16 + the overflow flag + a whole-mini-batch fp32 re-run.
+    Their magnitude is bounded by the weights alone (cs_transformer_static_scales), so the scales are chosen per checkpoint
+    and NO input can push them out of the fp16 range.  Checkpoints whose to_v (x 1e5: the r4 overflow recipe), to_q / to_k,
+    GEGLU projection or context sit far outside PyTorch-default scales: one UNet forward of the reduced model on F16X3 --
+    no flag -- within fp32 grade of the fp64 oracle on the same weights; both hosts agree bit for bit; with the feature
+    off the same checkpoint raises the flag."""
+    from commonscenes_amd import lib as L, ops, synth
+    from commonscenes_amd.unet import DiffusionUNet, unet_param_shapes
+    from commonscenes_amd.unet_native import NativeDiffusionUNet
+    from oracle import ref_torch as R
+    from test_model_gpu import _unet_cfg
+    cfg = _unet_cfg(True)
+    sd = synth.synth_state_dict(unet_param_shapes(cfg))
+    t0 = next(k for k in sorted(sd) if k.endswith("attn1.to_v.weight"))[:-len("attn1.to_v.weight")]
+    ctx_mag = 1.0
+    if scaled == "to_v x1e5":
+        sd[t0 + "attn1.to_v.weight"] = sd[t0 + "attn1.to_v.weight"] * 1.0e5
+    elif scaled == "to_q,to_k x30":
+        for n in ("to_q", "to_k"):
+            sd[t0 + f"attn1.{n}.weight"] = sd[t0 + f"attn1.{n}.weight"] * 30.0
+    elif scaled == "ff.net.0 x300":
+        for n in ("weight", "bias"):
+            sd[t0 + f"ff.net.0.proj.{n}"] = sd[t0 + f"ff.net.0.proj.{n}"] * 300.0
+    elif scaled == "context x1e4":
+        ctx_mag = 1.0e4
+    B = 2
+    x = synth.gaussian_like("ss:x", (B, 3, 16, 16, 16))
+    ctx = synth.gaussian_like("ss:ctx", (B, 1, 1280)) * ctx_mag
+    t = torch.tensor([981, 21], dtype=torch.long)
+    with torch.no_grad():
+        ref = R.unet_forward({k: v.double() for k, v in sd.items()}, cfg, x.double(), t, ctx.double())
+    df = DiffusionUNet(cfg, conditioning_key="crossattn", device="cuda").set_math("f16x3")
+    df.load_state_dict(sd)
+    ops.read_status()
+    eps = df(x.cuda(), t.cuda(), c_crossattn=[ctx.cuda()])
     torch.cuda.synchronize()
-    assert torch.isfinite(lat_a).all() and torch.equal(lat_a, lat_b) and torch.equal(sdf_a, sdf_b)
+    flag = ops.read_status()
+    e = rel_l2(eps, ref)
+    blk = next(iter(df._tstat))
+    ss = next(v for (k0, _, _), v in df._sscache.items() if k0 == blk)
+    with L.debug_override(no_static_scales=1):
+        df.reset_run_cache()
+        old = df(x.cuda(), t.cuda(), c_crossattn=[ctx.cuda()])
+        torch.cuda.synchronize()
+        fold = ops.read_status()
+    df.reset_run_cache()
+    print(f"static scales [{scaled}]: rel-L2 vs fp64 {e:.2e}, flag {flag}; first block scales attn {ss['attn']} a {ss['a']:g} "
+          f"gg {ss['gg']:g} t2 {ss['t2']:g}, bounds {({k_: float(f'{v_:.3g}') for k_, v_ in ss['bounds'].items()})}; "
+          f"constant 16: rel-L2 {rel_l2(old, ref):.2e}, flag {fold}")
+    assert flag == 0
+    assert e < 5e-6                                     # the UNet-forward gate of the goldens is 1e-5
+    if scaled == "to_v x1e5":
+        assert fold & L.STATUS_F16X3_OVERFLOW          # ... where the constant scale overflowed (the r4 recipe)
+    elif fold == 0:
+        assert rel_l2(eps, old) < 2e-6
+    # the native driver applies the same rule (cs_unet.hip::attn_block): bit-identical
+    nd = NativeDiffusionUNet(cfg, conditioning_key="crossattn", device="cuda", math="f16x3")
+    nd.load_state_dict(sd)
+    en = nd(x.cuda(), t.cuda(), c_crossattn=[ctx.cuda()])
+    torch.cuda.synchronize()
     assert ops.read_status() == 0
+    assert torch.equal(en, eps), f"native vs python: {rel_l2(en, eps):.2e}"
 
 
 def test_native_vqvae_overflow_falls_back_to_fp32(tmp_path, monkeypatch):
