@@ -544,6 +544,7 @@ struct ExecBase {
   int rc = CS_OK;
   int64_t peak = 0;
   int32_t* status = nullptr;     // caller's sticky CS_STATUS_* word (device) handed to every F16X3 kernel
+  bool stats_invariant_only = false;   // (the VQ-VAE decoder) GroupNorm partials only from batch-independent statistics tiles
   // magnitude-bound slots of this forward (CsConvGemm.a_bound; unet.py::_slot / ops.range_bound): one small zeroed region
   Buf amax_arena;
   int amax_next = 0, amax_cap = 0;
@@ -851,6 +852,14 @@ struct ExecBase {
     if (dry) dry_operands(probe, dry_bias, dry_ldr, dry_ldrv);
     int32_t rows = 0;
     if (cs_conv_gemm_epilogue_caps(&probe, &rows, nullptr) != CS_OK || rows <= 0) return;
+    if (stats_invariant_only) {
+      // r5: only where ONE sample's launch picks the same statistics tiles (ops.py::_epilogue_extras, stats="invariant"):
+      // the VQ decoder's bit-exact batch invariance
+      CsConvGemm one = probe;
+      one.nb = 1;
+      int32_t rows1 = 0;
+      if (cs_conv_gemm_epilogue_caps(&one, &rows1, nullptr) != CS_OK || rows1 != rows) return;
+    }
     const int64_t tiles = (m_rows + rows - 1) / rows;
     Stat sx = alloc_stat((int64_t)ncls * tiles, q.cout, nb, (int)(rps / rows), ncls);
     if (!ok()) return;

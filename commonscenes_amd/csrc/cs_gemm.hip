@@ -566,6 +566,16 @@ extern "C" int cs_conv_gemm_plan(const CsConvGemm* d, int32_t* splitk, int64_t* 
   return CS_OK;
 }
 
+// most 64x64 tiles a launch may have and still take the K-wave kernel (one 128 KB workgroup per CU): one resident round by
+// default; CS_KWAVE_MAX_TILES overrides (tuning sweeps)
+static int64_t kwave_max_tiles() {
+  static const int64_t v = [] {
+    const char* e = getenv("CS_KWAVE_MAX_TILES");
+    return (e && *e) ? atoll(e) : (long long)-1;
+  }();
+  return v >= 0 ? v : device_cus();
+}
+
 // tile of an automatic (desc->tile == 0) launch that is not the ping-pong kernel's
 static int auto_tile(const CsConvGemm& p, int M, bool f16x3) {
   int tile = 0;
@@ -624,8 +634,11 @@ static int auto_tile(const CsConvGemm& p, int M, bool f16x3) {
     // at least two K chunks per wave -- take the K-wave kernel: the four waves of a workgroup each run a quarter of the K
     // loop over the whole 64x64 tile, four accumulator chains and no barrier in the loop (cs_gemm_kw.hip).
     // CS_NO_KWAVE=1: the one-chain 64x64 tile (A/B runs).
-    if (f16x3 && tile == 3 && !cs_debug()->no_kwave && (p.cin + 15) / 16 >= 8 && cs_kw_gemm_applicable(p, M) &&
-        (int64_t)((M + 63) / 64) * ((p.cout + 63) / 64) <= device_cus())
+    // (cout % 224 == 0: the UNet's channel counts.  The VQ decoder's 1x1x1 convs -- 64 / 128 / 256 / 768 columns -- keep the
+    // one-chain tile at EVERY batch: the K-wave kernel partitions the K sum, and a decoder whose tile followed the batch
+    // would lose its bit-exact batch invariance, tests/test_model_gpu.py::test_vq_decode_batch_invariance)
+    if (f16x3 && tile == 3 && !cs_debug()->no_kwave && (p.cin + 15) / 16 >= 8 && p.cout % 224 == 0 &&
+        cs_kw_gemm_applicable(p, M) && (int64_t)((M + 63) / 64) * ((p.cout + 63) / 64) <= kwave_max_tiles())
       tile = 10;
   }
   return tile;

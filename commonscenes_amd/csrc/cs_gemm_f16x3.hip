@@ -948,7 +948,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
       // adds its 16 WMB values per column in fp32 (packed v_pk_add / v_pk_fma: a first version kept fp64 accumulators here
       // -- 768 double-rate VALU instructions per wave per tile, ~0.9 ms per step on an epilogue nothing overlaps); everything
       // above the lane -- rows of a wave, waves of a tile, tiles of a sample -- is summed in fp64.  Relative error of a
-      // 16-term fp32 sum ~2e-7, averaged down by the thousands of lane sums in a group: statistics stay at fp64 grade.
+      // 16-term fp32 sum ~2e-7, averaged down by the thousands of lane sums in a group: fp64 GRADE while the group's |mean|
+      // is of the order of its standard deviation (every GroupNorm input of the path: ratio <= ~3).  A group with |mean| >>
+      // std loses (mean / std)^2 x 1e-7 of its variance to the cancellation E[x^2] - mean^2 on fp32-rounded lane sums (ratio
+      // 30: rstd off by ~5e-5, tests/test_epilogue_outputs_gpu.py::test_partials_of_a_large_offset_tensor); the magnitude
+      // bound derived from the same statistics stays an upper bound, and the overflow flag still backs it.
       typedef float f32x2 __attribute__((ext_vector_type(2)));
       f32x2 gs[KU][2], gq[KU][2];
 #pragma unroll

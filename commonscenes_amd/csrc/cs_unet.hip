@@ -763,7 +763,7 @@ extern "C" int64_t cs_unet_workspace_bytes(const cs_unet* u, int nb_x, int cfg_p
   // the context pass needs one [nb_ctx][max c] temporary
   int maxc = 0;
   for (const Gemm& g : u->gemms) maxc = g.cout > maxc && g.cin == u->cfg.context_dim ? g.cout : maxc;
-  const int64_t ctx_ws = align_up((int64_t)(cfg_pairs ? 2 : 1) * nb_x * maxc * 4) + ALIGN;
+  const int64_t ctx_ws = align_up((int64_t)(cfg_pairs ? 2 : 1) * nb_x * maxc * 4) + 3 * ALIGN;      // (+ the bound slots)
   return e.peak > ctx_ws ? e.peak : ctx_ws;
 }
 
@@ -772,6 +772,10 @@ extern "C" int cs_unet_context(const cs_unet* u, const void* arena, const float*
   if (!u || !u->packed || !arena || !ctx || !ctxvec || !workspace || nb_ctx <= 0) return CS_EINVAL;
   if (!u->cfg.use_spatial_transformer) return CS_EINVAL;      // the concat family has no context
   Exec e(*u, arena, workspace, workspace_bytes, false, (hipStream_t)stream);
+  const bool dyn = u->cfg.math == CS_MATH_F16X3 && !cs_debug()->no_dyn_scale && !cs_debug()->no_static_scales;
+  Buf slots = e.alloc(64, 1);              // slot 0: max |ctx|; slot 1 + k: max |to_v(ctx)| of transformer block k
+  int nslot = 0;
+  if (dyn && e.ok() && hipMemsetAsync(e.p(slots), 0, 64 * 4, e.st) != hipSuccess) e.chk(CS_EINVAL);
   // ctx rows are read in place: describe them as a buffer view at offset (ctx - workspace)
   auto visit = [&](const Layer& l) {
     if (l.kind != ATTN || !e.ok()) return;
@@ -783,6 +787,19 @@ extern "C" int cs_unet_context(const cs_unet* u, const void* arena, const float*
     for (int pass = 0; pass < 2 && e.ok(); ++pass) {
       const Gemm& g = pass == 0 ? gv : go;
       memset(&q, 0, sizeof(q));
+      // r5 (unet.py::_context_vectors): the context and to_v's output are raw operands -- their scale follows a device-side
+      // magnitude bound (max |.| into a workspace slot, CsConvGemm.a_bound) instead of the constant 16
+      if (dyn) {
+        const float* src = pass == 0 ? ctx : e.p(v2);
+        const int64_t nel = (int64_t)nb_ctx * (pass == 0 ? u->cfg.context_dim : gv.cout);
+        float* slot = e.p(slots) + (pass == 0 ? 0 : 1 + nslot);
+        if (pass == 1 || nslot == 0) {
+          CS_LAUNCH(absmax_kernel, dim3(cs_grid_for(nel, 256, 256)), dim3(256), 0, e.st, src, nel, slot);
+          if (hipGetLastError() != hipSuccess) e.chk(CS_EINVAL);
+        }
+        q.a_bound = slot;
+        if (pass == 1) ++nslot;
+      }
       q.x = pass == 0 ? ctx : e.p(v2);
       q.out = pass == 0 ? e.p(v2) : ctxvec + l.ctx_off;
       q.w = reinterpret_cast<const float*>(e.arena + g.w_off);

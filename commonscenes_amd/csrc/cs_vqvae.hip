@@ -107,19 +107,23 @@ int build(cs_vqvae& u) {
 struct VExec : ExecBase {
   const cs_vqvae& u;
   VExec(const cs_vqvae& u_, const void* arena_, void* ws_, int64_t ws_bytes_, bool dry_, hipStream_t st_)
-      : ExecBase(u_, arena_, ws_, ws_bytes_, dry_, st_), u(u_) {}
+      : ExecBase(u_, arena_, ws_, ws_bytes_, dry_, st_), u(u_) {
+    stats_invariant_only = true;      // r5: GroupNorm partials only from batch-independent statistics tiles (vqvae.py)
+  }
 
   // ResnetBlock.forward (vqvae_modules.py:103-123): GN+swish -> conv -> GN+swish -> conv, + (1x1-projected) input
   Act res(const ResP& r, const Act& x) {
     Buf h = groupnorm(x.b, r.n1, x.nb, 1e-6f, CS_ACT_SILU, vq_groups(r.cin), r.c1);
-    Buf h1 = gemm(h, r.c1, x.nb, x.d, x.h, x.w);
+    // (want_stats: the conv's epilogue leaves the partial sums the next GroupNorm takes its statistics from -- vqvae.py::_res)
+    Buf h1 = gemm(h, r.c1, x.nb, x.d, x.h, x.w, 1, 0, CS_ACT_NONE, nullptr, 0, 1, nullptr, 0, 0, 1, 0, /*want_stats=*/true);
     release(h);
     Buf h2 = groupnorm(h1, r.n2, x.nb, 1e-6f, CS_ACT_SILU, vq_groups(r.cout), r.c2);
     release(h1);
     Buf skip = x.b;
     if (r.nin >= 0) skip = gemm(x.b, r.nin, x.nb, x.d, x.h, x.w);
     Act o = x;
-    o.b = gemm(h2, r.c2, x.nb, x.d, x.h, x.w, 1, 0, CS_ACT_NONE, nullptr, 0, 1, dry ? nullptr : p(skip), skip.c);
+    o.b = gemm(h2, r.c2, x.nb, x.d, x.h, x.w, 1, 0, CS_ACT_NONE, nullptr, 0, 1, dry ? nullptr : p(skip), skip.c, 0, 1, 0,
+               /*want_stats=*/true);
     release(h2);
     if (r.nin >= 0) release(skip);
     return o;
@@ -166,7 +170,7 @@ int decode(VExec& e, const float* latent_ncdhw, float* sdf_ncdhw, int64_t* idx_o
   h.nb = nb; h.d = h.h = h.w = g;
   Buf q4 = e.gemm(zl, u.g_post, nb, g, g, g);              // post_quant_conv (1x1x1)
   e.release(zl);
-  h.b = e.gemm(q4, u.g_conv_in, nb, g, g, g);
+  h.b = e.gemm(q4, u.g_conv_in, nb, g, g, g, 1, 0, CS_ACT_NONE, nullptr, 0, 1, nullptr, 0, 0, 1, 0, /*want_stats=*/true);
   e.release(q4);
   auto step = [&](Act o) {
     e.release(h.b);

@@ -488,6 +488,17 @@ def _epilogue_extras(lib, p, x_dev, nb: int, rps: int, m_tiles_rows: int, cout: 
         return None, False
     rows, pair = C.c_int32(0), C.c_int32(0)
     L.check(lib.cs_conv_gemm_epilogue_caps(C.byref(p), C.byref(rows), C.byref(pair)), "cs_conv_gemm_epilogue_caps")
+    if want_stats == "invariant" and rows.value > 0:
+        # r5: partial sums only where the statistics tiles do not depend on the BATCH -- the launch of ONE
+        # sample must pick the same statistics-tile rows, so that an object decoded alone and inside a slice of 16 sums its
+        # groups over the same tiles in the same order (the VQ decoder's bit-exact batch invariance,
+        # tests/test_model_gpu.py::test_vq_decode_batch_invariance)
+        q = L.CsConvGemm.from_buffer_copy(p)
+        q.nb = 1
+        rows1 = C.c_int32(0)
+        L.check(lib.cs_conv_gemm_epilogue_caps(C.byref(q), C.byref(rows1), None), "cs_conv_gemm_epilogue_caps")
+        if rows1.value != rows.value:
+            rows = C.c_int32(0)
     st = None
     if want and _sw("GN_PARTS") and rows.value > 0:
         tiles = (m_tiles_rows + rows.value - 1) // rows.value

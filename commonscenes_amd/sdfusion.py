@@ -335,6 +335,8 @@ class SDFusionText2ShapeModel:
         c_all, uc_all = torch.cat(cs, dim=0), torch.cat(ucs, dim=0)
         noise_all = torch.cat(noises, dim=0).contiguous()
         gen, lats = [], []
+        if launch_B is None:
+            launch_B = max(int(self.launch_B), 64)          # scenes are batched to fill the chip: up to 64 objects per launch
         for sl in self._launch_slices(0, total, mini_B, launch_B, ddim_eta):
             self.last_launch_sizes.append(sl.stop - sl.start)
             samples = self._sample_minibatch(smp, ddim_steps, shape, c_all[sl], uc_all[sl], noise_all[sl].contiguous(),

@@ -591,6 +591,7 @@ class DiffusionUNet:
         nb = ctx.shape[0]
         flat = ctx.reshape(nb, -1)
         vecs = {}
+        b_ctx = None
         inp, mid, out = self._blocks
         P = self.prefix
         for bp, layers in ([(f"{P}input_blocks.{i}", l) for i, l in enumerate(inp)] + [(P + "middle_block", mid)]
@@ -598,8 +599,14 @@ class DiffusionUNet:
             for l in layers:
                 if l["kind"] == "attn":
                     t = f"{bp}.{l['idx']}.transformer_blocks.0"
-                    v2 = ops.linear(flat, pk[t + ".attn2.to_v"], math=self.math)
-                    vecs[t] = ops.linear(v2, pk[t + ".attn2.to_out.0"], math=self.math)
+                    # (r5: the context is a RAW input and to_v's output a raw intermediate: their operand scales follow a
+                    # device-side magnitude bound -- max |.|, CsConvGemm.a_bound -- not the constant 16; no host read-back)
+                    dyn = self.math == L.MATH_F16X3 and ops._sw("DYN_SCALE") and ops._sw("STATIC_SCALES")
+                    if dyn and b_ctx is None:
+                        b_ctx = flat.abs().max().reshape(1)
+                    v2 = ops.linear(flat, pk[t + ".attn2.to_v"], math=self.math, x_bound=b_ctx if dyn else None)
+                    vecs[t] = ops.linear(v2, pk[t + ".attn2.to_out.0"], math=self.math,
+                                         x_bound=v2.abs().max().reshape(1) if dyn else None)
         # (r5: the largest |row-vector entry| per block -- it enters t1's static bound, _static_scales -- ONE read-back per
         # sampling run, beside the run's one status read-back; never inside the step loop)
         cmax = {}

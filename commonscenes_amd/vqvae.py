@@ -201,13 +201,15 @@ class VQVAE:
         s1 = self._nas(p + ".norm1", rows * (c // _vq_groups(c)))
         h = ops.groupnorm(x, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], _vq_groups(c), 1e-6, L.ACT_SILU,
                           split16=ops.wants_split16(m, pk[p + ".conv1"]), a_scale=s1)
-        h = ops.conv_gemm(h, pk[p + ".conv1"], math=self.math, a_scale=s1)
+        # (stats="invariant", r5: the conv's epilogue leaves the partial sums norm2 takes its statistics from -- only where
+        # the statistics tiles are the same for one object and for a slice of sixteen, see ops._epilogue_extras)
+        h = ops.conv_gemm(h, pk[p + ".conv1"], math=self.math, a_scale=s1, stats="invariant")
         co = h.shape[-1]
         s2 = self._nas(p + ".norm2", rows * (co // _vq_groups(co)))
         h = ops.groupnorm(h, sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], _vq_groups(co), 1e-6, L.ACT_SILU,
                           split16=ops.wants_split16(m, pk[p + ".conv2"]), a_scale=s2)
         skip = x if (p + ".nin_shortcut") not in pk else ops.conv_gemm(x, pk[p + ".nin_shortcut"], math=self.math)
-        return ops.conv_gemm(h, pk[p + ".conv2"], res=skip, math=self.math, a_scale=s2)
+        return ops.conv_gemm(h, pk[p + ".conv2"], res=skip, math=self.math, a_scale=s2, stats="invariant")
 
     def _attn(self, p: str, x: Tensor) -> Tensor:
         sd, pk = self._sd, self._packed
@@ -226,7 +228,7 @@ class VQVAE:
         sd, pk = self._sd, self._packed
         D = "decoder."
         nres = len(self.cfg["ch_mult"])
-        h = ops.conv_gemm(z, pk[D + "conv_in"], math=self.math)
+        h = ops.conv_gemm(z, pk[D + "conv_in"], math=self.math, stats="invariant")
         h = self._res(D + "mid.block_1", h)
         h = self._attn(D + "mid.attn_1", h)
         h = self._res(D + "mid.block_2", h)

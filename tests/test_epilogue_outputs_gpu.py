@@ -347,3 +347,36 @@ def test_statistics_pass_leaves_the_same_magnitude_bound(shape):
     assert float(zero) == 0.0
     assert lib.cs_groupnorm_stats_bound(x.data_ptr(), nb, rows, c, c, groups, 1e-5, ws.data_ptr(), st_b.data_ptr(), None,
                                         s) == L.CS_EINVAL
+
+
+@pytest.mark.parametrize("ratio", [3.0, 30.0])
+def test_partials_of_a_large_offset_tensor(ratio):
+    """the epilogue adds a lane's 16-32 values per column in fp32 (sum AND sum of squares) before widening to
+    fp64, so a group with |mean| >> std loses (mean / std)^2 x 1e-7 of its variance to cancellation.  Pin the actual
+    behaviour: at ratio 3 (beyond anything on the path) the statistics are still fp64 grade; at ratio 30 rstd is off by
+    < 2e-4 relative -- not fp64 grade, documented as such -- the mean stays within 1e-6 sigma x ratio, and the magnitude
+    bound derived from the same statistics is still an upper bound of max |x|."""
+    from commonscenes_amd import lib as L, ops
+    nb, d, h, w, cin, cout = 8, 16, 8, 8, 64, 448
+    x = _rand(nb, d, h, w, cin, seed=31)
+    wt = _rand(cout, cin, 3, 3, 3, seed=32, scale=(cin * 27) ** -0.5)
+    b = torch.full((cout,), float(ratio), device="cuda")                # output ~ N(ratio, 1) per channel
+    pw = ops.pack_weight(wt, b, math=L.MATH_F16X3)
+    y = ops.conv_gemm(x, pw, stats=True)
+    torch.cuda.synchronize()
+    st = getattr(y, "cs_stats", None)
+    assert st is not None
+    slot = torch.zeros(1, dtype=torch.float32, device="cuda")
+    a = ops.groupnorm_stats_from_parts([(0, st)], nb, d * h * w, cout, 32, 1e-5, y.device, bound=slot).double()
+    t = y.double().reshape(nb, -1, 32, cout // 32)
+    mean, var = t.mean(dim=(1, 3)), t.var(dim=(1, 3), unbiased=False)
+    rstd = 1.0 / (var + 1e-5).sqrt()
+    dm = float(((a[..., 0] - mean).abs() * rstd).max())
+    dr = float(((a[..., 1] - rstd).abs() / rstd).max())
+    torch.cuda.synchronize()
+    print(f"large-offset partials, |mean| / std ~ {ratio:g}: mean off by {dm:.2e} sigma, rstd by {dr:.2e} relative")
+    if ratio <= 3.0:
+        assert dm < 2e-7 and dr < 1e-6
+    else:
+        assert dm < 1e-5 and dr < 2e-4
+    assert float(slot.item()) >= float(y.abs().max())

@@ -228,7 +228,7 @@ def test_rel2shape_reruns_an_overflowing_minibatch_in_fp32(tmp_path):
         assert ops.read_status() == 0
 
 
-@pytest.mark.parametrize("scaled", ["to_v x1e5", "to_q,to_k x30", "ff.net.0 x300", "context x1e4", "none"])
+@pytest.mark.parametrize("scaled", ["to_v x1e5", "to_q,to_k x4", "ff.net.0 x300", "context x1e4", "none"])
 def test_transformer_operands_take_static_scales_and_need_no_fallback(scaled):
     """the operands BORN INSIDE a transformer block (attention.py:237-245: q / k / v, the attention
     output, the GEGLU product, t2) used to ride the constant scale 16 + the overflow flag + a whole-mini-batch fp32 re-run.
@@ -248,9 +248,9 @@ def test_transformer_operands_take_static_scales_and_need_no_fallback(scaled):
     ctx_mag = 1.0
     if scaled == "to_v x1e5":
         sd[t0 + "attn1.to_v.weight"] = sd[t0 + "attn1.to_v.weight"] * 1.0e5
-    elif scaled == "to_q,to_k x30":
+    elif scaled == "to_q,to_k x4":          # (logits x16: still a soft softmax -- x900 makes the fp64 comparison itself ill-conditioned)
         for n in ("to_q", "to_k"):
-            sd[t0 + f"attn1.{n}.weight"] = sd[t0 + f"attn1.{n}.weight"] * 30.0
+            sd[t0 + f"attn1.{n}.weight"] = sd[t0 + f"attn1.{n}.weight"] * 4.0
     elif scaled == "ff.net.0 x300":
         for n in ("weight", "bias"):
             sd[t0 + f"ff.net.0.proj.{n}"] = sd[t0 + f"ff.net.0.proj.{n}"] * 300.0
