@@ -813,14 +813,25 @@ static int attn16_dispatch(const float* q, const float* k, const float* v, float
   // profiles/r03_ar_attn_nw.txt).  Same per-query arithmetic either way: bit-identical.
   // CS_ATTN_NW8=1: the previous rule (eight waves from 512 / 256 queries), A/B runs.
   const bool fill8 = cs_debug()->attn_nw8 || (int64_t)nb * heads * ((nq + 255) / 256) >= 128;
+  // r5: one or two objects -- 16 (sample, head) groups -- are 128 four-wave workgroups at 1024 tokens and 32 at 256: with
+  // two-wave workgroups (64 queries each) every CU gets one; same per-query arithmetic: bit-identical.  CS_ATTN_NW2=0: off.
+  static const bool nw2_on = [] {
+    const char* e = getenv("CS_ATTN_NW2");
+    return !(e && e[0] == '0');
+  }();
+  const bool fill2 = nw2_on && (int64_t)nb * heads * ((nq + 127) / 128) < 256 && nq >= 128;
   if (dh <= 64) {
     if (nq >= 512 && fill8)
       return launch_attn16<2, 64, X1, 8>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, s, qs, ks, vs);
+    if (fill2)
+      return launch_attn16<2, 64, X1, 2>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, s, qs, ks, vs);
     return launch_attn16<2, 64, X1>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, s, qs, ks, vs);
   }
   if (dh <= 96) {
     if (nq >= 256 && fill8)
       return launch_attn16<3, 64, X1, 8>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, s, qs, ks, vs);
+    if (fill2)
+      return launch_attn16<3, 64, X1, 2>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, s, qs, ks, vs);
     return launch_attn16<3, 64, X1>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, s, qs, ks, vs);
   }
   if (dh <= 128) return launch_attn16<4, 64, X1>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, s, qs, ks, vs);

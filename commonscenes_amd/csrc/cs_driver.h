@@ -855,10 +855,18 @@ struct ExecBase {
     if (stats_invariant_only) {
       // r5: only where ONE sample's launch picks the same statistics tiles (ops.py::_epilogue_extras, stats="invariant"):
       // the VQ decoder's bit-exact batch invariance
-      CsConvGemm one = probe;
-      one.nb = 1;
-      int32_t rows1 = 0;
-      if (cs_conv_gemm_epilogue_caps(&one, &rows1, nullptr) != CS_OK || rows1 != rows) return;
+      // (the SAME kernel variant -- tile code, slab width, statistics rows -- at one sample, at the decode slice limit of
+      // sixteen and at this batch: ops.py::_epilogue_extras)
+      int32_t t0 = 0, s0 = 0;
+      if (nb > 16 || cs_conv_gemm_launch_info(&probe, &t0, &s0) != CS_OK) return;
+      for (int nbp : {1, 16}) {
+        CsConvGemm one = probe;
+        one.nb = nbp;
+        int32_t r1 = 0, t1 = 0, s1 = 0;
+        if (cs_conv_gemm_epilogue_caps(&one, &r1, nullptr) != CS_OK || cs_conv_gemm_launch_info(&one, &t1, &s1) != CS_OK ||
+            r1 != rows || t1 != t0 || s1 != s0)
+          return;
+      }
     }
     const int64_t tiles = (m_rows + rows - 1) / rows;
     Stat sx = alloc_stat((int64_t)ncls * tiles, q.cout, nb, (int)(rps / rows), ncls);

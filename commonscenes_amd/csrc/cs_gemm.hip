@@ -566,14 +566,15 @@ extern "C" int cs_conv_gemm_plan(const CsConvGemm* d, int32_t* splitk, int64_t* 
   return CS_OK;
 }
 
-// most 64x64 tiles a launch may have and still take the K-wave kernel (one 128 KB workgroup per CU): one resident round by
-// default; CS_KWAVE_MAX_TILES overrides (tuning sweeps)
+// most 64x64 tiles a launch may have and still take the K-wave kernel (one 128 KB workgroup per CU): four rounds of the chip
+// (r5, 7 objects: 24.09 / 24.05 ms per step at one round, 23.94 / 23.92 at four -- the level-2 C x C GEMMs of 616 tiles ran
+// at 73 TF/s on the one-chain tile, profiles/r05_e_kwave_tiles_ab.txt); CS_KWAVE_MAX_TILES overrides (tuning sweeps)
 static int64_t kwave_max_tiles() {
   static const int64_t v = [] {
     const char* e = getenv("CS_KWAVE_MAX_TILES");
     return (e && *e) ? atoll(e) : (long long)-1;
   }();
-  return v >= 0 ? v : device_cus();
+  return v >= 0 ? v : 4LL * device_cus();
 }
 
 // tile of an automatic (desc->tile == 0) launch that is not the ping-pong kernel's

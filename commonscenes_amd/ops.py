@@ -478,6 +478,9 @@ def groupnorm_stats_from_parts(segs, nb: int, rows: int, c: int, groups: int, ep
     return stats
 
 
+INVARIANT_MAX_BATCH = 16      # stats="invariant": the largest batch the tile choice is compared at (VQVAE.MAX_DECODE_BATCH)
+
+
 def _epilogue_extras(lib, p, x_dev, nb: int, rps: int, m_tiles_rows: int, cout: int, want_stats,
                      out_pair: Optional[float], ncls: int = 1):
     """Ask the library what this launch's epilogue can emit (cs_conv_gemm_epilogue_caps -- the one rule) and set the
@@ -493,12 +496,20 @@ def _epilogue_extras(lib, p, x_dev, nb: int, rps: int, m_tiles_rows: int, cout: 
         # sample must pick the same statistics-tile rows, so that an object decoded alone and inside a slice of 16 sums its
         # groups over the same tiles in the same order (the VQ decoder's bit-exact batch invariance,
         # tests/test_model_gpu.py::test_vq_decode_batch_invariance)
-        q = L.CsConvGemm.from_buffer_copy(p)
-        q.nb = 1
-        rows1 = C.c_int32(0)
-        L.check(lib.cs_conv_gemm_epilogue_caps(C.byref(q), C.byref(rows1), None), "cs_conv_gemm_epilogue_caps")
-        if rows1.value != rows.value:
-            rows = C.c_int32(0)
+        # (the SAME kernel variant -- tile code and statistics rows -- at one sample, at the decode slice limit of sixteen
+        # and at this batch: otherwise some batch sizes would take their statistics from the partials and others from a pass
+        # over the tensor, or from differently shaped lane sums)
+        t0, s0 = C.c_int32(0), C.c_int32(0)
+        L.check(lib.cs_conv_gemm_launch_info(C.byref(p), C.byref(t0), C.byref(s0)), "cs_conv_gemm_launch_info")
+        for nb_probe in (1, INVARIANT_MAX_BATCH):
+            q = L.CsConvGemm.from_buffer_copy(p)
+            q.nb = nb_probe
+            r1, t1, s1 = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+            L.check(lib.cs_conv_gemm_epilogue_caps(C.byref(q), C.byref(r1), None), "cs_conv_gemm_epilogue_caps")
+            L.check(lib.cs_conv_gemm_launch_info(C.byref(q), C.byref(t1), C.byref(s1)), "cs_conv_gemm_launch_info")
+            if r1.value != rows.value or t1.value != t0.value or s1.value != s0.value or nb > INVARIANT_MAX_BATCH:
+                rows = C.c_int32(0)
+                break
     st = None
     if want and _sw("GN_PARTS") and rows.value > 0:
         tiles = (m_tiles_rows + rows.value - 1) // rows.value

@@ -43,7 +43,8 @@ CASES = [
     (2048, 448, 448, True, 0, 0, "level-1 token GEMM"),
     (2, 896, 896, False, 0, 2, "time_embed.2 with SiLU: two rows"),
     (2, 896, 8064, False, 0, 0, "all emb_layers in one GEMM"),
-    (8192, 448, 224, False, 0, 0, "level-0 skip_connection: 512 tiles -> NOT auto-selected, explicit tile 10 still right"),
+    (8192, 448, 224, False, 0, 0, "level-0 skip_connection: 512 tiles, two rounds of the chip"),
+    (32768, 448, 224, False, 0, 0, "2048 tiles -> NOT auto-selected (beyond four rounds), explicit tile 10 still right"),
     (500, 200, 100, True, 0, 0, "ragged M, K and N (cin % 16 != 0, cout % 64 != 0)"),
     (64, 128, 64, False, 0, 0, "eight chunks: two per wave"),
 ]
@@ -77,7 +78,7 @@ def test_kwave_gemm_against_fp64_and_the_one_chain_tile(case):
     assert rel_l2(y10, y3) < 1e-6
     auto = _tile_of(m, cin, cout)
     tiles = ((m + 63) // 64) * ((cout + 63) // 64)
-    assert (auto == 10) == (tiles <= 256 and cin >= 128 and cin % 4 == 0 and cout % 224 == 0), (auto, tiles)
+    assert (auto == 10) == (tiles <= 1024 and cin >= 128 and cin % 4 == 0 and cout % 224 == 0), (auto, tiles)
     if auto == 10:
         assert torch.equal(ya, y10)
     with L.debug_override(no_kwave=1):
@@ -144,3 +145,31 @@ def test_kwave_flags_an_operand_beyond_the_fp16_range_and_follows_a_magnitude_bo
     torch.cuda.synchronize()
     ops.check_overflow()
     assert rel_l2(y, xb.double() @ wt.double().t()) < 1e-6
+
+
+@pytest.mark.parametrize("n,c,heads", [(1024, 448, 8), (256, 672, 8)])
+def test_small_batch_attention_on_two_wave_workgroups_is_bit_identical(n, c, heads):
+    """r5: at one or two objects the UNet's self-attention (attention.py:179-218) runs two-wave workgroups (64 queries
+    each) so that every CU gets one; the per-query arithmetic does not depend on the workgroup shape: the rows of a
+    2-sample call equal the same samples' rows inside a 32-sample call (eight-wave workgroups), bit for bit."""
+    from commonscenes_amd import lib as L, ops
+    big = _rand(32, n, 3 * c, seed=41)
+    small = big[5:7].contiguous()
+    scale = (c // heads) ** -0.5
+    a_big = ops.attention(big[..., :c], big[..., c:2 * c], big[..., 2 * c:], heads, scale, math=L.MATH_F16X3)
+    a_small = ops.attention(small[..., :c], small[..., c:2 * c], small[..., 2 * c:], heads, scale, math=L.MATH_F16X3)
+    a_sc = ops.attention(small[..., :c], small[..., c:2 * c], small[..., 2 * c:], heads, scale, math=L.MATH_F16X3,
+                         scales=(16.0, 16.0, 16.0))
+    torch.cuda.synchronize()
+    assert torch.equal(a_small, a_big[5:7])
+    assert torch.equal(a_sc, a_small)              # the scaled entry at the default scales is the plain entry
+    # fp64 softmax attention on one (sample, head)
+    q, k, v = (small[0, :, i * c:i * c + c // heads].double() for i in range(3))
+    ref = torch.softmax(q @ k.t() * scale, dim=-1) @ v
+    assert rel_l2(a_small[0, :, :c // heads], ref) < 1e-6
+    # other power-of-two operand scales: the same result up to the hi / lo split's rounding
+    a_s2 = ops.attention(small[..., :c], small[..., c:2 * c], small[..., 2 * c:], heads, scale, math=L.MATH_F16X3,
+                         scales=(256.0, 64.0, 1.0))
+    torch.cuda.synchronize()
+    assert rel_l2(a_s2, a_small) < 1e-6
+    ops.check_overflow()
