@@ -813,25 +813,17 @@ static int attn16_dispatch(const float* q, const float* k, const float* v, float
   // profiles/r03_ar_attn_nw.txt).  Same per-query arithmetic either way: bit-identical.
   // CS_ATTN_NW8=1: the previous rule (eight waves from 512 / 256 queries), A/B runs.
   const bool fill8 = cs_debug()->attn_nw8 || (int64_t)nb * heads * ((nq + 255) / 256) >= 128;
-  // r5: one or two objects -- 16 (sample, head) groups -- are 128 four-wave workgroups at 1024 tokens and 32 at 256: with
-  // two-wave workgroups (64 queries each) every CU gets one; same per-query arithmetic: bit-identical.  CS_ATTN_NW2=0: off.
-  static const bool nw2_on = [] {
-    const char* e = getenv("CS_ATTN_NW2");
-    return !(e && e[0] == '0');
-  }();
-  const bool fill2 = nw2_on && (int64_t)nb * heads * ((nq + 127) / 128) < 256 && nq >= 128;
+  // (r5, measured and not taken: TWO-wave workgroups at one or two objects -- every CU gets one -- ran 62.3 vs 55.4 us at 1024
+  // tokens x dh 56 and 49.7 vs 38.2 us at 256 x dh 84: the K / V staging per workgroup does not shrink with the query tile,
+  // profiles/r05_f_attn_nw2_ab.txt)
   if (dh <= 64) {
     if (nq >= 512 && fill8)
       return launch_attn16<2, 64, X1, 8>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, s, qs, ks, vs);
-    if (fill2)
-      return launch_attn16<2, 64, X1, 2>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, s, qs, ks, vs);
     return launch_attn16<2, 64, X1>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, s, qs, ks, vs);
   }
   if (dh <= 96) {
     if (nq >= 256 && fill8)
       return launch_attn16<3, 64, X1, 8>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, s, qs, ks, vs);
-    if (fill2)
-      return launch_attn16<3, 64, X1, 2>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, s, qs, ks, vs);
     return launch_attn16<3, 64, X1>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, s, qs, ks, vs);
   }
   if (dh <= 128) return launch_attn16<4, 64, X1>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, s, qs, ks, vs);

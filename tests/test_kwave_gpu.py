@@ -148,10 +148,11 @@ def test_kwave_flags_an_operand_beyond_the_fp16_range_and_follows_a_magnitude_bo
 
 
 @pytest.mark.parametrize("n,c,heads", [(1024, 448, 8), (256, 672, 8)])
-def test_small_batch_attention_on_two_wave_workgroups_is_bit_identical(n, c, heads):
-    """r5: at one or two objects the UNet's self-attention (attention.py:179-218) runs two-wave workgroups (64 queries
-    each) so that every CU gets one; the per-query arithmetic does not depend on the workgroup shape: the rows of a
-    2-sample call equal the same samples' rows inside a 32-sample call (eight-wave workgroups), bit for bit."""
+def test_small_batch_attention_is_batch_invariant_and_takes_operand_scales(n, c, heads):
+    """The UNet's self-attention (attention.py:179-218): the per-query arithmetic does not depend on the workgroup shape --
+    the rows of a 2-sample call (four-wave workgroups) equal the same samples' rows inside a 32-sample call (eight-wave
+    workgroups) bit for bit -- and the r5 entry with caller-given operand scales (cs_attn_selfattn_f16x3_scaled) is the
+    plain entry at the default scales and agrees with it within the split's rounding at other powers of two."""
     from commonscenes_amd import lib as L, ops
     big = _rand(32, n, 3 * c, seed=41)
     small = big[5:7].contiguous()

@@ -34,6 +34,7 @@ def test_two_rank_sharded_rel2shape_equals_single_rank_bit_for_bit(tmp_path):
         assert res[r]["tiny_shape"] == [1, 1, 64, 64, 64] and res[r]["tiny_finite"]   # rank 1's shard was empty
     # a failure on one rank reaches all of them (no hang); the fp32 fall-back is taken by every rank together
     from commonscenes_amd import lib as L
+    assert all(res[r]["no_flag_with_static_scales"] is True for r in (0, 1)), res     # r5: that input runs on F16X3 unflagged
     assert sorted(res[r]["raise_policy"] for r in (0, 1)) == ["CsOverflowError", "RuntimeError"], res
     assert res[1]["raise_policy"] == "CsOverflowError"       # the last object lives in rank 1's shard
     assert all(res[r]["fallback_finite"] and res[r]["math_after_fallback"] == L.MATH_FP32 for r in (0, 1)), res
