@@ -90,6 +90,9 @@ def parse():
                     help="full = BASELINE.md section 4 (B=1 x 5 steps, B=32 x 2 steps as mini-batches of 7 and as one "
                          "batch; ~1-2 min of host time); quick = one mini-batch of 7, one step, scaled")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the fp32-input-MFMA comparison steps")
+    ap.add_argument("--no-gemm-profile", action="store_true",
+                    help="no per-GEMM HIP-event hooks in the timed region (A/B runs at small batches: two event records per "
+                         "GEMM launch cost ~1.3 ms of a 6.4 ms one-object step); the roofline block is then null")
     ap.add_argument("--traffic", action="store_true",
                     help="(default at one GPU unless --no-extras / --no-traffic) measure the dominant kernel's HBM bytes per "
                          "launch now: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of a short run of this script "
@@ -476,7 +479,8 @@ def main():
 
     run(0, a.warmup)
     barrier()
-    ops.GEMM_PROFILE = prof = []
+    prof = []
+    ops.GEMM_PROFILE = None if a.no_gemm_profile else prof
     t0 = time.perf_counter()
     run(a.warmup, a.steps)
     barrier()

@@ -326,7 +326,13 @@ int plan_splitk(const CsConvGemm& p, int64_t M) {
     return (int)s;
   }
   int64_t s = 512 / wgs;
-  if (s > 32) s = 32;
+  // (r5: the cap was 32 -- one object's 4^3 level is 12 output tiles: 32 slices = 192 workgroups of the 256-row tile on 256
+  // CUs, 42 slices = 252; CS_SPLITK_CAP overrides for A/B runs)
+  static const int64_t cap = [] {
+    const char* e = getenv("CS_SPLITK_CAP");
+    return (e && *e) ? atoll(e) : 48LL;
+  }();
+  if (s > cap) s = cap;
   if (s > nk / 8) s = nk / 8;
   if (s < 1) s = 1;
   {

@@ -12,7 +12,7 @@ for o in $OBJS; do
   for rep in 1 2; do
     for v in 0 1; do
       if [ $v = 1 ]; then export $VAR=1; else unset $VAR; fi
-      ms=$(timeout 600 python bench.py --no-cpu-baseline --no-traffic --no-extras --no-fp32-leg --objects $o --steps $st --warmup 5 2>/dev/null | python -c "import sys,json; print(json.loads(sys.stdin.read().strip().splitlines()[-1])['ms_per_step'])")
+      ms=$(timeout 600 python bench.py --no-cpu-baseline --no-traffic --no-extras --no-fp32-leg --no-gemm-profile --objects $o --steps $st --warmup 5 2>/dev/null | python -c "import sys,json; print(json.loads(sys.stdin.read().strip().splitlines()[-1])['ms_per_step'])")
       echo "objects=$o $VAR=$v rep=$rep ms_per_step=$ms" | tee -a $OUT
     done
   done
