@@ -326,11 +326,13 @@ int plan_splitk(const CsConvGemm& p, int64_t M) {
     return (int)s;
   }
   int64_t s = 512 / wgs;
-  // (r5: the cap was 32 -- one object's 4^3 level is 12 output tiles: 32 slices = 192 workgroups of the 256-row tile on 256
-  // CUs, 42 slices = 252; CS_SPLITK_CAP overrides for A/B runs)
+  // (r5, measured and not taken: a cap of 48 -- one object's 4^3 level is 12 output tiles: 32 slices = 192 workgroups of the
+  // 256-row tile on 256 CUs, 42 slices = 252 -- ran 6.54 / 6.53 / 6.54 ms per one-object step against 6.47 / 6.47 / 6.45 at
+  // 32: a third more partial-tile traffic for a quarter shorter K loops, profiles/r05_h_splitk_cap_ab.txt; CS_SPLITK_CAP
+  // overrides for A/B runs)
   static const int64_t cap = [] {
     const char* e = getenv("CS_SPLITK_CAP");
-    return (e && *e) ? atoll(e) : 48LL;
+    return (e && *e) ? atoll(e) : 32LL;
   }();
   if (s > cap) s = cap;
   if (s > nk / 8) s = nk / 8;
@@ -493,6 +495,7 @@ void tile_dims(int tile, int& bm, int& bn) {
 
 static int auto_tile(const CsConvGemm& p, int M, bool f16x3);
 static bool up2_direct_batched(const CsConvGemm& d, int64_t m1, int ncls);
+static int up2_batched_tile(const CsConvGemm& d, int64_t m1, int ncls);
 
 // ONE rule for what a launch's epilogue can emit (CsConvGemm.gn_part / out_format): only the pipelined epilogue of the
 // F16X3 tile kernels and the split-K reduce can, so every condition under which the kernel takes another path is
@@ -525,7 +528,7 @@ extern "C" int cs_conv_gemm_epilogue_caps(const CsConvGemm* d, int32_t* gn_rows,
     q.ud = q.uh = q.uw = 0;
     q.dout = p.din; q.hout = p.hin; q.wout = p.win;
     q.tile = 0;
-    tile_dims(auto_tile(q, (int)m1, true), bm, bn);
+    tile_dims(up2_batched_tile(p, m1, ncls), bm, bn);
     rps = (int64_t)p.din * p.hin * p.win;
     if (!bm || !p.bias) return CS_OK;                         // (piped epilogue needs bias / residual / row vector)
     // ... the rest of the kernel's `piped` condition: no BN scale / shift, and the rows one tile's scattered
@@ -954,6 +957,11 @@ static bool up2_direct_batched(const CsConvGemm& d, int64_t m1, int ncls) {
   if (d.math != CS_MATH_F16X3 || !up2_ok(d) || m1 > 0x7fffffffLL) return false;
   if (cs_debug()->no_up2_direct || cs_debug()->no_up2_batch || m1 * (int64_t)ncls > 0x7fffffffLL) return false;
   const int nh = d.uh ? 2 : 1, nw = d.uw ? 2 : 1;
+  // r5: medium batches (seven objects' 4^3 -> 8x8 Upsample conv: four classes of 14 x 3 tiles) -- a class ALONE has few
+  // enough tiles for the plan to slice it (four K-sliced launches + four reduces + the interleave: 1.5 ms per step at 7
+  // objects), but all classes TOGETHER are 168 workgroups: one unsliced launch with the scattered store, from half the chip up
+  const int bn_all = d.cout % 224 == 0 ? 224 : 128;
+  const bool fills = d.cout % bn_all == 0 && (int64_t)ncls * ((m1 + 255) / 256) * (d.cout / bn_all) >= 128;
   for (int cls = 0; cls < ncls; ++cls) {
     const int pw = cls % nw, ph = (cls / nw) % nh, pd = cls / (nw * nh);
     CsConvGemm q = d;
@@ -964,8 +972,10 @@ static bool up2_direct_batched(const CsConvGemm& d, int64_t m1, int ncls) {
     q.ldo = d.cout;
     q.tile = 0;
     q.splitk = 0;
-    if (plan_splitk(q, m1) > 1 || !cs_f16x3_slab4_ok(q, auto_tile(q, (int)m1, true), 1)) return false;
+    const int tl = fills ? (bn_all == 224 ? 4 : 6) : auto_tile(q, (int)m1, true);
+    if ((!fills && plan_splitk(q, m1) > 1) || !cs_f16x3_slab4_ok(q, tl, 1)) return false;
   }
+  if (fills && (m1 > 0x7fffffffLL)) return false;
   return (int64_t)ncls * ((m1 + 255) / 256) * ((d.cout + 63) / 64) < 0x7fffffffLL;
 }
 
@@ -997,6 +1007,20 @@ static int up2_sliced_plan(const CsConvGemm& d, int64_t m1, int ncls) {
   sl = (nsc + (nsc + sl - 1) / sl - 1) / ((nsc + sl - 1) / sl);      // the fewest slices of that length
   if ((int64_t)ncls * sl * m1 * d.cout * 4 >= 0x7FF00000LL * 4) return 0;
   return sl < 2 ? 0 : (int)sl;
+}
+
+// tile of the one-launch batched route (0: the route is not taken): the automatic per-class tile, or -- where only all
+// classes together fill half the chip (up2_direct_batched) -- the 256-row tile of the channel count
+static int up2_batched_tile(const CsConvGemm& d, int64_t m1, int ncls) {
+  if (!up2_direct_batched(d, m1, ncls)) return 0;
+  CsConvGemm q = d;
+  q.kd = d.ud ? 2 : 3; q.kh = d.uh ? 2 : 3; q.kw = d.uw ? 2 : 3;
+  q.ud = q.uh = q.uw = 0;
+  q.dout = d.din; q.hout = d.hin; q.wout = d.win;
+  q.tile = 0; q.splitk = 0;
+  const int t = auto_tile(q, (int)m1, true);
+  if (t == 4 || t == 6) return t;
+  return d.cout % 224 == 0 ? 4 : 6;
 }
 
 extern "C" int cs_conv_up2_info(int ud, int uh, int uw, int32_t* ncls, int32_t* kd, int32_t* kh, int32_t* kw) {
@@ -1103,6 +1127,7 @@ extern "C" int cs_conv_gemm_up2(const CsConvGemm* d, const void* const* w_cls, c
     CsConvGemm q = class_desc(0);
     q.out = d->out;
     q.ldo = d->ldo;
+    q.tile = up2_batched_tile(*d, m1, ncls);           // (explicit: a class alone might pick a smaller tile)
     return conv_gemm_impl(&q, stream, omap_f, 0, w_cls, w_lo_cls, acc_scale_cls, ncls);
   }
   if (direct) {
