@@ -321,3 +321,48 @@ def test_shared_host_rules_and_debug_struct():
     p.pd = p.ph = p.pw = 0
     p.a_format = 0
     assert dll.cs_conv_gemm_launch_info(C.byref(p), C.byref(t), C.byref(sl)) == 0 and (t.value, sl.value) == (4, 0)
+
+
+def test_static_bound_scales_are_powers_of_two_that_keep_the_bound_in_range():
+    """r5 host rules (csrc/cs_plan.hip): cs_bound_a_scale = the largest power of two s with bound * s <= 65000;
+    cs_transformer_static_scales = the scales of the operands born inside a transformer block from the weights' statistics
+    (attention.py:237-245): every scale is a power of two, scale * bound stays inside the fp16 range, a larger weight
+    statistic never gives a larger scale, and the formula matches its restatement here."""
+    import ctypes as C
+    import math
+    from commonscenes_amd import lib
+    dll = lib.load()
+    for b in (1e-30, 1e-6, 0.3, 1.0, 15.9, 16.0, 4094.0, 65000.0, 65001.0, 1.2e6, 3e10):
+        s = dll.cs_bound_a_scale(b)
+        assert s > 0 and math.log2(s) == int(math.log2(s))
+        if 2.0 ** -24 < s < 2.0 ** 40:
+            assert b * s <= 65000.0 < b * s * 2
+    assert dll.cs_bound_a_scale(0.0) == 2.0 ** 40 and dll.cs_bound_a_scale(float("nan")) == 2.0 ** 40
+    st = lib.CsTransformerStats()
+    vals = dict(rq=0.6, rk=0.61, rv=0.59, ro=0.58, bo=0.05, rx=0.6, bx=0.05, rg=0.6, bg=0.05, r2=0.55, b2=0.02, rpi=0.58,
+                bpi=0.04, g1=1.2, be1=2.1, g3=1.2, be3=2.0)
+    for k, v in vals.items():
+        setattr(st, k, v)
+    out = (C.c_float * 12)()
+    c, ntok, heads = 448, 1024, 8
+    assert dll.cs_transformer_static_scales(C.byref(st), c, ntok, heads, 1.2, 0.1, 3.0, out) == 0
+    rc = math.sqrt(c)
+    y1 = vals["g1"] * rc + vals["be1"]
+    bq, bk, bv = vals["rq"] * y1, vals["rk"] * y1, vals["rv"] * y1
+    egn = 1.2 * math.sqrt(ntok * (c // 32) - 1) + 0.1
+    bt1 = vals["ro"] * rc * bv + vals["bo"] + (vals["rpi"] * rc * egn + vals["bpi"]) + 3.0
+    y3 = vals["g3"] * rc + vals["be3"]
+    bgg = (vals["rx"] * y3 + vals["bx"]) * (vals["rg"] * y3 + vals["bg"])
+    bt2 = vals["r2"] * math.sqrt(4 * c) * bgg + vals["b2"] + bt1
+    for got, want in zip(list(out)[6:], (bq, bk, bv, bt1, bgg, bt2)):
+        assert abs(got - want) <= 1e-5 * want
+    for s, b in zip(list(out)[:6], (bq / math.sqrt(c // heads), bk, bv, bv, bgg, bt2)):
+        assert math.log2(s) == int(math.log2(s)) and b * s <= 65000.0 * (1 + 1e-5) < 2 * b * s * (1 + 1e-4)
+    # monotone: scaling to_v up by 1e5 scales v's (and t1's, t2's) bound and can only shrink those scales
+    base = list(out)
+    st.rv = vals["rv"] * 1e5
+    assert dll.cs_transformer_static_scales(C.byref(st), c, ntok, heads, 1.2, 0.1, 3.0, out) == 0
+    assert out[2] < base[2] and out[3] < base[3] and out[5] < base[5] and out[0] == base[0] and out[4] == base[4]
+    assert out[8] * out[2] <= 65000.0 * (1 + 1e-5)
+    assert dll.cs_transformer_static_scales(None, c, ntok, heads, 1.0, 0.0, 0.0, out) == lib.CS_EINVAL
+    assert dll.cs_transformer_static_scales(C.byref(st), 450, ntok, 8, 1.0, 0.0, 0.0, out) == lib.CS_EINVAL
