@@ -56,7 +56,6 @@ void parse_env(CsDebug& d) {
   d.no_dyn_scale = flag("CS_NO_DYN_SCALE");
   d.no_tok_rules = flag("CS_NO_TOK_RULES");
   d.no_fused_reduce = flag("CS_NO_FUSED_REDUCE");
-  d.no_temb_table = flag("CS_NO_TEMB_TABLE");
   d.no_gn_fold = flag("CS_NO_GN_FOLD");
   d.no_kwave = flag("CS_NO_KWAVE");
   d.no_static_scales = flag("CS_NO_STATIC_SCALES");

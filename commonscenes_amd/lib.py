@@ -74,7 +74,7 @@ class CsDebug(C.Structure):
         "no_split16", "no_pair16", "no_upfold", "no_splitk", "no_fused_geglu", "no_tapcol", "tapcol_tile", "no_cfg_split",
         "concat_copy", "tile512", "no_pw", "no_slab4", "no_attn_img", "attn_nw8", "no_up2_direct", "no_up2_batch",
         "plan_pow2", "slice_tile2", "no_gn_parts", "no_pair_epilogue", "no_dyn_scale", "no_tok_rules", "no_fused_reduce",
-        "no_temb_table", "no_gn_fold", "no_kwave", "no_static_scales")] + [
+        "no_gn_fold", "no_kwave", "no_static_scales")] + [
         ("split16_min_rows", C.c_int64), ("cfg_split_min_rows", C.c_int64), ("gn_small_group", C.c_int64)]
 
 

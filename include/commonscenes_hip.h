@@ -90,7 +90,6 @@ typedef struct CsDebug {
   int32_t no_dyn_scale;       /* raw-activation consumers keep the fixed operand scale 16 + overflow flag (r4) */
   int32_t no_tok_rules;       /* 1-tap GEMMs keep r3's tile / K-slice choices (r4: quantisation-aware tile, no slices under 128 chunks) */
   int32_t no_fused_reduce;    /* split-K always as two kernels (slices, then reduce + epilogue); same bits (r5) */
-  int32_t no_temb_table;      /* timestep-embedding chain evaluated per step instead of looked up in the per-model table (r5) */
   int32_t no_gn_fold;         /* GroupNorm (mean, rstd) always by the separate finalize launch, never in the apply kernel's prologue (r5) */
   int32_t no_kwave;           /* small 1-tap GEMMs stay on the 64x64 one-accumulator-chain tile (r5: K cut across the four waves) */
   int32_t no_static_scales;   /* operands born inside a transformer block keep the constant scale 16 + overflow flag (r5: static bounds) */
