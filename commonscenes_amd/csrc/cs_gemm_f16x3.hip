@@ -41,7 +41,8 @@ constexpr int MAX_TAPS = 27;
 #define CS_ABLATE 0   // debug builds, timing only (results are wrong): 1 = no DMA issue, 2 = DMAs fetch nothing (all
                       // offsets out of range -> zero fill), 4 = no vmcnt wait in the loop, 8 = no barrier,
                       // 16 = s_setprio around the MFMAs, 32 = scalar epilogue, 64 = all fetches from one 16 KB window,
-                      // 1024 = no epilogue (K loop + prologue only), 2048 = no K loop (prologue + epilogue only)
+                      // 1024 = no epilogue (K loop + prologue only), 2048 = no K loop (prologue + epilogue only),
+                      // 4096 / 8192 = slab kernel reads every second / only the first B fragment pair from LDS
 #endif
 
 // PRE = the activations arrive already split: p.x / p.x_lo are fp16 hi / lo images [rows][lda halves] written by
@@ -777,10 +778,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
     if (!(CS_ABLATE & 8)) __builtin_amdgcn_s_barrier();
     const unsigned char* s = smem + RING0 + stage * STAGE;
     h8 ah2[WMB], al2[WMB];
+    h8 bh, bl;
 #pragma unroll
     for (int j = 0; j < WNB; ++j) {
-      const h8 bh = *reinterpret_cast<const h8*>(s + b_frag + j * 512);
-      const h8 bl = *reinterpret_cast<const h8*>(s + b_frag + B_BYTES + j * 512);
+      // (CS_ABLATE 4096 / 8192, timing only: every second / only the first B fragment pair is read from LDS)
+      if (!(((CS_ABLATE & 4096) && (j & 1)) || ((CS_ABLATE & 8192) && j > 0))) {
+        bh = *reinterpret_cast<const h8*>(s + b_frag + j * 512);
+        bl = *reinterpret_cast<const h8*>(s + b_frag + B_BYTES + j * 512);
+      }
 #pragma unroll
       for (int i = 0; i < WMB; ++i) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh, acc[i][j], 0, 0, 0);

@@ -3,7 +3,10 @@ fp16 hi/lo operand pair -> F16X3 conv (the slab kernel's PRE instantiation).  us
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from commonscenes_amd import lib as L, ops, synth
+from commonscenes_amd import lib as L
+if os.environ.get("CS_LIB"):          # a what-if build of the library (variants/*.so)
+    L._LIB = L.load(os.environ["CS_LIB"])
+from commonscenes_amd import ops, synth
 
 SHAPES = [("conv 16^3   224->224", (16, 16, 16), 224, 224), ("conv 16^3   672->224", (16, 16, 16), 672, 224),
           ("conv 16x8x8 448->448", (16, 8, 8), 448, 448), ("conv 16x8x8 1120->448", (16, 8, 8), 1120, 448),
