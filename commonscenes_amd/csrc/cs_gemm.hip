@@ -635,11 +635,17 @@ static int auto_tile(const CsConvGemm& p, int M, bool f16x3) {
         tile = 1;
       else if (p.a_format == 2 && (p.cin + 15) / 16 <= 32)
         tile = 2;
+      // (iii, r5) a single, not even full round of 256-row tiles and K <= 84 chunks (the level-0 skip convs at the reference's
+      // mini-batch of 7: 224 tiles; the 672-column GEMMs at 16384 rows: 192) -- two 128-row workgroups per CU instead: 50.1
+      // vs 58.6 us (448 -> 224) and 66.7 vs 72.8 (672 -> 224) at 57344 rows, 63.2 vs 68.0 (672 -> 672), 106.2 vs 111.7 (1344
+      // -> 672) at 16384; 2688 -> 672 (168 chunks) stays: 193.8 vs 183.8.  profiles/r05_tok_smallm_b{14,64}.txt
+      else if (t4 <= 256 && (p.cin + 15) / 16 <= 84)
+        tile = 2;
     }
-    if (p.act == CS_ACT_GEGLU && tile != 4) tile = 2;   // the fused gate needs whole [x | gate] 224-column tiles
-    // ... and with a short K loop (the 448-channel level: 28 chunks) two 128-row workgroups per CU overlap one's gate
-    // epilogue with the other's K loop: 805 vs 867 us at 65536 x 448 -> 3584 (the 672-channel one prefers 256 rows)
-    if (p.act == CS_ACT_GEGLU && tile == 4 && (p.cin + 15) / 16 <= 32) tile = 2;
+    // the fused gate needs whole [x | gate] 224-column tiles; two 128-row workgroups per CU overlap one's gate epilogue with
+    // the other's K loop at BOTH widths (r5 sweeps, profiles/r05_tok_smallm_b{14,64}.txt: 672 -> 5376 at 3584 rows 99.0 vs
+    // 113.5 us on the 256-row tile, at 16384 rows 363.8 vs 377.7; 448 -> 3584 at 65536 rows 717 vs 737)
+    if (p.act == CS_ACT_GEGLU) tile = 2;
     // r5 (VERDICT r4 next #1a): small one-tap GEMMs -- every 64x64 tile resident at once (one 128 KB workgroup per CU) and
     // at least two K chunks per wave -- take the K-wave kernel: the four waves of a workgroup each run a quarter of the K
     // loop over the whole 64x64 tile, four accumulator chains and no barrier in the loop (cs_gemm_kw.hip).

@@ -321,6 +321,15 @@ def test_shared_host_rules_and_debug_struct():
     p.pd = p.ph = p.pw = 0
     p.a_format = 0
     assert dll.cs_conv_gemm_launch_info(C.byref(p), C.byref(t), C.byref(sl)) == 0 and (t.value, sl.value) == (4, 0)
+    # r5 rules: a single partial round of 256-row tiles with a short K loop takes two 128-row workgroups per CU (the level-0
+    # skip conv at the reference's mini-batch of 7: 224 tiles); the fused gate always runs on the 128-row tile
+    p.nb, p.cin, p.lda = 14, 448, 448
+    assert dll.cs_conv_gemm_launch_info(C.byref(p), C.byref(t), C.byref(sl)) == 0 and (t.value, sl.value) == (2, 0)
+    with L.debug_override(no_tok_rules=1):
+        assert dll.cs_conv_gemm_launch_info(C.byref(p), C.byref(t), C.byref(sl)) == 0 and t.value == 4
+    p.nb, p.hin, p.win, p.hout, p.wout = 64, 4, 4, 4, 4
+    p.cin, p.lda, p.cout, p.ldo, p.ldw, p.act, p.a_format = 672, 672, 5376, 2688, 5376, L.ACT_GEGLU, 2
+    assert dll.cs_conv_gemm_launch_info(C.byref(p), C.byref(t), C.byref(sl)) == 0 and (t.value, sl.value) == (2, 0)
 
 
 def test_static_bound_scales_are_powers_of_two_that_keep_the_bound_in_range():
