@@ -313,7 +313,7 @@ def gemm_summary(prof, wall_ms, math):
     # ALGORITHMIC HBM bytes of the dominant kernel's launches (what `traffic`, the counted bytes, is to be ratioed against):
     # the A operand once (m x cin x 4 B: fp32, or the fp16 hi + lo pair), the packed weights once (k x n x 4 B: fp16 hi +
     # lo), the fp32 result once (m x n x 4 B) and the residual where the launch adds one -- per launch, averaged over the
-    # kernel's launches.  The counters come out ~2.4x above this at 32 objects: a slab conv re-reads its A rows once per
+    # kernel's launches.  The counters come out ~1.9x above this at 32 objects: a slab conv re-reads its A rows once per
     # 224-column tile of the output and per kd (the halo planes), both of which hit L2 / MALL rather than HBM only partly.
     ab = 0.0
     for r in sel:

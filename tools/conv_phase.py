@@ -13,7 +13,7 @@ from commonscenes_amd import ops, synth
 NB = int(os.environ.get("CP_BATCH", "2"))
 N = int(os.environ.get("CP_N", "20"))
 SPLITS = [int(v) for v in os.environ.get("CP_SPLITS", "0").split(",")]        # 0 = the automatic plan
-SHAPES = [((4, 4, 4), 672, 672), ((4, 4, 4), 1344, 672), ((8, 8, 8), 448, 448), ((8, 8, 8), 1120, 448),
+SHAPES = [((16, 4, 4), 672, 672), ((16, 4, 4), 1344, 672), ((16, 8, 8), 448, 448), ((16, 8, 8), 1120, 448),
           ((16, 16, 16), 224, 224), ((16, 16, 16), 448, 224), ((16, 16, 16), 672, 224)]
 for sp, cin, cout in SHAPES:
     x = synth.tensor_device(f"x{sp}{cin}", (NB, *sp, cin), 1.0)
