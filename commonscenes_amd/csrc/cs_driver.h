@@ -50,6 +50,10 @@ struct Gemm {        // one packed GEMM weight (possibly several reference tenso
   int up_mask = 0, ncls = 0, fkd = 3, fkh = 3, fkw = 3, amax_slot = -1;
   int64_t fold_off = 0, cls_w_off[8] = {0}, cls_wlo_off[8] = {0};
   float cls_acc_scale[8] = {0};
+  // r5: the Winograd-W pack of a 3x3x3 conv beside the direct one (CsConvGemm.a_format = 3, ops.py::pack_weight_wino): four
+  // position images, one power-of-two scale; -1 = the geometry can never take that route
+  int64_t wino_off = -1, wino_lo_off = -1;
+  float wino_acc = 1.f;
 };
 
 struct Norm {
@@ -223,6 +227,14 @@ void layout_arena(Plan& u) {
       off += align_up(img);
       g.wlo_off = off;
       off += align_up(img);
+      if (g.k == 3 && !g.tap_cout && g.w.size() == 1 && g.w[0].param >= 0 && g.w[0].row0 == 0 && g.w[0].rows == g.cout &&
+          !g.src_cin && g.cout % 224 == 0 && g.cin % 8 == 0 && g.cin >= 16 && g.cin_pad == g.cin) {
+        const int64_t wimg = 4LL * 9 * kg * g.cout * 16;
+        g.wino_off = off;
+        off += align_up(wimg);
+        g.wino_lo_off = off;
+        off += align_up(wimg);
+      }
     } else {
       g.ldw = (g.cout + 3) / 4 * 4;
       g.w_off = off;
@@ -478,6 +490,16 @@ int pack_plan(Plan* u, const void* raw_dev, void* arena_dev, cs_stream_t stream)
       n_off += pc.rows;
     }
     if (n_off != g.cout) return CS_EINVAL;
+    if (f16 && g.wino_off >= 0) {      // r5: the Winograd-W pack (max |u_q| <= 1.5 max |w|: ops.py::pack_weight_wino)
+      const double m = 1.5 * (double)amax[(size_t)g.w[0].param];
+      int ex = 0;
+      if (m > 0.0 && std::isfinite(m)) (void)std::frexp(m, &ex);
+      const float wscale = (float)std::ldexp(1.0, 14 - ex);
+      g.wino_acc = 1.0f / (wscale * 16.0f);
+      const int rc = cs_pack_weight_f16x3_wino(src(g.w[0].param), arena + g.wino_off, arena + g.wino_lo_off, g.cout, g.cin,
+                                               wscale, stream);
+      if (rc != CS_OK) return rc;
+    }
     n_off = 0;
     for (const Piece& pc : g.b) {
       if (pc.param < 0) {
@@ -525,6 +547,8 @@ struct Buf {
                        // same footprint as fp32 [rows][c]
   bool pair = false;   // the INTERLEAVED operand pair (CsConvGemm.a_format = 2): bytes / row stride of fp32 [rows][c],
                        // written by cs_layernorm_pair16
+  bool wino = false;   // r5: the Winograd-W operand (CsConvGemm.a_format = 3): fp16 hi images [4][rows / 4][c] followed by
+                       // the lo images -- `rows` = 2 x the volume's voxels (the footprint of fp32 [rows][c])
   float a_scale = 16.f;   // F16X3 operand scale a GEMM reading this buffer uses: the default for activations of unknown
                           // range, the producer's bound for normalisation outputs (norm_a_scale)
 };
@@ -680,7 +704,8 @@ struct ExecBase {
     const int ocols = act == CS_ACT_GEGLU ? g.cout / 2 : g.cout;
     Buf out = alloc(mo, ocols);
     if (!ok()) return out;
-    if (x.c != g.cin_pad || x.rows != (int64_t)nb * d * h * w) {
+    if (x.c != g.cin_pad || x.rows != (x.wino ? 2 : 1) * (int64_t)nb * d * h * w ||
+        (x.wino && (g.wino_off < 0 || k != 3 || s_hw != 1 || s_d != 1 || up_hw || up_d || tile || a_bound_off >= 0))) {
       chk(CS_EINVAL);
       return out;
     }
@@ -688,15 +713,17 @@ struct ExecBase {
     memset(&q, 0, sizeof(q));
     // (the operand format is part of what the tile rule looks at: set in the sizing pass too, so that both passes ask
     // cs_conv_gemm_epilogue_caps about the same launch)
-    q.a_format = x.half ? 1 : x.pair ? 2 : 0;
+    q.a_format = x.wino ? 3 : x.half ? 1 : x.pair ? 2 : 0;
     if (!dry) {
       q.x = p(x);
       if (x.half) q.x_lo = reinterpret_cast<const char*>(p(x)) + x.rows * x.c * 2;
+      if (x.wino) q.x_lo = reinterpret_cast<const char*>(p(x)) + x.rows * x.c * 2;      // (rows = 2 M: the hi images' bytes)
       q.out = p(out);
-      q.w = reinterpret_cast<const float*>(arena + g.w_off);
+      q.w = reinterpret_cast<const float*>(arena + (x.wino ? g.wino_off : g.w_off));
       if (pl.math == CS_MATH_F16X3) {
-        q.w_lo = arena + g.wlo_off;
-        q.acc_scale = g.acc_scale * (16.0f / x.a_scale);      // g.acc_scale = 1 / (weight scale * 16); powers of two
+        q.w_lo = arena + (x.wino ? g.wino_lo_off : g.wlo_off);
+        // g.acc_scale = 1 / (weight scale * 16); powers of two
+        q.acc_scale = (x.wino ? g.wino_acc : g.acc_scale) * (16.0f / x.a_scale);
         q.a_scale = x.a_scale;
       }
       q.bias = (g.b_off >= 0 && !tc) ? wf(g.b_off) : nullptr;
@@ -748,7 +775,17 @@ struct ExecBase {
     int32_t sk = 1;
     int64_t wsb = 0;
     Buf skws;
-    if (tile == 0 && cs_conv_gemm_plan(&q, &sk, &wsb) == CS_OK && sk > 1) {
+    if (x.wino) {
+      // r5: the four position results (x K slices) live in the workspace; output transform + epilogue in the reduce kernel
+      if (cs_conv_wino_plan(&q, &sk, &wsb) != CS_OK) {
+        chk(CS_EINVAL);
+        return out;
+      }
+      skws = alloc(wsb / 4, 1);
+      if (!ok()) return out;
+      q.splitk = sk;
+      q.splitk_ws = dry ? nullptr : p(skws);
+    } else if (tile == 0 && cs_conv_gemm_plan(&q, &sk, &wsb) == CS_OK && sk > 1) {
       skws = alloc(wsb / 4, 1);          // the dry run sizes the workspace with it too
       if (!ok()) return out;
       q.splitk = sk;
@@ -1017,13 +1054,42 @@ struct ExecBase {
     if (wsb > 0) release(ws);
   }
 
+  // r5: does the GroupNorm feeding the 3x3x3 conv `gi` over an [nb, d, h, w] volume emit the Winograd-W operand?
+  // (cs_conv_wino_ok: the one rule; ops.py::wants_wino)
+  bool wants_wino(int gi, int nb, int d, int h, int w) const {
+    if (gi < 0 || d <= 0 || pl.math != CS_MATH_F16X3 || cs_debug()->no_split16) return false;
+    const Gemm& g = pl.gemms[gi];
+    if (g.wino_off < 0) return false;
+    CsConvGemm q;
+    memset(&q, 0, sizeof(q));
+    q.nb = nb; q.din = q.dout = d; q.hin = q.hout = h; q.win = q.wout = w;
+    q.cin = g.cin_pad; q.cout = g.cout; q.lda = g.cin_pad; q.ldo = g.cout; q.ldw = g.ldw;
+    q.kd = q.kh = q.kw = 3;
+    q.sd = q.sh = q.sw = q.pd = q.ph = q.pw = 1;
+    q.math = pl.math; q.rv_rows = 1;
+    return cs_conv_wino_ok(&q) != 0;
+  }
+  // GroupNorm + activation emitted as the Winograd-W operand (y: 2 * x.rows "rows", see Buf::wino) at HALF the
+  // normalisation's operand scale (ops.py::groupnorm wino=True)
+  void emit_wino(const Buf& x, const Norm& n, const Buf& stats, Buf& y, int nb, int d, int h, int w, int groups, int act) {
+    y.wino = true;
+    y.a_scale *= 0.5f;
+    if (ok() && !dry) {
+      char* vh = reinterpret_cast<char*>(p(y));
+      chk(cs_groupnorm_apply_wino16(p(x), p(stats), wf(n.g_off), wf(n.b_off), vh, vh + x.rows * x.c * 4, nb, d, h, w, x.c, x.c,
+                                    x.c, groups, act, y.a_scale, status, st));
+    }
+  }
+
   // conv_gi: the 3x3x3 conv that consumes the result (decides the output format), or -1
   // bound_off (out, optional): wanted when a consumer will read x RAW (the ResBlock's skip conv): the slot x's magnitude
   // bound went to, -1 if none (ops.py::groupnorm bound=)
+  // vd, vh, vw (r5): the volume's extents where the consumer may take the Winograd-W route (the UNet's ResBlocks)
   Buf groupnorm(const Buf& x, int ni, int nb, float eps, int act, int groups = 32, int conv_gi = -1,
-                int64_t* bound_off = nullptr) {
+                int64_t* bound_off = nullptr, int vd = 0, int vh = 0, int vw = 0) {
     const Norm& n = pl.norms[ni];
-    Buf y = alloc(x.rows, x.c);
+    const bool wn = wants_wino(conv_gi, nb, vd, vh, vw);
+    Buf y = alloc(wn ? 2 * x.rows : x.rows, x.c);
     if (bound_off) *bound_off = -1;
     if (has_parts(x)) {      // r4: statistics from the producers' partials, the tensor is read once (ops.py::groupnorm)
       const int64_t boff = bound_off ? amax_slot() : -1;
@@ -1031,7 +1097,10 @@ struct ExecBase {
       Buf stats = alloc((int64_t)nb * groups * 2, 1);
       if (pl.math == CS_MATH_F16X3) y.a_scale = norm_a_scale(n.gmax, n.bmax, (x.rows / nb) * (int64_t)(x.c / groups));
       const int rows = (int)(x.rows / nb);
-      if (wants_split16(x.rows, conv_gi)) {
+      if (wn) {
+        finalize_parts(x, nb, eps, groups, stats, boff);
+        emit_wino(x, n, stats, y, nb, vd, vh, vw, groups, act);
+      } else if (wants_split16(x.rows, conv_gi)) {
         y.half = true;
         finalize_parts(x, nb, eps, groups, stats, boff);
         if (ok() && !dry) {
@@ -1054,6 +1123,13 @@ struct ExecBase {
     const int64_t boff = bound_off ? amax_slot() : -1;
     if (bound_off) *bound_off = boff;
     if (pl.math == CS_MATH_F16X3) y.a_scale = norm_a_scale(n.gmax, n.bmax, (x.rows / nb) * (int64_t)(x.c / groups));
+    if (wn) {
+      stats_pass(x, nb, eps, groups, wsb, stats, boff);
+      emit_wino(x, n, stats, y, nb, vd, vh, vw, groups, act);
+      release(wsb);
+      release(stats);
+      return y;
+    }
     if (wants_split16(x.rows, conv_gi)) {
       y.half = true;
       stats_pass(x, nb, eps, groups, wsb, stats, boff);

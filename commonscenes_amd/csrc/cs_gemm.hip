@@ -380,7 +380,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const CsConvGemm p, 
 // squares) of its rows per column for the GroupNorm that follows (statistics tile = SKR rows; at small batches nearly
 // every GroupNorm input comes out of this kernel) and (b) write the interleaved operand pair, lanes 2t / 2t + 1 swapping a
 // half as in the GEMM's own epilogue.  Same sums, same order per element as splitk_reduce_kernel.
+// WINO (r5, CsConvGemm.a_format = 3): ws holds the four Winograd-W position results [slice][4][M / 2][cout]; output row m =
+// pair m >> 1, parity m & 1 (W is even): even rows m0 + m1 + m2, odd rows m1 - m2 - m3, each position summed over its K
+// slices in slice order first.  The rest of the kernel -- epilogue terms, partial sums, pair output -- is shared.
 constexpr int SKR = 16;
+template <bool WINO>
 __global__ __launch_bounds__(256) void splitk_reduce_epi_kernel(const CsConvGemm p, const float* __restrict__ ws, int M,
                                                                 int splits) {
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -401,8 +405,27 @@ __global__ __launch_bounds__(256) void splitk_reduce_epi_kernel(const CsConvGemm
     const bool ok = nok && m < M;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (ok) {
-      v = *reinterpret_cast<const f32x4*>(ws + (int64_t)m * p.cout + n);
-      for (int sl = 1; sl < splits; ++sl) v += *reinterpret_cast<const f32x4*>(ws + ((int64_t)sl * M + m) * p.cout + n);
+      if constexpr (WINO) {
+        const int64_t half = (int64_t)(M >> 1) * p.cout, sstride = 4 * half;
+        const float* b = ws + (int64_t)(m >> 1) * p.cout + n;
+        auto pos = [&](int q) {
+          f32x4 t = *reinterpret_cast<const f32x4*>(b + q * half);
+          for (int sl = 1; sl < splits; ++sl) t += *reinterpret_cast<const f32x4*>(b + q * half + sl * sstride);
+          return t;
+        };
+        if (m & 1) {
+          v = pos(1);
+          v -= pos(2);
+          v -= pos(3);
+        } else {
+          v = pos(0);
+          v += pos(1);
+          v += pos(2);
+        }
+      } else {
+        v = *reinterpret_cast<const f32x4*>(ws + (int64_t)m * p.cout + n);
+        for (int sl = 1; sl < splits; ++sl) v += *reinterpret_cast<const f32x4*>(ws + ((int64_t)sl * M + m) * p.cout + n);
+      }
       if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
       if (p.scale) v = v * *reinterpret_cast<const f32x4*>(p.scale + n) + *reinterpret_cast<const f32x4*>(p.shift + n);
       if (p.rowvec) v += *reinterpret_cast<const f32x4*>(p.rowvec + (int64_t)(m / p.rv_rows) * p.ldrv + n);
@@ -540,7 +563,7 @@ extern "C" int cs_conv_gemm_epilogue_caps(const CsConvGemm* d, int32_t* gn_rows,
     if (gn_rows && rps % bm == 0 && p.act != CS_ACT_GEGLU) *gn_rows = bm;
     return CS_OK;                                            // (no pair output from the scattered store)
   }
-  if (p.splitk > 1) {
+  if (p.splitk > 1 || p.a_format == 3) {        // (a_format = 3: the Winograd-W output transform runs in the reduce kernel)
     if (gn_rows && rps % SKR == 0 && p.act != CS_ACT_GEGLU) *gn_rows = SKR;
     if (pair_ok && pair_geom && p.act != CS_ACT_GEGLU) *pair_ok = 1;
     return CS_OK;
@@ -704,6 +727,105 @@ static int fused_reduce_plan(const CsConvGemm& p, int M, int stile) {
 
 // omap_f / omap_p != 0 (cs_conv_gemm_up2 only): this GEMM is one output parity class of a folded Upsample conv and
 // stores straight into the doubled grid (cs_gemm_f16x3.hip, slab4 kernel); d->out / d->ldo are then the final tensor's
+// ---------------------------------------------------------------------------------------------------------------------
+// r5: Winograd F(2,3) along W for the 3x3x3 stride-1 convs (CsConvGemm.a_format = 3; every ResBlock conv,
+// openai_model_3d.py:294-314).  Four position GEMMs with a 3x3x1 kernel over (D, H, W/2) -- 18 instead of 27 multiply-adds
+// per output -- on the slab kernel's three-taps-per-kd instantiation (cs_gemm_f16x3.hip, TPK = 3), all four in ONE launch
+// (operands stacked along the batch, four consecutive packed weight images), then the output transform in the split-K
+// reduce + epilogue kernel's place.  Prototype on the per-tap gather path, separate launches: -21...-23 % GEMM time at the
+// 16^3 / 16x8x8 levels, rel-L2 vs fp64 2.5e-7...3.3e-7 (direct form 2.6e-7...5.2e-7), profiles/r05_q_wino_proto.txt.
+// ---------------------------------------------------------------------------------------------------------------------
+static bool wino_ok(const CsConvGemm& p) {
+  const CsDebug* dbg = cs_debug();
+  if (dbg->no_wino || p.math != CS_MATH_F16X3 || p.act == CS_ACT_GEGLU) return false;
+  if (!(p.kd == 3 && p.kh == 3 && p.kw == 3 && p.sd == 1 && p.sh == 1 && p.sw == 1 && p.pd == 1 && p.ph == 1 && p.pw == 1) ||
+      (p.ud | p.uh | p.uw) || p.din != p.dout || p.hin != p.hout || p.win != p.wout)
+    return false;
+  if ((p.win & 1) || p.win < 4 || p.win / 2 > 32 || p.cout % 224 || (p.cin & 7) || p.cin < 16) return false;
+  const int64_t M = (int64_t)p.nb * p.dout * p.hout * p.wout;
+  const int64_t min_rows = dbg->wino_min_rows > 0 ? dbg->wino_min_rows : 1024;
+  if (M < min_rows || M > 0x3fffffffLL || (M / 2) % 256) return false;
+  // (32-bit offsets of the position GEMMs' slab windows and of the reduce kernel's workspace reads)
+  if ((512 + 2LL * p.hin * (p.win / 2) + p.win + 32) * p.lda * 4 >= 0x7FF00000LL) return false;
+  return true;
+}
+
+// K slices of the position GEMMs: their launch is 4 x (M / 512) x (cout / 224) workgroups of the 256x224 tile, one per CU.
+// A small cost model in microseconds picks the slice count (whole super-chunks, padding <= 10 %, >= 2 super-chunks per
+// slice): rounds of the chip x (a slice's K loop at ~0.95 us per 16-wide chunk + ~10 us of prologue / tile store) + the
+// partial results each extra slice writes and the output transform reads back (~0.46 us per MB).  384 tiles at the 16x4x4
+// level of 32 objects -> two slices (three even rounds, as the direct form's four-way cut); 448 tiles (the 16^3 level at
+// 14 objects) -> one (the efficiency-only rule of the first version took four slices there and LOST 30 % to the direct
+// form, profiles/r05_r_wino_bench_small.txt).
+static int wino_splits(const CsConvGemm& p) {
+  const int64_t M = (int64_t)p.nb * p.dout * p.hout * p.wout;
+  const int64_t tiles = 4 * (M / 512) * (p.cout / 224);
+  const int64_t cus = device_cus() > 0 ? device_cus() : 256;
+  const int64_t nsc = 3LL * ((p.cin + 15) / 16);
+  const double mb = 2.0 * (double)M * p.cout * 4.0 / 1e6;            // one slice's position results
+  int best = 1;
+  double best_t = 0;
+  for (int sp = 1; sp <= 16; ++sp) {
+    const int64_t per = (nsc + sp - 1) / sp;
+    if (sp > 1 && (per < 2 || per * sp * 10 > nsc * 11 || (nsc + per - 1) / per != sp)) continue;
+    const int64_t rounds = (tiles * sp + cus - 1) / cus;
+    double seam = (sp - 1) * mb * 0.46;
+    if (sp > 1 && seam < 2.0 * (sp - 1)) seam = 2.0 * (sp - 1);
+    const double t = (double)rounds * ((double)per * 3.0 * 0.95 + 10.0) + seam;
+    if (sp == 1 || t < best_t * 0.97) {
+      best = sp;
+      best_t = t;
+    }
+  }
+  return best;
+}
+
+extern "C" int cs_conv_wino_ok(const CsConvGemm* d) { return (d && d->nb > 0 && d->cout > 0 && wino_ok(*d)) ? 1 : 0; }
+
+extern "C" int cs_conv_wino_plan(const CsConvGemm* d, int32_t* splitk, int64_t* ws_bytes) {
+  if (!d || !splitk || !wino_ok(*d)) return CS_EINVAL;
+  const int sp = wino_splits(*d);
+  *splitk = sp;
+  const int64_t M = (int64_t)d->nb * d->dout * d->hout * d->wout;
+  if (ws_bytes) *ws_bytes = (int64_t)sp * 2 * M * d->cout * 4;
+  return CS_OK;
+}
+
+// desc validated by conv_gemm_impl (incl. gn_part / out_format against cs_conv_gemm_epilogue_caps)
+static int conv_wino(const CsConvGemm& p, int M, hipStream_t s) {
+  auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+  if (!wino_ok(p) || !p.x_lo || !al16(p.x_lo) || !p.w_lo || !al16(p.w_lo) || (p.lda & 7) || !p.splitk_ws || !al16(p.splitk_ws) ||
+      p.a_bound || !(p.acc_scale > 0.f))
+    return CS_EINVAL;
+  if ((p.ldo & 3) || !al16(p.out) || (p.bias && !al16(p.bias)) || (p.scale && (!al16(p.scale) || !al16(p.shift))) ||
+      (p.rowvec && ((p.ldrv & 3) || !al16(p.rowvec))) || (p.res && ((p.ldr & 3) || !al16(p.res))))
+    return CS_EINVAL;
+  const int sp = p.splitk > 1 ? p.splitk : 1;
+  if (sp > 16) return CS_EINVAL;
+  CsConvGemm q = p;
+  q.nb = 4 * p.nb;
+  q.win = q.wout = p.win / 2;
+  q.kw = 1;
+  q.pw = 0;
+  q.a_format = 1;
+  q.out = reinterpret_cast<float*>(p.splitk_ws);
+  q.ldo = p.cout;
+  q.bias = q.scale = q.shift = q.rowvec = q.res = nullptr;
+  q.act = CS_ACT_NONE;
+  q.gn_part = nullptr;
+  q.out_format = 0;
+  q.splitk = 0;
+  q.tile = 4;
+  const int rc = cs_conv_gemm_f16x3_dispatch(q, 2 * M, 4, sp, s, 16, 4, nullptr, nullptr, nullptr, 0, nullptr);
+  if (rc != CS_OK) return rc;
+  const int64_t nblk = (int64_t)((M + SKR - 1) / SKR) * ((p.cout + 63) / 64);
+  if (nblk > 0x7fffffffLL) return CS_EINVAL;
+  CS_LAUNCH(splitk_reduce_epi_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, s, p,
+            reinterpret_cast<const float*>(p.splitk_ws), M, sp);
+  CS_CHECK_LAUNCH();
+  return CS_OK;
+}
+
 static int conv_gemm_impl(const CsConvGemm* d, cs_stream_t stream, int omap_f, int omap_p,
                           const void* const* cls_w = nullptr, const void* const* cls_w_lo = nullptr,
                           const float* cls_acc = nullptr, int ncls = 0) {
@@ -743,6 +865,7 @@ static int conv_gemm_impl(const CsConvGemm* d, cs_stream_t stream, int omap_f, i
     if (p.gn_part && (rows == 0 || rows != p.gn_rows || p.gn_ld < p.cout || ((uintptr_t)p.gn_part & 15))) return CS_EINVAL;
     if (p.out_format == 2 && (!pair || !(p.out_scale > 0.f))) return CS_EINVAL;
   }
+  if (p.a_format == 3) return (f16x3 && !omap_f) ? conv_wino(p, M, s) : CS_EINVAL;
   if (p.splitk > 1) {
     // caller-requested split-K (cs_conv_gemm_plan): partial tiles to the workspace, then reduce + epilogue
     auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
@@ -786,7 +909,7 @@ static int conv_gemm_impl(const CsConvGemm* d, cs_stream_t stream, int omap_f, i
     if (p.gn_part || p.out_format) {
       const int64_t nblk = (int64_t)((M + SKR - 1) / SKR) * ((p.cout + 63) / 64);
       if (nblk > 0x7fffffffLL) return CS_EINVAL;
-      CS_LAUNCH(splitk_reduce_epi_kernel, dim3((unsigned)nblk), dim3(256), 0, s, p,
+      CS_LAUNCH(splitk_reduce_epi_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, s, p,
                 reinterpret_cast<const float*>(p.splitk_ws), M, p.splitk);
     } else {
       CS_LAUNCH(splitk_reduce_kernel, dim3(cs_grid_for((int64_t)M * (p.cout >> 2), 256)), dim3(256), 0, s, p,
@@ -827,6 +950,11 @@ extern "C" int cs_conv_gemm_launch_info(const CsConvGemm* d, int32_t* tile_out, 
   const int M = (int)M64;
   const bool f16x3 = p.math == CS_MATH_F16X3;
   int tile = p.tile;
+  if (p.a_format == 3) {                      // the Winograd-W position GEMMs: 256x224 tile, three-tap slab
+    if (tile_out) *tile_out = 4;
+    if (slab_out) *slab_out = 32;
+    return CS_OK;
+  }
   if (p.splitk > 1) {
     tile = sliced_tile(p, M);
   } else {
@@ -1215,4 +1343,47 @@ extern "C" int cs_relayout_weight(const float* w_torch, float* w_out, int cout, 
   return CS_OK;
 }
 
-extern "C" int cs_abi_version(void) { return 15; }
+// r5: the Winograd-W weights of a 3x3x3 conv -- four packed images (position q-major), each in cs_pack_weight_f16x3's layout
+// with the nine (kd, kh) taps: u_q over the kw taps [g0, (g0 + g1 + g2) / 2, (g0 - g1 + g2) / 2, g2], formed and split in fp64
+namespace {
+__global__ __launch_bounds__(256) void pack_f16x3_wino_kernel(const float* __restrict__ w, _Float16* __restrict__ wh,
+                                                              _Float16* __restrict__ wl, int cout, int cin, int kg_per_tap,
+                                                              float scale) {
+  const int64_t per = 9LL * kg_per_tap * cout * 8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < 4 * per; i += (int64_t)gridDim.x * blockDim.x) {
+    const int q = (int)(i / per);
+    int64_t t = i - q * per;
+    const int j = (int)(t & 7);
+    t >>= 3;
+    const int n = (int)(t % cout);
+    t /= cout;
+    const int kg = (int)(t % kg_per_tap);
+    const int tap = (int)(t / kg_per_tap);              // kd * 3 + kh
+    const int c = kg * 8 + j;
+    double u = 0.0;
+    if (c < cin) {
+      const float* g = w + ((int64_t)n * cin + c) * 27 + tap * 3;
+      const double g0 = g[0], g1 = g[1], g2 = g[2];
+      u = q == 0 ? g0 : q == 1 ? 0.5 * (g0 + g1 + g2) : q == 2 ? 0.5 * (g0 - g1 + g2) : g2;
+    }
+    const double v = u * (double)scale;
+    const _Float16 h = (_Float16)v;
+    wh[i] = h;
+    wl[i] = (_Float16)(v - (double)h);
+  }
+}
+}  // namespace
+
+extern "C" int cs_pack_weight_f16x3_wino(const float* w_torch, void* w_hi, void* w_lo, int cout, int cin, float scale,
+                                         cs_stream_t stream) {
+  if (!w_torch || !w_hi || !w_lo || cout <= 0 || cin <= 0 || !(scale > 0.f)) return CS_EINVAL;
+  if (((uintptr_t)w_hi & 15) || ((uintptr_t)w_lo & 15)) return CS_EINVAL;
+  const int kg_per_tap = ((cin + 15) / 16) * 2;
+  const int64_t total = 4LL * 9 * kg_per_tap * cout * 8;
+  CS_LAUNCH(pack_f16x3_wino_kernel, dim3(cs_grid_for(total, 256, 256 * 32)), dim3(256), 0, (hipStream_t)stream, w_torch,
+            (_Float16*)w_hi, (_Float16*)w_lo, cout, cin, kg_per_tap, scale);
+  CS_CHECK_LAUNCH();
+  return CS_OK;
+}
+
+extern "C" int cs_abi_version(void) { return 16; }

@@ -235,12 +235,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   // ---- LDS map (bytes) ----
   static_assert(!SLAB || (WMB <= 2 && WAVES_N == 1), "slab path: one or two row blocks per wave");
   static_assert(!PAIR || (!PRE && SLAB == 0), "interleaved operand pairs: per-tap gather path only");
-  static_assert(TPK == 9 || (TPK == 4 && SLAB != 0), "taps per kd: 3x3 or (slab path only) 2x2");
+  static_assert(TPK == 9 || ((TPK == 4 || TPK == 3) && SLAB != 0), "taps per kd: 3x3 or (slab path only) 2x2 / 3x1");
   static_assert(!PW || SLAB == 0, "pointwise GEMMs take the gather path (there is one tap)");
-  constexpr int KW_ = TPK == 9 ? 3 : 2;            // (kh, kw) extent of a slab super-chunk
+  constexpr int KW_ = TPK == 9 ? 3 : TPK == 4 ? 2 : 1;   // kw extent of a slab super-chunk ...
+  constexpr int KH_ = TPK / KW_;                         // ... and its kh extent (3x3, 2x2, or 3x1: the Winograd-W position GEMMs)
   // wave-instructions per slab (SLAB = widest line W): fp32 rows of 64 B, 16 per instruction; PRE: a hi and a lo image
   // of 32 B rows, 32 per instruction each
-  constexpr int SLAB_ROWS = BM + (KW_ - 1) * (SLAB + 1);      // 3x3 taps: BM + 2W + 2 rows; 2x2 taps: BM + W + 1
+  constexpr int SLAB_ROWS = BM + (KH_ - 1) * SLAB + (KW_ - 1);   // 3x3 taps: BM + 2W + 2 rows; 2x2: BM + W + 1; 3x1: BM + 2W
   constexpr int SLAB_IMG_WI = (SLAB_ROWS + 31) / 32;
   constexpr int SLAB_WI = PRE ? 2 * SLAB_IMG_WI : (SLAB_ROWS + 15) / 16;
   constexpr int SLAB_IMG = SLAB_IMG_WI * 1024;     // PRE: byte offset of the lo image inside a slab
@@ -350,6 +351,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   }
   const int m0 = tm * BM;
   const int n0 = tn * BN;
+  // TPK == 3 (r5): the four Winograd-W position GEMMs of one 3x3x3 conv in ONE launch -- their transformed operands are
+  // stacked along the batch ([4][nb][D][H][W/2][C]: rows of class q = [q * M / 4, (q + 1) * M / 4), whole row tiles), their
+  // transformed weights are four consecutive packed images; everything else (pads 1 / 1 / 0, plain stores) is class-blind.
+  if constexpr (TPK == 3) {
+    if (omap_p_in > 1) {
+      const int tiles_m = (M + BM - 1) / BM;
+      const int q = tm / (tiles_m / omap_p_in);
+      w_hi_ = reinterpret_cast<const char*>(p.w) + (size_t)q * w_bytes;
+      w_lo_ = reinterpret_cast<const char*>(p.w_lo) + (size_t)q * w_bytes;
+    }
+  }
 
   const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc((void*)w_hi_, 0, w_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc((void*)w_lo_, 0, w_bytes, 0x00020000);
@@ -605,7 +617,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
                                                           // them, surplus ones as zero-fills: the counts below are exact)
   const int s_w = p.win, s_hw = p.hin * p.win;
   const int s_rows = p.nb * p.din * s_hw;                  // source rows in the tensor
-  const int s_need = BM + (KW_ - 1) * (s_w + 1);           // slab rows this problem uses
+  const int s_need = BM + (KH_ - 1) * s_w + (KW_ - 1);     // slab rows this problem uses
   // (per row block i of the wave -- one for the 256-row tiles, two for the 512-row ones)
   unsigned vmask[WMB];                                     // bit tap: that tap of this lane's output voxel is inside the volume
   int sl_row[SLAB_PW];
@@ -634,7 +646,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
         const int od = mm % p.din;
 #pragma unroll
         for (int t = 0; t < 3 * TPK; ++t) {               // (kd >= p.kd: never used)
-          const int kd_ = t / TPK, kh_ = (t / KW_) % KW_, kwi = t % KW_;
+          const int kd_ = t / TPK, kh_ = (t % TPK) / KW_, kwi = t % KW_;
           if ((unsigned)(od + kd_ - pad_d) < (unsigned)p.din && (unsigned)(oh + kh_ - pad_h) < (unsigned)p.hin &&
               (unsigned)(ow + kwi - pad_w) < (unsigned)p.win)
             vmask[i] |= 1u << t;
@@ -812,7 +824,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
     }
   };
   if constexpr (SLAB != 0) {
-    static_assert((TPK == 9 && NSTAGE == 3) || (TPK == 4 && NSTAGE == 4), "a chunk's ring stage is its tap index mod NSTAGE");
+    static_assert(((TPK == 9 || TPK == 3) && NSTAGE == 3) || (TPK == 4 && NSTAGE == 4), "a chunk's ring stage is its tap index mod NSTAGE");
     const int sc_first = k_first / TPK, sc_end = sc_first + nk / TPK;
     int kdc = sc_first % KD;                                // kd of the super-chunk
     constexpr unsigned TMASK = (1u << TPK) - 1u;
@@ -834,6 +846,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
         sstep(std::integral_constant<int, 0>{}, std::integral_constant<int, 6>{}, sc, m9, m9n);
         sstep(std::integral_constant<int, 1>{}, std::integral_constant<int, 7>{}, sc, m9, m9n);
         sstep(std::integral_constant<int, 2>{}, std::integral_constant<int, 8>{}, sc, m9, m9n);
+      } else if constexpr (TPK == 3) {
+        sstep(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, sc, m9, m9n);
+        sstep(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, sc, m9, m9n);
+        sstep(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, sc, m9, m9n);
       } else {
         sstep(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, sc, m9, m9n);
         sstep(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, sc, m9, m9n);
@@ -1331,7 +1347,7 @@ int launch16(const CsConvGemm& p, int M, int splits, hipStream_t stream, int oma
   }
   CS_LAUNCH((conv_gemm_f16x3_kernel<WMB, WNB, WAVES_M, WAVES_N, PRE, SLAB, PAIR, TPK, PW>), dim3((unsigned)nblk), dim3(64 * WAVES_M * WAVES_N), 0,
             stream, p, M, tiles_n, p.kh * p.kw, p.kw, kg_per_tap, (long long)x_bytes, (unsigned)w_bytes, vec, splits,
-            TPK == 4 ? omap_f : 0, TPK == 4 ? omap_p : 0, cb, fz);
+            TPK == 4 ? omap_f : 0, TPK != 9 ? omap_p : 0, cb, fz);
   CS_CHECK_LAUNCH();
   return CS_OK;
 }
@@ -1376,6 +1392,14 @@ bool cs_f16x3_slab4_ok(const CsConvGemm& p, int tile, int splits) {
 #endif
 }
 
+// r5: is this the geometry of a Winograd-W position GEMM -- a 3x3x1 kernel over (D, H, W/2), stride 1, pads 1 / 1 / 0, same
+// size out as in (cs_conv_gemm, a_format = 3, builds such a descriptor over the four stacked transformed operands)?
+bool cs_f16x3_wino_geom(const CsConvGemm& p) {
+  return p.kd == 3 && p.kh == 3 && p.kw == 1 && p.sd == 1 && p.sh == 1 && p.sw == 1 && p.pd == 1 && p.ph == 1 && p.pw == 0 &&
+         p.ud == 0 && p.uh == 0 && p.uw == 0 && p.din == p.dout && p.hin == p.hout && p.win == p.wout && p.win <= 32 &&
+         (512 + 2LL * p.hin * p.win + 2 * p.win + 32) * p.lda * 4 < 0x7FF00000LL;
+}
+
 // Line width of the A slab (32 / 64) the dispatch below stages for this descriptor on `tile` with `splits` K slices, 0 = the
 // per-tap gather.  ONE rule: the dispatch asks it, and so does cs_conv_gemm_launch_info (what the hosts' per-kernel
 // accounting reads instead of mirroring this file).
@@ -1386,6 +1410,13 @@ int cs_f16x3_slab_width(const CsConvGemm& p, int tile, int splits) {
   if (splits < 1) splits = 1;
   if (p.a_format == 2) return 0;                                   // interleaved pairs: gather path only
   if (p.a_format == 0 && cs_f16x3_slab4_ok(p, tile, splits)) return 32;      // folded Upsample classes: four taps per kd
+#ifndef CS_NO_SLAB
+  if (cs_f16x3_wino_geom(p)) {                                               // Winograd-W position GEMMs: three taps per kd
+    const int64_t nsc = 3LL * ((p.cin + 15) / 16);
+    const bool ok = splits == 1 || ((nsc + splits - 1) / splits) * splits * 10 <= nsc * 11;
+    return (p.a_format == 1 && tile == 4 && ok) ? 32 : 0;
+  }
+#endif
   const bool geom0 = p.kd == 3 && p.kh == 3 && p.kw == 3 && p.sd == 1 && p.sh == 1 && p.sw == 1 && p.pd == 1 && p.ph == 1 &&
                      p.pw == 1 && p.ud == 0 && p.uh == 0 && p.uw == 0 && p.din == p.dout && p.hin == p.hout &&
                      p.win == p.wout && p.win <= 64 && (512 + 2LL * p.hin * p.win + 2 * p.win + 32) * p.lda * 4 < 0x7FF00000LL;
@@ -1423,7 +1454,8 @@ int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p_in, int M, int tile, int spl
   if (cls_sliced && (splits < 2 || ncls < 2 || p.a_format != 0 || (tile != 4 && tile != 6) || !cs_f16x3_slab4_ok(p, tile, -1) ||
                      p.bias || p.res || p.rowvec || p.scale || p.act != CS_ACT_NONE || p.gn_part || p.out_format))
     return CS_EINVAL;
-  if (omap_f && !cls_sliced && !cs_f16x3_slab4_ok(p, tile, splits)) return CS_EINVAL;
+  // (omap_f bit 4, r5: the launch covers omap_p Winograd-W position classes stacked along the batch -- no scatter)
+  if ((omap_f & 15) && !cls_sliced && !cs_f16x3_slab4_ok(p, tile, splits)) return CS_EINVAL;
   CsClsBatch cb;
   memset(&cb, 0, sizeof(cb));
   if (ncls > 1) {
@@ -1456,6 +1488,11 @@ int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p_in, int M, int tile, int spl
   if (p.a_format == 1) {
     if (!p.x_lo || ((uintptr_t)p.x_lo & 15) || (p.cin & 7) || (p.lda & 7)) return CS_EINVAL;
 #ifndef CS_NO_SLAB
+    if (cs_f16x3_wino_geom(p) && tile == 4 && cs_f16x3_slab_width(p, tile, splits) == 32) {
+      const int ncls = (omap_f & 16) ? omap_p : 0;
+      if (ncls > 1 && (((M + 255) / 256) % ncls || M % 256)) return CS_EINVAL;     // whole row tiles per class
+      return launch16<1, 7, 8, 1, true, 32, false, 3>(p, M, splits, s, 0, ncls);
+    }
     if (slab_geom && slab_slices_ok) {
       switch (tile) {
         case 2: return launch16<1, 7, 4, 1, true, 32>(p, M, splits, s, 0, 0, nullptr, fuse);    // r3: small batches (128-row tiles, K slices)

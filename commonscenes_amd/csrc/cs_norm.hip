@@ -368,6 +368,88 @@ __global__ __launch_bounds__(256) void gn_apply_split16_kernel(const float* __re
   if (status && amax >= 65504.f) atomicOr(status, CS_STATUS_F16X3_OVERFLOW);
 }
 
+// r5: GroupNorm + activation emitted in the WINOGRAD-W form of the 3x3x3 conv that follows (CsConvGemm.a_format = 3): per W
+// line of a sample and pair of voxels (w = 2 w2, 2 w2 + 1) the four transformed values [d0 - d2, d1 + d2, d2 - d1, d1 - d3] of
+// d_j = y[w - 1 + j] (0 outside the line), split into fp16 hi / lo of value * a_scale -- images [4][nb][lines][W/2][ldv].
+// A thread keeps its float4 column and walks whole lines: every activation is evaluated once (a pair's d2, d3 are the
+// next pair's d0, d1).
+__global__ __launch_bounds__(256) void gn_apply_wino16_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, _Float16* __restrict__ vh,
+                                                              _Float16* __restrict__ vl, int lines, int w, int c, int ldx,
+                                                              int ldv, int groups, int act, float a_scale,
+                                                              int lines_per_block, int64_t pos_stride,
+                                                              int32_t* __restrict__ status) {
+  const int ch4 = c >> 2;
+  const int tpr = ch4 < 256 ? ch4 : 256;   // threads per line
+  const int linelanes = 256 / tpr;
+  const int tid = threadIdx.x;
+  const int ll = tid / tpr;
+  const int cl = tid - ll * tpr;
+  if (ll >= linelanes) return;
+  const int n = blockIdx.y;
+  const int l0 = blockIdx.x * lines_per_block;
+  const int l1 = min(lines, l0 + lines_per_block);
+  const int w2n = w >> 1, cpg = c / groups;
+  const float* xb = x + (int64_t)n * lines * w * ldx;
+  const int64_t vrow0 = (int64_t)n * lines * w2n;
+  const float* st = stats + (int64_t)n * groups * 2;
+  float amax = 0.f;
+  for (int c4 = cl; c4 < ch4; c4 += tpr) {
+    const float4 g = *reinterpret_cast<const float4*>(gamma + c4 * 4);
+    const float4 b = *reinterpret_cast<const float4*>(beta + c4 * 4);
+    const float gg[4] = {g.x, g.y, g.z, g.w};
+    const float bb[4] = {b.x, b.y, b.z, b.w};
+    float mean[4], rstd[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int grp = (c4 * 4 + k) / cpg;
+      mean[k] = st[grp * 2];
+      rstd[k] = st[grp * 2 + 1];
+    }
+    auto actv = [&](const float4 v, float (&o)[4]) {
+      const float in[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = cs_act((in[k] - mean[k]) * rstd[k] * gg[k] + bb[k], act) * a_scale;
+    };
+    for (int line = l0 + ll; line < l1; line += linelanes) {
+      const float* xl = xb + (int64_t)line * w * ldx + c4 * 4;
+      float d0[4] = {0.f, 0.f, 0.f, 0.f}, d1[4], d2[4], d3[4];
+      actv(*reinterpret_cast<const float4*>(xl), d1);
+      for (int w2 = 0; w2 < w2n; ++w2) {
+        actv(*reinterpret_cast<const float4*>(xl + (int64_t)(2 * w2 + 1) * ldx), d2);
+        if (2 * w2 + 2 < w) {
+          actv(*reinterpret_cast<const float4*>(xl + (int64_t)(2 * w2 + 2) * ldx), d3);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) d3[k] = 0.f;
+        }
+        const int64_t off = (vrow0 + (int64_t)line * w2n + w2) * ldv + c4 * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          h4v hi, lo;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float o = q == 0 ? d0[k] - d2[k] : q == 1 ? d1[k] + d2[k] : q == 2 ? d2[k] - d1[k] : d1[k] - d3[k];
+            amax = fmaxf(amax, fabsf(o));
+            const _Float16 hh = (_Float16)o;
+            hi[k] = hh;
+            lo[k] = (_Float16)(o - (float)hh);
+          }
+          *reinterpret_cast<h4v*>(vh + q * pos_stride + off) = hi;
+          *reinterpret_cast<h4v*>(vl + q * pos_stride + off) = lo;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          d0[k] = d2[k];
+          d1[k] = d3[k];
+        }
+      }
+    }
+  }
+  if (status && amax >= 65504.f) atomicOr(status, CS_STATUS_F16X3_OVERFLOW);
+}
+
 // LayerNorm: one wave per row; each lane owns up to MAXV float4 chunks (c <= 64*4*MAXV).
 template <int MAXV>
 __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x,
@@ -835,6 +917,35 @@ extern "C" int cs_groupnorm_apply_split16_range(const float* x, const float* sta
   CS_LAUNCH(gn_apply_split16_kernel, dim3((unsigned)((rows + rpb - 1) / rpb), (unsigned)nb), dim3(256), 0,
             (hipStream_t)stream, x, stats, gamma, beta, (_Float16*)y_hi, (_Float16*)y_lo, rows, c, ldx, ldy, groups, act,
             a_scale, rpb, status, cpg, ch0);
+  CS_CHECK_LAUNCH();
+  return CS_OK;
+}
+
+extern "C" int cs_groupnorm_apply_wino16(const float* x, const float* stats, const float* gamma, const float* beta,
+                                         void* v_hi, void* v_lo, int nb, int d, int h, int w, int c, int ldx, int ldv,
+                                         int groups, int act, float a_scale, int32_t* status, cs_stream_t stream) {
+  if (!x || !stats || !gamma || !beta || !v_hi || !v_lo || nb <= 0 || d <= 0 || h <= 0 || w < 2 || c <= 0 || groups <= 0)
+    return CS_EINVAL;
+  if ((w & 1) || (c & 7) || c % groups || (ldx & 3) || (ldv & 7) || ldx < c || ldv < c || !(a_scale > 0.f) || nb > 65535)
+    return CS_EINVAL;
+  if (((uintptr_t)x & 15) || ((uintptr_t)v_hi & 15) || ((uintptr_t)v_lo & 15) || ((uintptr_t)gamma & 15) ||
+      ((uintptr_t)beta & 15))
+    return CS_EINVAL;
+  const int64_t lines64 = (int64_t)d * h;
+  if (lines64 * w > 0x7fffffffLL) return CS_EINVAL;
+  const int lines = (int)lines64;
+  const int ch4 = c >> 2;
+  const int linelanes = 256 / (ch4 < 256 ? ch4 : 256);
+  // ~2048 workgroups in all, at least one line per line-lane
+  int blocks_per_sample = (2048 + nb - 1) / nb;
+  const int max_blocks = (lines + linelanes - 1) / linelanes;
+  if (blocks_per_sample > max_blocks) blocks_per_sample = max_blocks;
+  if (blocks_per_sample < 1) blocks_per_sample = 1;
+  const int lpb = (lines + blocks_per_sample - 1) / blocks_per_sample;
+  const int64_t pos_stride = (int64_t)nb * lines * (w >> 1) * ldv;
+  CS_LAUNCH(gn_apply_wino16_kernel, dim3((unsigned)((lines + lpb - 1) / lpb), (unsigned)nb), dim3(256), 0,
+            (hipStream_t)stream, x, stats, gamma, beta, (_Float16*)v_hi, (_Float16*)v_lo, lines, w, c, ldx, ldv, groups, act,
+            a_scale, lpb, pos_stride, status);
   CS_CHECK_LAUNCH();
   return CS_OK;
 }

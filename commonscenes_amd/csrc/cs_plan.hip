@@ -59,6 +59,8 @@ void parse_env(CsDebug& d) {
   d.no_gn_fold = flag("CS_NO_GN_FOLD");
   d.no_kwave = flag("CS_NO_KWAVE");
   d.no_static_scales = flag("CS_NO_STATIC_SCALES");
+  d.no_wino = flag("CS_NO_WINO");
+  d.wino_min_rows = (int32_t)num("CS_WINO_MIN_ROWS", 1024);
 }
 
 }  // namespace

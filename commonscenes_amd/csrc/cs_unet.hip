@@ -319,12 +319,13 @@ struct Exec : ExecBase {
     const int rows = x.d * x.h * x.w;
     // (xb: the skip conv below reads x RAW -- the GroupNorm's finalize kernel leaves x's magnitude bound on the way)
     int64_t xb = -1;
-    Buf hn = groupnorm(x.b, l.n[0], x.nb, 1e-5f, CS_ACT_SILU, 32, l.g[0], l.g[2] >= 0 ? &xb : nullptr);
+    // (x.d, x.h, x.w: where the conv takes the Winograd-W route the GroupNorm emits that operand, unet.py::_res)
+    Buf hn = groupnorm(x.b, l.n[0], x.nb, 1e-5f, CS_ACT_SILU, 32, l.g[0], l.g[2] >= 0 ? &xb : nullptr, x.d, x.h, x.w);
     // (want_stats: the conv's epilogue leaves the partial sums the next GroupNorm takes its statistics from -- unet.py::_res)
     Buf h1 = gemm(hn, l.g[0], x.nb, x.d, x.h, x.w, 1, 0, CS_ACT_NONE, dry ? nullptr : p(semb) + l.emb_lo, semb.c, rows,
                   nullptr, 0, 0, 1, 0, /*want_stats=*/true);
     release(hn);
-    Buf hn2 = groupnorm(h1, l.n[1], x.nb, 1e-5f, CS_ACT_SILU, 32, l.g[1]);
+    Buf hn2 = groupnorm(h1, l.n[1], x.nb, 1e-5f, CS_ACT_SILU, 32, l.g[1], nullptr, x.d, x.h, x.w);
     release(h1);
     Buf skip;
     const bool own_skip = l.g[2] >= 0;
@@ -385,7 +386,7 @@ struct Exec : ExecBase {
     release(a_h);
     release(y_s);
     Buf skc = gemm(x.b, l.g[2], nb, x.d, x.h, x.w, 1, 0, CS_ACT_NONE, nullptr, 0, 1, nullptr, 0, 0, 1, 0, false, 0.f, xb);
-    Buf hn2 = groupnorm(h1, l.n[1], nb, 1e-5f, CS_ACT_SILU, 32, l.g[1]);
+    Buf hn2 = groupnorm(h1, l.n[1], nb, 1e-5f, CS_ACT_SILU, 32, l.g[1], nullptr, x.d, x.h, x.w);
     release(h1);
     o.b = gemm(hn2, l.g[1], nb, x.d, x.h, x.w, 1, 0, CS_ACT_NONE, nullptr, 0, 1, dry ? nullptr : p(skc), cout, 0, 1, 0,
                /*want_stats=*/true);

@@ -167,6 +167,9 @@ class PackedWeight:
     # thin-output 3x3x3 conv as "taps as columns" (pack_weight_tapcol): the pointwise pack with 27 * cout (+ pad)
     # columns; wt / wh / wl are then unused and `bias` is added by cs_tapsum27
     tapcol: Optional["PackedWeight"] = None
+    # r5: the Winograd-W pack of a 3x3x3 conv (pack_weight_wino): (hi, lo) images of the four transformed position weights
+    # [4][9 taps][cin16/8][cout][8] and their accumulator scale; None = the conv only runs in direct form
+    wino: Optional[Tuple[Tensor, Tensor, float]] = None
 
 
 def pack_weight(w: Tensor, bias: Optional[Tensor] = None, cin_pad: Optional[int] = None,
@@ -298,6 +301,27 @@ def _pack_weight_f16x3(w: Tensor, bias: Optional[Tensor], cin_pad: Optional[int]
         _chk(bias, "bias")
         b = bias.contiguous()
     return PackedWeight(None, b, cout, cin, cp, cout, (kd, kh, kw), L.MATH_F16X3, wh, wl, 1.0 / (scale * A_SCALE))
+
+
+def pack_weight_wino(pw: PackedWeight, w: Tensor) -> PackedWeight:
+    """Add the Winograd-W pack (CsConvGemm.a_format = 3, cs_pack_weight_f16x3_wino) to the F16X3 pack `pw` of the 3x3x3 conv
+    weight `w` -- where the geometry can ever take that route (cout % 224 == 0, cin % 8 == 0); the per-call decision is
+    cs_conv_wino_ok (wants_wino).  One power-of-two scale for the four positions: max |u_q| <= 1.5 max |w|."""
+    import math as _m
+    if (pw.math != L.MATH_F16X3 or pw.classes is not None or pw.tapcol is not None or w.dim() != 5
+            or tuple(w.shape[2:]) != (3, 3, 3) or pw.cout % 224 or pw.cin % 8 or pw.cin < 16):
+        return pw
+    w = w.contiguous()
+    amax = 1.5 * float(w.abs().max().item())
+    e = _m.frexp(amax)[1] if amax > 0 and _m.isfinite(amax) else 0
+    scale = 2.0 ** (14 - e)
+    kg = (pw.cin + 15) // 16 * 2
+    wh = torch.empty((4, 9, kg, pw.cout, 8), dtype=torch.float16, device=w.device)
+    wl = torch.empty_like(wh)
+    L.check(L.load().cs_pack_weight_f16x3_wino(w.data_ptr(), wh.data_ptr(), wl.data_ptr(), pw.cout, pw.cin, scale, _stream()),
+            "cs_pack_weight_f16x3_wino")
+    pw.wino = (wh, wl, 1.0 / (scale * A_SCALE))
+    return pw
 
 
 def tapcol_ok(w: Tensor, math: int) -> bool:
@@ -545,6 +569,10 @@ def conv_gemm(x: Tensor, w: PackedWeight, *, spatial: Optional[Tuple[int, int, i
                 or res is not None or scale is not None or tile or splitk):
             raise L.CsError("taps-as-columns weights: plain 3x3x3 conv only (no stride / up / act / residual / tile)")
         return _conv_tapcol(x, w, spatial, a_scale, out, out_fn)
+    if isinstance(x, Wino16):
+        if tuple(stride) != (1, 1, 1) or tuple(up) != (0, 0, 0) or tile or splitk or x_bound is not None:
+            raise L.CsError("a Wino16 activation feeds a plain 3x3x3 stride-1 conv (no stride / up / tile / splitk)")
+        return _conv_wino(x, w, act, rowvec, rv_rows, res, scale, shift, out, out_fn, stats, out_pair)
     xs = xp = None
     if isinstance(x, Pair16):
         if w.math != L.MATH_F16X3 or w.classes is not None:
@@ -693,6 +721,70 @@ def conv_gemm(x: Tensor, w: PackedWeight, *, spatial: Optional[Tuple[int, int, i
     return attach_stats(out, st)
 
 
+def _conv_wino(xw: "Wino16", w: PackedWeight, act, rowvec, rv_rows, res, scale, shift, out, out_fn, stats, out_pair):
+    """3x3x3 stride-1 conv on the Winograd-W operand (CsConvGemm.a_format = 3): the library runs the four position GEMMs in
+    one launch into a workspace and the output transform + epilogue in the split-K reduce kernel's place."""
+    if w.wino is None or w.math != L.MATH_F16X3:
+        raise L.CsError("a Wino16 activation needs a weight with the Winograd-W pack (pack_weight_wino)")
+    nb, d, h, wd = xw.spatial
+    mo = nb * d * h * wd
+    dev = xw.hi.device
+    oshape = (nb, d, h, wd, w.cout)
+    if out is None:
+        out = out_fn(oshape) if out_fn is not None else torch.empty(oshape, dtype=torch.float32, device=dev)
+        if tuple(out.shape) != tuple(oshape):
+            out = out.view(oshape)
+    _chk(out, "out")
+    om, oc, ldo = rows_ld(out, "out")
+    if om != mo or oc != w.cout:
+        raise L.CsError(f"out has shape {tuple(out.shape)}, expected {mo} rows x {w.cout}")
+    lib = L.load()
+    p = _wino_desc(nb, d, h, wd, w)
+    wh, wl, wacc = w.wino
+    p.x, p.x_lo, p.a_format = xw.hi.data_ptr(), xw.lo.data_ptr(), 3
+    p.lda = int(xw.hi.shape[-1])
+    p.w, p.w_lo, p.out, p.ldo = wh.data_ptr(), wl.data_ptr(), out.data_ptr(), ldo
+    p.a_scale = float(xw.a_scale)
+    p.acc_scale = wacc * (A_SCALE / float(xw.a_scale))
+    p.status = status_word(dev).data_ptr()
+    p.bias = _ptr(w.bias)
+    p.scale, p.shift = _ptr(scale), _ptr(shift)
+    p.rowvec = _ptr(rowvec)
+    p.res = _ptr(res)
+    p.act, p.rv_rows = act, rv_rows
+    if res is not None:
+        _chk(res, "res")
+        rm, rc, ldr = rows_ld(res, "res")
+        if rm != mo or rc != w.cout:
+            raise L.CsError("res shape mismatch")
+        p.ldr = ldr
+    if rowvec is not None:
+        _chk(rowvec, "rowvec")
+        vm, vc, ldrv = rows_ld(rowvec, "rowvec")
+        if vc != w.cout or vm * rv_rows < mo:
+            raise L.CsError("rowvec shape mismatch")
+        p.ldrv = ldrv
+    sk, wsb = C.c_int32(1), C.c_int64(0)
+    L.check(lib.cs_conv_wino_plan(C.byref(p), C.byref(sk), C.byref(wsb)), "cs_conv_wino_plan")
+    ws = torch.empty((wsb.value // 4,), dtype=torch.float32, device=dev)
+    p.splitk, p.splitk_ws = sk.value, ws.data_ptr()
+    st, paired = _epilogue_extras(lib, p, dev, nb, d * h * wd, mo, w.cout, stats, out_pair)
+    prof = GEMM_PROFILE
+    if prof is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+    L.check(lib.cs_conv_gemm(C.byref(p), _stream()), "cs_conv_gemm")
+    if prof is not None:
+        e1.record()
+        # (flops = the DIRECT form's algorithmic work, as for every other route; `wino` marks the 18/27 executed share)
+        prof.append(dict(e0=e0, e1=e1, flops=2.0 * mo * w.cout * w.cin * 27, taps=27, m=mo, n=w.cout, k=w.cin * 27, tile=4,
+                         slab=32, pre=True, pair=False, res=res is not None, wino=True))
+    if paired:
+        return Pair16(out, float(out_pair))
+    return attach_stats(out, st)
+
+
 def _conv_gemm_up2(lib, p, w: PackedWeight, x: Tensor, out: Tensor, mo: int) -> Tensor:
     """upsample + conv on the source grid: one GEMM per output parity class into a scratch tensor, then the interleave
     (cs_conv_gemm_up2); the library splits K per class where the plan says so."""
@@ -737,8 +829,36 @@ def wants_split16(m: int, w: "PackedWeight") -> bool:
                                                int(w.classes is None and w.tapcol is None), int(w.math)))
 
 
+def _wino_desc(nb: int, d: int, h: int, wd: int, w: "PackedWeight"):
+    p = L.CsConvGemm()
+    p.nb, p.din, p.hin, p.win, p.dout, p.hout, p.wout = nb, d, h, wd, d, h, wd
+    p.cin, p.cout, p.lda, p.ldo, p.ldw = w.cin_pad, w.cout, w.cin_pad, w.cout, w.ldw
+    p.kd = p.kh = p.kw = 3
+    p.sd = p.sh = p.sw = p.pd = p.ph = p.pw = 1
+    p.math, p.rv_rows = w.math, 1
+    return p
+
+
+def wants_wino(nb: int, d: int, h: int, wd: int, w: "PackedWeight") -> bool:
+    """Should the GroupNorm feeding the 3x3x3 conv `w` over an [nb, d, h, wd] volume emit the Winograd-W operand
+    (groupnorm(..., wino=(d, h, wd)))?  cs_conv_wino_ok: the ONE rule (csrc/cs_gemm.hip) both hosts ask."""
+    if w.wino is None or not _sw("SPLIT16_PRODUCERS"):
+        return False
+    return bool(L.load().cs_conv_wino_ok(C.byref(_wino_desc(int(nb), int(d), int(h), int(wd), w))))
+
+
 def linear(x: Tensor, w: PackedWeight, **kw) -> Tensor:
     return conv_gemm(x, w, **kw)
+
+
+@dataclass
+class Wino16:
+    """An activation volume in the Winograd-W operand form of the 3x3x3 conv that reads it (CsConvGemm.a_format = 3): fp16
+    hi / lo images [4, nb, d, h, w/2, c] of the four transformed values * a_scale (cs_groupnorm_apply_wino16)."""
+    hi: Tensor
+    lo: Tensor
+    a_scale: float
+    spatial: Tuple[int, int, int, int]          # (nb, d, h, w) of the ORIGINAL volume
 
 
 @dataclass
@@ -792,9 +912,11 @@ class Pair16:
 
 def groupnorm(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float, act: int = L.ACT_NONE,
               out: Optional[Tensor] = None, split16: bool = False, a_scale: Optional[float] = None,
-              bound: Optional[Tensor] = None):
+              bound: Optional[Tensor] = None, wino: bool = False):
     """GroupNorm over [nb, ..., c] (stats per sample & group), fused activation.
     split16=True returns a Split16 (fp16 hi/lo pair, pre-scaled) for an F16X3 GEMM to consume.
+    r5: wino=True (x: [nb, d, h, w, c], ask wants_wino first) returns a Wino16 -- the Winograd-W operand of the 3x3x3 conv
+    that follows, at HALF the given a_scale (the transformed values are sums / differences of two activations).
     r4: when x carries its producers' partial sums (stats_segments) the statistics come from them -- one tiny launch
     instead of a pass over the tensor -- and the tensor is read once, by the apply kernel.  bound: a zeroed 1-element slot;
     on that route the finalize kernel also leaves x's magnitude bound there and x remembers it (`x.cs_bound`, range_bound)."""
@@ -804,6 +926,30 @@ def groupnorm(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float, a
     rows = m // nb
     lib = L.load()
     segs = stats_segments(x)
+    wino = bool(wino) and _sw("SPLIT16_PRODUCERS")
+    if wino:
+        if x.dim() != 5 or int(x.shape[3]) % 2 or c % 8:
+            raise L.CsError("groupnorm(wino=True) needs x as [nb, d, h, w, c] with even w and c % 8 == 0")
+        split16 = True          # (same statistics routes as the pre-split pair; only the apply kernel differs)
+
+    def _emit(stats):
+        yshape = (4, nb, int(x.shape[1]), int(x.shape[2]), int(x.shape[3]) // 2, c) if wino else x.shape
+        yh = torch.empty(yshape, dtype=torch.float16, device=x.device)
+        yl = torch.empty(yshape, dtype=torch.float16, device=x.device)
+        if wino:
+            a_sc = float(a_scale or A_SCALE) * 0.5
+            L.check(lib.cs_groupnorm_apply_wino16(x.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                                  yh.data_ptr(), yl.data_ptr(), nb, int(x.shape[1]), int(x.shape[2]),
+                                                  int(x.shape[3]), c, ldx, c, groups, act, a_sc,
+                                                  status_word(x.device).data_ptr(), _stream()), "cs_groupnorm_apply_wino16")
+            return Wino16(yh, yl, a_sc, (nb, int(x.shape[1]), int(x.shape[2]), int(x.shape[3])))
+        a_sc = float(a_scale or A_SCALE)
+        L.check(lib.cs_groupnorm_apply_split16(x.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                               yh.data_ptr(), yl.data_ptr(), nb, rows, c, ldx, c, groups, act,
+                                               a_sc, status_word(x.device).data_ptr(), _stream()),
+                "cs_groupnorm_apply_split16")
+        return Split16(yh, yl, a_sc)
+
     if segs is not None and not (split16 and _sw("SPLIT16_PRODUCERS")):
         # one call: a single launch for small tensors, finalize + apply otherwise (cs_groupnorm_parts decides)
         if out is None:
@@ -827,14 +973,7 @@ def groupnorm(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float, a
         if bound is not None:
             x.cs_bound = bound
         if split16 and _sw("SPLIT16_PRODUCERS"):
-            yh = torch.empty(x.shape, dtype=torch.float16, device=x.device)
-            yl = torch.empty(x.shape, dtype=torch.float16, device=x.device)
-            a_sc = float(a_scale or A_SCALE)
-            L.check(lib.cs_groupnorm_apply_split16(x.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                                   yh.data_ptr(), yl.data_ptr(), nb, rows, c, ldx, c, groups, act,
-                                                   a_sc, status_word(x.device).data_ptr(), _stream()),
-                    "cs_groupnorm_apply_split16")
-            return Split16(yh, yl, a_sc)
+            return _emit(stats)
         if out is None:
             out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
         om, oc, ldy = rows_ld(out, "out")
@@ -857,14 +996,7 @@ def groupnorm(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float, a
                                            stats.data_ptr(), _stream()), "cs_groupnorm_stats")
     if split16 and _sw("SPLIT16_PRODUCERS"):
         _stats()
-        yh = torch.empty(x.shape, dtype=torch.float16, device=x.device)
-        yl = torch.empty(x.shape, dtype=torch.float16, device=x.device)
-        a_sc = float(a_scale or A_SCALE)
-        L.check(lib.cs_groupnorm_apply_split16(x.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                               yh.data_ptr(), yl.data_ptr(), nb, rows, c, ldx, c, groups, act,
-                                               a_sc, status_word(x.device).data_ptr(), _stream()),
-                "cs_groupnorm_apply_split16")
-        return Split16(yh, yl, a_sc)
+        return _emit(stats)
     if out is None:
         out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
     om, oc, ldy = rows_ld(out, "out")

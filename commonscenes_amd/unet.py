@@ -321,6 +321,11 @@ class DiffusionUNet:
                 elif k == "res":
                     pw(p + ".in_layers.2")
                     pw(p + ".out_layers.3")
+                    # r5: the Winograd-W pack beside the direct one (openai_model_3d.py:294-314 convs; dims = 3 family only:
+                    # the concat family's volumes are 16^3 -> 8^3 -> 4^3 with W / 2 down to 2 -- eligible too, the rule decides)
+                    for nm in (".in_layers.2", ".out_layers.3"):
+                        if self.math == L.MATH_F16X3:
+                            ops.pack_weight_wino(pk[p + nm], sd[p + nm + ".weight"])
                     if l["cin"] != l["cout"]:
                         pw(p + ".skip_connection")
                 elif k == "attn" and not self.cfg["use_spatial_transformer"]:
@@ -523,16 +528,20 @@ class DiffusionUNet:
         # GN output goes straight to a conv: emit its fp16 hi/lo operand form where that conv runs the slab kernel
         s1 = self._nas(p + ".in_layers.0", rows * (l["cin"] // 32))
         # (bound=: the skip conv below reads x RAW -- the GroupNorm's finalize kernel leaves x's magnitude bound on the way)
+        # r5: ... or its Winograd-W operand where the conv takes that route (cs_conv_wino_ok: large batches)
+        vol = (nb, int(x.shape[1]), int(x.shape[2]), int(x.shape[3]))
         hn = ops.groupnorm(x, sd[p + ".in_layers.0.weight"], sd[p + ".in_layers.0.bias"], 32, 1e-5, L.ACT_SILU,
                            split16=ops.wants_split16(nb * rows, pk[p + ".in_layers.2"]), a_scale=s1,
-                           bound=self._slot() if l["cin"] != l["cout"] else None)
+                           bound=self._slot() if l["cin"] != l["cout"] else None,
+                           wino=ops.wants_wino(*vol, pk[p + ".in_layers.2"]))
         lo, hi = self._emb_slices[p]
         embo = semb[:, lo:hi]                         # slice of the batched emb projection (row stride = total)
         # (stats=True: the conv's epilogue leaves the partial sums the next GroupNorm takes its statistics from, r4)
         h = ops.conv_gemm(hn, pk[p + ".in_layers.2"], rowvec=embo, rv_rows=rows, math=self.math, a_scale=s1, stats=True)
         s2 = self._nas(p + ".out_layers.0", rows * (l["cout"] // 32))
         hn2 = ops.groupnorm(h, sd[p + ".out_layers.0.weight"], sd[p + ".out_layers.0.bias"], 32, 1e-5, L.ACT_SILU,
-                            split16=ops.wants_split16(nb * rows, pk[p + ".out_layers.3"]), a_scale=s2)
+                            split16=ops.wants_split16(nb * rows, pk[p + ".out_layers.3"]), a_scale=s2,
+                            wino=ops.wants_wino(*vol, pk[p + ".out_layers.3"]))
         # (x_bound: the skip conv reads the RAW residual stream -- its operand scale follows the tensor's actual range)
         skip = x if l["cin"] == l["cout"] else ops.conv_gemm(x, pk[p + ".skip_connection"], math=self.math,
                                                              x_bound=getattr(x, "cs_bound", None))
@@ -574,7 +583,8 @@ class DiffusionUNet:
         sk = ops.conv_gemm(x, pk[p + ".skip_connection"], math=self.math, x_bound=getattr(x, "cs_bound", None))
         s2 = self._nas(p + ".out_layers.0", rows * (cout // 32))
         hn2 = ops.groupnorm(h1, sd[p + ".out_layers.0.weight"], sd[p + ".out_layers.0.bias"], 32, 1e-5, L.ACT_SILU,
-                            split16=ops.wants_split16(nb * rows, pk[p + ".out_layers.3"]), a_scale=s2)
+                            split16=ops.wants_split16(nb * rows, pk[p + ".out_layers.3"]), a_scale=s2,
+                            wino=ops.wants_wino(nb, d, h, w, pk[p + ".out_layers.3"]))
         return ops.conv_gemm(hn2, pk[p + ".out_layers.3"], res=sk, math=self.math, out_fn=out_fn, a_scale=s2,
                              stats=True)
 

@@ -93,6 +93,8 @@ typedef struct CsDebug {
   int32_t no_gn_fold;         /* GroupNorm (mean, rstd) always by the separate finalize launch, never in the apply kernel's prologue (r5) */
   int32_t no_kwave;           /* small 1-tap GEMMs stay on the 64x64 one-accumulator-chain tile (r5: K cut across the four waves) */
   int32_t no_static_scales;   /* operands born inside a transformer block keep the constant scale 16 + overflow flag (r5: static bounds) */
+  int32_t no_wino;            /* 3x3x3 convs always in direct form, never Winograd F(2,3) along W (r5, a_format = 3); different fp32 sums */
+  int32_t wino_min_rows;      /* Winograd-W route from this many output rows (default 1024; 0 = the default) */
   int64_t split16_min_rows;   /* pre-split operands on the 128-row slab tile from this many rows (8192; 0 = never) */
   int64_t cfg_split_min_rows; /* channel-split ResBlocks from this many rows (65536) */
   int64_t gn_small_group;     /* single-launch GroupNorm up to this many elements per (sample, group) (11264) */
@@ -189,7 +191,20 @@ typedef struct CsConvGemm {
   /* CS_MATH_F16X3, a_format = 1: the activations are already split -- x = fp16 hi image, x_lo = fp16 lo image,
    * both [rows][lda] halves holding value * a_scale (written by cs_groupnorm_apply_split16); cin, lda % 8 == 0.
    * a_format = 2 (ABI 12): x is the INTERLEAVED pair -- same bytes and lda (in floats) as the fp32 tensor, per row and
-   * 16-channel chunk [hi c0-7 | lo c0-7 | hi c8-15 | lo c8-15] (cs_layernorm_pair16); cin, lda % 16 == 0; x_lo unused. */
+   * 16-channel chunk [hi c0-7 | lo c0-7 | hi c8-15 | lo c8-15] (cs_layernorm_pair16); cin, lda % 16 == 0; x_lo unused.
+   * a_format = 3 (ABI 16): WINOGRAD-W form of a 3x3x3 stride-1 "same" conv (openai_model_3d.py:294-314: every ResBlock conv).
+   *   F(2,3) along W only: per pair of output voxels (w = 2 w2, 2 w2 + 1) the four input voxels d0..d3 = w - 1 .. w + 2
+   *   (zero outside the volume) become [d0 - d2, d1 + d2, d2 - d1, d1 - d3], the three kw taps g0..g2 of every (kd, kh)
+   *   become [g0, (g0 + g1 + g2) / 2, (g0 - g1 + g2) / 2, g2], position q's products are summed over (kd, kh, cin) -- four
+   *   GEMMs with a 3x3x1 kernel over (D, H, W/2), 18 instead of 27 multiply-adds per output -- and
+   *   out[2 w2] = m0 + m1 + m2, out[2 w2 + 1] = m1 - m2 - m3.  Against fp64 the result is as close as the direct form's
+   *   (2.5e-7 - 3.3e-7 rel-L2 at the UNet's shapes); it is NOT bit-equal to it.
+   *   x / x_lo = the transformed operand, pre-split like a_format = 1: fp16 hi / lo images [4][nb][D][H][W/2][lda] of
+   *   value * a_scale, written by cs_groupnorm_apply_wino16; w / w_lo = four consecutive packed images of the transformed
+   *   weights (cs_pack_weight_f16x3_wino: ONE scale, so acc_scale as usual); din / hin / win, kd = kh = kw = 3 and every
+   *   epilogue field describe the ORIGINAL conv; splitk_ws must hold cs_conv_wino_ws_bytes(desc) bytes (the four position
+   *   results, x K slices if splitk > 1), the output transform + epilogue run in the split-K reduce kernel's place (same
+   *   epilogue outputs: gn_part on 16-row tiles, out_format).  cs_conv_wino_ok says where cs_conv_gemm accepts it. */
   const void* x_lo;
   int32_t a_format;
   /* Split-K (CS_MATH_F16X3, 224-column tiles): splitk > 1 cuts the K loop (taps x channel chunks) into that many
@@ -256,6 +271,14 @@ int cs_conv_gemm_launch_info(const CsConvGemm* desc, int32_t* tile, int32_t* sla
 /* The split-K factor cs_conv_gemm's heuristic would pick for this descriptor (1 = none) and the workspace it then
  * needs; host-only, no device work.  A caller that wants it sets desc->splitk / desc->splitk_ws accordingly. */
 int cs_conv_gemm_plan(const CsConvGemm* desc, int32_t* splitk, int64_t* splitk_ws_bytes);
+/* (ABI 16) Winograd-W route (CsConvGemm.a_format = 3).  cs_conv_wino_ok: 1 if cs_conv_gemm takes this 3x3x3 conv in that
+ * form -- desc as the conv would be issued in DIRECT form (a_format / x / w are not looked at): CS_MATH_F16X3, 3x3x3,
+ * stride 1, pad 1, no upsampling, even W with W / 2 <= 32, cout % 224 == 0, cin % 8 == 0, whole 256-row tiles per position,
+ * at least CsDebug.wino_min_rows output rows, CS_NO_WINO unset -- the ONE rule both hosts ask BEFORE they let the
+ * GroupNorm emit the transformed operand.  cs_conv_wino_plan: the K slices of the position GEMMs (1 = none) and the bytes
+ * of splitk_ws they need. */
+int cs_conv_wino_ok(const CsConvGemm* desc);
+int cs_conv_wino_plan(const CsConvGemm* desc, int32_t* splitk, int64_t* ws_bytes);
 
 /*
  * Nearest x2 upsampling (in the dims flagged by ud / uh / uw, each 0 or 1) followed by a 3x3x3 stride-1 "same" conv
@@ -305,6 +328,12 @@ int cs_relayout_weight(const float* w_torch, float* w_out, int cout, int cin, in
  */
 int cs_pack_weight_f16x3(const float* w_torch, void* w_hi, void* w_lo, int cout, int cin, int taps,
                          float scale, cs_stream_t stream);
+/* (ABI 16) The Winograd-W weights of a 3x3x3 conv (CsConvGemm.a_format = 3): w_torch [cout][cin][3][3][3] -> FOUR packed
+ * images (position q = 0..3, each [9 taps (kd, kh)][cin16/8][cout][8] halves, q-major) of
+ * u_q = [g0, (g0 + g1 + g2) / 2, (g0 - g1 + g2) / 2, g2] over the kw taps g0..g2 (formed in fp64, rounded once) * scale;
+ * max |u_q| <= 1.5 max |w|: choose scale with that headroom. */
+int cs_pack_weight_f16x3_wino(const float* w_torch, void* w_hi, void* w_lo, int cout, int cin, float scale,
+                              cs_stream_t stream);
 
 /*
  * Thin-output 3x3x3 convs (cout <= 4, stride 1, "same" padding: openai_model_3d.py:733-737 `self.out`,
@@ -342,6 +371,13 @@ int cs_groupnorm_apply(const float* x, const float* stats, const float* gamma, c
 int cs_groupnorm_apply_split16(const float* x, const float* stats, const float* gamma, const float* beta,
                                void* y_hi, void* y_lo, int nb, int rows, int c, int ldx, int ldy, int groups,
                                int act, float a_scale, int32_t* status, cs_stream_t stream);
+/* (ABI 16) ... emitted in the Winograd-W form (CsConvGemm.a_format = 3): the four transformed operands [d0 - d2, d1 + d2,
+ * d2 - d1, d1 - d3] of y = act(GroupNorm(x)) along W (y = 0 outside the volume), each split into fp16 hi / lo of value *
+ * a_scale -- v_hi / v_lo: [4][nb][d][h][w / 2][ldv] halves.  |value| <= 2 max|y|: a_scale must leave that headroom
+ * (cs_norm_a_scale(...) / 2).  w even, c % 8 == 0, ldv % 8 == 0. */
+int cs_groupnorm_apply_wino16(const float* x, const float* stats, const float* gamma, const float* beta, void* v_hi,
+                              void* v_lo, int nb, int d, int h, int w, int c, int ldx, int ldv, int groups, int act,
+                              float a_scale, int32_t* status, cs_stream_t stream);
 /* Channel-range forms of the two apply entries (ABI 11): the c channels handled are channels ch0 .. ch0 + c of a tensor
  * whose statistics were taken over `groups` groups of `cpg` channels (stats: [nb][groups][2]); x, gamma, beta and the
  * outputs point AT channel ch0 (ch0 % 4 == 0).  One statistics pass over a channel concatenation [h | skip]

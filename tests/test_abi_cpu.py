@@ -27,7 +27,7 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(dll, s), f"{s} declared in the header but not exported"
         assert s in lib.SIGNATURES, f"{s} has no ctypes signature"
     assert set(lib.SIGNATURES) == set(syms)
-    assert dll.cs_abi_version() == lib.ABI_VERSION == 15
+    assert dll.cs_abi_version() == lib.ABI_VERSION == 16
 
 
 def test_struct_layout_matches_header():
@@ -156,7 +156,8 @@ def test_every_entry_rejects_null_arguments_without_touching_the_device():
             "cs_unet_arena_bytes", "cs_unet_context_floats", "cs_vqvae_destroy", "cs_vqvae_param_count",
             "cs_vqvae_raw_bytes", "cs_vqvae_arena_bytes",
             # r4: host-side rule / switch queries (csrc/cs_plan.hip): plain functions of their arguments, no status code
-            "cs_debug", "cs_debug_set", "cs_norm_a_scale", "cs_bound_a_scale", "cs_conv_wants_split16", "cs_tapcol_ok", "cs_tapcol_tile"}
+            "cs_debug", "cs_debug_set", "cs_norm_a_scale", "cs_bound_a_scale", "cs_conv_wants_split16", "cs_tapcol_ok", "cs_tapcol_tile",
+            "cs_conv_wino_ok"}
     checked = 0
     for name, (res, args) in lib.SIGNATURES.items():
         if name in skip:

@@ -1,0 +1,120 @@
+"""r5: Winograd F(2,3) along W for the 3x3x3 stride-1 convs (CsConvGemm.a_format = 3; every ResBlock conv,
+openai_model_3d.py:294-314: GroupNorm32 + SiLU -> conv3 (+ emb row vector) -> GroupNorm32 + SiLU -> conv3 (+ skip)).
+
+The GroupNorm emits the transformed operand (cs_groupnorm_apply_wino16), the library runs the four position GEMMs (3x3x1
+kernels over (D, H, W/2), 18 instead of 27 multiply-adds per output) in one launch and the output transform + epilogue in
+the split-K reduce kernel's place.  Checked against fp64 at the per-op gate, against the direct form, with every epilogue
+term the ResBlock uses (bias, per-sample row vector, residual, GroupNorm partial sums), with K slices, and at the rule's
+edges."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).cuda()
+
+
+def _ref_gn_silu(x, g, b, eps=1e-5):
+    xd = x.double().permute(0, 4, 1, 2, 3)
+    y = F.group_norm(xd, 32, g.double(), b.double(), eps)
+    return F.silu(y).permute(0, 2, 3, 4, 1)
+
+
+def test_groupnorm_emits_the_transformed_operand():
+    from commonscenes_amd import lib as L, ops
+    nb, d, h, w, c = 2, 4, 4, 8, 64
+    x = _rand(nb, d, h, w, c, seed=1) * 2 + 0.3
+    g, b = _rand(c, seed=2) + 1.0, _rand(c, seed=3)
+    v = ops.groupnorm(x, g, b, 32, 1e-5, L.ACT_SILU, a_scale=16.0, wino=True)
+    assert isinstance(v, ops.Wino16) and tuple(v.hi.shape) == (4, nb, d, h, w // 2, c) and v.a_scale == 8.0
+    y = _ref_gn_silu(x, g, b)
+    yp = F.pad(y, (0, 0, 1, 1))
+    dj = [yp[:, :, :, j:j + w:2] for j in range(4)]
+    ref = torch.stack([dj[0] - dj[2], dj[1] + dj[2], dj[2] - dj[1], dj[1] - dj[3]])
+    got = (v.hi.double() + v.lo.double()) / v.a_scale
+    torch.cuda.synchronize()
+    assert rel_l2(got, ref) < 1e-6
+    ops.check_overflow()
+
+
+CASES = [
+    # nb, (d, h, w), cin, cout, note
+    (4, (16, 16, 16), 224, 224, "16^3 level, 224 -> 224"),
+    (2, (16, 16, 16), 448, 224, "16^3 level, 448 -> 224 (concatenated input)"),
+    (16, (16, 8, 8), 448, 448, "16x8x8 level"),
+    (64, (16, 4, 4), 672, 672, "16x4x4 level at 32 objects: 384 position tiles -> two K slices"),
+    (32, (16, 4, 4), 1344, 672, "16x4x4 level, concatenated input"),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[-1] for c in CASES])
+def test_winograd_conv_against_fp64_and_the_direct_form(case):
+    from commonscenes_amd import lib as L, ops
+    nb, sp, cin, cout, note = case
+    rows = sp[0] * sp[1] * sp[2]
+    x = _rand(nb, *sp, cin, seed=11) * 1.5 + 0.2
+    g, b = _rand(cin, seed=12) * 0.2 + 1.0, _rand(cin, seed=13) * 0.2
+    wt = _rand(cout, cin, 3, 3, 3, seed=14, scale=(cin * 27) ** -0.5)
+    bias = _rand(cout, seed=15)
+    emb = _rand(nb, cout, seed=16)
+    res = _rand(nb, *sp, cout, seed=17)
+    pw = ops.pack_weight(wt, bias, math=L.MATH_F16X3)
+    ops.pack_weight_wino(pw, wt)
+    assert pw.wino is not None
+    with L.debug_override(wino_min_rows=1024):
+        assert ops.wants_wino(nb, *sp, pw)
+        s1 = ops.norm_a_scale(float(g.abs().max()), float(b.abs().max()), rows * (cin // 32))
+        v = ops.groupnorm(x, g, b, 32, 1e-5, L.ACT_SILU, a_scale=s1, wino=True)
+        hn = ops.groupnorm(x, g, b, 32, 1e-5, L.ACT_SILU, a_scale=s1, split16=True)
+        yw = ops.conv_gemm(v, pw, rowvec=emb, rv_rows=rows, res=res, stats=True)
+        yd = ops.conv_gemm(hn, pw, rowvec=emb, rv_rows=rows, res=res, stats=True)
+        p = ops._wino_desc(nb, *sp, pw)
+        sk, wsb = C.c_int32(0), C.c_int64(0)
+        assert L.load().cs_conv_wino_plan(C.byref(p), C.byref(sk), C.byref(wsb)) == 0
+    torch.cuda.synchronize()
+    a = _ref_gn_silu(x, g, b)
+    ref = F.conv3d(a.permute(0, 4, 1, 2, 3), wt.double(), bias.double(), padding=1).permute(0, 2, 3, 4, 1)
+    ref = ref + emb.double()[:, None, None, None, :] + res.double()
+    ew, ed = rel_l2(yw, ref), rel_l2(yd, ref)
+    print(f"winograd-W {note}: rel-L2 vs fp64 {ew:.2e} (direct form {ed:.2e}), K slices {sk.value}")
+    assert ew < 1e-6 and ew < 2 * ed + 2e-7
+    if "two K slices" in note:
+        assert sk.value == 2 and wsb.value == 2 * 2 * nb * rows * cout * 4
+    # the GroupNorm partial sums its epilogue leaves == the direct form's route to the same statistics
+    stw, std = getattr(yw, "cs_stats", None), getattr(yd, "cs_stats", None)
+    assert stw is not None and std is not None
+    aw = ops.groupnorm_stats_from_parts([(0, stw)], nb, rows, cout, 32, 1e-5, yw.device)
+    t = yw.double().reshape(nb, rows, 32, cout // 32)
+    mean, var = t.mean(dim=(1, 3)), t.var(dim=(1, 3), unbiased=False)
+    assert float(((aw[..., 0].double() - mean).abs() / var.sqrt()).max()) < 2e-6
+    assert float((aw[..., 1].double() * (var + 1e-5).sqrt() - 1).abs().max()) < 2e-6
+    ops.check_overflow()
+
+
+def test_the_rule_keeps_small_odd_and_unsupported_launches_on_the_direct_form():
+    from commonscenes_amd import lib as L, ops
+    wt = _rand(224, 224, 3, 3, 3, seed=21, scale=0.02)
+    pw = ops.pack_weight_wino(ops.pack_weight(wt, None, math=L.MATH_F16X3), wt)
+    assert ops.wants_wino(4, 16, 16, 16, pw) and ops.wants_wino(1, 16, 8, 8, pw)      # from 1024 rows (the default threshold)
+    assert not ops.wants_wino(1, 16, 4, 4, pw)               # 256 rows: below it
+    assert not ops.wants_wino(7, 16, 4, 4, pw)               # M / 2 = 896 rows: not whole 256-row tiles per position
+    assert not ops.wants_wino(4, 16, 16, 2, pw)              # W / 2 < 2
+    with L.debug_override(no_wino=1):
+        assert not ops.wants_wino(4, 16, 16, 16, pw)
+    with L.debug_override(wino_min_rows=16384):
+        assert ops.wants_wino(4, 16, 16, 16, pw) and not ops.wants_wino(2, 16, 16, 16, pw)
+    w96 = _rand(96, 224, 3, 3, 3, seed=22, scale=0.02)       # not a 224-column width: no Winograd pack at all
+    assert ops.pack_weight_wino(ops.pack_weight(w96, None, math=L.MATH_F16X3), w96).wino is None
+    # a Wino16 operand on a weight without the pack is an error, not a silent fall-back
+    x = _rand(4, 16, 16, 16, 224, seed=23)
+    v = ops.groupnorm(x, torch.ones(224, device="cuda"), torch.zeros(224, device="cuda"), 32, 1e-5, L.ACT_SILU, wino=True)
+    with pytest.raises(L.CsError):
+        ops.conv_gemm(v, ops.pack_weight(wt, None, math=L.MATH_F16X3))
