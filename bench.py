@@ -61,9 +61,11 @@ def kernel_label(key):
         return "pw_gemm_f16x3_kernel (persistent ping-pong 2x128x224"
     wv, shape = TILE_SHAPES.get(tile, ("?", "?"))
     pair = len(key) > 3 and key[3]
-    return (f"conv_gemm_f16x3_kernel<{wv},{'true' if pre else 'false'},{slab}> ({shape}"
+    wino = len(key) > 4 and key[4]
+    return (f"conv_gemm_f16x3_kernel<{wv},{'true' if pre else 'false'},{slab}{',false,3' if wino else ''}> ({shape}"
             f"{', A slab' if slab else ''}{', pre-split activations' if pre else ''}"
-            f"{', interleaved operand pair' if pair else ''}")
+            f"{', interleaved operand pair' if pair else ''}"
+            f"{', the four Winograd-W position GEMMs of a 3x3x3 conv (3x3x1 taps) in one launch' if wino else ''}")
 
 
 def rocprof_name(key):
@@ -74,7 +76,10 @@ def rocprof_name(key):
     if tile == 5:
         return "pw_gemm_f16x3_kernel"
     wv = TILE_SHAPES.get(tile, ("?",))[0].replace(",", ", ")
-    return f"conv_gemm_f16x3_kernel<{wv}, {'true' if pre else 'false'}, {slab}, {'true' if pair else 'false'},"
+    wino = bool(key[4]) if len(key) > 4 else False
+    # (taps per kd follow: 3 = the Winograd-W position GEMMs; the 27-tap slab kernel and every gather kernel print 9)
+    return (f"conv_gemm_f16x3_kernel<{wv}, {'true' if pre else 'false'}, {slab}, {'true' if pair else 'false'},"
+            + (" 3," if wino else " 9," if slab and pre else ""))
 
 
 def parse():
@@ -297,7 +302,8 @@ def measure_mfma_busy(ksubs, a):
 def gemm_summary(prof, wall_ms, math):
     """dominant tile instantiation of a HIP-event profile: achieved TF/s, both roofline conventions."""
     by_tile = {}
-    keyf = lambda r: (r["tile"], r.get("slab", 0), bool(r.get("pre", False)), bool(r.get("pair", False)))
+    keyf = lambda r: (r["tile"], r.get("slab", 0), bool(r.get("pre", False)), bool(r.get("pair", False)),
+                      bool(r.get("wino", False)))
     for r in prof:
         k = keyf(r)
         by_tile[k] = by_tile.get(k, 0.0) + r["e0"].elapsed_time(r["e1"])
@@ -307,9 +313,14 @@ def gemm_summary(prof, wall_ms, math):
     sel = [r for r in prof if keyf(r) == dom]
     ms = sum(r["e0"].elapsed_time(r["e1"]) for r in sel)
     fl = sum(r["flops"] for r in sel)
-    all_ms = sum(r["e0"].elapsed_time(r["e1"]) for r in prof)
+    # (a Winograd-W record carries a third event: its output-transform launch, an HBM-bound pass, is counted into the GEMM
+    # totals' time but is not a launch of the dominant KERNEL)
+    xform_ms = sum(r["e1"].elapsed_time(r["e2"]) for r in prof if "e2" in r)
+    all_ms = sum(r["e0"].elapsed_time(r["e1"]) for r in prof) + xform_ms
     all_fl = sum(r["flops"] for r in prof)
+    all_fl_direct = sum(r.get("flops_direct", r["flops"]) for r in prof)
     achieved = fl / (ms * 1e-3) / 1e12
+    wino_dom = bool(dom[4])
     # ALGORITHMIC HBM bytes of the dominant kernel's launches (what `traffic`, the counted bytes, is to be ratioed against):
     # the A operand once (m x cin x 4 B: fp32, or the fp16 hi + lo pair), the packed weights once (k x n x 4 B: fp16 hi +
     # lo), the fp32 result once (m x n x 4 B) and the residual where the launch adds one -- per launch, averaged over the
@@ -318,7 +329,12 @@ def gemm_summary(prof, wall_ms, math):
     ab = 0.0
     for r in sel:
         cin = r["k"] / max(1, r["taps"])
-        ab += r["m"] * cin * 4.0 + r["k"] * r["n"] * 4.0 + r["m"] * r["n"] * 4.0 * (2.0 if r.get("res") else 1.0)
+        if r.get("wino"):
+            # the position launch: the transformed operand pair [4][M/2][cin] once, FOUR packed weight pairs, its fp32
+            # results [slices][4][M/2][n] (the epilogue terms belong to the output-transform launch)
+            ab += r["m"] * cin * 4.0 + 4.0 * r["k"] * r["n"] * 4.0 + r.get("slices", 1) * r["m"] * r["n"] * 4.0
+        else:
+            ab += r["m"] * cin * 4.0 + r["k"] * r["n"] * 4.0 + r["m"] * r["n"] * 4.0 * (2.0 if r.get("res") else 1.0)
     alg_bytes = ab / len(sel)
     if math == "f16x3":
         peak = F16_MFMA_PEAK_TFLOPS / 3.0
@@ -339,8 +355,19 @@ def gemm_summary(prof, wall_ms, math):
             "kernel": kname, "rocprof_kernel": rocprof_name(dom) if math == "f16x3" else "conv_gemm_f32_kernel<1, 7, 4, 1>",
             "math": math, "launches": len(sel), "avg_launch_ms": ms / len(sel),
             "algorithmic_gflop_per_launch": fl / len(sel) / 1e9, "algorithmic_bytes_per_launch": alg_bytes,
+            "flops_note": ("achieved / frac price the multiply-adds the kernel EXECUTES: this kernel is the Winograd-W position "
+                           "launch of the 3x3x3 convs (F(2,3) along W: 18 of the direct form's 27 multiply-adds per output), so "
+                           "the direct-form-equivalent rate of those convs -- with their output-transform launch counted in -- "
+                           "is `winograd_direct_equivalent_tflops`") if wino_dom else
+                          "achieved / frac price the direct form's algorithmic flops, all of which this kernel executes",
+            "winograd_direct_equivalent_tflops": (
+                sum(r["flops_direct"] for r in sel) / (sum(r["e0"].elapsed_time(r["e2"]) for r in sel) * 1e-3) / 1e12
+                if wino_dom else None),
+            "winograd_output_transform_ms_per_step_share": xform_ms / wall_ms if xform_ms else None,
             "share_of_wall_time": ms / wall_ms,
-            "all_gemm_tflops": all_fl / (all_ms * 1e-3) / 1e12, "all_gemm_share_of_wall_time": all_ms / wall_ms}
+            "all_gemm_tflops": all_fl / (all_ms * 1e-3) / 1e12,
+            "all_gemm_direct_equivalent_tflops": all_fl_direct / (all_ms * 1e-3) / 1e12,
+            "all_gemm_share_of_wall_time": all_ms / wall_ms}
 
 
 def spawn_ranks(a) -> int:
@@ -671,15 +698,21 @@ def main():
         if a.gemm_table:
             agg = {}
             for r in prof:
-                k = (r["taps"], r["m"], r["k"], r["n"], r["tile"] + (100 if r.get("slab") else 0))
-                t = agg.setdefault(k, [0, 0.0, 0.0])
+                k = (r["taps"], r["m"], r["k"], r["n"], r["tile"] + (100 if r.get("slab") else 0) + (1000 if r.get("wino") else 0))
+                t = agg.setdefault(k, [0, 0.0, 0.0, 0.0, 0.0])
                 t[0] += 1
                 t[1] += r["e0"].elapsed_time(r["e1"])
                 t[2] += r["flops"]
-            print(f"{'taps':>4} {'M':>7} {'K':>6} {'N':>6} tile {'calls':>5} {'ms/step':>8} {'TF/s':>7}", file=sys.stderr)
-            for k, t in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                if "e2" in r:                 # Winograd-W: the output-transform launch and the direct form's flops beside
+                    t[3] += r["e1"].elapsed_time(r["e2"])
+                    t[4] += r["flops_direct"]
+            print(f"{'taps':>4} {'M':>7} {'K':>6} {'N':>6} tile {'calls':>5} {'ms/step':>8} {'TF/s':>7}   (tile 1104 = the four "
+                  "Winograd-W position GEMMs of a 3x3x3 conv: executed TF/s, then + output transform ms/step and the "
+                  "direct-form-equivalent TF/s of the pair)", file=sys.stderr)
+            for k, t in sorted(agg.items(), key=lambda kv: -(kv[1][1] + kv[1][3])):
+                extra = f"  + {t[3] / a.steps:6.3f}  {t[4] / (t[1] + t[3]) / 1e9:7.1f}" if t[3] else ""
                 print(f"{k[0]:4d} {k[1]:7d} {k[2]:6d} {k[3]:6d} {k[4]:4d} {t[0]:5d} {t[1] / a.steps:8.3f} "
-                      f"{t[2] / t[1] / 1e9:7.1f}", file=sys.stderr)
+                      f"{t[2] / t[1] / 1e9:7.1f}{extra}", file=sys.stderr)
         # HBM bytes per launch of the dominant kernel come from PMC counters, which cannot be collected from inside this
         # process: --traffic runs the two rocprofv3 --pmc passes NOW (child runs of this script); without it the field
         # is null and the figure measured for this round's kernels is the committed profiles/r03_traffic.json

@@ -792,7 +792,8 @@ extern "C" int cs_conv_wino_plan(const CsConvGemm* d, int32_t* splitk, int64_t* 
 }
 
 // desc validated by conv_gemm_impl (incl. gn_part / out_format against cs_conv_gemm_epilogue_caps)
-static int conv_wino(const CsConvGemm& p, int M, hipStream_t s) {
+// phases: bit 0 = the position GEMMs, bit 1 = output transform + epilogue (cs_conv_gemm: both)
+static int conv_wino(const CsConvGemm& p, int M, hipStream_t s, int phases = 3) {
   auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
   if (!wino_ok(p) || !p.x_lo || !al16(p.x_lo) || !p.w_lo || !al16(p.w_lo) || (p.lda & 7) || !p.splitk_ws || !al16(p.splitk_ws) ||
       p.a_bound || !(p.acc_scale > 0.f))
@@ -816,8 +817,11 @@ static int conv_wino(const CsConvGemm& p, int M, hipStream_t s) {
   q.out_format = 0;
   q.splitk = 0;
   q.tile = 4;
-  const int rc = cs_conv_gemm_f16x3_dispatch(q, 2 * M, 4, sp, s, 16, 4, nullptr, nullptr, nullptr, 0, nullptr);
-  if (rc != CS_OK) return rc;
+  if (phases & 1) {
+    const int rc = cs_conv_gemm_f16x3_dispatch(q, 2 * M, 4, sp, s, 16, 4, nullptr, nullptr, nullptr, 0, nullptr);
+    if (rc != CS_OK) return rc;
+  }
+  if (!(phases & 2)) return CS_OK;
   const int64_t nblk = (int64_t)((M + SKR - 1) / SKR) * ((p.cout + 63) / 64);
   if (nblk > 0x7fffffffLL) return CS_EINVAL;
   CS_LAUNCH(splitk_reduce_epi_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, s, p,
@@ -828,7 +832,7 @@ static int conv_wino(const CsConvGemm& p, int M, hipStream_t s) {
 
 static int conv_gemm_impl(const CsConvGemm* d, cs_stream_t stream, int omap_f, int omap_p,
                           const void* const* cls_w = nullptr, const void* const* cls_w_lo = nullptr,
-                          const float* cls_acc = nullptr, int ncls = 0) {
+                          const float* cls_acc = nullptr, int ncls = 0, int wino_phases = 3) {
   if (!d || !d->x || !d->w || !d->out) return CS_EINVAL;
   const CsConvGemm& p = *d;
   if (p.nb <= 0 || p.cin <= 0 || p.cout <= 0 || p.dout <= 0 || p.hout <= 0 || p.wout <= 0)
@@ -865,7 +869,8 @@ static int conv_gemm_impl(const CsConvGemm* d, cs_stream_t stream, int omap_f, i
     if (p.gn_part && (rows == 0 || rows != p.gn_rows || p.gn_ld < p.cout || ((uintptr_t)p.gn_part & 15))) return CS_EINVAL;
     if (p.out_format == 2 && (!pair || !(p.out_scale > 0.f))) return CS_EINVAL;
   }
-  if (p.a_format == 3) return (f16x3 && !omap_f) ? conv_wino(p, M, s) : CS_EINVAL;
+  if (p.a_format == 3) return (f16x3 && !omap_f) ? conv_wino(p, M, s, wino_phases) : CS_EINVAL;
+  if (wino_phases != 3) return CS_EINVAL;
   if (p.splitk > 1) {
     // caller-requested split-K (cs_conv_gemm_plan): partial tiles to the workspace, then reduce + epilogue
     auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
@@ -937,6 +942,12 @@ static int conv_gemm_impl(const CsConvGemm* d, cs_stream_t stream, int omap_f, i
 }
 
 extern "C" int cs_conv_gemm(const CsConvGemm* d, cs_stream_t stream) { return conv_gemm_impl(d, stream, 0, 0); }
+extern "C" int cs_conv_wino_positions(const CsConvGemm* d, cs_stream_t stream) {
+  return conv_gemm_impl(d, stream, 0, 0, nullptr, nullptr, nullptr, 0, 1);
+}
+extern "C" int cs_conv_wino_output(const CsConvGemm* d, cs_stream_t stream) {
+  return conv_gemm_impl(d, stream, 0, 0, nullptr, nullptr, nullptr, 0, 2);
+}
 
 int cs_f16x3_slab_width(const CsConvGemm& p, int tile, int splits);      // cs_gemm_f16x3.hip
 

@@ -106,6 +106,8 @@ SIGNATURES = {
     "cs_conv_gemm_epilogue_caps": (_i, [C.POINTER(CsConvGemm), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "cs_conv_wino_ok": (_i, [C.POINTER(CsConvGemm)]),
     "cs_conv_wino_plan": (_i, [C.POINTER(CsConvGemm), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    "cs_conv_wino_positions": (_i, [C.POINTER(CsConvGemm), _s]),
+    "cs_conv_wino_output": (_i, [C.POINTER(CsConvGemm), _s]),
     "cs_conv_gemm_launch_info": (_i, [C.POINTER(CsConvGemm), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "cs_debug": (C.POINTER(CsDebug), []),
     "cs_debug_set": (None, [C.POINTER(CsDebug)]),

@@ -770,16 +770,21 @@ def _conv_wino(xw: "Wino16", w: PackedWeight, act, rowvec, rv_rows, res, scale, 
     p.splitk, p.splitk_ws = sk.value, ws.data_ptr()
     st, paired = _epilogue_extras(lib, p, dev, nb, d * h * wd, mo, w.cout, stats, out_pair)
     prof = GEMM_PROFILE
-    if prof is not None:
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
+    if prof is None:
+        L.check(lib.cs_conv_gemm(C.byref(p), _stream()), "cs_conv_gemm")
+    else:
+        # per-kernel HIP events: the position GEMMs and the output transform are the two launches of cs_conv_gemm
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         e0.record()
-    L.check(lib.cs_conv_gemm(C.byref(p), _stream()), "cs_conv_gemm")
-    if prof is not None:
+        L.check(lib.cs_conv_wino_positions(C.byref(p), _stream()), "cs_conv_wino_positions")
         e1.record()
-        # (flops = the DIRECT form's algorithmic work, as for every other route; `wino` marks the 18/27 executed share)
-        prof.append(dict(e0=e0, e1=e1, flops=2.0 * mo * w.cout * w.cin * 27, taps=27, m=mo, n=w.cout, k=w.cin * 27, tile=4,
-                         slab=32, pre=True, pair=False, res=res is not None, wino=True))
+        L.check(lib.cs_conv_wino_output(C.byref(p), _stream()), "cs_conv_wino_output")
+        e2.record()
+        # flops = what the position GEMMs EXECUTE (18 of the direct form's 27 multiply-adds per output); flops_direct = the
+        # direct form's algorithmic work the pair of launches replaces; m / k = the position launch's own GEMM shape
+        prof.append(dict(e0=e0, e1=e1, e2=e2, flops=2.0 * mo * w.cout * w.cin * 18, flops_direct=2.0 * mo * w.cout * w.cin * 27,
+                         taps=9, m=2 * mo, n=w.cout, k=w.cin * 9, tile=4, slab=32, pre=True, pair=False,
+                         res=res is not None, wino=True, slices=int(sk.value)))
     if paired:
         return Pair16(out, float(out_pair))
     return attach_stats(out, st)

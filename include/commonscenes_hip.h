@@ -279,6 +279,11 @@ int cs_conv_gemm_plan(const CsConvGemm* desc, int32_t* splitk, int64_t* splitk_w
  * of splitk_ws they need. */
 int cs_conv_wino_ok(const CsConvGemm* desc);
 int cs_conv_wino_plan(const CsConvGemm* desc, int32_t* splitk, int64_t* ws_bytes);
+/* The two launches of cs_conv_gemm(a_format = 3) on their own, for hosts that time them separately (bench.py's per-kernel
+ * HIP events): cs_conv_wino_positions = the four position GEMMs into splitk_ws, cs_conv_wino_output = the output transform +
+ * epilogue from splitk_ws.  Same descriptor, same validation; calling the first and then the second IS cs_conv_gemm. */
+int cs_conv_wino_positions(const CsConvGemm* desc, cs_stream_t stream);
+int cs_conv_wino_output(const CsConvGemm* desc, cs_stream_t stream);
 
 /*
  * Nearest x2 upsampling (in the dims flagged by ud / uh / uw, each 0 or 1) followed by a 3x3x3 stride-1 "same" conv
