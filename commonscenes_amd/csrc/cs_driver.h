@@ -227,8 +227,10 @@ void layout_arena(Plan& u) {
       off += align_up(img);
       g.wlo_off = off;
       off += align_up(img);
+      // (r5: the Winograd-W pack beside the direct one -- also for the input-channel halves of a channel-split conv, scaled
+      // by the whole tensor's maximum like their direct packs: ops.py::pack_weight_wino)
       if (g.k == 3 && !g.tap_cout && g.w.size() == 1 && g.w[0].param >= 0 && g.w[0].row0 == 0 && g.w[0].rows == g.cout &&
-          !g.src_cin && g.cout % 224 == 0 && g.cin % 8 == 0 && g.cin >= 16 && g.cin_pad == g.cin) {
+          (g.cout % 224 == 0 || g.cout % 128 == 0 || g.cout == 64) && g.cin % 8 == 0 && g.cin >= 16 && g.cin_pad == g.cin) {
         const int64_t wimg = 4LL * 9 * kg * g.cout * 16;
         g.wino_off = off;
         off += align_up(wimg);
@@ -312,6 +314,36 @@ __global__ __launch_bounds__(256) void pack_part_f16x3_kernel(const float* __res
     const int64_t o = (((int64_t)tap * kg_per_tap + kg) * cout_total + n_off + n) * 8 + j;
     wh[o] = h;
     wl[o] = (_Float16)(v - (float)h);
+  }
+}
+
+// r5: the Winograd-W pack of a 3x3x3 conv (or of an input-channel range [c0, c0 + cin) of one): cs_pack_weight_f16x3_wino's
+// arithmetic -- u_q over the kw taps formed and split in fp64 -- on a (cout, src_cin, 27) source tensor
+__global__ __launch_bounds__(256) void pack_part_f16x3_wino_kernel(const float* __restrict__ w, _Float16* __restrict__ wh,
+                                                                   _Float16* __restrict__ wl, int cout, int cin,
+                                                                   int kg_per_tap, float scale, int src_cin, int c0) {
+  if (src_cin == 0) src_cin = cin;
+  const int64_t per = 9LL * kg_per_tap * cout * 8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < 4 * per; i += (int64_t)gridDim.x * blockDim.x) {
+    const int q = (int)(i / per);
+    int64_t t = i - q * per;
+    const int j = (int)(t & 7);
+    t >>= 3;
+    const int n = (int)(t % cout);
+    t /= cout;
+    const int kg = (int)(t % kg_per_tap);
+    const int tap = (int)(t / kg_per_tap);
+    const int c = kg * 8 + j;
+    double u = 0.0;
+    if (c < cin) {
+      const float* g = w + ((int64_t)n * src_cin + c0 + c) * 27 + tap * 3;
+      const double g0 = g[0], g1 = g[1], g2 = g[2];
+      u = q == 0 ? g0 : q == 1 ? 0.5 * (g0 + g1 + g2) : q == 2 ? 0.5 * (g0 - g1 + g2) : g2;
+    }
+    const double v = u * (double)scale;
+    const _Float16 h = (_Float16)v;
+    wh[i] = h;
+    wl[i] = (_Float16)(v - (double)h);
   }
 }
 
@@ -496,9 +528,11 @@ int pack_plan(Plan* u, const void* raw_dev, void* arena_dev, cs_stream_t stream)
       if (m > 0.0 && std::isfinite(m)) (void)std::frexp(m, &ex);
       const float wscale = (float)std::ldexp(1.0, 14 - ex);
       g.wino_acc = 1.0f / (wscale * 16.0f);
-      const int rc = cs_pack_weight_f16x3_wino(src(g.w[0].param), arena + g.wino_off, arena + g.wino_lo_off, g.cout, g.cin,
-                                               wscale, stream);
-      if (rc != CS_OK) return rc;
+      const int kg = (g.cin + 15) / 16 * 2;
+      CS_LAUNCH(pack_part_f16x3_wino_kernel, dim3(cs_grid_for(4LL * 9 * kg * g.cout * 8, 256, 256 * 32)), dim3(256), 0, st,
+                src(g.w[0].param), (_Float16*)(arena + g.wino_off), (_Float16*)(arena + g.wino_lo_off), g.cout, g.cin, kg,
+                wscale, g.src_cin, g.c0);
+      CS_CHECK_LAUNCH();
     }
     n_off = 0;
     for (const Piece& pc : g.b) {
@@ -820,30 +854,36 @@ struct ExecBase {
   }
   // stride-1 conv / pointwise GEMM on explicit operand views: x (+ x_lo for the pre-split pair) with row stride lda,
   // out with row stride ldo -- channel ranges of wider buffers, sample ranges of a batch (res_block_split)
+  // wino (r5): x / x_lo are the hi / lo images of a Winograd-W operand (Buf::wino) of the [nb, d, h, w] volume
   void gemm_view(const float* x, const void* x_lo, int lda, int gi, int nb, int d, int h, int w, float* out, int ldo,
                  const float* rowvec = nullptr, int ldrv = 0, int rv_rows = 1, const float* res = nullptr, int ldr = 0,
-                 float a_scale = 16.f) {
+                 float a_scale = 16.f, bool wino = false) {
     const Gemm& g = pl.gemms[gi];
     CsConvGemm q;
     memset(&q, 0, sizeof(q));
+    if (wino && (g.wino_off < 0 || g.k != 3 || pl.math != CS_MATH_F16X3)) {
+      chk(CS_EINVAL);
+      return;
+    }
+    if (wino) q.a_format = 3;
     if (!dry) {
       q.x = x;
       if (x_lo) {
         q.x_lo = x_lo;
-        q.a_format = 1;
+        if (!wino) q.a_format = 1;
       }
       q.out = out;
-      q.w = reinterpret_cast<const float*>(arena + g.w_off);
+      q.w = reinterpret_cast<const float*>(arena + (wino ? g.wino_off : g.w_off));
       if (pl.math == CS_MATH_F16X3) {
-        q.w_lo = arena + g.wlo_off;
-        q.acc_scale = g.acc_scale * (16.0f / a_scale);
+        q.w_lo = arena + (wino ? g.wino_lo_off : g.wlo_off);
+        q.acc_scale = (wino ? g.wino_acc : g.acc_scale) * (16.0f / a_scale);
         q.a_scale = a_scale;
       }
       q.bias = g.b_off >= 0 ? wf(g.b_off) : nullptr;
       q.rowvec = rowvec;
       q.res = res;
       q.status = status;
-    } else if (x_lo) {
+    } else if (x_lo && !wino) {
       q.a_format = 1;           // the plan looks at it
     }
     const int k = g.k, pad = k / 2;
@@ -858,7 +898,16 @@ struct ExecBase {
     int32_t sk = 1;
     int64_t wsb = 0;
     Buf skws;
-    if (cs_conv_gemm_plan(&q, &sk, &wsb) == CS_OK && sk > 1) {
+    if (wino) {
+      if (cs_conv_wino_plan(&q, &sk, &wsb) != CS_OK) {
+        chk(CS_EINVAL);
+        return;
+      }
+      skws = alloc(wsb / 4, 1);
+      if (!ok()) return;
+      q.splitk = sk;
+      q.splitk_ws = dry ? nullptr : p(skws);
+    } else if (cs_conv_gemm_plan(&q, &sk, &wsb) == CS_OK && sk > 1) {
       skws = alloc(wsb / 4, 1);
       if (!ok()) return;
       q.splitk = sk;
@@ -993,12 +1042,26 @@ struct ExecBase {
   }
   // GroupNorm apply of channels [ch0, ch0 + c) (x already points at channel ch0, row stride ldx) -> a fresh [rows][c]
   // buffer, fp32 or the pre-split pair depending on the consuming conv
+  // vd > 0 (r5): emit the Winograd-W operand of the [nb, vd, vh, vw] volume instead (the caller asked wants_wino);
+  // stats_off: first sample's offset (in samples) into `stats`
   Buf gn_apply_range(const float* x, int ldx, int64_t rows_total, int nb, const Buf& stats, int ni, int groups, int cpg,
-                     int ch0, int c, int act, int conv_gi, int64_t m_launch) {
+                     int ch0, int c, int act, int conv_gi, int64_t m_launch, int vd = 0, int vh = 0, int vw = 0,
+                     int64_t stats_off = 0) {
     const Norm& n = pl.norms[ni];
-    Buf y = alloc(rows_total, c);
+    Buf y = alloc(vd > 0 ? 2 * rows_total : rows_total, c);
     const int rows = (int)(rows_total / nb);
     if (pl.math == CS_MATH_F16X3) y.a_scale = norm_a_scale(n.gmax, n.bmax, (int64_t)rows * cpg);
+    if (vd > 0) {
+      y.wino = true;
+      y.a_scale *= 0.5f;
+      if (ok() && !dry) {
+        char* vhi = reinterpret_cast<char*>(p(y));
+        chk(cs_groupnorm_apply_wino16_range(x, p(stats) + stats_off * groups * 2, wf(n.g_off) + ch0, wf(n.b_off) + ch0, vhi,
+                                            vhi + rows_total * c * 4, nb, vd, vh, vw, c, ldx, c, groups, cpg, ch0, act,
+                                            y.a_scale, status, st));
+      }
+      return y;
+    }
     if (wants_split16(m_launch, conv_gi)) {      // m_launch: rows per launch of the consuming conv
       y.half = true;
       if (ok() && !dry) {

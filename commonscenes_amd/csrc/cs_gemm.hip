@@ -735,13 +735,21 @@ static int fused_reduce_plan(const CsConvGemm& p, int M, int stile) {
 // reduce + epilogue kernel's place.  Prototype on the per-tap gather path, separate launches: -21...-23 % GEMM time at the
 // 16^3 / 16x8x8 levels, rel-L2 vs fp64 2.5e-7...3.3e-7 (direct form 2.6e-7...5.2e-7), profiles/r05_q_wino_proto.txt.
 // ---------------------------------------------------------------------------------------------------------------------
+// tile of the position GEMMs by output width: 256x224 (the UNet's widths), 256x128 / 256x64 (the VQ decoder's), 0 = none
+static int wino_tile(int cout) { return cout % 224 == 0 ? 4 : cout % 128 == 0 ? 6 : cout == 64 ? 7 : 0; }
+
 static bool wino_ok(const CsConvGemm& p) {
   const CsDebug* dbg = cs_debug();
   if (dbg->no_wino || p.math != CS_MATH_F16X3 || p.act == CS_ACT_GEGLU) return false;
   if (!(p.kd == 3 && p.kh == 3 && p.kw == 3 && p.sd == 1 && p.sh == 1 && p.sw == 1 && p.pd == 1 && p.ph == 1 && p.pw == 1) ||
       (p.ud | p.uh | p.uw) || p.din != p.dout || p.hin != p.hout || p.win != p.wout)
     return false;
-  if ((p.win & 1) || p.win < 4 || p.win / 2 > 32 || p.cout % 224 || (p.cin & 7) || p.cin < 16) return false;
+  if ((p.win & 1) || p.win < 4 || p.win / 2 > 32 || !wino_tile(p.cout) || (p.cin & 7) || p.cin < 16) return false;
+  // The VQ decoder's widths (64 / 128 / 256 columns) only at its 16^3 level: at 32^3 and 64^3 the transformed operand, the
+  // position results and the output transform are passes over 1 - 8 GB per conv that cost more than a third of a K loop of
+  // 36 - 144 chunks saves (decode of 32 objects 54.7 ms against 51.3 with every level on the route,
+  // profiles/r05_x_decode_table.txt).  A rule on the SAMPLE's geometry: the decoder's route never follows the batch.
+  if (p.cout % 224 && (int64_t)p.din * p.hin * p.win > 4096) return false;
   const int64_t M = (int64_t)p.nb * p.dout * p.hout * p.wout;
   const int64_t min_rows = dbg->wino_min_rows > 0 ? dbg->wino_min_rows : 1024;
   if (M < min_rows || M > 0x3fffffffLL || (M / 2) % 256) return false;
@@ -758,6 +766,9 @@ static bool wino_ok(const CsConvGemm& p) {
 // 14 objects) -> one (the efficiency-only rule of the first version took four slices there and LOST 30 % to the direct
 // form, profiles/r05_r_wino_bench_small.txt).
 static int wino_splits(const CsConvGemm& p) {
+  // (the VQ decoder's widths are never K-sliced: a slice count that followed the batch would cost the decoder its bit-exact
+  // batch invariance, tests/test_model_gpu.py::test_vq_decode_batch_invariance)
+  if (p.cout % 224) return 1;
   const int64_t M = (int64_t)p.nb * p.dout * p.hout * p.wout;
   const int64_t tiles = 4 * (M / 512) * (p.cout / 224);
   const int64_t cus = device_cus() > 0 ? device_cus() : 256;
@@ -816,9 +827,9 @@ static int conv_wino(const CsConvGemm& p, int M, hipStream_t s, int phases = 3) 
   q.gn_part = nullptr;
   q.out_format = 0;
   q.splitk = 0;
-  q.tile = 4;
+  q.tile = wino_tile(p.cout);
   if (phases & 1) {
-    const int rc = cs_conv_gemm_f16x3_dispatch(q, 2 * M, 4, sp, s, 16, 4, nullptr, nullptr, nullptr, 0, nullptr);
+    const int rc = cs_conv_gemm_f16x3_dispatch(q, 2 * M, q.tile, sp, s, 16, 4, nullptr, nullptr, nullptr, 0, nullptr);
     if (rc != CS_OK) return rc;
   }
   if (!(phases & 2)) return CS_OK;
@@ -961,8 +972,8 @@ extern "C" int cs_conv_gemm_launch_info(const CsConvGemm* d, int32_t* tile_out, 
   const int M = (int)M64;
   const bool f16x3 = p.math == CS_MATH_F16X3;
   int tile = p.tile;
-  if (p.a_format == 3) {                      // the Winograd-W position GEMMs: 256x224 tile, three-tap slab
-    if (tile_out) *tile_out = 4;
+  if (p.a_format == 3) {                      // the Winograd-W position GEMMs: 256-row tile, three-tap slab
+    if (tile_out) *tile_out = wino_tile(p.cout);
     if (slab_out) *slab_out = 32;
     return CS_OK;
   }

@@ -1414,7 +1414,7 @@ int cs_f16x3_slab_width(const CsConvGemm& p, int tile, int splits) {
   if (cs_f16x3_wino_geom(p)) {                                               // Winograd-W position GEMMs: three taps per kd
     const int64_t nsc = 3LL * ((p.cin + 15) / 16);
     const bool ok = splits == 1 || ((nsc + splits - 1) / splits) * splits * 10 <= nsc * 11;
-    return (p.a_format == 1 && tile == 4 && ok) ? 32 : 0;
+    return (p.a_format == 1 && (tile == 4 || tile == 6 || tile == 7) && ok) ? 32 : 0;
   }
 #endif
   const bool geom0 = p.kd == 3 && p.kh == 3 && p.kw == 3 && p.sd == 1 && p.sh == 1 && p.sw == 1 && p.pd == 1 && p.ph == 1 &&
@@ -1488,10 +1488,13 @@ int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p_in, int M, int tile, int spl
   if (p.a_format == 1) {
     if (!p.x_lo || ((uintptr_t)p.x_lo & 15) || (p.cin & 7) || (p.lda & 7)) return CS_EINVAL;
 #ifndef CS_NO_SLAB
-    if (cs_f16x3_wino_geom(p) && tile == 4 && cs_f16x3_slab_width(p, tile, splits) == 32) {
+    if (cs_f16x3_wino_geom(p) && (tile == 4 || tile == 6 || tile == 7) && cs_f16x3_slab_width(p, tile, splits) == 32) {
       const int ncls = (omap_f & 16) ? omap_p : 0;
       if (ncls > 1 && (((M + 255) / 256) % ncls || M % 256)) return CS_EINVAL;     // whole row tiles per class
-      return launch16<1, 7, 8, 1, true, 32, false, 3>(p, M, splits, s, 0, ncls);
+      // (256x224: the UNet's widths; 256x128 / 256x64: the VQ decoder's)
+      if (tile == 4) return launch16<1, 7, 8, 1, true, 32, false, 3>(p, M, splits, s, 0, ncls);
+      if (tile == 6) return launch16<1, 4, 8, 1, true, 32, false, 3>(p, M, splits, s, 0, ncls);
+      return launch16<1, 2, 8, 1, true, 32, false, 3>(p, M, splits, s, 0, ncls);
     }
     if (slab_geom && slab_slices_ok) {
       switch (tile) {

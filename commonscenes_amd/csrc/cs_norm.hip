@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void gn_apply_wino16_kernel(const float* __res
                                                               _Float16* __restrict__ vl, int lines, int w, int c, int ldx,
                                                               int ldv, int groups, int act, float a_scale,
                                                               int lines_per_block, int64_t pos_stride,
-                                                              int32_t* __restrict__ status) {
+                                                              int32_t* __restrict__ status, int cpg, int ch0) {
   const int ch4 = c >> 2;
   const int tpr = ch4 < 256 ? ch4 : 256;   // threads per line
   const int linelanes = 256 / tpr;
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256) void gn_apply_wino16_kernel(const float* __res
   const int n = blockIdx.y;
   const int l0 = blockIdx.x * lines_per_block;
   const int l1 = min(lines, l0 + lines_per_block);
-  const int w2n = w >> 1, cpg = c / groups;
+  const int w2n = w >> 1;
   const float* xb = x + (int64_t)n * lines * w * ldx;
   const int64_t vrow0 = (int64_t)n * lines * w2n;
   const float* st = stats + (int64_t)n * groups * 2;
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256) void gn_apply_wino16_kernel(const float* __res
     float mean[4], rstd[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int grp = (c4 * 4 + k) / cpg;
+      const int grp = (ch0 + c4 * 4 + k) / cpg;
       mean[k] = st[grp * 2];
       rstd[k] = st[grp * 2 + 1];
     }
@@ -921,12 +921,15 @@ extern "C" int cs_groupnorm_apply_split16_range(const float* x, const float* sta
   return CS_OK;
 }
 
-extern "C" int cs_groupnorm_apply_wino16(const float* x, const float* stats, const float* gamma, const float* beta,
-                                         void* v_hi, void* v_lo, int nb, int d, int h, int w, int c, int ldx, int ldv,
-                                         int groups, int act, float a_scale, int32_t* status, cs_stream_t stream) {
-  if (!x || !stats || !gamma || !beta || !v_hi || !v_lo || nb <= 0 || d <= 0 || h <= 0 || w < 2 || c <= 0 || groups <= 0)
+extern "C" int cs_groupnorm_apply_wino16_range(const float* x, const float* stats, const float* gamma, const float* beta,
+                                               void* v_hi, void* v_lo, int nb, int d, int h, int w, int c, int ldx, int ldv,
+                                               int groups, int cpg, int ch0, int act, float a_scale, int32_t* status,
+                                               cs_stream_t stream) {
+  if (!x || !stats || !gamma || !beta || !v_hi || !v_lo || nb <= 0 || d <= 0 || h <= 0 || w < 2 || c <= 0 || groups <= 0 ||
+      cpg <= 0 || ch0 < 0)
     return CS_EINVAL;
-  if ((w & 1) || (c & 7) || c % groups || (ldx & 3) || (ldv & 7) || ldx < c || ldv < c || !(a_scale > 0.f) || nb > 65535)
+  if ((w & 1) || (c & 7) || (int64_t)ch0 + c > (int64_t)groups * cpg || (ldx & 3) || (ldv & 7) || ldx < c || ldv < c ||
+      !(a_scale > 0.f) || nb > 65535)
     return CS_EINVAL;
   if (((uintptr_t)x & 15) || ((uintptr_t)v_hi & 15) || ((uintptr_t)v_lo & 15) || ((uintptr_t)gamma & 15) ||
       ((uintptr_t)beta & 15))
@@ -945,9 +948,17 @@ extern "C" int cs_groupnorm_apply_wino16(const float* x, const float* stats, con
   const int64_t pos_stride = (int64_t)nb * lines * (w >> 1) * ldv;
   CS_LAUNCH(gn_apply_wino16_kernel, dim3((unsigned)((lines + lpb - 1) / lpb), (unsigned)nb), dim3(256), 0,
             (hipStream_t)stream, x, stats, gamma, beta, (_Float16*)v_hi, (_Float16*)v_lo, lines, w, c, ldx, ldv, groups, act,
-            a_scale, lpb, pos_stride, status);
+            a_scale, lpb, pos_stride, status, cpg, ch0);
   CS_CHECK_LAUNCH();
   return CS_OK;
+}
+
+extern "C" int cs_groupnorm_apply_wino16(const float* x, const float* stats, const float* gamma, const float* beta,
+                                         void* v_hi, void* v_lo, int nb, int d, int h, int w, int c, int ldx, int ldv,
+                                         int groups, int act, float a_scale, int32_t* status, cs_stream_t stream) {
+  if (groups <= 0 || c <= 0 || c % groups) return CS_EINVAL;
+  return cs_groupnorm_apply_wino16_range(x, stats, gamma, beta, v_hi, v_lo, nb, d, h, w, c, ldx, ldv, groups, c / groups, 0,
+                                         act, a_scale, status, stream);
 }
 
 extern "C" int cs_groupnorm_apply_split16(const float* x, const float* stats, const float* gamma,

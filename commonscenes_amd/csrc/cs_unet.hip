@@ -358,20 +358,36 @@ struct Exec : ExecBase {
     int64_t xb = -1;
     Buf stats = gn_stats(x.b, nb, 1e-5f, 32, &xb);
     const float* xs = dry ? nullptr : p(sk.b) + off;           // the shared channels of the skip tensor
-    Buf a_h = gn_apply_range(dry ? nullptr : p(x.b), C, x.b.rows, nb, stats, l.n[0], 32, cpg, 0, ks, CS_ACT_SILU, l.gsp[0],
-                             m_launch);
-    Buf a_s = gn_apply_range(xs, ch_s, sk.b.rows, nbs, stats, l.n[0], 32, cpg, ks, cs, CS_ACT_SILU, l.gsp[1], m_launch);
-    release(stats);
-    auto lo_of = [&](const Buf& b) -> const void* {            // lo image of a pre-split pair
-      return (b.half && !dry) ? reinterpret_cast<const char*>(p(b)) + b.rows * b.c * 2 : nullptr;
+    // r5: where the halves' convs take the Winograd-W route (each launch covers nbs samples) their operands are emitted in
+    // that form -- the h half once per guidance half (unet.py::_res_split)
+    const bool wn_h = wants_wino(l.gsp[0], nbs, x.d, x.h, x.w), wn_s = wants_wino(l.gsp[1], nbs, x.d, x.h, x.w);
+    Buf a_h;
+    if (!wn_h)
+      a_h = gn_apply_range(dry ? nullptr : p(x.b), C, x.b.rows, nb, stats, l.n[0], 32, cpg, 0, ks, CS_ACT_SILU, l.gsp[0],
+                           m_launch);
+    Buf a_s = gn_apply_range(xs, ch_s, sk.b.rows, nbs, stats, l.n[0], 32, cpg, ks, cs, CS_ACT_SILU, l.gsp[1], m_launch,
+                             wn_s ? x.d : 0, x.h, x.w);
+    auto lo_of = [&](const Buf& b) -> const void* {            // lo image of a pre-split pair / of a Winograd-W operand
+      return ((b.half || b.wino) && !dry) ? reinterpret_cast<const char*>(p(b)) + b.rows * b.c * 2 : nullptr;
     };
     Buf y_s = alloc(sk.b.rows, cout);
-    if (ok()) gemm_view(dry ? nullptr : p(a_s), a_s.half ? (dry ? (const void*)1 : lo_of(a_s)) : nullptr, cs, l.gsp[1], nbs,
-                        x.d, x.h, x.w, dry ? nullptr : p(y_s), cout, nullptr, 0, 1, nullptr, 0, a_s.a_scale);
+    if (ok()) gemm_view(dry ? nullptr : p(a_s), (a_s.half || a_s.wino) ? (dry ? (const void*)1 : lo_of(a_s)) : nullptr, cs,
+                        l.gsp[1], nbs, x.d, x.h, x.w, dry ? nullptr : p(y_s), cout, nullptr, 0, 1, nullptr, 0, a_s.a_scale,
+                        a_s.wino);
     release(a_s);
     Buf h1 = alloc(x.b.rows, cout);
     for (int g = 0; g < nb / nbs && ok(); ++g) {
       const int64_t r0 = (int64_t)g * nbs * rows;
+      const float* rv = dry ? nullptr : p(semb) + (int64_t)g * nbs * semb.c + l.emb_lo;
+      if (wn_h) {
+        Buf a_g = gn_apply_range(dry ? nullptr : p(x.b) + r0 * C, C, (int64_t)nbs * rows, nbs, stats, l.n[0], 32, cpg, 0, ks,
+                                 CS_ACT_SILU, l.gsp[0], m_launch, x.d, x.h, x.w, (int64_t)g * nbs);
+        if (ok()) gemm_view(dry ? nullptr : p(a_g), dry ? (const void*)1 : lo_of(a_g), ks, l.gsp[0], nbs, x.d, x.h, x.w,
+                            dry ? nullptr : p(h1) + r0 * cout, cout, rv, semb.c, rows, dry ? nullptr : p(y_s), cout,
+                            a_g.a_scale, true);
+        release(a_g);
+        continue;
+      }
       const float* ah = nullptr;
       const void* al = a_h.half ? (const void*)1 : nullptr;
       if (!dry) {
@@ -379,11 +395,11 @@ struct Exec : ExecBase {
         ah = a_h.half ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(p(a_h)) + r0 * ks * 2) : p(a_h) + r0 * ks;
         if (a_h.half) al = reinterpret_cast<const char*>(lo_of(a_h)) + r0 * ks * 2;
       }
-      gemm_view(ah, al, ks, l.gsp[0], nbs, x.d, x.h, x.w, dry ? nullptr : p(h1) + r0 * cout, cout,
-                dry ? nullptr : p(semb) + (int64_t)g * nbs * semb.c + l.emb_lo, semb.c, rows, dry ? nullptr : p(y_s), cout,
-                a_h.a_scale);
+      gemm_view(ah, al, ks, l.gsp[0], nbs, x.d, x.h, x.w, dry ? nullptr : p(h1) + r0 * cout, cout, rv, semb.c, rows,
+                dry ? nullptr : p(y_s), cout, a_h.a_scale);
     }
-    release(a_h);
+    release(stats);
+    if (!wn_h) release(a_h);
     release(y_s);
     Buf skc = gemm(x.b, l.g[2], nb, x.d, x.h, x.w, 1, 0, CS_ACT_NONE, nullptr, 0, 1, nullptr, 0, 0, 1, 0, false, 0.f, xb);
     Buf hn2 = groupnorm(h1, l.n[1], nb, 1e-5f, CS_ACT_SILU, 32, l.g[1], nullptr, x.d, x.h, x.w);

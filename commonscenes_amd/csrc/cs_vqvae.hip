@@ -113,11 +113,12 @@ struct VExec : ExecBase {
 
   // ResnetBlock.forward (vqvae_modules.py:103-123): GN+swish -> conv -> GN+swish -> conv, + (1x1-projected) input
   Act res(const ResP& r, const Act& x) {
-    Buf h = groupnorm(x.b, r.n1, x.nb, 1e-6f, CS_ACT_SILU, vq_groups(r.cin), r.c1);
+    // (x.d, x.h, x.w, r5: the Winograd-W operand where the conv takes that route -- decided by the sample geometry, vqvae.py)
+    Buf h = groupnorm(x.b, r.n1, x.nb, 1e-6f, CS_ACT_SILU, vq_groups(r.cin), r.c1, nullptr, x.d, x.h, x.w);
     // (want_stats: the conv's epilogue leaves the partial sums the next GroupNorm takes its statistics from -- vqvae.py::_res)
     Buf h1 = gemm(h, r.c1, x.nb, x.d, x.h, x.w, 1, 0, CS_ACT_NONE, nullptr, 0, 1, nullptr, 0, 0, 1, 0, /*want_stats=*/true);
     release(h);
-    Buf h2 = groupnorm(h1, r.n2, x.nb, 1e-6f, CS_ACT_SILU, vq_groups(r.cout), r.c2);
+    Buf h2 = groupnorm(h1, r.n2, x.nb, 1e-6f, CS_ACT_SILU, vq_groups(r.cout), r.c2, nullptr, x.d, x.h, x.w);
     release(h1);
     Buf skip = x.b;
     if (r.nin >= 0) skip = gemm(x.b, r.nin, x.nb, x.d, x.h, x.w);

@@ -139,6 +139,7 @@ SIGNATURES = {
     "cs_groupnorm_apply": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),
     "cs_groupnorm_apply_split16": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _fl, _f, _s]),
     "cs_groupnorm_apply_wino16": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _f, _s]),
+    "cs_groupnorm_apply_wino16_range": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _f, _s]),
     "cs_layernorm_pair16": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _fl, _fl, _f, _s]),
     "cs_groupnorm_apply_range": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _s]),
     "cs_groupnorm_apply_split16_range": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _f, _s]),

@@ -303,16 +303,19 @@ def _pack_weight_f16x3(w: Tensor, bias: Optional[Tensor], cin_pad: Optional[int]
     return PackedWeight(None, b, cout, cin, cp, cout, (kd, kh, kw), L.MATH_F16X3, wh, wl, 1.0 / (scale * A_SCALE))
 
 
-def pack_weight_wino(pw: PackedWeight, w: Tensor) -> PackedWeight:
+def pack_weight_wino(pw: PackedWeight, w: Tensor, amax: Optional[float] = None) -> PackedWeight:
     """Add the Winograd-W pack (CsConvGemm.a_format = 3, cs_pack_weight_f16x3_wino) to the F16X3 pack `pw` of the 3x3x3 conv
-    weight `w` -- where the geometry can ever take that route (cout % 224 == 0, cin % 8 == 0); the per-call decision is
-    cs_conv_wino_ok (wants_wino).  One power-of-two scale for the four positions: max |u_q| <= 1.5 max |w|."""
+    weight `w` -- where the geometry can ever take that route (a 224-column width, or the VQ decoder's 64 / multiples of
+    128; cin % 8 == 0); the per-call decision is cs_conv_wino_ok (wants_wino).  One power-of-two scale for the four
+    positions: max |u_q| <= 1.5 max |w|.  `amax`: the magnitude of the WHOLE tensor `w` is an input-channel slice of (the
+    channel-split convs: both hosts scale their halves by the whole tensor's maximum)."""
     import math as _m
     if (pw.math != L.MATH_F16X3 or pw.classes is not None or pw.tapcol is not None or w.dim() != 5
-            or tuple(w.shape[2:]) != (3, 3, 3) or pw.cout % 224 or pw.cin % 8 or pw.cin < 16):
+            or tuple(w.shape[2:]) != (3, 3, 3) or not (pw.cout % 224 == 0 or pw.cout % 128 == 0 or pw.cout == 64)
+            or pw.cin % 8 or pw.cin < 16):
         return pw
     w = w.contiguous()
-    amax = 1.5 * float(w.abs().max().item())
+    amax = 1.5 * (float(w.abs().max().item()) if amax is None else float(amax))
     e = _m.frexp(amax)[1] if amax > 0 and _m.isfinite(amax) else 0
     scale = 2.0 ** (14 - e)
     kg = (pw.cin + 15) // 16 * 2
@@ -1044,7 +1047,7 @@ def groupnorm_stats(x: Tensor, groups: int, eps: float, bound: Optional[Tensor] 
 
 
 def groupnorm_apply_range(x: Tensor, stats: Tensor, gamma: Tensor, beta: Tensor, cpg: int, ch0: int,
-                          act: int = L.ACT_NONE, split16: bool = False, a_scale: Optional[float] = None):
+                          act: int = L.ACT_NONE, split16: bool = False, a_scale: Optional[float] = None, wino: bool = False):
     """Normalise + affine + activation of a CHANNEL RANGE: x (and gamma / beta) hold channels ch0 .. ch0 + c of a tensor
     whose statistics `stats` [nb', groups, 2] were taken over groups of cpg channels (cs_groupnorm_apply_range); sample n
     of x uses stats[n].  split16=True returns the Split16 operand pair."""
@@ -1055,6 +1058,18 @@ def groupnorm_apply_range(x: Tensor, stats: Tensor, gamma: Tensor, beta: Tensor,
     if stats.shape[0] < nb or not stats.is_contiguous() or gamma.numel() != c or beta.numel() != c:
         raise L.CsError("groupnorm_apply_range: stats / gamma / beta do not match x")
     lib = L.load()
+    if wino and _sw("SPLIT16_PRODUCERS"):       # r5: the Winograd-W operand of the conv that reads it (x: [nb, d, h, w, c])
+        if x.dim() != 5 or int(x.shape[3]) % 2 or c % 8:
+            raise L.CsError("groupnorm_apply_range(wino=True) needs x as [nb, d, h, w, c] with even w and c % 8 == 0")
+        d_, h_, w_ = int(x.shape[1]), int(x.shape[2]), int(x.shape[3])
+        yh = torch.empty((4, nb, d_, h_, w_ // 2, c), dtype=torch.float16, device=x.device)
+        yl = torch.empty_like(yh)
+        a_sc = float(a_scale or A_SCALE) * 0.5
+        L.check(lib.cs_groupnorm_apply_wino16_range(x.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                                    yh.data_ptr(), yl.data_ptr(), nb, d_, h_, w_, c, ldx, c, groups, cpg,
+                                                    ch0, act, a_sc, status_word(x.device).data_ptr(), _stream()),
+                "cs_groupnorm_apply_wino16_range")
+        return Wino16(yh, yl, a_sc, (nb, d_, h_, w_))
     if split16 and _sw("SPLIT16_PRODUCERS"):
         yh = torch.empty(x.shape, dtype=torch.float16, device=x.device)
         yl = torch.empty(x.shape, dtype=torch.float16, device=x.device)

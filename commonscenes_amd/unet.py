@@ -406,6 +406,9 @@ class DiffusionUNet:
                     pk[q + name + ":h"] = ops.pack_weight(wfull[:, :ks].contiguous(), sd[q + name + ".bias"],
                                                           math=self.math, amax=am)
                     pk[q + name + ":s"] = ops.pack_weight(wfull[:, ks:].contiguous(), None, math=self.math, amax=am)
+                    if self.math == L.MATH_F16X3:     # r5: the halves' Winograd-W packs, scaled by the whole tensor's maximum
+                        ops.pack_weight_wino(pk[q + name + ":h"], wfull[:, :ks].contiguous(), amax=am)
+                        ops.pack_weight_wino(pk[q + name + ":s"], wfull[:, ks:].contiguous(), amax=am)
                 self._split_info[q] = (ks, ch_h)
         # all 17 ResBlock `emb_layers` Linears read the same SiLU(emb): one GEMM [B,896] x [896, sum(cout)]
         # instead of 17 launch-bound ones; each ResBlock takes its column slice as the conv's row vector.
@@ -567,17 +570,22 @@ class DiffusionUNet:
         wh, ws = pk[p + ".in_layers.2:h"], pk[p + ".in_layers.2:s"]
         stats = ops.groupnorm_stats(x, 32, 1e-5, bound=self._slot())
         s1 = self._nas(p + ".in_layers.0", rows * cpg)
-        a_h = ops.groupnorm_apply_range(x[..., :ks], stats, gam[:ks], bet[:ks], cpg, 0, L.ACT_SILU,
-                                        split16=ops.wants_split16(nbs * rows, wh), a_scale=s1)
+        # r5: where the halves' convs take the Winograd-W route (each launch covers nbs samples) their operands are emitted
+        # in that form -- the h half once per guidance half (a position image holds whole launches)
+        wn_h, wn_s = ops.wants_wino(nbs, d, h, w, wh), ops.wants_wino(nbs, d, h, w, ws)
+        a_h = None if wn_h else ops.groupnorm_apply_range(x[..., :ks], stats, gam[:ks], bet[:ks], cpg, 0, L.ACT_SILU,
+                                                          split16=ops.wants_split16(nbs * rows, wh), a_scale=s1)
         a_s = ops.groupnorm_apply_range(skip[..., off:], stats, gam[ks:], bet[ks:], cpg, ks, L.ACT_SILU,
-                                        split16=ops.wants_split16(nbs * rows, ws), a_scale=s1)
+                                        split16=ops.wants_split16(nbs * rows, ws), a_scale=s1, wino=wn_s)
         y_s = ops.conv_gemm(a_s, ws, math=self.math, a_scale=s1)
         lo, hi = self._emb_slices[p]
         cout = l["cout"]
         h1 = torch.empty((nb, d, h, w, cout), dtype=torch.float32, device=x.device)
         for g in range(nb // nbs):                    # one launch per guidance half: both read the shared term
             sl = slice(g * nbs, (g + 1) * nbs)
-            ops.conv_gemm(a_h[sl], wh, rowvec=semb[sl, lo:hi], rv_rows=rows, res=y_s, out=h1[sl], math=self.math,
+            a_g = a_h[sl] if a_h is not None else ops.groupnorm_apply_range(
+                x[sl][..., :ks], stats[sl], gam[:ks], bet[:ks], cpg, 0, L.ACT_SILU, a_scale=s1, wino=True)
+            ops.conv_gemm(a_g, wh, rowvec=semb[sl, lo:hi], rv_rows=rows, res=y_s, out=h1[sl], math=self.math,
                           a_scale=s1)
         # (the two launches write sample ranges of h1: its GroupNorm takes its statistics from a pass over the tensor)
         sk = ops.conv_gemm(x, pk[p + ".skip_connection"], math=self.math, x_bound=getattr(x, "cs_bound", None))

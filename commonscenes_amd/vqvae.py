@@ -174,6 +174,8 @@ class VQVAE:
                 fold = (1, 1, 1) if p.endswith(".upsample.conv") else None
                 pk[p] = ops.pack_weight(sd[k], sd.get(p + ".bias"), cin_pad=(cin + 3) // 4 * 4, math=self.math,
                                         fold_up=fold)
+                if fold is None and self.math == L.MATH_F16X3:      # r5: + the Winograd-W pack where the geometry allows
+                    ops.pack_weight_wino(pk[p], sd[k])
         a = "decoder.mid.attn_1."
         wqkv = torch.cat([sd[a + "q.weight"], sd[a + "k.weight"], sd[a + "v.weight"]], dim=0)
         bqkv = torch.cat([sd[a + "q.bias"], sd[a + "k.bias"], sd[a + "v.bias"]], dim=0)
@@ -199,15 +201,19 @@ class VQVAE:
         m = x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3]
         rows = m // x.shape[0]
         s1 = self._nas(p + ".norm1", rows * (c // _vq_groups(c)))
+        vol = tuple(int(v) for v in x.shape[:4])
+        # (r5: the Winograd-W operand where the conv takes that route -- decided per sample geometry, never by the batch)
         h = ops.groupnorm(x, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], _vq_groups(c), 1e-6, L.ACT_SILU,
-                          split16=ops.wants_split16(m, pk[p + ".conv1"]), a_scale=s1)
+                          split16=ops.wants_split16(m, pk[p + ".conv1"]), a_scale=s1,
+                          wino=ops.wants_wino(*vol, pk[p + ".conv1"]))
         # (stats="invariant", r5: the conv's epilogue leaves the partial sums norm2 takes its statistics from -- only where
         # the statistics tiles are the same for one object and for a slice of sixteen, see ops._epilogue_extras)
         h = ops.conv_gemm(h, pk[p + ".conv1"], math=self.math, a_scale=s1, stats="invariant")
         co = h.shape[-1]
         s2 = self._nas(p + ".norm2", rows * (co // _vq_groups(co)))
         h = ops.groupnorm(h, sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], _vq_groups(co), 1e-6, L.ACT_SILU,
-                          split16=ops.wants_split16(m, pk[p + ".conv2"]), a_scale=s2)
+                          split16=ops.wants_split16(m, pk[p + ".conv2"]), a_scale=s2,
+                          wino=ops.wants_wino(*vol, pk[p + ".conv2"]))
         skip = x if (p + ".nin_shortcut") not in pk else ops.conv_gemm(x, pk[p + ".nin_shortcut"], math=self.math)
         return ops.conv_gemm(h, pk[p + ".conv2"], res=skip, math=self.math, a_scale=s2, stats="invariant")
 

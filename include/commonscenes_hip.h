@@ -273,7 +273,9 @@ int cs_conv_gemm_launch_info(const CsConvGemm* desc, int32_t* tile, int32_t* sla
 int cs_conv_gemm_plan(const CsConvGemm* desc, int32_t* splitk, int64_t* splitk_ws_bytes);
 /* (ABI 16) Winograd-W route (CsConvGemm.a_format = 3).  cs_conv_wino_ok: 1 if cs_conv_gemm takes this 3x3x3 conv in that
  * form -- desc as the conv would be issued in DIRECT form (a_format / x / w are not looked at): CS_MATH_F16X3, 3x3x3,
- * stride 1, pad 1, no upsampling, even W with W / 2 <= 32, cout % 224 == 0, cin % 8 == 0, whole 256-row tiles per position,
+ * stride 1, pad 1, no upsampling, even W with W / 2 <= 32, cout % 224 == 0 (the UNet's widths: 256x224 tile) or cout % 128
+ * == 0 / cout == 64 (the VQ decoder's: 256x128 / 256x64 tiles, never K-sliced -- its results must not depend on the batch),
+ * cin % 8 == 0, whole 256-row tiles per position,
  * at least CsDebug.wino_min_rows output rows, CS_NO_WINO unset -- the ONE rule both hosts ask BEFORE they let the
  * GroupNorm emit the transformed operand.  cs_conv_wino_plan: the K slices of the position GEMMs (1 = none) and the bytes
  * of splitk_ws they need. */
@@ -383,6 +385,11 @@ int cs_groupnorm_apply_split16(const float* x, const float* stats, const float* 
 int cs_groupnorm_apply_wino16(const float* x, const float* stats, const float* gamma, const float* beta, void* v_hi,
                               void* v_lo, int nb, int d, int h, int w, int c, int ldx, int ldv, int groups, int act,
                               float a_scale, int32_t* status, cs_stream_t stream);
+/* ... and its channel-range form (see cs_groupnorm_apply_split16_range): channels ch0 .. ch0 + c of a tensor whose statistics
+ * were taken over `groups` groups of `cpg` channels; x, gamma, beta point AT channel ch0 (the channel-split ResBlocks). */
+int cs_groupnorm_apply_wino16_range(const float* x, const float* stats, const float* gamma, const float* beta, void* v_hi,
+                                    void* v_lo, int nb, int d, int h, int w, int c, int ldx, int ldv, int groups, int cpg,
+                                    int ch0, int act, float a_scale, int32_t* status, cs_stream_t stream);
 /* Channel-range forms of the two apply entries (ABI 11): the c channels handled are channels ch0 .. ch0 + c of a tensor
  * whose statistics were taken over `groups` groups of `cpg` channels (stats: [nb][groups][2]); x, gamma, beta and the
  * outputs point AT channel ch0 (ch0 % 4 == 0).  One statistics pass over a channel concatenation [h | skip]

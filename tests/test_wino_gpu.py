@@ -52,6 +52,9 @@ CASES = [
     (16, (16, 8, 8), 448, 448, "16x8x8 level"),
     (64, (16, 4, 4), 672, 672, "16x4x4 level at 32 objects: 384 position tiles -> two K slices"),
     (32, (16, 4, 4), 1344, 672, "16x4x4 level, concatenated input"),
+    (2, (32, 32, 32), 128, 128, "VQ decoder width 128 (256x128 tile), never K-sliced"),
+    (1, (32, 32, 64), 64, 64, "VQ decoder width 64 (256x64 tile), W / 2 = 32"),
+    (2, (16, 16, 16), 256, 128, "VQ decoder 256 -> 128"),
 ]
 
 
@@ -88,6 +91,8 @@ def test_winograd_conv_against_fp64_and_the_direct_form(case):
     assert ew < 1e-6 and ew < 2 * ed + 2e-7
     if "two K slices" in note:
         assert sk.value == 2 and wsb.value == 2 * 2 * nb * rows * cout * 4
+    if "VQ decoder" in note:
+        assert sk.value == 1
     # the GroupNorm partial sums its epilogue leaves == the direct form's route to the same statistics
     stw, std = getattr(yw, "cs_stats", None), getattr(yd, "cs_stats", None)
     assert stw is not None and std is not None
@@ -118,3 +123,37 @@ def test_the_rule_keeps_small_odd_and_unsupported_launches_on_the_direct_form():
     v = ops.groupnorm(x, torch.ones(224, device="cuda"), torch.zeros(224, device="cuda"), 32, 1e-5, L.ACT_SILU, wino=True)
     with pytest.raises(L.CsError):
         ops.conv_gemm(v, ops.pack_weight(wt, None, math=L.MATH_F16X3))
+
+
+def test_channel_range_form_feeds_the_halves_of_a_channel_split_conv():
+    """unet.py::_res_split: GroupNorm statistics over the whole concatenation, the two input-channel ranges normalised
+    separately (cs_groupnorm_apply_wino16_range) and convolved with the halves of the weight packed at the WHOLE tensor's
+    scale: their sum is the conv of the concatenation."""
+    from commonscenes_amd import lib as L, ops
+    nb, sp, C, ks, cout = 4, (16, 8, 8), 448, 224, 224
+    rows = sp[0] * sp[1] * sp[2]
+    x = _rand(nb, *sp, C, seed=31) * 1.3
+    g, b = _rand(C, seed=32) * 0.2 + 1.0, _rand(C, seed=33) * 0.2
+    wt = _rand(cout, C, 3, 3, 3, seed=34, scale=(C * 27) ** -0.5)
+    bias = _rand(cout, seed=35)
+    am = float(wt.abs().max())
+    wh = ops.pack_weight(wt[:, :ks].contiguous(), bias, math=L.MATH_F16X3, amax=am)
+    ws = ops.pack_weight(wt[:, ks:].contiguous(), None, math=L.MATH_F16X3, amax=am)
+    ops.pack_weight_wino(wh, wt[:, :ks].contiguous(), amax=am)
+    ops.pack_weight_wino(ws, wt[:, ks:].contiguous(), amax=am)
+    assert wh.wino is not None and ws.wino is not None and wh.wino[2] == ws.wino[2]
+    stats = ops.groupnorm_stats(x, 32, 1e-5)
+    cpg = C // 32
+    s1 = ops.norm_a_scale(float(g.abs().max()), float(b.abs().max()), rows * cpg)
+    a_s = ops.groupnorm_apply_range(x[..., ks:], stats, g[ks:], b[ks:], cpg, ks, L.ACT_SILU, a_scale=s1, wino=True)
+    y_s = ops.conv_gemm(a_s, ws)
+    y = torch.empty(nb, *sp, cout, device="cuda")
+    for half in range(2):                         # per sample range, as the guidance halves are
+        sl = slice(2 * half, 2 * half + 2)
+        a_h = ops.groupnorm_apply_range(x[sl][..., :ks], stats[sl], g[:ks], b[:ks], cpg, 0, L.ACT_SILU, a_scale=s1, wino=True)
+        assert isinstance(a_h, ops.Wino16)
+        ops.conv_gemm(a_h, wh, res=y_s[sl], out=y[sl])
+    torch.cuda.synchronize()
+    ref = F.conv3d(_ref_gn_silu(x, g, b).permute(0, 4, 1, 2, 3), wt.double(), bias.double(), padding=1).permute(0, 2, 3, 4, 1)
+    assert rel_l2(y, ref) < 1e-6
+    ops.check_overflow()
