@@ -786,7 +786,8 @@ def _conv_wino(xw: "Wino16", w: PackedWeight, act, rowvec, rv_rows, res, scale, 
         # flops = what the position GEMMs EXECUTE (18 of the direct form's 27 multiply-adds per output); flops_direct = the
         # direct form's algorithmic work the pair of launches replaces; m / k = the position launch's own GEMM shape
         prof.append(dict(e0=e0, e1=e1, e2=e2, flops=2.0 * mo * w.cout * w.cin * 18, flops_direct=2.0 * mo * w.cout * w.cin * 27,
-                         taps=9, m=2 * mo, n=w.cout, k=w.cin * 9, tile=4, slab=32, pre=True, pair=False,
+                         taps=9, m=2 * mo, n=w.cout, k=w.cin * 9,
+                         tile=4 if w.cout % 224 == 0 else 6 if w.cout % 128 == 0 else 7, slab=32, pre=True, pair=False,
                          res=res is not None, wino=True, slices=int(sk.value)))
     if paired:
         return Pair16(out, float(out_pair))

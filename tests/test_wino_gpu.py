@@ -52,9 +52,10 @@ CASES = [
     (16, (16, 8, 8), 448, 448, "16x8x8 level"),
     (64, (16, 4, 4), 672, 672, "16x4x4 level at 32 objects: 384 position tiles -> two K slices"),
     (32, (16, 4, 4), 1344, 672, "16x4x4 level, concatenated input"),
-    (2, (32, 32, 32), 128, 128, "VQ decoder width 128 (256x128 tile), never K-sliced"),
-    (1, (32, 32, 64), 64, 64, "VQ decoder width 64 (256x64 tile), W / 2 = 32"),
-    (2, (16, 16, 16), 256, 128, "VQ decoder 256 -> 128"),
+    (8, (16, 16, 16), 128, 128, "VQ decoder width 128 (256x128 tile), never K-sliced"),
+    (4, (16, 16, 16), 64, 64, "VQ decoder width 64 (256x64 tile)"),
+    (2, (16, 16, 16), 256, 256, "VQ decoder 256 -> 256 at its 16^3 level"),
+    (2, (4, 8, 64), 224, 224, "lines of 64 voxels: W / 2 = 32, the slab's widest line"),
 ]
 
 
@@ -116,6 +117,9 @@ def test_the_rule_keeps_small_odd_and_unsupported_launches_on_the_direct_form():
         assert not ops.wants_wino(4, 16, 16, 16, pw)
     with L.debug_override(wino_min_rows=16384):
         assert ops.wants_wino(4, 16, 16, 16, pw) and not ops.wants_wino(2, 16, 16, 16, pw)
+    w128 = _rand(128, 128, 3, 3, 3, seed=24, scale=0.02)     # the VQ decoder's widths: at its 16^3 level only
+    p128 = ops.pack_weight_wino(ops.pack_weight(w128, None, math=L.MATH_F16X3), w128)
+    assert ops.wants_wino(1, 16, 16, 16, p128) and ops.wants_wino(16, 16, 16, 16, p128) and not ops.wants_wino(2, 32, 32, 32, p128)
     w96 = _rand(96, 224, 3, 3, 3, seed=22, scale=0.02)       # not a 224-column width: no Winograd pack at all
     assert ops.pack_weight_wino(ops.pack_weight(w96, None, math=L.MATH_F16X3), w96).wino is None
     # a Wino16 operand on a weight without the pack is an error, not a silent fall-back
