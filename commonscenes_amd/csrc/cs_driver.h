@@ -54,6 +54,9 @@ struct Gemm {        // one packed GEMM weight (possibly several reference tenso
   // position images, one power-of-two scale; -1 = the geometry can never take that route
   int64_t wino_off = -1, wino_lo_off = -1;
   float wino_acc = 1.f;
+  // ... and its F(4,3) sibling (six images; the UNet's 224-column widths only): CsConvGemm.a_format = 4
+  int64_t wino4_off = -1, wino4_lo_off = -1;
+  float wino4_acc = 1.f;
 };
 
 struct Norm {
@@ -236,6 +239,13 @@ void layout_arena(Plan& u) {
         off += align_up(wimg);
         g.wino_lo_off = off;
         off += align_up(wimg);
+        if (g.cout % 224 == 0) {
+          const int64_t wimg4 = 6LL * 9 * kg * g.cout * 16;
+          g.wino4_off = off;
+          off += align_up(wimg4);
+          g.wino4_lo_off = off;
+          off += align_up(wimg4);
+        }
       }
     } else {
       g.ldw = (g.cout + 3) / 4 * 4;
@@ -321,10 +331,12 @@ __global__ __launch_bounds__(256) void pack_part_f16x3_kernel(const float* __res
 // arithmetic -- u_q over the kw taps formed and split in fp64 -- on a (cout, src_cin, 27) source tensor
 __global__ __launch_bounds__(256) void pack_part_f16x3_wino_kernel(const float* __restrict__ w, _Float16* __restrict__ wh,
                                                                    _Float16* __restrict__ wl, int cout, int cin,
-                                                                   int kg_per_tap, float scale, int src_cin, int c0) {
+                                                                   int kg_per_tap, float scale, int src_cin, int c0,
+                                                                   int variant) {
   if (src_cin == 0) src_cin = cin;
   const int64_t per = 9LL * kg_per_tap * cout * 8;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < 4 * per; i += (int64_t)gridDim.x * blockDim.x) {
+  const int np = variant + 2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < np * per; i += (int64_t)gridDim.x * blockDim.x) {
     const int q = (int)(i / per);
     int64_t t = i - q * per;
     const int j = (int)(t & 7);
@@ -338,7 +350,11 @@ __global__ __launch_bounds__(256) void pack_part_f16x3_wino_kernel(const float* 
     if (c < cin) {
       const float* g = w + ((int64_t)n * src_cin + c0 + c) * 27 + tap * 3;
       const double g0 = g[0], g1 = g[1], g2 = g[2];
-      u = q == 0 ? g0 : q == 1 ? 0.5 * (g0 + g1 + g2) : q == 2 ? 0.5 * (g0 - g1 + g2) : g2;
+      if (variant == 4)
+        u = q == 0 ? g0 / 4.0 : q == 1 ? -(g0 + g1 + g2) / 6.0 : q == 2 ? (-g0 + g1 - g2) / 6.0
+            : q == 3 ? g0 / 24.0 + g1 / 12.0 + g2 / 6.0 : q == 4 ? g0 / 24.0 - g1 / 12.0 + g2 / 6.0 : g2;
+      else
+        u = q == 0 ? g0 : q == 1 ? 0.5 * (g0 + g1 + g2) : q == 2 ? 0.5 * (g0 - g1 + g2) : g2;
     }
     const double v = u * (double)scale;
     const _Float16 h = (_Float16)v;
@@ -523,16 +539,20 @@ int pack_plan(Plan* u, const void* raw_dev, void* arena_dev, cs_stream_t stream)
     }
     if (n_off != g.cout) return CS_EINVAL;
     if (f16 && g.wino_off >= 0) {      // r5: the Winograd-W pack (max |u_q| <= 1.5 max |w|: ops.py::pack_weight_wino)
-      const double m = 1.5 * (double)amax[(size_t)g.w[0].param];
-      int ex = 0;
-      if (m > 0.0 && std::isfinite(m)) (void)std::frexp(m, &ex);
-      const float wscale = (float)std::ldexp(1.0, 14 - ex);
-      g.wino_acc = 1.0f / (wscale * 16.0f);
       const int kg = (g.cin + 15) / 16 * 2;
-      CS_LAUNCH(pack_part_f16x3_wino_kernel, dim3(cs_grid_for(4LL * 9 * kg * g.cout * 8, 256, 256 * 32)), dim3(256), 0, st,
-                src(g.w[0].param), (_Float16*)(arena + g.wino_off), (_Float16*)(arena + g.wino_lo_off), g.cout, g.cin, kg,
-                wscale, g.src_cin, g.c0);
-      CS_CHECK_LAUNCH();
+      for (int variant = 2; variant <= (g.wino4_off >= 0 ? 4 : 2); variant += 2) {
+        // (max |u_q| <= 1.5 max |w| for F(2,3), <= max |w| for F(4,3): ops.py::pack_weight_wino)
+        const double m = (variant == 2 ? 1.5 : 1.0) * (double)amax[(size_t)g.w[0].param];
+        int ex = 0;
+        if (m > 0.0 && std::isfinite(m)) (void)std::frexp(m, &ex);
+        const float wscale = (float)std::ldexp(1.0, 14 - ex);
+        (variant == 2 ? g.wino_acc : g.wino4_acc) = 1.0f / (wscale * 16.0f);
+        CS_LAUNCH(pack_part_f16x3_wino_kernel, dim3(cs_grid_for((variant + 2LL) * 9 * kg * g.cout * 8, 256, 256 * 32)), dim3(256),
+                  0, st, src(g.w[0].param), (_Float16*)(arena + (variant == 2 ? g.wino_off : g.wino4_off)),
+                  (_Float16*)(arena + (variant == 2 ? g.wino_lo_off : g.wino4_lo_off)), g.cout, g.cin, kg, wscale, g.src_cin,
+                  g.c0, variant);
+        CS_CHECK_LAUNCH();
+      }
     }
     n_off = 0;
     for (const Piece& pc : g.b) {
@@ -581,8 +601,9 @@ struct Buf {
                        // same footprint as fp32 [rows][c]
   bool pair = false;   // the INTERLEAVED operand pair (CsConvGemm.a_format = 2): bytes / row stride of fp32 [rows][c],
                        // written by cs_layernorm_pair16
-  bool wino = false;   // r5: the Winograd-W operand (CsConvGemm.a_format = 3): fp16 hi images [4][rows / 4][c] followed by
-                       // the lo images -- `rows` = 2 x the volume's voxels (the footprint of fp32 [rows][c])
+  int wino = 0;        // r5: the Winograd-W operand (CsConvGemm.a_format = 3 / 4), the variant (2 = F(2,3), 4 = F(4,3)): fp16 hi
+                       // images [variant + 2][voxels / variant][c] followed by the lo images -- `rows` = (variant + 2) /
+                       // variant x the volume's voxels
   float a_scale = 16.f;   // F16X3 operand scale a GEMM reading this buffer uses: the default for activations of unknown
                           // range, the producer's bound for normalisation outputs (norm_a_scale)
 };
@@ -738,8 +759,9 @@ struct ExecBase {
     const int ocols = act == CS_ACT_GEGLU ? g.cout / 2 : g.cout;
     Buf out = alloc(mo, ocols);
     if (!ok()) return out;
-    if (x.c != g.cin_pad || x.rows != (x.wino ? 2 : 1) * (int64_t)nb * d * h * w ||
-        (x.wino && (g.wino_off < 0 || k != 3 || s_hw != 1 || s_d != 1 || up_hw || up_d || tile || a_bound_off >= 0))) {
+    if (x.c != g.cin_pad || x.rows != (x.wino ? wino_rows(x.wino, (int64_t)nb * d * h * w) : (int64_t)nb * d * h * w) ||
+        (x.wino && ((x.wino == 4 ? g.wino4_off : g.wino_off) < 0 || k != 3 || s_hw != 1 || s_d != 1 || up_hw || up_d || tile ||
+                    a_bound_off >= 0))) {
       chk(CS_EINVAL);
       return out;
     }
@@ -747,17 +769,17 @@ struct ExecBase {
     memset(&q, 0, sizeof(q));
     // (the operand format is part of what the tile rule looks at: set in the sizing pass too, so that both passes ask
     // cs_conv_gemm_epilogue_caps about the same launch)
-    q.a_format = x.wino ? 3 : x.half ? 1 : x.pair ? 2 : 0;
+    q.a_format = x.wino == 4 ? 4 : x.wino ? 3 : x.half ? 1 : x.pair ? 2 : 0;
     if (!dry) {
       q.x = p(x);
       if (x.half) q.x_lo = reinterpret_cast<const char*>(p(x)) + x.rows * x.c * 2;
-      if (x.wino) q.x_lo = reinterpret_cast<const char*>(p(x)) + x.rows * x.c * 2;      // (rows = 2 M: the hi images' bytes)
+      if (x.wino) q.x_lo = reinterpret_cast<const char*>(p(x)) + x.rows * x.c * 2;      // (the hi images' bytes)
       q.out = p(out);
-      q.w = reinterpret_cast<const float*>(arena + (x.wino ? g.wino_off : g.w_off));
+      q.w = reinterpret_cast<const float*>(arena + (x.wino == 4 ? g.wino4_off : x.wino ? g.wino_off : g.w_off));
       if (pl.math == CS_MATH_F16X3) {
-        q.w_lo = arena + (x.wino ? g.wino_lo_off : g.wlo_off);
+        q.w_lo = arena + (x.wino == 4 ? g.wino4_lo_off : x.wino ? g.wino_lo_off : g.wlo_off);
         // g.acc_scale = 1 / (weight scale * 16); powers of two
-        q.acc_scale = (x.wino ? g.wino_acc : g.acc_scale) * (16.0f / x.a_scale);
+        q.acc_scale = (x.wino == 4 ? g.wino4_acc : x.wino ? g.wino_acc : g.acc_scale) * (16.0f / x.a_scale);
         q.a_scale = x.a_scale;
       }
       q.bias = (g.b_off >= 0 && !tc) ? wf(g.b_off) : nullptr;
@@ -857,15 +879,15 @@ struct ExecBase {
   // wino (r5): x / x_lo are the hi / lo images of a Winograd-W operand (Buf::wino) of the [nb, d, h, w] volume
   void gemm_view(const float* x, const void* x_lo, int lda, int gi, int nb, int d, int h, int w, float* out, int ldo,
                  const float* rowvec = nullptr, int ldrv = 0, int rv_rows = 1, const float* res = nullptr, int ldr = 0,
-                 float a_scale = 16.f, bool wino = false) {
+                 float a_scale = 16.f, int wino = 0) {
     const Gemm& g = pl.gemms[gi];
     CsConvGemm q;
     memset(&q, 0, sizeof(q));
-    if (wino && (g.wino_off < 0 || g.k != 3 || pl.math != CS_MATH_F16X3)) {
+    if (wino && ((wino == 4 ? g.wino4_off : g.wino_off) < 0 || g.k != 3 || pl.math != CS_MATH_F16X3)) {
       chk(CS_EINVAL);
       return;
     }
-    if (wino) q.a_format = 3;
+    if (wino) q.a_format = wino == 4 ? 4 : 3;
     if (!dry) {
       q.x = x;
       if (x_lo) {
@@ -873,10 +895,10 @@ struct ExecBase {
         if (!wino) q.a_format = 1;
       }
       q.out = out;
-      q.w = reinterpret_cast<const float*>(arena + (wino ? g.wino_off : g.w_off));
+      q.w = reinterpret_cast<const float*>(arena + (wino == 4 ? g.wino4_off : wino ? g.wino_off : g.w_off));
       if (pl.math == CS_MATH_F16X3) {
-        q.w_lo = arena + (wino ? g.wino_lo_off : g.wlo_off);
-        q.acc_scale = (wino ? g.wino_acc : g.acc_scale) * (16.0f / a_scale);
+        q.w_lo = arena + (wino == 4 ? g.wino4_lo_off : wino ? g.wino_lo_off : g.wlo_off);
+        q.acc_scale = (wino == 4 ? g.wino4_acc : wino ? g.wino_acc : g.acc_scale) * (16.0f / a_scale);
         q.a_scale = a_scale;
       }
       q.bias = g.b_off >= 0 ? wf(g.b_off) : nullptr;
@@ -1042,23 +1064,23 @@ struct ExecBase {
   }
   // GroupNorm apply of channels [ch0, ch0 + c) (x already points at channel ch0, row stride ldx) -> a fresh [rows][c]
   // buffer, fp32 or the pre-split pair depending on the consuming conv
-  // vd > 0 (r5): emit the Winograd-W operand of the [nb, vd, vh, vw] volume instead (the caller asked wants_wino);
+  // variant > 0 (r5): emit the Winograd-W operand of the [nb, vd, vh, vw] volume instead (what wants_wino answered);
   // stats_off: first sample's offset (in samples) into `stats`
   Buf gn_apply_range(const float* x, int ldx, int64_t rows_total, int nb, const Buf& stats, int ni, int groups, int cpg,
-                     int ch0, int c, int act, int conv_gi, int64_t m_launch, int vd = 0, int vh = 0, int vw = 0,
+                     int ch0, int c, int act, int conv_gi, int64_t m_launch, int variant = 0, int vd = 0, int vh = 0, int vw = 0,
                      int64_t stats_off = 0) {
     const Norm& n = pl.norms[ni];
-    Buf y = alloc(vd > 0 ? 2 * rows_total : rows_total, c);
+    Buf y = alloc(variant ? wino_rows(variant, rows_total) : rows_total, c);
     const int rows = (int)(rows_total / nb);
     if (pl.math == CS_MATH_F16X3) y.a_scale = norm_a_scale(n.gmax, n.bmax, (int64_t)rows * cpg);
-    if (vd > 0) {
-      y.wino = true;
-      y.a_scale *= 0.5f;
+    if (variant) {
+      y.wino = variant;
+      y.a_scale *= variant == 2 ? 0.5f : 0.0625f;
       if (ok() && !dry) {
         char* vhi = reinterpret_cast<char*>(p(y));
-        chk(cs_groupnorm_apply_wino16_range(x, p(stats) + stats_off * groups * 2, wf(n.g_off) + ch0, wf(n.b_off) + ch0, vhi,
-                                            vhi + rows_total * c * 4, nb, vd, vh, vw, c, ldx, c, groups, cpg, ch0, act,
-                                            y.a_scale, status, st));
+        chk(cs_groupnorm_apply_wino_range(x, p(stats) + stats_off * groups * 2, wf(n.g_off) + ch0, wf(n.b_off) + ch0, vhi,
+                                          vhi + y.rows * c * 2, nb, vd, vh, vw, c, ldx, c, groups, cpg, ch0, act, y.a_scale,
+                                          variant, status, st));
       }
       return y;
     }
@@ -1119,10 +1141,11 @@ struct ExecBase {
 
   // r5: does the GroupNorm feeding the 3x3x3 conv `gi` over an [nb, d, h, w] volume emit the Winograd-W operand?
   // (cs_conv_wino_ok: the one rule; ops.py::wants_wino)
-  bool wants_wino(int gi, int nb, int d, int h, int w) const {
-    if (gi < 0 || d <= 0 || pl.math != CS_MATH_F16X3 || cs_debug()->no_split16) return false;
+  // (the variant: 0 = direct form, 2 = F(2,3), 4 = F(4,3))
+  int wants_wino(int gi, int nb, int d, int h, int w) const {
+    if (gi < 0 || d <= 0 || pl.math != CS_MATH_F16X3 || cs_debug()->no_split16) return 0;
     const Gemm& g = pl.gemms[gi];
-    if (g.wino_off < 0) return false;
+    if (g.wino_off < 0) return 0;
     CsConvGemm q;
     memset(&q, 0, sizeof(q));
     q.nb = nb; q.din = q.dout = d; q.hin = q.hout = h; q.win = q.wout = w;
@@ -1130,17 +1153,21 @@ struct ExecBase {
     q.kd = q.kh = q.kw = 3;
     q.sd = q.sh = q.sw = q.pd = q.ph = q.pw = 1;
     q.math = pl.math; q.rv_rows = 1;
-    return cs_conv_wino_ok(&q) != 0;
+    const int v = cs_conv_wino_ok(&q);
+    return v == 4 ? (g.wino4_off >= 0 ? 4 : 2) : v;
   }
+  // rows of the Buf that holds variant v's operand of a volume of `voxels` rows
+  static int64_t wino_rows(int v, int64_t voxels) { return voxels / v * (v + 2); }
   // GroupNorm + activation emitted as the Winograd-W operand (y: 2 * x.rows "rows", see Buf::wino) at HALF the
   // normalisation's operand scale (ops.py::groupnorm wino=True)
-  void emit_wino(const Buf& x, const Norm& n, const Buf& stats, Buf& y, int nb, int d, int h, int w, int groups, int act) {
-    y.wino = true;
-    y.a_scale *= 0.5f;
+  void emit_wino(const Buf& x, const Norm& n, const Buf& stats, Buf& y, int nb, int d, int h, int w, int groups, int act,
+                 int variant) {
+    y.wino = variant;
+    y.a_scale *= variant == 2 ? 0.5f : 0.0625f;      // |transformed| <= 2 x resp. 10 x the activation's bound
     if (ok() && !dry) {
       char* vh = reinterpret_cast<char*>(p(y));
-      chk(cs_groupnorm_apply_wino16(p(x), p(stats), wf(n.g_off), wf(n.b_off), vh, vh + x.rows * x.c * 4, nb, d, h, w, x.c, x.c,
-                                    x.c, groups, act, y.a_scale, status, st));
+      chk(cs_groupnorm_apply_wino_range(p(x), p(stats), wf(n.g_off), wf(n.b_off), vh, vh + y.rows * x.c * 2, nb, d, h, w, x.c,
+                                        x.c, x.c, groups, x.c / groups, 0, act, y.a_scale, variant, status, st));
     }
   }
 
@@ -1151,8 +1178,8 @@ struct ExecBase {
   Buf groupnorm(const Buf& x, int ni, int nb, float eps, int act, int groups = 32, int conv_gi = -1,
                 int64_t* bound_off = nullptr, int vd = 0, int vh = 0, int vw = 0) {
     const Norm& n = pl.norms[ni];
-    const bool wn = wants_wino(conv_gi, nb, vd, vh, vw);
-    Buf y = alloc(wn ? 2 * x.rows : x.rows, x.c);
+    const int wn = wants_wino(conv_gi, nb, vd, vh, vw);
+    Buf y = alloc(wn ? wino_rows(wn, x.rows) : x.rows, x.c);
     if (bound_off) *bound_off = -1;
     if (has_parts(x)) {      // r4: statistics from the producers' partials, the tensor is read once (ops.py::groupnorm)
       const int64_t boff = bound_off ? amax_slot() : -1;
@@ -1162,7 +1189,7 @@ struct ExecBase {
       const int rows = (int)(x.rows / nb);
       if (wn) {
         finalize_parts(x, nb, eps, groups, stats, boff);
-        emit_wino(x, n, stats, y, nb, vd, vh, vw, groups, act);
+        emit_wino(x, n, stats, y, nb, vd, vh, vw, groups, act, wn);
       } else if (wants_split16(x.rows, conv_gi)) {
         y.half = true;
         finalize_parts(x, nb, eps, groups, stats, boff);
@@ -1188,7 +1215,7 @@ struct ExecBase {
     if (pl.math == CS_MATH_F16X3) y.a_scale = norm_a_scale(n.gmax, n.bmax, (x.rows / nb) * (int64_t)(x.c / groups));
     if (wn) {
       stats_pass(x, nb, eps, groups, wsb, stats, boff);
-      emit_wino(x, n, stats, y, nb, vd, vh, vw, groups, act);
+      emit_wino(x, n, stats, y, nb, vd, vh, vw, groups, act, wn);
       release(wsb);
       release(stats);
       return y;

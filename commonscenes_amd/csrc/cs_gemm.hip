@@ -384,7 +384,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const CsConvGemm p, 
 // pair m >> 1, parity m & 1 (W is even): even rows m0 + m1 + m2, odd rows m1 - m2 - m3, each position summed over its K
 // slices in slice order first.  The rest of the kernel -- epilogue terms, partial sums, pair output -- is shared.
 constexpr int SKR = 16;
-template <bool WINO>
+// WINO = 4: F(4,3) -- ws [slice][6][M / 4][cout], output row m = tile m >> 2, element m & 3: (A^T m)_e with A^T rows
+// [1,1,1,1,1,0], [0,1,-1,2,-2,0], [0,1,1,4,4,0], [0,1,-1,8,-8,1], summed in that order.
+template <int WINO>
 __global__ __launch_bounds__(256) void splitk_reduce_epi_kernel(const CsConvGemm p, const float* __restrict__ ws, int M,
                                                                 int splits) {
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -405,7 +407,34 @@ __global__ __launch_bounds__(256) void splitk_reduce_epi_kernel(const CsConvGemm
     const bool ok = nok && m < M;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (ok) {
-      if constexpr (WINO) {
+      if constexpr (WINO == 4) {
+        const int64_t quarter = (int64_t)(M >> 2) * p.cout, sstride = 6 * quarter;
+        const float* b = ws + (int64_t)(m >> 2) * p.cout + n;
+        auto pos = [&](int q) {
+          f32x4 t = *reinterpret_cast<const f32x4*>(b + q * quarter);
+          for (int sl = 1; sl < splits; ++sl) t += *reinterpret_cast<const f32x4*>(b + q * quarter + sl * sstride);
+          return t;
+        };
+        const int e = m & 3;
+        const f32x4 m1 = pos(1), m2 = pos(2), m3 = pos(3), m4 = pos(4);
+        if (e == 0) {
+          v = pos(0);
+          v += m1;
+          v += m2;
+          v += m3;
+          v += m4;
+        } else if (e == 1) {
+          v = m1 - m2;
+          v += 2.f * (m3 - m4);
+        } else if (e == 2) {
+          v = m1 + m2;
+          v += 4.f * (m3 + m4);
+        } else {
+          v = m1 - m2;
+          v += 8.f * (m3 - m4);
+          v += pos(5);
+        }
+      } else if constexpr (WINO == 2) {
         const int64_t half = (int64_t)(M >> 1) * p.cout, sstride = 4 * half;
         const float* b = ws + (int64_t)(m >> 1) * p.cout + n;
         auto pos = [&](int q) {
@@ -563,7 +592,7 @@ extern "C" int cs_conv_gemm_epilogue_caps(const CsConvGemm* d, int32_t* gn_rows,
     if (gn_rows && rps % bm == 0 && p.act != CS_ACT_GEGLU) *gn_rows = bm;
     return CS_OK;                                            // (no pair output from the scattered store)
   }
-  if (p.splitk > 1 || p.a_format == 3) {        // (a_format = 3: the Winograd-W output transform runs in the reduce kernel)
+  if (p.splitk > 1 || p.a_format == 3 || p.a_format == 4) {     // (a_format = 3 / 4: the Winograd-W output transform runs in the reduce kernel)
     if (gn_rows && rps % SKR == 0 && p.act != CS_ACT_GEGLU) *gn_rows = SKR;
     if (pair_ok && pair_geom && p.act != CS_ACT_GEGLU) *pair_ok = 1;
     return CS_OK;
@@ -738,7 +767,11 @@ static int fused_reduce_plan(const CsConvGemm& p, int M, int stile) {
 // tile of the position GEMMs by output width: 256x224 (the UNet's widths), 256x128 / 256x64 (the VQ decoder's), 0 = none
 static int wino_tile(int cout) { return cout % 224 == 0 ? 4 : cout % 128 == 0 ? 6 : cout == 64 ? 7 : 0; }
 
-static bool wino_ok(const CsConvGemm& p) {
+// the variant of the Winograd-W route this conv takes: 0 = none (direct form), 2 = F(2,3), 4 = F(4,3)
+static int wino_variant(const CsConvGemm& p);
+static bool wino_ok(const CsConvGemm& p) { return wino_variant(p) != 0; }
+// F(2,3): the conditions of the route as such
+static bool wino23_ok(const CsConvGemm& p) {
   const CsDebug* dbg = cs_debug();
   if (dbg->no_wino || p.math != CS_MATH_F16X3 || p.act == CS_ACT_GEGLU) return false;
   if (!(p.kd == 3 && p.kh == 3 && p.kw == 3 && p.sd == 1 && p.sh == 1 && p.sw == 1 && p.pd == 1 && p.ph == 1 && p.pw == 1) ||
@@ -757,6 +790,19 @@ static bool wino_ok(const CsConvGemm& p) {
   if ((512 + 2LL * p.hin * (p.win / 2) + p.win + 32) * p.lda * 4 >= 0x7FF00000LL) return false;
   return true;
 }
+// F(4,3) (a_format = 4): six positions over M / 4 rows -- 13.5 of 27 multiply-adds, 1.5x (not 2x) operand / result passes, ~2x
+// the direct form's rounding error (6e-7 - 8e-7 per conv, profiles/r05_z_wino43_numerics.txt): the UNet's widths only, W % 4
+// == 0, whole 256-row tiles per position, from CsDebug.wino43_min_rows rows
+static int wino_variant(const CsConvGemm& p) {
+  if (!wino23_ok(p)) return 0;
+  const CsDebug* dbg = cs_debug();
+  const int64_t M = (int64_t)p.nb * p.dout * p.hout * p.wout;
+  const int64_t min43 = dbg->wino43_min_rows > 0 ? dbg->wino43_min_rows : 4096;
+  if (!dbg->no_wino43 && p.cout % 224 == 0 && p.win % 4 == 0 && (M / 4) % 256 == 0 && M >= min43) return 4;
+  return 2;
+}
+// positions / outputs per tile of a variant
+static inline int wino_pos(int variant) { return variant + 2; }
 
 // K slices of the position GEMMs: their launch is 4 x (M / 512) x (cout / 224) workgroups of the 256x224 tile, one per CU.
 // A small cost model in microseconds picks the slice count (whole super-chunks, padding <= 10 %, >= 2 super-chunks per
@@ -765,15 +811,15 @@ static bool wino_ok(const CsConvGemm& p) {
 // level of 32 objects -> two slices (three even rounds, as the direct form's four-way cut); 448 tiles (the 16^3 level at
 // 14 objects) -> one (the efficiency-only rule of the first version took four slices there and LOST 30 % to the direct
 // form, profiles/r05_r_wino_bench_small.txt).
-static int wino_splits(const CsConvGemm& p) {
+static int wino_splits(const CsConvGemm& p, int variant) {
   // (the VQ decoder's widths are never K-sliced: a slice count that followed the batch would cost the decoder its bit-exact
   // batch invariance, tests/test_model_gpu.py::test_vq_decode_batch_invariance)
   if (p.cout % 224) return 1;
   const int64_t M = (int64_t)p.nb * p.dout * p.hout * p.wout;
-  const int64_t tiles = 4 * (M / 512) * (p.cout / 224);
+  const int64_t tiles = wino_pos(variant) * (M / variant / 256) * (p.cout / 224);
   const int64_t cus = device_cus() > 0 ? device_cus() : 256;
   const int64_t nsc = 3LL * ((p.cin + 15) / 16);
-  const double mb = 2.0 * (double)M * p.cout * 4.0 / 1e6;            // one slice's position results
+  const double mb = (double)wino_pos(variant) / variant * (double)M * p.cout * 4.0 / 1e6;      // one slice's position results
   int best = 1;
   double best_t = 0;
   for (int sp = 1; sp <= 16; ++sp) {
@@ -791,14 +837,23 @@ static int wino_splits(const CsConvGemm& p) {
   return best;
 }
 
-extern "C" int cs_conv_wino_ok(const CsConvGemm* d) { return (d && d->nb > 0 && d->cout > 0 && wino_ok(*d)) ? 1 : 0; }
+extern "C" int cs_conv_wino_ok(const CsConvGemm* d) { return (d && d->nb > 0 && d->cout > 0) ? wino_variant(*d) : 0; }
+
+// the variant a descriptor asks for (a_format 3 / 4), 0 if this conv may not take it
+static int wino_asked(const CsConvGemm& p) {
+  const int v = p.a_format == 4 ? 4 : 2;
+  const int best = wino_variant(p);
+  return (best == 0 || v > best) ? 0 : v;          // (F(2,3) stays valid where F(4,3) is granted)
+}
 
 extern "C" int cs_conv_wino_plan(const CsConvGemm* d, int32_t* splitk, int64_t* ws_bytes) {
-  if (!d || !splitk || !wino_ok(*d)) return CS_EINVAL;
-  const int sp = wino_splits(*d);
+  if (!d || !splitk) return CS_EINVAL;
+  const int v = wino_asked(*d);
+  if (!v) return CS_EINVAL;
+  const int sp = wino_splits(*d, v);
   *splitk = sp;
   const int64_t M = (int64_t)d->nb * d->dout * d->hout * d->wout;
-  if (ws_bytes) *ws_bytes = (int64_t)sp * 2 * M * d->cout * 4;
+  if (ws_bytes) *ws_bytes = (int64_t)sp * wino_pos(v) * (M / v) * d->cout * 4;
   return CS_OK;
 }
 
@@ -806,7 +861,8 @@ extern "C" int cs_conv_wino_plan(const CsConvGemm* d, int32_t* splitk, int64_t* 
 // phases: bit 0 = the position GEMMs, bit 1 = output transform + epilogue (cs_conv_gemm: both)
 static int conv_wino(const CsConvGemm& p, int M, hipStream_t s, int phases = 3) {
   auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
-  if (!wino_ok(p) || !p.x_lo || !al16(p.x_lo) || !p.w_lo || !al16(p.w_lo) || (p.lda & 7) || !p.splitk_ws || !al16(p.splitk_ws) ||
+  const int v = wino_asked(p), np = wino_pos(v);
+  if (!v || !p.x_lo || !al16(p.x_lo) || !p.w_lo || !al16(p.w_lo) || (p.lda & 7) || !p.splitk_ws || !al16(p.splitk_ws) ||
       p.a_bound || !(p.acc_scale > 0.f))
     return CS_EINVAL;
   if ((p.ldo & 3) || !al16(p.out) || (p.bias && !al16(p.bias)) || (p.scale && (!al16(p.scale) || !al16(p.shift))) ||
@@ -815,8 +871,8 @@ static int conv_wino(const CsConvGemm& p, int M, hipStream_t s, int phases = 3) 
   const int sp = p.splitk > 1 ? p.splitk : 1;
   if (sp > 16) return CS_EINVAL;
   CsConvGemm q = p;
-  q.nb = 4 * p.nb;
-  q.win = q.wout = p.win / 2;
+  q.nb = np * p.nb;
+  q.win = q.wout = p.win / v;
   q.kw = 1;
   q.pw = 0;
   q.a_format = 1;
@@ -829,14 +885,19 @@ static int conv_wino(const CsConvGemm& p, int M, hipStream_t s, int phases = 3) 
   q.splitk = 0;
   q.tile = wino_tile(p.cout);
   if (phases & 1) {
-    const int rc = cs_conv_gemm_f16x3_dispatch(q, 2 * M, q.tile, sp, s, 16, 4, nullptr, nullptr, nullptr, 0, nullptr);
+    const int rc = cs_conv_gemm_f16x3_dispatch(q, np * (M / v), q.tile, sp, s, 16, np, nullptr, nullptr, nullptr, 0, nullptr);
     if (rc != CS_OK) return rc;
   }
   if (!(phases & 2)) return CS_OK;
   const int64_t nblk = (int64_t)((M + SKR - 1) / SKR) * ((p.cout + 63) / 64);
   if (nblk > 0x7fffffffLL) return CS_EINVAL;
-  CS_LAUNCH(splitk_reduce_epi_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, s, p,
-            reinterpret_cast<const float*>(p.splitk_ws), M, sp);
+  if (v == 4) {
+    CS_LAUNCH(splitk_reduce_epi_kernel<4>, dim3((unsigned)nblk), dim3(256), 0, s, p,
+              reinterpret_cast<const float*>(p.splitk_ws), M, sp);
+  } else {
+    CS_LAUNCH(splitk_reduce_epi_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, s, p,
+              reinterpret_cast<const float*>(p.splitk_ws), M, sp);
+  }
   CS_CHECK_LAUNCH();
   return CS_OK;
 }
@@ -880,7 +941,7 @@ static int conv_gemm_impl(const CsConvGemm* d, cs_stream_t stream, int omap_f, i
     if (p.gn_part && (rows == 0 || rows != p.gn_rows || p.gn_ld < p.cout || ((uintptr_t)p.gn_part & 15))) return CS_EINVAL;
     if (p.out_format == 2 && (!pair || !(p.out_scale > 0.f))) return CS_EINVAL;
   }
-  if (p.a_format == 3) return (f16x3 && !omap_f) ? conv_wino(p, M, s, wino_phases) : CS_EINVAL;
+  if (p.a_format == 3 || p.a_format == 4) return (f16x3 && !omap_f) ? conv_wino(p, M, s, wino_phases) : CS_EINVAL;
   if (wino_phases != 3) return CS_EINVAL;
   if (p.splitk > 1) {
     // caller-requested split-K (cs_conv_gemm_plan): partial tiles to the workspace, then reduce + epilogue
@@ -925,7 +986,7 @@ static int conv_gemm_impl(const CsConvGemm* d, cs_stream_t stream, int omap_f, i
     if (p.gn_part || p.out_format) {
       const int64_t nblk = (int64_t)((M + SKR - 1) / SKR) * ((p.cout + 63) / 64);
       if (nblk > 0x7fffffffLL) return CS_EINVAL;
-      CS_LAUNCH(splitk_reduce_epi_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, s, p,
+      CS_LAUNCH(splitk_reduce_epi_kernel<0>, dim3((unsigned)nblk), dim3(256), 0, s, p,
                 reinterpret_cast<const float*>(p.splitk_ws), M, p.splitk);
     } else {
       CS_LAUNCH(splitk_reduce_kernel, dim3(cs_grid_for((int64_t)M * (p.cout >> 2), 256)), dim3(256), 0, s, p,
@@ -972,7 +1033,7 @@ extern "C" int cs_conv_gemm_launch_info(const CsConvGemm* d, int32_t* tile_out, 
   const int M = (int)M64;
   const bool f16x3 = p.math == CS_MATH_F16X3;
   int tile = p.tile;
-  if (p.a_format == 3) {                      // the Winograd-W position GEMMs: 256-row tile, three-tap slab
+  if (p.a_format == 3 || p.a_format == 4) {   // the Winograd-W position GEMMs: 256-row tile, three-tap slab
     if (tile_out) *tile_out = wino_tile(p.cout);
     if (slab_out) *slab_out = 32;
     return CS_OK;
@@ -1370,9 +1431,10 @@ extern "C" int cs_relayout_weight(const float* w_torch, float* w_out, int cout, 
 namespace {
 __global__ __launch_bounds__(256) void pack_f16x3_wino_kernel(const float* __restrict__ w, _Float16* __restrict__ wh,
                                                               _Float16* __restrict__ wl, int cout, int cin, int kg_per_tap,
-                                                              float scale) {
+                                                              float scale, int variant, int src_cin, int c0) {
   const int64_t per = 9LL * kg_per_tap * cout * 8;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < 4 * per; i += (int64_t)gridDim.x * blockDim.x) {
+  const int np = variant + 2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < np * per; i += (int64_t)gridDim.x * blockDim.x) {
     const int q = (int)(i / per);
     int64_t t = i - q * per;
     const int j = (int)(t & 7);
@@ -1384,9 +1446,13 @@ __global__ __launch_bounds__(256) void pack_f16x3_wino_kernel(const float* __res
     const int c = kg * 8 + j;
     double u = 0.0;
     if (c < cin) {
-      const float* g = w + ((int64_t)n * cin + c) * 27 + tap * 3;
+      const float* g = w + ((int64_t)n * src_cin + c0 + c) * 27 + tap * 3;
       const double g0 = g[0], g1 = g[1], g2 = g[2];
-      u = q == 0 ? g0 : q == 1 ? 0.5 * (g0 + g1 + g2) : q == 2 ? 0.5 * (g0 - g1 + g2) : g2;
+      if (variant == 4)      // G of F(4,3): [1/4,0,0], [-1/6,-1/6,-1/6], [-1/6,1/6,-1/6], [1/24,1/12,1/6], [1/24,-1/12,1/6], [0,0,1]
+        u = q == 0 ? g0 / 4.0 : q == 1 ? -(g0 + g1 + g2) / 6.0 : q == 2 ? (-g0 + g1 - g2) / 6.0
+            : q == 3 ? g0 / 24.0 + g1 / 12.0 + g2 / 6.0 : q == 4 ? g0 / 24.0 - g1 / 12.0 + g2 / 6.0 : g2;
+      else
+        u = q == 0 ? g0 : q == 1 ? 0.5 * (g0 + g1 + g2) : q == 2 ? 0.5 * (g0 - g1 + g2) : g2;
     }
     const double v = u * (double)scale;
     const _Float16 h = (_Float16)v;
@@ -1396,16 +1462,23 @@ __global__ __launch_bounds__(256) void pack_f16x3_wino_kernel(const float* __res
 }
 }  // namespace
 
-extern "C" int cs_pack_weight_f16x3_wino(const float* w_torch, void* w_hi, void* w_lo, int cout, int cin, float scale,
-                                         cs_stream_t stream) {
-  if (!w_torch || !w_hi || !w_lo || cout <= 0 || cin <= 0 || !(scale > 0.f)) return CS_EINVAL;
+extern "C" int cs_pack_weight_f16x3_wino_v(const float* w_torch, void* w_hi, void* w_lo, int cout, int cin, float scale,
+                                           int variant, int src_cin, int c0, cs_stream_t stream) {
+  if (!w_torch || !w_hi || !w_lo || cout <= 0 || cin <= 0 || !(scale > 0.f) || (variant != 2 && variant != 4) || src_cin < 0 ||
+      c0 < 0 || (src_cin && c0 + cin > src_cin))
+    return CS_EINVAL;
   if (((uintptr_t)w_hi & 15) || ((uintptr_t)w_lo & 15)) return CS_EINVAL;
   const int kg_per_tap = ((cin + 15) / 16) * 2;
-  const int64_t total = 4LL * 9 * kg_per_tap * cout * 8;
+  const int64_t total = (int64_t)(variant + 2) * 9 * kg_per_tap * cout * 8;
   CS_LAUNCH(pack_f16x3_wino_kernel, dim3(cs_grid_for(total, 256, 256 * 32)), dim3(256), 0, (hipStream_t)stream, w_torch,
-            (_Float16*)w_hi, (_Float16*)w_lo, cout, cin, kg_per_tap, scale);
+            (_Float16*)w_hi, (_Float16*)w_lo, cout, cin, kg_per_tap, scale, variant, src_cin ? src_cin : cin, c0);
   CS_CHECK_LAUNCH();
   return CS_OK;
 }
 
-extern "C" int cs_abi_version(void) { return 16; }
+extern "C" int cs_pack_weight_f16x3_wino(const float* w_torch, void* w_hi, void* w_lo, int cout, int cin, float scale,
+                                         cs_stream_t stream) {
+  return cs_pack_weight_f16x3_wino_v(w_torch, w_hi, w_lo, cout, cin, scale, 2, 0, 0, stream);
+}
+
+extern "C" int cs_abi_version(void) { return 17; }

@@ -450,6 +450,98 @@ __global__ __launch_bounds__(256) void gn_apply_wino16_kernel(const float* __res
   if (status && amax >= 65504.f) atomicOr(status, CS_STATUS_F16X3_OVERFLOW);
 }
 
+// F(4,3) along W (CsConvGemm.a_format = 4): per W line and FOUR voxels (w = 4 t .. 4 t + 3) the six transformed values B^T d of
+// d_j = y[4 t - 1 + j] (0 outside the line) -- images [6][nb][lines][W/4][ldv].  Same line walk: a tile's d4, d5 are the next
+// tile's d0, d1.
+__global__ __launch_bounds__(256) void gn_apply_wino43_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, _Float16* __restrict__ vh,
+                                                              _Float16* __restrict__ vl, int lines, int w, int c, int ldx,
+                                                              int ldv, int groups, int act, float a_scale,
+                                                              int lines_per_block, int64_t pos_stride,
+                                                              int32_t* __restrict__ status, int cpg, int ch0) {
+  const int ch4 = c >> 2;
+  const int tpr = ch4 < 256 ? ch4 : 256;
+  const int linelanes = 256 / tpr;
+  const int tid = threadIdx.x;
+  const int ll = tid / tpr;
+  const int cl = tid - ll * tpr;
+  if (ll >= linelanes) return;
+  const int n = blockIdx.y;
+  const int l0 = blockIdx.x * lines_per_block;
+  const int l1 = min(lines, l0 + lines_per_block);
+  const int w4n = w >> 2;
+  const float* xb = x + (int64_t)n * lines * w * ldx;
+  const int64_t vrow0 = (int64_t)n * lines * w4n;
+  const float* st = stats + (int64_t)n * groups * 2;
+  float amax = 0.f;
+  for (int c4 = cl; c4 < ch4; c4 += tpr) {
+    const float4 g = *reinterpret_cast<const float4*>(gamma + c4 * 4);
+    const float4 b = *reinterpret_cast<const float4*>(beta + c4 * 4);
+    const float gg[4] = {g.x, g.y, g.z, g.w};
+    const float bb[4] = {b.x, b.y, b.z, b.w};
+    float mean[4], rstd[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int grp = (ch0 + c4 * 4 + k) / cpg;
+      mean[k] = st[grp * 2];
+      rstd[k] = st[grp * 2 + 1];
+    }
+    auto actv = [&](const float* px, bool in, float (&o)[4]) {
+      if (!in) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = 0.f;
+        return;
+      }
+      const float4 v = *reinterpret_cast<const float4*>(px);
+      const float iv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = cs_act((iv[k] - mean[k]) * rstd[k] * gg[k] + bb[k], act) * a_scale;
+    };
+    for (int line = l0 + ll; line < l1; line += linelanes) {
+      const float* xl = xb + (int64_t)line * w * ldx + c4 * 4;
+      float d[6][4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) d[0][k] = 0.f;
+      actv(xl, true, d[1]);
+      for (int t = 0; t < w4n; ++t) {
+#pragma unroll
+        for (int j = 2; j < 6; ++j) {
+          const int wi = 4 * t - 1 + j;
+          actv(xl + (int64_t)wi * ldx, wi < w, d[j]);
+        }
+        const int64_t off = (vrow0 + (int64_t)line * w4n + t) * ldv + c4 * 4;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          h4v hi, lo;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            float o;
+            if (q == 0) o = 4.f * d[0][k] - 5.f * d[2][k] + d[4][k];
+            else if (q == 1) o = (d[4][k] + d[3][k]) - 4.f * (d[1][k] + d[2][k]);
+            else if (q == 2) o = 4.f * (d[1][k] - d[2][k]) + (d[4][k] - d[3][k]);
+            else if (q == 3) o = 2.f * (d[3][k] - d[1][k]) + (d[4][k] - d[2][k]);
+            else if (q == 4) o = 2.f * (d[1][k] - d[3][k]) + (d[4][k] - d[2][k]);
+            else o = 4.f * d[1][k] - 5.f * d[3][k] + d[5][k];
+            amax = fmaxf(amax, fabsf(o));
+            const _Float16 hh = (_Float16)o;
+            hi[k] = hh;
+            lo[k] = (_Float16)(o - (float)hh);
+          }
+          *reinterpret_cast<h4v*>(vh + q * pos_stride + off) = hi;
+          *reinterpret_cast<h4v*>(vl + q * pos_stride + off) = lo;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          d[0][k] = d[4][k];
+          d[1][k] = d[5][k];
+        }
+      }
+    }
+  }
+  if (status && amax >= 65504.f) atomicOr(status, CS_STATUS_F16X3_OVERFLOW);
+}
+
 // LayerNorm: one wave per row; each lane owns up to MAXV float4 chunks (c <= 64*4*MAXV).
 template <int MAXV>
 __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x,
@@ -921,14 +1013,14 @@ extern "C" int cs_groupnorm_apply_split16_range(const float* x, const float* sta
   return CS_OK;
 }
 
-extern "C" int cs_groupnorm_apply_wino16_range(const float* x, const float* stats, const float* gamma, const float* beta,
-                                               void* v_hi, void* v_lo, int nb, int d, int h, int w, int c, int ldx, int ldv,
-                                               int groups, int cpg, int ch0, int act, float a_scale, int32_t* status,
-                                               cs_stream_t stream) {
+extern "C" int cs_groupnorm_apply_wino_range(const float* x, const float* stats, const float* gamma, const float* beta,
+                                             void* v_hi, void* v_lo, int nb, int d, int h, int w, int c, int ldx, int ldv,
+                                             int groups, int cpg, int ch0, int act, float a_scale, int variant,
+                                             int32_t* status, cs_stream_t stream) {
   if (!x || !stats || !gamma || !beta || !v_hi || !v_lo || nb <= 0 || d <= 0 || h <= 0 || w < 2 || c <= 0 || groups <= 0 ||
-      cpg <= 0 || ch0 < 0)
+      cpg <= 0 || ch0 < 0 || (variant != 2 && variant != 4))
     return CS_EINVAL;
-  if ((w & 1) || (c & 7) || (int64_t)ch0 + c > (int64_t)groups * cpg || (ldx & 3) || (ldv & 7) || ldx < c || ldv < c ||
+  if ((w % variant) || (c & 7) || (int64_t)ch0 + c > (int64_t)groups * cpg || (ldx & 3) || (ldv & 7) || ldx < c || ldv < c ||
       !(a_scale > 0.f) || nb > 65535)
     return CS_EINVAL;
   if (((uintptr_t)x & 15) || ((uintptr_t)v_hi & 15) || ((uintptr_t)v_lo & 15) || ((uintptr_t)gamma & 15) ||
@@ -945,12 +1037,26 @@ extern "C" int cs_groupnorm_apply_wino16_range(const float* x, const float* stat
   if (blocks_per_sample > max_blocks) blocks_per_sample = max_blocks;
   if (blocks_per_sample < 1) blocks_per_sample = 1;
   const int lpb = (lines + blocks_per_sample - 1) / blocks_per_sample;
-  const int64_t pos_stride = (int64_t)nb * lines * (w >> 1) * ldv;
-  CS_LAUNCH(gn_apply_wino16_kernel, dim3((unsigned)((lines + lpb - 1) / lpb), (unsigned)nb), dim3(256), 0,
-            (hipStream_t)stream, x, stats, gamma, beta, (_Float16*)v_hi, (_Float16*)v_lo, lines, w, c, ldx, ldv, groups, act,
-            a_scale, lpb, pos_stride, status, cpg, ch0);
+  const int64_t pos_stride = (int64_t)nb * lines * (w / variant) * ldv;
+  if (variant == 4) {
+    CS_LAUNCH(gn_apply_wino43_kernel, dim3((unsigned)((lines + lpb - 1) / lpb), (unsigned)nb), dim3(256), 0,
+              (hipStream_t)stream, x, stats, gamma, beta, (_Float16*)v_hi, (_Float16*)v_lo, lines, w, c, ldx, ldv, groups, act,
+              a_scale, lpb, pos_stride, status, cpg, ch0);
+  } else {
+    CS_LAUNCH(gn_apply_wino16_kernel, dim3((unsigned)((lines + lpb - 1) / lpb), (unsigned)nb), dim3(256), 0,
+              (hipStream_t)stream, x, stats, gamma, beta, (_Float16*)v_hi, (_Float16*)v_lo, lines, w, c, ldx, ldv, groups, act,
+              a_scale, lpb, pos_stride, status, cpg, ch0);
+  }
   CS_CHECK_LAUNCH();
   return CS_OK;
+}
+
+extern "C" int cs_groupnorm_apply_wino16_range(const float* x, const float* stats, const float* gamma, const float* beta,
+                                               void* v_hi, void* v_lo, int nb, int d, int h, int w, int c, int ldx, int ldv,
+                                               int groups, int cpg, int ch0, int act, float a_scale, int32_t* status,
+                                               cs_stream_t stream) {
+  return cs_groupnorm_apply_wino_range(x, stats, gamma, beta, v_hi, v_lo, nb, d, h, w, c, ldx, ldv, groups, cpg, ch0, act,
+                                       a_scale, 2, status, stream);
 }
 
 extern "C" int cs_groupnorm_apply_wino16(const float* x, const float* stats, const float* gamma, const float* beta,

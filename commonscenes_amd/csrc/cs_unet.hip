@@ -360,13 +360,13 @@ struct Exec : ExecBase {
     const float* xs = dry ? nullptr : p(sk.b) + off;           // the shared channels of the skip tensor
     // r5: where the halves' convs take the Winograd-W route (each launch covers nbs samples) their operands are emitted in
     // that form -- the h half once per guidance half (unet.py::_res_split)
-    const bool wn_h = wants_wino(l.gsp[0], nbs, x.d, x.h, x.w), wn_s = wants_wino(l.gsp[1], nbs, x.d, x.h, x.w);
+    const int wn_h = wants_wino(l.gsp[0], nbs, x.d, x.h, x.w), wn_s = wants_wino(l.gsp[1], nbs, x.d, x.h, x.w);
     Buf a_h;
     if (!wn_h)
       a_h = gn_apply_range(dry ? nullptr : p(x.b), C, x.b.rows, nb, stats, l.n[0], 32, cpg, 0, ks, CS_ACT_SILU, l.gsp[0],
                            m_launch);
     Buf a_s = gn_apply_range(xs, ch_s, sk.b.rows, nbs, stats, l.n[0], 32, cpg, ks, cs, CS_ACT_SILU, l.gsp[1], m_launch,
-                             wn_s ? x.d : 0, x.h, x.w);
+                             wn_s, x.d, x.h, x.w);
     auto lo_of = [&](const Buf& b) -> const void* {            // lo image of a pre-split pair / of a Winograd-W operand
       return ((b.half || b.wino) && !dry) ? reinterpret_cast<const char*>(p(b)) + b.rows * b.c * 2 : nullptr;
     };
@@ -381,10 +381,10 @@ struct Exec : ExecBase {
       const float* rv = dry ? nullptr : p(semb) + (int64_t)g * nbs * semb.c + l.emb_lo;
       if (wn_h) {
         Buf a_g = gn_apply_range(dry ? nullptr : p(x.b) + r0 * C, C, (int64_t)nbs * rows, nbs, stats, l.n[0], 32, cpg, 0, ks,
-                                 CS_ACT_SILU, l.gsp[0], m_launch, x.d, x.h, x.w, (int64_t)g * nbs);
+                                 CS_ACT_SILU, l.gsp[0], m_launch, wn_h, x.d, x.h, x.w, (int64_t)g * nbs);
         if (ok()) gemm_view(dry ? nullptr : p(a_g), dry ? (const void*)1 : lo_of(a_g), ks, l.gsp[0], nbs, x.d, x.h, x.w,
                             dry ? nullptr : p(h1) + r0 * cout, cout, rv, semb.c, rows, dry ? nullptr : p(y_s), cout,
-                            a_g.a_scale, true);
+                            a_g.a_scale, a_g.wino);
         release(a_g);
         continue;
       }

@@ -17,7 +17,7 @@ import torch  # noqa: F401
 
 from .build import LIB_PATH
 
-ABI_VERSION = 16     # cs_abi_version() of the library this module's SIGNATURES table describes
+ABI_VERSION = 17     # cs_abi_version() of the library this module's SIGNATURES table describes
 CS_OK = 0
 CS_EINVAL = -22
 CS_ENOMEM = -12
@@ -74,7 +74,7 @@ class CsDebug(C.Structure):
         "no_split16", "no_pair16", "no_upfold", "no_splitk", "no_fused_geglu", "no_tapcol", "tapcol_tile", "no_cfg_split",
         "concat_copy", "tile512", "no_pw", "no_slab4", "no_attn_img", "attn_nw8", "no_up2_direct", "no_up2_batch",
         "plan_pow2", "slice_tile2", "no_gn_parts", "no_pair_epilogue", "no_dyn_scale", "no_tok_rules", "no_fused_reduce",
-        "no_gn_fold", "no_kwave", "no_static_scales", "no_wino", "wino_min_rows")] + [
+        "no_gn_fold", "no_kwave", "no_static_scales", "no_wino", "wino_min_rows", "no_wino43", "wino43_min_rows")] + [
         ("split16_min_rows", C.c_int64), ("cfg_split_min_rows", C.c_int64), ("gn_small_group", C.c_int64)]
 
 
@@ -132,6 +132,7 @@ SIGNATURES = {
     "cs_pack_weight_f16x3": (_i, [_f, _f, _f, _i, _i, _i, _fl, _s]),
     "cs_pack_weight_f16x3_tapcol": (_i, [_f, _f, _f, _i, _i, _i, _fl, _s]),
     "cs_pack_weight_f16x3_wino": (_i, [_f, _f, _f, _i, _i, _fl, _s]),
+    "cs_pack_weight_f16x3_wino_v": (_i, [_f, _f, _f, _i, _i, _fl, _i, _i, _i, _s]),
     "cs_tapsum27": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),
     "cs_groupnorm_ws_bytes": (_l, [_i, _i]),
     "cs_groupnorm_stats": (_i, [_f, _i, _i, _i, _i, _i, _fl, _f, _f, _s]),
@@ -140,6 +141,7 @@ SIGNATURES = {
     "cs_groupnorm_apply_split16": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _fl, _f, _s]),
     "cs_groupnorm_apply_wino16": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _f, _s]),
     "cs_groupnorm_apply_wino16_range": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _f, _s]),
+    "cs_groupnorm_apply_wino_range": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _i, _f, _s]),
     "cs_layernorm_pair16": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _fl, _fl, _f, _s]),
     "cs_groupnorm_apply_range": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _s]),
     "cs_groupnorm_apply_split16_range": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _f, _s]),

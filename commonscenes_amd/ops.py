@@ -167,9 +167,9 @@ class PackedWeight:
     # thin-output 3x3x3 conv as "taps as columns" (pack_weight_tapcol): the pointwise pack with 27 * cout (+ pad)
     # columns; wt / wh / wl are then unused and `bias` is added by cs_tapsum27
     tapcol: Optional["PackedWeight"] = None
-    # r5: the Winograd-W pack of a 3x3x3 conv (pack_weight_wino): (hi, lo) images of the four transformed position weights
-    # [4][9 taps][cin16/8][cout][8] and their accumulator scale; None = the conv only runs in direct form
-    wino: Optional[Tuple[Tensor, Tensor, float]] = None
+    # r5: the Winograd-W packs of a 3x3x3 conv (pack_weight_wino), by variant (2 = F(2,3): four position images, 4 = F(4,3):
+    # six): {variant: (hi, lo, accumulator scale)} with images [positions][9 taps][cin16/8][cout][8]; None = direct form only
+    wino: Optional[dict] = None
 
 
 def pack_weight(w: Tensor, bias: Optional[Tensor] = None, cin_pad: Optional[int] = None,
@@ -315,15 +315,19 @@ def pack_weight_wino(pw: PackedWeight, w: Tensor, amax: Optional[float] = None) 
             or pw.cin % 8 or pw.cin < 16):
         return pw
     w = w.contiguous()
-    amax = 1.5 * (float(w.abs().max().item()) if amax is None else float(amax))
-    e = _m.frexp(amax)[1] if amax > 0 and _m.isfinite(amax) else 0
-    scale = 2.0 ** (14 - e)
+    amax0 = float(w.abs().max().item()) if amax is None else float(amax)
     kg = (pw.cin + 15) // 16 * 2
-    wh = torch.empty((4, 9, kg, pw.cout, 8), dtype=torch.float16, device=w.device)
-    wl = torch.empty_like(wh)
-    L.check(L.load().cs_pack_weight_f16x3_wino(w.data_ptr(), wh.data_ptr(), wl.data_ptr(), pw.cout, pw.cin, scale, _stream()),
-            "cs_pack_weight_f16x3_wino")
-    pw.wino = (wh, wl, 1.0 / (scale * A_SCALE))
+    pw.wino = {}
+    # F(2,3): max |u_q| <= 1.5 max |w|; F(4,3) (the UNet's widths only, cs_conv_wino_ok): <= max |w|
+    for variant, grow in ((2, 1.5),) + (((4, 1.0),) if pw.cout % 224 == 0 else ()):
+        am = grow * amax0
+        e = _m.frexp(am)[1] if am > 0 and _m.isfinite(am) else 0
+        scale = 2.0 ** (14 - e)
+        wh = torch.empty((variant + 2, 9, kg, pw.cout, 8), dtype=torch.float16, device=w.device)
+        wl = torch.empty_like(wh)
+        L.check(L.load().cs_pack_weight_f16x3_wino_v(w.data_ptr(), wh.data_ptr(), wl.data_ptr(), pw.cout, pw.cin, scale, variant,
+                                                     0, 0, _stream()), "cs_pack_weight_f16x3_wino_v")
+        pw.wino[variant] = (wh, wl, 1.0 / (scale * A_SCALE))
     return pw
 
 
@@ -727,8 +731,8 @@ def conv_gemm(x: Tensor, w: PackedWeight, *, spatial: Optional[Tuple[int, int, i
 def _conv_wino(xw: "Wino16", w: PackedWeight, act, rowvec, rv_rows, res, scale, shift, out, out_fn, stats, out_pair):
     """3x3x3 stride-1 conv on the Winograd-W operand (CsConvGemm.a_format = 3): the library runs the four position GEMMs in
     one launch into a workspace and the output transform + epilogue in the split-K reduce kernel's place."""
-    if w.wino is None or w.math != L.MATH_F16X3:
-        raise L.CsError("a Wino16 activation needs a weight with the Winograd-W pack (pack_weight_wino)")
+    if not w.wino or xw.variant not in w.wino or w.math != L.MATH_F16X3:
+        raise L.CsError("a Wino16 activation needs a weight with the Winograd-W pack of its variant (pack_weight_wino)")
     nb, d, h, wd = xw.spatial
     mo = nb * d * h * wd
     dev = xw.hi.device
@@ -743,8 +747,8 @@ def _conv_wino(xw: "Wino16", w: PackedWeight, act, rowvec, rv_rows, res, scale, 
         raise L.CsError(f"out has shape {tuple(out.shape)}, expected {mo} rows x {w.cout}")
     lib = L.load()
     p = _wino_desc(nb, d, h, wd, w)
-    wh, wl, wacc = w.wino
-    p.x, p.x_lo, p.a_format = xw.hi.data_ptr(), xw.lo.data_ptr(), 3
+    wh, wl, wacc = w.wino[xw.variant]
+    p.x, p.x_lo, p.a_format = xw.hi.data_ptr(), xw.lo.data_ptr(), (4 if xw.variant == 4 else 3)
     p.lda = int(xw.hi.shape[-1])
     p.w, p.w_lo, p.out, p.ldo = wh.data_ptr(), wl.data_ptr(), out.data_ptr(), ldo
     p.a_scale = float(xw.a_scale)
@@ -785,8 +789,10 @@ def _conv_wino(xw: "Wino16", w: PackedWeight, act, rowvec, rv_rows, res, scale, 
         e2.record()
         # flops = what the position GEMMs EXECUTE (18 of the direct form's 27 multiply-adds per output); flops_direct = the
         # direct form's algorithmic work the pair of launches replaces; m / k = the position launch's own GEMM shape
-        prof.append(dict(e0=e0, e1=e1, e2=e2, flops=2.0 * mo * w.cout * w.cin * 18, flops_direct=2.0 * mo * w.cout * w.cin * 27,
-                         taps=9, m=2 * mo, n=w.cout, k=w.cin * 9,
+        npos = xw.variant + 2
+        prof.append(dict(e0=e0, e1=e1, e2=e2, flops=2.0 * (mo // xw.variant) * npos * w.cout * w.cin * 9,
+                         flops_direct=2.0 * mo * w.cout * w.cin * 27, taps=9, m=(mo // xw.variant) * npos, n=w.cout, k=w.cin * 9,
+                         npos=npos,
                          tile=4 if w.cout % 224 == 0 else 6 if w.cout % 128 == 0 else 7, slab=32, pre=True, pair=False,
                          res=res is not None, wino=True, slices=int(sk.value)))
     if paired:
@@ -848,12 +854,14 @@ def _wino_desc(nb: int, d: int, h: int, wd: int, w: "PackedWeight"):
     return p
 
 
-def wants_wino(nb: int, d: int, h: int, wd: int, w: "PackedWeight") -> bool:
+def wants_wino(nb: int, d: int, h: int, wd: int, w: "PackedWeight") -> int:
     """Should the GroupNorm feeding the 3x3x3 conv `w` over an [nb, d, h, wd] volume emit the Winograd-W operand
-    (groupnorm(..., wino=(d, h, wd)))?  cs_conv_wino_ok: the ONE rule (csrc/cs_gemm.hip) both hosts ask."""
-    if w.wino is None or not _sw("SPLIT16_PRODUCERS"):
-        return False
-    return bool(L.load().cs_conv_wino_ok(C.byref(_wino_desc(int(nb), int(d), int(h), int(wd), w))))
+    (groupnorm(..., wino=variant)), and which -- 0 = no (direct form), 2 = F(2,3), 4 = F(4,3)?  cs_conv_wino_ok: the ONE
+    rule (csrc/cs_gemm.hip) both hosts ask."""
+    if not w.wino or not _sw("SPLIT16_PRODUCERS"):
+        return 0
+    v = int(L.load().cs_conv_wino_ok(C.byref(_wino_desc(int(nb), int(d), int(h), int(wd), w))))
+    return v if v in w.wino else (2 if v and 2 in w.wino else 0)
 
 
 def linear(x: Tensor, w: PackedWeight, **kw) -> Tensor:
@@ -862,12 +870,14 @@ def linear(x: Tensor, w: PackedWeight, **kw) -> Tensor:
 
 @dataclass
 class Wino16:
-    """An activation volume in the Winograd-W operand form of the 3x3x3 conv that reads it (CsConvGemm.a_format = 3): fp16
-    hi / lo images [4, nb, d, h, w/2, c] of the four transformed values * a_scale (cs_groupnorm_apply_wino16)."""
+    """An activation volume in the Winograd-W operand form of the 3x3x3 conv that reads it (CsConvGemm.a_format = 3 / 4):
+    fp16 hi / lo images [variant + 2, nb, d, h, w / variant, c] of the transformed values * a_scale
+    (cs_groupnorm_apply_wino_range); variant 2 = F(2,3), 4 = F(4,3)."""
     hi: Tensor
     lo: Tensor
     a_scale: float
     spatial: Tuple[int, int, int, int]          # (nb, d, h, w) of the ORIGINAL volume
+    variant: int = 2
 
 
 @dataclass
@@ -935,23 +945,26 @@ def groupnorm(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float, a
     rows = m // nb
     lib = L.load()
     segs = stats_segments(x)
-    wino = bool(wino) and _sw("SPLIT16_PRODUCERS")
+    # (wino: the variant wants_wino returned -- 2 / True = F(2,3), 4 = F(4,3); operand scale / 2 resp. / 16: the transformed
+    # values are bounded by 2 x resp. 10 x the activation's bound)
+    wino = (4 if wino == 4 else 2 if wino else 0) if _sw("SPLIT16_PRODUCERS") else 0
     if wino:
-        if x.dim() != 5 or int(x.shape[3]) % 2 or c % 8:
-            raise L.CsError("groupnorm(wino=True) needs x as [nb, d, h, w, c] with even w and c % 8 == 0")
+        if x.dim() != 5 or int(x.shape[3]) % wino or c % 8:
+            raise L.CsError("groupnorm(wino=v) needs x as [nb, d, h, w, c] with w % v == 0 and c % 8 == 0")
         split16 = True          # (same statistics routes as the pre-split pair; only the apply kernel differs)
 
     def _emit(stats):
-        yshape = (4, nb, int(x.shape[1]), int(x.shape[2]), int(x.shape[3]) // 2, c) if wino else x.shape
+        yshape = (wino + 2, nb, int(x.shape[1]), int(x.shape[2]), int(x.shape[3]) // wino, c) if wino else x.shape
         yh = torch.empty(yshape, dtype=torch.float16, device=x.device)
         yl = torch.empty(yshape, dtype=torch.float16, device=x.device)
         if wino:
-            a_sc = float(a_scale or A_SCALE) * 0.5
-            L.check(lib.cs_groupnorm_apply_wino16(x.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                                  yh.data_ptr(), yl.data_ptr(), nb, int(x.shape[1]), int(x.shape[2]),
-                                                  int(x.shape[3]), c, ldx, c, groups, act, a_sc,
-                                                  status_word(x.device).data_ptr(), _stream()), "cs_groupnorm_apply_wino16")
-            return Wino16(yh, yl, a_sc, (nb, int(x.shape[1]), int(x.shape[2]), int(x.shape[3])))
+            a_sc = float(a_scale or A_SCALE) * (0.5 if wino == 2 else 0.0625)
+            L.check(lib.cs_groupnorm_apply_wino_range(x.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                                      yh.data_ptr(), yl.data_ptr(), nb, int(x.shape[1]), int(x.shape[2]),
+                                                      int(x.shape[3]), c, ldx, c, groups, c // groups, 0, act, a_sc, wino,
+                                                      status_word(x.device).data_ptr(), _stream()),
+                    "cs_groupnorm_apply_wino_range")
+            return Wino16(yh, yl, a_sc, (nb, int(x.shape[1]), int(x.shape[2]), int(x.shape[3])), wino)
         a_sc = float(a_scale or A_SCALE)
         L.check(lib.cs_groupnorm_apply_split16(x.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                                                yh.data_ptr(), yl.data_ptr(), nb, rows, c, ldx, c, groups, act,
@@ -1060,17 +1073,18 @@ def groupnorm_apply_range(x: Tensor, stats: Tensor, gamma: Tensor, beta: Tensor,
         raise L.CsError("groupnorm_apply_range: stats / gamma / beta do not match x")
     lib = L.load()
     if wino and _sw("SPLIT16_PRODUCERS"):       # r5: the Winograd-W operand of the conv that reads it (x: [nb, d, h, w, c])
-        if x.dim() != 5 or int(x.shape[3]) % 2 or c % 8:
-            raise L.CsError("groupnorm_apply_range(wino=True) needs x as [nb, d, h, w, c] with even w and c % 8 == 0")
+        v = 4 if wino == 4 else 2
+        if x.dim() != 5 or int(x.shape[3]) % v or c % 8:
+            raise L.CsError("groupnorm_apply_range(wino=v) needs x as [nb, d, h, w, c] with w % v == 0 and c % 8 == 0")
         d_, h_, w_ = int(x.shape[1]), int(x.shape[2]), int(x.shape[3])
-        yh = torch.empty((4, nb, d_, h_, w_ // 2, c), dtype=torch.float16, device=x.device)
+        yh = torch.empty((v + 2, nb, d_, h_, w_ // v, c), dtype=torch.float16, device=x.device)
         yl = torch.empty_like(yh)
-        a_sc = float(a_scale or A_SCALE) * 0.5
-        L.check(lib.cs_groupnorm_apply_wino16_range(x.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                                    yh.data_ptr(), yl.data_ptr(), nb, d_, h_, w_, c, ldx, c, groups, cpg,
-                                                    ch0, act, a_sc, status_word(x.device).data_ptr(), _stream()),
-                "cs_groupnorm_apply_wino16_range")
-        return Wino16(yh, yl, a_sc, (nb, d_, h_, w_))
+        a_sc = float(a_scale or A_SCALE) * (0.5 if v == 2 else 0.0625)
+        L.check(lib.cs_groupnorm_apply_wino_range(x.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                                  yh.data_ptr(), yl.data_ptr(), nb, d_, h_, w_, c, ldx, c, groups, cpg,
+                                                  ch0, act, a_sc, v, status_word(x.device).data_ptr(), _stream()),
+                "cs_groupnorm_apply_wino_range")
+        return Wino16(yh, yl, a_sc, (nb, d_, h_, w_), v)
     if split16 and _sw("SPLIT16_PRODUCERS"):
         yh = torch.empty(x.shape, dtype=torch.float16, device=x.device)
         yl = torch.empty(x.shape, dtype=torch.float16, device=x.device)

@@ -584,7 +584,7 @@ class DiffusionUNet:
         for g in range(nb // nbs):                    # one launch per guidance half: both read the shared term
             sl = slice(g * nbs, (g + 1) * nbs)
             a_g = a_h[sl] if a_h is not None else ops.groupnorm_apply_range(
-                x[sl][..., :ks], stats[sl], gam[:ks], bet[:ks], cpg, 0, L.ACT_SILU, a_scale=s1, wino=True)
+                x[sl][..., :ks], stats[sl], gam[:ks], bet[:ks], cpg, 0, L.ACT_SILU, a_scale=s1, wino=wn_h)
             ops.conv_gemm(a_g, wh, rowvec=semb[sl, lo:hi], rv_rows=rows, res=y_s, out=h1[sl], math=self.math,
                           a_scale=s1)
         # (the two launches write sample ranges of h1: its GroupNorm takes its statistics from a pass over the tensor)

@@ -95,6 +95,8 @@ typedef struct CsDebug {
   int32_t no_static_scales;   /* operands born inside a transformer block keep the constant scale 16 + overflow flag (r5: static bounds) */
   int32_t no_wino;            /* 3x3x3 convs always in direct form, never Winograd F(2,3) along W (r5, a_format = 3); different fp32 sums */
   int32_t wino_min_rows;      /* Winograd-W route from this many output rows (default 1024; 0 = the default) */
+  int32_t no_wino43;          /* never F(4,3) along W (a_format = 4): F(2,3) wherever the Winograd-W route is taken */
+  int32_t wino43_min_rows;    /* F(4,3) from this many output rows (default 4096; 0 = the default) */
   int64_t split16_min_rows;   /* pre-split operands on the 128-row slab tile from this many rows (8192; 0 = never) */
   int64_t cfg_split_min_rows; /* channel-split ResBlocks from this many rows (65536) */
   int64_t gn_small_group;     /* single-launch GroupNorm up to this many elements per (sample, group) (11264) */
@@ -204,7 +206,15 @@ typedef struct CsConvGemm {
    *   weights (cs_pack_weight_f16x3_wino: ONE scale, so acc_scale as usual); din / hin / win, kd = kh = kw = 3 and every
    *   epilogue field describe the ORIGINAL conv; splitk_ws must hold cs_conv_wino_ws_bytes(desc) bytes (the four position
    *   results, x K slices if splitk > 1), the output transform + epilogue run in the split-K reduce kernel's place (same
-   *   epilogue outputs: gn_part on 16-row tiles, out_format).  cs_conv_wino_ok says where cs_conv_gemm accepts it. */
+   *   epilogue outputs: gn_part on 16-row tiles, out_format).  cs_conv_wino_ok says where cs_conv_gemm accepts it.
+   * a_format = 4 (ABI 17): the same with F(4,3) along W -- per FOUR output voxels the six inputs d0..d5 = w - 1 .. w + 4
+   *   become B^T d (rows [4,0,-5,0,1,0], [0,-4,-4,1,1,0], [0,4,-4,-1,1,0], [0,-2,-1,2,1,0], [0,2,-1,-2,1,0], [0,4,0,-5,0,1]),
+   *   the kw taps become G g (rows [1/4,0,0], [-1/6,-1/6,-1/6], [-1/6,1/6,-1/6], [1/24,1/12,1/6], [1/24,-1/12,1/6], [0,0,1]),
+   *   SIX position GEMMs over (D, H, W/4) -- 13.5 of 27 multiply-adds per output -- and out[4 t + e] = (A^T m)_e with A^T rows
+   *   [1,1,1,1,1,0], [0,1,-1,2,-2,0], [0,1,1,4,4,0], [0,1,-1,8,-8,1].  x / x_lo: images [6][nb][D][H][W/4][lda]
+   *   (cs_groupnorm_apply_wino16_range with variant 4), w / w_lo: six packed images (cs_pack_weight_f16x3_wino variant 4).
+   *   Against fp64 6e-7 - 8e-7 rel-L2 per conv at the UNet's shapes (direct form 3e-7): inside the per-op gate, ~2x the
+   *   direct form's error -- which is why cs_conv_wino_ok grants it from a larger size only. */
   const void* x_lo;
   int32_t a_format;
   /* Split-K (CS_MATH_F16X3, 224-column tiles): splitk > 1 cuts the K loop (taps x channel chunks) into that many
@@ -279,6 +289,9 @@ int cs_conv_gemm_plan(const CsConvGemm* desc, int32_t* splitk, int64_t* splitk_w
  * at least CsDebug.wino_min_rows output rows, CS_NO_WINO unset -- the ONE rule both hosts ask BEFORE they let the
  * GroupNorm emit the transformed operand.  cs_conv_wino_plan: the K slices of the position GEMMs (1 = none) and the bytes
  * of splitk_ws they need. */
+/* (ABI 17: the return value is the VARIANT -- 0 = direct form, 2 = F(2,3) (a_format = 3), 4 = F(4,3) (a_format = 4: W % 4 == 0,
+ * whole 256-row tiles per position over M / 4 rows, at least CsDebug.wino43_min_rows rows, a 224-column width).  cs_conv_wino_plan
+ * reads the variant from desc->a_format (3 or 4).) */
 int cs_conv_wino_ok(const CsConvGemm* desc);
 int cs_conv_wino_plan(const CsConvGemm* desc, int32_t* splitk, int64_t* ws_bytes);
 /* The two launches of cs_conv_gemm(a_format = 3) on their own, for hosts that time them separately (bench.py's per-kernel
@@ -341,6 +354,10 @@ int cs_pack_weight_f16x3(const float* w_torch, void* w_hi, void* w_lo, int cout,
  * max |u_q| <= 1.5 max |w|: choose scale with that headroom. */
 int cs_pack_weight_f16x3_wino(const float* w_torch, void* w_hi, void* w_lo, int cout, int cin, float scale,
                               cs_stream_t stream);
+/* (ABI 17) variant = 2: the entry above; variant = 4: SIX images of G g (F(4,3), max |u_q| <= max |w|); src_cin / c0: the
+ * packed weight is input channels [c0, c0 + cin) of a [cout][src_cin][27] tensor (0 / 0 = the whole tensor). */
+int cs_pack_weight_f16x3_wino_v(const float* w_torch, void* w_hi, void* w_lo, int cout, int cin, float scale, int variant,
+                                int src_cin, int c0, cs_stream_t stream);
 
 /*
  * Thin-output 3x3x3 convs (cout <= 4, stride 1, "same" padding: openai_model_3d.py:733-737 `self.out`,
@@ -390,6 +407,11 @@ int cs_groupnorm_apply_wino16(const float* x, const float* stats, const float* g
 int cs_groupnorm_apply_wino16_range(const float* x, const float* stats, const float* gamma, const float* beta, void* v_hi,
                                     void* v_lo, int nb, int d, int h, int w, int c, int ldx, int ldv, int groups, int cpg,
                                     int ch0, int act, float a_scale, int32_t* status, cs_stream_t stream);
+/* (ABI 17) ... with the transform as an argument: variant = 2 is the entry above (F(2,3): four images over W / 2), variant = 4
+ * emits the SIX F(4,3) images [6][nb][d][h][w / 4][ldv] (w % 4 == 0; |value| <= 10 max|y|: a_scale = cs_norm_a_scale(...) / 16). */
+int cs_groupnorm_apply_wino_range(const float* x, const float* stats, const float* gamma, const float* beta, void* v_hi,
+                                  void* v_lo, int nb, int d, int h, int w, int c, int ldx, int ldv, int groups, int cpg,
+                                  int ch0, int act, float a_scale, int variant, int32_t* status, cs_stream_t stream);
 /* Channel-range forms of the two apply entries (ABI 11): the c channels handled are channels ch0 .. ch0 + c of a tensor
  * whose statistics were taken over `groups` groups of `cpg` channels (stats: [nb][groups][2]); x, gamma, beta and the
  * outputs point AT channel ch0 (ch0 % 4 == 0).  One statistics pass over a channel concatenation [h | skip]

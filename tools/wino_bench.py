@@ -31,15 +31,16 @@ for sp, cin, cout in SHAPES:
     w = synth.tensor_device(f"w{cin}{cout}", (cout, cin, 3, 3, 3), (3.0 / (cin * 27)) ** 0.5)
     pw = ops.pack_weight_wino(ops.pack_weight(w, synth.tensor_device(f"c{cout}", (cout,), 0.1), math=L.MATH_F16X3), w)
     emb = synth.tensor_device(f"e{cout}", (nb, cout), 1.0)
-    if not ops.wants_wino(nb, *sp, pw):
+    wv = ops.wants_wino(nb, *sp, pw)
+    if not wv:
         print(f"{sp} {cin}->{cout} batch {nb}: not eligible"); continue
     hn = ops.groupnorm(x, g, b, 32, 1e-5, L.ACT_SILU, split16=True)
-    v = ops.groupnorm(x, g, b, 32, 1e-5, L.ACT_SILU, wino=True)
+    v = ops.groupnorm(x, g, b, 32, 1e-5, L.ACT_SILU, wino=wv)
     t_gd = timeit(lambda: ops.groupnorm(x, g, b, 32, 1e-5, L.ACT_SILU, split16=True))
-    t_gw = timeit(lambda: ops.groupnorm(x, g, b, 32, 1e-5, L.ACT_SILU, wino=True))
+    t_gw = timeit(lambda: ops.groupnorm(x, g, b, 32, 1e-5, L.ACT_SILU, wino=wv))
     t_d = timeit(lambda: ops.conv_gemm(hn, pw, rowvec=emb, rv_rows=rows, stats=True))
     t_w = timeit(lambda: ops.conv_gemm(v, pw, rowvec=emb, rv_rows=rows, stats=True))
     fl = 2.0 * nb * rows * cin * cout * 27
     print(f"{sp} {cin}->{cout} batch {nb}: conv direct {t_d:.3f} ms ({fl / t_d / 1e9:.0f} TF/s) winograd-W {t_w:.3f} ms "
-          f"({fl / t_w / 1e9:.0f} direct-equivalent TF/s) | GroupNorm (stats + apply) pair {t_gd:.3f} ms wino {t_gw:.3f} ms | "
+          f"({fl / t_w / 1e9:.0f} direct-equivalent TF/s, F({wv},3)) | GroupNorm (stats + apply) pair {t_gd:.3f} ms wino {t_gw:.3f} ms | "
           f"sum {t_d + t_gd:.3f} -> {t_w + t_gw:.3f} ms ({100 * (t_w + t_gw) / (t_d + t_gd) - 100:+.1f} %)", flush=True)
