@@ -65,7 +65,7 @@ def kernel_label(key):
     return (f"conv_gemm_f16x3_kernel<{wv},{'true' if pre else 'false'},{slab}{',false,3' if wino else ''}> ({shape}"
             f"{', A slab' if slab else ''}{', pre-split activations' if pre else ''}"
             f"{', interleaved operand pair' if pair else ''}"
-            f"{', the four Winograd-W position GEMMs of a 3x3x3 conv (3x3x1 taps) in one launch' if wino else ''}")
+            f"{', the Winograd-W position GEMMs of a 3x3x3 conv (3x3x1 taps; six for F(4,3), four for F(2,3)) in one launch' if wino else ''}")
 
 
 def rocprof_name(key):
@@ -330,9 +330,9 @@ def gemm_summary(prof, wall_ms, math):
     for r in sel:
         cin = r["k"] / max(1, r["taps"])
         if r.get("wino"):
-            # the position launch: the transformed operand pair [4][M/2][cin] once, FOUR packed weight pairs, its fp32
-            # results [slices][4][M/2][n] (the epilogue terms belong to the output-transform launch)
-            ab += r["m"] * cin * 4.0 + 4.0 * r["k"] * r["n"] * 4.0 + r.get("slices", 1) * r["m"] * r["n"] * 4.0
+            # the position launch: the transformed operand pair [npos][M/variant][cin] once, npos packed weight pairs, its
+            # fp32 results [slices][npos][M/variant][n] (the epilogue terms belong to the output-transform launch)
+            ab += r["m"] * cin * 4.0 + r.get("npos", 4) * r["k"] * r["n"] * 4.0 + r.get("slices", 1) * r["m"] * r["n"] * 4.0
         else:
             ab += r["m"] * cin * 4.0 + r["k"] * r["n"] * 4.0 + r["m"] * r["n"] * 4.0 * (2.0 if r.get("res") else 1.0)
     alg_bytes = ab / len(sel)
@@ -356,7 +356,7 @@ def gemm_summary(prof, wall_ms, math):
             "math": math, "launches": len(sel), "avg_launch_ms": ms / len(sel),
             "algorithmic_gflop_per_launch": fl / len(sel) / 1e9, "algorithmic_bytes_per_launch": alg_bytes,
             "flops_note": ("achieved / frac price the multiply-adds the kernel EXECUTES: this kernel is the Winograd-W position "
-                           "launch of the 3x3x3 convs (F(2,3) along W: 18 of the direct form's 27 multiply-adds per output), so "
+                           "launch of the 3x3x3 convs (F(4,3) along W: 13.5 of the direct form's 27 multiply-adds per output; F(2,3): 18), so "
                            "the direct-form-equivalent rate of those convs -- with their output-transform launch counted in -- "
                            "is `winograd_direct_equivalent_tflops`") if wino_dom else
                           "achieved / frac price the direct form's algorithmic flops, all of which this kernel executes",
@@ -706,7 +706,7 @@ def main():
                 if "e2" in r:                 # Winograd-W: the output-transform launch and the direct form's flops beside
                     t[3] += r["e1"].elapsed_time(r["e2"])
                     t[4] += r["flops_direct"]
-            print(f"{'taps':>4} {'M':>7} {'K':>6} {'N':>6} tile {'calls':>5} {'ms/step':>8} {'TF/s':>7}   (tile 1104 = the four "
+            print(f"{'taps':>4} {'M':>7} {'K':>6} {'N':>6} tile {'calls':>5} {'ms/step':>8} {'TF/s':>7}   (tile 1104 = the "
                   "Winograd-W position GEMMs of a 3x3x3 conv: executed TF/s, then + output transform ms/step and the "
                   "direct-form-equivalent TF/s of the pair)", file=sys.stderr)
             for k, t in sorted(agg.items(), key=lambda kv: -(kv[1][1] + kv[1][3])):
