@@ -380,13 +380,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const CsConvGemm p, 
 // squares) of its rows per column for the GroupNorm that follows (statistics tile = SKR rows; at small batches nearly
 // every GroupNorm input comes out of this kernel) and (b) write the interleaved operand pair, lanes 2t / 2t + 1 swapping a
 // half as in the GEMM's own epilogue.  Same sums, same order per element as splitk_reduce_kernel.
-// WINO (r5, CsConvGemm.a_format = 3): ws holds the four Winograd-W position results [slice][4][M / 2][cout]; output row m =
-// pair m >> 1, parity m & 1 (W is even): even rows m0 + m1 + m2, odd rows m1 - m2 - m3, each position summed over its K
-// slices in slice order first.  The rest of the kernel -- epilogue terms, partial sums, pair output -- is shared.
 constexpr int SKR = 16;
-// WINO = 4: F(4,3) -- ws [slice][6][M / 4][cout], output row m = tile m >> 2, element m & 3: (A^T m)_e with A^T rows
-// [1,1,1,1,1,0], [0,1,-1,2,-2,0], [0,1,1,4,4,0], [0,1,-1,8,-8,1], summed in that order.
-template <int WINO>
 __global__ __launch_bounds__(256) void splitk_reduce_epi_kernel(const CsConvGemm p, const float* __restrict__ ws, int M,
                                                                 int splits) {
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -407,54 +401,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_epi_kernel(const CsConvGemm
     const bool ok = nok && m < M;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (ok) {
-      if constexpr (WINO == 4) {
-        const int64_t quarter = (int64_t)(M >> 2) * p.cout, sstride = 6 * quarter;
-        const float* b = ws + (int64_t)(m >> 2) * p.cout + n;
-        auto pos = [&](int q) {
-          f32x4 t = *reinterpret_cast<const f32x4*>(b + q * quarter);
-          for (int sl = 1; sl < splits; ++sl) t += *reinterpret_cast<const f32x4*>(b + q * quarter + sl * sstride);
-          return t;
-        };
-        const int e = m & 3;
-        const f32x4 m1 = pos(1), m2 = pos(2), m3 = pos(3), m4 = pos(4);
-        if (e == 0) {
-          v = pos(0);
-          v += m1;
-          v += m2;
-          v += m3;
-          v += m4;
-        } else if (e == 1) {
-          v = m1 - m2;
-          v += 2.f * (m3 - m4);
-        } else if (e == 2) {
-          v = m1 + m2;
-          v += 4.f * (m3 + m4);
-        } else {
-          v = m1 - m2;
-          v += 8.f * (m3 - m4);
-          v += pos(5);
-        }
-      } else if constexpr (WINO == 2) {
-        const int64_t half = (int64_t)(M >> 1) * p.cout, sstride = 4 * half;
-        const float* b = ws + (int64_t)(m >> 1) * p.cout + n;
-        auto pos = [&](int q) {
-          f32x4 t = *reinterpret_cast<const f32x4*>(b + q * half);
-          for (int sl = 1; sl < splits; ++sl) t += *reinterpret_cast<const f32x4*>(b + q * half + sl * sstride);
-          return t;
-        };
-        if (m & 1) {
-          v = pos(1);
-          v -= pos(2);
-          v -= pos(3);
-        } else {
-          v = pos(0);
-          v += pos(1);
-          v += pos(2);
-        }
-      } else {
-        v = *reinterpret_cast<const f32x4*>(ws + (int64_t)m * p.cout + n);
-        for (int sl = 1; sl < splits; ++sl) v += *reinterpret_cast<const f32x4*>(ws + ((int64_t)sl * M + m) * p.cout + n);
-      }
+      v = *reinterpret_cast<const f32x4*>(ws + (int64_t)m * p.cout + n);
+      for (int sl = 1; sl < splits; ++sl) v += *reinterpret_cast<const f32x4*>(ws + ((int64_t)sl * M + m) * p.cout + n);
       if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
       if (p.scale) v = v * *reinterpret_cast<const f32x4*>(p.scale + n) + *reinterpret_cast<const f32x4*>(p.shift + n);
       if (p.rowvec) v += *reinterpret_cast<const f32x4*>(p.rowvec + (int64_t)(m / p.rv_rows) * p.ldrv + n);
@@ -529,6 +477,146 @@ __global__ __launch_bounds__(256) void splitk_reduce_epi_kernel(const CsConvGemm
   }
 }
 
+// r5: output transform + epilogue of the Winograd-W route, one TILE of R outputs per thread (R = 2: F(2,3), 4: F(4,3)):
+// the thread reads its R + 2 position results once (each summed over its K slices in slice order), forms the R outputs
+// (slice-order sums, then A^T m in a fixed order) and applies the epilogue row by row.  A workgroup
+// = 16 tile lanes x 16 float4 column lanes = 16 R rows x 64 columns, which is also its GroupNorm statistics tile (fp64
+// sums: a thread over its R rows in row order, then the 16 tile lanes in order).  The first version gave every output ROW a
+// thread: each position result was fetched by up to four rows' threads and the kernel ran at ~3 TB/s of useful traffic.
+template <int R>
+__global__ __launch_bounds__(256) void wino_out_kernel(const CsConvGemm p, const float* __restrict__ ws, int M, int splits) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  constexpr int P = R + 2;
+  __shared__ double sc[16][64];
+  const int cbn = (p.cout + 63) / 64;
+  const int rb = blockIdx.x / cbn, cbi = blockIdx.x - rb * cbn;
+  const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
+  const int n = cbi * 64 + cl * 4;
+  const bool nok = n < p.cout;
+  const int64_t Mt = M / R;                                    // tiles = rows of a position
+  const int64_t t = (int64_t)rb * 16 + tl;
+  const bool tok = nok && t < Mt;
+  const bool gstat = p.gn_part != nullptr, opair = p.out_format == 2;
+  f32x4 mq[P];
+#pragma unroll
+  for (int q = 0; q < P; ++q) mq[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (tok) {
+    const int64_t pstride = Mt * p.cout, sstride = P * pstride;
+    const float* b = ws + t * p.cout + n;
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+      f32x4 a = *reinterpret_cast<const f32x4*>(b + q * pstride);
+      for (int sl = 1; sl < splits; ++sl) a += *reinterpret_cast<const f32x4*>(b + q * pstride + sl * sstride);
+      mq[q] = a;
+    }
+  }
+  f32x4 y[R];
+  if constexpr (R == 4) {
+    y[0] = mq[0];
+    y[0] += mq[1];
+    y[0] += mq[2];
+    y[0] += mq[3];
+    y[0] += mq[4];
+    y[1] = mq[1] - mq[2];
+    y[1] += 2.f * (mq[3] - mq[4]);
+    y[2] = mq[1] + mq[2];
+    y[2] += 4.f * (mq[3] + mq[4]);
+    y[3] = mq[1] - mq[2];
+    y[3] += 8.f * (mq[3] - mq[4]);
+    y[3] += mq[5];
+  } else {
+    y[0] = mq[0];
+    y[0] += mq[1];
+    y[0] += mq[2];
+    y[1] = mq[1];
+    y[1] -= mq[2];
+    y[1] -= mq[3];
+  }
+  double s[4] = {0, 0, 0, 0}, sq[4] = {0, 0, 0, 0};
+  float oamax = 0.f;
+#pragma unroll
+  for (int e = 0; e < R; ++e) {
+    const int64_t m = t * R + e;
+    f32x4 v = y[e];
+    if (tok) {
+      if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+      if (p.scale) v = v * *reinterpret_cast<const f32x4*>(p.scale + n) + *reinterpret_cast<const f32x4*>(p.shift + n);
+      if (p.rowvec) v += *reinterpret_cast<const f32x4*>(p.rowvec + (m / p.rv_rows) * p.ldrv + n);
+      if (p.act != CS_ACT_NONE) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = cs_act(v[k], p.act);
+      }
+      if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + m * p.ldr + n);
+      if (gstat) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const double d = (double)v[k];
+          s[k] += d;
+          sq[k] += d * d;
+        }
+      }
+    } else {
+      v = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (opair) {      // uniform branch: every lane takes part in the half swap
+      h4 hi, lo;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float o = v[k] * p.out_scale;
+        oamax = fmaxf(oamax, fabsf(o));
+        hi[k] = (_Float16)o;
+        lo[k] = (_Float16)(o - (float)hi[k]);
+      }
+      const u32x2 H = __builtin_bit_cast(u32x2, hi), Lw = __builtin_bit_cast(u32x2, lo);
+      const bool odd = cl & 1;
+      const u32x2 send = odd ? H : Lw;
+      u32x2 recv;
+      recv[0] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send[0], 0xB1, 0xF, 0xF, true);
+      recv[1] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send[1], 0xB1, 0xF, 0xF, true);
+      u32x4 r;
+      r[0] = odd ? recv[0] : H[0];
+      r[1] = odd ? recv[1] : H[1];
+      r[2] = odd ? Lw[0] : recv[0];
+      r[3] = odd ? Lw[1] : recv[1];
+      if (tok) {
+        char* row = reinterpret_cast<char*>(p.out + m * p.ldo);
+        *reinterpret_cast<u32x4*>(row + (n >> 4) * 64 + ((n & 8) ? 32 : 0) + ((n & 4) ? 16 : 0)) = r;
+      }
+    } else if (tok) {
+      *reinterpret_cast<f32x4*>(p.out + m * p.ldo + n) = v;
+    }
+  }
+  if (opair && p.status && oamax >= 65504.f) atomicOr(p.status, CS_STATUS_F16X3_OVERFLOW);
+  if (gstat) {
+    double tot[2][4];
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 4; ++k) sc[tl][cl * 4 + k] = which ? sq[k] : s[k];
+      __syncthreads();
+      if (tl == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          double a = 0.0;
+          for (int r2 = 0; r2 < 16; ++r2) a += sc[r2][cl * 4 + k];
+          tot[which][k] = a;
+        }
+      }
+    }
+    if (tl == 0 && nok) {
+      double* o = p.gn_part + ((int64_t)rb * p.gn_ld + n) * 2;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        o[2 * k] = tot[0][k];
+        o[2 * k + 1] = tot[1][k];
+      }
+    }
+  }
+}
+
 // rows x columns of a tile code's output tile (0: no fixed tile -- the ping-pong kernel, the 512-row codes that may fall back)
 void tile_dims(int tile, int& bm, int& bn) {
   switch (tile) {
@@ -592,7 +680,13 @@ extern "C" int cs_conv_gemm_epilogue_caps(const CsConvGemm* d, int32_t* gn_rows,
     if (gn_rows && rps % bm == 0 && p.act != CS_ACT_GEGLU) *gn_rows = bm;
     return CS_OK;                                            // (no pair output from the scattered store)
   }
-  if (p.splitk > 1 || p.a_format == 3 || p.a_format == 4) {     // (a_format = 3 / 4: the Winograd-W output transform runs in the reduce kernel)
+  if (p.a_format == 3 || p.a_format == 4) {      // the Winograd-W output-transform launch (wino_out_kernel): its workgroup's rows
+    const int wr = p.a_format == 4 ? 64 : 32;
+    if (gn_rows && rps % wr == 0 && p.act != CS_ACT_GEGLU) *gn_rows = wr;
+    if (pair_ok && pair_geom && p.act != CS_ACT_GEGLU) *pair_ok = 1;
+    return CS_OK;
+  }
+  if (p.splitk > 1) {
     if (gn_rows && rps % SKR == 0 && p.act != CS_ACT_GEGLU) *gn_rows = SKR;
     if (pair_ok && pair_geom && p.act != CS_ACT_GEGLU) *pair_ok = 1;
     return CS_OK;
@@ -797,7 +891,7 @@ static int wino_variant(const CsConvGemm& p) {
   if (!wino23_ok(p)) return 0;
   const CsDebug* dbg = cs_debug();
   const int64_t M = (int64_t)p.nb * p.dout * p.hout * p.wout;
-  const int64_t min43 = dbg->wino43_min_rows > 0 ? dbg->wino43_min_rows : 4096;
+  const int64_t min43 = dbg->wino43_min_rows > 0 ? dbg->wino43_min_rows : 2048;
   if (!dbg->no_wino43 && p.cout % 224 == 0 && p.win % 4 == 0 && (M / 4) % 256 == 0 && M >= min43) return 4;
   return 2;
 }
@@ -889,14 +983,13 @@ static int conv_wino(const CsConvGemm& p, int M, hipStream_t s, int phases = 3) 
     if (rc != CS_OK) return rc;
   }
   if (!(phases & 2)) return CS_OK;
-  const int64_t nblk = (int64_t)((M + SKR - 1) / SKR) * ((p.cout + 63) / 64);
-  if (nblk > 0x7fffffffLL) return CS_EINVAL;
+  // (one tile of v outputs per thread: 16 v rows x 64 columns per workgroup = the statistics tile cs_conv_gemm_epilogue_caps names)
+  const int64_t nblk = (int64_t)((M / v + 15) / 16) * ((p.cout + 63) / 64);
+  if (nblk > 0x7fffffffLL || (p.gn_part && p.gn_rows != 16 * v)) return CS_EINVAL;
   if (v == 4) {
-    CS_LAUNCH(splitk_reduce_epi_kernel<4>, dim3((unsigned)nblk), dim3(256), 0, s, p,
-              reinterpret_cast<const float*>(p.splitk_ws), M, sp);
+    CS_LAUNCH(wino_out_kernel<4>, dim3((unsigned)nblk), dim3(256), 0, s, p, reinterpret_cast<const float*>(p.splitk_ws), M, sp);
   } else {
-    CS_LAUNCH(splitk_reduce_epi_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, s, p,
-              reinterpret_cast<const float*>(p.splitk_ws), M, sp);
+    CS_LAUNCH(wino_out_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, s, p, reinterpret_cast<const float*>(p.splitk_ws), M, sp);
   }
   CS_CHECK_LAUNCH();
   return CS_OK;
@@ -986,7 +1079,7 @@ static int conv_gemm_impl(const CsConvGemm* d, cs_stream_t stream, int omap_f, i
     if (p.gn_part || p.out_format) {
       const int64_t nblk = (int64_t)((M + SKR - 1) / SKR) * ((p.cout + 63) / 64);
       if (nblk > 0x7fffffffLL) return CS_EINVAL;
-      CS_LAUNCH(splitk_reduce_epi_kernel<0>, dim3((unsigned)nblk), dim3(256), 0, s, p,
+      CS_LAUNCH(splitk_reduce_epi_kernel, dim3((unsigned)nblk), dim3(256), 0, s, p,
                 reinterpret_cast<const float*>(p.splitk_ws), M, p.splitk);
     } else {
       CS_LAUNCH(splitk_reduce_kernel, dim3(cs_grid_for((int64_t)M * (p.cout >> 2), 256)), dim3(256), 0, s, p,

@@ -62,7 +62,7 @@ void parse_env(CsDebug& d) {
   d.no_wino = flag("CS_NO_WINO");
   d.wino_min_rows = (int32_t)num("CS_WINO_MIN_ROWS", 1024);
   d.no_wino43 = flag("CS_NO_WINO43");
-  d.wino43_min_rows = (int32_t)num("CS_WINO43_MIN_ROWS", 4096);
+  d.wino43_min_rows = (int32_t)num("CS_WINO43_MIN_ROWS", 2048);
 }
 
 }  // namespace

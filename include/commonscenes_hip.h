@@ -96,7 +96,7 @@ typedef struct CsDebug {
   int32_t no_wino;            /* 3x3x3 convs always in direct form, never Winograd F(2,3) along W (r5, a_format = 3); different fp32 sums */
   int32_t wino_min_rows;      /* Winograd-W route from this many output rows (default 1024; 0 = the default) */
   int32_t no_wino43;          /* never F(4,3) along W (a_format = 4): F(2,3) wherever the Winograd-W route is taken */
-  int32_t wino43_min_rows;    /* F(4,3) from this many output rows (default 4096; 0 = the default) */
+  int32_t wino43_min_rows;    /* F(4,3) from this many output rows (default 2048; 0 = the default) */
   int64_t split16_min_rows;   /* pre-split operands on the 128-row slab tile from this many rows (8192; 0 = never) */
   int64_t cfg_split_min_rows; /* channel-split ResBlocks from this many rows (65536) */
   int64_t gn_small_group;     /* single-launch GroupNorm up to this many elements per (sample, group) (11264) */
