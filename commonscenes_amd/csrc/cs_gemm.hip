@@ -909,8 +909,16 @@ static int wino_splits(const CsConvGemm& p, int variant) {
   // (the VQ decoder's widths are never K-sliced: a slice count that followed the batch would cost the decoder its bit-exact
   // batch invariance, tests/test_model_gpu.py::test_vq_decode_batch_invariance)
   if (p.cout % 224) return 1;
+  static const int forced = [] {              // CS_WINO_SPLITS: tuning sweeps only
+    const char* e = getenv("CS_WINO_SPLITS");
+    return (e && *e) ? atoi(e) : 0;
+  }();
   const int64_t M = (int64_t)p.nb * p.dout * p.hout * p.wout;
   const int64_t tiles = wino_pos(variant) * (M / variant / 256) * (p.cout / 224);
+  if (forced > 0) {
+    const int64_t nsc0 = 3LL * ((p.cin + 15) / 16), per0 = (nsc0 + forced - 1) / forced;
+    if (forced == 1 || (per0 >= 2 && per0 * forced * 10 <= nsc0 * 11 && (nsc0 + per0 - 1) / per0 == forced)) return forced;
+  }
   const int64_t cus = device_cus() > 0 ? device_cus() : 256;
   const int64_t nsc = 3LL * ((p.cin + 15) / 16);
   const double mb = (double)wino_pos(variant) / variant * (double)M * p.cout * 4.0 / 1e6;      // one slice's position results

@@ -205,8 +205,8 @@ typedef struct CsConvGemm {
    *   value * a_scale, written by cs_groupnorm_apply_wino16; w / w_lo = four consecutive packed images of the transformed
    *   weights (cs_pack_weight_f16x3_wino: ONE scale, so acc_scale as usual); din / hin / win, kd = kh = kw = 3 and every
    *   epilogue field describe the ORIGINAL conv; splitk_ws must hold cs_conv_wino_ws_bytes(desc) bytes (the four position
-   *   results, x K slices if splitk > 1), the output transform + epilogue run in the split-K reduce kernel's place (same
-   *   epilogue outputs: gn_part on 16-row tiles, out_format).  cs_conv_wino_ok says where cs_conv_gemm accepts it.
+   *   results, x K slices if splitk > 1), the output transform + epilogue run in a second launch with the split-K reduce
+   *   kernel's epilogue outputs (gn_part on 32-row tiles -- 64-row for a_format = 4 --, out_format).  cs_conv_wino_ok says where cs_conv_gemm accepts it.
    * a_format = 4 (ABI 17): the same with F(4,3) along W -- per FOUR output voxels the six inputs d0..d5 = w - 1 .. w + 4
    *   become B^T d (rows [4,0,-5,0,1,0], [0,-4,-4,1,1,0], [0,4,-4,-1,1,0], [0,-2,-1,2,1,0], [0,2,-1,-2,1,0], [0,4,0,-5,0,1]),
    *   the kw taps become G g (rows [1/4,0,0], [-1/6,-1/6,-1/6], [-1/6,1/6,-1/6], [1/24,1/12,1/6], [1/24,-1/12,1/6], [0,0,1]),
