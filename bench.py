@@ -85,8 +85,8 @@ def rocprof_name(key):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--objects", type=int, default=32, help="objects per GPU (BASELINE metric: 32)")
     ap.add_argument("--ddim-steps", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
