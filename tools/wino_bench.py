@@ -5,7 +5,10 @@ GroupNorm-apply part timed separately.  usage (GPU box): python tools/wino_bench
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from commonscenes_amd import lib as L, ops, synth
+from commonscenes_amd import lib as L
+if os.environ.get("CS_LIB"):          # a what-if build of the library (variants/*.so)
+    L._LIB = L.load(os.environ["CS_LIB"])
+from commonscenes_amd import ops, synth
 
 NB = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 SHAPES = [((16, 16, 16), 224, 224), ((16, 16, 16), 672, 224), ((16, 8, 8), 448, 448), ((16, 8, 8), 1120, 448),
