@@ -156,6 +156,51 @@ def test_k_sliced_conv_and_its_groupnorm_partials_at_full_size_against_fp64():
     assert dm < 1e-6 and dr < 1e-6
 
 
+@pytest.mark.parametrize("dims,cin,cout,nb", [((16, 4, 4), 672, 672, NB), ((16, 8, 8), 1120, 448, NB), ((16, 16, 16), 224, 224, NB // 2)],
+                         ids=["16x4x4 672->672", "16x8x8 1120->448", "16^3 224->224 (prefix batch)"])
+def test_winograd_route_of_the_resblock_convs_at_full_size_against_fp64(dims, cin, cout, nb):
+    """r5: the ResBlock convs at the benchmark's own batch on the route the step loop takes them -- GroupNorm emitting the
+    Winograd-W operand (F(4,3) at these sizes), six position GEMMs in one launch, output transform with bias + row vector +
+    residual + GroupNorm partial sums -- against sampled fp64 values (openai_model_3d.py:294-314)."""
+    from commonscenes_amd import lib as L, ops, synth
+    D, H, W = dims
+    tag = f"fsw{cin}{cout}"
+    x = synth.tensor_device(tag + ":x", (nb, D, H, W, cin), 1.0)
+    g, bt = synth.tensor_device(tag + ":g", (cin,), 0.3) + 1.0, synth.tensor_device(tag + ":bt", (cin,), 0.1)
+    w = synth.tensor_device(tag + ":w", (cout, cin, 3, 3, 3), (cin * 27) ** -0.5)
+    b = synth.tensor_device(tag + ":b", (cout,), 0.1)
+    rv = synth.tensor_device(tag + ":rv", (nb, cout), 0.5)
+    res = synth.tensor_device(tag + ":res", (nb, D, H, W, cout), 1.0)
+    pk = ops.pack_weight_wino(ops.pack_weight(w, b, math=L.MATH_F16X3), w)
+    variant = ops.wants_wino(nb, D, H, W, pk)
+    assert variant == 4                                           # the route of the 32-object step at every level
+    rows = D * H * W
+    s1 = ops.norm_a_scale(float(g.abs().max()), float(bt.abs().max()), rows * (cin // 32))
+    v = ops.groupnorm(x, g, bt, 32, 1e-5, L.ACT_SILU, a_scale=s1, wino=variant)
+    out = ops.conv_gemm(v, pk, rowvec=rv, rv_rows=rows, res=res, stats=True)
+    torch.cuda.synchronize()
+    ops.check_overflow()
+
+    def act64(n):
+        xs = x[n].double().reshape(rows, 32, cin // 32)
+        mu = xs.mean(dim=(0, 2), keepdim=True)
+        var = ((xs - mu) ** 2).mean(dim=(0, 2), keepdim=True)
+        y = ((xs - mu) / torch.sqrt(var + 1e-5)).reshape(D, H, W, cin) * g.double() + bt.double()
+        return y * torch.sigmoid(y)
+    rs = np.random.RandomState(17)
+    pick = _pick(rs, (nb, D, H, W, cout))
+    ref = _conv_points_fp64(act64, w.double().cpu().numpy(), b.double().cpu().numpy(), pick, (D, H, W))
+    ref = ref + rv.double().cpu().numpy()[pick[:, 0], pick[:, 4]] + _at(res, pick)
+    err, worst = _report(f"{cin} -> {cout} conv on the Winograd-W route (F({variant},3))", _at(out, pick), ref)
+    assert err < 2e-6 and worst < 2.5e-5
+    st = ops.groupnorm_stats(out, 32, 1e-5).double()              # (from the output transform's partial sums)
+    assert getattr(out, "cs_stats", None) is not None
+    o64 = out.double().reshape(nb, rows, 32, cout // 32)
+    mu = o64.mean(dim=(1, 3))
+    rstd = 1.0 / torch.sqrt(((o64 - mu[:, None, :, None]) ** 2).mean(dim=(1, 3)) + 1e-5)
+    assert float(((st[..., 0] - mu).abs() * rstd).max()) < 1e-6 and float(((st[..., 1] - rstd).abs() / rstd).max()) < 1e-6
+
+
 def test_feed_forward_chain_at_full_size_against_fp64():
     """BasicTransformerBlock's feed-forward (attention.py:39-66, 241-245) at the 1024-token level, batch 64:
     x + ff.net.2(GEGLU(LayerNorm(x))) as LayerNorm -> operand pair, 448 -> 3584 GEMM with the gate in its epilogue writing
