@@ -54,7 +54,7 @@ struct Gemm {        // one packed GEMM weight (possibly several reference tenso
   // position images, one power-of-two scale; -1 = the geometry can never take that route
   int64_t wino_off = -1, wino_lo_off = -1;
   float wino_acc = 1.f;
-  // ... and its F(4,3) sibling (six images; the UNet's 224-column widths only): CsConvGemm.a_format = 4
+  // ... and its F(4,3) sibling (six images): CsConvGemm.a_format = 4
   int64_t wino4_off = -1, wino4_lo_off = -1;
   float wino4_acc = 1.f;
 };
@@ -239,7 +239,7 @@ void layout_arena(Plan& u) {
         off += align_up(wimg);
         g.wino_lo_off = off;
         off += align_up(wimg);
-        if (g.cout % 224 == 0) {
+        {
           const int64_t wimg4 = 6LL * 9 * kg * g.cout * 16;
           g.wino4_off = off;
           off += align_up(wimg4);

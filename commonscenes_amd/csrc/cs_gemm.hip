@@ -885,14 +885,18 @@ static bool wino23_ok(const CsConvGemm& p) {
   return true;
 }
 // F(4,3) (a_format = 4): six positions over M / 4 rows -- 13.5 of 27 multiply-adds, 1.5x (not 2x) operand / result passes, ~2x
-// the direct form's rounding error (6e-7 - 8e-7 per conv, profiles/r05_z_wino43_numerics.txt): the UNet's widths only, W % 4
+// the direct form's rounding error (6e-7 - 8e-7 per conv, profiles/r05_z_wino43_numerics.txt): W % 4
 // == 0, whole 256-row tiles per position, from CsDebug.wino43_min_rows rows
 static int wino_variant(const CsConvGemm& p) {
   if (!wino23_ok(p)) return 0;
   const CsDebug* dbg = cs_debug();
   const int64_t M = (int64_t)p.nb * p.dout * p.hout * p.wout;
   const int64_t min43 = dbg->wino43_min_rows > 0 ? dbg->wino43_min_rows : 2048;
-  if (!dbg->no_wino43 && p.cout % 224 == 0 && p.win % 4 == 0 && (M / 4) % 256 == 0 && M >= min43) return 4;
+  // (the VQ decoder's widths too -- at its 16^3 level, the only one wino23_ok grants them: 4096 rows per sample, so the variant
+  // does not follow the batch either while the threshold stays <= 4096)
+  // (other widths -- the decoder's, the reduced test UNet's: the SAMPLE's rows decide, so that the variant cannot follow the batch)
+  const int64_t rdec = p.cout % 224 ? (int64_t)p.din * p.hin * p.win : M;
+  if (!dbg->no_wino43 && p.win % 4 == 0 && (M / 4) % 256 == 0 && (rdec / 4) % 256 == 0 && rdec >= min43) return 4;
   return 2;
 }
 // positions / outputs per tile of a variant

@@ -318,8 +318,8 @@ def pack_weight_wino(pw: PackedWeight, w: Tensor, amax: Optional[float] = None) 
     amax0 = float(w.abs().max().item()) if amax is None else float(amax)
     kg = (pw.cin + 15) // 16 * 2
     pw.wino = {}
-    # F(2,3): max |u_q| <= 1.5 max |w|; F(4,3) (the UNet's widths only, cs_conv_wino_ok): <= max |w|
-    for variant, grow in ((2, 1.5),) + (((4, 1.0),) if pw.cout % 224 == 0 else ()):
+    # F(2,3): max |u_q| <= 1.5 max |w|; F(4,3): <= max |w|
+    for variant, grow in ((2, 1.5), (4, 1.0)):
         am = grow * amax0
         e = _m.frexp(am)[1] if am > 0 and _m.isfinite(am) else 0
         scale = 2.0 ** (14 - e)

@@ -290,7 +290,7 @@ int cs_conv_gemm_plan(const CsConvGemm* desc, int32_t* splitk, int64_t* splitk_w
  * GroupNorm emit the transformed operand.  cs_conv_wino_plan: the K slices of the position GEMMs (1 = none) and the bytes
  * of splitk_ws they need. */
 /* (ABI 17: the return value is the VARIANT -- 0 = direct form, 2 = F(2,3) (a_format = 3), 4 = F(4,3) (a_format = 4: W % 4 == 0,
- * whole 256-row tiles per position over M / 4 rows, at least CsDebug.wino43_min_rows rows, a 224-column width).  cs_conv_wino_plan
+ * whole 256-row tiles per position over M / 4 rows, at least CsDebug.wino43_min_rows rows).  cs_conv_wino_plan
  * reads the variant from desc->a_format (3 or 4).) */
 int cs_conv_wino_ok(const CsConvGemm* desc);
 int cs_conv_wino_plan(const CsConvGemm* desc, int32_t* splitk, int64_t* ws_bytes);
