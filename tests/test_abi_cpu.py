@@ -376,3 +376,54 @@ def test_static_bound_scales_are_powers_of_two_that_keep_the_bound_in_range():
     assert out[8] * out[2] <= 65000.0 * (1 + 1e-5)
     assert dll.cs_transformer_static_scales(None, c, ntok, heads, 1.0, 0.0, 0.0, out) == lib.CS_EINVAL
     assert dll.cs_transformer_static_scales(C.byref(st), 450, ntok, 8, 1.0, 0.0, 0.0, out) == lib.CS_EINVAL
+
+
+def test_winograd_route_rule_and_slice_plan_are_host_functions_of_the_geometry():
+    """r5 (csrc/cs_gemm.hip: cs_conv_wino_ok / cs_conv_wino_plan; openai_model_3d.py:294-314 convs): which 3x3x3 convs take the
+    Winograd-W route, in which variant, and how many K slices their position GEMMs get -- plain functions of the descriptor,
+    asked by both hosts BEFORE the GroupNorm emits the operand.  No GPU needed."""
+    import ctypes as C
+    from commonscenes_amd import lib as L
+    dll = L.load()
+
+    def desc(nb, d, h, w, cin, cout, a_format=0):
+        p = L.CsConvGemm()
+        p.nb, p.din, p.hin, p.win, p.dout, p.hout, p.wout = nb, d, h, w, d, h, w
+        p.cin, p.cout, p.lda, p.ldo, p.ldw = cin, cout, cin, cout, cout
+        p.kd = p.kh = p.kw = 3
+        p.sd = p.sh = p.sw = p.pd = p.ph = p.pw = 1
+        p.math, p.rv_rows, p.a_format = L.MATH_F16X3, 1, a_format
+        return p
+
+    ok = lambda *a: dll.cs_conv_wino_ok(C.byref(desc(*a)))
+    # the UNet's widths: F(4,3) from 2048 rows where W % 4 == 0 and M / 4 is whole 256-row tiles, F(2,3) from 1024, else direct
+    assert ok(64, 16, 16, 16, 224, 224) == 4 and ok(64, 16, 4, 4, 672, 672) == 4 and ok(2, 16, 8, 8, 448, 448) == 4
+    assert ok(14, 16, 4, 4, 672, 672) == 2          # 3584 rows: M / 4 = 896 is not whole tiles, M / 2 = 1792 is
+    assert ok(2, 16, 4, 4, 672, 672) == 0           # 512 rows: below the threshold
+    assert ok(7, 16, 4, 4, 672, 672) == 0           # M / 2 = 896: not whole tiles either
+    assert ok(4, 16, 16, 6, 224, 224) == 2          # W % 4 != 0
+    assert ok(64, 16, 16, 16, 224, 96) == 0         # not a width any position tile covers
+    # the VQ decoder's widths: at its 16^3 level only, and the same answer at every batch
+    assert ok(1, 16, 16, 16, 256, 256) == ok(16, 16, 16, 16, 256, 256) == 4 and ok(1, 32, 32, 32, 128, 128) == 0
+    with L.debug_override(no_wino43=1):
+        assert ok(64, 16, 16, 16, 224, 224) == 2
+    with L.debug_override(no_wino=1):
+        assert ok(64, 16, 16, 16, 224, 224) == 0
+    p = desc(64, 16, 16, 16, 224, 224)
+    p.sw = 2
+    assert dll.cs_conv_wino_ok(C.byref(p)) == 0     # strided convs never
+
+    def plan(nb, d, h, w, cin, cout, fmt):
+        sk, wsb = C.c_int32(0), C.c_int64(0)
+        rc = dll.cs_conv_wino_plan(C.byref(desc(nb, d, h, w, cin, cout, fmt)), C.byref(sk), C.byref(wsb))
+        return rc, sk.value, wsb.value
+    # 32 objects, 16x4x4 level, F(2,3): 384 position tiles -> two slices = three even rounds of 256 CUs; workspace = slices x 4
+    # positions x M / 2 rows
+    assert plan(64, 16, 4, 4, 672, 672, 3) == (0, 2, 2 * 4 * 8192 * 672 * 4)
+    # 14 samples at the 16^3 level, F(2,3): 448 tiles -> ONE slice (the efficiency-only rule took four and lost 30 %)
+    assert plan(14, 16, 16, 16, 224, 224, 3)[:2] == (0, 1)
+    # F(4,3): six positions x M / 4 rows
+    rc, sk, wsb = plan(64, 16, 8, 8, 448, 448, 4)
+    assert rc == 0 and sk == 1 and wsb == 6 * 16384 * 448 * 4
+    assert plan(14, 16, 4, 4, 672, 672, 4)[0] != 0      # F(4,3) asked where only F(2,3) is granted: refused
+    assert plan(1, 16, 16, 16, 256, 256, 4)[:2] == (0, 1) and plan(16, 16, 16, 16, 256, 256, 4)[1] == 1   # decoder: never sliced
