@@ -48,6 +48,12 @@ def main():
     res["gather_latents_equal"] = bool(torch.equal(D.all_gather_objects(lat, B), lat))
     empty = torch.empty((0, 1, 64, 64, 64), dtype=torch.float32, device=dev)
     res["gather_b0_shape"] = list(D.all_gather_objects(empty, 0).shape)
+    # the EMPTY-SHARD shape of a job with more ranks than objects (total < world cannot happen at world 1, so it is emulated:
+    # a zero-row local slab joins a padded all-gather sized for `total` rows): the pad-to-largest-shard copy of nothing, the
+    # device-to-device all_gather_into_tensor of a slab that is all padding, the per-rank slicing of the result
+    e2 = D.all_gather_objects(torch.empty((0, 1, 8, 8, 8), dtype=torch.float32, device=dev), 3)
+    res["gather_empty_local_shape"] = list(e2.shape)
+    res["gather_empty_local_zero"] = bool(e2.is_cuda and float(e2.abs().max()) == 0.0)
     # (3) the fp32 flags
     res["any_failed_false"] = D.any_rank_failed(False, dev)
     res["any_failed_true"] = D.any_rank_failed(True, dev)
@@ -72,6 +78,22 @@ def main():
         res["rel2shape_shape"] = list(a.shape)
     td.barrier()
     td.destroy_process_group()
+    # (5) bench.py itself through `init_process_group(backend="nccl", device_id=...)` (bench.py:414 -- the call the driver's
+    # multi-GPU launch makes) in a forced one-rank group, with dist.py's collectives forced on: the reduced-width model, two
+    # steps; its broadcast / barrier / all-reduce MAX / all-gather all run on RCCL
+    import subprocess
+    env = dict(os.environ, CS_BENCH_FORCE_GROUP="1", CS_DIST_FORCE_COLLECTIVES="1", CS_RCCL_PORT=str(port + 1))
+    for k in ("MASTER_ADDR", "MASTER_PORT", "RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--small",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
+    res["bench_rc"] = r.returncode
+    res["bench_tail"] = (r.stdout[-1500:] + r.stderr[-1500:]) if r.returncode else ""
+    if r.returncode == 0:
+        line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        res["bench_group"] = line["ranks"].get("process_group")
+        res["bench_backend"] = line["ranks"].get("backend")
+        res["bench_finite"] = line["finite"]
     Path(os.environ["CS_RCCL_OUT"]).write_text(json.dumps(res))
 
 

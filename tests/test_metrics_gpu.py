@@ -87,3 +87,93 @@ def test_match_cost_interface_properties():
     match_cost(a_d, b.cuda()).sum().backward()
     torch.cuda.synchronize()
     assert a_d.grad.shape == a.shape and torch.isfinite(a_d.grad).all() and float(a_d.grad.abs().max()) > 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# r6: hand-derived known-answer tests read off the reference's CUDA sources (they cannot be compiled
+# here: cuda_runtime.h / ATen-CUDA), so these are the only pins N4 can get without a CUDA box.  Every expected value below
+# was derived by hand from the cited lines and is exactly representable (or a closed form in one exp).
+# ---------------------------------------------------------------------------------------------------------------------
+def test_chamfer_kat_tie_breaking_follows_the_scan_order():
+    """extension/chamfer.cu:12-134 (NmDistanceKernel): inside a 512-target batch the scan keeps the FIRST of equidistant
+    targets (`k==0 || d<best`, strict), and a later batch replaces the running result only if strictly closer
+    (`result[...]>best`, :126) -- so among equidistant nearest targets the LOWEST index wins, also across the 512 boundary
+    and in the `end_k & 3` tail (:113-122)."""
+    from commonscenes_amd.chamfer import chamferDist
+    cd = chamferDist()
+    # one query at the origin, three targets at distance 1: index 0
+    a = torch.zeros(1, 1, 3)
+    b = torch.tensor([[[1.0, 0, 0], [-1.0, 0, 0], [0, 1.0, 0]]])
+    d1, d2 = cd(a.cuda(), b.cuda())
+    assert d1.cpu().tolist() == [[1.0]] and cd.idx1.cpu().tolist() == [[0]]
+    assert d2.cpu().tolist() == [[1.0, 1.0, 1.0]] and cd.idx2.cpu().tolist() == [[0, 0, 0]]
+    # 600 far targets; equidistant nearest ones at indices 3 (first batch), 510 (the unrolled part's last quad), 515 (second
+    # batch) and 599 (the second batch's 88 = 4 * 22 targets end on a whole quad; 598 % 4 tail of a 599-target run below)
+    m = 600
+    far = torch.zeros(1, m, 3)
+    far[0, :, 0] = 50.0 + torch.arange(m, dtype=torch.float32)
+    for idx, p in ((3, (0.0, 2.0, 0.0)), (510, (0.0, -2.0, 0.0)), (515, (2.0, 0.0, 0.0)), (599, (0.0, 0.0, 2.0))):
+        far[0, idx] = torch.tensor(p)
+    q = torch.zeros(1, 2, 3)
+    q[0, 1] = torch.tensor([0.0, 0.0, 1.5])               # second query: index 599 is strictly nearest (0.25 < ...)
+    d1, _ = cd(q.cuda(), far.cuda())
+    assert cd.idx1.cpu().tolist() == [[3, 599]] and d1.cpu().tolist() == [[4.0, 0.25]]
+    # drop target 3: the tie is now 510 (batch one) vs 515 (batch two) -> 510; drop 510 too -> 515 vs 599 -> 515
+    far[0, 3] = torch.tensor([1000.0, 0.0, 0.0])
+    cd(q[:, :1].cuda(), far.cuda())
+    assert cd.idx1.cpu().tolist() == [[510]]
+    far[0, 510] = torch.tensor([1000.0, 0.0, 0.0])
+    cd(q[:, :1].cuda(), far.cuda())
+    assert cd.idx1.cpu().tolist() == [[515]]
+    # a 599-target cloud: the second batch has 87 = 4 * 21 + 3 targets, its last three go through the scalar tail loop
+    tail = far[:, :599].clone()
+    tail[0, 515] = torch.tensor([1000.0, 0.0, 0.0])
+    tail[0, 597] = torch.tensor([0.0, 3.0, 0.0])
+    tail[0, 598] = torch.tensor([0.0, -3.0, 0.0])
+    d1, _ = cd(q[:, :1].cuda(), tail.cuda())
+    assert cd.idx1.cpu().tolist() == [[597]] and d1.cpu().tolist() == [[9.0]]
+
+
+def test_chamfer_kat_gradient_of_a_three_point_cloud():
+    """extension/chamfer.cu:155-185 (NmDistanceGradKernel, called twice with the clouds swapped): g = 2 * grad_dist,
+    grad_xyz1[j] += g (p_j - q_idx), grad_xyz2[idx] -= the same.  Clouds p = (0,0,0), (1,0,0), (0,2,0) and
+    q = (0,0,1), (1,1,0), (0,2,3): idx1 = [0, 1, 1] (d1 = 1, 1, 2), idx2 = [0, 1, 2] (d2 = 1, 1, 9); with grad_dist1 = (1, 2, 3)
+    and grad_dist2 = (4, 5, 6) the two passes add up, by hand, to the integers below."""
+    from commonscenes_amd.chamfer import chamferDist
+    p = torch.tensor([[[0.0, 0, 0], [1.0, 0, 0], [0, 2.0, 0]]]).cuda().requires_grad_(True)
+    q = torch.tensor([[[0.0, 0, 1.0], [1.0, 1.0, 0], [0, 2.0, 3.0]]]).cuda().requires_grad_(True)
+    cd = chamferDist()
+    d1, d2 = cd(p, q)
+    assert d1.detach().cpu().tolist() == [[1.0, 1.0, 2.0]] and d2.detach().cpu().tolist() == [[1.0, 1.0, 9.0]]
+    assert cd.idx1.cpu().tolist() == [[0, 1, 1]] and cd.idx2.cpu().tolist() == [[0, 1, 2]]
+    g1 = torch.tensor([[1.0, 2.0, 3.0]]).cuda()
+    g2 = torch.tensor([[4.0, 5.0, 6.0]]).cuda()
+    ((d1 * g1).sum() + (d2 * g2).sum()).backward()
+    assert p.grad.cpu().tolist() == [[[0.0, 0.0, -10.0], [0.0, -14.0, 0.0], [-6.0, 6.0, -36.0]]]
+    assert q.grad.cpu().tolist() == [[[0.0, 0.0, 10.0], [6.0, 8.0, 0.0], [0.0, 0.0, 36.0]]]
+
+
+def test_approxmatch_kat_nine_level_schedule():
+    """scripts/pytorch_structural_losses/src/approxmatch.cu:24-27: `for (j=7;j>-2;j--) level=-powf(4,j)` runs NINE levels,
+    -4^7 ... -4^0, -4^-1, and the `j==-2 -> level=0` branch is dead.  Two decoupled pairs pin that by hand:
+      p1 = q1 (squared distance 0): the first level ships everything -- suml = 1e-9 + 1 = 1 (fp32), ratioL = 1, sumr = 1,
+        consumption = 1, match += 1, both remainders drop to 0 and every later level adds 0;
+      p0 / q0 at squared distance 121: exp(level * 121) underflows to exactly 0 for the eight levels -4^7 ... -1, so they add
+        nothing and leave remainL = remainR = 1, ratioR = 1; ONLY the ninth level (-1/4) sees E = exp(-30.25):
+        suml = 1e-9 + E, ratioL = 1 / suml, match += E * ratioL * ratioR = E / (1e-9 + E).
+    The cross pairs are ~1e6 apart (exp = 0 everywhere).  Eight levels would leave match[0][0] = 0, a tenth (level 0) would
+    ship the remaining mass and leave ~1.  match is laid out [b][m][n] (:157)."""
+    from commonscenes_amd import emd
+    a = torch.tensor([[[0.0, 0.0, 0.0], [1000.0, 0.0, 0.0]]])
+    b = torch.tensor([[[0.0, 0.0, 11.0], [1000.0, 0.0, 0.0]]])
+    match, _ = emd.ApproxMatch(a.cuda(), b.cuda())
+    torch.cuda.synchronize()
+    mm = match.cpu().double().numpy()[0]
+    E = float(np.exp(-30.25))
+    want = E / (1e-9 + E)                                    # 7.2856e-5
+    assert mm[1, 1] == 1.0 and mm[0, 1] == 0.0 and mm[1, 0] == 0.0
+    assert abs(mm[0, 0] - want) < 2e-4 * want, (mm[0, 0], want)
+    # and the numpy restatement agrees with the same hand-derived values (pins oracle/ref_metrics.py on this KAT)
+    from oracle import ref_metrics as RM
+    rm = RM.approxmatch(a.numpy(), b.numpy())[0]
+    assert rm[1, 1] == 1.0 and abs(float(rm[0, 0]) - want) < 1e-5 * want

@@ -514,6 +514,48 @@ def test_sample_end_to_end_vs_reference_golden(tmp_path, concat):
     _sdf_gates(m, g, gen, lat, "e2e_concat_small" if concat else "e2e_small")
 
 
+@pytest.mark.parametrize("route", ["split", "product"])
+def test_sample_end_to_end_100_steps_vs_reference_golden(tmp_path, route):
+    """r6: the end-to-end fixture at the METRIC's own depth -- rel2shape's default ddim_steps=100
+    (sdfusion_txt2shape_model.py:459-516; loop at samplers/ddim.py:126-179): 8 shaped objects (mini-batches 7 + 1), the
+    whole 100-step schedule, then quantise + decode.  Latents <= 1e-4 after 100 steps, VQ flips accounted voxel by voxel on
+    the 100-step latents, SDFs <= 1e-4 -- on the forced channel-split route AND on the product's own threshold (ROUTES)."""
+    g = _g("e2e100_small")
+    assert int(g["ddim_steps"]) == 100
+    m = _scene(tmp_path)
+    m.Diff.df.split_min_rows = ROUTES[route]
+    O = g["objs"].shape[0]
+    dec_sdfs = torch.zeros(O, 1, 4, 4, 4)
+    dec_sdfs[torch.from_numpy(g["dec_sdfs_nonzero"])] = 1.0
+    m.Diff.mini_B = 7
+    lat = _record_latents(m)
+    boxes, gen = m.sample(None, np.zeros(64), np.eye(64), torch.from_numpy(g["objs"]), torch.from_numpy(g["triples"]),
+                          dec_sdfs, torch.from_numpy(g["text_feats"]), torch.from_numpy(g["rel_feats"]),
+                          gen_shape=True, z=torch.from_numpy(g["z"]), x_T=torch.from_numpy(g["x_T"]), ddim_steps=100)
+    torch.cuda.synchronize()
+    assert gen.shape == (8, 1, 64, 64, 64)
+    assert rel_l2(boxes[0], torch.from_numpy(g["boxes"])) < 2e-6
+    _sdf_gates(m, g, gen, lat, f"e2e100_small[{route}]")
+
+
+def test_sample_end_to_end_on_the_product_route(tmp_path):
+    """conftest forces CS_CFG_SPLIT_MIN_ROWS=0 for the suite; the 2-step end-to-end fixture is also run
+    with the PRODUCT's threshold (65536 rows: the unsplit ResBlock route at these batches)."""
+    g = _g("e2e_small")
+    m = _scene(tmp_path)
+    m.Diff.df.split_min_rows = ROUTES["product"]
+    O = g["objs"].shape[0]
+    dec_sdfs = torch.zeros(O, 1, 4, 4, 4)
+    dec_sdfs[torch.from_numpy(g["dec_sdfs_nonzero"])] = 1.0
+    m.Diff.mini_B = 7
+    lat = _record_latents(m)
+    _, gen = m.sample(None, np.zeros(64), np.eye(64), torch.from_numpy(g["objs"]), torch.from_numpy(g["triples"]),
+                      dec_sdfs, torch.from_numpy(g["text_feats"]), torch.from_numpy(g["rel_feats"]),
+                      gen_shape=True, z=torch.from_numpy(g["z"]), x_T=torch.from_numpy(g["x_T"]), ddim_steps=2)
+    torch.cuda.synchronize()
+    _sdf_gates(m, g, gen, lat, "e2e_small[product route]")
+
+
 def test_sample_end_to_end_full_width_vs_reference_golden(tmp_path):
     """The whole path at the SHIPPED width (413.5 M-parameter UNet, full VQ-VAE decoder) against the reference:
     Sg2ScVAEModel.sample(gen_shape=True), 8 shaped objects (mini-batches 7 + 1), 2 DDIM steps, F16X3 GEMMs."""

@@ -86,6 +86,20 @@ def test_ddim_whole_trajectory_vs_reference_golden(small, math, route):
     assert dev[50] < 1e-4 and p0 < 1e-4
 
 
+@pytest.mark.parametrize("math,route", [("f16x3", "split"), ("f16x3", "product"), ("fp32", "split")])
+def test_ddim_100_step_trajectory_at_the_shipped_width_vs_reference_golden(math, route):
+    """r6: BASELINE configs[2]'s own schedule depth -- the reference's DDIMSampler.sample(S=100)
+    (sdfusion_txt2shape_model.py:128,460; ddim.py:126-179), one object at the SHIPPED width (413.5 M parameters), x after
+    steps {1, 2, 5, 10, 25, 50, 75, 100} + the final pred_x0.  Gate: rel-L2 <= 1e-4 at every kept step."""
+    from commonscenes_amd.ddim import DDIMSampler
+    dev, p0 = _run_traj("traj100_full", DDIMSampler, False, math, route)
+    print(f"[traj100_full {math} {route}] rel-L2 by step: " + ", ".join(f"{k}:{e:.2e}" for k, e in dev.items()) + f"; pred_x0 {p0:.2e}")
+    _report(f"traj100_full:{math}" + ("" if route == "split" else ":product_route"), dict(per_step=dev, pred_x0_final=p0))
+    assert sorted(dev) == [1, 2, 5, 10, 25, 50, 75, 100]
+    assert max(dev.values()) < 1e-4, dev
+    assert dev[100] < 1e-4 and p0 < 1e-4
+
+
 def test_plms_whole_trajectory_vs_reference_golden():
     """N4: PLMSSampler (samplers/plms.py:61-236) over its whole 50-step run, B=2, CFG 3.0, reduced width: pseudo
     improved Euler start-up (two model evaluations) + Adams-Bashforth orders 2-4, fused into cs_plms_update."""

@@ -28,6 +28,10 @@ def test_rccl_collectives_on_device_tensors_in_a_one_rank_group(tmp_path):
     assert res["any_failed_false"] is False and res["any_failed_true"] is True
     assert res["flags"] == [0.0, 1.0]
     assert res["rel2shape_equal"] and res["rel2shape_shape"] == [3, 1, 64, 64, 64]
+    # r6: the empty-shard padded all-gather, and bench.py through the `nccl` + `device_id=` init path
+    assert res["gather_empty_local_shape"] == [3, 1, 8, 8, 8] and res["gather_empty_local_zero"]
+    assert res["bench_rc"] == 0, res["bench_tail"]
+    assert res["bench_group"].startswith("forced one-rank group") and "rccl" in res["bench_backend"] and res["bench_finite"]
 
 
 def test_force_switch_is_inert_without_a_process_group():

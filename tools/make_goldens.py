@@ -409,9 +409,11 @@ def g_gcn(tmp: Path, concat: bool = False):
          rel_feats=g["rel_feats"], z=g["z"], uc=uc, c=c)
 
 
-def g_e2e(tmp: Path, concat: bool = False, full: bool = False):
+def g_e2e(tmp: Path, concat: bool = False, full: bool = False, steps: int = 2):
     """Sg2ScVAEModel.sample(gen_shape=True) end to end (VAEGAN_V2FULL.py:600-618): 8 shaped objects (mini-batch
-    boundary at 7), 2 DDIM steps; reduced-width UNet, or (full=True) the shipped 413.5 M-parameter one."""
+    boundary at 7), 2 DDIM steps; reduced-width UNet, or (full=True) the shipped 413.5 M-parameter one.
+    steps=100 (fixture `e2e100_small`) is the metric's own depth: rel2shape's default ddim_steps
+    (sdfusion_txt2shape_model.py:459-516), every latent / code index / SDF after the whole 100-step schedule."""
     import functools
     model, sd, df_sd, vq_sd = build_ref_scene(tmp, small=not full, concat=concat)
     nobj = 8
@@ -430,7 +432,7 @@ def g_e2e(tmp: Path, concat: bool = False, full: bool = False):
         rec["uc"], rec["c"] = r[0].detach().clone(), r[1].detach().clone()
         return r
     model.encoder_2 = enc2_rec
-    model.Diff.rel2shape = functools.partial(model.Diff.rel2shape, ddim_steps=2)
+    model.Diff.rel2shape = functools.partial(model.Diff.rel2shape, ddim_steps=steps)
     lat = []
     dnq = model.Diff.vqvae_module.decode_no_quant
 
@@ -454,7 +456,11 @@ def g_e2e(tmp: Path, concat: bool = False, full: bool = False):
         arrs["boxes"], arrs["angles"] = boxes[0], boxes[1]
     else:
         arrs["boxes"] = boxes
-    if full:
+    arrs["ddim_steps"] = np.int64(steps)
+    if steps != 2:
+        assert not full and not concat
+        save(f"e2e{steps}_small", **arrs)
+    elif full:
         # keep the fixture small: every other voxel of every object, one object in full
         save("e2e_full", **arrs)
     else:
@@ -519,7 +525,7 @@ def g_full_manip(tmp: Path):
     z = synth.gaussian_like("fm:z", (O, 64))
     z_in = torch.cat([z[:2], z[3:]], dim=0)
     x_T = synth.gaussian_like("fm:xT", (1, 3, 16, 16, 16))
-    model.Diff.rel2shape = functools.partial(model.Diff.rel2shape, ddim_steps=2)
+    model.Diff.rel2shape = functools.partial(model.Diff.rel2shape, ddim_steps=steps)
     idx_rec = _record_vq_indices(model.Diff.vqvae_module)
     lat = []
     dnq = model.Diff.vqvae_module.decode_no_quant
@@ -563,15 +569,21 @@ def _record_vq_indices(vq):
 TRAJ_KEEP = (1, 2, 3, 5, 10, 15, 20, 25, 30, 35, 40, 45, 50)
 
 
-def g_traj(small: bool):
-    """BASELINE configs[1] (C2): ONE object, the whole 50-step classifier-free-guided DDIM run through the
+TRAJ100_KEEP = (1, 2, 5, 10, 25, 50, 75, 100)
+
+
+def g_traj(small: bool, S: int = 50):
+    """S=100 (fixture `traj100_full`): BASELINE configs[2]'s own schedule depth (ddim_steps=100,
+    sdfusion_txt2shape_model.py:128,460; loop at samplers/ddim.py:154), one object at the shipped width.
+    BASELINE configs[1] (C2): ONE object, the whole 50-step classifier-free-guided DDIM run through the
     reference's own DDIMSampler.sample() loop (ddim.py:60-179), reduced width (small) or the shipped 413.5 M-parameter
     UNet (full).  x after the steps in TRAJ_KEEP is kept so a test can report the per-step growth of the deviation."""
     from model.networks.diffusion_networks.samplers.ddim import DDIMSampler
-    name = "traj_small" if small else "traj_full"
+    name = ("traj_small" if small else "traj_full") if S == 50 else f"traj{S}_{'small' if small else 'full'}"
+    keep = TRAJ_KEEP if S == 50 else TRAJ100_KEEP
     df, p, sd = build_ref_unet(small)
     m = _ref_model_for_sampler(df)
-    B, S = 1, 50
+    B = 1
     x_T = synth.gaussian_like(f"{name}:xT", (1, 3, 16, 16, 16))
     c = synth.gaussian_like(f"{name}:c", (B, 1, 1280))
     uc = synth.gaussian_like(f"{name}:uc", (B, 1, 1280))
@@ -581,10 +593,10 @@ def g_traj(small: bool):
                                          verbose=False, unconditional_guidance_scale=3.0,
                                          unconditional_conditioning=uc, eta=0.0, log_every_t=1)
     print(f"[{name}] {S} reference DDIM steps {time.time() - t0:.1f}s  final rms {x.pow(2).mean().sqrt():.4f}")
-    xi = inter["x_inter"]                      # [x_T, x after step 1, ..., x after step 50]
+    xi = inter["x_inter"]                      # [x_T, x after step 1, ..., x after step S]
     assert len(xi) == S + 1 and torch.equal(xi[-1], x)
-    save(name, x_T=x_T, c=c, uc=uc, S=np.int64(S), scale=np.float32(3.0), keep=np.asarray(TRAJ_KEEP, dtype=np.int64),
-         x=torch.stack([xi[k] for k in TRAJ_KEEP]), pred_x0_final=inter["pred_x0"][-1])
+    save(name, x_T=x_T, c=c, uc=uc, S=np.int64(S), scale=np.float32(3.0), keep=np.asarray(keep, dtype=np.int64),
+         x=torch.stack([xi[k] for k in keep]), pred_x0_final=inter["pred_x0"][-1])
 
 
 def g_plms():
@@ -624,7 +636,7 @@ def main():
     install_patches()
     todo = a.only or ["schedule", "unet_small", "unet_full", "ddim_small", "ddim_full", "vq", "gcn", "e2e",
                       "unet_concat_small", "unet_concat_full", "ddim_concat_small", "gcn_concat", "e2e_concat", "box",
-                      "full_manip", "e2e_full", "traj_small", "traj_full", "plms"]
+                      "full_manip", "e2e_full", "traj_small", "traj_full", "plms", "traj100_full", "e2e100_small"]
     with tempfile.TemporaryDirectory() as td:
         tmp = Path(td)
         for name in todo:
@@ -663,6 +675,10 @@ def main():
                 g_traj(False)
             elif name == "plms":
                 g_plms()
+            elif name == "traj100_full":
+                g_traj(False, S=100)
+            elif name == "e2e100_small":
+                g_e2e(tmp, steps=100)
             elif name == "box":
                 g_box()
             elif name == "full_manip":
