@@ -82,15 +82,25 @@ struct CsClsBatch {
   int n;
 };
 
-// The slices of output tile `otile` have each stored their partial tile to ws[slice][M][cout].  Publish (agent-scope release),
-// arrive, and -- slices 0 .. R-1 only -- wait for the others, then sum rows [split * BM/R, +BM/R) of the tile over the slices
-// IN SLICE ORDER and apply the epilogue: per element the arithmetic of splitk_reduce_epi_kernel / splitk_reduce_kernel
-// (cs_gemm.hip), per (16-row block, column) the same fp64 row-order sums for gn_part, the same pair conversion -- bit for bit
-// the two-kernel form.  Visibility follows MI355X_MICROARCH.md "inter-workgroup visibility": plain stores -> barrier -> one
-// lane's release fence -> drained -> relaxed agent atomic; one relaxed poll loop -> one acquire fence -> barrier -> plain loads.
+// The slices of output tile `otile` have each stored their partial tile to ws[slice][M][cout].  Publish, arrive, and -- the
+// LAST R ARRIVERS only (r6) -- wait for the rest, then sum rows [share * BM/R, +BM/R) of the tile over the slices IN SLICE
+// ORDER and apply the epilogue: per element the arithmetic of splitk_reduce_epi_kernel / splitk_reduce_kernel (cs_gemm.hip),
+// per (16-row block, column) the same fp64 row-order sums for gn_part, the same pair conversion -- bit for bit the two-kernel
+// form whichever workgroup ends up with which share.
+// Visibility (MI355X_MICROARCH.md "inter-workgroup visibility", the write-through form): the partial tile goes out as 16-byte
+// `sc1` stores -> `s_waitcnt vmcnt(0)` (inline asm) -> barrier -> one lane's relaxed agent-scope atomic on the tile's counter;
+// the reducers poll that counter with relaxed agent-scope loads and read the partials with `sc1` loads (never served by a
+// CU's L1).  No release / acquire fence on either side: the stores were written through, the loads bypass L1.
+// Roles by ARRIVAL TICKET, not by slice index (r6): HIP promises nothing about dispatch order or residency, and with
+// fixed roles (slices 0 .. R-1 reduce) the FIRST-dispatched workgroups of a tile were the ones that span while later slices
+// might still be waiting for a CU -- safe only while the whole launch is resident.  The ticket of the atomic arrive decides
+// instead: the first splits - R arrivers leave at once (their CUs are free for slices not yet dispatched), the last R arrivers
+// take shares 0 .. R-1 and wait only for slices that arrived at a CU before they could finish.  A launch that is not fully
+// resident (CUs held by another stream, a CU mask) therefore still completes; the bounded wait stays as a backstop and
+// raises CS_STATUS_SPLITK_TIMEOUT, which the hosts answer by re-running with the two-kernel form (no_fused_reduce).
 template <int NT, int BM, int BN>
 __device__ __forceinline__ void fused_splitk_reduce(const CsFuseK& f, const float* __restrict__ ws, unsigned char* smem, int M,
-                                                    int cout, int m0, int n0, int split, int splits, int otile, int tid) {
+                                                    int cout, int m0, int n0, int splits, int otile, int tid) {
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -100,15 +110,18 @@ __device__ __forceinline__ void fused_splitk_reduce(const CsFuseK& f, const floa
   // ~23 us per conv against ~15 for the second launch, profiles/r05_a_fused_ab.txt)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();                                           // every wave's partial stores are drained
-  if (tid == 0) __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int* const tick = reinterpret_cast<int*>(smem);            // (the staging LDS is free: the caller synchronised)
+  if (tid == 0) *tick = __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
   const int R = f.reducers;
-  if (split >= R) return;                                    // (workgroup-uniform)
+  const int split = *tick - (splits - R);                    // this workgroup's share of the tile's rows, < 0 = none
+  if (split < 0) return;                                     // (workgroup-uniform)
   if (tid == 0) {
     int spins = 0;
     while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < splits) {
       __builtin_amdgcn_s_sleep(4);
-      if (++spins > (1 << 23)) {                             // ~ seconds: a slice that is not resident (planning bug), not a hang
-        if (f.status) atomicOr(f.status, CS_STATUS_INTERNAL);
+      if (++spins > (1 << 23)) {                             // ~ seconds: a slice that never got a CU, not a hang
+        if (f.status) atomicOr(f.status, CS_STATUS_SPLITK_TIMEOUT);
         break;
       }
     }
@@ -227,7 +240,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
                                                               int taps_hw, int kw_, int kg_per_tap,
                                                               long long x_bytes, unsigned w_bytes, int vec_epilogue,
                                                               int splits, int omap_f, int omap_p_in, const CsClsBatch cb,
-                                                              const CsFuseK fz) {
+                                                              const CsFuseK fz, int tm_base, int tm_count) {
   constexpr int BM = 32 * WMB * WAVES_M;
   constexpr int BN = 32 * WNB * WAVES_N;
   constexpr int NW = WAVES_M * WAVES_N;            // waves per workgroup (4, or 8 for the 256-row tile)
@@ -336,9 +349,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   // Slab kernel with K slices (the large-batch four-way cut of the 4^3-level convs: 49 MB of weights per conv, far
   // beyond an XCD's L2): row tiles fastest instead, so the workgroups an XCD runs together stream the SAME weight
   // slice (one or two (column tile, K slice) pairs per XCD instead of twelve).
+  // r6: a launch may cover a RANGE of row tiles [tm_base, tm_base + tm_count) (tm_count = 0: all of them) -- the Winograd-W
+  // position GEMMs of a launch whose tile count is not a whole number of rounds of the chip run as a main launch over whole
+  // rounds (unsliced) and a K-sliced tail launch over the remaining row tiles (cs_gemm.hip::conv_wino).
   int split, tn, tm;
   if (SLAB != 0 && splits > 1) {
-    const int tiles_m = (M + BM - 1) / BM;
+    const int tiles_m = tm_count > 0 ? tm_count : (M + BM - 1) / BM;
     tm = tile % tiles_m;
     tile /= tiles_m;
     split = tile % splits;
@@ -349,6 +365,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
     tn = tile % tiles_n;
     tm = tile / tiles_n;
   }
+  tm += tm_base;
   const int m0 = tm * BM;
   const int n0 = tn * BN;
   // TPK == 3 (r5): the four Winograd-W position GEMMs of one 3x3x3 conv in ONE launch -- their transformed operands are
@@ -1276,7 +1293,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
     if constexpr (BN <= NT && TPK == 9) {
       if (fz.sync) {
         __syncthreads();                                      // the staging LDS is free again
-        fused_splitk_reduce<NT, BM, BN>(fz, p.out, smem, M, p.cout, m0, n0, split, splits, tm * tiles_n + tn, tid);
+        fused_splitk_reduce<NT, BM, BN>(fz, p.out, smem, M, p.cout, m0, n0, splits, tm * tiles_n + tn, tid);
       }
     }
     return;
@@ -1309,10 +1326,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
 
 template <int WMB, int WNB, int WAVES_M, int WAVES_N, bool PRE, int SLAB = 0, bool PAIR = false, int TPK = 9, bool PW = false>
 int launch16(const CsConvGemm& p, int M, int splits, hipStream_t stream, int omap_f = 0, int omap_p = 0,
-             const CsClsBatch* cls = nullptr, const CsFuseK* fuse = nullptr) {
+             const CsClsBatch* cls = nullptr, const CsFuseK* fuse = nullptr, int tm_base = 0, int tm_count = 0) {
   constexpr int BM = 32 * WMB * WAVES_M;
   constexpr int BN = 32 * WNB * WAVES_N;
-  const int tiles_m = (M + BM - 1) / BM;
+  const int tiles_m_all = (M + BM - 1) / BM;
+  if (tm_count < 0 || tm_base < 0 || tm_base + tm_count > tiles_m_all || (tm_count > 0 && (TPK != 3 || (cls && cls->n > 1) || fuse)))
+    return CS_EINVAL;                                  // a row-tile range: the Winograd-W position launches only
+  const int tiles_m = tm_count > 0 ? tm_count : tiles_m_all;
   const int tiles_n = (p.cout + BN - 1) / BN;
   CsClsBatch cb;
   memset(&cb, 0, sizeof(cb));
@@ -1347,7 +1367,7 @@ int launch16(const CsConvGemm& p, int M, int splits, hipStream_t stream, int oma
   }
   CS_LAUNCH((conv_gemm_f16x3_kernel<WMB, WNB, WAVES_M, WAVES_N, PRE, SLAB, PAIR, TPK, PW>), dim3((unsigned)nblk), dim3(64 * WAVES_M * WAVES_N), 0,
             stream, p, M, tiles_n, p.kh * p.kw, p.kw, kg_per_tap, (long long)x_bytes, (unsigned)w_bytes, vec, splits,
-            TPK == 4 ? omap_f : 0, TPK != 9 ? omap_p : 0, cb, fz);
+            TPK == 4 ? omap_f : 0, TPK != 9 ? omap_p : 0, cb, fz, tm_base, tm_count);
   CS_CHECK_LAUNCH();
   return CS_OK;
 }
@@ -1447,8 +1467,9 @@ int cs_f16x3_slab_width(const CsConvGemm& p, int tile, int splits) {
 // and accumulator scale cls_acc[c]; its pads and scatter parity follow from c and omap_f (see the kernel)
 int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p_in, int M, int tile, int splits, hipStream_t s, int omap_f, int omap_p,
                                 const void* const* cls_w, const void* const* cls_w_lo, const float* cls_acc, int ncls,
-                                const CsFuseK* fuse) {
+                                const CsFuseK* fuse, int tm_base, int tm_count) {
   CsConvGemm p = p_in;
+  if (tm_count != 0 && !(p.a_format == 1 && cs_f16x3_wino_geom(p) && (omap_f & 16))) return CS_EINVAL;
   if (splits < 1) splits = 1;
   const bool cls_sliced = (omap_f & 8) != 0;           // r5: all parity classes x K slices in one launch, partial tiles out
   if (cls_sliced && (splits < 2 || ncls < 2 || p.a_format != 0 || (tile != 4 && tile != 6) || !cs_f16x3_slab4_ok(p, tile, -1) ||
@@ -1492,9 +1513,9 @@ int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p_in, int M, int tile, int spl
       const int ncls = (omap_f & 16) ? omap_p : 0;
       if (ncls > 1 && (((M + 255) / 256) % ncls || M % 256)) return CS_EINVAL;     // whole row tiles per class
       // (256x224: the UNet's widths; 256x128 / 256x64: the VQ decoder's)
-      if (tile == 4) return launch16<1, 7, 8, 1, true, 32, false, 3>(p, M, splits, s, 0, ncls);
-      if (tile == 6) return launch16<1, 4, 8, 1, true, 32, false, 3>(p, M, splits, s, 0, ncls);
-      return launch16<1, 2, 8, 1, true, 32, false, 3>(p, M, splits, s, 0, ncls);
+      if (tile == 4) return launch16<1, 7, 8, 1, true, 32, false, 3>(p, M, splits, s, 0, ncls, nullptr, nullptr, tm_base, tm_count);
+      if (tile == 6) return launch16<1, 4, 8, 1, true, 32, false, 3>(p, M, splits, s, 0, ncls, nullptr, nullptr, tm_base, tm_count);
+      return launch16<1, 2, 8, 1, true, 32, false, 3>(p, M, splits, s, 0, ncls, nullptr, nullptr, tm_base, tm_count);
     }
     if (slab_geom && slab_slices_ok) {
       switch (tile) {

@@ -271,30 +271,37 @@ __global__ __launch_bounds__(256, 1) void kw_gemm_f16x3_kernel(const CsConvGemm 
 
 }  // namespace
 
-// Is this descriptor a GEMM the K-wave kernel takes?  Pointwise, F16X3, fp32 or pair operands, float4-aligned epilogue
-// operands.  (The tile RULE -- when auto-selection prefers it -- lives in cs_gemm.hip::auto_tile.)
-bool cs_kw_gemm_applicable(const CsConvGemm& p, int64_t M) {
-  auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+// Is this descriptor a GEMM the K-wave kernel takes?  Split in two: the GEOMETRY rule -- what auto_tile and
+// cs_conv_gemm_epilogue_caps ask, also in a sizing pass whose operand pointers are still null -- and the pointer / alignment
+// validation of an actual launch.  (The tile RULE -- when auto-selection prefers it -- lives in cs_gemm.hip::auto_tile.)
+bool cs_kw_gemm_geometry_ok(const CsConvGemm& p, int64_t M) {
   if (p.math != CS_MATH_F16X3 || M <= 0 || M > 0x7fffffffLL || p.act == CS_ACT_GEGLU) return false;
   if (!(p.kd == 1 && p.kh == 1 && p.kw == 1 && p.sd == 1 && p.sh == 1 && p.sw == 1 && p.ud == 0 && p.uh == 0 && p.uw == 0 &&
         p.pd == 0 && p.ph == 0 && p.pw == 0 && (int64_t)p.dout * p.hout * p.wout == (int64_t)p.din * p.hin * p.win))
     return false;
   if (p.a_format != 0 && p.a_format != 2) return false;
   if (p.a_format == 2 && ((p.cin & 15) || (p.lda & 15))) return false;
-  if ((p.cin & 3) || (p.lda & 3) || (p.cout & 3) || (p.ldo & 3) || !al16(p.x) || !al16(p.out) || !al16(p.w) || !p.w_lo ||
-      !al16(p.w_lo))
-    return false;
-  if ((p.bias && !al16(p.bias)) || (p.scale && (!p.shift || !al16(p.scale) || !al16(p.shift))) ||
-      (p.rowvec && ((p.ldrv & 3) || !al16(p.rowvec) || p.rv_rows <= 0)) || (p.res && ((p.ldr & 3) || !al16(p.res))))
-    return false;
+  if ((p.cin & 3) || (p.lda & 3) || (p.cout & 3) || (p.ldo & 3)) return false;
+  if ((p.scale && !p.shift) || (p.rowvec && ((p.ldrv & 3) || p.rv_rows <= 0)) || (p.res && (p.ldr & 3))) return false;
   if (64LL * p.lda * 4 >= 0x7FF00000LL) return false;            // a tile's rows inside one 32-bit offset window
   if (p.splitk > 1) return false;
   return true;
 }
 
+// the operands of a launch: present and 16-byte aligned.  A NULL x / out / w / w_lo (a dry sizing pass) is "not given yet",
+// not a reason to plan another tile: only a pointer that IS given and misaligned disqualifies the kernel.
+static bool kw_operands_ok(const CsConvGemm& p, bool launch) {
+  auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+  if (launch && (!p.x || !p.out || !p.w || !p.w_lo)) return false;
+  return al16(p.x) && al16(p.out) && al16(p.w) && al16(p.w_lo) && al16(p.bias) && al16(p.scale) && al16(p.shift) &&
+         al16(p.rowvec) && al16(p.res);
+}
+
+bool cs_kw_gemm_applicable(const CsConvGemm& p, int64_t M) { return cs_kw_gemm_geometry_ok(p, M) && kw_operands_ok(p, false); }
+
 int cs_kw_gemm_f16x3_launch(const CsConvGemm& p_in, int M, hipStream_t s) {
   CsConvGemm p = p_in;
-  if (!cs_kw_gemm_applicable(p, M)) return CS_EINVAL;
+  if (!cs_kw_gemm_geometry_ok(p, M) || !kw_operands_ok(p, true)) return CS_EINVAL;
   if (p.a_scale == 0.f) p.a_scale = cs16::A_SCALE_DEFAULT;
   if (!(p.acc_scale > 0.f) || !(p.a_scale > 0.f)) return CS_EINVAL;
   if (p.out_format != 0 && (p.out_format != 2 || !(p.out_scale > 0.f) || ((p.act == CS_ACT_GEGLU ? p.cout / 2 : p.cout) & 7) ||

@@ -540,6 +540,33 @@ extern "C" int cs_ddim_coefficients(float a_t, float a_prev, float sigma_t, floa
   return CS_OK;
 }
 
+// max |x| of an fp32 tensor folded into *slot by atomicMax of the bits (non-negative floats order like their bit patterns):
+// zero the slot first.  r6: the UNet's conv_in reads the RAW latent x_t, whose magnitude no normalisation bounds -- both hosts
+// leave its exact max |.| in a bound slot (CsConvGemm.a_bound) so that the F16X3 operand scale follows it instead of the
+// constant 16 + overflow flag + fp32 re-run (openai_model_3d.py:752-766: h = module(h, emb, context) over input_blocks[0]).
+__global__ __launch_bounds__(256) void absmax_slot_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ slot) {
+  __shared__ float red[4];
+  float m = 0.f;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (!(m < 3.0e38f)) m = 3.0e38f;                 // inf / NaN: a bound no scale can honour -- the kernel's flag reports it
+    atomicMax(reinterpret_cast<unsigned int*>(slot), __float_as_uint(m));
+  }
+}
+
+extern "C" int cs_absmax(const float* x, int64_t n, float* slot, cs_stream_t stream) {
+  if (!x || !slot || n <= 0) return CS_EINVAL;
+  CS_LAUNCH(absmax_slot_kernel, dim3(cs_grid_for(n, 256, 256 * 8)), dim3(256), 0, (hipStream_t)stream, x, n, slot);
+  CS_CHECK_LAUNCH();
+  return CS_OK;
+}
+
 extern "C" int cs_ddim_cfg_update_dev(const float* x, const float* eps, const float* noise, float* x_prev,
                                       float* pred_x0, int64_t nb, int64_t per, const float* coef5_dev,
                                       float cfg_scale, int cfg, cs_stream_t stream) {

@@ -63,6 +63,7 @@ void parse_env(CsDebug& d) {
   d.wino_min_rows = (int32_t)num("CS_WINO_MIN_ROWS", 1024);
   d.no_wino43 = flag("CS_NO_WINO43");
   d.wino43_min_rows = (int32_t)num("CS_WINO43_MIN_ROWS", 2048);
+  d.no_wino_tail = flag("CS_NO_WINO_TAIL");
 }
 
 }  // namespace

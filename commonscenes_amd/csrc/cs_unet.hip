@@ -314,6 +314,7 @@ struct Exec : ExecBase {
   const cs_unet& u;
   Exec(const cs_unet& u_, const void* arena_, void* ws_, int64_t ws_bytes_, bool dry_, hipStream_t st_)
       : ExecBase(u_, arena_, ws_, ws_bytes_, dry_, st_), u(u_) {}
+  int64_t in_bound_off = -1;      // bound slot of the latent (conv_in's operand), set by forward()
 
   Act res_block(const Layer& l, const Act& x, const Buf& semb) {
     const int rows = x.d * x.h * x.w;
@@ -496,7 +497,8 @@ struct Exec : ExecBase {
       switch (l.kind) {
         case CONV_IN:
           o = h;
-          o.b = gemm(h.b, l.g[0], h.nb, h.d, h.h, h.w, 1, 0, CS_ACT_NONE, nullptr, 0, 1, nullptr, 0, 0, 1, 0, true);
+          o.b = gemm(h.b, l.g[0], h.nb, h.d, h.h, h.w, 1, 0, CS_ACT_NONE, nullptr, 0, 1, nullptr, 0, 0, 1, 0, true, 0.f,
+                     in_bound_off);
           break;
         case RES:
           o = res_block(l, h, semb);
@@ -578,6 +580,10 @@ int forward(Exec& e, const float* x_ncdhw, const int64_t* t, const float* ctxvec
   h.nb = nbx; h.d = c.d; h.h = c.h; h.w = c.w;
   h.b = e.alloc((int64_t)nbx * S, u.cpad_in);
   if (e.ok() && !e.dry) e.chk(cs_nchw_to_ndhwc(x_ncdhw, e.p(h.b), nbx, c.in_channels, S, u.cpad_in, e.st));
+  // r6: conv_in reads the RAW latent -- its exact max |.| goes to a bound slot (unet.py::forward_ndhwc: ops.absmax_bound)
+  e.in_bound_off = e.amax_slot();
+  if (e.in_bound_off >= 0 && e.ok() && !e.dry)
+    e.chk(cs_absmax(e.p(h.b), (int64_t)nbx * S * u.cpad_in, e.bound_ptr(e.in_bound_off), e.st));
   bool shared = cfg_pairs != 0;
   auto split = [&](bool h_retained) {   // first context-dependent block: one copy per guidance half, [uc; c]
     Buf h2 = e.duplicate(h.b);

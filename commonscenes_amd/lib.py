@@ -17,7 +17,7 @@ import torch  # noqa: F401
 
 from .build import LIB_PATH
 
-ABI_VERSION = 17     # cs_abi_version() of the library this module's SIGNATURES table describes
+ABI_VERSION = 18     # cs_abi_version() of the library this module's SIGNATURES table describes
 CS_OK = 0
 CS_EINVAL = -22
 CS_ENOMEM = -12
@@ -74,7 +74,8 @@ class CsDebug(C.Structure):
         "no_split16", "no_pair16", "no_upfold", "no_splitk", "no_fused_geglu", "no_tapcol", "tapcol_tile", "no_cfg_split",
         "concat_copy", "tile512", "no_pw", "no_slab4", "no_attn_img", "attn_nw8", "no_up2_direct", "no_up2_batch",
         "plan_pow2", "slice_tile2", "no_gn_parts", "no_pair_epilogue", "no_dyn_scale", "no_tok_rules", "no_fused_reduce",
-        "no_gn_fold", "no_kwave", "no_static_scales", "no_wino", "wino_min_rows", "no_wino43", "wino43_min_rows")] + [
+        "no_gn_fold", "no_kwave", "no_static_scales", "no_wino", "wino_min_rows", "no_wino43", "wino43_min_rows",
+        "no_wino_tail")] + [
         ("split16_min_rows", C.c_int64), ("cfg_split_min_rows", C.c_int64), ("gn_small_group", C.c_int64)]
 
 
@@ -106,6 +107,7 @@ SIGNATURES = {
     "cs_conv_gemm_epilogue_caps": (_i, [C.POINTER(CsConvGemm), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "cs_conv_wino_ok": (_i, [C.POINTER(CsConvGemm)]),
     "cs_conv_wino_plan": (_i, [C.POINTER(CsConvGemm), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    "cs_conv_wino_plan_info": (_i, [C.POINTER(CsConvGemm), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "cs_conv_wino_positions": (_i, [C.POINTER(CsConvGemm), _s]),
     "cs_conv_wino_output": (_i, [C.POINTER(CsConvGemm), _s]),
     "cs_conv_gemm_launch_info": (_i, [C.POINTER(CsConvGemm), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
@@ -158,6 +160,7 @@ SIGNATURES = {
     "cs_copy_rows": (_i, [_f, _f, _l, _i, _i, _i, _s]),
     "cs_add_rowvec": (_i, [_f, _f, _l, _i, _i, _i, _i, _s]),
     "cs_nchw_to_ndhwc": (_i, [_f, _f, _i, _i, _i, _i, _s]),
+    "cs_absmax": (_i, [_f, _l, _f, _s]),
     "cs_ndhwc_to_nchw": (_i, [_f, _f, _i, _i, _i, _i, _s]),
     "cs_timestep_embedding": (_i, [_f, _f, _i, _i, _fl, _s]),
     "cs_ddim_cfg_update": (_i, [_f, _f, _f, _f, _f, _l, _l, _fl, _fl, _fl, _fl, _fl, _i, _s]),
@@ -249,8 +252,14 @@ class CsOverflowError(CsError):
     """A CS_MATH_F16X3 kernel met an activation beyond the fp16 range (CS_STATUS_F16X3_OVERFLOW)."""
 
 
+class CsSplitKTimeout(CsError):
+    """A reducer of a fused split-K launch gave up waiting for a slice that never reached a CU (CS_STATUS_SPLITK_TIMEOUT):
+    the launch was not resident.  The host classes re-run with the two-kernel form."""
+
+
 STATUS_F16X3_OVERFLOW = 1
 STATUS_INTERNAL = 2
+STATUS_SPLITK_TIMEOUT = 4
 
 
 def check(rc: int, what: str) -> None:
@@ -262,6 +271,17 @@ def check(rc: int, what: str) -> None:
 def debug() -> CsDebug:
     """The library's CsDebug struct (live view): the ONE parse of the CS_* A/B switches, shared by every host."""
     return load().cs_debug().contents
+
+
+def debug_set(**fields) -> None:
+    """Flip CsDebug switches for the REST of the process (no restore): what a host does when it must leave a route for good,
+    e.g. `debug_set(no_fused_reduce=1)` after CS_STATUS_SPLITK_TIMEOUT."""
+    new = CsDebug.from_buffer_copy(debug())
+    for k, v in fields.items():
+        if not hasattr(new, k):
+            raise AttributeError(f"CsDebug has no field {k!r}")
+        setattr(new, k, int(v))
+    load().cs_debug_set(C.byref(new))
 
 
 class debug_override:

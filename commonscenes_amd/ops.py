@@ -78,15 +78,22 @@ def check_overflow(device=None, what: str = "F16X3 kernels") -> None:
     is carried as fp16 halves of a * a_scale, where a_scale is the layer's operand scale -- derived from the producing
     normalisation's bound (norm_a_scale: cannot overflow) or 16 for raw activations (|a| >= 65504 / 16 ~ 4094
     overflows).  That launch's output is garbage; the caller re-runs with set_math('fp32').
-    CS_STATUS_INTERNAL (a kernel was asked for an epilogue output on a path that cannot produce it, or a K slice never
-    arrived at its tile's counter: a planning bug, never a data condition) raises CsError -- no fall-back hides it."""
+    CS_STATUS_INTERNAL (a kernel was asked for an epilogue output on a path that cannot produce it: a planning bug, never
+    a data condition) raises CsError -- no fall-back hides it.  CS_STATUS_SPLITK_TIMEOUT (a fused split-K launch was not
+    resident: CUs held by another stream or masked) raises CsSplitKTimeout; the model classes answer it by re-running with
+    the two-kernel split-K, which needs no co-residency."""
     st = read_status(device)
-    if st & L.STATUS_INTERNAL:
+    if st & (L.STATUS_INTERNAL | L.STATUS_SPLITK_TIMEOUT):
         for t in _SYNC.values():          # the counters of an aborted hand-off may be left non-zero
             t.zero_()
+    if st & L.STATUS_INTERNAL:
         raise L.CsError(f"{what}: CS_STATUS_INTERNAL -- a kernel reached an epilogue path that cannot emit what its "
-                        "descriptor asked for (GroupNorm partials / operand pair), or a split-K slice never arrived; "
+                        "descriptor asked for (GroupNorm partials / operand pair); "
                         "results of this run are invalid (library planning bug)")
+    if st & L.STATUS_SPLITK_TIMEOUT:
+        raise L.CsSplitKTimeout(f"{what}: CS_STATUS_SPLITK_TIMEOUT -- a fused split-K launch was not resident (a slice never "
+                                "reached a CU before its tile's reducers gave up); results of this run are invalid -- re-run "
+                                "with the two-kernel split-K (lib.debug_set(no_fused_reduce=1); the model classes do)")
     if st & L.STATUS_F16X3_OVERFLOW:
         raise L.CsOverflowError(f"{what}: an activation left the fp16 range of CS_MATH_F16X3 (|a| * a_scale >= 65504, "
                                 "a_scale = the layer's operand scale: 16 for raw activations); "
@@ -233,16 +240,22 @@ _SWITCHES = {
 
 
 def _sw(name: str):
-    """The switch's value: the library's CsDebug view (lib.debug_override(...) / cs_debug_set reach every host at once).
-    A module global of the same name -- `ops.SPLITK = False`, monkeypatch.setattr(ops, ...) -- overrides it ONLY while it
-    DIFFERS from the default-on state: setting it back to True (what monkeypatch's undo and the old tests' `finally` do)
-    removes the override instead of pinning the switch on for the rest of the process."""
+    """The switch's value: the library's CsDebug view (lib.debug_override(...) / cs_debug_set reach every host at once),
+    unless a module global of the same name shadows it -- `ops.SPLITK = False` / monkeypatch.setattr(ops, "SPLITK", True)
+    force the switch off / ON for this module's reads (also against the environment).  Reading never writes (ADVICE r5:
+    r4's version deleted a truthy override on read, so a forced-on switch was silently dropped); `reset_switches()`
+    removes every shadow -- the tests' autouse fixture calls it, so a leftover override cannot outlive its test."""
     g = globals()
     if name in g:
-        if g[name] is False or g[name] == 0:
-            return False
-        del g[name]                         # restored to "on": back to the live CsDebug view
+        return bool(g[name])
     return _SWITCHES[name](L.debug())
+
+
+def reset_switches() -> None:
+    """drop every module-global shadow of a CsDebug switch (back to the live view)"""
+    g = globals()
+    for name in _SWITCHES:
+        g.pop(name, None)
 
 
 def __getattr__(name: str):          # PEP 562: ops.SPLITK etc. for outside readers
@@ -790,11 +803,17 @@ def _conv_wino(xw: "Wino16", w: PackedWeight, act, rowvec, rv_rows, res, scale, 
         # flops = what the position GEMMs EXECUTE (18 of the direct form's 27 multiply-adds per output); flops_direct = the
         # direct form's algorithmic work the pair of launches replaces; m / k = the position launch's own GEMM shape
         npos = xw.variant + 2
+        # (r6: the tail plan writes one slice for the main row tiles and `slices` for the tail's: the average per row tile)
+        sl_, tmm_, tmt_ = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        L.check(lib.cs_conv_wino_plan_info(C.byref(p), C.byref(sl_), C.byref(tmm_), C.byref(tmt_)), "cs_conv_wino_plan_info")
+        eff_slices = float(sk.value)
+        if tmm_.value > 0 and sl_.value == sk.value:
+            eff_slices = (tmm_.value + (tmt_.value - tmm_.value) * sk.value) / float(tmt_.value)
         prof.append(dict(e0=e0, e1=e1, e2=e2, flops=2.0 * (mo // xw.variant) * npos * w.cout * w.cin * 9,
                          flops_direct=2.0 * mo * w.cout * w.cin * 27, taps=9, m=(mo // xw.variant) * npos, n=w.cout, k=w.cin * 9,
                          npos=npos,
                          tile=4 if w.cout % 224 == 0 else 6 if w.cout % 128 == 0 else 7, slab=32, pre=True, pair=False,
-                         res=res is not None, wino=True, slices=int(sk.value)))
+                         res=res is not None, wino=True, slices=eff_slices, tail_plan=bool(tmm_.value > 0)))
     if paired:
         return Pair16(out, float(out_pair))
     return attach_stats(out, st)
@@ -1213,6 +1232,20 @@ def add_rowvec_(x: Tensor, v: Tensor, rows: int) -> Tensor:
         raise L.CsError("add_rowvec shape mismatch")
     L.check(L.load().cs_add_rowvec(x.data_ptr(), v.data_ptr(), m, c, ldx, ldv, rows, _stream()), "cs_add_rowvec")
     return x
+
+
+def absmax_bound(x: Tensor, slot: Optional[Tensor]) -> Optional[Tensor]:
+    """Leave the exact max |x| in `slot` (a zeroed 1-element fp32 device tensor) and remember it on x (`x.cs_bound`): the
+    magnitude bound of a RAW tensor that nothing normalises -- the UNet's conv_in operand x_t (cs_absmax; r6).  A consumer
+    hands it to conv_gemm(x_bound=).  None when the feature is off."""
+    if slot is None or not _sw("DYN_SCALE"):
+        return None
+    _chk(x, "x")
+    if not x.is_contiguous():
+        raise L.CsError("absmax_bound: contiguous tensor expected")
+    L.check(L.load().cs_absmax(x.data_ptr(), x.numel(), slot.data_ptr(), _stream()), "cs_absmax")
+    x.cs_bound = slot
+    return slot
 
 
 def nchw_to_ndhwc(x: Tensor, cpad: Optional[int] = None) -> Tensor:

@@ -20,6 +20,7 @@ Extensions over the reference (SURVEY 8b "Extension the build adds"):
 """
 from __future__ import annotations
 
+import logging
 import os
 
 import time
@@ -41,6 +42,7 @@ from .vqvae_native import NativeVQVAE
 from .vqvae import VQVAE, load_vqvae
 
 Tensor = torch.Tensor
+_log = logging.getLogger("commonscenes_amd.sdfusion")
 
 
 class AttrDict(dict):
@@ -131,7 +133,23 @@ class SDFusionText2ShapeModel:
         self.mini_B = int(os.environ.get("CS_MINI_B", "7"))               # :493 (hard-coded 7 in the reference)
         # objects per sampler LAUNCH: consecutive mini-batches of the deterministic sampler run as one batch (see the
         # module docstring); 0 = never coalesce
-        self.launch_B = int(os.environ.get("CS_LAUNCH_B", "32"))
+        self._launch_B = int(os.environ.get("CS_LAUNCH_B", "32"))
+        self._launch_B_explicit = "CS_LAUNCH_B" in os.environ      # (rel2shape_many's fill-the-chip default)
+        # which fall-backs this model has taken (sticky, like the math mode itself): `unet_fp32` / `vqvae_fp32` = an F16X3
+        # operand left the fp16 range and the module continues on the fp32-input MFMA kernels (4-5x slower);
+        # `splitk_two_kernel` = a fused split-K launch was not resident.  Every rel2shape* call reports a copy in `last_meta`
+        # (and returns it with return_meta=True); each transition is logged at WARNING.
+        self.fell_back = {"unet_fp32": False, "vqvae_fp32": False, "splitk_two_kernel": False}
+        self.last_meta = None
+
+    @property
+    def launch_B(self) -> int:
+        return self._launch_B
+
+    @launch_B.setter
+    def launch_B(self, v):           # an assignment is an explicit cap: rel2shape_many honours it
+        self._launch_B = int(v)
+        self._launch_B_explicit = True
 
     def name(self):
         return "SDFusion-Text2Shape-Model"
@@ -213,30 +231,53 @@ class SDFusionText2ShapeModel:
             ops.check_overflow(self.device, "DDIM sampling (UNet)")
             return out
         try:
-            return run()
+            try:
+                return run()
+            except L.CsSplitKTimeout as e:
+                # a fused split-K launch was not resident (CUs held by another stream / a CU mask): same arithmetic on the
+                # two-kernel form, which needs no co-residency -- for the rest of the process
+                import warnings
+                warnings.warn(f"{e}; re-running with the two-kernel split-K")
+                _log.warning("fused split-K reduce timed out: re-running this mini-batch with no_fused_reduce=1")
+                L.debug_set(no_fused_reduce=1)
+                self.fell_back["splitk_two_kernel"] = True
+                return run()
         except L.CsOverflowError:
             if self.overflow_policy != "fp32" or getattr(self.df, "math", None) != L.MATH_F16X3:
                 raise
             import warnings
             warnings.warn("F16X3 activation overflow in the UNet: re-running this mini-batch (and continuing) on the "
                           "fp32-input MFMA kernels (set_math('fp32'))")
+            _log.warning("F16X3 activation overflow in the UNet: this model continues on the fp32-input MFMA kernels "
+                         "(~4-5x slower); tools/check_checkpoint.py prints the per-layer bounds of a checkpoint")
             self.df.set_math("fp32")
             self._df_fell_back = True
+            self.fell_back["unet_fp32"] = True
             return run()
 
     def _decode_checked(self, samples):
         ops.clear_status(self.device)               # see _sample_minibatch: attribute only this decode's kernels
         out = self.vqvae_module.decode_no_quant(samples)
         try:
-            ops.check_overflow(self.device, "VQ-VAE decode")
+            try:
+                ops.check_overflow(self.device, "VQ-VAE decode")
+            except L.CsSplitKTimeout as e:              # see _sample_minibatch
+                _log.warning("fused split-K reduce timed out in the VQ-VAE decode: re-running with no_fused_reduce=1 (%s)", e)
+                L.debug_set(no_fused_reduce=1)
+                self.fell_back["splitk_two_kernel"] = True
+                ops.clear_status(self.device)
+                out = self.vqvae_module.decode_no_quant(samples)
+                ops.check_overflow(self.device, "VQ-VAE decode")
         except L.CsOverflowError:
             if (self.overflow_policy != "fp32" or getattr(self.vqvae, "math", None) != L.MATH_F16X3
                     or not hasattr(self.vqvae, "set_math")):
                 raise
             import warnings
             warnings.warn("F16X3 activation overflow in the VQ-VAE decoder: re-running on the fp32-input MFMA kernels")
+            _log.warning("F16X3 activation overflow in the VQ-VAE decoder: this model continues on the fp32-input MFMA kernels")
             self.vqvae.set_math("fp32")
             self._vq_fell_back = True
+            self.fell_back["vqvae_fp32"] = True
             out = self.vqvae_module.decode_no_quant(samples)
         return out
 
@@ -250,11 +291,15 @@ class SDFusionText2ShapeModel:
                               float(bool(getattr(self, "_vq_fell_back", False)))], device=self.device)
         flags = dist.all_reduce_max(flags)
         if flags[0] > 0 and getattr(self.df, "math", None) == L.MATH_F16X3:
+            _log.warning("another rank's UNet fell back to fp32: this rank follows (all ranks stay on the same numerics)")
             self.df.set_math("fp32")
             self._df_fell_back = True
+            self.fell_back["unet_fp32"] = True
         if flags[1] > 0 and getattr(self.vqvae, "math", None) == L.MATH_F16X3 and hasattr(self.vqvae, "set_math"):
+            _log.warning("another rank's VQ-VAE decoder fell back to fp32: this rank follows")
             self.vqvae.set_math("fp32")
             self._vq_fell_back = True
+            self.fell_back["vqvae_fp32"] = True
 
     def _launch_slices(self, lo: int, hi: int, mini_B: Optional[int], launch_B: Optional[int], ddim_eta: float):
         """The sampler launches over objects [lo, hi).  :493-511 slices the objects into ceil(B / 7) mini-batches and runs
@@ -284,8 +329,11 @@ class SDFusionText2ShapeModel:
     @torch.no_grad()
     def rel2shape_many(self, datas, ddim_steps=100, ddim_eta=0.0, uc_scale=None, x_Ts=None, mini_B: Optional[int] = None,
                        return_latents: bool = False, max_steps: Optional[int] = None, sampler: str = "ddim",
-                       launch_B: Optional[int] = None):
+                       launch_B: Optional[int] = None, return_meta: bool = False):
         """Extension: rel2shape for SEVERAL scenes in one coalesced sampler + decode.
+        Single-rank only (it has no object sharding: under torch.distributed with more than one rank it raises -- call
+        rel2shape per scene there); `launch_B=None` = model.launch_B when that was set explicitly (attribute / CS_LAUNCH_B),
+        else the fill-the-chip default of 64 objects per launch.
 
         The reference's evaluation loop calls rel2shape once per scene (scripts/eval_3dfront.py:484-513 ->
         VAEGAN_V2FULL.py:600-618 -> sdfusion_txt2shape_model.py:459-516) with 5-15 shaped objects each: small batches, the
@@ -297,6 +345,11 @@ class SDFusionText2ShapeModel:
         the launch's object count), within fp32 summation order otherwise.  Deterministic samplers only (eta = 0)."""
         if float(ddim_eta) != 0.0:
             raise ValueError("rel2shape_many coalesces scenes: deterministic sampling (ddim_eta = 0) only")
+        if dist.world()[1] > 1:
+            raise RuntimeError("rel2shape_many is single-rank (no object sharding / rank-failure agreement): call "
+                               "rel2shape(sharded=True) per scene under torch.distributed")
+        if x_Ts is not None and len(x_Ts) != len(datas):
+            raise ValueError(f"rel2shape_many: {len(datas)} scenes but {len(x_Ts)} x_Ts (one per scene, or None)")
         self.switch_eval()
         if sampler == "ddim":
             smp = DDIMSampler(self)
@@ -336,7 +389,9 @@ class SDFusionText2ShapeModel:
         noise_all = torch.cat(noises, dim=0).contiguous()
         gen, lats = [], []
         if launch_B is None:
-            launch_B = max(int(self.launch_B), 64)          # scenes are batched to fill the chip: up to 64 objects per launch
+            # scenes are batched to fill the chip (up to 64 objects per launch) -- unless the operator capped launch_B
+            # (memory): an explicit attribute / CS_LAUNCH_B is honoured, never silently raised
+            launch_B = int(self.launch_B) if self._launch_B_explicit else 64
         for sl in self._launch_slices(0, total, mini_B, launch_B, ddim_eta):
             self.last_launch_sizes.append(sl.stop - sl.start)
             samples = self._sample_minibatch(smp, ddim_steps, shape, c_all[sl], uc_all[sl], noise_all[sl].contiguous(),
@@ -347,13 +402,28 @@ class SDFusionText2ShapeModel:
         gens = list(torch.split(g_all, counts, dim=0))
         lat = list(torch.split(l_all, counts, dim=0))
         self.last_latents, self.gen_df = l_all, g_all
-        return (gens, lat) if return_latents else gens
+        meta = self._meta(ddim_steps, sampler)
+        out = (gens, lat) if return_latents else gens
+        if return_meta:
+            return (*out, meta) if return_latents else (out, meta)
+        return out
+
+    def _meta(self, ddim_steps, sampler):
+        """what the last rel2shape* call ran as: kept in `last_meta`, returned with return_meta=True."""
+        self.last_meta = {"fell_back": dict(self.fell_back), "any_fell_back": any(self.fell_back.values()),
+                          "launch_sizes": list(self.last_launch_sizes), "ddim_steps": int(ddim_steps), "sampler": sampler,
+                          "unet_math": {L.MATH_FP32: "fp32", L.MATH_F16X3: "f16x3"}.get(getattr(self.df, "math", None)),
+                          "vqvae_math": {L.MATH_FP32: "fp32", L.MATH_F16X3: "f16x3"}.get(getattr(self.vqvae, "math", None))}
+        return self.last_meta
 
     @torch.no_grad()
     def rel2shape(self, data, ddim_steps=100, ddim_eta=0.0, uc_scale=None, x_T: Optional[Tensor] = None,
                   mini_B: Optional[int] = None, return_latents: bool = False, max_steps: Optional[int] = None,
-                  sharded: Optional[bool] = None, sampler: str = "ddim", launch_B: Optional[int] = None):
+                  sharded: Optional[bool] = None, sampler: str = "ddim", launch_B: Optional[int] = None,
+                  return_meta: bool = False):
         """:459-516.  data = {'sdf': (B,...) only its batch size is used, 'rel': (B,1,1280), 'uc': (B,1,1280)}.
+        `return_meta=True` appends a dict (also kept as `self.last_meta`): `fell_back` (which fall-backs this model has taken:
+        fp32 re-runs after an F16X3 range overflow, the two-kernel split-K), the launch sizes, the math modes.
 
         Extensions: `x_T` injection (the reference seeds from the clock), `mini_B` (reference: 7),
         `launch_B` (objects per sampler launch: consecutive mini-batches of the deterministic sampler are coalesced, see
@@ -435,9 +505,10 @@ class SDFusionText2ShapeModel:
                 llat = dist.all_gather_objects(llat, B)
         self.last_latents = llat            # this rank's (or, with return_latents, all) sampled latents: diagnostics
         self.gen_df = local
+        meta = self._meta(ddim_steps, sampler)
         if return_latents:
-            return self.gen_df, llat
-        return self.gen_df
+            return (self.gen_df, llat, meta) if return_meta else (self.gen_df, llat)
+        return (self.gen_df, meta) if return_meta else self.gen_df
 
     # ---- the other callers of the same sampler (sdfusion_txt2shape_model.py:368-457) -----------------------------------
     # The reference runs these over ALL objects in one sampler call (no mini-batching) with fresh noise per object

@@ -716,7 +716,8 @@ class DiffusionUNet:
             k = l["kind"]
             of = out_fn if li == len(layers) - 1 else None
             if k == "conv_in":
-                h = ops.conv_gemm(h, pk[p], math=self.math, out_fn=of, stats=True)
+                # (x_bound: the RAW latent -- its exact max |.| from forward_ndhwc, so no x_t can leave the fp16 range, r6)
+                h = ops.conv_gemm(h, pk[p], math=self.math, out_fn=of, stats=True, x_bound=getattr(h, "cs_bound", None))
             elif k == "res":
                 if li == 0 and split_skip is not None and p in self._split_info:
                     h = self._res_split(p, l, h, split_skip, semb, of)
@@ -751,6 +752,8 @@ class DiffusionUNet:
         self._amax = (torch.zeros(64, dtype=torch.float32, device=h.device)
                       if self.math == L.MATH_F16X3 and ops._sw("DYN_SCALE") and ops._sw("GN_PARTS") else None)
         self._amax_i = 0
+        if self._amax is not None:
+            ops.absmax_bound(h, self._slot())          # conv_in's operand scale follows the latent itself (ops.absmax_bound)
         temb = ops.timestep_embedding(t, self.cfg["model_channels"])
         e1 = ops.linear(temb, pk[P + "time_embed.0"], act=L.ACT_SILU, math=self.math)
         # every consumer of `emb` is emb_layers = SiLU -> Linear (openai_model_3d.py:257-263): keep SiLU(emb)

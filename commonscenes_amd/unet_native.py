@@ -179,7 +179,12 @@ class NativeDiffusionUNet:
             from .unet import unet_blocks
             inp, mid, out = unet_blocks(self.cfg)[:3]
             widths = [l["cin"] for layers in (list(inp) + [mid] + list(out)) for l in layers if l["kind"] == "attn"]
-            if sum(widths) == self.ctx_floats and widths:
+            if widths and sum(widths) != self.ctx_floats:
+                # the static t1 / t2 scales would silently omit the context term and the run would rest on the overflow
+                # flag alone: a layout mismatch between unet_blocks() and the driver is a bug, say so
+                raise L.CsError(f"cs_unet context row vector has {self.ctx_floats} floats, the attention blocks' widths sum "
+                                f"to {sum(widths)}: cannot derive the per-block context bounds")
+            if widths:
                 mx = torch.stack([seg.abs().max() for seg in torch.split(vec, widths, dim=1)]).cpu().tolist()
                 arr = (C.c_float * len(widths))(*[float(v) for v in mx])
                 L.check(L.load().cs_unet_set_context_bounds(self._h, arr, len(widths)), "cs_unet_set_context_bounds")

@@ -56,6 +56,11 @@ typedef struct ihipStream_t* cs_stream_t; /* == hipStream_t */
 /*   CS_STATUS_INTERNAL: a kernel was asked for an epilogue output (gn_part / out_format) on a path that cannot produce it
  *   -- a host-side planning bug, never data dependent; the launch's extra outputs are missing. */
 #define CS_STATUS_INTERNAL 2
+/*   CS_STATUS_SPLITK_TIMEOUT (r6): a reducer of a fused split-K launch (CsConvGemm.splitk_sync) gave up waiting for a slice
+ *   of its tile that never reached a CU -- the launch was not resident and the backstop fired (never data dependent).  That
+ *   launch's output is incomplete and the counters may be left non-zero: zero splitk_sync and re-run with the two-kernel
+ *   form (CsDebug.no_fused_reduce = 1 / splitk_sync = NULL) -- the host classes do. */
+#define CS_STATUS_SPLITK_TIMEOUT 4
 
 /*
  * Debug / A-B switches (r4: ONE struct instead of ~40 getenv() calls spread over two host languages).  All zero = the
@@ -97,6 +102,8 @@ typedef struct CsDebug {
   int32_t wino_min_rows;      /* Winograd-W route from this many output rows (default 1024; 0 = the default) */
   int32_t no_wino43;          /* never F(4,3) along W (a_format = 4): F(2,3) wherever the Winograd-W route is taken */
   int32_t wino43_min_rows;    /* F(4,3) from this many output rows (default 2048; 0 = the default) */
+  int32_t no_wino_tail;       /* Winograd-W position launches always with ONE slice count for every tile (r6: whole rounds unsliced +
+                                 a K-sliced tail launch over the remaining row tiles); different fp32 sum order */
   int64_t split16_min_rows;   /* pre-split operands on the 128-row slab tile from this many rows (8192; 0 = never) */
   int64_t cfg_split_min_rows; /* channel-split ResBlocks from this many rows (65536) */
   int64_t gn_small_group;     /* single-launch GroupNorm up to this many elements per (sample, group) (11264) */
@@ -254,13 +261,14 @@ typedef struct CsConvGemm {
   const float* a_bound;
   /* ABI 15 (r5), split-K only: splitk_sync != NULL lets cs_conv_gemm fold the reduce + epilogue INTO the slice kernel (no
    * second launch, no flush of the partial tiles between two kernels): every slice workgroup publishes its partial tile,
-   * arrives on its output tile's counter, and the first `reducers` slices of the tile then each sum a 16-row-aligned share of
+   * arrives on its output tile's counter, and the LAST `reducers` ARRIVERS of the tile (by the ticket of that atomic: r6 --
+   * earlier arrivers leave at once and free their CUs) then each sum a 16-row-aligned share of
    * the tile over all slices IN SLICE ORDER and apply the epilogue -- the same sums, the same order, the same bits as the
    * two-kernel form (which remains the path when splitk_sync is NULL, when the launch has more workgroups than the device
    * can hold resident at once, or under CS_NO_FUSED_REDUCE=1).  splitk_sync points at splitk_sync_words int32 words
    * (>= 2 per output tile) that are ZERO on entry; the kernel returns them to zero, so one buffer zeroed once serves every
-   * launch on a stream (launches on different streams need different buffers).  A slice that never arrives (a resident-
-   * workgroup miscount) raises CS_STATUS_INTERNAL after a bounded wait instead of hanging. */
+   * launch on a stream (launches on different streams need different buffers).  A slice that never arrives raises
+   * CS_STATUS_SPLITK_TIMEOUT after a bounded wait instead of hanging (see that status bit). */
   int32_t* splitk_sync;
   int32_t splitk_sync_words;
 } CsConvGemm;
@@ -294,6 +302,11 @@ int cs_conv_gemm_plan(const CsConvGemm* desc, int32_t* splitk, int64_t* splitk_w
  * reads the variant from desc->a_format (3 or 4).) */
 int cs_conv_wino_ok(const CsConvGemm* desc);
 int cs_conv_wino_plan(const CsConvGemm* desc, int32_t* splitk, int64_t* ws_bytes);
+/* (ABI 18) the shape of the position launch(es) behind that plan: `slices` = cs_conv_wino_plan's splitk; tm_main > 0 = the TAIL
+ * plan -- row tiles [0, tm_main) of the tiles_m 256-row tiles run unsliced (whole rounds of the chip), row tiles [tm_main,
+ * tiles_m) as a second launch cut into `slices` K slices; tm_main = 0 = every tile in `slices` uniform slices.  Host-only
+ * (bench.py's byte accounting); cs_conv_gemm takes the tail plan exactly when desc->splitk == slices. */
+int cs_conv_wino_plan_info(const CsConvGemm* desc, int32_t* slices, int32_t* tm_main, int32_t* tiles_m);
 /* The two launches of cs_conv_gemm(a_format = 3) on their own, for hosts that time them separately (bench.py's per-kernel
  * HIP events): cs_conv_wino_positions = the four position GEMMs into splitk_ws, cs_conv_wino_output = the output transform +
  * epilogue from splitk_ws.  Same descriptor, same validation; calling the first and then the second IS cs_conv_gemm. */
@@ -529,6 +542,10 @@ int cs_add_rowvec(float* x, const float* v, int64_t m, int c, int ldx, int ldv, 
 
 /* Layout: NCDHW [nb][c][s] -> NDHWC [nb][s][cpad] (channels >= c zero filled) and back. */
 int cs_nchw_to_ndhwc(const float* x, float* y, int nb, int c, int s, int cpad, cs_stream_t stream);
+/* (ABI 18) max |x| over n floats folded into *slot (atomicMax of the bits: zero it first).  What both hosts leave as the
+ * magnitude bound (CsConvGemm.a_bound) of the UNet's conv_in operand -- the RAW latent x_t, which no normalisation bounds
+ * (openai_model_3d.py:752-766, input_blocks[0]): its F16X3 operand scale then follows the tensor, no overflow possible. */
+int cs_absmax(const float* x, int64_t n, float* slot, cs_stream_t stream);
 int cs_ndhwc_to_nchw(const float* x, float* y, int nb, int c, int s, int ldx, cs_stream_t stream);
 
 /*

@@ -29,6 +29,16 @@ def pytest_collection_modifyitems(config, items):
             it.add_marker(skip)
 
 
+@pytest.fixture(autouse=True)
+def _reset_ops_switch_shadows():
+    """a test may shadow a CsDebug switch with a module global (ops.SPLITK = False, monkeypatch.setattr(ops, ...)); whatever
+    it leaves behind is dropped here, so no override outlives its test (ops._sw no longer clears anything on read)."""
+    yield
+    mod = sys.modules.get("commonscenes_amd.ops")
+    if mod is not None:
+        mod.reset_switches()
+
+
 def rel_l2(a, b):
     """rel-L2 of a against b in fp64.  CS_PARITY_LOG=<file>: every measured value is appended with the id of the test that
     took it (how profiles/r03_parity_per_op.txt -- the record the per-op gates were set from -- is produced)."""

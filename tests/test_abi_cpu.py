@@ -27,7 +27,7 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(dll, s), f"{s} declared in the header but not exported"
         assert s in lib.SIGNATURES, f"{s} has no ctypes signature"
     assert set(lib.SIGNATURES) == set(syms)
-    assert dll.cs_abi_version() == lib.ABI_VERSION == 17
+    assert dll.cs_abi_version() == lib.ABI_VERSION == 18
 
 
 def test_struct_layout_matches_header():

@@ -309,6 +309,51 @@ def test_transformer_operands_take_static_scales_and_need_no_fallback(scaled):
     assert torch.equal(en, eps), f"native vs python: {rel_l2(en, eps):.2e}"
 
 
+@pytest.mark.parametrize("mag", [1.0, 3.0e4, 1.0e-4])
+def test_conv_in_operand_scale_follows_the_latent(mag):
+    """r6: the UNet's conv_in reads the RAW latent x_t (openai_model_3d.py:752-766), which used to ride
+    the constant operand scale 16 + the overflow flag (|x| >= 4094 -> fp32 re-run of the mini-batch, a 4.6x cliff).  Both
+    hosts now leave its exact max |.| in a bound slot (cs_absmax -> CsConvGemm.a_bound): a latent at 3e4 (and one at 1e-4)
+    runs on F16X3 without a flag, at fp32 grade of the fp64 oracle, the two hosts bit for bit; with the feature off
+    (CS_NO_DYN_SCALE: the constant 16) the 3e4 latent raises the flag."""
+    from commonscenes_amd import lib as L, ops, synth
+    from commonscenes_amd.unet import DiffusionUNet, unet_param_shapes
+    from commonscenes_amd.unet_native import NativeDiffusionUNet
+    from oracle import ref_torch as R
+    from test_model_gpu import _unet_cfg
+    cfg = _unet_cfg(True)
+    sd = synth.synth_state_dict(unet_param_shapes(cfg))
+    B = 2
+    x = synth.gaussian_like("cin:x", (B, 3, 16, 16, 16)) * mag
+    ctx = synth.gaussian_like("cin:ctx", (B, 1, 1280))
+    t = torch.tensor([981, 21], dtype=torch.long)
+    with torch.no_grad():
+        ref = R.unet_forward({k: v.double() for k, v in sd.items()}, cfg, x.double(), t, ctx.double())
+    df = DiffusionUNet(cfg, conditioning_key="crossattn", device="cuda").set_math("f16x3")
+    df.load_state_dict(sd)
+    ops.read_status()
+    eps = df(x.cuda(), t.cuda(), c_crossattn=[ctx.cuda()])
+    torch.cuda.synchronize()
+    flag = ops.read_status()
+    e = rel_l2(eps, ref)
+    with L.debug_override(no_dyn_scale=1):
+        df.reset_run_cache()
+        df(x.cuda(), t.cuda(), c_crossattn=[ctx.cuda()])
+        torch.cuda.synchronize()
+        fold = ops.read_status()
+    df.reset_run_cache()
+    print(f"conv_in operand at |x| ~ {mag:g}: rel-L2 vs fp64 {e:.2e}, flag {flag}; constant scale 16: flag {fold}")
+    assert flag == 0 and e < 5e-6
+    if mag >= 1e4:
+        assert fold & L.STATUS_F16X3_OVERFLOW
+    nd = NativeDiffusionUNet(cfg, conditioning_key="crossattn", device="cuda", math="f16x3")
+    nd.load_state_dict(sd)
+    en = nd(x.cuda(), t.cuda(), c_crossattn=[ctx.cuda()])
+    torch.cuda.synchronize()
+    assert ops.read_status() == 0
+    assert torch.equal(en, eps), f"native vs python: {rel_l2(en, eps):.2e}"
+
+
 def test_native_vqvae_overflow_falls_back_to_fp32(tmp_path, monkeypatch):
     """with unet_driver='native' the decode runs on NativeVQVAE, whose F16X3 overflow fall-back needs
     set_math().  A decoder whose conv_in bias puts one channel at 1e4 overflows the first raw-activation consumer
