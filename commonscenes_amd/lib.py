@@ -222,7 +222,10 @@ def load(path: Path | None = None) -> C.CDLL:
     global _LIB
     if _LIB is not None and path is None:
         return _LIB
-    p = Path(path) if path else LIB_PATH
+    # CS_LIB_PATH (A/B timing of compile-time what-if builds only: tools/build_alt.sh writes them next to the product
+    # library): another build of the SAME sources and ABI; never set in the product
+    alt = os.environ.get("CS_LIB_PATH")
+    p = Path(path) if path else (Path(alt) if alt else LIB_PATH)
     if not p.exists():
         raise NativeLibraryMissing(
             f"{p} not found. Build it with `python -m commonscenes_amd.build` "

@@ -37,7 +37,7 @@ def R():
 
 def test_library_loads():
     from commonscenes_amd import lib
-    assert lib.load().cs_abi_version() == lib.ABI_VERSION == 17
+    assert lib.load().cs_abi_version() == lib.ABI_VERSION == 18
 
 
 # ---- implicit-GEMM conv / linear ----------------------------------------------------------------
