@@ -57,8 +57,6 @@ TILE_SHAPES = {1: ("2,2,2,2", "128x128"), 2: ("1,7,4,1", "128x224"), 3: ("1,1,2,
 
 def kernel_label(key):
     tile, slab, pre = key[:3]
-    if tile == 5:
-        return "pw_gemm_f16x3_kernel (persistent ping-pong 2x128x224"
     wv, shape = TILE_SHAPES.get(tile, ("?", "?"))
     pair = len(key) > 3 and key[3]
     wino = len(key) > 4 and key[4]
@@ -73,8 +71,6 @@ def rocprof_name(key):
     SLAB, PAIR, ...> -- further template arguments (taps per kd, pointwise) follow; the prefix identifies the launches"""
     tile, slab, pre = key[:3]
     pair = bool(key[3]) if len(key) > 3 else False
-    if tile == 5:
-        return "pw_gemm_f16x3_kernel"
     wv = TILE_SHAPES.get(tile, ("?",))[0].replace(",", ", ")
     wino = bool(key[4]) if len(key) > 4 else False
     # (taps per kd follow: 3 = the Winograd-W position GEMMs; the 27-tap slab kernel and every gather kernel print 9)

@@ -15,7 +15,7 @@ PKG_DIR = Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
 LIB_NAME = "libcommonscenes_hip.so"
 LIB_PATH = PKG_DIR / LIB_NAME
-SOURCES = ["cs_plan.hip", "cs_gemm.hip", "cs_gemm_f16x3.hip", "cs_gemm_pw.hip", "cs_gemm_kw.hip", "cs_mesh.hip", "cs_metrics.hip", "cs_norm.hip", "cs_attention.hip", "cs_attention_f16x3.hip", "cs_ops.hip", "cs_unet.hip", "cs_vqvae.hip"]
+SOURCES = ["cs_plan.hip", "cs_gemm.hip", "cs_gemm_f16x3.hip", "cs_gemm_kw.hip", "cs_mesh.hip", "cs_metrics.hip", "cs_norm.hip", "cs_attention.hip", "cs_attention_f16x3.hip", "cs_ops.hip", "cs_unet.hip", "cs_vqvae.hip"]
 HEADERS = [CSRC / "cs_common.h", CSRC / "cs_f16x3.h", CSRC / "cs_mc_tables.h", CSRC / "cs_driver.h", PKG_DIR.parent / "include" / "commonscenes_hip.h"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f"--offload-arch={ARCH}", "-Wall",

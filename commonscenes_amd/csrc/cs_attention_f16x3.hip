@@ -372,7 +372,9 @@ struct AttnImg {
 template <int DB, int KT>
 __global__ __launch_bounds__(256) void attn_presplit_kernel(const float* __restrict__ k, const float* __restrict__ v,
                                                             _Float16* __restrict__ img, int nk, int heads, int dh,
-                                                            int ldk, int ldv, int ntiles, int32_t* __restrict__ status) {
+                                                            int ldk, int ldv, int ntiles, int32_t* __restrict__ status,
+                                                            float ks, float vs) {
+  // ks / vs (r6): the operand pre-scales of K and V (QK_SCALE = 16 by default; static bounds: cs_attn_selfattn_f16x3_ws_scaled)
   using I = AttnImg<DB, KT>;
   constexpr int LDK = I::LDK, LDV = I::LDV, DP = I::DP;
   extern __shared__ __attribute__((aligned(16))) _Float16 sm[];
@@ -400,10 +402,10 @@ __global__ __launch_bounds__(256) void attn_presplit_kernel(const float* __restr
     if (kt0 + j < nk) kv = *reinterpret_cast<const float4*>(kb + (int64_t)(kt0 + j) * ldk + c4 * 4);
     h4 hi, lo;
     _Float16 a, c;
-    split1m(kv.x * QK_SCALE, a, c, amax); hi[0] = a; lo[0] = c;
-    split1m(kv.y * QK_SCALE, a, c, amax); hi[1] = a; lo[1] = c;
-    split1m(kv.z * QK_SCALE, a, c, amax); hi[2] = a; lo[2] = c;
-    split1m(kv.w * QK_SCALE, a, c, amax); hi[3] = a; lo[3] = c;
+    split1m(kv.x * ks, a, c, amax); hi[0] = a; lo[0] = c;
+    split1m(kv.y * ks, a, c, amax); hi[1] = a; lo[1] = c;
+    split1m(kv.z * ks, a, c, amax); hi[2] = a; lo[2] = c;
+    split1m(kv.w * ks, a, c, amax); hi[3] = a; lo[3] = c;
     *reinterpret_cast<h4*>(Kh + j * LDK + c4 * 4) = hi;
     *reinterpret_cast<h4*>(Kl + j * LDK + c4 * 4) = lo;
   }
@@ -417,7 +419,7 @@ __global__ __launch_bounds__(256) void attn_presplit_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       _Float16 a, c;
-      split1m(x[i] * QK_SCALE, a, c, amax);
+      split1m(x[i] * vs, a, c, amax);
       Vh[(c4 * 4 + i) * LDV + pj] = a;
       Vl[(c4 * 4 + i) * LDV + pj] = c;
     }
@@ -433,7 +435,8 @@ __global__ __launch_bounds__(64 * NW) void attn_f16x3_img_kernel(const float* __
                                                                  const _Float16* __restrict__ img,
                                                                  float* __restrict__ out, int nq, int nk, int heads,
                                                                  int dh, int ldq, int ldo, float scale, int qtiles,
-                                                                 int ntiles, int nbh, int32_t* __restrict__ status) {
+                                                                 int ntiles, int nbh, int32_t* __restrict__ status,
+                                                                 float qs, float ks, float vs) {
   using I = AttnImg<DB, KT>;
   constexpr int DP = I::DP, LDK = I::LDK, LDV = I::LDV;
   constexpr int JB = KT / 32;
@@ -507,7 +510,7 @@ __global__ __launch_bounds__(64 * NW) void attn_f16x3_img_kernel(const float* __
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int d = 16 * t + 8 * half + e;
-      const float x = d < dh ? qp[d] * (scale * QK_SCALE) : 0.f;
+      const float x = d < dh ? qp[d] * (scale * qs) : 0.f;
       _Float16 a, c;
       split1m(x, a, c, amax);
       qh[t][e] = a;
@@ -521,7 +524,7 @@ __global__ __launch_bounds__(64 * NW) void attn_f16x3_img_kernel(const float* __
     for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
   float mrun = -INFINITY;
   float lrun = 0.f;
-  const float cexp = 1.44269504088896340736f / (QK_SCALE * QK_SCALE);
+  const float cexp = 1.44269504088896340736f / (qs * ks);
   const float lp = 10.0f;             // log2(P_SCALE)
 
   // S^T = K Q^T of tile t (its K image sits in K slot t & 1)
@@ -704,7 +707,7 @@ __global__ __launch_bounds__(64 * NW) void attn_f16x3_img_kernel(const float* __
 
   if (status && amax >= 65504.f) atomicOr(status, CS_STATUS_F16X3_OVERFLOW);
   const float ltot = lrun + __shfl_xor(lrun, 32, 64);
-  const float inv = 1.0f / (ltot * QK_SCALE);       // ltot already carries P_SCALE
+  const float inv = 1.0f / (ltot * vs);       // ltot already carries P_SCALE
   if (q0 + l31 < nq) {
     float* op = out + ((int64_t)b * nq + q0 + l31) * ldo + h * dh;
 #pragma unroll
@@ -726,7 +729,8 @@ __global__ __launch_bounds__(64 * NW) void attn_f16x3_img_kernel(const float* __
 
 template <int DB, int KT, int NW>
 int launch_attn16_img(const float* q, const float* k, const float* v, float* out, int nb, int nq, int nk, int heads,
-                      int dh, int ldq, int ldk, int ldv, int ldo, float scale, int32_t* status, void* ws, hipStream_t s) {
+                      int dh, int ldq, int ldk, int ldv, int ldo, float scale, int32_t* status, void* ws, hipStream_t s,
+                      float qs = QK_SCALE, float ks = QK_SCALE, float vs = QK_SCALE) {
   using I = AttnImg<DB, KT>;
   const int ntiles = (nk + KT - 1) / KT;
   if ((int64_t)ntiles * I::TILE_BYTES >= 0x7FF00000LL) return CS_EINVAL;
@@ -750,10 +754,10 @@ int launch_attn16_img(const float* q, const float* k, const float* v, float* out
     if (e != hipSuccess) return (int)e;
   }
   CS_LAUNCH(pk, dim3((unsigned)pgrid), dim3(256), (size_t)I::TILE_BYTES, s, k, v, (_Float16*)ws, nk, heads, dh, ldk, ldv,
-            ntiles, status);
+            ntiles, status, ks, vs);
   CS_CHECK_LAUNCH();
   CS_LAUNCH(kern, dim3((unsigned)grid), dim3(64 * NW), (size_t)2 * I::TILE_BYTES, s, q, (const _Float16*)ws, out, nq, nk,
-            heads, dh, ldq, ldo, scale, qtiles, ntiles, nb * heads, status);
+            heads, dh, ldq, ldo, scale, qtiles, ntiles, nb * heads, status, qs, ks, vs);
   CS_CHECK_LAUNCH();
   return CS_OK;
 }
@@ -868,17 +872,37 @@ extern "C" int64_t cs_attn_f16x3_ws_bytes(int nb, int nq, int nk, int heads, int
   return 0;
 }
 
-extern "C" int cs_attn_selfattn_f16x3_ws(const float* q, const float* k, const float* v, float* out, int nb, int nq,
-                                         int nk, int heads, int dh, int ldq, int ldk, int ldv, int ldo, float scale,
-                                         int32_t* status, void* ws, cs_stream_t stream) {
+static int attn_ws_impl(const float* q, const float* k, const float* v, float* out, int nb, int nq,
+                       int nk, int heads, int dh, int ldq, int ldk, int ldv, int ldo, float scale,
+                       int32_t* status, void* ws, cs_stream_t stream, float qs, float ks, float vs) {
   const int var = ws ? img_variant(nq, nk, dh) : 0;
   if (var == 0)
-    return attn16_dispatch<false>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, stream);
+    return attn16_dispatch<false>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, stream, qs, ks, vs);
   if (!q || !k || !v || !out || nb <= 0 || nq <= 0 || nk <= 0 || heads <= 0 || dh <= 0) return CS_EINVAL;
   if ((dh & 3) || (ldq & 3) || (ldk & 3) || (ldv & 3) || (ldo & 3)) return CS_EINVAL;
   if (ldq < heads * dh || ldk < heads * dh || ldv < heads * dh || ldo < heads * dh) return CS_EINVAL;
   if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || ((uintptr_t)out & 15) || ((uintptr_t)ws & 15))
     return CS_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  return launch_attn16_img<8, 32, 4>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, ws, s);
+  return launch_attn16_img<8, 32, 4>(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, ws, s, qs, ks, vs);
+}
+
+extern "C" int cs_attn_selfattn_f16x3_ws(const float* q, const float* k, const float* v, float* out, int nb, int nq,
+                                         int nk, int heads, int dh, int ldq, int ldk, int ldv, int ldo, float scale,
+                                         int32_t* status, void* ws, cs_stream_t stream) {
+  return attn_ws_impl(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, ws, stream, QK_SCALE, QK_SCALE,
+                      QK_SCALE);
+}
+
+// r6 (ABI 18): the workspace form with the caller's operand pre-scales (see cs_attn_selfattn_f16x3_scaled) -- what an
+// attention block fed by a GroupNorm takes (vqvae_modules.py:154-178 AttnBlock, openai_model_3d.py:360-366 AttentionBlock):
+// its q / k / v are Conv1x1(GroupNorm(x)), bounded by the weights and the norm's affine parameters alone
+// (cs_attnblock_static_scales), so no activation can leave the fp16 range there either.
+extern "C" int cs_attn_selfattn_f16x3_ws_scaled(const float* q, const float* k, const float* v, float* out, int nb, int nq,
+                                                int nk, int heads, int dh, int ldq, int ldk, int ldv, int ldo, float scale,
+                                                float q_scale, float k_scale, float v_scale, int32_t* status, void* ws,
+                                                cs_stream_t stream) {
+  if (!(q_scale > 0.f) || !(k_scale > 0.f) || !(v_scale > 0.f)) return CS_EINVAL;
+  return attn_ws_impl(q, k, v, out, nb, nq, nk, heads, dh, ldq, ldk, ldv, ldo, scale, status, ws, stream, q_scale, k_scale,
+                      v_scale);
 }

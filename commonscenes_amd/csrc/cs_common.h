@@ -61,7 +61,11 @@ __device__ __forceinline__ float cs_erff(float a) {
 }
 // exact GELU (attention.py:44-46 F.gelu, vqvae_modules.py: nn.GELU): 0.5 x (1 + erf(x / sqrt 2))
 __device__ __forceinline__ float cs_gelu(float x) {
+#ifdef CS_OCML_ERF       // what-if build (tools/build_alt.sh): the device library's erff, as until r5 (same-box A/B of cs_erff)
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+#else
   return 0.5f * x * (1.0f + cs_erff(x * 0.70710678118654752440f));
+#endif
 }
 __device__ __forceinline__ float cs_act(float v, int act) {
   switch (act) {

@@ -1113,6 +1113,14 @@ struct ExecBase {
     return cs_conv_wants_split16(m, g.cin, g.cout, g.k, !g.up_mask && !g.tap_cout && g.cin_pad == g.cin, pl.math) != 0;
   }
 
+  // r6: the F16X3 operand scales of an attention block fed by a GroupNorm (cs_attnblock_static_scales: the one rule; vqvae.py /
+  // unet.py call it with the same statistics) -- false: feature off / not F16X3 / no statistics, the constant 16 then
+  bool attnblock_scales(int norm, int64_t n_per_group, int c, float w_l2max, float b_absmax, float qk_scale, float out4[4]) const {
+    if (pl.math != CS_MATH_F16X3 || cs_debug()->no_static_scales || !(w_l2max > 0.f)) return false;
+    const Norm& nm = pl.norms[norm];
+    return cs_attnblock_static_scales(nm.gmax, nm.bmax, n_per_group, c, w_l2max, b_absmax, qk_scale, out4) == CS_OK;
+  }
+
   // self-attention over a fused [rows][3c] q | k | v buffer -> a [rows][c]; F16X3: K / V tile images in a scratch buffer
   // where the library has that path (cs_attn_f16x3_ws_bytes > 0)
   // qkv_scales (r5): the static-bound operand scales of q * scale, k, v (cs_transformer_static_scales), or nullptr = 16
@@ -1120,11 +1128,17 @@ struct ExecBase {
                       const float* qkv_scales = nullptr) {
     Buf ws;
     if (qkv_scales && pl.math == CS_MATH_F16X3) {
+      // (r6: the image path too -- cs_attn_selfattn_f16x3_ws_scaled; ops.py::attention does the same)
+      const int64_t wsb2 = cs_attn_f16x3_ws_bytes(nb, n, n, heads, dh);
+      if (wsb2 > 0) ws = alloc(wsb2 / 4, 1);
       if (ok() && !dry) {
         const float* q = p(qkv);
-        chk(cs_attn_selfattn_f16x3_scaled(q, q + c, q + 2 * c, p(a), nb, n, n, heads, dh, 3 * c, 3 * c, 3 * c, c, scale,
-                                          qkv_scales[0], qkv_scales[1], qkv_scales[2], status, st));
+        chk(wsb2 > 0 ? cs_attn_selfattn_f16x3_ws_scaled(q, q + c, q + 2 * c, p(a), nb, n, n, heads, dh, 3 * c, 3 * c, 3 * c, c,
+                                                        scale, qkv_scales[0], qkv_scales[1], qkv_scales[2], status, (void*)p(ws), st)
+                     : cs_attn_selfattn_f16x3_scaled(q, q + c, q + 2 * c, p(a), nb, n, n, heads, dh, 3 * c, 3 * c, 3 * c, c, scale,
+                                                     qkv_scales[0], qkv_scales[1], qkv_scales[2], status, st));
       }
+      if (wsb2 > 0) release(ws);
       return;
     }
     const int64_t wsb = pl.math == CS_MATH_F16X3 ? cs_attn_f16x3_ws_bytes(nb, n, n, heads, dh) : 0;

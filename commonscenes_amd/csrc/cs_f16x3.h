@@ -1,4 +1,4 @@
-// Shared pieces of the CS_MATH_F16X3 GEMM kernels (cs_gemm_f16x3.hip, cs_gemm_pw.hip).
+// Shared pieces of the CS_MATH_F16X3 GEMM kernels (cs_gemm_f16x3.hip, cs_gemm_kw.hip).
 #pragma once
 #include "cs_common.h"
 

@@ -255,9 +255,9 @@ int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p, int M, int tile, int splits
                                 const float* cls_acc = nullptr, int ncls = 0,
                                 const CsFuseK* fuse = nullptr, int tm_base = 0, int tm_count = 0);   // cs_gemm_f16x3.hip
 bool cs_f16x3_slab4_ok(const CsConvGemm& p, int tile, int splits);                      // cs_gemm_f16x3.hip
-bool cs_pw_gemm_f16x3_applicable(const CsConvGemm& p, int64_t M);                                   // cs_gemm_pw.hip
-bool cs_pw_gemm_f16x3_preferred(const CsConvGemm& p, int64_t M);
-int cs_pw_gemm_f16x3_launch(const CsConvGemm& p, int M, hipStream_t s);
+// (tile code 5 -- r2's persistent ping-pong pointwise GEMM, cs_gemm_pw.hip -- was removed in r6: measured a loser in r2 at
+// every shape (NOTES section 4.3: 128-row tiles double the weight DMA per flop, one wave per SIMD keeps the matrix pipe ~55 %
+// busy), never selected since, and VERDICT r5 asked for it to earn its place or go; the code refuses the tile code)
 bool cs_kw_gemm_applicable(const CsConvGemm& p, int64_t M);                                          // cs_gemm_kw.hip
 int cs_kw_gemm_f16x3_launch(const CsConvGemm& p, int M, hipStream_t s);
 static int device_cus();
@@ -620,7 +620,7 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const CsConvGemm p, const
   }
 }
 
-// rows x columns of a tile code's output tile (0: no fixed tile -- the ping-pong kernel, the 512-row codes that may fall back)
+// rows x columns of a tile code's output tile (0: no fixed tile -- the 512-row codes that may fall back)
 void tile_dims(int tile, int& bm, int& bn) {
   switch (tile) {
     case 1: bm = 128; bn = 128; break;
@@ -695,7 +695,7 @@ extern "C" int cs_conv_gemm_epilogue_caps(const CsConvGemm* d, int32_t* gn_rows,
     return CS_OK;
   }
   int tile = p.tile ? p.tile : auto_tile(p, M, true);
-  if (tile == 5 || (p.tile == 0 && cs_pw_gemm_f16x3_applicable(p, M) && cs_pw_gemm_f16x3_preferred(p, M))) return CS_OK;
+  if (tile == 5) return CS_OK;                             // (removed tile code: no extras)
   tile_dims(tile, bm, bn);
   if (!bm) return CS_OK;
   if (tile == 10) {                        // the K-wave kernel's single epilogue emits both, whatever the epilogue terms
@@ -735,7 +735,7 @@ static int64_t kwave_max_tiles() {
   return v >= 0 ? v : 4LL * device_cus();
 }
 
-// tile of an automatic (desc->tile == 0) launch that is not the ping-pong kernel's
+// tile of an automatic (desc->tile == 0) launch
 static int auto_tile(const CsConvGemm& p, int M, bool f16x3) {
   int tile = 0;
   {
@@ -1114,9 +1114,7 @@ static int conv_gemm_impl(const CsConvGemm* d, cs_stream_t stream, int omap_f, i
   if (M64 > 0x7fffffffLL) return CS_EINVAL;
   const int M = (int)M64;
   int tile = p.tile;
-  if (tile == 5 && !(f16x3 && cs_pw_gemm_f16x3_applicable(p, M))) return CS_EINVAL;
-  if (tile == 0 && f16x3 && cs_pw_gemm_f16x3_applicable(p, M) && cs_pw_gemm_f16x3_preferred(p, M))
-    tile = 5;                                        // short-K token GEMMs: persistent ping-pong kernel
+  if (tile == 5) return CS_EINVAL;                         // (the ping-pong kernel's code: removed in r6)
   if (tile == 0) tile = auto_tile(p, M, f16x3);
   hipStream_t s = (hipStream_t)stream;
   if (p.splitk > 1 && omap_f) return CS_EINVAL;
@@ -1183,9 +1181,8 @@ static int conv_gemm_impl(const CsConvGemm* d, cs_stream_t stream, int omap_f, i
     CS_CHECK_LAUNCH();
     return CS_OK;
   }
-  if (omap_f && (!f16x3 || tile == 5)) return CS_EINVAL;
-  if ((p.gn_part || p.out_format) && (!f16x3 || tile == 5)) return CS_EINVAL;
-  if (tile == 5) return cs_pw_gemm_f16x3_launch(p, M, s);
+  if (omap_f && !f16x3) return CS_EINVAL;
+  if ((p.gn_part || p.out_format) && !f16x3) return CS_EINVAL;
   if (tile == 10) return (f16x3 && !omap_f) ? cs_kw_gemm_f16x3_launch(p, M, s) : CS_EINVAL;
   if (f16x3) return cs_conv_gemm_f16x3_dispatch(p, M, tile, 1, s, omap_f, omap_p, cls_w, cls_w_lo, cls_acc, ncls);
   switch (tile) {
@@ -1229,11 +1226,11 @@ extern "C" int cs_conv_gemm_launch_info(const CsConvGemm* d, int32_t* tile_out, 
   if (p.splitk > 1) {
     tile = sliced_tile(p, M);
   } else {
-    if (tile == 0 && f16x3 && cs_pw_gemm_f16x3_applicable(p, M) && cs_pw_gemm_f16x3_preferred(p, M)) tile = 5;
+    if (tile == 5) return CS_EINVAL;
     if (tile == 0) tile = auto_tile(p, M, f16x3);
   }
   if (tile_out) *tile_out = tile;
-  if (slab_out) *slab_out = (f16x3 && tile != 5) ? cs_f16x3_slab_width(p, tile, p.splitk > 1 ? p.splitk : 1) : 0;
+  if (slab_out) *slab_out = f16x3 ? cs_f16x3_slab_width(p, tile, p.splitk > 1 ? p.splitk : 1) : 0;
   return CS_OK;
 }
 

@@ -107,6 +107,22 @@ extern "C" float cs_bound_a_scale(float bound) {
   return (float)std::ldexp(1.0, k);
 }
 
+// r6: the same for an attention block fed by a GroupNorm -- see the header.  ONE rule for both hosts
+// (vqvae.py::_attn / cs_vqvae.hip, unet.py::_attnblock / cs_unet.hip::attnblock).
+extern "C" int cs_attnblock_static_scales(float gmax, float bmax, int64_t n, int c, float w_l2max, float b_absmax, float qk_scale,
+                                          float* out4) {
+  if (!out4 || n < 1 || c < 1 || !(qk_scale > 0.f) || !(gmax >= 0.f) || !(bmax >= 0.f) || !(w_l2max >= 0.f) || !(b_absmax >= 0.f))
+    return CS_EINVAL;
+  const double e = (double)gmax * std::sqrt((double)(n > 1 ? n - 1 : 1)) + (double)bmax;
+  const double b = (double)w_l2max * std::sqrt((double)c) * e + (double)b_absmax;
+  auto S = [](double v) { return cs_bound_a_scale(v < 3.0e38 ? (float)(v * (1.0 + 1e-6)) : 3.0e38f); };
+  out4[0] = S(b * (double)qk_scale);
+  out4[1] = S(b);
+  out4[2] = S(b);
+  out4[3] = S(b);
+  return CS_OK;
+}
+
 // r5: F16X3 operand scales of the operands BORN INSIDE a transformer block (attention.py:237-245,
 // 335-351) from bounds that hold for every input -- so they can never leave the fp16 range and CS_STATUS_F16X3_OVERFLOW is a
 // pure assertion there.  ONE rule for both hosts (unet.py::_static_scales, cs_unet.hip::attn_block).

@@ -38,6 +38,10 @@ struct Layer {
   bool has_ts = false;
   float ctx_max = 0.f;
   int ts_slot = -1;    // first of this block's 34 float slots behind the plan's |w| maxima
+  // ATTNBLOCK, F16X3 (r6): max row 2-norm of the fused qkv weight and max |bias| (cs_attnblock_static_scales), filled by
+  // cs_unet_pack; ab_slot = the block's 4 float slots, ab_w / ab_b = the raw parameters
+  int ab_slot = -1, ab_w = -1, ab_b = -1;
+  float ab_l2max = 0.f, ab_bmax = 0.f;
 };
 
 }  // namespace
@@ -144,6 +148,8 @@ Layer make_attnblock(cs_unet& u, const std::string& p, int c, int heads) {
       b.push_back({bq, h * 3 * ch + j * ch, ch});
     }
   l.g[0] = add_gemm(u, w, b, 3 * c, c, 0);
+  l.ab_w = wq;
+  l.ab_b = bq;
   const int wo = add_param(u, p + ".proj_out.weight", {c, c, 1});
   const int bo = add_param(u, p + ".proj_out.bias", {c});
   l.g[1] = add_gemm(u, {{wo, 0, c}}, {{bo, 0, c}}, c, c, 0);
@@ -285,16 +291,18 @@ int build(cs_unet& u) {
   u.emb_total = emb.total;
 
   {
-    // r5: 34 float slots per transformer block for the static-bound statistics (cs_unet_pack)
-    int nblk = 0;
+    // r5: 34 float slots per transformer block for the static-bound statistics (cs_unet_pack); r6: 4 per AttentionBlock
+    int nblk = 0, nab = 0;
     auto count = [&](std::vector<Layer>& layers) {
-      for (Layer& l : layers)
+      for (Layer& l : layers) {
         if (l.kind == ATTN) ++nblk;
+        if (l.kind == ATTNBLOCK) ++nab;
+      }
     };
     for (auto& layers : u.inp) count(layers);
     count(u.mid);
     for (auto& layers : u.out) count(layers);
-    u.extra_slots = (c.math == CS_MATH_F16X3) ? 34 * nblk : 0;
+    u.extra_slots = (c.math == CS_MATH_F16X3) ? 34 * nblk + 4 * nab : 0;
   }
   layout_arena(u);
   if (u.extra_slots) {
@@ -306,6 +314,17 @@ int build(cs_unet& u) {
     for (auto& layers : u.inp) assign(layers);
     assign(u.mid);
     for (auto& layers : u.out) assign(layers);
+    int k2 = 34 * k;                      // (the AttentionBlocks' slots follow the transformer blocks')
+    auto assign2 = [&](std::vector<Layer>& layers) {
+      for (Layer& l : layers)
+        if (l.kind == ATTNBLOCK) {
+          l.ab_slot = u.extra_slot0 + k2;
+          k2 += 4;
+        }
+    };
+    for (auto& layers : u.inp) assign2(layers);
+    assign2(u.mid);
+    for (auto& layers : u.out) assign2(layers);
   }
   return CS_OK;
 }
@@ -472,7 +491,12 @@ struct Exec : ExecBase {
     Buf qkv = linear(xn, l.g[0]);
     release(xn);
     Buf a = alloc(rows, c);
-    self_attention(qkv, a, x.nb, n, heads, dh, c, (float)std::pow((double)dh, -0.5));
+    // r6: static operand scales of q / k / v and of the attention output (unet.py::_attnblock: the same rule and statistics)
+    float ss[4];
+    const float qks = (float)std::pow((double)dh, -0.5);
+    const bool stat = attnblock_scales(l.n[0], (int64_t)n * (c / 32), c, l.ab_l2max, l.ab_bmax, qks, ss);
+    self_attention(qkv, a, x.nb, n, heads, dh, c, qks, stat ? ss : nullptr);
+    if (stat) a.a_scale = ss[3];
     release(qkv);
     Act o = x;
     o.b = gemm(a, l.g[1], x.nb, n, 1, 1, 1, 0, CS_ACT_NONE, nullptr, 0, 1, dry ? nullptr : p(x.b), c, 0, 1, 0,
@@ -695,7 +719,42 @@ extern "C" int64_t cs_unet_context_floats(const cs_unet* u) { return u ? u->ctx_
 
 extern "C" int cs_unet_pack(cs_unet* u, const void* raw_dev, void* arena_dev, cs_stream_t stream) {
   const int rc = pack_plan(u, raw_dev, arena_dev, stream);
-  if (rc != CS_OK || !u || u->math != CS_MATH_F16X3 || !u->cfg.use_spatial_transformer) return rc;
+  if (rc != CS_OK || !u || u->math != CS_MATH_F16X3) return rc;
+  {
+    // r6: every AttentionBlock's static-bound statistics (unet.py::_pack: the same kernel on the same tensors, the same values):
+    // {max row 2-norm, max |.|} of the fused qkv weight into slots 0-1, of its bias into slots 2-3; one read-back
+    hipStream_t st0 = (hipStream_t)stream;
+    const char* raw0 = reinterpret_cast<const char*>(raw_dev);
+    float* d0 = reinterpret_cast<float*>(reinterpret_cast<char*>(arena_dev) + u->amax_off);
+    std::vector<Layer*> abs_;
+    auto collect_ab = [&](std::vector<Layer>& layers) {
+      for (Layer& l : layers)
+        if (l.kind == ATTNBLOCK && l.ab_slot >= 0) abs_.push_back(&l);
+    };
+    for (auto& layers : u->inp) collect_ab(layers);
+    collect_ab(u->mid);
+    for (auto& layers : u->out) collect_ab(layers);
+    for (Layer* lp : abs_) {
+      const int c3 = 3 * lp->cin;
+      int r2 = cs_weight_rowstats(reinterpret_cast<const float*>(raw0 + u->params[lp->ab_w].raw_off), c3, lp->cin, d0 + lp->ab_slot,
+                                  stream);
+      if (r2 == CS_OK)
+        r2 = cs_weight_rowstats(reinterpret_cast<const float*>(raw0 + u->params[lp->ab_b].raw_off), 1, c3, d0 + lp->ab_slot + 2,
+                                stream);
+      if (r2 != CS_OK) return r2;
+    }
+    if (!abs_.empty()) {
+      std::vector<float> host0(4 * abs_.size());
+      if (hipMemcpyAsync(host0.data(), d0 + abs_[0]->ab_slot, host0.size() * 4, hipMemcpyDeviceToHost, st0) != hipSuccess ||
+          hipStreamSynchronize(st0) != hipSuccess)
+        return CS_EINVAL;
+      for (size_t i = 0; i < abs_.size(); ++i) {
+        abs_[i]->ab_l2max = host0[4 * i];
+        abs_[i]->ab_bmax = host0[4 * i + 3];
+      }
+    }
+  }
+  if (!u->cfg.use_spatial_transformer) return rc;
   // r5: the static-bound statistics of every transformer block (unet.py::_pack: the same kernel, the same values) -- row
   // 2-norm maxima and |.| maxima of the block's Linears and LayerNorm parameters; 34 float slots per block behind the
   // plan's |w| maxima (zeroed by pack_plan), ONE more read-back at load time

@@ -33,6 +33,10 @@ struct cs_vqvae : Plan {
   std::vector<std::vector<ResP>> up;      // [level][block]
   std::vector<int> up_conv;               // [level] upsample conv GEMM or -1
   int block_in0 = 0, c_final = 0, grid = 0;
+  // r6: what bounds mid.attn_1's q / k / v (cs_attnblock_static_scales): max row 2-norm of the three 1x1x1 conv weights and
+  // max |bias|, filled by cs_vqvae_pack from the raw weights (F16X3 only; 0 = none: the constant scale 16)
+  int p_qkv_w[3] = {-1, -1, -1}, p_qkv_b[3] = {-1, -1, -1};
+  float attn_l2max = 0.f, attn_bmax = 0.f;
 };
 
 namespace {
@@ -70,6 +74,10 @@ int build(cs_vqvae& u) {
   for (int j = 0; j < 3; ++j) add_wb(u, D + "mid.attn_1." + qkv[j], block_in, block_in, 1, true, w[j], b[j]);
   u.g_qkv = add_gemm(u, {{w[0], 0, block_in}, {w[1], 0, block_in}, {w[2], 0, block_in}},
                      {{b[0], 0, block_in}, {b[1], 0, block_in}, {b[2], 0, block_in}}, 3 * block_in, block_in, 1);
+  for (int j = 0; j < 3; ++j) {
+    u.p_qkv_w[j] = w[j];
+    u.p_qkv_b[j] = b[j];
+  }
   u.g_proj = add_layer_gemm(u, D + "mid.attn_1.proj_out", block_in, block_in, 1);
   u.mid2 = make_res(u, D + "mid.block_2", block_in, block_in);
   u.up.assign(c.n_mult, {});
@@ -100,6 +108,7 @@ int build(cs_vqvae& u) {
     pb.push_back({-1, 0, zpad});
   }
   u.g_post = add_gemm(u, pw, pb, c.z_channels + zpad, c.embed_dim, 1);
+  u.extra_slots = c.math == CS_MATH_F16X3 ? 4 : 0;        // r6: the attention block's static-bound statistics (cs_vqvae_pack)
   layout_arena(u);
   return CS_OK;
 }
@@ -138,7 +147,12 @@ struct VExec : ExecBase {
     Buf qkv = linear(hn, u.g_qkv);
     release(hn);
     Buf a = alloc(rows, c);
-    self_attention(qkv, a, x.nb, n, 1, c, c, (float)std::pow((double)c, -0.5));
+    // r6: static operand scales of q / k / v and of the attention output (vqvae.py::_attn: the same rule, the same statistics)
+    float ss[4];
+    const float qks = (float)std::pow((double)c, -0.5);
+    const bool stat = attnblock_scales(u.n_attn, (int64_t)n * (c / vq_groups(c)), c, u.attn_l2max, u.attn_bmax, qks, ss);
+    self_attention(qkv, a, x.nb, n, 1, c, c, qks, stat ? ss : nullptr);
+    if (stat) a.a_scale = ss[3];
     release(qkv);
     Act o = x;
     o.b = linear(a, u.g_proj, CS_ACT_NONE, nullptr, 0, 1, dry ? nullptr : p(x.b), c);
@@ -225,7 +239,26 @@ extern "C" int cs_vqvae_param_info(const cs_vqvae* u, int i, const char** name, 
 extern "C" int64_t cs_vqvae_raw_bytes(const cs_vqvae* u) { return u ? u->raw_bytes : 0; }
 extern "C" int64_t cs_vqvae_arena_bytes(const cs_vqvae* u) { return u ? u->arena_bytes : 0; }
 extern "C" int cs_vqvae_pack(cs_vqvae* u, const void* raw_dev, void* arena_dev, cs_stream_t stream) {
-  return pack_plan(u, raw_dev, arena_dev, stream);
+  const int rc = pack_plan(u, raw_dev, arena_dev, stream);
+  if (rc != CS_OK || !u || u->math != CS_MATH_F16X3 || u->extra_slots < 4) return rc;
+  // r6: the attention block's static-bound statistics (vqvae.py::_pack: the same kernel on the same tensors, the same values):
+  // {max row 2-norm, max |.|} over the q, k, v weights into slots 0-1, over their biases into slots 2-3
+  hipStream_t st = (hipStream_t)stream;
+  const char* raw = reinterpret_cast<const char*>(raw_dev);
+  float* o = reinterpret_cast<float*>(reinterpret_cast<char*>(arena_dev) + u->amax_off) + u->extra_slot0;
+  const int c = u->block_in0;
+  for (int j = 0; j < 3; ++j) {
+    int r2 = cs_weight_rowstats(reinterpret_cast<const float*>(raw + u->params[u->p_qkv_w[j]].raw_off), c, c, o, stream);
+    if (r2 == CS_OK)
+      r2 = cs_weight_rowstats(reinterpret_cast<const float*>(raw + u->params[u->p_qkv_b[j]].raw_off), 1, c, o + 2, stream);
+    if (r2 != CS_OK) return r2;
+  }
+  float host[4];
+  if (hipMemcpyAsync(host, o, sizeof(host), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+    return CS_EINVAL;
+  u->attn_l2max = host[0];
+  u->attn_bmax = host[3];
+  return CS_OK;
 }
 
 // Objects decode independently; a 64^3 x 128-channel activation is 134 MB per object (4.3 GB at 32), so a large

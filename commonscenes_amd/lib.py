@@ -155,6 +155,8 @@ SIGNATURES = {
     "cs_attn_selfattn_f16x3_scaled": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _fl, _fl, _fl, _f, _s]),
     "cs_attn_f16x3_ws_bytes": (_l, [_i, _i, _i, _i, _i]),
     "cs_attn_selfattn_f16x3_ws": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _f, _f, _s]),
+    "cs_attn_selfattn_f16x3_ws_scaled": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _fl, _fl, _fl, _f, _f, _s]),
+    "cs_attnblock_static_scales": (_i, [_fl, _fl, _l, _i, _fl, _fl, _fl, _f]),
     "cs_attn_selfattn_f16": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _f, _s]),
     "cs_geglu": (_i, [_f, _f, _i, _i, _i, _i, _s]),
     "cs_copy_rows": (_i, [_f, _f, _l, _i, _i, _i, _s]),

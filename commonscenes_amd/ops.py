@@ -1166,10 +1166,20 @@ def attention(q: Tensor, k: Tensor, v: Tensor, heads: int, scale: float, out: Op
     _, _, ldo = rows_ld(out, "out")
     lib = L.load()
     if math == L.MATH_F16X3 and scales is not None:
-        L.check(lib.cs_attn_selfattn_f16x3_scaled(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), nb, nq, nk, heads,
-                                                  dh, ldq, ldk, ldv, ldo, scale, float(scales[0]), float(scales[1]),
-                                                  float(scales[2]), status_word(q.device).data_ptr(), _stream()),
-                "cs_attn_selfattn_f16x3_scaled")
+        # (r6: the K / V tile-image path too, where the library has it for this shape: cs_attn_selfattn_f16x3_ws_scaled)
+        wsb = lib.cs_attn_f16x3_ws_bytes(nb, nq, nk, heads, dh)
+        if wsb > 0:
+            ws = torch.empty((wsb // 4,), dtype=torch.float32, device=q.device)
+            L.check(lib.cs_attn_selfattn_f16x3_ws_scaled(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), nb, nq, nk,
+                                                         heads, dh, ldq, ldk, ldv, ldo, scale, float(scales[0]),
+                                                         float(scales[1]), float(scales[2]),
+                                                         status_word(q.device).data_ptr(), ws.data_ptr(), _stream()),
+                    "cs_attn_selfattn_f16x3_ws_scaled")
+        else:
+            L.check(lib.cs_attn_selfattn_f16x3_scaled(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), nb, nq, nk,
+                                                      heads, dh, ldq, ldk, ldv, ldo, scale, float(scales[0]), float(scales[1]),
+                                                      float(scales[2]), status_word(q.device).data_ptr(), _stream()),
+                    "cs_attn_selfattn_f16x3_scaled")
     elif math == L.MATH_F16X3:
         # K / V split once per call into their LDS tile images where the library has that path (ws_bytes > 0)
         wsb = lib.cs_attn_f16x3_ws_bytes(nb, nq, nk, heads, dh)
@@ -1185,6 +1195,35 @@ def attention(q: Tensor, k: Tensor, v: Tensor, heads: int, scale: float, out: Op
         L.check(lib.cs_attn_selfattn(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), nb, nq, nk, heads, dh,
                                      ldq, ldk, ldv, ldo, scale, _stream()), "cs_attn_selfattn")
     return out
+
+
+def weight_rowstats(mats: Sequence[Tensor]) -> Tuple[float, float]:
+    """(max row 2-norm rounded up, max |entry|) over the rows of every [rows, cols] matrix in `mats` -- cs_weight_rowstats into
+    ONE zeroed slot pair (the kernel folds by atomicMax), one read-back: load time only.  The native drivers run the same
+    kernel on the same tensors, so both hosts derive the same scales."""
+    if not mats:
+        return 0.0, 0.0
+    lib = L.load()
+    slot = torch.zeros((2,), dtype=torch.float32, device=mats[0].device)
+    for m in mats:
+        m = m.contiguous()
+        L.check(lib.cs_weight_rowstats(m.data_ptr(), int(m.shape[0]), int(m.shape[1]), slot.data_ptr(), _stream()),
+                "cs_weight_rowstats")
+    v = slot.cpu().tolist()
+    return float(v[0]), float(v[1])
+
+
+def attnblock_static_scales(gmax: float, bmax: float, n: int, c: int, w_l2max: float, b_absmax: float,
+                            qk_scale: float) -> Optional[Tuple[float, float, float, float]]:
+    """F16X3 operand scales (q * qk_scale, k, v, attention output) of an attention block whose q / k / v are
+    Conv1x1(GroupNorm(x)) + bias, from bounds that hold for every input (cs_attnblock_static_scales: ONE rule, both hosts;
+    r6).  None when the feature is off (CS_NO_STATIC_SCALES) or there are no statistics."""
+    if not _sw("STATIC_SCALES") or not w_l2max > 0.0:
+        return None
+    o = (C.c_float * 4)()
+    L.check(L.load().cs_attnblock_static_scales(float(gmax), float(bmax), int(n), int(c), float(w_l2max), float(b_absmax),
+                                                float(qk_scale), o), "cs_attnblock_static_scales")
+    return float(o[0]), float(o[1]), float(o[2]), float(o[3])
 
 
 def geglu(x: Tensor, out: Optional[Tensor] = None) -> Tensor:

@@ -471,6 +471,19 @@ class DiffusionUNet:
                 for (t, fld, _, which), v_ in zip(jobs, host):
                     st = self._tstat.setdefault(t, L.CsTransformerStats())
                     setattr(st, fld, float(v_[which]))
+        # r6: the AttentionBlocks' (concat family) static-bound statistics: max row 2-norm of the fused qkv weight, max |bias|
+        self._abstat: Dict[str, Tuple[float, float]] = {}
+        if self.math == L.MATH_F16X3 and not self.cfg["use_spatial_transformer"]:
+            for bp, layers in ([(f"{P}input_blocks.{i}", l) for i, l in enumerate(inp)] + [(P + "middle_block", mid)]
+                               + [(f"{P}output_blocks.{i}", l) for i, l in enumerate(out)]):
+                for l in layers:
+                    if l["kind"] != "attn":
+                        continue
+                    p = f"{bp}.{l['idx']}"
+                    wq, bq = sd[p + ".qkv.weight"], sd[p + ".qkv.bias"]
+                    l2, _ = ops.weight_rowstats([wq.reshape(wq.shape[0], -1)])
+                    _, bm = ops.weight_rowstats([bq.reshape(1, -1)])
+                    self._abstat[p] = (l2, bm)
         self._packed = pk
         self._blocks = (inp, mid, out)
         self._ctx_cache = None
@@ -646,12 +659,19 @@ class DiffusionUNet:
         n = d * h * w
         xn = ops.groupnorm(x, sd[p + ".norm.weight"], sd[p + ".norm.bias"], 32, 1e-5, L.ACT_NONE)
         qkv = ops.linear(xn.view(nb, n, c), pk[p + ".qkv"], math=self.math, a_scale=self._nas(p + ".norm", n * (c // 32)))
-        a = ops.attention(qkv[..., 0:c], qkv[..., c:2 * c], qkv[..., 2 * c:3 * c], heads, (c // heads) ** -0.5,
-                          math=self.attn_math if self.attn_math is not None else self.math)
+        # r6: q / k / v = Conv1d(GroupNorm(x)) + bias are bounded by the weights and the norm's affine parameters alone
+        # (ops.attnblock_static_scales; cs_unet.hip::attnblock applies the same rule to the same statistics)
+        amath = self.attn_math if self.attn_math is not None else self.math
+        ss = None
+        gb, st = self._ngb.get(p + ".norm"), self.__dict__.get("_abstat", {}).get(p)
+        if self.math == L.MATH_F16X3 and gb is not None and st is not None:
+            ss = ops.attnblock_static_scales(gb[0], gb[1], n * (c // 32), c, st[0], st[1], (c // heads) ** -0.5)
+        a = ops.attention(qkv[..., 0:c], qkv[..., c:2 * c], qkv[..., 2 * c:3 * c], heads, (c // heads) ** -0.5, math=amath,
+                          scales=ss[:3] if (ss is not None and amath == L.MATH_F16X3) else None)
         dst = out_fn((nb, d, h, w, c)).view(nb, n, c) if out_fn is not None else None
         # (spatial=: the rows are nb samples of n tokens -- what the epilogue's GroupNorm partial sums are tiled by)
         out = ops.linear(a, pk[p + ".proj_out"], res=x.view(nb, n, c), math=self.math, out=dst, stats=True,
-                         spatial=(nb, n, 1, 1))
+                         spatial=(nb, n, 1, 1), a_scale=ss[3] if ss is not None else None)
         return ops.attach_stats(out.view(nb, d, h, w, c), getattr(out, "cs_stats", None))
 
     def _attn(self, p: str, l: dict, x: Tensor, ctx, out_fn=None) -> Tensor:

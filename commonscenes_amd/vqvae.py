@@ -180,6 +180,13 @@ class VQVAE:
         wqkv = torch.cat([sd[a + "q.weight"], sd[a + "k.weight"], sd[a + "v.weight"]], dim=0)
         bqkv = torch.cat([sd[a + "q.bias"], sd[a + "k.bias"], sd[a + "v.bias"]], dim=0)
         pk[a + "qkv"] = ops.pack_weight(wqkv, bqkv, math=self.math)
+        # r6: what bounds the attention block's q / k / v (ops.attnblock_static_scales; cs_vqvae_pack takes the same statistics)
+        self._attn_stat = None
+        if self.math == L.MATH_F16X3:
+            c_ = int(sd[a + "q.weight"].shape[0])
+            l2, _ = ops.weight_rowstats([sd[a + f"{n}.weight"].reshape(c_, -1) for n in ("q", "k", "v")])
+            _, bm = ops.weight_rowstats([sd[a + f"{n}.bias"].reshape(1, -1) for n in ("q", "k", "v")])
+            self._attn_stat = (l2, bm)
         # |gamma|, |beta| maxima of the Normalize layers: norm-fed GEMMs take their F16X3 operand scale from the
         # producer's bound (ops.norm_a_scale), one read-back at load time
         norms = [k[:-7] for k in sd if k.startswith("decoder.") and k.endswith(".weight") and sd[k].dim() == 1]
@@ -224,8 +231,17 @@ class VQVAE:
         hn = ops.groupnorm(x, sd[p + ".norm.weight"], sd[p + ".norm.bias"], _vq_groups(c), 1e-6, L.ACT_NONE)
         qkv = ops.linear(hn.view(nb, n, c), pk[p + ".qkv"], math=self.math,
                          a_scale=self._nas(p + ".norm", n * (c // _vq_groups(c))))
-        a = ops.attention(qkv[..., 0:c], qkv[..., c:2 * c], qkv[..., 2 * c:], 1, int(c) ** (-0.5), math=self.math)
-        out = ops.linear(a, pk[p + ".proj_out"], res=x.view(nb, n, c), math=self.math)
+        # r6: q / k / v = Conv1x1(Normalize(x)) + bias are bounded by the weights and the norm's affine parameters alone: static
+        # operand scales (no input can leave the fp16 range; the attention output is a convex combination of v rows)
+        ss = None
+        gb = getattr(self, "_ngb", {}).get(p + ".norm")
+        st = getattr(self, "_attn_stat", None)
+        if self.math == L.MATH_F16X3 and gb is not None and st is not None:
+            ss = ops.attnblock_static_scales(gb[0], gb[1], n * (c // _vq_groups(c)), c, st[0], st[1], int(c) ** (-0.5))
+        a = ops.attention(qkv[..., 0:c], qkv[..., c:2 * c], qkv[..., 2 * c:], 1, int(c) ** (-0.5), math=self.math,
+                          scales=ss[:3] if ss is not None else None)
+        out = ops.linear(a, pk[p + ".proj_out"], res=x.view(nb, n, c), math=self.math,
+                         a_scale=ss[3] if ss is not None else None)
         return out.view(nb, d, h, w, c)
 
     @torch.no_grad()

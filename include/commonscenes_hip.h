@@ -126,6 +126,14 @@ float cs_norm_a_scale(float gmax, float bmax, int64_t n);
  *                          scale of a tensor whose magnitude is bounded by `bound` (static bounds of the operands born
  *                          inside a transformer block). */
 float cs_bound_a_scale(float bound);
+/*   cs_attnblock_static_scales  (ABI 18, r6) the F16X3 operand scales of an attention block whose q / k / v are
+ *                          Conv1x1(GroupNorm(x)) + bias (vqvae_modules.py:154-178; openai_model_3d.py:360-366), from bounds
+ *                          that hold for every input:  |GN(x)| <= E = gmax sqrt(n - 1) + bmax (n elements per group),
+ *                          |q|, |k|, |v| <= B = w_l2max sqrt(c) E + b_absmax (w_l2max / b_absmax over ALL 3c rows of the fused
+ *                          q | k | v weight / bias: cs_weight_rowstats), |attention output| <= B (softmax rows are convex
+ *                          weights).  out4 = {scale of q * qk_scale, of k, of v, of the attention output -> proj_out}. */
+int cs_attnblock_static_scales(float gmax, float bmax, int64_t n, int c, float w_l2max, float b_absmax, float qk_scale,
+                               float* out4);
 /*   cs_weight_rowstats     (r5; device work) out2 = {max over rows of ||row||_2 (rounded up), max |entry|} of a [rows][cols]
  *                          fp32 matrix, folded into out2 by atomicMax of the bits: zero it first.
  *   cs_transformer_static_scales  (r5) the F16X3 scales of the operands born inside a transformer block -- q / k / v of the
@@ -188,8 +196,8 @@ typedef struct CsConvGemm {
                          6 = 256x128, 7 = 256x64 (F16X3: channel counts that are not multiples of 224; FP32 runs them as 1 / 3),
                          8 = 512x64, 9 = 512x128 (F16X3, 3x3x3 stride-1 convs on pre-split operands: two row blocks per wave
                          over one A slab; any other call runs them as 7 / 6),
-                         5 = persistent ping-pong kernel (F16X3 pointwise GEMMs, cout % 224 == 0, cin >= 448, >= 384
-                         128x224 tiles; csrc/cs_gemm_pw.hip).  Every tile code gives the same bits. */
+                         5 = (removed in r6) r2's persistent ping-pong kernel: a measured loser, never auto-selected; refused with
+                         CS_EINVAL.  Every tile code gives the same bits. */
   /* CS_MATH_F16X3 only: w = hi halves, w_lo = lo halves, both laid out [tap][cin16/8][cout][8] by
    * cs_pack_weight_f16x3 (cin16 = cin rounded up to 16).  Activations are multiplied by a_scale (a power of
    * two; 0 means the default 16) before the fp16 split: |a| * a_scale must stay below 65504, and values
@@ -282,7 +290,7 @@ int cs_conv_gemm(const CsConvGemm* desc, cs_stream_t stream);
 int cs_conv_gemm_epilogue_caps(const CsConvGemm* desc, int32_t* gn_rows, int32_t* pair_ok);
 
 /* Which kernel variant cs_conv_gemm will launch for this descriptor (fill in everything, including splitk): *tile = the
- * tile code (CsConvGemm.tile's numbering; 5 = the ping-pong kernel), *slab = the line width of the A slab (32 / 64) or 0
+ * tile code (CsConvGemm.tile's numbering; 5 = removed), *slab = the line width of the A slab (32 / 64) or 0
  * for the per-tap gather.  Host-only; what bench.py's per-kernel accounting asks instead of mirroring the dispatch. */
 int cs_conv_gemm_launch_info(const CsConvGemm* desc, int32_t* tile, int32_t* slab);
 
@@ -521,6 +529,13 @@ int64_t cs_attn_f16x3_ws_bytes(int nb, int nq, int nk, int heads, int dh);
 int cs_attn_selfattn_f16x3_ws(const float* q, const float* k, const float* v, float* out, int nb, int nq,
                               int nk, int heads, int dh, int ldq, int ldk, int ldv, int ldo, float scale,
                               int32_t* status, void* ws, cs_stream_t stream);
+/* (ABI 18, r6) the workspace form with caller-chosen operand pre-scales (cs_attn_selfattn_f16x3_scaled's arguments): what an
+ * attention block fed by a GroupNorm takes -- the VQ decoder's AttnBlock (vqvae_modules.py:154-178), the concat family's
+ * AttentionBlock (openai_model_3d.py:360-366) -- with the scales of cs_attnblock_static_scales. */
+int cs_attn_selfattn_f16x3_ws_scaled(const float* q, const float* k, const float* v, float* out, int nb, int nq,
+                                     int nk, int heads, int dh, int ldq, int ldk, int ldv, int ldo, float scale,
+                                     float q_scale, float k_scale, float v_scale, int32_t* status, void* ws,
+                                     cs_stream_t stream);
 
 /* Same contract, PLAIN fp16 operands on the fp16 MFMA (one pass instead of three; fp32 softmax and accumulation):
  * the "fp16 MFMA attention" option BASELINE configs[4] names.  Reduced precision (~3e-4 relative on the attention

@@ -502,86 +502,14 @@ def test_f16x3_conv_on_a_tensor_larger_than_4_gib():
     assert rel_l2(big[-3:], tail) < 1e-6 and rel_l2(big[:2], head) < 1e-6
 
 
-# ----------------------------------------------------------------------------------------------------------------------
-# persistent ping-pong pointwise GEMM (tile 5, csrc/cs_gemm_pw.hip)
-# ----------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("case", [
-    dict(m=(64, 1024), k=448, n=448, res=True, rowvec=True, bias=True),          # attn1.to_out at the 1024-token level
-    dict(m=(64, 256), k=672, n=2016, bias=False),                                # fused q|k|v at the 256-token level
-    dict(m=(64, 256), k=672, n=672, res=True, bias=True, act="silu"),
-    dict(m=(33, 1000), k=448, n=448, res=True, bias=True),                       # M = 33000: a ragged last tile
-    dict(m=(64, 1024), k=448, n=3584, geglu=True),                               # ff.net.0.proj with the fused gate
-    dict(m=(32, 1024), k=1792, n=448, res=True, bias=True, strided=True),        # ff.net.2, views into wider buffers
-])
-def test_pingpong_gemm_is_bit_identical_to_the_tile_kernels(case):
-    """tile 5 must give the same bits as the one-tile-per-workgroup kernels (same chunk order, same MFMA sequence, same
-    epilogue expression), whatever the epilogue: bias, per-sample row vector, activation, residual, fused GEGLU gate,
-    ragged M, strided operands; tile=0 (auto: tile 5 for the short-K C x C shapes, the 256x224 tile otherwise) agrees."""
-    from commonscenes_amd import lib as L
-    from commonscenes_amd import ops, synth
-    nb, tok = case["m"]
-    k, n = case["k"], case["n"]
-    tag = f"pp:{nb}:{tok}:{k}:{n}"
-    if case.get("strided"):
-        xw = synth.tensor_device(tag + ":x", (nb, tok, k + 64), 1.0)
-        x = xw[..., 32:32 + k]
-        rw = synth.tensor_device(tag + ":r", (nb, tok, n + 32), 1.0)
-        r = rw[..., 16:16 + n]
-    else:
-        x = synth.tensor_device(tag + ":x", (nb, tok, k), 1.0)
-        r = synth.tensor_device(tag + ":r", (nb, tok, n), 1.0)
-    w = synth.tensor_device(tag + ":w", (n, k), (3.0 / k) ** 0.5)
-    b = synth.tensor_device(tag + ":b", (n,), 0.1)
-    if case.get("geglu"):
-        pw = ops.pack_geglu_weight(w, b)
-        kw = dict(act=L.ACT_GEGLU)
-    else:
-        pw = ops.pack_weight(w, b if case.get("bias") else None, math=L.MATH_F16X3)
-        kw = dict(act={"silu": L.ACT_SILU}.get(case.get("act"), L.ACT_NONE))
-        if case.get("res"):
-            kw["res"] = r
-        if case.get("rowvec"):
-            kw.update(rowvec=synth.tensor_device(tag + ":rv", (nb, n), 1.0), rv_rows=tok)
-    # (tile = 5 below is refused with CS_EINVAL where the ping-pong kernel is not applicable: the call is the check)
-    ops.read_status()
-    ref = ops.linear(x, pw, tile=2, **kw)
-    got = ops.linear(x, pw, tile=5, **kw)
-    auto = ops.linear(x, pw, **kw)
-    torch.cuda.synchronize()
-    assert ops.read_status() == 0
-    assert torch.isfinite(ref).all()
-    assert torch.equal(got, ref) and torch.equal(auto, ref)
-    # and against fp64 for good measure (not just self-consistency)
-    if not case.get("geglu"):
-        y = x.double() @ w.double().t()
-        if case.get("bias"):
-            y = y + b.double()
-        if case.get("rowvec"):
-            y = y + kw["rowvec"].double()[:, None, :]
-        if case.get("act") == "silu":
-            y = y * torch.sigmoid(y)
-        if case.get("res"):
-            y = y + r.double()
-        assert rel_l2(got, y) < 1e-6
-
-
-def test_pingpong_gemm_reports_overflow_and_rejects_what_it_cannot_do():
+def test_removed_pingpong_tile_code_is_refused():
+    """tile code 5 (r2's persistent ping-pong GEMM, removed in r6) is refused, never silently mapped to another kernel"""
     from commonscenes_amd import lib as L
     from commonscenes_amd import ops, synth
     x = synth.tensor_device("ppo:x", (64, 1024, 448), 1.0)
-    w = synth.tensor_device("ppo:w", (448, 448), 0.05)
-    pw = ops.pack_weight(w, None, math=L.MATH_F16X3)
-    ops.read_status()
-    x[5, 77, 300] = 1.0e4
-    ops.linear(x, pw, tile=5)
-    torch.cuda.synchronize()
-    assert ops.read_status() == L.STATUS_F16X3_OVERFLOW
-    small = synth.tensor_device("ppo:s", (2, 64, 448), 1.0)        # far too few tiles: tile 5 must refuse, auto falls back
+    pw = ops.pack_weight(synth.tensor_device("ppo:w", (448, 448), 0.05), None, math=L.MATH_F16X3)
     with pytest.raises(L.CsError):
-        ops.linear(small, pw, tile=5)
-    out = ops.linear(small, pw)
-    torch.cuda.synchronize()
-    assert torch.isfinite(out).all()
+        ops.linear(x, pw, tile=5)
 
 
 @pytest.mark.parametrize("shape,cin,cout,tile", [((2, 4, 12, 64), 32, 64, 8), ((3, 8, 8, 16), 48, 128, 9)])
