@@ -31,41 +31,13 @@ __device__ __forceinline__ float cs_silu_acc(float x) {
 #else
 __device__ __forceinline__ float cs_silu_acc(float x) { return x / (1.0f + expf(-x)); }
 #endif
-// erf(a) in fp32, <= 1.5 ulp (r6).  The device library's erff -- the same two minimax branches, whose coefficients these are --
-// spends twelve of its ~45 instructions on a range-reduced exp and its overflow selects; for the branch |a| >= 1 the result
-// is 1 - exp(-r) with r >= 1.2, where v_exp_f32 (1 ulp of an exp <= 0.3, argument rounding ~|r| 2^-24 relative) already sits
-// below half an ulp of the result.  The fused GEGLU epilogue of ff.net.0.proj evaluates 56 exact GELUs per lane and tile and
-// was VALU-bound on them (epilogue-only timing 247 us of the 842 us 448 -> 3584 GEMM at batch 64, profiles/r05_m_tok_phase.txt).
-__device__ __forceinline__ float cs_erff(float a) {
-  const float t = fabsf(a);
-  float r;
-  if (t >= 1.0f) {
-    r = fmaf(t, 0x1.1d3156p-16f, -0x1.8d129p-12f);
-    r = fmaf(t, r, 0x1.f9a6d2p-9f);
-    r = fmaf(t, r, -0x1.8c3164p-6f);
-    r = fmaf(t, r, 0x1.b4e9c8p-4f);
-    r = fmaf(t, r, 0x1.4515fap-1f);
-    r = fmaf(t, r, 0x1.078e5p-3f);
-    r = fmaf(t, r, t);
-    r = 1.0f - __builtin_amdgcn_exp2f(r * -0x1.715476p+0f);       // exp(-r); -> 1 for r beyond ~17 (exp2 underflows to 0)
-  } else {
-    const float s = a * a;
-    r = fmaf(s, -0x1.268bc2p-11f, 0x1.420828p-8f);
-    r = fmaf(s, r, -0x1.b5937p-6f);
-    r = fmaf(s, r, 0x1.ce077cp-4f);
-    r = fmaf(s, r, -0x1.81266p-2f);
-    r = fmaf(s, r, 0x1.06ebap-3f);
-    r = fmaf(t, r, t);
-  }
-  return copysignf(r, a);
-}
-// exact GELU (attention.py:44-46 F.gelu, vqvae_modules.py: nn.GELU): 0.5 x (1 + erf(x / sqrt 2))
+// exact GELU (attention.py:44-46 F.gelu, vqvae_modules.py: nn.GELU): 0.5 x (1 + erf(x / sqrt 2)).
+// (r6, measured and not kept: a hand-rolled erf -- the device library's two minimax branches with v_exp_f32 in place of its
+// range-reduced exp, 25 instead of 45 instructions per GELU, <= 1.5 ulp -- on the suspicion that the fused GEGLU epilogue was
+// VALU-bound on erff: same-box A/B of the whole step 62.93 / 62.82 vs 62.90 / 62.86 ms, i.e. nothing; the library's erff stays.
+// profiles/r06_c_erf_whatif_ab.txt)
 __device__ __forceinline__ float cs_gelu(float x) {
-#ifdef CS_OCML_ERF       // what-if build (tools/build_alt.sh): the device library's erff, as until r5 (same-box A/B of cs_erff)
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
-#else
-  return 0.5f * x * (1.0f + cs_erff(x * 0.70710678118654752440f));
-#endif
 }
 __device__ __forceinline__ float cs_act(float v, int act) {
   switch (act) {

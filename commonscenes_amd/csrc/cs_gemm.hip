@@ -253,7 +253,7 @@ __global__ void relayout_weight_kernel(const float* __restrict__ w, float* __res
 int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p, int M, int tile, int splits, hipStream_t s, int omap_f = 0,
                                 int omap_p = 0, const void* const* cls_w = nullptr, const void* const* cls_w_lo = nullptr,
                                 const float* cls_acc = nullptr, int ncls = 0,
-                                const CsFuseK* fuse = nullptr, int tm_base = 0, int tm_count = 0);   // cs_gemm_f16x3.hip
+                                const CsFuseK* fuse = nullptr, int u_base = 0, int u_count = 0);   // cs_gemm_f16x3.hip
 bool cs_f16x3_slab4_ok(const CsConvGemm& p, int tile, int splits);                      // cs_gemm_f16x3.hip
 // (tile code 5 -- r2's persistent ping-pong pointwise GEMM, cs_gemm_pw.hip -- was removed in r6: measured a loser in r2 at
 // every shape (NOTES section 4.3: 128-row tiles double the weight DMA per flop, one wave per SIMD keeps the matrix pipe ~55 %
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_epi_kernel(const CsConvGemm
 // thread: each position result was fetched by up to four rows' threads and the kernel ran at ~3 TB/s of useful traffic.
 template <int R>
 __global__ __launch_bounds__(256) void wino_out_kernel(const CsConvGemm p, const float* __restrict__ ws, int M, int splits,
-                                                       long long tail_row0, int tail_splits) {
+                                                       int tail_unit0, int tail_splits, int unit_cols) {
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -509,8 +509,9 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const CsConvGemm p, const
 #pragma unroll
     for (int q = 0; q < P; ++q) {
       f32x4 a = *reinterpret_cast<const f32x4*>(b + q * pstride);
-      // (r6: the position rows from `tail_row0` on -- stacked row index q * Mt + t -- came from the K-sliced tail launch)
-      const int nsl = (q * Mt + t >= tail_row0) ? tail_splits : splits;
+      // (r6: the (position, column tile) units from `tail_unit0` on came from the K-sliced tail launch: unit = q * tiles_n +
+      // n / unit_cols -- a function of position and column only, so a sample's sums never depend on its place in the batch)
+      const int nsl = (q * ((p.cout + unit_cols - 1) / unit_cols) + n / unit_cols >= tail_unit0) ? tail_splits : splits;
       for (int sl = 1; sl < nsl; ++sl) a += *reinterpret_cast<const f32x4*>(b + q * pstride + sl * sstride);
       mq[q] = a;
     }
@@ -912,16 +913,19 @@ static inline int wino_pos(int variant) { return variant + 2; }
 // level of 32 objects -> two slices (three even rounds, as the direct form's four-way cut); 448 tiles (the 16^3 level at
 // 14 objects) -> one (the efficiency-only rule of the first version took four slices there and LOST 30 % to the direct
 // form, profiles/r05_r_wino_bench_small.txt).
-// r6: the plan of a position launch.  `slices` = the uniform slice count, or -- tail > 0 -- the launch runs as TWO: row tiles
-// [0, tm_main) unsliced over whole rounds of the chip, then row tiles [tm_main, tiles_m) cut into `slices` K slices that
-// together fill (at most) one more round.  The workspace holds `slices` slices either way; the output transform reads one
-// slice for the main rows and `slices` for the tail's.  Why: 288 tiles (the 16x4x4 level at 32 objects: 96 row tiles x 3 column
-// tiles) on 256 CUs are 1.125 rounds -- three uniform slices ran as 3.4 rounds of a third of the K loop each = 4 x 1/3 = 1.33
-// rounds' worth of time at 320 TF/s against 390-415 at the levels whose tile counts are whole rounds (DESIGN r5 open item
-// (v)); 85 row tiles x 3 = 255 workgroups for the whole K loop + 11 x 3 x 7 = 231 workgroups for a seventh of it are 1 + 1/7.
+// r6: the plan of a position launch.  `slices` = the uniform slice count, or -- units_main > 0 -- the launch runs as TWO: the
+// first units_main (position, column tile) units unsliced over whole rounds of the chip, then the remaining units cut into
+// `slices` K slices that together fill (at most) one more round.  The workspace holds `slices` slices either way; the output
+// transform reads one slice for the main units and `slices` for the tail's.  Why: 288 tiles (the 16x4x4 level at 32 objects:
+// 6 positions x 3 column tiles = 18 units of 16 row tiles) on 256 CUs are 1.125 rounds -- three uniform slices ran as 3.4
+// rounds of a third of the K loop each = 4 x 1/3 = 1.33 rounds' worth of time at 320 TF/s against 390-415 at the levels whose
+// tile counts are whole rounds (DESIGN r5 open item (v)); 16 units = 256 workgroups for the whole K loop + 2 units x 7 slices =
+// 224 workgroups for a seventh of it are 1 + 1/7.  The cut is by UNIT, not by row tile: every row of a unit is summed the same
+// way, so a sample's result does not depend on where it sits in the batch (tests: objects with equal conditioning get equal
+// shapes; a rank shard computed on its own equals the same rows of the whole launch).
 struct WinoPlan {
   int slices;       // slices of the workspace (uniform plan: of every tile; tail plan: of the tail's tiles)
-  int tm_main;      // tail plan: row tiles of the unsliced main launch (0 = uniform plan)
+  int units_main;   // tail plan: (position, column tile) units of the unsliced main launch (0 = uniform plan)
 };
 static int wino_splits(const CsConvGemm& p, int variant, double* cost_us = nullptr);
 
@@ -929,17 +933,19 @@ static WinoPlan wino_plan(const CsConvGemm& p, int variant) {
   WinoPlan pl;
   double t_uni = 0;
   pl.slices = wino_splits(p, variant, &t_uni);
-  pl.tm_main = 0;
+  pl.units_main = 0;
   static const bool forced = [] { const char* e = getenv("CS_WINO_SPLITS"); return e && *e && atoi(e) > 0; }();
   if (forced || cs_debug()->no_wino_tail || p.cout % 224) return pl;
   const int64_t M = (int64_t)p.nb * p.dout * p.hout * p.wout;
-  const int64_t tiles_m = wino_pos(variant) * (M / variant / 256), tiles_n = p.cout / 224;
+  const int64_t R = M / variant / 256, tiles_n = p.cout / 224;      // row tiles per position; column tiles
+  const int64_t units = wino_pos(variant) * tiles_n;
   const int64_t cus = device_cus() > 0 ? device_cus() : 256;
-  const int64_t rounds = tiles_m * tiles_n / cus;                  // whole rounds the main launch may fill
+  if (R < 1) return pl;
+  const int64_t rounds = units * R / cus;                         // whole rounds the main launch may fill
   if (rounds < 1) return pl;
-  const int64_t tm_main = rounds * cus / tiles_n;                  // whole row tiles (every column tile of a row tile together)
-  const int64_t tail_tiles = (tiles_m - tm_main) * tiles_n;
-  if (tm_main < 1 || tail_tiles < 1) return pl;
+  const int64_t units_main = rounds * cus / R;                    // whole units
+  const int64_t tail_tiles = (units - units_main) * R;
+  if (units_main < 1 || tail_tiles < 1) return pl;
   const int64_t nsc = 3LL * ((p.cin + 15) / 16);
   int best = 0;
   for (int sp = 2; sp <= 16 && tail_tiles * sp <= cus; ++sp) {     // (one slice: the uniform plan's own extra round)
@@ -952,11 +958,11 @@ static WinoPlan wino_plan(const CsConvGemm& p, int variant) {
   const double mb_tail = (double)tail_tiles * 256.0 * 224.0 * 4.0 / 1e6;
   double seam = (best - 1) * mb_tail * 0.46;
   if (seam < 2.0 * (best - 1)) seam = 2.0 * (best - 1);
-  const double main_rounds = (double)((tm_main * tiles_n + cus - 1) / cus);
+  const double main_rounds = (double)((units_main * R + cus - 1) / cus);
   const double t_tail = main_rounds * ((double)nsc * 3.0 * 0.95 + 10.0) + ((double)per * 3.0 * 0.95 + 10.0) + seam + 5.0;
   if (t_tail < t_uni * 0.97) {
     pl.slices = best;
-    pl.tm_main = (int)tm_main;
+    pl.units_main = (int)units_main;
   }
   return pl;
 }
@@ -1017,15 +1023,14 @@ extern "C" int cs_conv_wino_plan(const CsConvGemm* d, int32_t* splitk, int64_t* 
   return CS_OK;
 }
 
-extern "C" int cs_conv_wino_plan_info(const CsConvGemm* d, int32_t* slices, int32_t* tm_main, int32_t* tiles_m) {
+extern "C" int cs_conv_wino_plan_info(const CsConvGemm* d, int32_t* slices, int32_t* units_main, int32_t* units) {
   if (!d) return CS_EINVAL;
   const int v = wino_asked(*d);
   if (!v) return CS_EINVAL;
   const WinoPlan pl = wino_plan(*d, v);
-  const int64_t M = (int64_t)d->nb * d->dout * d->hout * d->wout;
   if (slices) *slices = pl.slices;
-  if (tm_main) *tm_main = pl.tm_main;
-  if (tiles_m) *tiles_m = (int32_t)(wino_pos(v) * (M / v / 256));
+  if (units_main) *units_main = pl.units_main;
+  if (units) *units = (int32_t)(wino_pos(v) * ((d->cout + 223) / 224));
   return CS_OK;
 }
 
@@ -1059,32 +1064,32 @@ static int conv_wino(const CsConvGemm& p, int M, hipStream_t s, int phases = 3) 
   // r6: the tail plan (wino_plan) -- taken when the hosts pass the slice count cs_conv_wino_plan gave them; any other p.splitk
   // (tests, tuning sweeps) runs as that many uniform slices
   const WinoPlan pl = wino_plan(p, v);
-  const bool tail = pl.tm_main > 0 && pl.slices == sp;
-  const int tiles_m = np * (M / v) / 256;
+  const bool tail = pl.units_main > 0 && pl.slices == sp;
+  const int units = np * (p.cout / 224);
   if (phases & 1) {
     int rc;
     if (tail) {
-      rc = cs_conv_gemm_f16x3_dispatch(q, np * (M / v), q.tile, 1, s, 16, np, nullptr, nullptr, nullptr, 0, nullptr, 0, pl.tm_main);
+      rc = cs_conv_gemm_f16x3_dispatch(q, np * (M / v), q.tile, 1, s, 16, np, nullptr, nullptr, nullptr, 0, nullptr, 0, pl.units_main);
       if (rc == CS_OK)
-        rc = cs_conv_gemm_f16x3_dispatch(q, np * (M / v), q.tile, sp, s, 16, np, nullptr, nullptr, nullptr, 0, nullptr, pl.tm_main,
-                                         tiles_m - pl.tm_main);
+        rc = cs_conv_gemm_f16x3_dispatch(q, np * (M / v), q.tile, sp, s, 16, np, nullptr, nullptr, nullptr, 0, nullptr, pl.units_main,
+                                         units - pl.units_main);
     } else {
       rc = cs_conv_gemm_f16x3_dispatch(q, np * (M / v), q.tile, sp, s, 16, np, nullptr, nullptr, nullptr, 0, nullptr);
     }
     if (rc != CS_OK) return rc;
   }
   if (!(phases & 2)) return CS_OK;
-  const long long tail_row0 = tail ? (long long)pl.tm_main * 256 : 0x7fffffffffffffffLL;
+  const int tail_unit0 = tail ? pl.units_main : 0x7fffffff;
   const int sp_main = tail ? 1 : sp;
   // (one tile of v outputs per thread: 16 v rows x 64 columns per workgroup = the statistics tile cs_conv_gemm_epilogue_caps names)
   const int64_t nblk = (int64_t)((M / v + 15) / 16) * ((p.cout + 63) / 64);
   if (nblk > 0x7fffffffLL || (p.gn_part && p.gn_rows != 16 * v)) return CS_EINVAL;
   if (v == 4) {
     CS_LAUNCH(wino_out_kernel<4>, dim3((unsigned)nblk), dim3(256), 0, s, p, reinterpret_cast<const float*>(p.splitk_ws), M, sp_main,
-              tail_row0, sp);
+              tail_unit0, sp, 224);
   } else {
     CS_LAUNCH(wino_out_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, s, p, reinterpret_cast<const float*>(p.splitk_ws), M, sp_main,
-              tail_row0, sp);
+              tail_unit0, sp, 224);
   }
   CS_CHECK_LAUNCH();
   return CS_OK;

@@ -43,6 +43,8 @@ constexpr int MAX_TAPS = 27;
                       // 16 = s_setprio around the MFMAs, 32 = scalar epilogue, 64 = all fetches from one 16 KB window,
                       // 1024 = no epilogue (K loop + prologue only), 2048 = no K loop (prologue + epilogue only),
                       // 4096 / 8192 = slab kernel reads every second / only the first B fragment pair from LDS
+                      // (r6, the piped epilogue's own budget) 16384 = its global stores dropped, 32768 = the fused gate
+                      // multiplies by the raw gate column instead of its GELU
 #endif
 
 // PRE = the activations arrive already split: p.x / p.x_lo are fp16 hi / lo images [rows][lda halves] written by
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
                                                               int taps_hw, int kw_, int kg_per_tap,
                                                               long long x_bytes, unsigned w_bytes, int vec_epilogue,
                                                               int splits, int omap_f, int omap_p_in, const CsClsBatch cb,
-                                                              const CsFuseK fz, int tm_base, int tm_count) {
+                                                              const CsFuseK fz, int u_base, int u_count) {
   constexpr int BM = 32 * WMB * WAVES_M;
   constexpr int BN = 32 * WNB * WAVES_N;
   constexpr int NW = WAVES_M * WAVES_N;            // waves per workgroup (4, or 8 for the 256-row tile)
@@ -349,12 +351,23 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
   // Slab kernel with K slices (the large-batch four-way cut of the 4^3-level convs: 49 MB of weights per conv, far
   // beyond an XCD's L2): row tiles fastest instead, so the workgroups an XCD runs together stream the SAME weight
   // slice (one or two (column tile, K slice) pairs per XCD instead of twelve).
-  // r6: a launch may cover a RANGE of row tiles [tm_base, tm_base + tm_count) (tm_count = 0: all of them) -- the Winograd-W
-  // position GEMMs of a launch whose tile count is not a whole number of rounds of the chip run as a main launch over whole
-  // rounds (unsliced) and a K-sliced tail launch over the remaining row tiles (cs_gemm.hip::conv_wino).
+  // r6: a launch of the Winograd-W position GEMMs may cover a RANGE of (position, column tile) UNITS [u_base, u_base + u_count)
+  // (u_count = 0: everything, the plain decode below) -- unit u = position u / tiles_n, column tile u % tiles_n, each with the
+  // R = tiles_m / positions row tiles of its position.  A launch whose tile count is not a whole number of rounds of the chip
+  // runs as a main launch over whole rounds (unsliced) and a K-sliced tail launch over the remaining units
+  // (cs_gemm.hip::conv_wino).  Units, not row tiles: how a sum is cut then depends on (position, column) only, never on the
+  // row -- a sample's result stays independent of its place in the batch.
   int split, tn, tm;
-  if (SLAB != 0 && splits > 1) {
-    const int tiles_m = tm_count > 0 ? tm_count : (M + BM - 1) / BM;
+  if (TPK == 3 && u_count > 0) {
+    const int R = ((M + BM - 1) / BM) / (omap_p_in > 1 ? omap_p_in : 1);
+    const int r = tile % R;                      // row tiles fastest: neighbours stream the same weight slice
+    tile /= R;
+    split = tile % splits;
+    const int u = u_base + tile / splits;
+    tn = u % tiles_n;
+    tm = (u / tiles_n) * R + r;
+  } else if (SLAB != 0 && splits > 1) {
+    const int tiles_m = (M + BM - 1) / BM;
     tm = tile % tiles_m;
     tile /= tiles_m;
     split = tile % splits;
@@ -365,7 +378,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
     tn = tile % tiles_n;
     tm = tile / tiles_n;
   }
-  tm += tm_base;
   const int m0 = tm * BM;
   const int n0 = tn * BN;
   // TPK == 3 (r5): the four Winograd-W position GEMMs of one 3x3x3 conv in ONE launch -- their transformed operands are
@@ -1107,12 +1119,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
                 gv += *reinterpret_cast<const f32x4*>(vb + wn0 + HC + 4 * c4);
               }
 #pragma unroll
-              for (int e = 0; e < 4; ++e) xv[e] = xv[e] * cs_gelu(gv[e]);
+              for (int e = 0; e < 4; ++e) xv[e] = xv[e] * ((CS_ABLATE & 32768) ? gv[e] : cs_gelu(gv[e]));
               off = (unsigned)(orel(row) * p.ldo + (n0 + wn0) / 2 + 4 * c4) * 4u;
             }
             if (opair) {                                     // (uniform branch: every lane takes part in the half swap)
               const u32x4 pk = pair16(xv);
               if (ok) off = (unsigned)(orel(row) * p.ldo) * 4u + pair_off((n0 + wn0) / 2 + 4 * c4);
+              if (CS_ABLATE & 16384) off = OOB;
               __builtin_amdgcn_raw_buffer_store_b128(pk, ors, off, 0, 0);
             } else {
               __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xv), ors, off, 0, 0);
@@ -1146,9 +1159,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
               gq[k][1] = __builtin_elementwise_fma(hi2, hi2, gq[k][1]);
             }
           }
+          if (CS_ABLATE & 16384) off = OOB;
           if (opair) {
             const u32x4 pk = pair16(v);
-            if (ok) off = (unsigned)(orel(row) * p.ldo) * 4u + pair_off(n0 + wn0 + 4 * c4);
+            if (ok && !(CS_ABLATE & 16384)) off = (unsigned)(orel(row) * p.ldo) * 4u + pair_off(n0 + wn0 + 4 * c4);
             __builtin_amdgcn_raw_buffer_store_b128(pk, ors, off, 0, 0);
           } else {
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, off, 0, 0);   // OOB lanes: dropped
@@ -1326,18 +1340,21 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
 
 template <int WMB, int WNB, int WAVES_M, int WAVES_N, bool PRE, int SLAB = 0, bool PAIR = false, int TPK = 9, bool PW = false>
 int launch16(const CsConvGemm& p, int M, int splits, hipStream_t stream, int omap_f = 0, int omap_p = 0,
-             const CsClsBatch* cls = nullptr, const CsFuseK* fuse = nullptr, int tm_base = 0, int tm_count = 0) {
+             const CsClsBatch* cls = nullptr, const CsFuseK* fuse = nullptr, int u_base = 0, int u_count = 0) {
   constexpr int BM = 32 * WMB * WAVES_M;
   constexpr int BN = 32 * WNB * WAVES_N;
-  const int tiles_m_all = (M + BM - 1) / BM;
-  if (tm_count < 0 || tm_base < 0 || tm_base + tm_count > tiles_m_all || (tm_count > 0 && (TPK != 3 || (cls && cls->n > 1) || fuse)))
-    return CS_EINVAL;                                  // a row-tile range: the Winograd-W position launches only
-  const int tiles_m = tm_count > 0 ? tm_count : tiles_m_all;
+  const int tiles_m = (M + BM - 1) / BM;
   const int tiles_n = (p.cout + BN - 1) / BN;
+  // a unit range [u_base, u_base + u_count) of (position, column tile) pairs: the Winograd-W position launches only
+  const int npos = (TPK == 3 && omap_p > 1) ? omap_p : 1;
+  if (u_count < 0 || u_base < 0 || (u_count > 0 && (TPK != 3 || (cls && cls->n > 1) || fuse || tiles_m % npos ||
+                                                    u_base + u_count > npos * tiles_n)))
+    return CS_EINVAL;
   CsClsBatch cb;
   memset(&cb, 0, sizeof(cb));
   if (cls && TPK == 4 && cls->n > 1 && (omap_f & 7) && ((omap_f & 8) ? splits > 1 : splits == 1)) cb = *cls;
-  const int64_t nblk = (int64_t)tiles_m * tiles_n * splits * (cb.n > 1 ? cb.n : 1);
+  const int64_t nblk = u_count > 0 ? (int64_t)u_count * (tiles_m / npos) * splits
+                                   : (int64_t)tiles_m * tiles_n * splits * (cb.n > 1 ? cb.n : 1);
   if (nblk > 0x7fffffffLL) return CS_EINVAL;
   const int kg_per_tap = ((p.cin + 15) / 16) * 2;
   // buffer-descriptor extents: everything the loader may touch, and < 0xFFE00000 so OOB stays out of range
@@ -1367,7 +1384,7 @@ int launch16(const CsConvGemm& p, int M, int splits, hipStream_t stream, int oma
   }
   CS_LAUNCH((conv_gemm_f16x3_kernel<WMB, WNB, WAVES_M, WAVES_N, PRE, SLAB, PAIR, TPK, PW>), dim3((unsigned)nblk), dim3(64 * WAVES_M * WAVES_N), 0,
             stream, p, M, tiles_n, p.kh * p.kw, p.kw, kg_per_tap, (long long)x_bytes, (unsigned)w_bytes, vec, splits,
-            TPK == 4 ? omap_f : 0, TPK != 9 ? omap_p : 0, cb, fz, tm_base, tm_count);
+            TPK == 4 ? omap_f : 0, TPK != 9 ? omap_p : 0, cb, fz, u_base, u_count);
   CS_CHECK_LAUNCH();
   return CS_OK;
 }
@@ -1467,9 +1484,9 @@ int cs_f16x3_slab_width(const CsConvGemm& p, int tile, int splits) {
 // and accumulator scale cls_acc[c]; its pads and scatter parity follow from c and omap_f (see the kernel)
 int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p_in, int M, int tile, int splits, hipStream_t s, int omap_f, int omap_p,
                                 const void* const* cls_w, const void* const* cls_w_lo, const float* cls_acc, int ncls,
-                                const CsFuseK* fuse, int tm_base, int tm_count) {
+                                const CsFuseK* fuse, int u_base, int u_count) {
   CsConvGemm p = p_in;
-  if (tm_count != 0 && !(p.a_format == 1 && cs_f16x3_wino_geom(p) && (omap_f & 16))) return CS_EINVAL;
+  if (u_count != 0 && !(p.a_format == 1 && cs_f16x3_wino_geom(p) && (omap_f & 16))) return CS_EINVAL;
   if (splits < 1) splits = 1;
   const bool cls_sliced = (omap_f & 8) != 0;           // r5: all parity classes x K slices in one launch, partial tiles out
   if (cls_sliced && (splits < 2 || ncls < 2 || p.a_format != 0 || (tile != 4 && tile != 6) || !cs_f16x3_slab4_ok(p, tile, -1) ||
@@ -1513,9 +1530,9 @@ int cs_conv_gemm_f16x3_dispatch(const CsConvGemm& p_in, int M, int tile, int spl
       const int ncls = (omap_f & 16) ? omap_p : 0;
       if (ncls > 1 && (((M + 255) / 256) % ncls || M % 256)) return CS_EINVAL;     // whole row tiles per class
       // (256x224: the UNet's widths; 256x128 / 256x64: the VQ decoder's)
-      if (tile == 4) return launch16<1, 7, 8, 1, true, 32, false, 3>(p, M, splits, s, 0, ncls, nullptr, nullptr, tm_base, tm_count);
-      if (tile == 6) return launch16<1, 4, 8, 1, true, 32, false, 3>(p, M, splits, s, 0, ncls, nullptr, nullptr, tm_base, tm_count);
-      return launch16<1, 2, 8, 1, true, 32, false, 3>(p, M, splits, s, 0, ncls, nullptr, nullptr, tm_base, tm_count);
+      if (tile == 4) return launch16<1, 7, 8, 1, true, 32, false, 3>(p, M, splits, s, 0, ncls, nullptr, nullptr, u_base, u_count);
+      if (tile == 6) return launch16<1, 4, 8, 1, true, 32, false, 3>(p, M, splits, s, 0, ncls, nullptr, nullptr, u_base, u_count);
+      return launch16<1, 2, 8, 1, true, 32, false, 3>(p, M, splits, s, 0, ncls, nullptr, nullptr, u_base, u_count);
     }
     if (slab_geom && slab_slices_ok) {
       switch (tile) {

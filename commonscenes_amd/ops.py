@@ -803,17 +803,17 @@ def _conv_wino(xw: "Wino16", w: PackedWeight, act, rowvec, rv_rows, res, scale, 
         # flops = what the position GEMMs EXECUTE (18 of the direct form's 27 multiply-adds per output); flops_direct = the
         # direct form's algorithmic work the pair of launches replaces; m / k = the position launch's own GEMM shape
         npos = xw.variant + 2
-        # (r6: the tail plan writes one slice for the main row tiles and `slices` for the tail's: the average per row tile)
-        sl_, tmm_, tmt_ = C.c_int32(0), C.c_int32(0), C.c_int32(0)
-        L.check(lib.cs_conv_wino_plan_info(C.byref(p), C.byref(sl_), C.byref(tmm_), C.byref(tmt_)), "cs_conv_wino_plan_info")
+        # (r6: the tail plan writes one slice for the main (position, column tile) units and `slices` for the tail's: the average)
+        sl_, um_, ut_ = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        L.check(lib.cs_conv_wino_plan_info(C.byref(p), C.byref(sl_), C.byref(um_), C.byref(ut_)), "cs_conv_wino_plan_info")
         eff_slices = float(sk.value)
-        if tmm_.value > 0 and sl_.value == sk.value:
-            eff_slices = (tmm_.value + (tmt_.value - tmm_.value) * sk.value) / float(tmt_.value)
+        if um_.value > 0 and sl_.value == sk.value:
+            eff_slices = (um_.value + (ut_.value - um_.value) * sk.value) / float(ut_.value)
         prof.append(dict(e0=e0, e1=e1, e2=e2, flops=2.0 * (mo // xw.variant) * npos * w.cout * w.cin * 9,
                          flops_direct=2.0 * mo * w.cout * w.cin * 27, taps=9, m=(mo // xw.variant) * npos, n=w.cout, k=w.cin * 9,
                          npos=npos,
                          tile=4 if w.cout % 224 == 0 else 6 if w.cout % 128 == 0 else 7, slab=32, pre=True, pair=False,
-                         res=res is not None, wino=True, slices=eff_slices, tail_plan=bool(tmm_.value > 0)))
+                         res=res is not None, wino=True, slices=eff_slices, tail_plan=bool(um_.value > 0)))
     if paired:
         return Pair16(out, float(out_pair))
     return attach_stats(out, st)

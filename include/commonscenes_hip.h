@@ -103,7 +103,7 @@ typedef struct CsDebug {
   int32_t no_wino43;          /* never F(4,3) along W (a_format = 4): F(2,3) wherever the Winograd-W route is taken */
   int32_t wino43_min_rows;    /* F(4,3) from this many output rows (default 2048; 0 = the default) */
   int32_t no_wino_tail;       /* Winograd-W position launches always with ONE slice count for every tile (r6: whole rounds unsliced +
-                                 a K-sliced tail launch over the remaining row tiles); different fp32 sum order */
+                                 a K-sliced tail launch over the remaining (position, column tile) units); different fp32 sum order */
   int64_t split16_min_rows;   /* pre-split operands on the 128-row slab tile from this many rows (8192; 0 = never) */
   int64_t cfg_split_min_rows; /* channel-split ResBlocks from this many rows (65536) */
   int64_t gn_small_group;     /* single-launch GroupNorm up to this many elements per (sample, group) (11264) */
@@ -310,11 +310,12 @@ int cs_conv_gemm_plan(const CsConvGemm* desc, int32_t* splitk, int64_t* splitk_w
  * reads the variant from desc->a_format (3 or 4).) */
 int cs_conv_wino_ok(const CsConvGemm* desc);
 int cs_conv_wino_plan(const CsConvGemm* desc, int32_t* splitk, int64_t* ws_bytes);
-/* (ABI 18) the shape of the position launch(es) behind that plan: `slices` = cs_conv_wino_plan's splitk; tm_main > 0 = the TAIL
- * plan -- row tiles [0, tm_main) of the tiles_m 256-row tiles run unsliced (whole rounds of the chip), row tiles [tm_main,
- * tiles_m) as a second launch cut into `slices` K slices; tm_main = 0 = every tile in `slices` uniform slices.  Host-only
- * (bench.py's byte accounting); cs_conv_gemm takes the tail plan exactly when desc->splitk == slices. */
-int cs_conv_wino_plan_info(const CsConvGemm* desc, int32_t* slices, int32_t* tm_main, int32_t* tiles_m);
+/* (ABI 18) the shape of the position launch(es) behind that plan: `slices` = cs_conv_wino_plan's splitk; units_main > 0 = the
+ * TAIL plan -- of the `units` (position, 224-column tile) units the first units_main run unsliced (whole rounds of the chip),
+ * the rest as a second launch cut into `slices` K slices; units_main = 0 = every tile in `slices` uniform slices.  A unit's
+ * rows are all summed the same way: results never depend on a sample's place in the batch.  Host-only (bench.py's byte
+ * accounting); cs_conv_gemm takes the tail plan exactly when desc->splitk == slices. */
+int cs_conv_wino_plan_info(const CsConvGemm* desc, int32_t* slices, int32_t* units_main, int32_t* units);
 /* The two launches of cs_conv_gemm(a_format = 3) on their own, for hosts that time them separately (bench.py's per-kernel
  * HIP events): cs_conv_wino_positions = the four position GEMMs into splitk_ws, cs_conv_wino_output = the output transform +
  * epilogue from splitk_ws.  Same descriptor, same validation; calling the first and then the second IS cs_conv_gemm. */

@@ -372,8 +372,11 @@ def test_vq_decoder_attention_takes_static_scales_and_needs_no_fallback(scaled):
     sd = synth.synth_state_dict(vqvae_param_shapes(VQ_FULL, 8192, 3), device="cuda")
     a = "decoder.mid.attn_1."
     if scaled == "v x3e3":
+        # (proj_out / 3e3 keeps the residual stream where it was: this test is about the attention block's own operands -- the
+        # decoder's RAW-stream consumers further down, nin_shortcut and the folded Upsample convs, still carry the constant scale)
         sd[a + "v.weight"] = sd[a + "v.weight"] * 3.0e3
         sd[a + "v.bias"] = sd[a + "v.bias"] * 3.0e3
+        sd[a + "proj_out.weight"] = sd[a + "proj_out.weight"] / 3.0e3
     elif scaled == "q,k x4":
         for n in ("q", "k"):
             sd[a + f"{n}.weight"] = sd[a + f"{n}.weight"] * 4.0

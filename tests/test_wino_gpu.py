@@ -186,10 +186,12 @@ def test_channel_range_form_feeds_the_halves_of_a_channel_split_conv(variant):
 
 
 def test_tail_plan_of_a_position_launch_that_is_not_whole_rounds():
-    """r6: 288 position tiles (the 16x4x4 level at 32 objects, F(4,3): 96 row tiles x 3 column tiles) on 256 CUs -- the plan is
-    a main launch over whole rounds (85 row tiles x 3, unsliced) + a K-sliced tail launch over the other 11 row tiles
+    """r6: 288 position tiles (the 16x4x4 level at 32 objects, F(4,3): 6 positions x 3 column tiles = 18 units of 16 row tiles) on
+    256 CUs -- the plan is a main launch over whole rounds (16 units, unsliced) + a K-sliced tail launch over the other 2 units
     (cs_conv_wino_plan_info); CS_NO_WINO_TAIL=1 is the uniform-slices form.  Both against fp64 at the per-op gate and against
-    each other (they differ in the fp32 summation order only), GroupNorm partials included."""
+    each other (they differ in the fp32 summation order only), GroupNorm partials included -- and, because the cut is by
+    (position, column tile) and never by row, a sample's result does not depend on its place in the batch: the last sample is a
+    copy of the first and must come out bit-identical."""
     from commonscenes_amd import lib as L, ops
     nb, sp, cin, cout = 64, (16, 4, 4), 672, 672
     rows = sp[0] * sp[1] * sp[2]
@@ -197,6 +199,7 @@ def test_tail_plan_of_a_position_launch_that_is_not_whole_rounds():
     g, b = _rand(cin, seed=22) * 0.2 + 1.0, _rand(cin, seed=23) * 0.2
     wt = _rand(cout, cin, 3, 3, 3, seed=24, scale=(cin * 27) ** -0.5)
     bias, emb, res = _rand(cout, seed=25), _rand(nb, cout, seed=26), _rand(nb, *sp, cout, seed=27)
+    x[-1], emb[-1], res[-1] = x[0], emb[0], res[0]
     pw = ops.pack_weight(wt, bias, math=L.MATH_F16X3)
     ops.pack_weight_wino(pw, wt)
     s1 = ops.norm_a_scale(float(g.abs().max()), float(b.abs().max()), rows * (cin // 32))
@@ -208,23 +211,25 @@ def test_tail_plan_of_a_position_launch_that_is_not_whole_rounds():
             outs[tail] = ops.conv_gemm(v, pw, rowvec=emb, rv_rows=rows, res=res, stats=True)
             p = ops._wino_desc(nb, *sp, pw)
             p.a_format = 4
-            sl, tmm, tmt = C.c_int32(0), C.c_int32(0), C.c_int32(0)
-            assert L.load().cs_conv_wino_plan_info(C.byref(p), C.byref(sl), C.byref(tmm), C.byref(tmt)) == 0
-            plans[tail] = (sl.value, tmm.value, tmt.value)
+            sl, um, ut = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+            assert L.load().cs_conv_wino_plan_info(C.byref(p), C.byref(sl), C.byref(um), C.byref(ut)) == 0
+            plans[tail] = (sl.value, um.value, ut.value)
     torch.cuda.synchronize()
     ops.check_overflow()
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     print(f"tail plan {plans[1]}, uniform plan {plans[0]} on {cus} CUs")
-    assert plans[0][1] == 0 and plans[0][2] == 96
+    assert plans[0][1] == 0 and plans[0][2] == 18
     if cus == 256:
-        assert plans[1] == (7, 85, 96)                     # 255 workgroups for the whole K loop, then 33 tiles x 7 slices = 231
+        assert plans[1] == (7, 16, 18)                     # 256 workgroups for the whole K loop, then 2 units x 16 tiles x 7 slices = 224
     a = _ref_gn_silu(x, g, b)
     ref = F.conv3d(a.permute(0, 4, 1, 2, 3), wt.double(), bias.double(), padding=1).permute(0, 2, 3, 4, 1)
     ref = ref + emb.double()[:, None, None, None, :] + res.double()
     e1, e0 = rel_l2(outs[1], ref), rel_l2(outs[0], ref)
     print(f"tail plan rel-L2 vs fp64 {e1:.2e}, uniform {e0:.2e}, tail vs uniform {rel_l2(outs[1], outs[0]):.2e}")
-    assert e1 < 1e-6 and e0 < 1e-6 and rel_l2(outs[1], outs[0]) < 5e-7
+    # (an unsliced 6048-term fp32 chain rounds a little more than three chains of 2016: 6.8e-7 vs 4.4e-7 measured)
+    assert e1 < 1e-6 and e0 < 1e-6 and rel_l2(outs[1], outs[0]) < 1.5e-6
     for o in outs.values():
+        assert torch.equal(o[-1], o[0])                    # the batch position does not enter the arithmetic
         st = ops.groupnorm_stats_from_parts([(0, o.cs_stats)], nb, rows, cout, 32, 1e-5, o.device)
         t = o.double().reshape(nb, rows, 32, cout // 32)
         mean, var = t.mean(dim=(1, 3)), t.var(dim=(1, 3), unbiased=False)
