@@ -919,8 +919,8 @@ static inline int wino_pos(int variant) { return variant + 2; }
 // transform reads one slice for the main units and `slices` for the tail's.  Why: 288 tiles (the 16x4x4 level at 32 objects:
 // 6 positions x 3 column tiles = 18 units of 16 row tiles) on 256 CUs are 1.125 rounds -- three uniform slices ran as 3.4
 // rounds of a third of the K loop each = 4 x 1/3 = 1.33 rounds' worth of time at 320 TF/s against 390-415 at the levels whose
-// tile counts are whole rounds (DESIGN r5 open item (v)); 16 units = 256 workgroups for the whole K loop + 2 units x 7 slices =
-// 224 workgroups for a seventh of it are 1 + 1/7.  The cut is by UNIT, not by row tile: every row of a unit is summed the same
+// tile counts are whole rounds (DESIGN r5 open item (v)); 16 units = 256 workgroups for the whole K loop + 2 units x 8 slices =
+// 256 workgroups for an eighth of it are 1 + 1/8.  The cut is by UNIT, not by row tile: every row of a unit is summed the same
 // way, so a sample's result does not depend on where it sits in the batch (tests: objects with equal conditioning get equal
 // shapes; a rank shard computed on its own equals the same rows of the whole launch).
 struct WinoPlan {

@@ -220,7 +220,7 @@ def test_tail_plan_of_a_position_launch_that_is_not_whole_rounds():
     print(f"tail plan {plans[1]}, uniform plan {plans[0]} on {cus} CUs")
     assert plans[0][1] == 0 and plans[0][2] == 18
     if cus == 256:
-        assert plans[1] == (7, 16, 18)                     # 256 workgroups for the whole K loop, then 2 units x 16 tiles x 7 slices = 224
+        assert plans[1] == (8, 16, 18)                     # 256 workgroups for the whole K loop, then 2 units x 16 tiles x 8 slices = 256
     a = _ref_gn_silu(x, g, b)
     ref = F.conv3d(a.permute(0, 4, 1, 2, 3), wt.double(), bias.double(), padding=1).permute(0, 2, 3, 4, 1)
     ref = ref + emb.double()[:, None, None, None, :] + res.double()
