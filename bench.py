@@ -331,7 +331,10 @@ def gemm_summary(prof, wall_ms, math):
             ab += r["m"] * cin * 4.0 + r.get("npos", 4) * r["k"] * r["n"] * 4.0 + r.get("slices", 1) * r["m"] * r["n"] * 4.0
         else:
             ab += r["m"] * cin * 4.0 + r["k"] * r["n"] * 4.0 + r["m"] * r["n"] * 4.0 * (2.0 if r.get("res") else 1.0)
-    alg_bytes = ab / len(sel)
+    # r6: a position launch on the tail plan is TWO dispatches of the kernel (main + K-sliced tail): per-launch figures are per
+    # DISPATCH, which is what rocprofv3's per-kernel average and the PMC bytes per launch count
+    ndisp = sum(int(r.get("dispatches", 1)) for r in sel)
+    alg_bytes = ab / ndisp
     if math == "f16x3":
         peak = F16_MFMA_PEAK_TFLOPS / 3.0
         kname = f"{kernel_label(dom)}; implicit GEMM, 3x v_mfma_f32_32x32x16_f16 per K=16 on hi/lo splits)"
@@ -349,8 +352,8 @@ def gemm_summary(prof, wall_ms, math):
             "frac_of_fp32_matrix_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
             "issued_mfma_tflops": 3.0 * achieved if math == "f16x3" else achieved,
             "kernel": kname, "rocprof_kernel": rocprof_name(dom) if math == "f16x3" else "conv_gemm_f32_kernel<1, 7, 4, 1>",
-            "math": math, "launches": len(sel), "avg_launch_ms": ms / len(sel),
-            "algorithmic_gflop_per_launch": fl / len(sel) / 1e9, "algorithmic_bytes_per_launch": alg_bytes,
+            "math": math, "launches": ndisp, "avg_launch_ms": ms / ndisp, "host_calls": len(sel),
+            "algorithmic_gflop_per_launch": fl / ndisp / 1e9, "algorithmic_bytes_per_launch": alg_bytes,
             "flops_note": ("achieved / frac price the multiply-adds the kernel EXECUTES: this kernel is the Winograd-W position "
                            "launch of the 3x3x3 convs (F(4,3) along W: 13.5 of the direct form's 27 multiply-adds per output; F(2,3): 18), so "
                            "the direct-form-equivalent rate of those convs -- with their output-transform launch counted in -- "

@@ -813,7 +813,8 @@ def _conv_wino(xw: "Wino16", w: PackedWeight, act, rowvec, rv_rows, res, scale, 
                          flops_direct=2.0 * mo * w.cout * w.cin * 27, taps=9, m=(mo // xw.variant) * npos, n=w.cout, k=w.cin * 9,
                          npos=npos,
                          tile=4 if w.cout % 224 == 0 else 6 if w.cout % 128 == 0 else 7, slab=32, pre=True, pair=False,
-                         res=res is not None, wino=True, slices=eff_slices, tail_plan=bool(um_.value > 0)))
+                         res=res is not None, wino=True, slices=eff_slices, tail_plan=bool(um_.value > 0),
+                         dispatches=2 if (um_.value > 0 and sl_.value == sk.value) else 1))
     if paired:
         return Pair16(out, float(out_pair))
     return attach_stats(out, st)
