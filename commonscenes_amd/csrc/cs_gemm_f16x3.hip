@@ -982,7 +982,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_gemm_f16x3_ker
     const bool has_res = p.res != nullptr;
     // (r4: an edge column tile -- cout not a multiple of BN -- takes this path too, its lanes past cout masked like the rows
     // past M; only the fused gate needs whole [x | gate] column groups)
-    const bool piped = !(CS_ABLATE & 32) && vec_epilogue && (p.res || p.bias || p.rowvec) && !p.scale && splits == 1 &&
+    // (r6: launches WITHOUT bias / residual / row vector -- the fused q | k | v projection, the Winograd position GEMMs -- take
+    // this path too: its buffer stores with precomputed 32-bit offsets beat the plain path's per-store 64-bit address arithmetic,
+    // 64.70 -> 64.41 ms per 32-object step same box, bit-identical, profiles/r06_h_piped_plain_ab.txt; -DCS_PIPED_PLAIN=0 = the r5
+    // rule.  cs_conv_gemm_epilogue_caps keeps the narrower rule: no host asks such a launch for GroupNorm partials / a pair.)
+#ifndef CS_PIPED_PLAIN
+#define CS_PIPED_PLAIN 1
+#endif
+    const bool piped = !(CS_ABLATE & 32) && vec_epilogue && (p.res || p.bias || p.rowvec || CS_PIPED_PLAIN) && !p.scale && splits == 1 &&
                        (!geglu || n0 + BN <= p.cout) && (!p.rowvec || (m0 / p.rv_rows == m_last / p.rv_rows)) &&
                        (long long)ospan * p.ldo * 4 < 0x7FF00000LL && (!p.res || (long long)BM * p.ldr * 4 < 0x7FF00000LL);
     // r4 (ABI 14): what the epilogue emits beside / instead of the fp32 tile -- only this (piped) path can; the host asks
