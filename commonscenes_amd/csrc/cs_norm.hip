@@ -453,6 +453,11 @@ __global__ __launch_bounds__(256) void gn_apply_wino16_kernel(const float* __res
 // F(4,3) along W (CsConvGemm.a_format = 4): per W line and FOUR voxels (w = 4 t .. 4 t + 3) the six transformed values B^T d of
 // d_j = y[4 t - 1 + j] (0 outside the line) -- images [6][nb][lines][W/4][ldv].  Same line walk: a tile's d4, d5 are the next
 // tile's d0, d1.
+// (V = channels per thread.  r6 measured V = 8 -- two float4 loads, ONE 16-byte store per image and position instead of two
+// 8-byte ones -- and it LOST: 80.7 vs 61.3 us per launch, 64.63 vs 64.00 ms per 32-object step same box
+// (profiles/r06_j_gn_wino_v8_whatif_ab.txt): half the threads in flight cost more than the wider stores gain.  V = 4 stays;
+// -DCS_GN_WINO_V8 is the what-if build.  Same arithmetic per element either way.)
+template <int V>
 __global__ __launch_bounds__(256) void gn_apply_wino43_kernel(const float* __restrict__ x, const float* __restrict__ stats,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, _Float16* __restrict__ vh,
@@ -460,8 +465,9 @@ __global__ __launch_bounds__(256) void gn_apply_wino43_kernel(const float* __res
                                                               int ldv, int groups, int act, float a_scale,
                                                               int lines_per_block, int64_t pos_stride,
                                                               int32_t* __restrict__ status, int cpg, int ch0) {
-  const int ch4 = c >> 2;
-  const int tpr = ch4 < 256 ? ch4 : 256;
+  typedef _Float16 hv __attribute__((ext_vector_type(V)));
+  const int chv = c / V;
+  const int tpr = chv < 256 ? chv : 256;
   const int linelanes = 256 / tpr;
   const int tid = threadIdx.x;
   const int ll = tid / tpr;
@@ -475,34 +481,41 @@ __global__ __launch_bounds__(256) void gn_apply_wino43_kernel(const float* __res
   const int64_t vrow0 = (int64_t)n * lines * w4n;
   const float* st = stats + (int64_t)n * groups * 2;
   float amax = 0.f;
-  for (int c4 = cl; c4 < ch4; c4 += tpr) {
-    const float4 g = *reinterpret_cast<const float4*>(gamma + c4 * 4);
-    const float4 b = *reinterpret_cast<const float4*>(beta + c4 * 4);
-    const float gg[4] = {g.x, g.y, g.z, g.w};
-    const float bb[4] = {b.x, b.y, b.z, b.w};
-    float mean[4], rstd[4];
+  for (int cv = cl; cv < chv; cv += tpr) {
+    float gg[V], bb[V], mean[V], rstd[V];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int grp = (ch0 + c4 * 4 + k) / cpg;
+    for (int k4 = 0; k4 < V / 4; ++k4) {
+      const float4 g = *reinterpret_cast<const float4*>(gamma + cv * V + 4 * k4);
+      const float4 b = *reinterpret_cast<const float4*>(beta + cv * V + 4 * k4);
+      gg[4 * k4] = g.x; gg[4 * k4 + 1] = g.y; gg[4 * k4 + 2] = g.z; gg[4 * k4 + 3] = g.w;
+      bb[4 * k4] = b.x; bb[4 * k4 + 1] = b.y; bb[4 * k4 + 2] = b.z; bb[4 * k4 + 3] = b.w;
+    }
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      const int grp = (ch0 + cv * V + k) / cpg;
       mean[k] = st[grp * 2];
       rstd[k] = st[grp * 2 + 1];
     }
-    auto actv = [&](const float* px, bool in, float (&o)[4]) {
+    auto actv = [&](const float* px, bool in, float (&o)[V]) {
       if (!in) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = 0.f;
+        for (int k = 0; k < V; ++k) o[k] = 0.f;
         return;
       }
-      const float4 v = *reinterpret_cast<const float4*>(px);
-      const float iv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-      for (int k = 0; k < 4; ++k) o[k] = cs_act((iv[k] - mean[k]) * rstd[k] * gg[k] + bb[k], act) * a_scale;
+      for (int k4 = 0; k4 < V / 4; ++k4) {
+        const float4 v = *reinterpret_cast<const float4*>(px + 4 * k4);
+        const float iv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          o[4 * k4 + k] = cs_act((iv[k] - mean[4 * k4 + k]) * rstd[4 * k4 + k] * gg[4 * k4 + k] + bb[4 * k4 + k], act) * a_scale;
+      }
     };
     for (int line = l0 + ll; line < l1; line += linelanes) {
-      const float* xl = xb + (int64_t)line * w * ldx + c4 * 4;
-      float d[6][4];
+      const float* xl = xb + (int64_t)line * w * ldx + cv * V;
+      float d[6][V];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) d[0][k] = 0.f;
+      for (int k = 0; k < V; ++k) d[0][k] = 0.f;
       actv(xl, true, d[1]);
       for (int t = 0; t < w4n; ++t) {
 #pragma unroll
@@ -510,12 +523,12 @@ __global__ __launch_bounds__(256) void gn_apply_wino43_kernel(const float* __res
           const int wi = 4 * t - 1 + j;
           actv(xl + (int64_t)wi * ldx, wi < w, d[j]);
         }
-        const int64_t off = (vrow0 + (int64_t)line * w4n + t) * ldv + c4 * 4;
+        const int64_t off = (vrow0 + (int64_t)line * w4n + t) * ldv + cv * V;
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
-          h4v hi, lo;
+          hv hi, lo;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
+          for (int k = 0; k < V; ++k) {
             float o;
             if (q == 0) o = 4.f * d[0][k] - 5.f * d[2][k] + d[4][k];
             else if (q == 1) o = (d[4][k] + d[3][k]) - 4.f * (d[1][k] + d[2][k]);
@@ -528,11 +541,11 @@ __global__ __launch_bounds__(256) void gn_apply_wino43_kernel(const float* __res
             hi[k] = hh;
             lo[k] = (_Float16)(o - (float)hh);
           }
-          *reinterpret_cast<h4v*>(vh + q * pos_stride + off) = hi;
-          *reinterpret_cast<h4v*>(vl + q * pos_stride + off) = lo;
+          *reinterpret_cast<hv*>(vh + q * pos_stride + off) = hi;
+          *reinterpret_cast<hv*>(vl + q * pos_stride + off) = lo;
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < V; ++k) {
           d[0][k] = d[4][k];
           d[1][k] = d[5][k];
         }
@@ -1029,7 +1042,12 @@ extern "C" int cs_groupnorm_apply_wino_range(const float* x, const float* stats,
   const int64_t lines64 = (int64_t)d * h;
   if (lines64 * w > 0x7fffffffLL) return CS_EINVAL;
   const int lines = (int)lines64;
-  const int ch4 = c >> 2;
+#ifdef CS_GN_WINO_V8           // what-if build: eight channels per thread (one 16-byte store per image and position)
+  constexpr int WV = 8;
+#else
+  constexpr int WV = 4;            // channels per thread of the F(4,3) kernel
+#endif
+  const int ch4 = variant == 4 ? c / WV : c >> 2;
   const int linelanes = 256 / (ch4 < 256 ? ch4 : 256);
   // ~2048 workgroups in all, at least one line per line-lane
   int blocks_per_sample = (2048 + nb - 1) / nb;
@@ -1039,7 +1057,7 @@ extern "C" int cs_groupnorm_apply_wino_range(const float* x, const float* stats,
   const int lpb = (lines + blocks_per_sample - 1) / blocks_per_sample;
   const int64_t pos_stride = (int64_t)nb * lines * (w / variant) * ldv;
   if (variant == 4) {
-    CS_LAUNCH(gn_apply_wino43_kernel, dim3((unsigned)((lines + lpb - 1) / lpb), (unsigned)nb), dim3(256), 0,
+    CS_LAUNCH(gn_apply_wino43_kernel<WV>, dim3((unsigned)((lines + lpb - 1) / lpb), (unsigned)nb), dim3(256), 0,
               (hipStream_t)stream, x, stats, gamma, beta, (_Float16*)v_hi, (_Float16*)v_lo, lines, w, c, ldx, ldv, groups, act,
               a_scale, lpb, pos_stride, status, cpg, ch0);
   } else {
