@@ -736,6 +736,14 @@ static int64_t kwave_max_tiles() {
   return v >= 0 ? v : 4LL * device_cus();
 }
 
+static int tok_t2_maxk() {
+  static const int v = [] {
+    const char* e = getenv("CS_TOK_T2_MAXK");
+    return (e && *e) ? atoi(e) : 128;
+  }();
+  return v;
+}
+
 // tile of an automatic (desc->tile == 0) launch
 static int auto_tile(const CsConvGemm& p, int M, bool f16x3) {
   int tile = 0;
@@ -790,6 +798,15 @@ static int auto_tile(const CsConvGemm& p, int M, bool f16x3) {
       // vs 58.6 us (448 -> 224) and 66.7 vs 72.8 (672 -> 224) at 57344 rows, 63.2 vs 68.0 (672 -> 672), 106.2 vs 111.7 (1344
       // -> 672) at 16384; 2688 -> 672 (168 chunks) stays: 193.8 vs 183.8.  profiles/r05_tok_smallm_b{14,64}.txt
       else if (t4 <= 256 && (p.cin + 15) / 16 <= 84)
+        tile = 2;
+      // (iv, r6) the same K bound for fp32 operands and for launches of several rounds: in the r5 sweep the 128-row pair of
+      // workgroups wins every one-tap shape up to 84 chunks at batch 64 whatever the operand format (448 -> 448 f32 at 65536
+      // rows 125.3 vs 130.9 us, 448 -> 224 at 262144 rows 220.0 vs 253.9, 672 -> 224 304.9 vs 322.8, 672 -> 448 140.3 vs
+      // 151.8, 1120 -> 448 216.0 vs 226.1; at 112 chunks the tiles tie in isolation -- 1792 -> 448 319.9 vs 321.8 -- and the
+      // 128-row pair wins inside the step; 2688 -> 672, 168 chunks, loses).  Same-box step A/B (profiles/r06_p_tok_t2_rule_*.txt):
+      // bound 0 / 84 / 112 / 128 / 176 chunks = 64.26 / 63.86 resp. 63.25 / 63.00 / 62.94 / 63.01 ms per 32-object step -> 128.
+      // CS_TOK_T2_MAXK overrides the bound (0 = rules (ii) / (iii) only: A/B runs).
+      else if ((p.cin + 15) / 16 <= tok_t2_maxk())
         tile = 2;
     }
     // the fused gate needs whole [x | gate] 224-column tiles; two 128-row workgroups per CU overlap one's gate epilogue with

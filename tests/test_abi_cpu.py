@@ -268,7 +268,10 @@ def test_epilogue_caps_is_one_host_side_rule():
     q.bias = None
     assert caps(q) == (0, 0)
     # token GEMM seen as nb samples of n tokens: tiles of 256 rows divide the 1024-token samples, not 100-token ones
-    assert caps(desc(nb=64, din=1024, hin=1, win=1, dout=1024, hout=1, wout=1, cin=448, cout=448)) == (256, 1)
+    # (r6: one-tap GEMMs up to 128 K chunks run two 128-row workgroups per CU -- rule (iv) of auto_tile; longer K loops keep the
+    # 256-row tile)
+    assert caps(desc(nb=64, din=1024, hin=1, win=1, dout=1024, hout=1, wout=1, cin=448, cout=448)) == (128, 1)
+    assert caps(desc(nb=64, din=256, hin=1, win=1, dout=256, hout=1, wout=1, cin=2688, cout=672)) == (256, 1)
     assert caps(desc(nb=64, din=100, hin=1, win=1, dout=100, hout=1, wout=1, cin=448, cout=448)) == (0, 1)
     # rows described as M one-row samples (how a plain Linear is described): no sample structure to tile
     assert caps(desc(nb=65536, din=1, hin=1, win=1, dout=1, hout=1, wout=1, cin=448, cout=448))[0] == 0
@@ -321,6 +324,10 @@ def test_shared_host_rules_and_debug_struct():
     p.kd = p.kh = p.kw = 1
     p.pd = p.ph = p.pw = 0
     p.a_format = 0
+    # (r6 rule (iv): a one-tap GEMM of 42 K chunks -- 672 -> 224 at 262144 rows -- runs on the 128-row pair; 2688 channels, 168
+    # chunks, keep the 256-row tile)
+    assert dll.cs_conv_gemm_launch_info(C.byref(p), C.byref(t), C.byref(sl)) == 0 and (t.value, sl.value) == (2, 0)
+    p.cin, p.lda = 2688, 2688
     assert dll.cs_conv_gemm_launch_info(C.byref(p), C.byref(t), C.byref(sl)) == 0 and (t.value, sl.value) == (4, 0)
     # r5 rules: a single partial round of 256-row tiles with a short K loop takes two 128-row workgroups per CU (the level-0
     # skip conv at the reference's mini-batch of 7: 224 tiles); the fused gate always runs on the 128-row tile
