@@ -187,3 +187,31 @@ def test_product_model_with_native_drivers_equals_python_drivers(tmp_path, monke
     assert torch.isfinite(outs[1]).all() and torch.equal(outs[0], outs[1])
     sub, ref = outs[1][:, :, ::2, ::2, ::2], torch.from_numpy(g["gen_sdf_sub"])
     assert sorted(rel_l2(sub[i], ref[i]) for i in range(8))[5] < 1e-4
+
+
+def test_native_driver_equals_python_driver_at_the_benchmark_batch():
+    """r6: the two hosts at BASELINE configs[2]'s own size -- 32 objects under classifier-free guidance = UNet batch 64 at the
+    shipped width, the PRODUCT's channel-split threshold (65536 rows) -- where the plan differs from every small-batch test:
+    Winograd F(4,3) position launches with the main + K-sliced tail plan at the 16x4x4 level, unsliced whole rounds elsewhere,
+    128-row workgroup pairs for the one-tap GEMMs (auto_tile rule iv), CFG-shared skip halves.  cs_unet_step must equal the
+    Python sequencer bit for bit there too (both ask the same C plan functions), and equal-conditioned objects must come out
+    equal whatever their place in the batch."""
+    from commonscenes_amd import lib as L, ops, synth
+    with L.debug_override(cfg_split_min_rows=65536):
+        py, nat = _pair(False, "f16x3")
+        py.split_min_rows = 65536
+        B = 32
+        x = synth.gaussian_like("nat64:x", (1, 3, 16, 16, 16)).cuda().repeat(B, 1, 1, 1, 1)
+        t = torch.full((B,), 501, dtype=torch.long).cuda()
+        c = synth.gaussian_like("nat64:c", (B, 1, 1280)).cuda()
+        uc = synth.gaussian_like("nat64:uc", (B, 1, 1280)).cuda()
+        c[29], uc[29] = c[2], uc[2]                       # a twin at another place in the batch
+        c_in = torch.cat([uc, c])
+        a = py.forward_cfg(x, t, c_in)
+        b = nat.forward_cfg(x, t, c_in)
+        torch.cuda.synchronize()
+        ops.check_overflow()
+    assert a.shape == (2 * B, 3, 16, 16, 16) and torch.isfinite(b).all()
+    assert torch.equal(a, b)
+    assert torch.equal(b[2], b[29]) and torch.equal(b[B + 2], b[B + 29])
+    assert not torch.equal(b[B + 2], b[B + 3])
