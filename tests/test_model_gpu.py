@@ -577,6 +577,32 @@ def test_sample_end_to_end_full_width_vs_reference_golden(tmp_path):
     _sdf_gates(m, g, gen, lat, "e2e_full")
 
 
+def test_sample_end_to_end_full_width_100_steps_vs_reference_golden(tmp_path):
+    """r6: the product call at the SHIPPED width AND the metric's own depth against the reference -- Sg2ScVAEModel.sample(
+    gen_shape=True) with rel2shape's default ddim_steps=100 (sdfusion_txt2shape_model.py:459-516), 413.5 M-parameter UNet,
+    full VQ-VAE decoder, 8 shaped objects (mini-batches 7 + 1), F16X3 GEMMs on the product's own ResBlock route: latents <= 1e-4
+    after the whole schedule, VQ flips accounted voxel by voxel, every object's SDF <= 1e-4 (`e2e100_full`: 45 minutes of
+    reference CPU time in the build container)."""
+    g = _g("e2e100_full")
+    assert int(g["ddim_steps"]) == 100
+    m = _scene(tmp_path, small=False)
+    m.Diff.df.set_math("f16x3")
+    m.Diff.vqvae.set_math("f16x3")
+    m.Diff.df.split_min_rows = ROUTES["product"]
+    O = g["objs"].shape[0]
+    dec_sdfs = torch.zeros(O, 1, 4, 4, 4)
+    dec_sdfs[torch.from_numpy(g["dec_sdfs_nonzero"])] = 1.0
+    m.Diff.mini_B = 7
+    lat = _record_latents(m)
+    boxes, gen = m.sample(None, np.zeros(64), np.eye(64), torch.from_numpy(g["objs"]), torch.from_numpy(g["triples"]),
+                          dec_sdfs, torch.from_numpy(g["text_feats"]), torch.from_numpy(g["rel_feats"]),
+                          gen_shape=True, z=torch.from_numpy(g["z"]), x_T=torch.from_numpy(g["x_T"]), ddim_steps=100)
+    torch.cuda.synchronize()
+    assert gen.shape == (8, 1, 64, 64, 64) and torch.isfinite(gen).all()
+    assert rel_l2(boxes[0], torch.from_numpy(g["boxes"])) < 3e-6
+    _sdf_gates(m, g, gen, lat, "e2e100_full")
+
+
 def test_v2full_manipulation_surface_vs_reference_golden(tmp_path):
     """encoder / decoder_with_changes (gen_shape=True, 2 DDIM steps) / decoder_with_additions of the v2_full model
     (VAEGAN_V2FULL.py:185-218, 291-396) with numpy's RNG seeded like the generator."""

@@ -458,8 +458,8 @@ def g_e2e(tmp: Path, concat: bool = False, full: bool = False, steps: int = 2):
         arrs["boxes"] = boxes
     arrs["ddim_steps"] = np.int64(steps)
     if steps != 2:
-        assert not full and not concat
-        save(f"e2e{steps}_small", **arrs)
+        assert not concat
+        save(f"e2e{steps}_full" if full else f"e2e{steps}_small", **arrs)
     elif full:
         # keep the fixture small: every other voxel of every object, one object in full
         save("e2e_full", **arrs)
@@ -636,7 +636,7 @@ def main():
     install_patches()
     todo = a.only or ["schedule", "unet_small", "unet_full", "ddim_small", "ddim_full", "vq", "gcn", "e2e",
                       "unet_concat_small", "unet_concat_full", "ddim_concat_small", "gcn_concat", "e2e_concat", "box",
-                      "full_manip", "e2e_full", "traj_small", "traj_full", "plms", "traj100_full", "e2e100_small"]
+                      "full_manip", "e2e_full", "traj_small", "traj_full", "plms", "traj100_full", "e2e100_small", "e2e100_full"]
     with tempfile.TemporaryDirectory() as td:
         tmp = Path(td)
         for name in todo:
@@ -679,6 +679,8 @@ def main():
                 g_traj(False, S=100)
             elif name == "e2e100_small":
                 g_e2e(tmp, steps=100)
+            elif name == "e2e100_full":          # r6: the shipped width at the metric's depth (~45 CPU-minutes on 8 cores)
+                g_e2e(tmp, full=True, steps=100)
             elif name == "box":
                 g_box()
             elif name == "full_manip":
