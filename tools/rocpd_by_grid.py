@@ -8,13 +8,18 @@ cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
 name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
 gcol = [c for c in cols if c.lower() in ("grid_x", "grid_size_x", "grid")] or [c for c in cols if "grid" in c.lower()]
 wcol = [c for c in cols if "workgroup" in c.lower() or "block" in c.lower()]
-q = f"select {name_col}, start, end, {gcol[0]}" + (f", {wcol[0]}" if wcol else "") + " from kernels"
+# (r6: all three grid dimensions -- the GroupNorm kernels launch 2-D grids)
+full3 = all(c in cols for c in ("grid_x", "grid_y", "grid_z", "workgroup_x", "workgroup_y", "workgroup_z"))
+if full3:
+    q = f"select {name_col}, start, end, grid_x * grid_y * grid_z, workgroup_x * workgroup_y * workgroup_z from kernels"
+else:
+    q = f"select {name_col}, start, end, {gcol[0]}" + (f", {wcol[0]}" if wcol else "") + " from kernels"
 agg = {}
 for row in cur.execute(q):
     name = re.sub(r"\(.*$", "", row[0].replace("(anonymous namespace)::", "").replace("void ", ""))
     if sub not in name:
         continue
-    g = row[3] // (row[4] if wcol and row[4] else 1)
+    g = row[3] // (row[4] if (full3 or wcol) and row[4] else 1)
     a = agg.setdefault((name, g), [0, 0.0])
     a[0] += 1; a[1] += (row[2] - row[1]) / 1e3
 print("columns:", cols)
